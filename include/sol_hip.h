@@ -1,0 +1,210 @@
+/*
+ * sol_hip.h  --  C ABI of libsol_hip.so, the MI355X (gfx950) engine for the
+ * solver-in-the-loop hot path.
+ *
+ * The reference exposes no FFI of its own for this path: the seam is
+ * the Python call surface of karman_train.py / burgers_train.py, and the nearest plug
+ * point is PhiFlow's PressureSolver / CUDASolver custom op imported at
+ * /root/reference/karman-2d/karman_train.py:51.  Each entry point below cites the
+ * reference lines whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; sol_last_error() gives the text
+ *     (thread local).  Nothing is allocated inside: all buffers, including workspaces,
+ *     are caller-owned DEVICE pointers (fp32 unless noted).
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on that stream and
+ *     thread-safe with respect to distinct streams (no global mutable state).
+ *   - layouts: density d [B,Y,X]; v_y [B,Y+1,X]; v_x [B,Y,X+1]  (component 0 = y, the
+ *     reference's `velocity.data[0]`, karman_train.py:367); images NHWC; conv kernels
+ *     HWIO (Keras layout); `params`/`grads` = Keras get_weights() order, flattened.
+ */
+#ifndef SOL_HIP_H
+#define SOL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOL_OK 0
+#define SOL_ERR_ARG (-1)      /* invalid argument / unsupported shape */
+#define SOL_ERR_HIP (-2)      /* HIP runtime error (text in sol_last_error) */
+#define SOL_ERR_WORKSPACE (-3)
+
+#define SOL_MARS_MOON_PARAMS 260354   /* model_mars_moon, karman_train.py:101-138 */
+
+const char* sol_last_error(void);
+int sol_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Solver step:  KarmanFlow.step  (karman-2d/karman_train.py:173-185) =
+ *   explicit diffusion + velocity BC (lines 175-183) followed by PhiFlow's
+ *   IncompressibleFlow.step: semi-Lagrangian advection of density and velocity, inflow,
+ *   divergence_free() with the obstacle (hard-BC face masks, divergence, CG pressure
+ *   solve, gradient subtraction).  One workgroup per simulation; everything between the
+ *   input load and the output store stays in LDS / registers.
+ * ---------------------------------------------------------------------------------- */
+typedef struct sol_karman_cfg {
+    int32_t B, Y, X;        /* batch, cells in y, cells in x (Y%8==0, X in {8,16,32,64}) */
+    float dx;               /* cell size = len / X  (karman_train.py:363)              */
+    float dt;               /* time step (step(..., dt=1.0))                            */
+    float res;              /* `res` argument of step(): alpha = dt*res*res/Re (l.175)  */
+    float cg_rtol;          /* CG stops when |r|_2 <= max(cg_rtol*|b|_2, cg_atol)       */
+    float cg_atol;
+    int32_t cg_max_iter;    /* PhiFlow SparseCG: 2000                                   */
+    int32_t grad_pad;       /* 0: replicate (PhiFlow 1.x), 1: dirichlet0                */
+    int32_t inflow_before;  /* 0: density += inflow*dt after advection (phi 1.x),
+                               1: before advection (karman-2d-phi2/karman_train.py:182) */
+} sol_karman_cfg;
+
+/* active  [Y,X]  1 - obstacle mask (cell centres inside Obstacle geometries -> 0)
+ * inflow  [Y,X]  inflow rate mask (Inflow(box[5:10,25:75]) -> 1 inside)
+ * velBCy, velBCyMask  [Y+1,X] (bc_batch_stride 0) or [B,Y+1,X] (stride (Y+1)*X)
+ * saved_vy/saved_vx: post-diffusion+BC velocity kept for the backward pass (NULL: inference)
+ * feat_out [B,Y,X,4] (NULL to skip): fused to_feature (karman_train.py:77-86) scaled by
+ *   feat_scale[3] = 1/std (l.416-419); channel 3 is zero padding.
+ * iters [B]: CG iterations used per simulation (may be NULL).                           */
+int sol_karman_step_fwd(const sol_karman_cfg* cfg, void* stream,
+                        const float* d_in, const float* vy_in, const float* vx_in,
+                        const float* re, const float* active, const float* inflow,
+                        const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
+                        float* d_out, float* vy_out, float* vx_out,
+                        float* saved_vy, float* saved_vx,
+                        float* feat_out, const float* feat_scale,
+                        int32_t* iters);
+
+/* Adjoint of the step w.r.t. its input velocity (density is a passive tracer and has no
+ * adjoint: buoyancy_factor=0, karman_train.py:363).  The pressure adjoint is a second CG
+ * solve with the same symmetric matrix (PhiFlow's custom gradient).
+ * dfeat [B,Y,X,2] (may be NULL): gradient w.r.t. the fused feature channels 0,1; it is
+ *   added as g_v_out += feat_scale[c]*dfeat[...,c] before the adjoint runs.              */
+int sol_karman_step_bwd(const sol_karman_cfg* cfg, void* stream,
+                        const float* saved_vy, const float* saved_vx,
+                        const float* re, const float* active,
+                        const float* velBCyMask, int64_t bc_batch_stride,
+                        const float* g_vy_out, const float* g_vx_out,
+                        const float* dfeat, const float* feat_scale,
+                        float* g_vy_in, float* g_vx_in,
+                        int32_t* iters);
+
+/* ------------------------------------------------------------------------------------
+ * Burgers step: BurgersTest.step / step_with_f (burgers/burgers_train.py:182-187) =
+ *   semi-Lagrangian self-advection on the periodic staggered grid followed by PhiFlow's
+ *   periodic (spectral) diffusion, expressed as two real circulant matrices cy [Y+1,Y+1]
+ *   (for v_y rows) ... see sol_burgers_cfg; then v += dt*f.
+ * ---------------------------------------------------------------------------------- */
+typedef struct sol_burgers_cfg {
+    int32_t B, Y, X;        /* cells; staggered arrays v_y [B,Y+1,X], v_x [B,Y,X+1]  (<= 64) */
+    float dx, dt;
+} sol_burgers_cfg;
+
+/* circ_* are the symmetric circulant matrices of exp(-(2 pi k)^2 * nu*dt), row major:
+ * circ_yp1 [Y+1,Y+1], circ_x [X,X] act on v_y; circ_y [Y,Y], circ_xp1 [X+1,X+1] on v_x.
+ * f_y/f_x may be NULL (BurgersTest.step).  saved_* keep the input velocity for backward. */
+int sol_burgers_step_fwd(const sol_burgers_cfg* cfg, void* stream,
+                         const float* vy_in, const float* vx_in,
+                         const float* f_y, const float* f_x,
+                         const float* circ_yp1, const float* circ_x,
+                         const float* circ_y, const float* circ_xp1,
+                         float* vy_out, float* vx_out);
+int sol_burgers_step_bwd(const sol_burgers_cfg* cfg, void* stream,
+                         const float* vy_in, const float* vx_in,
+                         const float* circ_yp1, const float* circ_x,
+                         const float* circ_y, const float* circ_xp1,
+                         const float* g_vy_out, const float* g_vx_out,
+                         float* g_vy_in, float* g_vx_in);
+
+/* ------------------------------------------------------------------------------------
+ * 5x5 SAME convolution, NHWC fp32, on fp32 MFMA (v_mfma_f32_16x16x4_f32).
+ * Replaces keras.layers.Conv2D(filters, 5, padding='same') + LeakyReLU / add
+ * (karman_train.py:101-138) and its TF gradients.
+ * ---------------------------------------------------------------------------------- */
+#define SOL_CONV_FWD 0        /* pack for y = conv(x, w)                       */
+#define SOL_CONV_BWD_DATA 1   /* pack for dx = conv(dy, flip(w)^T)             */
+/* number of floats of a packed weight buffer for (cin, cout, mode) */
+size_t sol_conv5x5_packed_floats(int32_t cin, int32_t cout, int32_t mode);
+/* w_hwio [5,5,cin,cout] -> packed (zero padded to the MFMA tile shape) */
+int sol_conv5x5_pack(void* stream, const float* w_hwio, int32_t cin, int32_t cout,
+                     int32_t mode, float* packed);
+
+#define SOL_EPI_NONE 0        /* y = conv + bias (+ residual)                       */
+#define SOL_EPI_LRELU 1       /* y = lrelu(conv + bias (+ residual))                */
+#define SOL_EPI_DLRELU 2      /* y = (conv (+ residual)) * lrelu'(act_ref)  (backward) */
+/* x [B,H,W,cin]; packed from sol_conv5x5_pack with the same (cin,cout) (for BWD_DATA pass
+ * cin = channels of dy, cout = channels of dx, and the weights packed with mode BWD_DATA
+ * from the forward layer's (cout_fwd=cin, cin_fwd=cout)); bias [cout] or NULL;
+ * residual/act_ref [B,H,W,cout] or NULL; y [B,H,W,cout].  H*W % 64 == 0, W | 64 or 64 | W. */
+int sol_conv5x5(void* stream, const float* x, const float* packed, const float* bias,
+                const float* residual, const float* act_ref, float* y,
+                int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,
+                int32_t epilogue, float slope);
+
+/* dW[5,5,cin,cout] += sum_px x[px+tap] * dz[px];  db[cout] += sum_px dz[px].
+ * `partial` is a caller workspace of sol_conv5x5_bwd_weight_ws_floats() floats that the
+ * caller zeroes once and may reuse to ACCUMULATE over many calls (the unrolled steps share
+ * the weights); sol_conv5x5_bwd_weight_reduce() folds it into dw/db.                     */
+size_t sol_conv5x5_bwd_weight_ws_floats(int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout);
+int sol_conv5x5_bwd_weight(void* stream, const float* x, const float* dz, float* partial,
+                           int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout);
+int sol_conv5x5_bwd_weight_reduce(void* stream, const float* partial, float* dw_hwio, float* db,
+                                  int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,
+                                  int32_t accumulate);
+
+/* ------------------------------------------------------------------------------------
+ * Whole training step: the unrolled msteps graph of karman_train.py:397-457
+ *   for i in range(msteps): state = simulator_lo.step(state);  state.velocity += CNN(state)
+ *   loss = sum_i l2_loss((gt_i - prd_i)/std_v)/msteps;  Adam.
+ * ---------------------------------------------------------------------------------- */
+typedef struct sol_train_cfg {
+    sol_karman_cfg karman;
+    int32_t msteps;
+    float std_v0, std_v1;   /* dataStats['std'][1]  (karman_train.py:234-255,419,432) */
+    float std_re;           /* dataStats['ext.std'][0]                                 */
+    float lrelu_slope;      /* Keras LeakyReLU default 0.3                              */
+} sol_train_cfg;
+
+size_t sol_train_workspace_bytes(const sol_train_cfg* cfg);
+
+/* params/grads: SOL_MARS_MOON_PARAMS floats.  gt_vy [msteps,B,Y+1,X], gt_vx [msteps,B,Y,X+1].
+ * Outputs: grads (overwritten), loss_steps[msteps] (device, the per-step l2_loss values,
+ * NOT yet divided by msteps), optional prd_* = final corrected state (may be NULL),
+ * iters_fwd/iters_bwd [msteps*B] CG iteration counts (device, may be NULL).             */
+int sol_train_fwd_bwd(const sol_train_cfg* cfg, void* stream,
+                      const float* params,
+                      const float* d0, const float* vy0, const float* vx0, const float* re,
+                      const float* active, const float* inflow,
+                      const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
+                      const float* gt_vy, const float* gt_vx,
+                      void* workspace, size_t workspace_bytes,
+                      float* grads, float* loss_steps,
+                      float* d_final, float* vy_final, float* vx_final,
+                      int32_t* iters_fwd, int32_t* iters_bwd);
+
+/* Forward only (karman_apply.py:138-158 roll-out without the frame dump): runs `nsteps`
+ * solver+CNN steps in place of d/vy/vx.  workspace: sol_rollout_workspace_bytes().       */
+size_t sol_rollout_workspace_bytes(const sol_train_cfg* cfg);
+int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* params,
+                float* d, float* vy, float* vx, const float* re,
+                const float* active, const float* inflow,
+                const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
+                int32_t nsteps, void* workspace, size_t workspace_bytes, int32_t* iters);
+
+/* tf.compat.v1.train.AdamOptimizer update (karman_train.py:449-457), epsilon-hat form:
+ *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  p -= lr_t*m/(sqrt(v)+eps).
+ * clip_norm > 0: per-tensor tf.clip_by_norm(g, clip_norm) first (l.451-454), tensors given
+ * by tensor_offsets[n_tensors+1] (HOST array, element offsets).  t is the 1-based step.  */
+int sol_adam_tf_step(void* stream, float* params, const float* grads, float* m, float* v,
+                     int64_t n, int32_t t, float lr, float beta1, float beta2, float eps,
+                     float clip_norm, const int64_t* tensor_offsets, int32_t n_tensors,
+                     float* scratch /* >= n_tensors floats, device */);
+
+/* offsets (in floats) of layer l's kernel / bias inside the flat mars_moon parameter
+ * vector; l in [0,12).  cin/cout may be NULL.                                            */
+int sol_mars_moon_layer(int32_t l, int64_t* kernel_off, int64_t* bias_off, int32_t* cin, int32_t* cout);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOL_HIP_H */

@@ -1,0 +1,129 @@
+"""ctypes binding of libsol_hip.so (C ABI declared in include/sol_hip.h).
+
+The product path has NO CPU fallback: if the library is missing, or a call is made without
+a ROCm device, this module raises.  PyTorch is used only as the owner of device memory and
+streams (tensor.data_ptr(), torch.cuda.current_stream()).
+"""
+import ctypes as C
+import os
+import re
+
+import torch
+
+from . import _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(_HERE, "..", "include", "sol_hip.h")
+
+
+class SolError(RuntimeError):
+    pass
+
+
+class KarmanCfg(C.Structure):
+    """sol_karman_cfg"""
+    _fields_ = [("B", C.c_int32), ("Y", C.c_int32), ("X", C.c_int32),
+                ("dx", C.c_float), ("dt", C.c_float), ("res", C.c_float),
+                ("cg_rtol", C.c_float), ("cg_atol", C.c_float), ("cg_max_iter", C.c_int32),
+                ("grad_pad", C.c_int32), ("inflow_before", C.c_int32)]
+
+
+class BurgersCfg(C.Structure):
+    """sol_burgers_cfg"""
+    _fields_ = [("B", C.c_int32), ("Y", C.c_int32), ("X", C.c_int32), ("dx", C.c_float), ("dt", C.c_float)]
+
+
+class TrainCfg(C.Structure):
+    """sol_train_cfg"""
+    _fields_ = [("karman", KarmanCfg), ("msteps", C.c_int32),
+                ("std_v0", C.c_float), ("std_v1", C.c_float), ("std_re", C.c_float),
+                ("lrelu_slope", C.c_float)]
+
+
+_P = C.c_void_p
+_SIGS = {
+    "sol_last_error": (C.c_char_p, []),
+    "sol_version": (C.c_int, []),
+    "sol_karman_step_fwd": (C.c_int, [C.POINTER(KarmanCfg), _P] + [_P] * 8 + [C.c_int64] + [_P] * 6 + [C.POINTER(C.c_float), _P]),
+    "sol_karman_step_bwd": (C.c_int, [C.POINTER(KarmanCfg), _P] + [_P] * 5 + [C.c_int64] + [_P] * 3 + [C.POINTER(C.c_float)] + [_P] * 3),
+    "sol_burgers_step_fwd": (C.c_int, [C.POINTER(BurgersCfg), _P] + [_P] * 10),
+    "sol_burgers_step_bwd": (C.c_int, [C.POINTER(BurgersCfg), _P] + [_P] * 10),
+    "sol_conv5x5_packed_floats": (C.c_size_t, [C.c_int32] * 3),
+    "sol_conv5x5_pack": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "sol_conv5x5": (C.c_int, [_P] * 7 + [C.c_int32] * 6 + [C.c_float]),
+    "sol_conv5x5_bwd_weight_ws_floats": (C.c_size_t, [C.c_int32] * 5),
+    "sol_conv5x5_bwd_weight": (C.c_int, [_P] * 4 + [C.c_int32] * 5),
+    "sol_conv5x5_bwd_weight_reduce": (C.c_int, [_P] * 4 + [C.c_int32] * 6),
+    "sol_train_workspace_bytes": (C.c_size_t, [C.POINTER(TrainCfg)]),
+    "sol_train_fwd_bwd": (C.c_int, [C.POINTER(TrainCfg), _P] + [_P] * 9 + [C.c_int64] + [_P] * 3 + [C.c_size_t] + [_P] * 7),
+    "sol_rollout_workspace_bytes": (C.c_size_t, [C.POINTER(TrainCfg)]),
+    "sol_rollout": (C.c_int, [C.POINTER(TrainCfg), _P] + [_P] * 9 + [C.c_int64, C.c_int32, _P, C.c_size_t, _P]),
+    "sol_adam_tf_step": (C.c_int, [_P] * 5 + [C.c_int64, C.c_int32] + [C.c_float] * 5 + [C.POINTER(C.c_int64), C.c_int32, _P]),
+    "sol_mars_moon_layer": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+}
+
+_lib = None
+
+
+def declared_symbols():
+    """Every function name declared in include/sol_hip.h (used by the CPU test-suite)."""
+    with open(HEADER) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sol_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load (building on demand when hipcc is available) and type the library."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        try:
+            _build.build()
+        except Exception as e:  # no silent fallback: the HIP extension IS the product
+            raise SolError("libsol_hip.so is missing and could not be built: %s" % e)
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)     # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise SolError("libsol_hip error %d: %s" % (code, load().sol_last_error().decode()))
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise SolError("no ROCm device visible: the solver-in-the-loop engine has no CPU fallback")
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int32 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SolError("expected a CUDA tensor")
+    if not t.is_contiguous():
+        raise SolError("expected a contiguous tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def f32(t, device=None):
+    """contiguous fp32 CUDA tensor view/copy of t"""
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(t)
+    return t.to(device=device or "cuda", dtype=torch.float32).contiguous()

@@ -1,0 +1,261 @@
+// Burgers step on the periodic staggered grid and its adjoint  --  gfx950 / CDNA4.
+//
+// Replaces BurgersTest.step / step_with_f (/root/reference/burgers/burgers_train.py:182-187)
+// -> PhiFlow Burgers.step: v = semi_lagrangian(v, v, dt); v = diffuse(v, dt*nu) (periodic
+// domain -> spectral branch); then v += dt*f.  One workgroup per simulation, all in LDS.
+//
+// The spectral diffusion  ifft(fft(f) * exp(-(2 pi)^2 |k|^2 a))  is separable and real, so it
+// is applied as two small dense products with symmetric circulant matrices prepared by the
+// host (out = Cy * f * Cx^T): no FFT library, and the adjoint is the same operator.
+// PhiFlow-1.x quirk kept on purpose: the periodic staggered
+// components keep the duplicated +1 face and every wrap-around is modulo the ARRAY length.
+#include "common.hpp"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAXTB = 17;   // ceil(65*64 / 256)
+
+struct BArgs {
+    int B, Y, X;
+    float dtdx, dt;
+    const float *vy_in, *vx_in, *fy, *fx, *cyp1, *cx, *cy, *cxp1, *g_vy_out, *g_vx_out;
+    float *vy_out, *vx_out, *g_vy_in, *g_vx_in;
+};
+
+__host__ __device__ inline int al4b(int n) { return (n + 3) & ~3; }
+__host__ inline size_t blds_bytes(int Y, int X) {
+    const int nVy = (Y + 1) * X, nVx = Y * (X + 1);
+    const int nmax = nVy > nVx ? nVy : nVx;
+    return (size_t)(2 * (al4b(nVy) + al4b(nVx)) + al4b(nmax) + al4b((Y + 1) * (Y + 1)) + al4b(X * X) +
+                    al4b(Y * Y) + al4b((X + 1) * (X + 1))) * sizeof(float);
+}
+
+struct BLds {
+    float *Avy, *Avx, *Bvy, *Bvx, *T, *Cyp1, *Cx, *Cy, *Cxp1;
+};
+__device__ inline BLds bcarve(float* s, int Y, int X) {
+    const int nVy = (Y + 1) * X, nVx = Y * (X + 1);
+    const int nmax = nVy > nVx ? nVy : nVx;
+    BLds l;
+    l.Avy = s; l.Avx = l.Avy + al4b(nVy);
+    l.Bvy = l.Avx + al4b(nVx); l.Bvx = l.Bvy + al4b(nVy);
+    l.T = l.Bvx + al4b(nVx);
+    l.Cyp1 = l.T + al4b(nmax);
+    l.Cx = l.Cyp1 + al4b((Y + 1) * (Y + 1));
+    l.Cy = l.Cx + al4b(X * X);
+    l.Cxp1 = l.Cy + al4b(Y * Y);
+    return l;
+}
+
+__device__ __forceinline__ int wrap(int v, int n) {
+    v %= n;
+    return v < 0 ? v + n : v;
+}
+
+struct BilP {
+    int j0, j1, i0, i1;
+    float wy, wx;
+};
+__device__ __forceinline__ BilP bil_wrap(int H, int W, int jb, float oy, int ib, float ox) {
+    BilP s;
+    const float fy = floorf(oy), fx = floorf(ox);
+    s.wy = oy - fy;
+    s.wx = ox - fx;
+    const int j0 = jb + (int)fy, i0 = ib + (int)fx;
+    s.j0 = wrap(j0, H); s.j1 = wrap(j0 + 1, H);
+    s.i0 = wrap(i0, W); s.i1 = wrap(i0 + 1, W);
+    return s;
+}
+
+// out[H,W] = Cl[H,H] * (in[H,W] * Cr[W,W]^T), T is scratch [H,W]; out may alias in.
+__device__ void diffuse2(const float* in, float* out, float* T, const float* Cl, const float* Cr, int H, int W) {
+    for (int e = threadIdx.x; e < H * W; e += NT) {
+        const int j = e / W, i = e - j * W;
+        float s = 0.f;
+        for (int k = 0; k < W; ++k) s += in[j * W + k] * Cr[i * W + k];
+        T[e] = s;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < H * W; e += NT) {
+        const int j = e / W, i = e - j * W;
+        float s = 0.f;
+        for (int k = 0; k < H; ++k) s += Cl[j * H + k] * T[k * W + i];
+        out[e] = s;
+    }
+    __syncthreads();
+}
+
+__device__ void load_common(const BArgs& a, const BLds& L) {
+    const int Y = a.Y, X = a.X;
+    for (int e = threadIdx.x; e < (Y + 1) * (Y + 1); e += NT) L.Cyp1[e] = a.cyp1[e];
+    for (int e = threadIdx.x; e < X * X; e += NT) L.Cx[e] = a.cx[e];
+    for (int e = threadIdx.x; e < Y * Y; e += NT) L.Cy[e] = a.cy[e];
+    for (int e = threadIdx.x; e < (X + 1) * (X + 1); e += NT) L.Cxp1[e] = a.cxp1[e];
+}
+
+__global__ void __launch_bounds__(NT) k_burgers_fwd(BArgs a) {
+    extern __shared__ __align__(16) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int Y = a.Y, X = a.X, nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
+    const BLds L = bcarve(smem, Y, X);
+    for (int k = tid; k < nVy; k += NT) L.Avy[k] = a.vy_in[(size_t)b * nVy + k];
+    for (int k = tid; k < nVx; k += NT) L.Avx[k] = a.vx_in[(size_t)b * nVx + k];
+    load_common(a, L);
+    __syncthreads();
+    // semi-Lagrangian self-advection (A -> B), wrap modulo the array length
+    for (int k = tid; k < nVy; k += NT) {
+        const int j = k / X, i = k - j * X;
+        const float uy = L.Avy[k];
+        const int ja = wrap(j - 1, Y), jb = wrap(j, Y);
+        const float ux = 0.25f * (L.Avx[ja * XP + i] + L.Avx[ja * XP + i + 1] + L.Avx[jb * XP + i] + L.Avx[jb * XP + i + 1]);
+        const BilP s = bil_wrap(Y + 1, X, j, -uy * a.dtdx, i, -ux * a.dtdx);
+        L.Bvy[k] = (1.f - s.wy) * ((1.f - s.wx) * L.Avy[s.j0 * X + s.i0] + s.wx * L.Avy[s.j0 * X + s.i1]) +
+                   s.wy * ((1.f - s.wx) * L.Avy[s.j1 * X + s.i0] + s.wx * L.Avy[s.j1 * X + s.i1]);
+    }
+    for (int k = tid; k < nVx; k += NT) {
+        const int j = k / XP, i = k - j * XP;
+        const float ux = L.Avx[k];
+        const int ia = wrap(i - 1, X), ib = wrap(i, X);
+        const float uy = 0.25f * (L.Avy[j * X + ia] + L.Avy[j * X + ib] + L.Avy[(j + 1) * X + ia] + L.Avy[(j + 1) * X + ib]);
+        const BilP s = bil_wrap(Y, XP, j, -uy * a.dtdx, i, -ux * a.dtdx);
+        L.Bvx[k] = (1.f - s.wy) * ((1.f - s.wx) * L.Avx[s.j0 * XP + s.i0] + s.wx * L.Avx[s.j0 * XP + s.i1]) +
+                   s.wy * ((1.f - s.wx) * L.Avx[s.j1 * XP + s.i0] + s.wx * L.Avx[s.j1 * XP + s.i1]);
+    }
+    __syncthreads();
+    diffuse2(L.Bvy, L.Bvy, L.T, L.Cyp1, L.Cx, Y + 1, X);
+    diffuse2(L.Bvx, L.Bvx, L.T, L.Cy, L.Cxp1, Y, XP);
+    for (int k = tid; k < nVy; k += NT) {
+        float v = L.Bvy[k];
+        if (a.fy) v += a.dt * a.fy[(size_t)b * nVy + k];
+        a.vy_out[(size_t)b * nVy + k] = v;
+    }
+    for (int k = tid; k < nVx; k += NT) {
+        float v = L.Bvx[k];
+        if (a.fx) v += a.dt * a.fx[(size_t)b * nVx + k];
+        a.vx_out[(size_t)b * nVx + k] = v;
+    }
+}
+
+__global__ void __launch_bounds__(NT) k_burgers_bwd(BArgs a) {
+    extern __shared__ __align__(16) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int Y = a.Y, X = a.X, nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
+    const BLds L = bcarve(smem, Y, X);
+    for (int k = tid; k < nVy; k += NT) { L.Avy[k] = a.vy_in[(size_t)b * nVy + k]; L.Bvy[k] = a.g_vy_out[(size_t)b * nVy + k]; }
+    for (int k = tid; k < nVx; k += NT) { L.Avx[k] = a.vx_in[(size_t)b * nVx + k]; L.Bvx[k] = a.g_vx_out[(size_t)b * nVx + k]; }
+    load_common(a, L);
+    __syncthreads();
+    // diffusion adjoint = same symmetric operator
+    diffuse2(L.Bvy, L.Bvy, L.T, L.Cyp1, L.Cx, Y + 1, X);
+    diffuse2(L.Bvx, L.Bvx, L.T, L.Cy, L.Cxp1, Y, XP);
+    float gy[MAXTB], gx[MAXTB];
+#pragma unroll
+    for (int n = 0; n < MAXTB; ++n) {
+        const int k = tid + n * NT;
+        gy[n] = k < nVy ? L.Bvy[k] : 0.f;
+        gx[n] = k < nVx ? L.Bvx[k] : 0.f;
+    }
+    __syncthreads();
+    for (int k = tid; k < nVy; k += NT) L.Bvy[k] = 0.f;
+    for (int k = tid; k < nVx; k += NT) L.Bvx[k] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < MAXTB; ++n) {
+        const int k = tid + n * NT;
+        if (k < nVy && gy[n] != 0.f) {
+            const int j = k / X, i = k - j * X;
+            const float g = gy[n];
+            const float uy = L.Avy[k];
+            const int ja = wrap(j - 1, Y), jb = wrap(j, Y);
+            const float ux = 0.25f * (L.Avx[ja * XP + i] + L.Avx[ja * XP + i + 1] + L.Avx[jb * XP + i] + L.Avx[jb * XP + i + 1]);
+            const BilP s = bil_wrap(Y + 1, X, j, -uy * a.dtdx, i, -ux * a.dtdx);
+            const float f00 = L.Avy[s.j0 * X + s.i0], f01 = L.Avy[s.j0 * X + s.i1];
+            const float f10 = L.Avy[s.j1 * X + s.i0], f11 = L.Avy[s.j1 * X + s.i1];
+            atomicAdd(&L.Bvy[s.j0 * X + s.i0], (1.f - s.wy) * (1.f - s.wx) * g);
+            atomicAdd(&L.Bvy[s.j0 * X + s.i1], (1.f - s.wy) * s.wx * g);
+            atomicAdd(&L.Bvy[s.j1 * X + s.i0], s.wy * (1.f - s.wx) * g);
+            atomicAdd(&L.Bvy[s.j1 * X + s.i1], s.wy * s.wx * g);
+            const float ddy = (1.f - s.wx) * (f10 - f00) + s.wx * (f11 - f01);
+            const float ddx = (1.f - s.wy) * (f01 - f00) + s.wy * (f11 - f10);
+            const float guy = -a.dtdx * g * ddy, gux = -0.25f * a.dtdx * g * ddx;
+            atomicAdd(&L.Bvy[k], guy);
+            atomicAdd(&L.Bvx[ja * XP + i], gux);
+            atomicAdd(&L.Bvx[ja * XP + i + 1], gux);
+            atomicAdd(&L.Bvx[jb * XP + i], gux);
+            atomicAdd(&L.Bvx[jb * XP + i + 1], gux);
+        }
+        if (k < nVx && gx[n] != 0.f) {
+            const int j = k / XP, i = k - j * XP;
+            const float g = gx[n];
+            const float ux = L.Avx[k];
+            const int ia = wrap(i - 1, X), ib = wrap(i, X);
+            const float uy = 0.25f * (L.Avy[j * X + ia] + L.Avy[j * X + ib] + L.Avy[(j + 1) * X + ia] + L.Avy[(j + 1) * X + ib]);
+            const BilP s = bil_wrap(Y, XP, j, -uy * a.dtdx, i, -ux * a.dtdx);
+            const float f00 = L.Avx[s.j0 * XP + s.i0], f01 = L.Avx[s.j0 * XP + s.i1];
+            const float f10 = L.Avx[s.j1 * XP + s.i0], f11 = L.Avx[s.j1 * XP + s.i1];
+            atomicAdd(&L.Bvx[s.j0 * XP + s.i0], (1.f - s.wy) * (1.f - s.wx) * g);
+            atomicAdd(&L.Bvx[s.j0 * XP + s.i1], (1.f - s.wy) * s.wx * g);
+            atomicAdd(&L.Bvx[s.j1 * XP + s.i0], s.wy * (1.f - s.wx) * g);
+            atomicAdd(&L.Bvx[s.j1 * XP + s.i1], s.wy * s.wx * g);
+            const float ddy = (1.f - s.wx) * (f10 - f00) + s.wx * (f11 - f01);
+            const float ddx = (1.f - s.wy) * (f01 - f00) + s.wy * (f11 - f10);
+            const float gux = -a.dtdx * g * ddx, guy = -0.25f * a.dtdx * g * ddy;
+            atomicAdd(&L.Bvx[k], gux);
+            atomicAdd(&L.Bvy[j * X + ia], guy);
+            atomicAdd(&L.Bvy[j * X + ib], guy);
+            atomicAdd(&L.Bvy[(j + 1) * X + ia], guy);
+            atomicAdd(&L.Bvy[(j + 1) * X + ib], guy);
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < nVy; k += NT) a.g_vy_in[(size_t)b * nVy + k] = L.Bvy[k];
+    for (int k = tid; k < nVx; k += NT) a.g_vx_in[(size_t)b * nVx + k] = L.Bvx[k];
+}
+
+int bcheck(const sol_burgers_cfg* c) {
+    SOL_REQUIRE(c != nullptr, "cfg is NULL");
+    SOL_REQUIRE(c->B >= 1 && c->Y >= 2 && c->X >= 2 && c->Y <= 64 && c->X <= 64, "burgers: need 2 <= Y,X <= 64 (got %d,%d)", c->Y, c->X);
+    SOL_REQUIRE(c->dx > 0.f, "dx must be > 0");
+    SOL_REQUIRE(blds_bytes(c->Y, c->X) <= 160 * 1024, "burgers: grid does not fit the LDS");
+    return SOL_OK;
+}
+
+template <typename K>
+int blaunch(K kernel, const sol_burgers_cfg* c, void* stream, const BArgs& a) {
+    const size_t lds = blds_bytes(c->Y, c->X);
+    SOL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3(c->B), dim3(NT), lds, (hipStream_t)stream, a);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
+}  // namespace
+
+extern "C" int sol_burgers_step_fwd(const sol_burgers_cfg* cfg, void* stream, const float* vy_in, const float* vx_in,
+                                    const float* f_y, const float* f_x, const float* circ_yp1, const float* circ_x,
+                                    const float* circ_y, const float* circ_xp1, float* vy_out, float* vx_out) {
+    if (int e = bcheck(cfg)) return e;
+    SOL_REQUIRE(vy_in && vx_in && circ_yp1 && circ_x && circ_y && circ_xp1 && vy_out && vx_out, "sol_burgers_step_fwd: NULL pointer");
+    SOL_REQUIRE((f_y == nullptr) == (f_x == nullptr), "f_y and f_x must both be given or both be NULL");
+    BArgs a{};
+    a.B = cfg->B; a.Y = cfg->Y; a.X = cfg->X; a.dtdx = cfg->dt / cfg->dx; a.dt = cfg->dt;
+    a.vy_in = vy_in; a.vx_in = vx_in; a.fy = f_y; a.fx = f_x;
+    a.cyp1 = circ_yp1; a.cx = circ_x; a.cy = circ_y; a.cxp1 = circ_xp1;
+    a.vy_out = vy_out; a.vx_out = vx_out;
+    return blaunch(k_burgers_fwd, cfg, stream, a);
+}
+
+extern "C" int sol_burgers_step_bwd(const sol_burgers_cfg* cfg, void* stream, const float* vy_in, const float* vx_in,
+                                    const float* circ_yp1, const float* circ_x, const float* circ_y, const float* circ_xp1,
+                                    const float* g_vy_out, const float* g_vx_out, float* g_vy_in, float* g_vx_in) {
+    if (int e = bcheck(cfg)) return e;
+    SOL_REQUIRE(vy_in && vx_in && circ_yp1 && circ_x && circ_y && circ_xp1 && g_vy_out && g_vx_out && g_vy_in && g_vx_in,
+                "sol_burgers_step_bwd: NULL pointer");
+    BArgs a{};
+    a.B = cfg->B; a.Y = cfg->Y; a.X = cfg->X; a.dtdx = cfg->dt / cfg->dx; a.dt = cfg->dt;
+    a.vy_in = vy_in; a.vx_in = vx_in;
+    a.cyp1 = circ_yp1; a.cx = circ_x; a.cy = circ_y; a.cxp1 = circ_xp1;
+    a.g_vy_out = g_vy_out; a.g_vx_out = g_vx_out; a.g_vy_in = g_vy_in; a.g_vx_in = g_vx_in;
+    return blaunch(k_burgers_bwd, cfg, stream, a);
+}

@@ -1,0 +1,47 @@
+// Shared helpers for the gfx950 kernels of libsol_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/sol_hip.h"
+
+int sol_set_error(int code, const char* fmt, ...);
+
+#define SOL_HIP_CHECK(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return sol_set_error(SOL_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                \
+                                 hipGetErrorString(e_), __FILE__, __LINE__);                 \
+    } while (0)
+#define SOL_LAUNCH_CHECK() SOL_HIP_CHECK(hipGetLastError())
+#define SOL_REQUIRE(cond, ...)                                                               \
+    do {                                                                                     \
+        if (!(cond)) return sol_set_error(SOL_ERR_ARG, __VA_ARGS__);                         \
+    } while (0)
+
+// wave64 all-reduce (every lane gets the sum)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Workgroup all-reduce through LDS.  `red` holds 2 x 32 floats; `slot` alternates 0/1
+// between consecutive calls so that no extra barrier is needed against the previous use.
+// Every thread returns the bit-identical sum (same summation order), so branches on it
+// are workgroup-uniform.
+__device__ __forceinline__ float block_sum(float v, float* red, int slot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    float* r = red + slot * 32;
+    if (lane == 0) r[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int w = 0; w < nw; ++w) s += r[w];
+    return s;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -1,0 +1,394 @@
+// 5x5 SAME convolution (NHWC, fp32) on the gfx950 fp32 matrix cores, forward / backward-data
+// (same kernel, differently packed weights) and backward-weight.
+//
+// Replaces keras.layers.Conv2D(filters, 5, padding='same') (+bias, LeakyReLU, residual add)
+// of model_mars_moon (/root/reference/karman-2d/karman_train.py:101-138) and TF's conv
+// gradients.  fp32 in / fp32 accumulate (v_mfma_f32_16x16x4_f32): bf16 would break the 1e-5
+// parity bar of the solver-in-the-loop loss.
+//
+// Implicit GEMM, per workgroup: M = 64 output pixels (4 waves x 16), N = 16*NT output
+// channels, K = 25 taps x CIN.  The input halo tile is staged once in LDS (pixel stride
+// padded for conflict-free ds_read_b128), the weights stream from L1/L2 in the packed
+// [tap][cout][cin] layout so that one float4 load yields 4 K-steps of the B operand.
+// MFMA operand maps (cdna guide section 3):  A: lane l -> A[i = l&15][k = l>>4],
+// B: lane l -> B[k = l>>4][j = l&15],  C/D: lane l, reg r -> C[row = 4*(l>>4)+r][col = l&15].
+// The K index inside one MFMA is permuted (k-step kk of lane group g uses channel 8g+kk);
+// A and B use the same permutation so the product is unchanged.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int pad_in(int c) { return c <= 4 ? 4 : 32; }       // K-side channel padding
+__host__ __device__ inline int pad_out(int c) { return c <= 16 ? 16 : 32; }    // N-side channel padding
+
+// ------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------
+// FWD:      packed[tap][o][i] = w[tap][i][o]            (o = cout, i = cin)
+// BWD_DATA: packed[tap][o][i] = w[24-tap][o][i]         (o = forward cin, i = forward cout)
+// `cin`/`cout` are the channel counts of the convolution being RUN (for BWD_DATA: cin =
+// channels of dy = forward cout).
+__global__ void k_pack(const float* __restrict__ w, float* __restrict__ packed, int cin, int cout, int mode) {
+    const int IP = pad_in(cin), OP = pad_out(cout);
+    const int total = 25 * OP * IP;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int i = e % IP, o = (e / IP) % OP, tap = e / (IP * OP);
+        float v = 0.f;
+        if (i < cin && o < cout) {
+            if (mode == SOL_CONV_FWD) v = w[(tap * cin + i) * cout + o];      // HWIO, I = cin, O = cout
+            else v = w[((24 - tap) * cout + o) * cin + i];                     // HWIO, I = cout(run), O = cin(run)
+        }
+        packed[e] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// forward / backward-data kernel
+// ------------------------------------------------------------------------------------
+struct ConvArgs {
+    const float *x, *wp, *bias, *res, *act;
+    float* y;
+    int B, H, W, CO;   // CO = real number of stored output channels
+    int epi;
+    float slope;
+    int TW, RPW, tiles_x;
+};
+
+template <int CIN, int NT>
+__global__ void __launch_bounds__(256) k_conv5x5(ConvArgs a) {
+    constexpr int CP = CIN == 4 ? 4 : 36;   // LDS pixel stride in floats
+    constexpr int OP = NT * 16;
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int H = a.H, W = a.W, TW = a.TW, RPW = a.RPW;
+    const int HW = TW + 4;   // halo width in pixels
+    int blk = blockIdx.x;
+    const int tx = blk % a.tiles_x; blk /= a.tiles_x;
+    const int rows_blk = H / RPW;
+    const int ty = blk % rows_blk;
+    const int b = blk / rows_blk;
+    const int y0 = ty * RPW, x0 = tx * TW;
+
+    // ---- stage the zero padded halo tile -------------------------------------------------
+    {
+        constexpr int C4 = CIN / 4;
+        const int npix = (RPW + 4) * HW;
+        const float4* gx = reinterpret_cast<const float4*>(a.x);
+        for (int e = tid; e < npix * C4; e += 256) {
+            const int pix = e / C4, c4 = e - pix * C4;
+            const int hr = pix / HW, hc = pix - hr * HW;
+            const int yy = y0 + hr - 2, xx = x0 + hc - 2;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = gx[((size_t)(b * H + yy) * W + xx) * C4 + c4];
+            *reinterpret_cast<float4*>(&smem[pix * CP + c4 * 4]) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- implicit GEMM ------------------------------------------------------------------
+    const int q = wave * 16 + li;            // this lane's A-row pixel inside the tile
+    const int prr = q / TW, pcc = q - prr * TW;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if constexpr (CIN == 32) {
+        const float* abase = &smem[(prr * HW + pcc) * CP + 8 * g];
+        const float* wbase = a.wp + (size_t)li * 32 + 8 * g;
+#pragma unroll 1
+        for (int dy = 0; dy < 5; ++dy) {
+#pragma unroll
+            for (int dx = 0; dx < 5; ++dx) {
+                const int tap = dy * 5 + dx;
+                const float* ap = abase + (dy * HW + dx) * CP;
+                const float4 a0 = *reinterpret_cast<const float4*>(ap);
+                const float4 a1 = *reinterpret_cast<const float4*>(ap + 4);
+                const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const float* wp = wbase + ((size_t)tap * OP + n * 16) * 32;
+                    const float4 b0 = *reinterpret_cast<const float4*>(wp);
+                    const float4 b1 = *reinterpret_cast<const float4*>(wp + 4);
+                    const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk)
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[kk], acc[n], 0, 0, 0);
+                }
+            }
+        }
+    } else {   // CIN == 4: one MFMA per tap, lane group g = channel
+        const float* abase = &smem[(prr * HW + pcc) * CP + g];
+        const float* wbase = a.wp + (size_t)li * 4 + g;
+#pragma unroll
+        for (int tap = 0; tap < 25; ++tap) {
+            const int dy = tap / 5, dx = tap - dy * 5;
+            const float av = abase[(dy * HW + dx) * CP];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float bv = wbase[((size_t)tap * OP + n * 16) * 4];
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[n], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: bias, residual, LeakyReLU / LeakyReLU' ---------------------------------
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = n * 16 + li;
+        if (co >= a.CO) continue;
+        const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qq = wave * 16 + 4 * g + r;
+            const int rr = qq / TW, cc = qq - rr * TW;
+            const size_t o = ((size_t)(b * H + y0 + rr) * W + x0 + cc) * a.CO + co;
+            float v = acc[n][r] + bias;
+            if (a.res) v += a.res[o];
+            if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
+            else if (a.epi == SOL_EPI_DLRELU) v *= (a.act[o] > 0.f ? 1.f : a.slope);
+            a.y[o] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// backward-weight
+// ------------------------------------------------------------------------------------
+// Workgroup (dy, row block): accumulates dW[dy][0..4][ci][co] over RB image rows in MFMA
+// accumulators (GEMM with K = pixels), then adds them into its private slice of `partial`
+// (no atomics; the slice is owned by the workgroup index, calls on one stream serialise).
+constexpr int RB = 8;   // image rows per workgroup
+
+struct BwArgs {
+    const float *x, *dz;
+    float* partial;
+    int B, H, W, cin, cout;
+    int nblk;
+};
+
+template <int CIN, int COUT>   // real channel counts: CIN in {3,4,32} staged as pad_in, COUT in {2,32}
+__global__ void __launch_bounds__(256) k_conv5x5_bww(BwArgs a) {
+    constexpr int CI = CIN <= 4 ? 4 : 32;         // channels per pixel in global x
+    constexpr int CPX = CI == 4 ? 4 : 48;         // LDS strides ( = 16 mod 32 -> conflict free b32 reads)
+    constexpr int CPZ = COUT <= 4 ? 4 : 48;
+    constexpr int NTA = CI == 4 ? 1 : 2;          // 16-wide tiles along ci / co
+    constexpr int NTC = COUT <= 16 ? 1 : 2;
+    constexpr int IP = CI == 4 ? 16 : 32;         // padded dims of the partial buffer
+    constexpr int OP = NTC * 16;
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int H = a.H, W = a.W;
+    const int dy = blockIdx.x % 5, blk = blockIdx.x / 5;
+    float* xs = smem;                       // [(W+4)][CPX]
+    float* zs = smem + (W + 4) * CPX;       // [W][CPZ]
+    const int ta = wave / NTC, tc = wave % NTC;
+    const bool active_wave = wave < NTA * NTC;
+
+    f32x4 acc[5];
+#pragma unroll
+    for (int d = 0; d < 5; ++d) acc[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    const int R = a.B * H;
+    for (int gr = blk * RB; gr < min((blk + 1) * RB, R); ++gr) {
+        const int b = gr / H, y = gr - b * H;
+        const int yy = y + dy - 2;
+        const bool valid = yy >= 0 && yy < H;       // workgroup uniform
+        if (!valid && dy != 2) continue;
+        __syncthreads();                            // previous row fully consumed
+        if (valid) {
+            if constexpr (CI == 32) {
+                const float4* gx = reinterpret_cast<const float4*>(a.x) + (size_t)(b * H + yy) * W * 8;
+                for (int e = tid; e < (W + 4) * 8; e += 256) {
+                    const int px = e >> 3, c4 = e & 7;
+                    const int xx = px - 2;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (xx >= 0 && xx < W) v = gx[xx * 8 + c4];
+                    *reinterpret_cast<float4*>(&xs[px * CPX + c4 * 4]) = v;
+                }
+            } else {
+                const float4* gx = reinterpret_cast<const float4*>(a.x) + (size_t)(b * H + yy) * W;
+                for (int px = tid; px < W + 4; px += 256) {
+                    const int xx = px - 2;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (xx >= 0 && xx < W) v = gx[xx];
+                    *reinterpret_cast<float4*>(&xs[px * CPX]) = v;
+                }
+            }
+        }
+        if constexpr (COUT > 4) {
+            const float4* gz = reinterpret_cast<const float4*>(a.dz) + (size_t)(b * H + y) * W * (COUT / 4);
+            for (int e = tid; e < W * (COUT / 4); e += 256) {
+                const int px = e / (COUT / 4), c4 = e % (COUT / 4);
+                *reinterpret_cast<float4*>(&zs[px * CPZ + c4 * 4]) = gz[e];
+            }
+        } else {   // COUT == 2
+            const float2* gz = reinterpret_cast<const float2*>(a.dz) + (size_t)(b * H + y) * W;
+            for (int px = tid; px < W; px += 256) {
+                const float2 v = gz[px];
+                zs[px * CPZ] = v.x; zs[px * CPZ + 1] = v.y; zs[px * CPZ + 2] = 0.f; zs[px * CPZ + 3] = 0.f;
+            }
+        }
+        __syncthreads();
+        if (!active_wave) continue;
+        for (int p0 = 0; p0 < W; p0 += 4) {
+            const int px = p0 + g;
+            float bv;
+            if constexpr (COUT > 4) bv = zs[px * CPZ + tc * 16 + li];
+            else bv = li < 4 ? zs[px * CPZ + li] : 0.f;
+            if (dy == 2 && ta == 0) bsum += bv;
+            if (valid) {
+#pragma unroll
+                for (int d = 0; d < 5; ++d) {
+                    float av;
+                    if constexpr (CI == 32) av = xs[(px + d) * CPX + ta * 16 + li];
+                    else av = li < 4 ? xs[(px + d) * CPX + li] : 0.f;
+                    acc[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[d], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!active_wave) return;
+    // partial layout: [blk][25 taps][IP][OP] then [blk][OP] bias sums
+    float* pw = a.partial + (size_t)blk * (25 * IP * OP);
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        const int tap = dy * 5 + d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = ta * 16 + 4 * g + r, co = tc * 16 + li;
+            pw[(tap * IP + ci) * OP + co] += acc[d][r];
+        }
+    }
+    if (dy == 2 && ta == 0) {
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (g == 0) {
+            float* pb = a.partial + (size_t)a.nblk * (25 * IP * OP) + (size_t)blk * OP;
+            pb[tc * 16 + li] += bsum;
+        }
+    }
+}
+
+__global__ void k_bww_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
+                             int nblk, int cin, int cout, int IP, int OP, int accumulate) {
+    const int nw = 25 * cin * cout;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nw) {
+        const int co = e % cout, ci = (e / cout) % cin, tap = e / (cout * cin);
+        const size_t off = (size_t)(tap * IP + ci) * OP + co;
+        float s = 0.f;
+        for (int k = 0; k < nblk; ++k) s += partial[(size_t)k * (25 * IP * OP) + off];
+        dw[e] = accumulate ? dw[e] + s : s;
+    } else if (e < nw + cout) {
+        const int co = e - nw;
+        const float* pb = partial + (size_t)nblk * (25 * IP * OP);
+        float s = 0.f;
+        for (int k = 0; k < nblk; ++k) s += pb[(size_t)k * OP + co];
+        db[co] = accumulate ? db[co] + s : s;
+    }
+}
+
+int check_shape(int B, int H, int W, int cin, int cout) {
+    SOL_REQUIRE(B >= 1 && H >= 1 && W >= 4, "conv5x5: bad image shape B=%d H=%d W=%d", B, H, W);
+    SOL_REQUIRE((W <= 64 && 64 % W == 0 && H % (64 / W) == 0) || W % 64 == 0,
+                "conv5x5: W must divide 64 (with H %% (64/W) == 0) or be a multiple of 64 (H=%d W=%d)", H, W);
+    SOL_REQUIRE(cin == 4 || cin == 32, "conv5x5: input channels must be 4 (zero padded) or 32 (got %d)", cin);
+    SOL_REQUIRE(cout >= 1 && cout <= 32, "conv5x5: output channels must be in [1,32] (got %d)", cout);
+    return SOL_OK;
+}
+
+}  // namespace
+
+extern "C" size_t sol_conv5x5_packed_floats(int32_t cin, int32_t cout, int32_t /*mode*/) {
+    return (size_t)25 * pad_in(cin) * pad_out(cout);
+}
+
+extern "C" int sol_conv5x5_pack(void* stream, const float* w_hwio, int32_t cin, int32_t cout, int32_t mode, float* packed) {
+    SOL_REQUIRE(w_hwio && packed, "sol_conv5x5_pack: NULL pointer");
+    SOL_REQUIRE(cin >= 1 && cin <= 32 && cout >= 1 && cout <= 32, "sol_conv5x5_pack: channels out of range");
+    SOL_REQUIRE(mode == SOL_CONV_FWD || mode == SOL_CONV_BWD_DATA, "sol_conv5x5_pack: bad mode %d", mode);
+    const int total = 25 * pad_in(cin) * pad_out(cout);
+    hipLaunchKernelGGL(k_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_hwio, packed, cin, cout, mode);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
+extern "C" int sol_conv5x5(void* stream, const float* x, const float* packed, const float* bias,
+                           const float* residual, const float* act_ref, float* y,
+                           int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,
+                           int32_t epilogue, float slope) {
+    if (int e = check_shape(B, H, W, cin, cout)) return e;
+    SOL_REQUIRE(x && packed && y, "sol_conv5x5: NULL pointer");
+    SOL_REQUIRE(epilogue != SOL_EPI_DLRELU || act_ref, "sol_conv5x5: SOL_EPI_DLRELU needs act_ref");
+    ConvArgs a{};
+    a.x = x; a.wp = packed; a.bias = bias; a.res = residual; a.act = act_ref; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.CO = cout; a.epi = epilogue; a.slope = slope;
+    a.TW = W < 64 ? W : 64;
+    a.RPW = 64 / a.TW;
+    a.tiles_x = W / a.TW;
+    const int grid = B * (H / a.RPW) * a.tiles_x;
+    const int CP = cin == 4 ? 4 : 36;
+    const size_t lds = (size_t)(a.RPW + 4) * (a.TW + 4) * CP * sizeof(float);
+    const int NT = pad_out(cout) / 16;
+    hipStream_t s = (hipStream_t)stream;
+    if (cin == 32 && NT == 2) hipLaunchKernelGGL((k_conv5x5<32, 2>), dim3(grid), dim3(256), lds, s, a);
+    else if (cin == 32 && NT == 1) hipLaunchKernelGGL((k_conv5x5<32, 1>), dim3(grid), dim3(256), lds, s, a);
+    else if (cin == 4 && NT == 2) hipLaunchKernelGGL((k_conv5x5<4, 2>), dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((k_conv5x5<4, 1>), dim3(grid), dim3(256), lds, s, a);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
+static int bww_dims(int B, int H, int cin, int cout, int* nblk, int* IP, int* OP) {
+    *nblk = (B * H + RB - 1) / RB;
+    *IP = cin <= 4 ? 16 : 32;
+    *OP = cout <= 16 ? 16 : 32;
+    return 0;
+}
+
+extern "C" size_t sol_conv5x5_bwd_weight_ws_floats(int32_t B, int32_t H, int32_t /*W*/, int32_t cin, int32_t cout) {
+    int nblk, IP, OP;
+    bww_dims(B, H, cin, cout, &nblk, &IP, &OP);
+    return (size_t)nblk * (25 * IP * OP + OP);
+}
+
+extern "C" int sol_conv5x5_bwd_weight(void* stream, const float* x, const float* dz, float* partial,
+                                      int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout) {
+    SOL_REQUIRE(x && dz && partial, "sol_conv5x5_bwd_weight: NULL pointer");
+    SOL_REQUIRE(B >= 1 && H >= 1 && W >= 4 && W % 4 == 0, "sol_conv5x5_bwd_weight: bad shape");
+    SOL_REQUIRE((cin == 4 || cin == 32) && (cout == 2 || cout == 32),
+                "sol_conv5x5_bwd_weight: supported (cin,cout) are {4,32}x{2,32} (got %d,%d)", cin, cout);
+    BwArgs a{};
+    a.x = x; a.dz = dz; a.partial = partial; a.B = B; a.H = H; a.W = W; a.cin = cin; a.cout = cout;
+    int IP, OP;
+    bww_dims(B, H, cin, cout, &a.nblk, &IP, &OP);
+    const int CPX = cin == 4 ? 4 : 48, CPZ = cout <= 4 ? 4 : 48;
+    const size_t lds = ((size_t)(W + 4) * CPX + (size_t)W * CPZ) * sizeof(float);
+    const int grid = a.nblk * 5;
+    hipStream_t s = (hipStream_t)stream;
+    if (cin == 32 && cout == 32) hipLaunchKernelGGL((k_conv5x5_bww<32, 32>), dim3(grid), dim3(256), lds, s, a);
+    else if (cin == 32 && cout == 2) hipLaunchKernelGGL((k_conv5x5_bww<32, 2>), dim3(grid), dim3(256), lds, s, a);
+    else if (cin == 4 && cout == 32) hipLaunchKernelGGL((k_conv5x5_bww<4, 32>), dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((k_conv5x5_bww<4, 2>), dim3(grid), dim3(256), lds, s, a);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
+extern "C" int sol_conv5x5_bwd_weight_reduce(void* stream, const float* partial, float* dw_hwio, float* db,
+                                             int32_t B, int32_t H, int32_t /*W*/, int32_t cin, int32_t cout,
+                                             int32_t accumulate) {
+    SOL_REQUIRE(partial && dw_hwio && db, "sol_conv5x5_bwd_weight_reduce: NULL pointer");
+    SOL_REQUIRE(cin >= 1 && cin <= 32 && cout >= 1 && cout <= 32, "sol_conv5x5_bwd_weight_reduce: channels out of range");
+    int nblk, IP, OP;
+    bww_dims(B, H, cin <= 4 ? 4 : 32, cout, &nblk, &IP, &OP);
+    const int total = 25 * cin * cout + cout;
+    hipLaunchKernelGGL(k_bww_reduce, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       partial, dw_hwio, db, nblk, cin, cout, IP, OP, accumulate);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}

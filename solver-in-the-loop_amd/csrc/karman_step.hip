@@ -1,0 +1,595 @@
+// Fused solver step for the karman-2d scene and its adjoint  --  gfx950 / CDNA4.
+//
+// Replaces KarmanFlow.step (/root/reference/karman-2d/karman_train.py:173-185) and the
+// PhiFlow ops it calls (diffuse, advect.semi_lagrangian x2, effect_applied(Inflow),
+// divergence_free -> SparseCG, StaggeredGrid.gradient) and their TF gradients.
+//
+// Design (MI355X first): one simulation = one workgroup.  All solver state of a sample
+// (two staggered components, <= 33 KB each at 128x64) lives in that CU's 160 KB LDS from
+// the input load to the output store.  The CG vectors x, r, p, Mp never touch LDS at all:
+// each thread owns a column strip of 8 cells, so the y-neighbours are registers, the
+// x-neighbours are one lane away (wave shift) and only the strip end rows are exchanged
+// through LDS (2 floats per thread per iteration).  The dot products are wave64 shuffles
+// plus one LDS slot per wave.
+#include "common.hpp"
+
+namespace {
+
+constexpr int CPT = 8;       // cells per thread (strip height)
+constexpr int MAXT = 9;      // max face targets per thread: (Y+1)*X / (Y*X/8) <= 9 for Y >= 8
+
+struct StepArgs {
+    int B, Y, X;
+    float dtdx;    // dt / dx  (index-space displacement per unit velocity)
+    float dt;
+    float adt;     // dt*res*res  -> alpha_b = adt / Re_b   (karman_train.py:175)
+    float rtol2, atol2;
+    int max_iter, grad_pad, inflow_before;
+    const float *d_in, *vy_in, *vx_in, *re, *active, *inflow, *bcv, *bcm;
+    long bc_stride;
+    float *d_out, *vy_out, *vx_out, *saved_vy, *saved_vx, *feat;
+    float fs0, fs1, fs2;
+    int* iters;
+    // backward only
+    const float *g_vy_out, *g_vx_out, *dfeat;
+    float *g_vy_in, *g_vx_in;
+};
+
+__host__ __device__ inline int al4(int n) { return (n + 3) & ~3; }
+
+struct Lds {
+    float *Avy, *Avx, *Bvy, *Bvx, *E, *red;
+    unsigned char* act;
+};
+
+__host__ __device__ inline size_t lds_floats(int Y, int X) {
+    const int nVy = (Y + 1) * X, nVx = Y * (X + 1);
+    return 2 * (size_t)(al4(nVy) + al4(nVx)) + 4 * (size_t)(Y / CPT) * X + 64;
+}
+__host__ inline size_t lds_bytes(int Y, int X) { return lds_floats(Y, X) * 4 + (size_t)al4(Y * X); }
+
+__device__ inline Lds carve(float* smem, int Y, int X) {
+    const int nVy = (Y + 1) * X, nVx = Y * (X + 1);
+    Lds l;
+    l.Avy = smem;
+    l.Avx = l.Avy + al4(nVy);
+    l.Bvy = l.Avx + al4(nVx);
+    l.Bvx = l.Bvy + al4(nVy);
+    l.E = l.Bvx + al4(nVx);
+    l.red = l.E + 4 * (Y / CPT) * X;
+    l.act = reinterpret_cast<unsigned char*>(l.red + 64);
+    return l;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// accessible(j,i): active mask with 'boundary' extrapolation (OPEN domain) [EXT-RECALL A.6]
+__device__ __forceinline__ float acc_at(const unsigned char* act, int Y, int X, int j, int i) {
+    return (float)act[clampi(j, 0, Y - 1) * X + clampi(i, 0, X - 1)];
+}
+__device__ __forceinline__ float mask_y(const unsigned char* act, int Y, int X, int j, int i) {
+    return fminf(acc_at(act, Y, X, j - 1, i), acc_at(act, Y, X, j, i));
+}
+__device__ __forceinline__ float mask_x(const unsigned char* act, int Y, int X, int j, int i) {
+    return fminf(acc_at(act, Y, X, j, i - 1), acc_at(act, Y, X, j, i));
+}
+
+// Bilinear sample with index clamping ('boundary' extrapolation).  The sample coordinate is
+// (jb + oy, ib + ox) with small float offsets, so the interpolation weights keep full fp32
+// precision even at large indices.
+struct Bil {
+    int j0, j1, i0, i1;
+    float wy, wx;
+};
+__device__ __forceinline__ Bil bil_clamp(int H, int W, int jb, float oy, int ib, float ox) {
+    Bil s;
+    const float fy = floorf(oy), fx = floorf(ox);
+    s.wy = oy - fy;
+    s.wx = ox - fx;
+    const int j0 = jb + (int)fy, i0 = ib + (int)fx;
+    s.j0 = clampi(j0, 0, H - 1);
+    s.j1 = clampi(j0 + 1, 0, H - 1);
+    s.i0 = clampi(i0, 0, W - 1);
+    s.i1 = clampi(i0 + 1, 0, W - 1);
+    return s;
+}
+__device__ __forceinline__ float bil_eval(const float* f, int W, const Bil& s) {
+    const float f00 = f[s.j0 * W + s.i0], f01 = f[s.j0 * W + s.i1];
+    const float f10 = f[s.j1 * W + s.i0], f11 = f[s.j1 * W + s.i1];
+    return (1.f - s.wy) * ((1.f - s.wx) * f00 + s.wx * f01) + s.wy * ((1.f - s.wx) * f10 + s.wx * f11);
+}
+
+// ------------------------------------------------------------------------------------
+// Strip ownership for the CG: thread -> (strip, column i), rows j0..j0+7
+// ------------------------------------------------------------------------------------
+struct Own {
+    int strip, i, j0, nstrips;
+    bool owner;
+};
+__device__ __forceinline__ Own ownership(int Y, int X) {
+    Own o;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int spw = 64 / X;   // strips per wave (X <= 64, power of two)
+    o.nstrips = Y / CPT;
+    o.strip = wave * spw + lane / X;
+    o.i = lane % X;
+    o.j0 = o.strip * CPT;
+    o.owner = o.strip < o.nstrips;
+    return o;
+}
+
+// Solve M x = rhs with M = -A (SPD): M[c,c] = dg[c] (number of accessible neighbours,
+// >= 1), M[c,n] = -active[c]*active[n]; p = 0 outside the OPEN domain.  Matrix-free CG
+// from x0 = 0; per-sample stop |r|^2 <= max(rtol2*|b|^2, atol2).  rhs comes in r[], the
+// solution leaves in x[].  Returns the iteration count (workgroup uniform).
+__device__ __forceinline__ int cg_solve(const Own& o, int X, const float (&dg)[CPT], const float (&ac)[CPT],
+                                        float (&r)[CPT], float (&x)[CPT], float* E, float* red,
+                                        float rtol2, float atol2, int max_iter) {
+    float p[CPT], Mp[CPT];
+    float part = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        x[k] = 0.f;
+        p[k] = r[k];
+        part += r[k] * r[k];
+    }
+    int slot = 0;
+    float rr = block_sum(part, red, slot);
+    slot ^= 1;
+    const float thresh = fmaxf(rtol2 * rr, atol2);
+    const int EW = o.nstrips * X;
+    const bool has_l = o.i > 0, has_r = o.i < X - 1;
+    int it = 0;
+    while (rr > thresh && it < max_iter) {
+        float* Et = E + (it & 1) * 2 * EW;
+        float* Eb = Et + EW;
+        if (o.owner) {
+            Et[o.strip * X + o.i] = p[0];
+            Eb[o.strip * X + o.i] = p[CPT - 1];
+        }
+        __syncthreads();
+        const float hprev = (o.owner && o.strip > 0) ? Eb[(o.strip - 1) * X + o.i] : 0.f;
+        const float hnext = (o.owner && o.strip < o.nstrips - 1) ? Et[(o.strip + 1) * X + o.i] : 0.f;
+        part = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const float pl = __shfl_up(p[k], 1, 64);
+            const float pr = __shfl_down(p[k], 1, 64);
+            const float prev = k > 0 ? p[k - 1] : hprev;
+            const float next = k < CPT - 1 ? p[k + 1] : hnext;
+            const float nb = prev + next + (has_l ? pl : 0.f) + (has_r ? pr : 0.f);
+            Mp[k] = dg[k] * p[k] - ac[k] * nb;
+            part += p[k] * Mp[k];
+        }
+        const float pMp = block_sum(part, red, slot);
+        slot ^= 1;
+        if (!(pMp > 0.f)) break;
+        const float alpha = rr / pMp;
+        part = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            x[k] += alpha * p[k];
+            r[k] -= alpha * Mp[k];
+            part += r[k] * r[k];
+        }
+        const float rrn = block_sum(part, red, slot);
+        slot ^= 1;
+        const float beta = rrn / rr;
+        rr = rrn;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) p[k] = r[k] + beta * p[k];
+        ++it;
+    }
+    return it;
+}
+
+// per-cell matrix coefficients of the owned strip
+__device__ __forceinline__ void cell_coeffs(const Own& o, const unsigned char* act, int Y, int X,
+                                            float (&dg)[CPT], float (&ac)[CPT]) {
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        dg[k] = 1.f;
+        ac[k] = 0.f;
+        if (o.owner) {
+            const int j = o.j0 + k, i = o.i;
+            ac[k] = (float)act[j * X + i];
+            const float nacc = acc_at(act, Y, X, j - 1, i) + acc_at(act, Y, X, j + 1, i) +
+                               acc_at(act, Y, X, j, i - 1) + acc_at(act, Y, X, j, i + 1);
+            dg[k] = fmaxf(nacc, 1.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_karman_fwd(StepArgs a) {
+    extern __shared__ __align__(16) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int Y = a.Y, X = a.X, N = Y * X, nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
+    const Lds L = carve(smem, Y, X);
+
+    // ---- phase 1: load inputs -------------------------------------------------------
+    {
+        const float* gvy = a.vy_in + (size_t)b * nVy;
+        const float* gvx = a.vx_in + (size_t)b * nVx;
+        for (int k = tid; k < nVy; k += nthr) L.Avy[k] = gvy[k];
+        for (int k = tid; k < nVx; k += nthr) L.Avx[k] = gvx[k];
+        for (int k = tid; k < N; k += nthr) L.act[k] = a.active[k] != 0.f ? 1 : 0;
+    }
+    __syncthreads();
+
+    // ---- phase 2: explicit diffusion (replicate padding, dx = 1) + velocity BC ------
+    {
+        const float alpha = a.adt / a.re[b];
+        const float* bcv = a.bcv + (size_t)b * a.bc_stride;
+        const float* bcm = a.bcm + (size_t)b * a.bc_stride;
+        for (int k = tid; k < nVy; k += nthr) {
+            const int j = k / X, i = k - j * X;
+            const float c = L.Avy[k];
+            const float lap = L.Avy[min(j + 1, Y) * X + i] + L.Avy[max(j - 1, 0) * X + i] +
+                              L.Avy[j * X + min(i + 1, X - 1)] + L.Avy[j * X + max(i - 1, 0)] - 4.f * c;
+            float v = c + alpha * lap;
+            v = v * (1.f - bcm[k]) + bcv[k];
+            L.Bvy[k] = v;
+            if (a.saved_vy) a.saved_vy[(size_t)b * nVy + k] = v;
+        }
+        for (int k = tid; k < nVx; k += nthr) {
+            const int j = k / XP, i = k - j * XP;
+            const float c = L.Avx[k];
+            const float lap = L.Avx[min(j + 1, Y - 1) * XP + i] + L.Avx[max(j - 1, 0) * XP + i] +
+                              L.Avx[j * XP + min(i + 1, X)] + L.Avx[j * XP + max(i - 1, 0)] - 4.f * c;
+            const float v = c + alpha * lap;
+            L.Bvx[k] = v;
+            if (a.saved_vx) a.saved_vx[(size_t)b * nVx + k] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: semi-Lagrangian advection (B -> A), hard-BC face mask fused --------
+    for (int k = tid; k < nVy; k += nthr) {
+        const int j = k / X, i = k - j * X;
+        const float uy = L.Bvy[k];
+        const int ja = max(j - 1, 0), jb = min(j, Y - 1);
+        const float ux = 0.25f * (L.Bvx[ja * XP + i] + L.Bvx[ja * XP + i + 1] + L.Bvx[jb * XP + i] + L.Bvx[jb * XP + i + 1]);
+        const Bil s = bil_clamp(Y + 1, X, j, -uy * a.dtdx, i, -ux * a.dtdx);
+        L.Avy[k] = bil_eval(L.Bvy, X, s) * mask_y(L.act, Y, X, j, i);
+    }
+    for (int k = tid; k < nVx; k += nthr) {
+        const int j = k / XP, i = k - j * XP;
+        const float ux = L.Bvx[k];
+        const int ia = max(i - 1, 0), ib = min(i, X - 1);
+        const float uy = 0.25f * (L.Bvy[j * X + ia] + L.Bvy[j * X + ib] + L.Bvy[(j + 1) * X + ia] + L.Bvy[(j + 1) * X + ib]);
+        const Bil s = bil_clamp(Y, XP, j, -uy * a.dtdx, i, -ux * a.dtdx);
+        L.Avx[k] = bil_eval(L.Bvx, XP, s) * mask_x(L.act, Y, X, j, i);
+    }
+    if (a.d_out) {
+        const float* gd = a.d_in + (size_t)b * N;
+        for (int k = tid; k < N; k += nthr) {
+            const int j = k / X, i = k - j * X;
+            const float uy = 0.5f * (L.Bvy[k] + L.Bvy[k + X]);
+            const float ux = 0.5f * (L.Bvx[j * XP + i] + L.Bvx[j * XP + i + 1]);
+            const float oy = -uy * a.dtdx, ox = -ux * a.dtdx;
+            const float fy = floorf(oy), fx = floorf(ox);
+            const float wy = oy - fy, wx = ox - fx;
+            const int j0 = j + (int)fy, i0 = i + (int)fx;
+            float f[2][2];
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+                for (int di = 0; di < 2; ++di) {
+                    const int jj = j0 + dj, ii = i0 + di;
+                    float v = 0.f;   // extrapolation 'constant': one ring of zero ghost cells
+                    if (jj >= 0 && jj < Y && ii >= 0 && ii < X) {
+                        v = gd[jj * X + ii];
+                        if (a.inflow_before) v += a.inflow[jj * X + ii];
+                    }
+                    f[dj][di] = v;
+                }
+            float v = (1.f - wy) * ((1.f - wx) * f[0][0] + wx * f[0][1]) + wy * ((1.f - wx) * f[1][0] + wx * f[1][1]);
+            if (!a.inflow_before) v += a.inflow[k] * a.dt;
+            a.d_out[(size_t)b * N + k] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 4/5: divergence + CG pressure solve ----------------------------------
+    const Own o = ownership(Y, X);
+    float dg[CPT], ac[CPT], r[CPT], x[CPT];
+    cell_coeffs(o, L.act, Y, X, dg, ac);
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        r[k] = 0.f;
+        if (o.owner) {
+            const int j = o.j0 + k, i = o.i;
+            const float div = (L.Avy[(j + 1) * X + i] - L.Avy[j * X + i]) + (L.Avx[j * XP + i + 1] - L.Avx[j * XP + i]);
+            r[k] = -div;   // M p = -div  <=>  A p = div
+        }
+    }
+    const int it = cg_solve(o, X, dg, ac, r, x, L.E, L.red, a.rtol2, a.atol2, a.max_iter);
+    if (a.iters && tid == 0) a.iters[b] = it;
+
+    // ---- phase 6: v -= mask * grad p ;  outputs --------------------------------------
+    float* P = L.Bvy;   // region B is free after the advection
+    if (o.owner) {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) P[(o.j0 + k) * X + o.i] = x[k];
+    }
+    __syncthreads();
+    {
+        float* gvy = a.vy_out + (size_t)b * nVy;
+        float* gvx = a.vx_out + (size_t)b * nVx;
+        for (int k = tid; k < nVy; k += nthr) {
+            const int j = k / X, i = k - j * X;
+            float g = 0.f;
+            if (j >= 1 && j <= Y - 1) g = P[j * X + i] - P[(j - 1) * X + i];
+            else if (a.grad_pad == 1) g = (j == 0) ? P[i] : -P[(Y - 1) * X + i];
+            const float v = L.Avy[k] - mask_y(L.act, Y, X, j, i) * g;
+            L.Avy[k] = v;
+            gvy[k] = v;
+        }
+        for (int k = tid; k < nVx; k += nthr) {
+            const int j = k / XP, i = k - j * XP;
+            float g = 0.f;
+            if (i >= 1 && i <= X - 1) g = P[j * X + i] - P[j * X + i - 1];
+            else if (a.grad_pad == 1) g = (i == 0) ? P[j * X] : -P[j * X + X - 1];
+            const float v = L.Avx[k] - mask_x(L.act, Y, X, j, i) * g;
+            L.Avx[k] = v;
+            gvx[k] = v;
+        }
+    }
+    if (a.feat) {   // fused to_feature + 1/std scaling (karman_train.py:77-86,416-419)
+        __syncthreads();
+        float4* gf = reinterpret_cast<float4*>(a.feat) + (size_t)b * N;
+        const float rech = a.re[b] * a.fs2;
+        for (int k = tid; k < N; k += nthr) {
+            const int j = k / X, i = k - j * X;
+            gf[k] = make_float4(L.Avy[k] * a.fs0, L.Avx[j * XP + i] * a.fs1, rech, 0.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// backward (adjoint w.r.t. the input velocity)
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_karman_bwd(StepArgs a) {
+    extern __shared__ __align__(16) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int Y = a.Y, X = a.X, N = Y * X, nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
+    const Lds L = carve(smem, Y, X);
+    const bool dirichlet = a.grad_pad == 1;
+
+    // ---- 1: load incoming gradient (+ feature gradient) ------------------------------
+    {
+        const float* gy = a.g_vy_out + (size_t)b * nVy;
+        const float* gx = a.g_vx_out + (size_t)b * nVx;
+        const float* df = a.dfeat ? a.dfeat + (size_t)b * N * 2 : nullptr;
+        for (int k = tid; k < nVy; k += nthr) {
+            float g = gy[k];
+            if (df && k < N) g += a.fs0 * df[2 * k];            // rows j < Y
+            L.Avy[k] = g;
+        }
+        for (int k = tid; k < nVx; k += nthr) {
+            const int j = k / XP, i = k - j * XP;
+            float g = gx[k];
+            if (df && i < X) g += a.fs1 * df[2 * (j * X + i) + 1];
+            L.Avx[k] = g;
+        }
+        for (int k = tid; k < N; k += nthr) L.act[k] = a.active[k] != 0.f ? 1 : 0;
+    }
+    __syncthreads();
+
+    // ---- 2: projection adjoint:  M z = G^T (m * g) -----------------------------------
+    const Own o = ownership(Y, X);
+    float dg[CPT], ac[CPT], r[CPT], z[CPT];
+    cell_coeffs(o, L.act, Y, X, dg, ac);
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        r[k] = 0.f;
+        if (o.owner) {
+            const int j = o.j0 + k, i = o.i;
+            float s = 0.f;
+            if (j >= 1 || dirichlet) s += mask_y(L.act, Y, X, j, i) * L.Avy[j * X + i];
+            if (j + 1 <= Y - 1 || dirichlet) s -= mask_y(L.act, Y, X, j + 1, i) * L.Avy[(j + 1) * X + i];
+            if (i >= 1 || dirichlet) s += mask_x(L.act, Y, X, j, i) * L.Avx[j * XP + i];
+            if (i + 1 <= X - 1 || dirichlet) s -= mask_x(L.act, Y, X, j, i + 1) * L.Avx[j * XP + i + 1];
+            r[k] = s;
+        }
+    }
+    const int it = cg_solve(o, X, dg, ac, r, z, L.E, L.red, a.rtol2, a.atol2, a.max_iter);
+    if (a.iters && tid == 0) a.iters[b] = it;
+
+    // ---- 3: g_adv = m * (g + D^T z), kept in registers ---------------------------------
+    float* Z = L.Bvy;
+    if (o.owner) {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) Z[(o.j0 + k) * X + o.i] = z[k];
+    }
+    __syncthreads();
+    float gy[MAXT], gx[MAXT];
+#pragma unroll
+    for (int n = 0; n < MAXT; ++n) {
+        const int k = tid + n * nthr;
+        gy[n] = 0.f;
+        gx[n] = 0.f;
+        if (k < nVy) {
+            const int j = k / X, i = k - j * X;
+            const float zp = j >= 1 ? Z[(j - 1) * X + i] : 0.f;
+            const float zc = j <= Y - 1 ? Z[j * X + i] : 0.f;
+            gy[n] = mask_y(L.act, Y, X, j, i) * (L.Avy[k] + (zp - zc));
+        }
+        if (k < nVx) {
+            const int j = k / XP, i = k - j * XP;
+            const float zp = i >= 1 ? Z[j * X + i - 1] : 0.f;
+            const float zc = i <= X - 1 ? Z[j * X + i] : 0.f;
+            gx[n] = mask_x(L.act, Y, X, j, i) * (L.Avx[k] + (zp - zc));
+        }
+    }
+    __syncthreads();
+
+    // ---- 4: stage the saved (post-diffusion) velocity, clear the accumulators ---------
+    {
+        const float* sy = a.saved_vy + (size_t)b * nVy;
+        const float* sx = a.saved_vx + (size_t)b * nVx;
+        for (int k = tid; k < nVy; k += nthr) { L.Bvy[k] = sy[k]; L.Avy[k] = 0.f; }
+        for (int k = tid; k < nVx; k += nthr) { L.Bvx[k] = sx[k]; L.Avx[k] = 0.f; }
+    }
+    __syncthreads();
+
+    // ---- 5: advection adjoint (scatter-add into LDS) -----------------------------------
+#pragma unroll
+    for (int n = 0; n < MAXT; ++n) {
+        const int k = tid + n * nthr;
+        if (k < nVy && gy[n] != 0.f) {
+            const int j = k / X, i = k - j * X;
+            const float g = gy[n];
+            const float uy = L.Bvy[k];
+            const int ja = max(j - 1, 0), jb = min(j, Y - 1);
+            const float ux = 0.25f * (L.Bvx[ja * XP + i] + L.Bvx[ja * XP + i + 1] + L.Bvx[jb * XP + i] + L.Bvx[jb * XP + i + 1]);
+            const Bil s = bil_clamp(Y + 1, X, j, -uy * a.dtdx, i, -ux * a.dtdx);
+            const float f00 = L.Bvy[s.j0 * X + s.i0], f01 = L.Bvy[s.j0 * X + s.i1];
+            const float f10 = L.Bvy[s.j1 * X + s.i0], f11 = L.Bvy[s.j1 * X + s.i1];
+            atomicAdd(&L.Avy[s.j0 * X + s.i0], (1.f - s.wy) * (1.f - s.wx) * g);
+            atomicAdd(&L.Avy[s.j0 * X + s.i1], (1.f - s.wy) * s.wx * g);
+            atomicAdd(&L.Avy[s.j1 * X + s.i0], s.wy * (1.f - s.wx) * g);
+            atomicAdd(&L.Avy[s.j1 * X + s.i1], s.wy * s.wx * g);
+            const float ddy = (1.f - s.wx) * (f10 - f00) + s.wx * (f11 - f01);
+            const float ddx = (1.f - s.wy) * (f01 - f00) + s.wy * (f11 - f10);
+            const float guy = -a.dtdx * g * ddy, gux = -0.25f * a.dtdx * g * ddx;
+            atomicAdd(&L.Avy[k], guy);
+            atomicAdd(&L.Avx[ja * XP + i], gux);
+            atomicAdd(&L.Avx[ja * XP + i + 1], gux);
+            atomicAdd(&L.Avx[jb * XP + i], gux);
+            atomicAdd(&L.Avx[jb * XP + i + 1], gux);
+        }
+        if (k < nVx && gx[n] != 0.f) {
+            const int j = k / XP, i = k - j * XP;
+            const float g = gx[n];
+            const float ux = L.Bvx[k];
+            const int ia = max(i - 1, 0), ib = min(i, X - 1);
+            const float uy = 0.25f * (L.Bvy[j * X + ia] + L.Bvy[j * X + ib] + L.Bvy[(j + 1) * X + ia] + L.Bvy[(j + 1) * X + ib]);
+            const Bil s = bil_clamp(Y, XP, j, -uy * a.dtdx, i, -ux * a.dtdx);
+            const float f00 = L.Bvx[s.j0 * XP + s.i0], f01 = L.Bvx[s.j0 * XP + s.i1];
+            const float f10 = L.Bvx[s.j1 * XP + s.i0], f11 = L.Bvx[s.j1 * XP + s.i1];
+            atomicAdd(&L.Avx[s.j0 * XP + s.i0], (1.f - s.wy) * (1.f - s.wx) * g);
+            atomicAdd(&L.Avx[s.j0 * XP + s.i1], (1.f - s.wy) * s.wx * g);
+            atomicAdd(&L.Avx[s.j1 * XP + s.i0], s.wy * (1.f - s.wx) * g);
+            atomicAdd(&L.Avx[s.j1 * XP + s.i1], s.wy * s.wx * g);
+            const float ddy = (1.f - s.wx) * (f10 - f00) + s.wx * (f11 - f01);
+            const float ddx = (1.f - s.wy) * (f01 - f00) + s.wy * (f11 - f10);
+            const float gux = -a.dtdx * g * ddx, guy = -0.25f * a.dtdx * g * ddy;
+            atomicAdd(&L.Avx[k], gux);
+            atomicAdd(&L.Avy[j * X + ia], guy);
+            atomicAdd(&L.Avy[j * X + ib], guy);
+            atomicAdd(&L.Avy[(j + 1) * X + ia], guy);
+            atomicAdd(&L.Avy[(j + 1) * X + ib], guy);
+        }
+    }
+    __syncthreads();
+
+    // ---- 6: BC adjoint, then diffusion adjoint (the replicate Laplacian is symmetric) --
+    {
+        const float* bcm = a.bcm + (size_t)b * a.bc_stride;
+        for (int k = tid; k < nVy; k += nthr) L.Avy[k] *= (1.f - bcm[k]);
+    }
+    __syncthreads();
+    {
+        const float alpha = a.adt / a.re[b];
+        float* oy = a.g_vy_in + (size_t)b * nVy;
+        float* ox = a.g_vx_in + (size_t)b * nVx;
+        for (int k = tid; k < nVy; k += nthr) {
+            const int j = k / X, i = k - j * X;
+            const float c = L.Avy[k];
+            const float lap = L.Avy[min(j + 1, Y) * X + i] + L.Avy[max(j - 1, 0) * X + i] +
+                              L.Avy[j * X + min(i + 1, X - 1)] + L.Avy[j * X + max(i - 1, 0)] - 4.f * c;
+            oy[k] = c + alpha * lap;
+        }
+        for (int k = tid; k < nVx; k += nthr) {
+            const int j = k / XP, i = k - j * XP;
+            const float c = L.Avx[k];
+            const float lap = L.Avx[min(j + 1, Y - 1) * XP + i] + L.Avx[max(j - 1, 0) * XP + i] +
+                              L.Avx[j * XP + min(i + 1, X)] + L.Avx[j * XP + max(i - 1, 0)] - 4.f * c;
+            ox[k] = c + alpha * lap;
+        }
+    }
+}
+
+int check_cfg(const sol_karman_cfg* c) {
+    SOL_REQUIRE(c != nullptr, "cfg is NULL");
+    SOL_REQUIRE(c->B >= 1, "B must be >= 1 (got %d)", c->B);
+    SOL_REQUIRE(c->Y >= 8 && c->Y % CPT == 0, "Y must be a positive multiple of 8 (got %d)", c->Y);
+    SOL_REQUIRE(c->X == 8 || c->X == 16 || c->X == 32 || c->X == 64, "X must be 8, 16, 32 or 64 (got %d)", c->X);
+    SOL_REQUIRE((c->Y / CPT) * c->X <= 1024, "grid %dx%d exceeds one workgroup (Y*X/8 <= 1024)", c->Y, c->X);
+    SOL_REQUIRE(lds_bytes(c->Y, c->X) <= 160 * 1024, "grid %dx%d does not fit the 160 KiB LDS", c->Y, c->X);
+    SOL_REQUIRE(c->dx > 0.f && c->cg_max_iter >= 0, "dx must be > 0 and cg_max_iter >= 0");
+    return SOL_OK;
+}
+
+void fill_common(StepArgs& a, const sol_karman_cfg* c) {
+    a.B = c->B; a.Y = c->Y; a.X = c->X;
+    a.dtdx = c->dt / c->dx;
+    a.dt = c->dt;
+    a.adt = c->dt * c->res * c->res;
+    a.rtol2 = c->cg_rtol * c->cg_rtol;
+    a.atol2 = c->cg_atol * c->cg_atol;
+    a.max_iter = c->cg_max_iter;
+    a.grad_pad = c->grad_pad;
+    a.inflow_before = c->inflow_before;
+}
+
+template <typename K>
+int launch_step(K kernel, const sol_karman_cfg* c, void* stream, const StepArgs& a) {
+    const int threads = (int)align_up((size_t)(c->Y / CPT) * c->X, 64);
+    const size_t lds = lds_bytes(c->Y, c->X);
+    SOL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3(c->B), dim3(threads), lds, (hipStream_t)stream, a);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
+}  // namespace
+
+extern "C" int sol_karman_step_fwd(const sol_karman_cfg* cfg, void* stream,
+                                   const float* d_in, const float* vy_in, const float* vx_in,
+                                   const float* re, const float* active, const float* inflow,
+                                   const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
+                                   float* d_out, float* vy_out, float* vx_out,
+                                   float* saved_vy, float* saved_vx,
+                                   float* feat_out, const float* feat_scale, int32_t* iters) {
+    if (int e = check_cfg(cfg)) return e;
+    SOL_REQUIRE(vy_in && vx_in && re && active && velBCy && velBCyMask && vy_out && vx_out,
+                "sol_karman_step_fwd: NULL pointer argument");
+    SOL_REQUIRE((d_in && inflow) || !d_out, "density output requested without d_in/inflow");
+    SOL_REQUIRE(!feat_out || feat_scale, "feat_out requires feat_scale");
+    StepArgs a{};
+    fill_common(a, cfg);
+    a.d_in = d_in; a.vy_in = vy_in; a.vx_in = vx_in; a.re = re; a.active = active; a.inflow = inflow;
+    a.bcv = velBCy; a.bcm = velBCyMask; a.bc_stride = bc_batch_stride;
+    a.d_out = d_out; a.vy_out = vy_out; a.vx_out = vx_out; a.saved_vy = saved_vy; a.saved_vx = saved_vx;
+    a.feat = feat_out;
+    if (feat_scale) { a.fs0 = feat_scale[0]; a.fs1 = feat_scale[1]; a.fs2 = feat_scale[2]; }
+    a.iters = iters;
+    return launch_step(k_karman_fwd, cfg, stream, a);
+}
+
+extern "C" int sol_karman_step_bwd(const sol_karman_cfg* cfg, void* stream,
+                                   const float* saved_vy, const float* saved_vx,
+                                   const float* re, const float* active,
+                                   const float* velBCyMask, int64_t bc_batch_stride,
+                                   const float* g_vy_out, const float* g_vx_out,
+                                   const float* dfeat, const float* feat_scale,
+                                   float* g_vy_in, float* g_vx_in, int32_t* iters) {
+    if (int e = check_cfg(cfg)) return e;
+    SOL_REQUIRE(saved_vy && saved_vx && re && active && velBCyMask && g_vy_out && g_vx_out && g_vy_in && g_vx_in,
+                "sol_karman_step_bwd: NULL pointer argument");
+    SOL_REQUIRE(!dfeat || feat_scale, "dfeat requires feat_scale");
+    StepArgs a{};
+    fill_common(a, cfg);
+    a.saved_vy = const_cast<float*>(saved_vy); a.saved_vx = const_cast<float*>(saved_vx);
+    a.re = re; a.active = active; a.bcm = velBCyMask; a.bc_stride = bc_batch_stride;
+    a.g_vy_out = g_vy_out; a.g_vx_out = g_vx_out; a.dfeat = dfeat;
+    if (feat_scale) { a.fs0 = feat_scale[0]; a.fs1 = feat_scale[1]; a.fs2 = feat_scale[2]; }
+    a.g_vy_in = g_vy_in; a.g_vx_in = g_vx_in; a.iters = iters;
+    return launch_step(k_karman_bwd, cfg, stream, a);
+}

@@ -1,0 +1,406 @@
+// Unrolled solver-in-the-loop training step, inference roll-out, loss and TF-style Adam.
+//
+// Replaces the msteps graph of /root/reference/karman-2d/karman_train.py:397-457 (forward
+// unroll :399-426, loss :428-436, optimizer :449-457) and the roll-out loop of
+// karman_apply.py:138-158.  The per-step order (step -> CNN correction -> add -> loss) and
+// the reverse sweep follow SURVEY.md appendix C.9.
+#include "common.hpp"
+
+thread_local char g_sol_err[512] = "";
+
+int sol_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_sol_err, sizeof(g_sol_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char* sol_last_error(void) { return g_sol_err; }
+extern "C" int sol_version(void) { return 100; }
+
+namespace {
+
+constexpr int NL = 12;   // conv layers of model_mars_moon
+inline int layer_cin(int l) { return l == 0 ? 3 : 32; }
+inline int layer_cout(int l) { return l == NL - 1 ? 2 : 32; }
+inline int64_t layer_koff(int l) {
+    int64_t off = 0;
+    for (int k = 0; k < l; ++k) off += 25 * layer_cin(k) * layer_cout(k) + layer_cout(k);
+    return off;
+}
+
+// ---- velocity += CNN correction (to_staggered pad, karman_train.py:88-90,413-426) + l2 loss ----
+__global__ void k_correct_loss(float* __restrict__ vy, float* __restrict__ vx, const float* __restrict__ O,
+                               const float* __restrict__ gt_vy, const float* __restrict__ gt_vx,
+                               float s0, float s1, float* __restrict__ loss, int B, int Y, int X) {
+    __shared__ float red[64];
+    const int N = Y * X, nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
+    const int total = B * (nVy + nVx);
+    float l = 0.f;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        if (e < B * nVy) {
+            const int b = e / nVy, k = e - b * nVy;
+            float v = vy[e];
+            if (k < N) v += s0 * O[((size_t)b * N + k) * 2];
+            vy[e] = v;
+            if (gt_vy) { const float d = (gt_vy[e] - v) / s0; l += 0.5f * d * d; }
+        } else {
+            const int e2 = e - B * nVy;
+            const int b = e2 / nVx, k = e2 - b * nVx;
+            const int j = k / XP, i = k - j * XP;
+            float v = vx[e2];
+            if (i < X) v += s1 * O[((size_t)b * N + j * X + i) * 2 + 1];
+            vx[e2] = v;
+            if (gt_vx) { const float d = (gt_vx[e2] - v) / s1; l += 0.5f * d * d; }
+        }
+    }
+    if (loss) {
+        const float s = block_sum(l, red, 0);
+        if (threadIdx.x == 0) atomicAdd(loss, s);
+    }
+}
+
+// ---- backward seed: g_prd = g_next + (prd - gt)/(std^2 msteps);  dO = std * g_prd on cells ----
+__global__ void k_seed(float* __restrict__ gvy, float* __restrict__ gvx, const float* __restrict__ vy,
+                       const float* __restrict__ vx, const float* __restrict__ gt_vy, const float* __restrict__ gt_vx,
+                       float s0, float s1, float inv_m, float* __restrict__ dO4, float* __restrict__ dO2,
+                       int first, int B, int Y, int X) {
+    const int N = Y * X, nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
+    const int total = B * (nVy + nVx);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        if (e < B * nVy) {
+            const int b = e / nVy, k = e - b * nVy;
+            float g = (vy[e] - gt_vy[e]) * inv_m / (s0 * s0);
+            if (!first) g += gvy[e];
+            gvy[e] = g;
+            if (k < N) {
+                const size_t c = (size_t)b * N + k;
+                dO4[c * 4] = s0 * g;
+                dO2[c * 2] = s0 * g;
+            }
+        } else {
+            const int e2 = e - B * nVy;
+            const int b = e2 / nVx, k = e2 - b * nVx;
+            const int j = k / XP, i = k - j * XP;
+            float g = (vx[e2] - gt_vx[e2]) * inv_m / (s1 * s1);
+            if (!first) g += gvx[e2];
+            gvx[e2] = g;
+            if (i < X) {
+                const size_t c = (size_t)b * N + j * X + i;
+                dO4[c * 4 + 1] = s1 * g;
+                dO2[c * 2 + 1] = s1 * g;
+            }
+        }
+    }
+}
+
+__global__ void k_pad_bias(const float* __restrict__ params, float* __restrict__ biasp, int64_t boff, int cout) {
+    const int t = threadIdx.x;
+    if (t < 32) biasp[t] = t < cout ? params[boff + t] : 0.f;
+}
+
+// ---- TF1 AdamOptimizer ------------------------------------------------------------------
+__global__ void k_tensor_scale(const float* __restrict__ g, float* __restrict__ scale, int64_t off, int64_t n,
+                               float clip_norm) {
+    __shared__ float red[64];
+    float s = 0.f;
+    for (int64_t e = threadIdx.x; e < n; e += blockDim.x) { const float v = g[off + e]; s += v * v; }
+    s = block_sum(s, red, 0);
+    if (threadIdx.x == 0) {
+        const float nrm = sqrtf(s);
+        *scale = nrm > clip_norm ? clip_norm / nrm : 1.f;   // tf.clip_by_norm
+    }
+}
+
+struct AdamTensors {
+    int n;
+    int64_t off[40];
+};
+
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                       int64_t n, float lr_t, float b1, float b2, float eps, const float* __restrict__ scale, AdamTensors T) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        float gr = g[e];
+        if (scale) {
+            int t = 0;
+            while (t + 1 < T.n && e >= T.off[t + 1]) ++t;
+            gr *= scale[t];
+        }
+        const float mi = b1 * m[e] + (1.f - b1) * gr;
+        const float vi = b2 * v[e] + (1.f - b2) * gr * gr;
+        m[e] = mi;
+        v[e] = vi;
+        p[e] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// ---- workspace carving ------------------------------------------------------------------
+struct Ws {
+    // sizes in floats
+    size_t nVy, nVx, N, cells, st_vy, st_vx, st_d;
+    float *vy, *vx, *d;            // [msteps][B][...] states after step i (index i = state i+1)
+    float *svy, *svx;              // [msteps] saved post-diffusion velocity
+    float *feat;                   // [msteps][cells][4]
+    float *acts;                   // [msteps][11][cells][32]
+    float *O;                      // [cells][2]
+    float *gA, *gB;                // [cells][32]
+    float *dO4, *dO2, *dF;         // [cells][4], [cells][2], [cells][2]
+    float *gvy[2], *gvx[2];
+    float *wf[NL], *wb[NL], *bias[NL];
+    float *part[NL];
+    size_t part_floats[NL];
+    float *adam_scale;
+    size_t total_floats;
+};
+
+size_t carve_ws(const sol_train_cfg* c, float* base, Ws& w, bool training) {
+    const int B = c->karman.B, Y = c->karman.Y, X = c->karman.X;
+    const int ms = training ? c->msteps : 1;
+    w.N = (size_t)Y * X;
+    w.cells = (size_t)B * w.N;
+    w.nVy = (size_t)(Y + 1) * X;
+    w.nVx = (size_t)Y * (X + 1);
+    w.st_vy = B * w.nVy; w.st_vx = B * w.nVx; w.st_d = w.cells;
+    size_t off = 0;
+    auto take = [&](size_t n) { float* p = base ? base + off : nullptr; off += align_up(n, 64); return p; };
+    w.vy = take(ms * w.st_vy); w.vx = take(ms * w.st_vx); w.d = take(ms * w.st_d);
+    w.svy = take(ms * w.st_vy); w.svx = take(ms * w.st_vx);
+    w.feat = take(ms * w.cells * 4);
+    w.acts = take((size_t)ms * 11 * w.cells * 32);
+    w.O = take(w.cells * 2);
+    w.gA = take(w.cells * 32); w.gB = take(w.cells * 32);
+    w.dO4 = take(w.cells * 4); w.dO2 = take(w.cells * 2); w.dF = take(w.cells * 2);
+    for (int k = 0; k < 2; ++k) { w.gvy[k] = take(w.st_vy); w.gvx[k] = take(w.st_vx); }
+    for (int l = 0; l < NL; ++l) {
+        const int cin = layer_cin(l), cout = layer_cout(l);
+        w.wf[l] = take(sol_conv5x5_packed_floats(cin == 3 ? 4 : cin, cout, SOL_CONV_FWD));
+        w.wb[l] = take(sol_conv5x5_packed_floats(cout == 2 ? 4 : cout, cin, SOL_CONV_BWD_DATA));
+        w.bias[l] = take(32);
+        w.part_floats[l] = training ? sol_conv5x5_bwd_weight_ws_floats(B, Y, X, cin == 3 ? 4 : cin, cout) : 0;
+        w.part[l] = take(w.part_floats[l]);
+    }
+    w.adam_scale = take(64);
+    w.total_floats = off;
+    return off * sizeof(float);
+}
+
+int pack_all(const sol_train_cfg* /*c*/, void* stream, const float* params, Ws& w, bool bwd) {
+    for (int l = 0; l < NL; ++l) {
+        const int cin = layer_cin(l), cout = layer_cout(l);
+        const int64_t koff = layer_koff(l), boff = koff + 25 * cin * cout;
+        if (int e = sol_conv5x5_pack(stream, params + koff, cin, cout, SOL_CONV_FWD, w.wf[l])) return e;
+        if (bwd) {
+            // run-conv of backward-data: input channels = forward cout, output channels = forward cin
+            if (int e = sol_conv5x5_pack(stream, params + koff, cout, cin, SOL_CONV_BWD_DATA, w.wb[l])) return e;
+        }
+        hipLaunchKernelGGL(k_pad_bias, dim3(1), dim3(64), 0, (hipStream_t)stream, params, w.bias[l], boff, cout);
+        SOL_LAUNCH_CHECK();
+    }
+    return SOL_OK;
+}
+
+// CNN forward (model_mars_moon, karman_train.py:101-138).  acts: 11 buffers [cells][32].
+int net_forward(const sol_train_cfg* c, void* s, const Ws& w, const float* feat, float* const* act, float* O) {
+    const int B = c->karman.B, Y = c->karman.Y, X = c->karman.X;
+    const float sl = c->lrelu_slope;
+    if (int e = sol_conv5x5(s, feat, w.wf[0], w.bias[0], nullptr, nullptr, act[0], B, Y, X, 4, 32, SOL_EPI_LRELU, sl)) return e;
+    for (int k = 0; k < 5; ++k) {
+        const float* h = act[2 * k];
+        if (int e = sol_conv5x5(s, h, w.wf[1 + 2 * k], w.bias[1 + 2 * k], nullptr, nullptr, act[1 + 2 * k], B, Y, X, 32, 32, SOL_EPI_LRELU, sl)) return e;
+        if (int e = sol_conv5x5(s, act[1 + 2 * k], w.wf[2 + 2 * k], w.bias[2 + 2 * k], h, nullptr, act[2 + 2 * k], B, Y, X, 32, 32, SOL_EPI_LRELU, sl)) return e;
+    }
+    return sol_conv5x5(s, act[10], w.wf[11], w.bias[11], nullptr, nullptr, O, B, Y, X, 32, 2, SOL_EPI_NONE, sl);
+}
+
+int check_train_cfg(const sol_train_cfg* c) {
+    SOL_REQUIRE(c != nullptr, "train cfg is NULL");
+    SOL_REQUIRE(c->msteps >= 1 && c->msteps <= 1024, "msteps out of range (%d)", c->msteps);
+    SOL_REQUIRE(c->std_v0 > 0.f && c->std_v1 > 0.f && c->std_re > 0.f,
+                "std values must be > 0 (the reference divides by them, karman_train.py:416-421; -n 1 gives std(Re)=0)");
+    const int Y = c->karman.Y, X = c->karman.X;
+    SOL_REQUIRE((Y * X) % 64 == 0, "Y*X must be a multiple of 64");
+    return SOL_OK;
+}
+
+}  // namespace
+
+extern "C" int sol_mars_moon_layer(int32_t l, int64_t* kernel_off, int64_t* bias_off, int32_t* cin, int32_t* cout) {
+    SOL_REQUIRE(l >= 0 && l < NL, "layer index out of range (%d)", l);
+    const int64_t k = layer_koff(l);
+    if (kernel_off) *kernel_off = k;
+    if (bias_off) *bias_off = k + 25 * layer_cin(l) * layer_cout(l);
+    if (cin) *cin = layer_cin(l);
+    if (cout) *cout = layer_cout(l);
+    return SOL_OK;
+}
+
+extern "C" size_t sol_train_workspace_bytes(const sol_train_cfg* cfg) {
+    if (!cfg) return 0;
+    Ws w;
+    return carve_ws(cfg, nullptr, w, true);
+}
+
+extern "C" size_t sol_rollout_workspace_bytes(const sol_train_cfg* cfg) {
+    if (!cfg) return 0;
+    Ws w;
+    return carve_ws(cfg, nullptr, w, false);
+}
+
+extern "C" int sol_train_fwd_bwd(const sol_train_cfg* cfg, void* stream, const float* params,
+                                 const float* d0, const float* vy0, const float* vx0, const float* re,
+                                 const float* active, const float* inflow,
+                                 const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
+                                 const float* gt_vy, const float* gt_vx,
+                                 void* workspace, size_t workspace_bytes,
+                                 float* grads, float* loss_steps,
+                                 float* d_final, float* vy_final, float* vx_final,
+                                 int32_t* iters_fwd, int32_t* iters_bwd) {
+    if (int e = check_train_cfg(cfg)) return e;
+    SOL_REQUIRE(params && d0 && vy0 && vx0 && re && active && inflow && velBCy && velBCyMask && gt_vy && gt_vx &&
+                workspace && grads && loss_steps, "sol_train_fwd_bwd: NULL pointer argument");
+    Ws w;
+    const size_t need = carve_ws(cfg, static_cast<float*>(workspace), w, true);
+    if (workspace_bytes < need)
+        return sol_set_error(SOL_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t hs = (hipStream_t)stream;
+    const sol_karman_cfg* kc = &cfg->karman;
+    const int B = kc->B, Y = kc->Y, X = kc->X, ms = cfg->msteps;
+    const float fscale[3] = {1.f / cfg->std_v0, 1.f / cfg->std_v1, 1.f / cfg->std_re};
+    const int egrid = (int)((w.st_vy + w.st_vx + 255) / 256);
+
+    if (int e = pack_all(cfg, stream, params, w, true)) return e;
+    for (int l = 0; l < NL; ++l) SOL_HIP_CHECK(hipMemsetAsync(w.part[l], 0, w.part_floats[l] * sizeof(float), hs));
+    SOL_HIP_CHECK(hipMemsetAsync(loss_steps, 0, ms * sizeof(float), hs));
+    SOL_HIP_CHECK(hipMemsetAsync(w.dO4, 0, w.cells * 4 * sizeof(float), hs));
+
+    // ---------------- forward unroll ----------------
+    for (int i = 0; i < ms; ++i) {
+        const float* din = i == 0 ? d0 : w.d + (size_t)(i - 1) * w.st_d;
+        const float* vyin = i == 0 ? vy0 : w.vy + (size_t)(i - 1) * w.st_vy;
+        const float* vxin = i == 0 ? vx0 : w.vx + (size_t)(i - 1) * w.st_vx;
+        float* dcur = w.d + (size_t)i * w.st_d;
+        float* vycur = w.vy + (size_t)i * w.st_vy;
+        float* vxcur = w.vx + (size_t)i * w.st_vx;
+        float* feat = w.feat + (size_t)i * w.cells * 4;
+        if (int e = sol_karman_step_fwd(kc, stream, din, vyin, vxin, re, active, inflow, velBCy, velBCyMask, bc_batch_stride,
+                                        dcur, vycur, vxcur, w.svy + (size_t)i * w.st_vy, w.svx + (size_t)i * w.st_vx,
+                                        feat, fscale, iters_fwd ? iters_fwd + (size_t)i * B : nullptr)) return e;
+        float* act[11];
+        for (int k = 0; k < 11; ++k) act[k] = w.acts + ((size_t)i * 11 + k) * w.cells * 32;
+        if (int e = net_forward(cfg, stream, w, feat, act, w.O)) return e;
+        hipLaunchKernelGGL(k_correct_loss, dim3(egrid), dim3(256), 0, hs, vycur, vxcur, w.O,
+                           gt_vy + (size_t)i * w.st_vy, gt_vx + (size_t)i * w.st_vx,
+                           cfg->std_v0, cfg->std_v1, loss_steps + i, B, Y, X);
+        SOL_LAUNCH_CHECK();
+    }
+    if (d_final) SOL_HIP_CHECK(hipMemcpyAsync(d_final, w.d + (size_t)(ms - 1) * w.st_d, w.st_d * sizeof(float), hipMemcpyDeviceToDevice, hs));
+    if (vy_final) SOL_HIP_CHECK(hipMemcpyAsync(vy_final, w.vy + (size_t)(ms - 1) * w.st_vy, w.st_vy * sizeof(float), hipMemcpyDeviceToDevice, hs));
+    if (vx_final) SOL_HIP_CHECK(hipMemcpyAsync(vx_final, w.vx + (size_t)(ms - 1) * w.st_vx, w.st_vx * sizeof(float), hipMemcpyDeviceToDevice, hs));
+
+    // ---------------- reverse sweep ----------------
+    const float sl = cfg->lrelu_slope;
+    int cur = 0;
+    for (int i = ms - 1; i >= 0; --i) {
+        float* gvy = w.gvy[cur];
+        float* gvx = w.gvx[cur];
+        const float* vycur = w.vy + (size_t)i * w.st_vy;
+        const float* vxcur = w.vx + (size_t)i * w.st_vx;
+        hipLaunchKernelGGL(k_seed, dim3(egrid), dim3(256), 0, hs, gvy, gvx, vycur, vxcur,
+                           gt_vy + (size_t)i * w.st_vy, gt_vx + (size_t)i * w.st_vx,
+                           cfg->std_v0, cfg->std_v1, 1.f / (float)ms, w.dO4, w.dO2, i == ms - 1 ? 1 : 0, B, Y, X);
+        SOL_LAUNCH_CHECK();
+        const float* feat = w.feat + (size_t)i * w.cells * 4;
+        const float* act[11];
+        for (int k = 0; k < 11; ++k) act[k] = w.acts + ((size_t)i * 11 + k) * w.cells * 32;
+        // output layer (cout 2)
+        if (int e = sol_conv5x5_bwd_weight(stream, act[10], w.dO2, w.part[11], B, Y, X, 32, 2)) return e;
+        if (int e = sol_conv5x5(stream, w.dO4, w.wb[11], nullptr, nullptr, act[10], w.gA, B, Y, X, 4, 32, SOL_EPI_DLRELU, sl)) return e;
+        for (int k = 4; k >= 0; --k) {
+            const float* h = act[2 * k];
+            const float* a = act[1 + 2 * k];
+            if (int e = sol_conv5x5_bwd_weight(stream, a, w.gA, w.part[2 + 2 * k], B, Y, X, 32, 32)) return e;
+            if (int e = sol_conv5x5(stream, w.gA, w.wb[2 + 2 * k], nullptr, nullptr, a, w.gB, B, Y, X, 32, 32, SOL_EPI_DLRELU, sl)) return e;
+            if (int e = sol_conv5x5_bwd_weight(stream, h, w.gB, w.part[1 + 2 * k], B, Y, X, 32, 32)) return e;
+            if (int e = sol_conv5x5(stream, w.gB, w.wb[1 + 2 * k], nullptr, w.gA, h, w.gA, B, Y, X, 32, 32, SOL_EPI_DLRELU, sl)) return e;
+        }
+        if (int e = sol_conv5x5_bwd_weight(stream, feat, w.gA, w.part[0], B, Y, X, 4, 32)) return e;
+        if (i > 0) {
+            if (int e = sol_conv5x5(stream, w.gA, w.wb[0], nullptr, nullptr, nullptr, w.dF, B, Y, X, 32, 2, SOL_EPI_NONE, sl)) return e;
+            if (int e = sol_karman_step_bwd(kc, stream, w.svy + (size_t)i * w.st_vy, w.svx + (size_t)i * w.st_vx, re, active,
+                                            velBCyMask, bc_batch_stride, gvy, gvx, w.dF, fscale,
+                                            w.gvy[cur ^ 1], w.gvx[cur ^ 1],
+                                            iters_bwd ? iters_bwd + (size_t)i * B : nullptr)) return e;
+            cur ^= 1;
+        }
+    }
+    if (iters_bwd) SOL_HIP_CHECK(hipMemsetAsync(iters_bwd, 0, B * sizeof(int32_t), hs));   // step 0 needs no adjoint
+    for (int l = 0; l < NL; ++l) {
+        const int cin = layer_cin(l), cout = layer_cout(l);
+        const int64_t koff = layer_koff(l), boff = koff + 25 * cin * cout;
+        if (int e = sol_conv5x5_bwd_weight_reduce(stream, w.part[l], grads + koff, grads + boff, B, Y, X, cin, cout, 0)) return e;
+    }
+    return SOL_OK;
+}
+
+extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* params,
+                           float* d, float* vy, float* vx, const float* re,
+                           const float* active, const float* inflow,
+                           const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
+                           int32_t nsteps, void* workspace, size_t workspace_bytes, int32_t* iters) {
+    if (int e = check_train_cfg(cfg)) return e;
+    SOL_REQUIRE(params && d && vy && vx && re && active && inflow && velBCy && velBCyMask && workspace,
+                "sol_rollout: NULL pointer argument");
+    SOL_REQUIRE(nsteps >= 0, "nsteps must be >= 0");
+    Ws w;
+    const size_t need = carve_ws(cfg, static_cast<float*>(workspace), w, false);
+    if (workspace_bytes < need)
+        return sol_set_error(SOL_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t hs = (hipStream_t)stream;
+    const sol_karman_cfg* kc = &cfg->karman;
+    const int B = kc->B, Y = kc->Y, X = kc->X;
+    const float fscale[3] = {1.f / cfg->std_v0, 1.f / cfg->std_v1, 1.f / cfg->std_re};
+    const int egrid = (int)((w.st_vy + w.st_vx + 255) / 256);
+    if (int e = pack_all(cfg, stream, params, w, false)) return e;
+    float* act[11];
+    // two ping-pong activation buffers suffice without the backward pass (+1 for the skip input)
+    for (int k = 0; k < 11; ++k) act[k] = w.acts + (size_t)(k % 3) * w.cells * 32;
+    for (int i = 0; i < nsteps; ++i) {
+        // the step reads its inputs fully into LDS before writing outputs -> safe in place
+        if (int e = sol_karman_step_fwd(kc, stream, d, vy, vx, re, active, inflow, velBCy, velBCyMask, bc_batch_stride,
+                                        w.d, w.vy, w.vx, nullptr, nullptr, w.feat, fscale,
+                                        iters ? iters + (size_t)i * B : nullptr)) return e;
+        if (int e = net_forward(cfg, stream, w, w.feat, act, w.O)) return e;
+        hipLaunchKernelGGL(k_correct_loss, dim3(egrid), dim3(256), 0, hs, w.vy, w.vx, w.O,
+                           (const float*)nullptr, (const float*)nullptr, cfg->std_v0, cfg->std_v1, (float*)nullptr, B, Y, X);
+        SOL_LAUNCH_CHECK();
+        SOL_HIP_CHECK(hipMemcpyAsync(d, w.d, w.st_d * sizeof(float), hipMemcpyDeviceToDevice, hs));
+        SOL_HIP_CHECK(hipMemcpyAsync(vy, w.vy, w.st_vy * sizeof(float), hipMemcpyDeviceToDevice, hs));
+        SOL_HIP_CHECK(hipMemcpyAsync(vx, w.vx, w.st_vx * sizeof(float), hipMemcpyDeviceToDevice, hs));
+    }
+    return SOL_OK;
+}
+
+extern "C" int sol_adam_tf_step(void* stream, float* params, const float* grads, float* m, float* v,
+                                int64_t n, int32_t t, float lr, float beta1, float beta2, float eps,
+                                float clip_norm, const int64_t* tensor_offsets, int32_t n_tensors, float* scratch) {
+    SOL_REQUIRE(params && grads && m && v && n > 0 && t >= 1, "sol_adam_tf_step: bad arguments");
+    hipStream_t hs = (hipStream_t)stream;
+    AdamTensors T{};
+    const float* scale = nullptr;
+    if (clip_norm > 0.f) {
+        SOL_REQUIRE(tensor_offsets && scratch && n_tensors >= 1 && n_tensors < 40, "clip_norm needs tensor_offsets/scratch (n_tensors < 40)");
+        T.n = n_tensors;
+        for (int k = 0; k <= n_tensors; ++k) T.off[k] = tensor_offsets[k];
+        for (int k = 0; k < n_tensors; ++k) {
+            hipLaunchKernelGGL(k_tensor_scale, dim3(1), dim3(256), 0, hs, grads, scratch + k, T.off[k], T.off[k + 1] - T.off[k], clip_norm);
+            SOL_LAUNCH_CHECK();
+        }
+        scale = scratch;
+    }
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, hs, params, grads, m, v, n, (float)lr_t, beta1, beta2, eps, scale, T);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}

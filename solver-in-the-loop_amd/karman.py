@@ -1,0 +1,101 @@
+"""Reference-shaped Python surface of the karman-2d hot path.
+
+Mirrors /root/reference/karman-2d/karman_train.py:
+  to_feature (l.77-86), to_staggered (l.88-90), model_mercury / model_mars_moon (l.92-138),
+  lr_schedule (l.146-163), KarmanFlow (l.166-185), velocity BC masks (l.366-373).
+`simulator_lo.step(state, re=, res=, velBCy=, velBCyMask=)` keeps its call shape; under it a
+single fused HIP kernel per direction (csrc/karman_step.hip) does the work.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .fluid import (Box, Sphere, Inflow, Obstacle, Gravity, StaggeredGrid, CenteredGrid, box)
+
+
+def velocity_bc_masks(Y, X, batch_size=None):
+    """karman_train.py:366-373 -- returns (velBCy, velBCyMask) as numpy [B?,Y+1,X,1]."""
+    shape = (Y + 1, X, 1) if batch_size is None else (batch_size, Y + 1, X, 1)
+    vn = np.zeros(shape)
+    vn[..., 0:2, 0:X - 1, 0] = 1.0
+    vn[..., 0:Y + 1, 0:1, 0] = 1.0
+    vn[..., 0:Y + 1, -1:, 0] = 1.0
+    return vn, np.copy(vn)
+
+
+class KarmanFlow:
+    """KarmanFlow(IncompressibleFlow), karman_train.py:166-185."""
+
+    def __init__(self, pressure_solver=None, make_input_divfree=False, make_output_divfree=True,
+                 cg_rtol=1e-6, cg_atol=1e-9, cg_max_iter=2000, grad_pad="replicate", inflow_order="after"):
+        if pressure_solver is not None:
+            raise NotImplementedError("the pressure solve is the fused LDS-resident CG of libsol_hip.so")
+        if make_input_divfree or not make_output_divfree:
+            raise NotImplementedError("only (make_input_divfree=False, make_output_divfree=True) is on the reference path")
+        self.infl = Inflow(box[5:10, 25:75])
+        self.obst = Obstacle(Sphere([50, 50], 10))
+        self._solver = dict(cg_rtol=cg_rtol, cg_atol=cg_atol, cg_max_iter=cg_max_iter,
+                            grad_pad=grad_pad, inflow_order=inflow_order)
+        self._cache = {}
+        self.solve_info = {}
+
+    # -- constant masks of the scene for a given domain ----------------------------------
+    def scene_arrays(self, domain):
+        yc, xc = domain.cell_centers()
+        active = 1.0 - self.obst.geometry.value_at(yc, xc)
+        inflow = self.infl.geometry.value_at(yc, xc) * self.infl.rate
+        return active, inflow
+
+    def _masks(self, domain, velBCy, velBCyMask, device):
+        key = (domain.resolution, domain.box.lower, domain.box.upper, id(velBCy), id(velBCyMask), str(device))
+        if key not in self._cache:
+            active, inflow = self.scene_arrays(domain)
+            Y, X = domain.resolution
+            bcv = np.asarray(velBCy, dtype=np.float64).reshape(-1, Y + 1, X)
+            bcm = np.asarray(velBCyMask, dtype=np.float64).reshape(-1, Y + 1, X)
+            if bcv.shape[0] > 1 and np.all(bcv == bcv[0:1]) and np.all(bcm == bcm[0:1]):
+                bcv, bcm = bcv[0:1], bcm[0:1]
+            self._cache[key] = ops.SceneMasks(active, inflow, bcv, bcm, device)
+        return self._cache[key]
+
+    def step(self, smoke, re, res, velBCy, velBCyMask, dt=1.0, gravity=None):
+        """karman_train.py:173-185 (diffuse + BC) -> IncompressibleFlow.step."""
+        domain = smoke.domain
+        Y, X = domain.resolution
+        B = smoke._batch_size
+        dev = smoke.density.data.device
+        masks = self._masks(domain, velBCy, velBCyMask, dev)
+        cfg = ops.karman_cfg(B, Y, X, domain.dx[1], dt=dt, res=res, **self._solver)
+        re_t = torch.as_tensor(re, dtype=torch.float32, device=dev).reshape(B)
+        d = smoke.density.data.reshape(B, Y, X)
+        vy = smoke.velocity.data[0].data.reshape(B, Y + 1, X)
+        vx = smoke.velocity.data[1].data.reshape(B, Y, X + 1)
+        info = {}
+        d2, vy2, vx2 = ops.karman_step(d, vy, vx, re_t, cfg, masks, info)
+        self.solve_info = info
+        return smoke.copied_with(density=d2.reshape(B, Y, X, 1),
+                                 velocity=StaggeredGrid([vy2.reshape(B, Y + 1, X, 1), vx2.reshape(B, Y, X + 1, 1)],
+                                                        smoke.velocity.box))
+
+
+def to_feature(smokestate, ext_const_channel):
+    """karman_train.py:77-86 -> [B,Y,X,3]."""
+    st = smokestate.velocity.staggered_tensor()[:, :-1, :-1, 0:2]
+    B = smokestate._batch_size
+    re = torch.as_tensor(ext_const_channel, dtype=torch.float32, device=st.device).reshape(B, 1, 1, 1)
+    return torch.cat([st, torch.ones_like(smokestate.density.data) * re], dim=-1)
+
+
+def to_staggered(tensor_cen, box):
+    """karman_train.py:88-90."""
+    return StaggeredGrid(torch.nn.functional.pad(tensor_cen, (0, 0, 0, 1, 0, 1)), box=box)
+
+
+def lr_schedule(epoch, current_lr):
+    """karman_train.py:146-163."""
+    lr = current_lr
+    if epoch == 23: lr *= 0.5
+    elif epoch == 21: lr *= 1e-1
+    elif epoch == 16: lr *= 1e-1
+    elif epoch == 11: lr *= 1e-1
+    return lr

@@ -1,0 +1,216 @@
+"""Differentiable PyTorch-ROCm wrappers over the C ABI (one autograd.Function per op).
+
+These are the composable building blocks behind the reference-shaped Python surface
+(karman.py, burgers.py, model.py).  The fused whole-step entry point lives in trainer.py.
+Every function here calls libsol_hip.so; there is no CPU implementation.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import KarmanCfg, BurgersCfg, check, ptr, stream
+
+EPI_NONE, EPI_LRELU, EPI_DLRELU = 0, 1, 2
+CONV_FWD, CONV_BWD_DATA = 0, 1
+
+
+def karman_cfg(B, Y, X, dx, dt=1.0, res=None, cg_rtol=1e-6, cg_atol=1e-9, cg_max_iter=2000,
+               grad_pad="replicate", inflow_order="after"):
+    return KarmanCfg(B, Y, X, float(dx), float(dt), float(X if res is None else res),
+                     float(cg_rtol), float(cg_atol), int(cg_max_iter),
+                     {"replicate": 0, "dirichlet0": 1}[grad_pad], {"after": 0, "before": 1}[inflow_order])
+
+
+class SceneMasks:
+    """Device-resident constant masks of a scene: active (1 - obstacle), inflow rate, velBCy,
+    velBCyMask (reference: KarmanFlow.__init__ karman_train.py:166-171 and :366-373)."""
+
+    def __init__(self, active, inflow, velBCy, velBCyMask, device="cuda"):
+        self.active = _lib.f32(active, device)
+        self.inflow = _lib.f32(inflow, device)
+        self.velBCy = _lib.f32(velBCy, device)
+        self.velBCyMask = _lib.f32(velBCyMask, device)
+        Y, X = self.active.shape[-2:]
+        n = (Y + 1) * X
+        assert self.velBCy.numel() % n == 0 and self.velBCy.numel() == self.velBCyMask.numel()
+        self.bc_stride = 0 if self.velBCy.numel() == n else n
+
+
+def _scale3(vals):
+    return (C.c_float * 3)(*[float(v) for v in vals])
+
+
+class KarmanStepFn(torch.autograd.Function):
+    """(d, vy, vx) [B,Y,X] / [B,Y+1,X] / [B,Y,X+1] -> one simulator_lo.step(...)."""
+
+    @staticmethod
+    def forward(ctx, d, vy, vx, re, cfg, masks, info):
+        _lib.require_gpu()
+        lib = _lib.load()
+        d, vy, vx, re = (_lib.f32(t) for t in (d, vy, vx, re))
+        B, Y, X = cfg.B, cfg.Y, cfg.X
+        assert vy.shape == (B, Y + 1, X) and vx.shape == (B, Y, X + 1) and d.shape == (B, Y, X) and re.shape == (B,)
+        d_out = torch.empty_like(d)
+        vy_out = torch.empty_like(vy)
+        vx_out = torch.empty_like(vx)
+        svy = torch.empty_like(vy)
+        svx = torch.empty_like(vx)
+        iters = torch.empty(B, dtype=torch.int32, device=vy.device)
+        check(lib.sol_karman_step_fwd(C.byref(cfg), stream(), ptr(d), ptr(vy), ptr(vx), ptr(re),
+                                      ptr(masks.active), ptr(masks.inflow), ptr(masks.velBCy), ptr(masks.velBCyMask),
+                                      masks.bc_stride, ptr(d_out), ptr(vy_out), ptr(vx_out), ptr(svy), ptr(svx),
+                                      None, None, ptr(iters)))
+        ctx.save_for_backward(svy, svx, re)
+        ctx.cfg, ctx.masks, ctx.info = cfg, masks, info
+        if info is not None:
+            info["iterations"] = iters
+        ctx.mark_non_differentiable(d_out)
+        return d_out, vy_out, vx_out
+
+    @staticmethod
+    def backward(ctx, _gd, gvy, gvx):
+        lib = _lib.load()
+        svy, svx, re = ctx.saved_tensors
+        cfg, masks = ctx.cfg, ctx.masks
+        gvy = torch.zeros_like(svy) if gvy is None else gvy.contiguous()
+        gvx = torch.zeros_like(svx) if gvx is None else gvx.contiguous()
+        oy = torch.empty_like(svy)
+        ox = torch.empty_like(svx)
+        iters = torch.empty(cfg.B, dtype=torch.int32, device=svy.device)
+        check(lib.sol_karman_step_bwd(C.byref(cfg), stream(), ptr(svy), ptr(svx), ptr(re), ptr(masks.active),
+                                      ptr(masks.velBCyMask), masks.bc_stride, ptr(gvy), ptr(gvx), None, None,
+                                      ptr(oy), ptr(ox), ptr(iters)))
+        if ctx.info is not None:
+            ctx.info["iterations_bwd"] = iters
+        return None, oy, ox, None, None, None, None
+
+
+def karman_step(d, vy, vx, re, cfg, masks, info=None):
+    return KarmanStepFn.apply(d, vy, vx, re, cfg, masks, info)
+
+
+# --------------------------------------------------------------------------------------
+# conv 5x5
+# --------------------------------------------------------------------------------------
+def _pack(w_hwio, cin_run, cout_run, mode):
+    lib = _lib.load()
+    n = lib.sol_conv5x5_packed_floats(cin_run, cout_run, mode)
+    out = torch.empty(n, dtype=torch.float32, device=w_hwio.device)
+    check(lib.sol_conv5x5_pack(stream(), ptr(w_hwio), cin_run, cout_run, mode, ptr(out)))
+    return out
+
+
+def _pad_channels(x, c):
+    if x.shape[-1] == c:
+        return x.contiguous()
+    return torch.nn.functional.pad(x, (0, c - x.shape[-1])).contiguous()
+
+
+def conv5x5_raw(x, packed, bias, residual, act_ref, cout, epilogue, slope):
+    lib = _lib.load()
+    B, H, W, cin = x.shape
+    y = torch.empty(B, H, W, cout, dtype=torch.float32, device=x.device)
+    check(lib.sol_conv5x5(stream(), ptr(x), ptr(packed), ptr(bias), ptr(residual), ptr(act_ref), ptr(y),
+                          B, H, W, cin, cout, epilogue, float(slope)))
+    return y
+
+
+class Conv5x5Fn(torch.autograd.Function):
+    """y = act(conv5x5_same(x, w) + b (+ residual)), NHWC, w in Keras HWIO layout."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, residual, lrelu, slope):
+        _lib.require_gpu()
+        cin, cout = w.shape[2], w.shape[3]
+        x = _lib.f32(x); w = _lib.f32(w); b = _lib.f32(b)
+        cin_k = 4 if cin <= 4 else 32
+        assert cin in (1, 2, 3, 4, 32), "conv5x5 supports <=4 or 32 input channels"
+        xk = _pad_channels(x, cin_k)
+        packed = _pack(w, cin, cout, CONV_FWD)
+        res = None if residual is None else _lib.f32(residual)
+        y = conv5x5_raw(xk, packed, b, res, None, cout, EPI_LRELU if lrelu else EPI_NONE, slope)
+        ctx.save_for_backward(xk, w, y)
+        ctx.meta = (cin, cout, cin_k, lrelu, slope, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        xk, w, y = ctx.saved_tensors
+        cin, cout, cin_k, lrelu, slope, has_res = ctx.meta
+        B, H, W, _ = xk.shape
+        dz = gy.contiguous()
+        if lrelu:
+            dz = dz * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, slope))
+        # weight / bias gradient
+        cout_k = cout if cout in (2, 32) else None
+        assert cout_k is not None, "conv5x5 backward-weight supports 2 or 32 output channels"
+        nws = lib.sol_conv5x5_bwd_weight_ws_floats(B, H, W, cin_k, cout)
+        part = torch.zeros(nws, dtype=torch.float32, device=xk.device)
+        check(lib.sol_conv5x5_bwd_weight(stream(), ptr(xk), ptr(dz), ptr(part), B, H, W, cin_k, cout))
+        dw = torch.empty_like(w)
+        db = torch.empty(cout, dtype=torch.float32, device=xk.device)
+        check(lib.sol_conv5x5_bwd_weight_reduce(stream(), ptr(part), ptr(dw), ptr(db), B, H, W, cin, cout, 0))
+        # data gradient: run-conv with cin_run = cout (padded to 4/32), cout_run = cin
+        dzk = _pad_channels(dz, 4 if cout <= 4 else 32)
+        packed = _pack(w, cout, cin, CONV_BWD_DATA)
+        dx = conv5x5_raw(dzk, packed, None, None, None, cin, EPI_NONE, slope)
+        return dx, dw, db, (dz if has_res else None), None, None
+
+
+def conv5x5(x, w, b, residual=None, lrelu=False, slope=0.3):
+    return Conv5x5Fn.apply(x, w, b, residual, lrelu, slope)
+
+
+# --------------------------------------------------------------------------------------
+# Burgers step
+# --------------------------------------------------------------------------------------
+def circulant_diffusion_matrix(n, amount):
+    """Real symmetric circulant matrix of PhiFlow's periodic diffusion along one axis of
+    length n: ifft(fft(.) * exp(-(2 pi k)^2 amount)), k = fftfreq(n)  (dx = 1)."""
+    k = np.fft.fftfreq(n)
+    col = np.fft.ifft(np.exp(-(2 * np.pi) ** 2 * k ** 2 * amount)).real
+    idx = (np.arange(n)[:, None] - np.arange(n)[None, :]) % n
+    return col[idx]
+
+
+class BurgersStepFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vy, vx, fy, fx, cfg, circ):
+        _lib.require_gpu()
+        lib = _lib.load()
+        vy = _lib.f32(vy); vx = _lib.f32(vx)
+        fy = None if fy is None else _lib.f32(fy)
+        fx = None if fx is None else _lib.f32(fx)
+        oy = torch.empty_like(vy)
+        ox = torch.empty_like(vx)
+        check(lib.sol_burgers_step_fwd(C.byref(cfg), stream(), ptr(vy), ptr(vx), ptr(fy), ptr(fx),
+                                       ptr(circ[0]), ptr(circ[1]), ptr(circ[2]), ptr(circ[3]), ptr(oy), ptr(ox)))
+        ctx.save_for_backward(vy, vx)
+        ctx.cfg, ctx.circ, ctx.has_f = cfg, circ, fy is not None
+        return oy, ox
+
+    @staticmethod
+    def backward(ctx, gy, gx):
+        lib = _lib.load()
+        vy, vx = ctx.saved_tensors
+        cfg, circ = ctx.cfg, ctx.circ
+        gy = gy.contiguous(); gx = gx.contiguous()
+        oy = torch.empty_like(vy)
+        ox = torch.empty_like(vx)
+        check(lib.sol_burgers_step_bwd(C.byref(cfg), stream(), ptr(vy), ptr(vx),
+                                       ptr(circ[0]), ptr(circ[1]), ptr(circ[2]), ptr(circ[3]),
+                                       ptr(gy), ptr(gx), ptr(oy), ptr(ox)))
+        dt = cfg.dt
+        return oy, ox, (gy * dt if ctx.has_f else None), (gx * dt if ctx.has_f else None), None, None
+
+
+def burgers_circ(Y, X, amount, device="cuda"):
+    mk = lambda n: torch.as_tensor(circulant_diffusion_matrix(n, amount), dtype=torch.float32, device=device).contiguous()
+    return (mk(Y + 1), mk(X), mk(Y), mk(X + 1))
+
+
+def burgers_step(vy, vx, fy, fx, cfg, circ):
+    return BurgersStepFn.apply(vy, vx, fy, fx, cfg, circ)

@@ -1,0 +1,132 @@
+"""Fused solver-in-the-loop training step (one C call = the reference's one sess.run).
+
+Replaces the graph built at /root/reference/karman-2d/karman_train.py:397-457 and executed
+at :502: msteps x [simulator_lo.step -> CNN correction -> add], the l2 loss against the
+ground-truth frames, the reverse sweep and TF-Adam.  Python only owns the device buffers;
+the whole unroll is driven from C++ (sol_train_fwd_bwd) so that no per-op Python overhead
+sits between the ~1000 kernel launches of a SOL-32 step.
+
+Data parallel (new capability): one process per GPU, each rank runs the
+full unroll on its shard of simulations, then ONE all-reduce(SUM) of the flat 260,354-float
+gradient over RCCL (the loss is a batch SUM, karman_train.py:430, so summed shard gradients
+equal the large-batch gradient) and an identical Adam update on every rank.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import TrainCfg, check, ptr, stream
+from .dist import DPStep
+
+
+class SolTrainer:
+    def __init__(self, net, masks, B, Y, X, msteps, dx, std_v, std_re, dt=1.0, res=None,
+                 clip_grad=False, beta1=0.9, beta2=0.999, eps=1e-8, group=None,
+                 cg_rtol=1e-6, cg_atol=1e-9, cg_max_iter=2000, grad_pad="replicate", inflow_order="after"):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        assert net.name == "mars_moon", "the fused trainer implements model_mars_moon (the reference default)"
+        self.net, self.masks = net, masks
+        self.B, self.Y, self.X, self.msteps = B, Y, X, msteps
+        kc = ops.karman_cfg(B, Y, X, dx, dt=dt, res=res, cg_rtol=cg_rtol, cg_atol=cg_atol,
+                            cg_max_iter=cg_max_iter, grad_pad=grad_pad, inflow_order=inflow_order)
+        self.cfg = TrainCfg(kc, msteps, float(std_v[0]), float(std_v[1]), float(std_re), float(net.slope))
+        dev = net.params.device
+        self.device = dev
+        nbytes = self.lib.sol_train_workspace_bytes(C.byref(self.cfg))
+        self.workspace = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+        self.workspace_bytes = nbytes
+        n = net.n_params
+        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.loss_steps = torch.zeros(msteps, dtype=torch.float32, device=dev)
+        self.iters_fwd = torch.zeros(msteps * B, dtype=torch.int32, device=dev)
+        self.iters_bwd = torch.zeros(msteps * B, dtype=torch.int32, device=dev)
+        self.scratch = torch.zeros(64, dtype=torch.float32, device=dev)
+        self.t = 0
+        self.clip_norm = 1e-3 if clip_grad else 0.0      # karman_train.py:453
+        self.beta1, self.beta2, self.eps = beta1, beta2, eps
+        self._offsets = (C.c_int64 * len(net.offsets))(*[int(o) for o in net.offsets])
+        self.final = None
+        self._dp = DPStep(self._fwd_bwd_flat, self._apply_flat, group=group)
+
+    # ---- the two halves of a step -------------------------------------------------------
+    def fwd_bwd(self, d0, vy0, vx0, re, gt_vy, gt_vx, want_final=False):
+        """Inputs: d0 [B,Y,X], vy0 [B,Y+1,X], vx0 [B,Y,X+1], re [B], gt_vy [msteps,B,Y+1,X],
+        gt_vx [msteps,B,Y,X+1] (fp32 CUDA, contiguous).  Fills self.grads / self.loss_steps and
+        returns the scalar loss tensor (sum of per-step l2 losses / msteps, karman_train.py:436)."""
+        B, Y, X, ms = self.B, self.Y, self.X, self.msteps
+        assert vy0.shape == (B, Y + 1, X) and vx0.shape == (B, Y, X + 1) and d0.shape == (B, Y, X)
+        assert gt_vy.shape == (ms, B, Y + 1, X) and gt_vx.shape == (ms, B, Y, X + 1) and re.shape == (B,)
+        fin = [None, None, None]
+        if want_final:
+            fin = [torch.empty_like(d0), torch.empty_like(vy0), torch.empty_like(vx0)]
+        mk = self.masks
+        check(self.lib.sol_train_fwd_bwd(
+            C.byref(self.cfg), stream(), ptr(self.net.params.detach()),
+            ptr(d0), ptr(vy0), ptr(vx0), ptr(re), ptr(mk.active), ptr(mk.inflow),
+            ptr(mk.velBCy), ptr(mk.velBCyMask), mk.bc_stride, ptr(gt_vy), ptr(gt_vx),
+            ptr(self.workspace), self.workspace_bytes, ptr(self.grads), ptr(self.loss_steps),
+            ptr(fin[0]), ptr(fin[1]), ptr(fin[2]), ptr(self.iters_fwd), ptr(self.iters_bwd)))
+        self.final = fin if want_final else None
+        return self.loss_steps.sum() / ms
+
+    def apply_gradients(self, lr):
+        """tf.compat.v1.train.AdamOptimizer(lr) update (+ optional per-tensor clip_by_norm)."""
+        self.t += 1
+        n = self.net.n_params
+        check(self.lib.sol_adam_tf_step(stream(), ptr(self.net.params.detach()), ptr(self.grads), ptr(self.m), ptr(self.v),
+                                        n, self.t, float(lr), self.beta1, self.beta2, self.eps, float(self.clip_norm),
+                                        self._offsets, len(self.net.shapes), ptr(self.scratch)))
+
+    # ---- data-parallel composition --------------------------------------------------------
+    def _fwd_bwd_flat(self, *batch):
+        loss = self.fwd_bwd(*batch)
+        return loss, self.grads
+
+    def _apply_flat(self, grads, lr):
+        assert grads is self.grads
+        self.apply_gradients(lr)
+
+    def train_step(self, d0, vy0, vx0, re, gt_vy, gt_vx, lr):
+        """One training step on this rank's shard; returns the GLOBAL loss tensor."""
+        return self._dp(d0, vy0, vx0, re, gt_vy, gt_vx, lr=lr)
+
+    # ---- algorithmic traffic of the solver part ---------------------
+    def solver_algorithmic_bytes(self):
+        """4*(10*Nf + 9*N + 11*N*k) per forward sample-step and 4*(2*(10*Nf+9*N) + 11*N*k_bwd)
+        per backward sample-step with the MEASURED CG iteration counts."""
+        N = self.Y * self.X
+        Nf = (self.Y + 1) * self.X + self.Y * (self.X + 1)
+        kf = self.iters_fwd.double().sum().item()
+        kb = self.iters_bwd.double().sum().item()
+        nss = self.msteps * self.B
+        fwd = 4.0 * ((10 * Nf + 9 * N) * nss + 11.0 * N * kf)
+        bwd = 4.0 * (2 * (10 * Nf + 9 * N) * (nss - self.B) + 11.0 * N * kb)
+        return fwd, bwd, kf / nss, kb / max(1, nss - self.B)
+
+
+class SolRollout:
+    """No-grad roll-out of solver step + CNN correction (karman_apply.py:138-158)."""
+
+    def __init__(self, net, masks, B, Y, X, dx, std_v, std_re, dt=1.0, res=None, **solver):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.net, self.masks, self.B = net, masks, B
+        kc = ops.karman_cfg(B, Y, X, dx, dt=dt, res=res, **solver)
+        self.cfg = TrainCfg(kc, 1, float(std_v[0]), float(std_v[1]), float(std_re), float(net.slope))
+        nbytes = self.lib.sol_rollout_workspace_bytes(C.byref(self.cfg))
+        self.workspace = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=net.params.device)
+        self.workspace_bytes = nbytes
+
+    def run(self, d, vy, vx, re, nsteps):
+        """Advances (d, vy, vx) in place by nsteps; returns CG iterations [nsteps,B]."""
+        iters = torch.zeros(nsteps * self.B, dtype=torch.int32, device=d.device)
+        mk = self.masks
+        check(self.lib.sol_rollout(C.byref(self.cfg), stream(), ptr(self.net.params.detach()), ptr(d), ptr(vy), ptr(vx),
+                                   ptr(re), ptr(mk.active), ptr(mk.inflow), ptr(mk.velBCy), ptr(mk.velBCyMask),
+                                   mk.bc_stride, nsteps, ptr(self.workspace), self.workspace_bytes, ptr(iters)))
+        return iters.reshape(nsteps, self.B)
