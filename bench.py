@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""bench.py -- SOL-32 karman-2d 128x64 training-step throughput on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL).  Prints ONE JSON line on
+  rank 0.  A "step" = one full training step (msteps=32 unrolled solver+CNN forward, loss,
+  reverse sweep, gradient all-reduce, TF-Adam) on a synthetic batch of 6 simulations per GPU
+  (BASELINE.json configs[2]); value = sim-steps/s of the whole job = N*B*msteps*K / time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--msteps", type=int, default=32)
+    p.add_argument("--res", type=int, default=64, help="cells in x (Y = 2*res)")
+    p.add_argument("--batch", type=int, default=6, help="simulations per GPU")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-msteps", type=int, default=2, help="msteps of the bounded CPU-baseline sample")
+    return p.parse_args()
+
+
+def cpu_baseline(args, Y, X, B):
+    """Oracle (CPU restatement of the PhiFlow-1.5.1 algorithm, NOT TF-PhiFlow) timed on the host
+    cores on a bounded sample: one fp32 training step (fwd + autograd bwd) of SOL-<cpu_msteps>."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sol_oracle as o
+    cores = min(os.cpu_count() or 1, 16)   # small 128x64 convs do not scale past ~16 threads
+    torch.set_num_threads(cores)
+    ms = args.cpu_msteps
+    dt = torch.float32
+    g = o.geometry(Y, X)
+    d, vy, vx = o.synthetic_state(B, Y, X, 1234, dtype=dt)
+    re = torch.tensor([o.RE_TRAIN[i % 6] for i in range(B)], dtype=dt)
+    gts = [o.synthetic_state(B, Y, X, 4321 + i, dtype=dt, project_it=False) for i in range(ms)]
+    params = [p.requires_grad_(True) for p in o.init_params(0, dtype=dt)]
+
+    def one_step(m):
+        loss = o.unrolled_loss(params, d, vy, vx, re, [s[1] for s in gts[:m]], [s[2] for s in gts[:m]], g, (0.2, 0.2), o.STD_RE)
+        loss.backward()
+
+    one_step(1)                       # warm-up: LU factorisation, oneDNN primitive caches
+    reps, t0 = 0, time.time()
+    while True:
+        one_step(ms)
+        reps += 1
+        sec = time.time() - t0
+        if sec > 10.0 or reps >= 20:
+            break
+    return {"value": reps * B * ms / sec, "unit": "sim-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d fp32 training steps of SOL-%d (fwd + autograd bwd, B=%d, %dx%d) = %d sim-steps in %.1f s on %d "
+                      "threads; torch-CPU restatement of the PhiFlow-1.5.1 algorithm (oracle/sol_oracle.py), not TF-PhiFlow"
+                      % (reps, ms, B, Y, X, reps * B * ms, sec, cores)}
+
+
+def main():
+    args = parse()
+    import sol_amd
+    from sol_amd import ops, synthetic
+    rank, world, local = sol_amd.dist.init_from_env()
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    sol_amd._lib.require_gpu()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    X = args.res
+    Y = 2 * X
+    B, ms = args.batch, args.msteps
+    dom = sol_amd.Domain([Y, X], box=sol_amd.box[0:200, 0:100])
+    flow = sol_amd.KarmanFlow()
+    active, inflow = flow.scene_arrays(dom)
+    bcv, bcm = sol_amd.velocity_bc_masks(Y, X)
+    masks = ops.SceneMasks(active, inflow, bcv.reshape(Y + 1, X), bcm.reshape(Y + 1, X), dev)
+    net = sol_amd.model_mars_moon(cin=3, cout=2, seed=0, device=dev)
+    std_v = (0.2, 0.2)
+    tr = sol_amd.SolTrainer(net, masks, B, Y, X, ms, dom.dx[1], std_v, synthetic.STD_RE)
+
+    f = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+    d0, vy0, vx0 = (f(t) for t in synthetic.state(B, Y, X, 1234 + rank))
+    re = f(synthetic.reynolds(B))
+    # spin-up: one solver step makes the random start state divergence free / consistent
+    cfgk = ops.karman_cfg(B, Y, X, dom.dx[1])
+    d0, vy0, vx0 = (t.detach().contiguous() for t in ops.karman_step(d0, vy0, vx0, re, cfgk, masks))
+    # ground truth = plain solver roll-out of a slightly perturbed start state: the loss and its
+    # gradients are non-zero but the training dynamics stay physical (random frames as targets
+    # make Adam drive the corrector -- and with it the 32-step unroll -- to blow up)
+    _, py, px = synthetic.state(B, Y, X, 4321 + rank)
+    gd, gy, gx = d0, vy0 + 0.05 * f(py - 1.0), vx0 + 0.05 * f(px)
+    gts_y, gts_x = [], []
+    for _ in range(ms):
+        gd, gy, gx = (t.detach() for t in ops.karman_step(gd, gy, gx, re, cfgk, masks))
+        gts_y.append(gy)
+        gts_x.append(gx)
+    gt_vy, gt_vx = torch.stack(gts_y).contiguous(), torch.stack(gts_x).contiguous()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    lr = 1e-4
+    for _ in range(args.warmup):
+        loss = tr.train_step(d0, vy0, vx0, re, gt_vy, gt_vx, lr)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.train_step(d0, vy0, vx0, re, gt_vy, gt_vx, lr)
+    barrier()
+    sec = time.perf_counter() - t0
+    tsec = torch.tensor([sec], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tsec, op=torch.distributed.ReduceOp.MAX)
+    sec = float(tsec.item())
+    ms_per_step = sec / args.steps * 1e3
+    value = world * B * ms * args.steps / sec
+
+    # ---- per-kernel roofline numbers (rank 0): HIP events on the launch stream --------------
+    out = None
+    if rank == 0:
+        N = Y * X
+        Nf = (Y + 1) * X + Y * (X + 1)
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+
+        def time_call(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            a, b = ev(), ev()
+            a.record()
+            for _ in range(reps):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / reps * 1e-3
+
+        # (1) fused solver step (advect + pressure), forward: algorithmic bytes with measured k
+        info = {}
+        step_fn = lambda: ops.karman_step(d0, vy0, vx0, re, cfgk, masks, info)
+        t_step = time_call(step_fn, 20)
+        k_f = float(info["iterations"].double().mean().item())
+        bytes_step = 4.0 * (10 * Nf + 9 * N + 11.0 * N * k_f) * B
+        # (2) mid-layer conv (32->32) forward: the FLOP-dominant kernel
+        x = torch.randn(B, Y, X, 32, device=dev)
+        w = torch.randn(5, 5, 32, 32, device=dev) * 0.05
+        packed = ops._pack(w, 32, 32, ops.CONV_FWD)
+        bias = torch.zeros(32, device=dev)
+        conv_fn = lambda: ops.conv5x5_raw(x, packed, bias, None, None, 32, ops.EPI_LRELU, 0.3)
+        t_conv = time_call(conv_fn, 50)
+        flop_conv = 2.0 * 25 * 32 * 32 * B * N
+        fwd_b, bwd_b, kf_tr, kb_tr = tr.solver_algorithmic_bytes()
+        conv_flops_step = 3.0 * 520000.0 * N * B * ms
+        roof_solver = {"kernel": "k_karman_fwd", "bound": "hbm", "achieved": bytes_step / t_step / 1e9, "peak": 8000.0,
+                       "unit": "GB/s", "frac": bytes_step / t_step / 8e12, "traffic": None,
+                       "launch_us": t_step * 1e6, "cg_iters": k_f, "algorithmic_bytes_per_launch": bytes_step}
+        roof_conv = {"kernel": "k_conv5x5<32,2>", "bound": "mfma", "achieved": flop_conv / t_conv / 1e12, "peak": 157.3,
+                     "unit": "TFLOP/s", "frac": flop_conv / t_conv / 157.3e12, "traffic": None,
+                     "launch_us": t_conv * 1e6, "flop_per_launch": flop_conv}
+        # dominant kernel by time inside one training step: conv fwd+bwd (36 launches/sim-step of ~t_conv)
+        t_convs = 36 * ms * t_conv
+        t_solver = 2 * ms * t_step
+        dominant = roof_conv if t_convs >= t_solver else roof_solver
+        out = {
+            "metric": "sim-steps/s, SOL-32 training (karman-2d 128x64, fwd+bwd+Adam)",
+            "value": value, "unit": "sim-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "karman-2d %dx%d SOL-%d, batch %d Re values per GPU (BASELINE configs[2])" % (Y, X, ms, B),
+                       "global_batch": world * B, "msteps": ms, "parallelism": "dp%d" % world},
+            "loss": float(loss.item()),
+            "roofline": dominant,
+            "roofline_solver_step": roof_solver,
+            "roofline_conv": roof_conv,
+            "train_step_breakdown": {"est_conv_ms": t_convs * 1e3, "est_solver_ms": t_solver * 1e3,
+                                     "solver_alg_bytes_fwd": fwd_b, "solver_alg_bytes_bwd": bwd_b,
+                                     "cg_iters_fwd_mean": kf_tr, "cg_iters_bwd_mean": kb_tr,
+                                     "conv_flop_per_train_step": conv_flops_step,
+                                     "conv_mfma_frac_of_step": conv_flops_step / (ms_per_step * 1e-3) / 157.3e12},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, Y, X, B)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

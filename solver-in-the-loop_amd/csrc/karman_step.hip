@@ -12,11 +12,14 @@
 // through LDS (2 floats per thread per iteration).  The dot products are wave64 shuffles
 // plus one LDS slot per wave.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int CPT = 8;       // cells per thread (strip height)
-constexpr int MAXT = 9;      // max face targets per thread: (Y+1)*X / (Y*X/8) <= 9 for Y >= 8
+// CPT = cells per thread (strip height) is a template parameter (8 or 16): fewer, fatter
+// threads amortise the per-wave reduction/halo overhead of a CG iteration (the loop is
+// instruction-issue bound), more threads help the tiny grids.
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct StepArgs {
     int B, Y, X;
@@ -42,13 +45,13 @@ struct Lds {
     unsigned char* act;
 };
 
-__host__ __device__ inline size_t lds_floats(int Y, int X) {
+__host__ __device__ inline size_t lds_floats(int Y, int X, int cpt) {
     const int nVy = (Y + 1) * X, nVx = Y * (X + 1);
-    return 2 * (size_t)(al4(nVy) + al4(nVx)) + 4 * (size_t)(Y / CPT) * X + 64;
+    return 2 * (size_t)(al4(nVy) + al4(nVx)) + 4 * (size_t)(Y / cpt + 2) * X + 64;
 }
-__host__ inline size_t lds_bytes(int Y, int X) { return lds_floats(Y, X) * 4 + (size_t)al4(Y * X); }
+__host__ inline size_t lds_bytes(int Y, int X, int cpt) { return lds_floats(Y, X, cpt) * 4 + (size_t)al4(Y * X); }
 
-__device__ inline Lds carve(float* smem, int Y, int X) {
+__device__ inline Lds carve(float* smem, int Y, int X, int cpt) {
     const int nVy = (Y + 1) * X, nVx = Y * (X + 1);
     Lds l;
     l.Avy = smem;
@@ -56,7 +59,7 @@ __device__ inline Lds carve(float* smem, int Y, int X) {
     l.Bvy = l.Avx + al4(nVx);
     l.Bvx = l.Bvy + al4(nVy);
     l.E = l.Bvx + al4(nVx);
-    l.red = l.E + 4 * (Y / CPT) * X;
+    l.red = l.E + 4 * (Y / cpt + 2) * X;
     l.act = reinterpret_cast<unsigned char*>(l.red + 64);
     return l;
 }
@@ -106,6 +109,7 @@ struct Own {
     int strip, i, j0, nstrips;
     bool owner;
 };
+template <int CPT>
 __device__ __forceinline__ Own ownership(int Y, int X) {
     Own o;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -122,74 +126,136 @@ __device__ __forceinline__ Own ownership(int Y, int X) {
 // >= 1), M[c,n] = -active[c]*active[n]; p = 0 outside the OPEN domain.  Matrix-free CG
 // from x0 = 0; per-sample stop |r|^2 <= max(rtol2*|b|^2, atol2).  rhs comes in r[], the
 // solution leaves in x[].  Returns the iteration count (workgroup uniform).
-__device__ __forceinline__ int cg_solve(const Own& o, int X, const float (&dg)[CPT], const float (&ac)[CPT],
-                                        float (&r)[CPT], float (&x)[CPT], float* E, float* red,
+//
+// Classic (Hestenes-Stiefel) CG arithmetic with TWO workgroup barriers per iteration: the
+// strip-end rows of the next search direction are exchanged as (r, p_old) pairs BEFORE the
+// |r|^2 reduction barrier, and every thread forms p_halo = r_halo + beta*p_old_halo itself
+// once beta is known.  The loop is VALU-issue bound (rocprof: SQ_ACTIVE_INST_ANY ~ 100% of
+// one SIMD's issue slots), so it is written for instruction count: x-neighbours are folded
+// DPP operands (v_add_f32_dpp wave_shr/shl), the vector updates are packed (v_pk_fma_f32),
+// the dot products reduce with DPP row ops + row_bcast + ONE v_readlane, divisions are
+// v_rcp_f32, the obstacle mask is applied only by waves that own obstacle cells.
+template <int CTRL, int ROWMASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, true));
+}
+__device__ __forceinline__ float row_allsum(float v) {
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<0x140>(v);   // row_mirror  -> every lane holds its row-of-16 sum
+    return v;
+}
+// all-reduce over the workgroup; `slot` (16 floats, entries >= #waves stay zero) must not be
+// rewritten before every thread has passed the NEXT barrier.  Bit-identical in every lane of
+// every wave (same association everywhere), so branches on the result are uniform.
+__device__ __forceinline__ float cg_block_sum(float v, float* slot) {
+    v = row_allsum(v);
+    v += dpp_mov<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3 += rows 0,2
+    v += dpp_mov<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3 += row 1   => lane 63 = wave total
+    const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    slot[threadIdx.x >> 6] = s;    // every lane stores the same value to the same address
+    __syncthreads();
+    return row_allsum(slot[threadIdx.x & 15]);
+}
+
+template <int CPT, bool FULLROW>   // FULLROW: X == 64, one wave per strip row -> DPP bound_ctrl supplies the zero halo
+__device__ __forceinline__ int cg_solve(const Own& o, int X, const float (&dgf)[CPT], const float (&acf)[CPT],
+                                        float (&rf)[CPT], float (&xf)[CPT], float* E, float* red,
                                         float rtol2, float atol2, int max_iter) {
-    float p[CPT], Mp[CPT];
-    float part = 0.f;
+    constexpr int H = CPT / 2;
+    f2 dg[H], ac[H], r[H], x[H], p[H], Mp[H];
+    bool hasobst = false;
+    f2 part2 = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-        x[k] = 0.f;
-        p[k] = r[k];
-        part += r[k] * r[k];
+    for (int q = 0; q < H; ++q) {
+        dg[q] = (f2){dgf[2 * q], dgf[2 * q + 1]};
+        ac[q] = (f2){acf[2 * q], acf[2 * q + 1]};
+        r[q] = (f2){rf[2 * q], rf[2 * q + 1]};
+        x[q] = (f2){0.f, 0.f};
+        p[q] = r[q];
+        part2 += r[q] * r[q];
+        hasobst |= (acf[2 * q] == 0.f) | (acf[2 * q + 1] == 0.f);
     }
-    int slot = 0;
-    float rr = block_sum(part, red, slot);
-    slot ^= 1;
+    const bool wobst = __ballot(hasobst && o.owner) != 0ull;   // wave uniform
+    const int EW = (o.nstrips + 2) * X;
+    // E: [4][nstrips+2][X] = r_top, r_bot, p_top, p_bot of every strip; rows 0 and nstrips+1 stay zero
+    float* Ert = E; float* Erb = E + EW; float* Ept = E + 2 * EW; float* Epb = E + 3 * EW;
+    for (int k = threadIdx.x; k < 4 * EW; k += blockDim.x) E[k] = 0.f;
+    if (threadIdx.x < 64) red[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int eo = (o.strip + 1) * X + o.i;
+    if (FULLROW || o.owner) { Ert[eo] = r[0].x; Erb[eo] = r[H - 1].y; }
+    float rr = cg_block_sum(part2.x + part2.y, red + 16);      // barrier: also publishes the halo rows
+    float hprev = 0.f, hnext = 0.f;
+    if (FULLROW || o.owner) { hprev = Erb[eo - X]; hnext = Ert[eo + X]; }   // p == r at start
     const float thresh = fmaxf(rtol2 * rr, atol2);
-    const int EW = o.nstrips * X;
     const bool has_l = o.i > 0, has_r = o.i < X - 1;
     int it = 0;
     while (rr > thresh && it < max_iter) {
-        float* Et = E + (it & 1) * 2 * EW;
-        float* Eb = Et + EW;
-        if (o.owner) {
-            Et[o.strip * X + o.i] = p[0];
-            Eb[o.strip * X + o.i] = p[CPT - 1];
-        }
-        __syncthreads();
-        const float hprev = (o.owner && o.strip > 0) ? Eb[(o.strip - 1) * X + o.i] : 0.f;
-        const float hnext = (o.owner && o.strip < o.nstrips - 1) ? Et[(o.strip + 1) * X + o.i] : 0.f;
-        part = 0.f;
+        float nb[CPT];
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
-            const float pl = __shfl_up(p[k], 1, 64);
-            const float pr = __shfl_down(p[k], 1, 64);
-            const float prev = k > 0 ? p[k - 1] : hprev;
-            const float next = k < CPT - 1 ? p[k + 1] : hnext;
-            const float nb = prev + next + (has_l ? pl : 0.f) + (has_r ? pr : 0.f);
-            Mp[k] = dg[k] * p[k] - ac[k] * nb;
-            part += p[k] * Mp[k];
+            const float prev = k > 0 ? p[(k - 1) / 2][(k - 1) & 1] : hprev;
+            const float next = k < CPT - 1 ? p[(k + 1) / 2][(k + 1) & 1] : hnext;
+            nb[k] = prev + next;
         }
-        const float pMp = block_sum(part, red, slot);
-        slot ^= 1;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            float pl = dpp_mov<0x138>(p[k / 2][k & 1]);   // wave_shr:1  lane i <- lane i-1 (0 into lane 0)
+            if (!FULLROW) pl = has_l ? pl : 0.f;
+            nb[k] += pl;
+        }
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            float pr = dpp_mov<0x130>(p[k / 2][k & 1]);   // wave_shl:1  lane i <- lane i+1 (0 into lane 63)
+            if (!FULLROW) pr = has_r ? pr : 0.f;
+            nb[k] += pr;
+        }
+        part2 = (f2){0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < H; ++q) Mp[q] = dg[q] * p[q] - (f2){nb[2 * q], nb[2 * q + 1]};
+        if (wobst) {
+#pragma unroll
+            for (int q = 0; q < H; ++q) Mp[q] *= ac[q];
+        }
+#pragma unroll
+        for (int q = 0; q < H; ++q) part2 += p[q] * Mp[q];
+        const float pMp = cg_block_sum(part2.x + part2.y, red);            // barrier A
         if (!(pMp > 0.f)) break;
-        const float alpha = rr / pMp;
-        part = 0.f;
+        const float alpha = rr * __builtin_amdgcn_rcpf(pMp);
+        part2 = (f2){0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-            x[k] += alpha * p[k];
-            r[k] -= alpha * Mp[k];
-            part += r[k] * r[k];
+        for (int q = 0; q < H; ++q) {
+            x[q] += alpha * p[q];
+            r[q] -= alpha * Mp[q];
+            part2 += r[q] * r[q];
         }
-        const float rrn = block_sum(part, red, slot);
-        slot ^= 1;
-        const float beta = rrn / rr;
+        if (FULLROW || o.owner) { Ert[eo] = r[0].x; Erb[eo] = r[H - 1].y; Ept[eo] = p[0].x; Epb[eo] = p[H - 1].y; }
+        const float rrn = cg_block_sum(part2.x + part2.y, red + 16);       // barrier B (publishes the halo rows too)
+        const float beta = rrn * __builtin_amdgcn_rcpf(rr);
         rr = rrn;
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) p[k] = r[k] + beta * p[k];
+        for (int q = 0; q < H; ++q) p[q] = r[q] + beta * p[q];
+        if (FULLROW || o.owner) {
+            hprev = Erb[eo - X] + beta * Epb[eo - X];
+            hnext = Ert[eo + X] + beta * Ept[eo + X];
+        }
         ++it;
     }
+#pragma unroll
+    for (int q = 0; q < H; ++q) { xf[2 * q] = x[q].x; xf[2 * q + 1] = x[q].y; }
     return it;
 }
 
 // per-cell matrix coefficients of the owned strip
+template <int CPT>
 __device__ __forceinline__ void cell_coeffs(const Own& o, const unsigned char* act, int Y, int X,
                                             float (&dg)[CPT], float (&ac)[CPT]) {
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         dg[k] = 1.f;
-        ac[k] = 0.f;
+        ac[k] = 1.f;    // non-owner lanes: identity rows (r = 0 there)
         if (o.owner) {
             const int j = o.j0 + k, i = o.i;
             ac[k] = (float)act[j * X + i];
@@ -203,11 +269,12 @@ __device__ __forceinline__ void cell_coeffs(const Own& o, const unsigned char* a
 // ------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_karman_fwd(StepArgs a) {
+template <int CPT>
+__global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs a) {
     extern __shared__ __align__(16) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int Y = a.Y, X = a.X, N = Y * X, nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
-    const Lds L = carve(smem, Y, X);
+    const Lds L = carve(smem, Y, X, CPT);
 
     // ---- phase 1: load inputs -------------------------------------------------------
     {
@@ -294,9 +361,9 @@ __global__ void __launch_bounds__(1024) k_karman_fwd(StepArgs a) {
     __syncthreads();
 
     // ---- phase 4/5: divergence + CG pressure solve ----------------------------------
-    const Own o = ownership(Y, X);
+    const Own o = ownership<CPT>(Y, X);
     float dg[CPT], ac[CPT], r[CPT], x[CPT];
-    cell_coeffs(o, L.act, Y, X, dg, ac);
+    cell_coeffs<CPT>(o, L.act, Y, X, dg, ac);
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         r[k] = 0.f;
@@ -306,7 +373,8 @@ __global__ void __launch_bounds__(1024) k_karman_fwd(StepArgs a) {
             r[k] = -div;   // M p = -div  <=>  A p = div
         }
     }
-    const int it = cg_solve(o, X, dg, ac, r, x, L.E, L.red, a.rtol2, a.atol2, a.max_iter);
+    const int it = X == 64 ? cg_solve<CPT, true>(o, X, dg, ac, r, x, L.E, L.red, a.rtol2, a.atol2, a.max_iter)
+                           : cg_solve<CPT, false>(o, X, dg, ac, r, x, L.E, L.red, a.rtol2, a.atol2, a.max_iter);
     if (a.iters && tid == 0) a.iters[b] = it;
 
     // ---- phase 6: v -= mask * grad p ;  outputs --------------------------------------
@@ -352,11 +420,13 @@ __global__ void __launch_bounds__(1024) k_karman_fwd(StepArgs a) {
 // ------------------------------------------------------------------------------------
 // backward (adjoint w.r.t. the input velocity)
 // ------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_karman_bwd(StepArgs a) {
+template <int CPT>
+__global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs a) {
+    constexpr int MAXT = CPT + 1;   // face targets per thread: (Y+1)*X / (Y*X/CPT) <= CPT+1 for Y >= CPT
     extern __shared__ __align__(16) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int Y = a.Y, X = a.X, N = Y * X, nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
-    const Lds L = carve(smem, Y, X);
+    const Lds L = carve(smem, Y, X, CPT);
     const bool dirichlet = a.grad_pad == 1;
 
     // ---- 1: load incoming gradient (+ feature gradient) ------------------------------
@@ -380,9 +450,9 @@ __global__ void __launch_bounds__(1024) k_karman_bwd(StepArgs a) {
     __syncthreads();
 
     // ---- 2: projection adjoint:  M z = G^T (m * g) -----------------------------------
-    const Own o = ownership(Y, X);
+    const Own o = ownership<CPT>(Y, X);
     float dg[CPT], ac[CPT], r[CPT], z[CPT];
-    cell_coeffs(o, L.act, Y, X, dg, ac);
+    cell_coeffs<CPT>(o, L.act, Y, X, dg, ac);
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         r[k] = 0.f;
@@ -396,7 +466,8 @@ __global__ void __launch_bounds__(1024) k_karman_bwd(StepArgs a) {
             r[k] = s;
         }
     }
-    const int it = cg_solve(o, X, dg, ac, r, z, L.E, L.red, a.rtol2, a.atol2, a.max_iter);
+    const int it = X == 64 ? cg_solve<CPT, true>(o, X, dg, ac, r, z, L.E, L.red, a.rtol2, a.atol2, a.max_iter)
+                           : cg_solve<CPT, false>(o, X, dg, ac, r, z, L.E, L.red, a.rtol2, a.atol2, a.max_iter);
     if (a.iters && tid == 0) a.iters[b] = it;
 
     // ---- 3: g_adv = m * (g + D^T z), kept in registers ---------------------------------
@@ -514,13 +585,25 @@ __global__ void __launch_bounds__(1024) k_karman_bwd(StepArgs a) {
     }
 }
 
+// strip height: 16 cells per thread when the grid allows it (fewer waves -> less per-wave
+// reduction overhead in the issue-bound CG loop), 8 otherwise.  SOL_CPT=8|16 overrides.
+int pick_cpt(const sol_karman_cfg* c) {
+    int cpt = (c->Y % 16 == 0 && c->X >= 16) ? 16 : 8;
+    if (const char* e = getenv("SOL_CPT")) {
+        const int v = atoi(e);
+        if (v == 8 || (v == 16 && c->Y % 16 == 0 && c->X >= 16)) cpt = v;
+    }
+    return cpt;
+}
+
 int check_cfg(const sol_karman_cfg* c) {
     SOL_REQUIRE(c != nullptr, "cfg is NULL");
     SOL_REQUIRE(c->B >= 1, "B must be >= 1 (got %d)", c->B);
-    SOL_REQUIRE(c->Y >= 8 && c->Y % CPT == 0, "Y must be a positive multiple of 8 (got %d)", c->Y);
+    SOL_REQUIRE(c->Y >= 8 && c->Y % 8 == 0, "Y must be a positive multiple of 8 (got %d)", c->Y);
     SOL_REQUIRE(c->X == 8 || c->X == 16 || c->X == 32 || c->X == 64, "X must be 8, 16, 32 or 64 (got %d)", c->X);
-    SOL_REQUIRE((c->Y / CPT) * c->X <= 1024, "grid %dx%d exceeds one workgroup (Y*X/8 <= 1024)", c->Y, c->X);
-    SOL_REQUIRE(lds_bytes(c->Y, c->X) <= 160 * 1024, "grid %dx%d does not fit the 160 KiB LDS", c->Y, c->X);
+    const int cpt = pick_cpt(c);
+    SOL_REQUIRE((c->Y / cpt) * c->X <= (cpt == 16 ? 512 : 1024), "grid %dx%d exceeds one workgroup", c->Y, c->X);
+    SOL_REQUIRE(lds_bytes(c->Y, c->X, cpt) <= 160 * 1024, "grid %dx%d does not fit the 160 KiB LDS", c->Y, c->X);
     SOL_REQUIRE(c->dx > 0.f && c->cg_max_iter >= 0, "dx must be > 0 and cg_max_iter >= 0");
     return SOL_OK;
 }
@@ -538,9 +621,9 @@ void fill_common(StepArgs& a, const sol_karman_cfg* c) {
 }
 
 template <typename K>
-int launch_step(K kernel, const sol_karman_cfg* c, void* stream, const StepArgs& a) {
-    const int threads = (int)align_up((size_t)(c->Y / CPT) * c->X, 64);
-    const size_t lds = lds_bytes(c->Y, c->X);
+int launch_step(K kernel, int cpt, const sol_karman_cfg* c, void* stream, const StepArgs& a) {
+    const int threads = (int)align_up((size_t)(c->Y / cpt) * c->X, 64);
+    const size_t lds = lds_bytes(c->Y, c->X, cpt);
     SOL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kernel, dim3(c->B), dim3(threads), lds, (hipStream_t)stream, a);
@@ -570,7 +653,8 @@ extern "C" int sol_karman_step_fwd(const sol_karman_cfg* cfg, void* stream,
     a.feat = feat_out;
     if (feat_scale) { a.fs0 = feat_scale[0]; a.fs1 = feat_scale[1]; a.fs2 = feat_scale[2]; }
     a.iters = iters;
-    return launch_step(k_karman_fwd, cfg, stream, a);
+    const int cpt = pick_cpt(cfg);
+    return cpt == 16 ? launch_step(k_karman_fwd<16>, 16, cfg, stream, a) : launch_step(k_karman_fwd<8>, 8, cfg, stream, a);
 }
 
 extern "C" int sol_karman_step_bwd(const sol_karman_cfg* cfg, void* stream,
@@ -591,5 +675,6 @@ extern "C" int sol_karman_step_bwd(const sol_karman_cfg* cfg, void* stream,
     a.g_vy_out = g_vy_out; a.g_vx_out = g_vx_out; a.dfeat = dfeat;
     if (feat_scale) { a.fs0 = feat_scale[0]; a.fs1 = feat_scale[1]; a.fs2 = feat_scale[2]; }
     a.g_vy_in = g_vy_in; a.g_vx_in = g_vx_in; a.iters = iters;
-    return launch_step(k_karman_bwd, cfg, stream, a);
+    const int cpt = pick_cpt(cfg);
+    return cpt == 16 ? launch_step(k_karman_bwd<16>, 16, cfg, stream, a) : launch_step(k_karman_bwd<8>, 8, cfg, stream, a);
 }
