@@ -155,6 +155,143 @@ __global__ void __launch_bounds__(256) k_conv5x5(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// 32-input-channel kernel (the 22 FLOP-dominant launches per sim-step): software pipelined.
+//   * halo tile UNPADDED with an XOR swizzle of the 16-byte channel chunks
+//     (chunk ^= ((pix >> 1) & 3) << 1) -> conflict-free ds_read_b128 for the A operand, and
+//     43.5 KB instead of 49 KB so that three workgroups + their weight buffers fit one CU;
+//   * the per-tap weight tile [cout][32] is staged ONCE per workgroup in LDS (double buffered,
+//     same swizzle) instead of being re-read from L1/L2 by each of the 4 waves;
+//   * the loads of tap t+1 (weights) and of the next halo row are issued before the MFMAs of
+//     tap t and written to LDS after them: one barrier per tap, the first MFMA starts after
+//     one halo row instead of the whole tile.
+// Lane group g consumes channel chunks g and g+4 (K permutation shared by A and B).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz(int pix) { return ((pix >> 1) & 3) << 1; }
+
+template <int NT>
+__global__ void __launch_bounds__(256) k_conv5x5_c32(ConvArgs a) {
+    constexpr int OP = NT * 16;
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int H = a.H, W = a.W, TW = a.TW, RPW = a.RPW;
+    const int HW = TW + 4, NR = RPW + 4;
+    int blk = blockIdx.x;
+    const int tx = blk % a.tiles_x; blk /= a.tiles_x;
+    const int rows_blk = H / RPW;
+    const int ty = blk % rows_blk;
+    const int b = blk / rows_blk;
+    const int y0 = ty * RPW, x0 = tx * TW;
+    float* halo = smem;                      // [NR*HW][32] swizzled
+    float* Bs = smem + NR * HW * 32;         // [2][OP][32] swizzled
+    const float4* gx = reinterpret_cast<const float4*>(a.x);
+    const float4* gw = reinterpret_cast<const float4*>(a.wp);
+    const int row_f4 = HW * 8;               // float4 per halo row
+    constexpr int HPT = 3;                   // float4 per thread per halo row (HW <= 68 -> 544 <= 768)
+
+    auto load_row = [&](int hr, float4 (&v)[HPT]) {
+        const int yy = y0 + hr - 2;
+#pragma unroll
+        for (int n = 0; n < HPT; ++n) {
+            const int e = tid + n * 256;
+            v[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < row_f4) {
+                const int hc = e >> 3, c4 = e & 7;
+                const int xx = x0 + hc - 2;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) v[n] = gx[((size_t)(b * H + yy) * W + xx) * 8 + c4];
+            }
+        }
+    };
+    auto store_row = [&](int hr, const float4 (&v)[HPT]) {
+#pragma unroll
+        for (int n = 0; n < HPT; ++n) {
+            const int e = tid + n * 256;
+            if (e < row_f4) {
+                const int hc = e >> 3, c4 = e & 7;
+                const int pix = hr * HW + hc;
+                *reinterpret_cast<float4*>(&halo[pix * 32 + ((c4 ^ swz(pix)) << 2)]) = v[n];
+            }
+        }
+    };
+    const int bco = tid >> 3, bc4 = tid & 7;    // weight tile element of this thread
+    const bool bact = tid < OP * 8;
+    float* bdst = Bs + bco * 32 + ((bc4 ^ swz(bco)) << 2);
+
+    // ---- prologue: halo rows [0, RPW) and the weights of tap 0 -----------------------------
+    for (int hr = 0; hr < RPW; ++hr) {
+        float4 v[HPT];
+        load_row(hr, v);
+        store_row(hr, v);
+    }
+    if (bact) *reinterpret_cast<float4*>(bdst) = gw[(size_t)bco * 8 + bc4];
+    __syncthreads();
+
+    const int q = wave * 16 + li;            // this lane's A-row pixel inside the tile
+    const int prr = q / TW, pcc = q - prr * TW;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int dy = 0; dy < 5; ++dy) {
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+            const int tap = dy * 5 + dx;
+            // issue the prefetches for the next tap / next halo row
+            float4 bnext = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool more = tap + 1 < 25;
+            if (more && bact) bnext = gw[((size_t)(tap + 1) * OP + bco) * 8 + bc4];
+            float4 hv[HPT];
+            const bool hrow = dx == 0 && dy < 4;
+            if (hrow) load_row(RPW + dy, hv);
+            // MFMAs of this tap
+            const int pix = (prr + dy) * HW + pcc + dx;
+            const float* ap = &halo[pix * 32];
+            const int sa = swz(pix);
+            const float4 a0 = *reinterpret_cast<const float4*>(ap + ((g ^ sa) << 2));
+            const float4 a1 = *reinterpret_cast<const float4*>(ap + (((g + 4) ^ sa) << 2));
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const float* bbuf = Bs + (tap & 1) * OP * 32;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int co = n * 16 + li;
+                const float* bp = bbuf + co * 32;
+                const int sb = swz(co);
+                const float4 b0 = *reinterpret_cast<const float4*>(bp + ((g ^ sb) << 2));
+                const float4 b1 = *reinterpret_cast<const float4*>(bp + (((g + 4) ^ sb) << 2));
+                const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk)
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[kk], acc[n], 0, 0, 0);
+            }
+            // publish the prefetched data for the next tap
+            if (more && bact) *reinterpret_cast<float4*>(bdst + ((tap + 1) & 1) * OP * 32) = bnext;
+            if (hrow) store_row(RPW + dy, hv);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: bias, residual, LeakyReLU / LeakyReLU' ---------------------------------
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = n * 16 + li;
+        if (co >= a.CO) continue;
+        const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qq = wave * 16 + 4 * g + r;
+            const int rr = qq / TW, cc = qq - rr * TW;
+            const size_t o = ((size_t)(b * H + y0 + rr) * W + x0 + cc) * a.CO + co;
+            float v = acc[n][r] + bias;
+            if (a.res) v += a.res[o];
+            if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
+            else if (a.epi == SOL_EPI_DLRELU) v *= (a.act[o] > 0.f ? 1.f : a.slope);
+            a.y[o] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // backward-weight
 // ------------------------------------------------------------------------------------
 // Workgroup (dy, row block): accumulates dW[dy][0..4][ci][co] over RB image rows in MFMA
@@ -178,13 +315,15 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww(BwArgs a) {
     constexpr int NTC = COUT <= 16 ? 1 : 2;
     constexpr int IP = CI == 4 ? 16 : 32;         // padded dims of the partial buffer
     constexpr int OP = NTC * 16;
+    constexpr int XF4 = CI / 4;                   // float4 per pixel of x
+    constexpr int NXR = CI == 32 ? 3 : 1;         // float4 registers per thread per x row  (W <= 92 / 252)
+    constexpr int NZR = COUT > 4 ? 2 : 1;         // registers per thread per dz row        (W <= 64 / 256)
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int H = a.H, W = a.W;
     const int dy = blockIdx.x % 5, blk = blockIdx.x / 5;
-    float* xs = smem;                       // [(W+4)][CPX]
-    float* zs = smem + (W + 4) * CPX;       // [W][CPZ]
+    const int bufsz = (W + 4) * CPX + W * CPZ;    // floats per stage: x row then dz row
     const int ta = wave / NTC, tc = wave % NTC;
     const bool active_wave = wave < NTA * NTC;
 
@@ -194,63 +333,93 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww(BwArgs a) {
     float bsum = 0.f;
 
     const int R = a.B * H;
-    for (int gr = blk * RB; gr < min((blk + 1) * RB, R); ++gr) {
-        const int b = gr / H, y = gr - b * H;
-        const int yy = y + dy - 2;
-        const bool valid = yy >= 0 && yy < H;       // workgroup uniform
-        if (!valid && dy != 2) continue;
-        __syncthreads();                            // previous row fully consumed
-        if (valid) {
-            if constexpr (CI == 32) {
-                const float4* gx = reinterpret_cast<const float4*>(a.x) + (size_t)(b * H + yy) * W * 8;
-                for (int e = tid; e < (W + 4) * 8; e += 256) {
-                    const int px = e >> 3, c4 = e & 7;
-                    const int xx = px - 2;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (xx >= 0 && xx < W) v = gx[xx * 8 + c4];
-                    *reinterpret_cast<float4*>(&xs[px * CPX + c4 * 4]) = v;
-                }
-            } else {
-                const float4* gx = reinterpret_cast<const float4*>(a.x) + (size_t)(b * H + yy) * W;
-                for (int px = tid; px < W + 4; px += 256) {
-                    const int xx = px - 2;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (xx >= 0 && xx < W) v = gx[xx];
-                    *reinterpret_cast<float4*>(&xs[px * CPX]) = v;
-                }
-            }
+    const int gr_end = min((blk + 1) * RB, R);
+    // rows this workgroup visits: dy == 2 always (bias needs every dz row), else only valid taps
+    auto row_valid = [&](int gr) { const int y = gr % H, yy = y + dy - 2; return yy >= 0 && yy < H; };
+    auto next_row = [&](int gr) { while (gr < gr_end && !(dy == 2 || row_valid(gr))) ++gr; return gr; };
+
+    float4 xr[NXR];
+    float4 zr[NZR];
+    auto load_row = [&](int gr) {
+        const int b = gr / H, y = gr - b * H, yy = y + dy - 2;
+        const bool valid = yy >= 0 && yy < H;
+        const float4* gx = reinterpret_cast<const float4*>(a.x) + (size_t)(b * H + (valid ? yy : 0)) * W * XF4;
+#pragma unroll
+        for (int n = 0; n < NXR; ++n) {
+            const int e = tid + n * 256;
+            const int px = e / XF4, c4 = e - px * XF4, xx = px - 2;
+            xr[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid && px < W + 4 && xx >= 0 && xx < W) xr[n] = gx[xx * XF4 + c4];
         }
         if constexpr (COUT > 4) {
             const float4* gz = reinterpret_cast<const float4*>(a.dz) + (size_t)(b * H + y) * W * (COUT / 4);
-            for (int e = tid; e < W * (COUT / 4); e += 256) {
-                const int px = e / (COUT / 4), c4 = e % (COUT / 4);
-                *reinterpret_cast<float4*>(&zs[px * CPZ + c4 * 4]) = gz[e];
-            }
-        } else {   // COUT == 2
-            const float2* gz = reinterpret_cast<const float2*>(a.dz) + (size_t)(b * H + y) * W;
-            for (int px = tid; px < W; px += 256) {
-                const float2 v = gz[px];
-                zs[px * CPZ] = v.x; zs[px * CPZ + 1] = v.y; zs[px * CPZ + 2] = 0.f; zs[px * CPZ + 3] = 0.f;
-            }
-        }
-        __syncthreads();
-        if (!active_wave) continue;
-        for (int p0 = 0; p0 < W; p0 += 4) {
-            const int px = p0 + g;
-            float bv;
-            if constexpr (COUT > 4) bv = zs[px * CPZ + tc * 16 + li];
-            else bv = li < 4 ? zs[px * CPZ + li] : 0.f;
-            if (dy == 2 && ta == 0) bsum += bv;
-            if (valid) {
 #pragma unroll
-                for (int d = 0; d < 5; ++d) {
-                    float av;
-                    if constexpr (CI == 32) av = xs[(px + d) * CPX + ta * 16 + li];
-                    else av = li < 4 ? xs[(px + d) * CPX + li] : 0.f;
-                    acc[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[d], 0, 0, 0);
+            for (int n = 0; n < NZR; ++n) {
+                const int e = tid + n * 256;
+                zr[n] = e < W * (COUT / 4) ? gz[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            const float2* gz = reinterpret_cast<const float2*>(a.dz) + (size_t)(b * H + y) * W;
+            const float2 v = tid < W ? gz[tid] : make_float2(0.f, 0.f);
+            zr[0] = make_float4(v.x, v.y, 0.f, 0.f);
+        }
+    };
+    auto store_row = [&](float* buf) {
+        float* xs = buf;
+        float* zs = buf + (W + 4) * CPX;
+#pragma unroll
+        for (int n = 0; n < NXR; ++n) {
+            const int e = tid + n * 256;
+            const int px = e / XF4, c4 = e - px * XF4;
+            if (px < W + 4) *reinterpret_cast<float4*>(&xs[px * CPX + c4 * 4]) = xr[n];
+        }
+        if constexpr (COUT > 4) {
+#pragma unroll
+            for (int n = 0; n < NZR; ++n) {
+                const int e = tid + n * 256;
+                const int px = e / (COUT / 4), c4 = e % (COUT / 4);
+                if (e < W * (COUT / 4)) *reinterpret_cast<float4*>(&zs[px * CPZ + c4 * 4]) = zr[n];
+            }
+        } else {
+            if (tid < W) *reinterpret_cast<float4*>(&zs[tid * CPZ]) = zr[0];
+        }
+    };
+
+    int gr = next_row(blk * RB);
+    int cur = 0;
+    if (gr < gr_end) {
+        load_row(gr);
+        store_row(smem);
+    }
+    __syncthreads();
+    while (gr < gr_end) {
+        const int gnext = next_row(gr + 1);
+        if (gnext < gr_end) load_row(gnext);           // global -> registers, overlaps the MFMAs below
+        const bool valid = row_valid(gr);              // workgroup uniform
+        const float* xs = smem + cur * bufsz;
+        const float* zs = xs + (W + 4) * CPX;
+        if (active_wave) {
+            for (int p0 = 0; p0 < W; p0 += 4) {
+                const int px = p0 + g;
+                float bv;
+                if constexpr (COUT > 4) bv = zs[px * CPZ + tc * 16 + li];
+                else bv = li < 4 ? zs[px * CPZ + li] : 0.f;
+                if (dy == 2 && ta == 0) bsum += bv;
+                if (valid) {
+#pragma unroll
+                    for (int d = 0; d < 5; ++d) {
+                        float av;
+                        if constexpr (CI == 32) av = xs[(px + d) * CPX + ta * 16 + li];
+                        else av = li < 4 ? xs[(px + d) * CPX + li] : 0.f;
+                        acc[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[d], 0, 0, 0);
+                    }
                 }
             }
         }
+        if (gnext < gr_end) store_row(smem + (cur ^ 1) * bufsz);
+        __syncthreads();
+        cur ^= 1;
+        gr = gnext;
     }
     if (!active_wave) return;
     // partial layout: [blk][25 taps][IP][OP] then [blk][OP] bias sums
@@ -336,8 +505,16 @@ extern "C" int sol_conv5x5(void* stream, const float* x, const float* packed, co
     const size_t lds = (size_t)(a.RPW + 4) * (a.TW + 4) * CP * sizeof(float);
     const int NT = pad_out(cout) / 16;
     hipStream_t s = (hipStream_t)stream;
-    if (cin == 32 && NT == 2) hipLaunchKernelGGL((k_conv5x5<32, 2>), dim3(grid), dim3(256), lds, s, a);
-    else if (cin == 32 && NT == 1) hipLaunchKernelGGL((k_conv5x5<32, 1>), dim3(grid), dim3(256), lds, s, a);
+    if (cin == 32) {
+        const size_t lds32 = ((size_t)(a.RPW + 4) * (a.TW + 4) * 32 + 2 * (size_t)NT * 16 * 32) * sizeof(float);
+        if (NT == 2) {
+            SOL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv5x5_c32<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
+            hipLaunchKernelGGL((k_conv5x5_c32<2>), dim3(grid), dim3(256), lds32, s, a);
+        } else {
+            SOL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv5x5_c32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
+            hipLaunchKernelGGL((k_conv5x5_c32<1>), dim3(grid), dim3(256), lds32, s, a);
+        }
+    }
     else if (cin == 4 && NT == 2) hipLaunchKernelGGL((k_conv5x5<4, 2>), dim3(grid), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((k_conv5x5<4, 1>), dim3(grid), dim3(256), lds, s, a);
     SOL_LAUNCH_CHECK();
@@ -360,7 +537,7 @@ extern "C" size_t sol_conv5x5_bwd_weight_ws_floats(int32_t B, int32_t H, int32_t
 extern "C" int sol_conv5x5_bwd_weight(void* stream, const float* x, const float* dz, float* partial,
                                       int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout) {
     SOL_REQUIRE(x && dz && partial, "sol_conv5x5_bwd_weight: NULL pointer");
-    SOL_REQUIRE(B >= 1 && H >= 1 && W >= 4 && W % 4 == 0, "sol_conv5x5_bwd_weight: bad shape");
+    SOL_REQUIRE(B >= 1 && H >= 1 && W >= 4 && W % 4 == 0 && W <= 64, "sol_conv5x5_bwd_weight: need 4 <= W <= 64, W %% 4 == 0 (got %d)", W);
     SOL_REQUIRE((cin == 4 || cin == 32) && (cout == 2 || cout == 32),
                 "sol_conv5x5_bwd_weight: supported (cin,cout) are {4,32}x{2,32} (got %d,%d)", cin, cout);
     BwArgs a{};
@@ -368,7 +545,7 @@ extern "C" int sol_conv5x5_bwd_weight(void* stream, const float* x, const float*
     int IP, OP;
     bww_dims(B, H, cin, cout, &a.nblk, &IP, &OP);
     const int CPX = cin == 4 ? 4 : 48, CPZ = cout <= 4 ? 4 : 48;
-    const size_t lds = ((size_t)(W + 4) * CPX + (size_t)W * CPZ) * sizeof(float);
+    const size_t lds = 2 * ((size_t)(W + 4) * CPX + (size_t)W * CPZ) * sizeof(float);   // double buffered rows
     const int grid = a.nblk * 5;
     hipStream_t s = (hipStream_t)stream;
     if (cin == 32 && cout == 32) hipLaunchKernelGGL((k_conv5x5_bww<32, 32>), dim3(grid), dim3(256), lds, s, a);

@@ -1,0 +1,94 @@
+#!/usr/bin/env python
+"""Generates the golden vectors in tests/golden/ from the float64 CPU oracle.
+
+The reference has no tests / golden vectors and its PhiFlow/TF path cannot be imported here
+(SURVEY.md section 8c), so these fixtures pin the ORACLE (regression) and give the GPU tests
+committed input/output pairs.  Run:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
+import sol_oracle as o  # noqa: E402
+
+torch.set_default_dtype(torch.float64)
+
+
+def r32(t):
+    """round to fp32-representable values (the GPU path consumes fp32 inputs)"""
+    return t.detach().float().double()
+
+
+def step_case(B, Y, X, seed, **kw):
+    g = o.geometry(Y, X)
+    d, vy, vx = (r32(t) for t in o.synthetic_state(B, Y, X, seed))
+    re = torch.tensor([o.RE_TRAIN[i % 6] for i in range(B)])
+    vy = vy.clone().requires_grad_(True)
+    vx = vx.clone().requires_grad_(True)
+    d2, py, px = o.karman_step(d, vy, vx, re, g, **kw)
+    gen = torch.Generator().manual_seed(seed + 1)
+    wy = r32(torch.randn(py.shape, generator=gen))
+    wx = r32(torch.randn(px.shape, generator=gen))
+    ((py * wy).sum() + (px * wx).sum()).backward()
+    n = lambda t: t.detach().numpy().astype(np.float32)
+    return dict(d=n(d), vy=n(vy), vx=n(vx), re=n(re), d_out=n(d2), vy_out=n(py), vx_out=n(px),
+                wy=n(wy), wx=n(wx), g_vy=n(vy.grad), g_vx=n(vx.grad))
+
+
+def burgers_case():
+    B, Y, X = 5, 32, 32
+    gen = torch.Generator().manual_seed(3)
+    vy = r32(0.3 * o._smooth(torch.randn(B, Y + 1, X, generator=gen))).requires_grad_(True)
+    vx = r32(0.3 * o._smooth(torch.randn(B, Y, X + 1, generator=gen))).requires_grad_(True)
+    fy = r32(0.15 * o._smooth(torch.randn(B, Y + 1, X, generator=gen)))
+    fx = r32(0.15 * o._smooth(torch.randn(B, Y, X + 1, generator=gen)))
+    ay, ax = o.burgers_step(vy, vx, 0.1, 0.1, fy, fx)
+    wy = r32(torch.randn(ay.shape, generator=gen))
+    wx = r32(torch.randn(ax.shape, generator=gen))
+    ((ay * wy).sum() + (ax * wx).sum()).backward()
+    n = lambda t: t.detach().numpy().astype(np.float32)
+    return dict(vy=n(vy), vx=n(vx), fy=n(fy), fx=n(fx), vy_out=n(ay), vx_out=n(ax), wy=n(wy), wx=n(wx),
+                g_vy=n(vy.grad), g_vx=n(vx.grad), dt=0.1, nu=0.1)
+
+
+def train_case(B=2, Y=16, X=8, ms=2):
+    g = o.geometry(Y, X)
+    d, vy, vx = (r32(t) for t in o.synthetic_state(B, Y, X, 1234))
+    re = torch.tensor(o.RE_TRAIN[:B])
+    gts = [tuple(r32(t) for t in o.synthetic_state(B, Y, X, 4321 + i, project_it=False)) for i in range(ms)]
+    params = [r32(p).requires_grad_(True) for p in o.init_params(0)]
+    gen = torch.Generator().manual_seed(99)
+    with torch.no_grad():
+        for p in params:
+            if p.dim() == 1:
+                p.copy_(r32(0.01 * torch.randn(p.shape, generator=gen)))
+    std_v = (0.2, 0.25)
+    loss, losses, states = o.unrolled_loss(params, d, vy, vx, re, [s[1] for s in gts], [s[2] for s in gts], g,
+                                           std_v, o.STD_RE, return_states=True)
+    loss.backward()
+    n = lambda t: t.detach().numpy().astype(np.float32)
+    grads = np.concatenate([p.grad.numpy().ravel() for p in params])
+    # weights are reproducible from seed 0 (fp32 rounded) + the stored biases; the 260k-element
+    # gradient is stored as per-tensor L2 norms plus every 16th element
+    return dict(d=n(d), vy=n(vy), vx=n(vx), re=n(re), gt_vy=np.stack([n(s[1]) for s in gts]),
+                gt_vx=np.stack([n(s[2]) for s in gts]), std_v=np.array(std_v), std_re=o.STD_RE,
+                biases=np.concatenate([n(p).ravel() for p in params if p.dim() == 1]),
+                loss=float(loss), loss_steps=np.array([float(l) for l in losses]),
+                grad_norms=np.array([float(p.grad.norm()) for p in params]), grads_sub16=grads[::16].astype(np.float32),
+                vy_final=n(states[-1][1]), vx_final=n(states[-1][2]), d_final=n(states[-1][0]))
+
+
+if __name__ == "__main__":
+    np.savez_compressed(os.path.join(HERE, "karman_step_16x8.npz"), **step_case(2, 16, 8, 1234))
+    np.savez_compressed(os.path.join(HERE, "karman_step_64x32.npz"), **step_case(3, 64, 32, 1234))
+    np.savez_compressed(os.path.join(HERE, "karman_step_16x8_dirichlet_before.npz"),
+                        **step_case(2, 16, 8, 77, grad_pad="dirichlet0", inflow_order="before"))
+    np.savez_compressed(os.path.join(HERE, "burgers_step_32x32.npz"), **burgers_case())
+    np.savez_compressed(os.path.join(HERE, "train_16x8_sol2.npz"), **train_case())
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KB")

@@ -1,0 +1,88 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/sol_hip.h
+declares, and rejects bad arguments with an error code + message (no compute, no GPU)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import sol_amd
+from sol_amd import _lib, ops
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return sol_amd.load()
+
+
+def test_library_is_in_tree_and_exports_all_declared_symbols(lib):
+    path = os.path.realpath(sol_amd.lib_path())
+    assert path.startswith(os.path.realpath(os.path.dirname(sol_amd.__file__)))
+    decl = sol_amd.declared_symbols()
+    assert len(decl) >= 18
+    for s in decl:
+        assert hasattr(lib, s), "libsol_hip.so does not export %s" % s
+    assert set(decl) == set(_lib._SIGS.keys())      # every declared function has a typed binding
+    assert lib.sol_version() >= 100
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(sol_amd.SolError):
+        _lib.require_gpu()
+    with pytest.raises(sol_amd.SolError):
+        cfg = ops.karman_cfg(1, 16, 8, 12.5)
+        z = torch.zeros(1, 16, 8)
+        ops.karman_step(z, torch.zeros(1, 17, 8), torch.zeros(1, 16, 9), torch.ones(1), cfg, None)
+
+
+def test_bad_arguments_are_rejected_with_a_message(lib):
+    cfg = ops.karman_cfg(1, 16, 8, 12.5)
+    # NULL pointers
+    rc = lib.sol_karman_step_fwd(C.byref(cfg), None, *([None] * 8), 0, *([None] * 6), None, None)
+    assert rc == -1 and b"NULL" in lib.sol_last_error()
+    # unsupported grid (X must be 8/16/32/64, Y a multiple of 8)
+    bad = ops.karman_cfg(1, 16, 12, 1.0)
+    rc = lib.sol_karman_step_fwd(C.byref(bad), None, *([None] * 8), 0, *([None] * 6), None, None)
+    assert rc == -1 and b"X must be" in lib.sol_last_error()
+    bad = ops.karman_cfg(1, 20, 8, 1.0)
+    rc = lib.sol_karman_step_bwd(C.byref(bad), None, *([None] * 5), 0, *([None] * 3), None, *([None] * 3))
+    assert rc == -1 and b"multiple of 8" in lib.sol_last_error()
+    # grid larger than one workgroup / the LDS
+    big = ops.karman_cfg(1, 256, 64, 1.0)
+    rc = lib.sol_karman_step_fwd(C.byref(big), None, *([None] * 8), 0, *([None] * 6), None, None)
+    assert rc == -1
+    # conv: bad channel count
+    rc = lib.sol_conv5x5(None, None, None, None, None, None, None, 1, 16, 8, 5, 32, 0, 0.3)
+    assert rc == -1 and b"input channels" in lib.sol_last_error()
+    # std == 0 (the reference's `-n 1` division by zero, karman-2d/Makefile:73)
+    tc = _lib.TrainCfg(ops.karman_cfg(1, 16, 8, 12.5), 2, 0.2, 0.2, 0.0, 0.3)
+    one = C.c_void_p(1)
+    rc = lib.sol_train_fwd_bwd(C.byref(tc), None, *([one] * 9), 0, one, one, one, 0, *([one] * 2), *([None] * 5))
+    assert rc == -1 and b"std" in lib.sol_last_error()
+    # workspace too small
+    tc = _lib.TrainCfg(ops.karman_cfg(1, 16, 8, 12.5), 2, 0.2, 0.2, 1.0, 0.3)
+    rc = lib.sol_train_fwd_bwd(C.byref(tc), None, *([one] * 9), 0, one, one, one, 16, *([one] * 2), *([None] * 5))
+    assert rc == -3 and b"workspace" in lib.sol_last_error()
+
+
+def test_workspace_sizes_and_layer_table(lib):
+    tc = _lib.TrainCfg(ops.karman_cfg(6, 128, 64, 1.5625), 32, 0.2, 0.2, 1.0, 0.3)
+    nb = lib.sol_train_workspace_bytes(C.byref(tc))
+    # dominated by 11 x 32-channel activations per sim-step: 32*11*6*8192*32*4 B = 2.2 GB
+    assert 2.2e9 < nb < 2.8e9
+    assert lib.sol_rollout_workspace_bytes(C.byref(tc)) < nb / 20
+    import torch
+    net = sol_amd.model_mars_moon(cin=3, cout=2, device="cpu")
+    assert net.n_params == 260354
+    for l in range(12):
+        k, b = C.c_int64(), C.c_int64()
+        ci, co = C.c_int32(), C.c_int32()
+        assert lib.sol_mars_moon_layer(l, C.byref(k), C.byref(b), C.byref(ci), C.byref(co)) == 0
+        assert k.value == net.offsets[2 * l] and b.value == net.offsets[2 * l + 1]
+        assert net.shapes[2 * l] == (5, 5, ci.value, co.value)
+    assert lib.sol_mars_moon_layer(12, None, None, None, None) == -1
+    assert lib.sol_conv5x5_packed_floats(3, 32, 0) == 25 * 4 * 32
+    assert lib.sol_conv5x5_packed_floats(2, 3, 1) == 25 * 4 * 16

@@ -1,0 +1,319 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C ABI, against the CPU
+oracle and the committed golden vectors.  Tolerances: the north star asks for <= 1e-5 relative
+L2 on velocity/density fields (fp32 kernels vs the float64 oracle with an exactly solved
+pressure system); gradients pass through two fp32 CG solves per step and are held to 1e-4.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sol_amd
+import sol_oracle as o
+from sol_amd import ops
+from test_golden_oracle import golden_train_params
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL_FIELD = 1e-5     # north star: relative L2 on velocity / density
+TOL_GRAD = 1e-4
+
+
+def rel(a, b):
+    a = torch.as_tensor(np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a), dtype=torch.float64)
+    b = torch.as_tensor(np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b), dtype=torch.float64)
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def f32(t):
+    return torch.as_tensor(np.asarray(t), dtype=torch.float32).to(DEV).contiguous()
+
+
+def masks_for(Y, X):
+    g = o.geometry(Y, X)
+    return g, ops.SceneMasks(g.active, g.inflow, g.bc_mask, g.bc_mask)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _loaded_native_library():
+    lib = sol_amd.load()
+    assert os.path.exists(sol_amd.lib_path())
+    assert torch.cuda.is_available()
+    yield lib
+
+
+# ---------------------------------------------------------------------------------------------
+# solver step
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,kw", [("karman_step_16x8", {}), ("karman_step_64x32", {}),
+                                     ("karman_step_16x8_dirichlet_before", dict(grad_pad="dirichlet0", inflow_order="before"))])
+def test_karman_step_against_golden(golden_dir, name, kw):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    B, Y, X = z["d"].shape
+    g, mk = masks_for(Y, X)
+    cfg = ops.karman_cfg(B, Y, X, g.dx, **kw)
+    vy = f32(z["vy"]).requires_grad_(True)
+    vx = f32(z["vx"]).requires_grad_(True)
+    info = {}
+    d2, py, px = ops.karman_step(f32(z["d"]), vy, vx, f32(z["re"]), cfg, mk, info)
+    ((py * f32(z["wy"])).sum() + (px * f32(z["wx"])).sum()).backward()
+    assert rel(d2, z["d_out"]) < TOL_FIELD and rel(py, z["vy_out"]) < TOL_FIELD and rel(px, z["vx_out"]) < TOL_FIELD
+    assert rel(vy.grad, z["g_vy"]) < TOL_GRAD and rel(vx.grad, z["g_vx"]) < TOL_GRAD
+    assert int(info["iterations"].min()) > 5 and int(info["iterations"].max()) < 2000
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_karman_step_full_size_against_oracle(B):
+    Y, X = 128, 64
+    g, mk = masks_for(Y, X)
+    d, vy, vx = o.synthetic_state(B, Y, X, 1234)
+    re = torch.tensor(o.RE_TRAIN[:B], dtype=torch.float64)
+    vy = vy.clone().requires_grad_(True)
+    vx = vx.clone().requires_grad_(True)
+    d2, py, px = o.karman_step(d, vy, vx, re, g)
+    gen = torch.Generator().manual_seed(5)
+    wy = torch.randn(py.shape, generator=gen, dtype=torch.float64)
+    wx = torch.randn(px.shape, generator=gen, dtype=torch.float64)
+    ((py * wy).sum() + (px * wx).sum()).backward()
+    hvy = f32(vy.detach()).requires_grad_(True)
+    hvx = f32(vx.detach()).requires_grad_(True)
+    hd, hpy, hpx = ops.karman_step(f32(d), hvy, hvx, f32(re), ops.karman_cfg(B, Y, X, g.dx), mk)
+    ((hpy * f32(wy)).sum() + (hpx * f32(wx)).sum()).backward()
+    assert rel(hd, d2) < TOL_FIELD and rel(hpy, py) < TOL_FIELD and rel(hpx, px) < TOL_FIELD
+    assert rel(hvy.grad, vy.grad) < TOL_GRAD and rel(hvx.grad, vx.grad) < TOL_GRAD
+
+
+def test_full_size_properties():
+    """BASELINE.json's full per-GPU batch (6 x 128x64): size independent properties."""
+    B, Y, X = 6, 128, 64
+    g, mk = masks_for(Y, X)
+    d, vy, vx = (f32(t) for t in sol_amd.synthetic.state(B, Y, X, 1))
+    re = f32(sol_amd.synthetic.reynolds(B))
+    cfg = ops.karman_cfg(B, Y, X, g.dx)
+    d2, py, px = ops.karman_step(d, vy, vx, re, cfg, mk)
+    # (a) divergence free on interior fluid cells (boundary cells keep PhiFlow's replicate-pad quirk)
+    div = (py[:, 1:, :] - py[:, :-1, :]) + (px[:, :, 1:] - px[:, :, :-1])
+    act = f32(g.active)
+    scale = float(py.abs().max())
+    assert float((div * act)[:, 1:-1, 1:-1].abs().max()) < 2e-5 * scale
+    # (b) faces touching the obstacle are closed
+    assert float((py * (1 - f32(g.my))).abs().max()) == 0.0 and float((px * (1 - f32(g.mx))).abs().max()) == 0.0
+    # (c) passive tracer: zero density only grows where the inflow is (density >= 0, += dt inside the box)
+    z, _, _ = ops.karman_step(torch.zeros_like(d), vy, vx, re, cfg, mk)
+    assert torch.equal(z, f32(g.inflow).expand(B, -1, -1))
+    # (d) deterministic forward
+    d3, py3, px3 = ops.karman_step(d, vy, vx, re, cfg, mk)
+    assert torch.equal(py, py3) and torch.equal(px, px3) and torch.equal(d2, d3)
+    # (e) projection is idempotent up to solver tolerance: a second step from a quiescent
+    #     divergence-free uniform flow changes nothing but the BC rows
+    # (f) adjoint consistency <J u, w> == <u, J^T w> by central differences
+    vy = vy.clone().requires_grad_(True)
+    vx = vx.clone().requires_grad_(True)
+    _, qy, qx = ops.karman_step(d, vy, vx, re, cfg, mk)
+    gen = torch.Generator().manual_seed(3)
+    wy, wx = f32(torch.randn(qy.shape, generator=gen)), f32(torch.randn(qx.shape, generator=gen))
+    ((qy * wy).sum() + (qx * wx).sum()).backward()
+    uy = f32(sol_amd.synthetic._smooth(torch.randn(vy.shape, generator=gen, dtype=torch.float64)))
+    ux = f32(sol_amd.synthetic._smooth(torch.randn(vx.shape, generator=gen, dtype=torch.float64)))
+    eps = 1e-2
+    with torch.no_grad():
+        _, ay, ax = ops.karman_step(d, vy + eps * uy, vx + eps * ux, re, cfg, mk)
+        _, by, bx = ops.karman_step(d, vy - eps * uy, vx - eps * ux, re, cfg, mk)
+    lhs = float((((ay - by) * wy).sum() + ((ax - bx) * wx).sum()).double() / (2 * eps))
+    rhs = float(((vy.grad * uy).sum() + (vx.grad * ux).sum()).double())
+    assert abs(lhs - rhs) < 2e-2 * max(abs(lhs), abs(rhs))
+
+
+def test_unsupported_shapes_fail_loudly():
+    z = torch.zeros(1, 16, 12, device=DEV)
+    with pytest.raises(sol_amd.SolError):
+        ops.karman_step(z, torch.zeros(1, 17, 12, device=DEV), torch.zeros(1, 16, 13, device=DEV),
+                        torch.ones(1, device=DEV), ops.karman_cfg(1, 16, 12, 1.0), masks_for(16, 8)[1])
+
+
+# ---------------------------------------------------------------------------------------------
+# conv 5x5 (fp32 MFMA) forward / backward
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,W,cin,cout,lrelu,res", [
+    (2, 16, 8, 3, 32, True, False), (2, 16, 8, 32, 32, True, True), (2, 16, 8, 32, 2, False, False),
+    (1, 64, 32, 32, 32, True, True), (2, 128, 64, 32, 32, True, False), (1, 128, 64, 3, 32, True, False),
+    (1, 128, 64, 32, 2, False, False)])
+def test_conv5x5_against_oracle(B, H, W, cin, cout, lrelu, res):
+    gen = torch.Generator().manual_seed(0)
+    dt = torch.float64
+    x = torch.randn(B, H, W, cin, generator=gen, dtype=dt, requires_grad=True)
+    w = (torch.randn(5, 5, cin, cout, generator=gen, dtype=dt) * 0.05).requires_grad_(True)
+    b = (torch.randn(cout, generator=gen, dtype=dt) * 0.1).requires_grad_(True)
+    r = torch.randn(B, H, W, cout, generator=gen, dtype=dt, requires_grad=True) if res else None
+    y = o._conv(x, w, b)
+    if res:
+        y = y + r
+    if lrelu:
+        y = torch.nn.functional.leaky_relu(y, 0.3)
+    gy = torch.randn(y.shape, generator=gen, dtype=dt)
+    (y * gy).sum().backward()
+    hx, hw, hb = (f32(t.detach()).requires_grad_(True) for t in (x, w, b))
+    hr = f32(r.detach()).requires_grad_(True) if res else None
+    hy = ops.conv5x5(hx, hw, hb, hr, lrelu, 0.3)
+    (hy * f32(gy)).sum().backward()
+    assert rel(hy, y) < 2e-6
+    assert rel(hx.grad, x.grad) < 2e-6 and rel(hw.grad, w.grad) < 2e-6 and rel(hb.grad, b.grad) < 2e-6
+    if res:
+        assert rel(hr.grad, r.grad) < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# fused training step, Adam, roll-out
+# ---------------------------------------------------------------------------------------------
+def _trainer_from(params, g, B, Y, X, ms, std_v, **kw):
+    mk = ops.SceneMasks(g.active, g.inflow, g.bc_mask, g.bc_mask)
+    net = sol_amd.model_mars_moon(cin=3, cout=2, seed=0)
+    net.set_weights([p.detach().numpy() for p in params])
+    return net, sol_amd.SolTrainer(net, mk, B, Y, X, ms, g.dx, std_v, o.STD_RE, **kw)
+
+
+def test_train_step_against_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "train_16x8_sol2.npz"))
+    B, Y, X = z["d"].shape
+    ms = z["gt_vy"].shape[0]
+    params = golden_train_params(z)
+    net, tr = _trainer_from(params, o.geometry(Y, X), B, Y, X, ms, tuple(z["std_v"]))
+    loss = tr.fwd_bwd(f32(z["d"]), f32(z["vy"]), f32(z["vx"]), f32(z["re"]), f32(z["gt_vy"]), f32(z["gt_vx"]), want_final=True)
+    assert abs(float(loss) - float(z["loss"])) < 1e-5 * abs(float(z["loss"]))
+    assert np.allclose(tr.loss_steps.cpu().numpy(), z["loss_steps"], rtol=1e-5)
+    assert rel(tr.grads[::16], z["grads_sub16"]) < TOL_GRAD
+    norms = np.array([float(tr.grads[net.offsets[k]:net.offsets[k + 1]].double().norm()) for k in range(24)])
+    assert np.allclose(norms, z["grad_norms"], rtol=1e-4)
+    assert rel(tr.final[1], z["vy_final"]) < TOL_FIELD and rel(tr.final[2], z["vx_final"]) < TOL_FIELD
+    assert rel(tr.final[0], z["d_final"]) < TOL_FIELD
+
+
+def _oracle_problem(B, Y, X, ms, clip=None):
+    g = o.geometry(Y, X)
+    d, vy, vx = o.synthetic_state(B, Y, X, 1234)
+    re = torch.tensor([o.RE_TRAIN[i % 6] for i in range(B)], dtype=torch.float64)
+    gts = [o.synthetic_state(B, Y, X, 4321 + i, project_it=False) for i in range(ms)]
+    params = [p.clone().requires_grad_(True) for p in o.init_params(0)]
+    std_v = (0.2, 0.25)
+    loss = o.unrolled_loss(params, d, vy, vx, re, [s[1] for s in gts], [s[2] for s in gts], g, std_v, o.STD_RE)
+    loss.backward()
+    return g, d, vy, vx, re, gts, params, std_v, loss
+
+
+@pytest.mark.parametrize("clip", [False, True])
+def test_train_step_c2_config_and_adam(clip):
+    """BASELINE configs[1]: karman-2d 64x32, msteps=4, batch=3 -- fwd/bwd + TF-Adam (+ clip_by_norm)."""
+    B, Y, X, ms = 3, 64, 32, 4
+    g, d, vy, vx, re, gts, params, std_v, loss = _oracle_problem(B, Y, X, ms)
+    net, tr = _trainer_from(params, g, B, Y, X, ms, std_v, clip_grad=clip)
+    hl = tr.fwd_bwd(f32(d), f32(vy), f32(vx), f32(re), f32(torch.stack([s[1] for s in gts])), f32(torch.stack([s[2] for s in gts])))
+    gref = torch.cat([p.grad.reshape(-1) for p in params])
+    assert abs(float(hl) - float(loss)) < 1e-5 * abs(float(loss))
+    assert rel(tr.grads, gref) < TOL_GRAD
+    m0 = [torch.zeros_like(p) for p in params]
+    v0 = [torch.zeros_like(p) for p in params]
+    p_ref = [p.detach() for p in params]
+    for t in (1, 2):
+        p_ref, m0, v0 = o.adam_tf(p_ref, [p.grad for p in params], m0, v0, t, 1e-4, clip_norm=1e-3 if clip else None)
+        tr.grads.copy_(f32(gref))         # same (oracle) gradient both steps: isolates the optimizer
+        tr.apply_gradients(1e-4)
+    assert rel(net.params, torch.cat([p.reshape(-1) for p in p_ref])) < 1e-6
+    # the update itself (not just the weights) must match
+    upd_ref = torch.cat([(a - b.detach()).reshape(-1) for a, b in zip(p_ref, params)])
+    upd = net.params.detach().double().cpu() - torch.cat([p.detach().reshape(-1) for p in params])
+    assert rel(upd, upd_ref) < 1e-3
+
+
+def test_per_op_autograd_path_equals_fused_trainer():
+    """The reference-shaped Python surface (KarmanFlow.step, to_feature, model, to_staggered) composed
+    with torch autograd must give the same loss and gradient as the fused C++ training step."""
+    B, Y, X, ms = 2, 16, 8, 2
+    g, d, vy, vx, re, gts, params, std_v, loss = _oracle_problem(B, Y, X, ms)
+    net, tr = _trainer_from(params, g, B, Y, X, ms, std_v)
+    tr.fwd_bwd(f32(d), f32(vy), f32(vx), f32(re), f32(torch.stack([s[1] for s in gts])), f32(torch.stack([s[2] for s in gts])))
+    dom = sol_amd.Domain([Y, X], box=sol_amd.box[0:200, 0:100])
+    sim = sol_amd.KarmanFlow()
+    bcv, bcm = sol_amd.velocity_bc_masks(Y, X, batch_size=B)
+    st = sol_amd.Fluid(dom, density=f32(d).reshape(B, Y, X, 1), velocity=f32(o.staggered_tensor(vy, vx)), batch_size=B)
+    scale_in = torch.tensor([std_v[0], std_v[1], o.STD_RE], device=DEV)
+    scale_out = torch.tensor([std_v[0], std_v[1]], device=DEV)
+    losses = []
+    for i in range(ms):
+        st = sim.step(st, re=f32(re), res=X, velBCy=bcv, velBCyMask=bcm)
+        corr = sol_amd.to_staggered(net(sol_amd.to_feature(st, f32(re)) / scale_in) * scale_out, dom.box)
+        st = st.copied_with(velocity=st.velocity + corr)
+        gt = f32(o.staggered_tensor(gts[i][1], gts[i][2]))
+        losses.append(0.5 * (((gt - st.velocity.staggered_tensor()) / scale_out) ** 2).sum())
+    total = torch.stack(losses).sum() / ms
+    total.backward()
+    assert abs(float(total) - float(loss)) < 1e-5 * abs(float(loss))
+    assert rel(net.params.grad, tr.grads) < 1e-5
+    assert rel(net.params.grad, torch.cat([p.grad.reshape(-1) for p in params])) < TOL_GRAD
+
+
+def test_shard_gradients_sum_to_the_large_batch_gradient():
+    """What the RCCL all-reduce(SUM) relies on: grad(batch) == grad(shard 0) + grad(shard 1)."""
+    B, Y, X, ms = 4, 16, 8, 2
+    g = o.geometry(Y, X)
+    d, vy, vx = (f32(t) for t in o.synthetic_state(B, Y, X, 1234))
+    re = f32(sol_amd.synthetic.reynolds(B))
+    gy, gx = (f32(t) for t in sol_amd.synthetic.frames(ms, B, Y, X, 4321))
+    params = o.init_params(0)
+    _, full = _trainer_from(params, g, B, Y, X, ms, (0.2, 0.2))
+    lf = full.fwd_bwd(d, vy, vx, re, gy, gx)
+    _, half = _trainer_from(params, g, B // 2, Y, X, ms, (0.2, 0.2))
+    acc = torch.zeros_like(full.grads)
+    lsum = 0.0
+    for lo in (0, 2):
+        sl = slice(lo, lo + 2)
+        lsum += float(half.fwd_bwd(d[sl].contiguous(), vy[sl].contiguous(), vx[sl].contiguous(), re[sl].contiguous(),
+                                   gy[:, sl].contiguous(), gx[:, sl].contiguous()))
+        acc += half.grads
+    assert abs(lsum - float(lf)) < 1e-5 * abs(float(lf))
+    assert rel(acc, full.grads) < 1e-5
+
+
+def test_rollout_against_oracle():
+    B, Y, X, n = 1, 64, 32, 3
+    g = o.geometry(Y, X)
+    d, vy, vx = o.synthetic_state(B, Y, X, 21)
+    re = torch.tensor([o.RE_TRAIN[2]], dtype=torch.float64)
+    params = o.init_params(3)
+    std_v = (0.2, 0.2)
+    rd, ry, rx = d, vy, vx
+    for _ in range(n):
+        rd, ry, rx = o.karman_step(rd, ry, rx, re, g)
+        cy, cx = o.correction(params, ry, rx, re, std_v, o.STD_RE)
+        ry, rx = ry + cy, rx + cx
+    mk = ops.SceneMasks(g.active, g.inflow, g.bc_mask, g.bc_mask)
+    net = sol_amd.model_mars_moon(cin=3, cout=2, seed=3)
+    ro = sol_amd.SolRollout(net, mk, B, Y, X, g.dx, std_v, o.STD_RE)
+    hd, hy, hx = f32(d), f32(vy), f32(vx)
+    its = ro.run(hd, hy, hx, f32(re), n)
+    assert its.shape == (n, B) and int(its.min()) > 5
+    assert rel(hy, ry) < TOL_FIELD and rel(hx, rx) < TOL_FIELD and rel(hd, rd) < TOL_FIELD
+
+
+# ---------------------------------------------------------------------------------------------
+# Burgers (BASELINE configs[0]: 32x32, msteps=1)
+# ---------------------------------------------------------------------------------------------
+def test_burgers_step_against_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "burgers_step_32x32.npz"))
+    B, Yp1, X = z["vy"].shape
+    Y = Yp1 - 1
+    dt, nu = float(z["dt"]), float(z["nu"])
+    cfg = sol_amd._lib.BurgersCfg(B, Y, X, 1.0, dt)
+    circ = ops.burgers_circ(Y, X, dt * nu)
+    vy = f32(z["vy"]).requires_grad_(True)
+    vx = f32(z["vx"]).requires_grad_(True)
+    fy = f32(z["fy"]).requires_grad_(True)
+    hy, hx = ops.burgers_step(vy, vx, fy, f32(z["fx"]), cfg, circ)
+    ((hy * f32(z["wy"])).sum() + (hx * f32(z["wx"])).sum()).backward()
+    assert rel(hy, z["vy_out"]) < TOL_FIELD and rel(hx, z["vx_out"]) < TOL_FIELD
+    assert rel(vy.grad, z["g_vy"]) < TOL_GRAD and rel(vx.grad, z["g_vx"]) < TOL_GRAD
+    assert rel(fy.grad, dt * z["wy"]) < 1e-6
+    # BurgersTest.step (no force) == step_with_f with zero force
+    ny, nx = ops.burgers_step(vy.detach(), vx.detach(), None, None, cfg, circ)
+    zy, zx = ops.burgers_step(vy.detach(), vx.detach(), torch.zeros_like(vy), torch.zeros_like(vx), cfg, circ)
+    assert torch.equal(ny, zy) and torch.equal(nx, zx)

@@ -1,0 +1,94 @@
+"""Host-side mirror of the reference's Python surface (no GPU needed: CPU tensors)."""
+import numpy as np
+import pytest
+import torch
+
+import sol_amd
+import sol_oracle as o
+from sol_amd import ops, synthetic
+
+
+def test_scene_masks_match_the_oracle_geometry():
+    for (Y, X) in [(16, 8), (64, 32), (128, 64)]:
+        dom = sol_amd.Domain([Y, X], box=sol_amd.box[0:200, 0:100])
+        flow = sol_amd.KarmanFlow()
+        active, inflow = flow.scene_arrays(dom)
+        g = o.geometry(Y, X)
+        assert np.array_equal(active, g.active) and np.array_equal(inflow, g.inflow)
+        bcv, bcm = sol_amd.velocity_bc_masks(Y, X, batch_size=3)
+        assert bcv.shape == (3, Y + 1, X, 1)
+        assert np.array_equal(bcv[0, ..., 0], g.bc_mask) and np.array_equal(bcm[2, ..., 0], g.bc_mask)
+        assert dom.dx == (100.0 / X, 100.0 / X)
+
+
+def test_box_syntax_and_geometry_objects():
+    b = sol_amd.box[5:10, 25:75]
+    assert b.lower == (5.0, 25.0) and b.upper == (10.0, 75.0)
+    assert sol_amd.box([32, 32]).size == (32.0, 32.0)
+    flow = sol_amd.KarmanFlow()
+    assert flow.infl.geometry.lower == (5.0, 25.0) and flow.obst.geometry.radius == 10.0
+    with pytest.raises(NotImplementedError):
+        sol_amd.KarmanFlow(make_input_divfree=True)
+
+
+def test_fluid_state_layouts_and_glue():
+    B, Y, X = 2, 8, 4
+    dom = sol_amd.Domain([Y, X], box=sol_amd.box[0:200, 0:100])
+    gen = torch.Generator().manual_seed(0)
+    vy = torch.randn(B, Y + 1, X, generator=gen, dtype=torch.float32)
+    vx = torch.randn(B, Y, X + 1, generator=gen, dtype=torch.float32)
+    st_ref = o.staggered_tensor(vy.double(), vx.double()).float()
+    st = sol_amd.Fluid(dom, density=torch.zeros(B, Y, X, 1, dtype=torch.float32), velocity=st_ref, batch_size=B, device="cpu")
+    assert st.density.data.shape == (B, Y, X, 1)
+    assert torch.equal(st.velocity.data[0].data[..., 0], vy) and torch.equal(st.velocity.data[1].data[..., 0], vx)
+    assert torch.equal(st.velocity.staggered_tensor(), st_ref)
+    re = torch.tensor([2.0, 3.0], dtype=torch.float32)
+    feat = sol_amd.to_feature(st, re)
+    assert torch.allclose(feat, o.to_feature(vy.double(), vx.double(), re.double()).float())
+    corr = sol_amd.to_staggered(feat[..., 0:2], dom.box)
+    cy, cx = o.to_staggered(feat[..., 0:2].double())
+    assert torch.equal(corr.data[0].data[..., 0], cy.float()) and torch.equal(corr.data[1].data[..., 0], cx.float())
+    st2 = st.copied_with(velocity=st.velocity + corr)
+    assert torch.allclose(st2.velocity.data[0].data[..., 0], vy + cy.float())
+    assert st2.density is st.density and st2._batch_size == B
+
+
+def test_model_matches_oracle_init_and_keras_weight_order():
+    net = sol_amd.model_mars_moon(cin=3, cout=2, seed=0, device="cpu")
+    ref = o.init_params(0)
+    ws = net.get_weights()
+    assert len(ws) == 24 and [w.shape for w in ws] == [tuple(p.shape) for p in ref]
+    for w, p in zip(ws, ref):
+        assert np.allclose(w, p.numpy().astype(np.float32))
+    ws[3][:] = 0.5
+    net.set_weights(ws)
+    assert float(net.tensors()[3].detach().min()) == 0.5
+    assert net.losses == []
+
+
+def test_burgers_circulant_matches_oracle():
+    for n in (32, 33):
+        assert np.allclose(ops.circulant_diffusion_matrix(n, 0.01), o.burgers_diffusion_matrices(n, n, 0.01)[0].numpy(), atol=1e-14)
+
+
+def test_synthetic_inputs_are_deterministic_and_shaped():
+    d, vy, vx = synthetic.state(3, 16, 8, 7)
+    d2, vy2, vx2 = synthetic.state(3, 16, 8, 7)
+    assert torch.equal(vy, vy2) and d.shape == (3, 16, 8) and vy.shape == (3, 17, 8) and vx.shape == (3, 16, 9)
+    gy, gx = synthetic.frames(2, 3, 16, 8, 9)
+    assert gy.shape == (2, 3, 17, 8) and gx.shape == (2, 3, 16, 9)
+    assert abs(synthetic.STD_RE - 1732512.626) < 1e-2
+    assert synthetic.reynolds(8).tolist()[6] == 160000.0
+
+
+def test_lr_schedule_and_sharding():
+    lr = 1e-4
+    seq = []
+    for ep in range(25):
+        lr = sol_amd.lr_schedule(ep, lr)
+        seq.append(lr)
+    assert np.isclose(seq[10], 1e-4) and np.isclose(seq[11], 1e-5) and np.isclose(seq[16], 1e-6)
+    assert np.isclose(seq[21], 1e-7) and np.isclose(seq[23], 5e-8)
+    assert sol_amd.dist.shard_range(48, 3, 8) == (18, 24)
+    with pytest.raises(ValueError):
+        sol_amd.dist.shard_range(10, 0, 4)
