@@ -15,6 +15,7 @@
 // The K index inside one MFMA is permuted (k-step kk of lane group g uses channel 8g+kk);
 // A and B use the same permutation so the product is unchanged.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -292,6 +293,182 @@ __global__ void __launch_bounds__(256) k_conv5x5_c32(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// W % 64 == 0 variant: three independent 64-pixel row tiles per workgroup (768 threads = 12
+// waves = 3 per SIMD, one workgroup per CU at C3) that SHARE the staged weights.  A row tile
+// needs exactly one halo row per tap row dy, so the halo is a 2-slot ring (17 KB per tile) and
+// the weights of a whole tap row (5 taps, 20 KB) are double buffered: ONE barrier per 5 taps
+// (5 per launch instead of 25) and 80 back-to-back MFMAs per wave between barriers.
+// ------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(768) k_conv5x5_r3(ConvArgs a, int ntiles) {
+    constexpr int OP = NT * 16;
+    constexpr int HWP = 68;                       // halo pixels per row (64 + 4)
+    constexpr int SLOT = HWP * 32;                // floats per halo row
+    constexpr int WBUF = 5 * OP * 32;             // floats per weight phase
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = tid & 63, wave = (tid >> 6) & 3;
+    const int g = lane >> 4, li = lane & 15;
+    const int H = a.H, W = a.W;
+    const int tile = blockIdx.x * 3 + grp;
+    const bool tvalid = tile < ntiles;
+    const int tx = tvalid ? tile % a.tiles_x : 0;
+    const int gy = tvalid ? tile / a.tiles_x : 0;     // global row index b*H + y
+    const int b = gy / H, y = gy - b * H, x0 = tx * 64;
+    float* halo = smem + grp * 2 * SLOT;              // [2][68][32] swizzled, private to the tile
+    float* Wt = smem + 3 * 2 * SLOT;                  // [2][5][OP][32] swizzled, shared
+    const float4* gx = reinterpret_cast<const float4*>(a.x);
+    const float4* gw = reinterpret_cast<const float4*>(a.wp);
+    constexpr int HPT = 3;                            // 544 float4 per halo row / 256 threads
+    constexpr int WPT = (5 * OP * 8 + 767) / 768;     // float4 per thread per weight phase
+
+    auto load_row = [&](int dy, float4 (&v)[HPT]) {
+        const int yy = y + dy - 2;
+#pragma unroll
+        for (int n = 0; n < HPT; ++n) {
+            const int e = t + n * 256;
+            v[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < HWP * 8) {
+                const int hc = e >> 3, c4 = e & 7, xx = x0 + hc - 2;
+                if (tvalid && yy >= 0 && yy < H && xx >= 0 && xx < W) v[n] = gx[((size_t)(b * H + yy) * W + xx) * 8 + c4];
+            }
+        }
+    };
+    auto store_row = [&](int slot, const float4 (&v)[HPT]) {
+        float* dst = halo + slot * SLOT;
+#pragma unroll
+        for (int n = 0; n < HPT; ++n) {
+            const int e = t + n * 256;
+            if (e < HWP * 8) {
+                const int hc = e >> 3, c4 = e & 7;
+                *reinterpret_cast<float4*>(&dst[hc * 32 + ((c4 ^ swz(hc)) << 2)]) = v[n];
+            }
+        }
+    };
+    auto load_w = [&](int dy, float4 (&v)[WPT]) {
+#pragma unroll
+        for (int n = 0; n < WPT; ++n) {
+            const int e = tid + n * 768;
+            v[n] = e < 5 * OP * 8 ? gw[(size_t)dy * (5 * OP * 8) + e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_w = [&](int buf, const float4 (&v)[WPT]) {
+        float* dst = Wt + buf * WBUF;
+#pragma unroll
+        for (int n = 0; n < WPT; ++n) {
+            const int e = tid + n * 768;
+            if (e < 5 * OP * 8) {
+                const int c4 = e & 7, rowi = e >> 3;           // rowi = tapl*OP + co
+                const int co = rowi % OP;
+                *reinterpret_cast<float4*>(&dst[rowi * 32 + ((c4 ^ swz(co)) << 2)]) = v[n];
+            }
+        }
+    };
+
+    {   // prologue: tap row 0
+        float4 hv[HPT];
+        float4 wv[WPT];
+        load_row(0, hv);
+        load_w(0, wv);
+        store_row(0, hv);
+        store_w(0, wv);
+    }
+    __syncthreads();
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int pcc = wave * 16 + li;                   // this lane's A-row pixel inside the tile
+
+#pragma unroll 1
+    for (int dy = 0; dy < 5; ++dy) {
+        float4 hv[HPT];
+        float4 wv[WPT];
+        if (dy < 4) {
+            load_row(dy + 1, hv);
+            load_w(dy + 1, wv);
+        }
+        const float* hrow = halo + (dy & 1) * SLOT;
+        const float* wbuf = Wt + (dy & 1) * WBUF;
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+            const int hc = pcc + dx;
+            const float* ap = hrow + hc * 32;
+            const int sa = swz(hc);
+            const float4 a0 = *reinterpret_cast<const float4*>(ap + ((g ^ sa) << 2));
+            const float4 a1 = *reinterpret_cast<const float4*>(ap + (((g + 4) ^ sa) << 2));
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int co = n * 16 + li;
+                const float* bp = wbuf + (dx * OP + co) * 32;
+                const int sb = swz(co);
+                const float4 b0 = *reinterpret_cast<const float4*>(bp + ((g ^ sb) << 2));
+                const float4 b1 = *reinterpret_cast<const float4*>(bp + (((g + 4) ^ sb) << 2));
+                const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk)
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[kk], acc[n], 0, 0, 0);
+            }
+        }
+        if (dy < 4) {
+            store_row((dy + 1) & 1, hv);
+            store_w((dy + 1) & 1, wv);
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: transpose the wave's [16 px][OP] tile through LDS (the tile's halo ring is free
+    //      after the last barrier) so that every lane moves 16-byte pieces of full 128-byte pixels ----
+    if (a.CO == OP) {
+        float* tb = halo + wave * (16 * OP);              // 16 px x OP floats per wave
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const float bias = a.bias ? a.bias[n * 16 + li] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tb[(4 * g + r) * OP + n * 16 + li] = acc[n][r] + bias;
+        }
+        // same-wave LDS round trip: the compiler's s_waitcnt lgkmcnt orders write -> read
+        if (tvalid) {
+            constexpr int F4 = 16 * OP / 4 / 64;          // float4 per lane
+#pragma unroll
+            for (int n = 0; n < F4; ++n) {
+                const int e = lane + n * 64;              // float4 index inside the tile
+                const int px = e / (OP / 4), c4 = e % (OP / 4);
+                float4 v = *reinterpret_cast<const float4*>(&tb[px * OP + c4 * 4]);
+                const size_t o4 = ((size_t)gy * W + x0 + wave * 16 + px) * (OP / 4) + c4;
+                if (a.res) { const float4 q = reinterpret_cast<const float4*>(a.res)[o4]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+                if (a.epi == SOL_EPI_LRELU) {
+                    v.x = v.x > 0.f ? v.x : a.slope * v.x; v.y = v.y > 0.f ? v.y : a.slope * v.y;
+                    v.z = v.z > 0.f ? v.z : a.slope * v.z; v.w = v.w > 0.f ? v.w : a.slope * v.w;
+                } else if (a.epi == SOL_EPI_DLRELU) {
+                    const float4 q = reinterpret_cast<const float4*>(a.act)[o4];
+                    v.x *= q.x > 0.f ? 1.f : a.slope; v.y *= q.y > 0.f ? 1.f : a.slope;
+                    v.z *= q.z > 0.f ? 1.f : a.slope; v.w *= q.w > 0.f ? 1.f : a.slope;
+                }
+                reinterpret_cast<float4*>(a.y)[o4] = v;
+            }
+        }
+        return;
+    }
+    if (!tvalid) return;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = n * 16 + li;
+        if (co >= a.CO) continue;
+        const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cc = wave * 16 + 4 * g + r;
+            const size_t o = ((size_t)gy * W + x0 + cc) * a.CO + co;
+            float v = acc[n][r] + bias;
+            if (a.res) v += a.res[o];
+            if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
+            else if (a.epi == SOL_EPI_DLRELU) v *= (a.act[o] > 0.f ? 1.f : a.slope);
+            a.y[o] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // backward-weight
 // ------------------------------------------------------------------------------------
 // Workgroup (dy, row block): accumulates dW[dy][0..4][ci][co] over RB image rows in MFMA
@@ -443,6 +620,108 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww(BwArgs a) {
     }
 }
 
+// 32x32-channel, W == 64 variant on v_mfma_f32_32x32x2_f32: the whole [ci 32][co 32] tile of a tap
+// is ONE accumulator (A[i=ci][k=px], B[k=px][j=co]; lanes 0-31 / 32-63 take two consecutive pixels),
+// so both operands are conflict-free ds_read_b32 straight from the NHWC rows -- no transpose, no
+// padding, 6 LDS reads per 5 MFMAs of 64 cycles.  The 4 waves split the 64 pixels of a row (K split)
+// and fold their accumulators through LDS once at the end.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(256) k_conv5x5_bww32(BwArgs a) {
+    constexpr int W = 64, STG = (W + 4) * 32 + W * 32;      // floats per stage: x row (68 px) + dz row
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, kpx = lane >> 5;
+    const int H = a.H;
+    const int dy = blockIdx.x % 5, blk = blockIdx.x / 5;
+    f32x16 acc[5];
+#pragma unroll
+    for (int d = 0; d < 5; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+    float bsum = 0.f;
+    const int R = a.B * H;
+    const int gr_end = min((blk + 1) * RB, R);
+    auto row_valid = [&](int gr) { const int y = gr % H, yy = y + dy - 2; return yy >= 0 && yy < H; };
+    auto next_row = [&](int gr) { while (gr < gr_end && !(dy == 2 || row_valid(gr))) ++gr; return gr; };
+    float4 xr[3], zr[2];
+    auto load_row = [&](int gr) {
+        const int b = gr / H, y = gr - b * H, yy = y + dy - 2;
+        const bool valid = yy >= 0 && yy < H;
+        const float4* gx = reinterpret_cast<const float4*>(a.x) + (size_t)(b * H + (valid ? yy : 0)) * W * 8;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const int e = tid + n * 256, px = e >> 3, c4 = e & 7, xx = px - 2;
+            xr[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid && px < W + 4 && xx >= 0 && xx < W) xr[n] = gx[xx * 8 + c4];
+        }
+        const float4* gz = reinterpret_cast<const float4*>(a.dz) + (size_t)(b * H + y) * W * 8;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) zr[n] = gz[tid + n * 256];
+    };
+    auto store_row = [&](float* buf) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const int e = tid + n * 256;
+            if (e < (W + 4) * 8) reinterpret_cast<float4*>(buf)[e] = xr[n];
+        }
+        float4* zs4 = reinterpret_cast<float4*>(buf + (W + 4) * 32);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) zs4[tid + n * 256] = zr[n];
+    };
+    int gr = next_row(blk * RB);
+    int cur = 0;
+    if (gr < gr_end) { load_row(gr); store_row(smem); }
+    __syncthreads();
+    while (gr < gr_end) {
+        const int gnext = next_row(gr + 1);
+        if (gnext < gr_end) load_row(gnext);
+        const bool valid = row_valid(gr);
+        const float* xs = smem + cur * STG + (16 * wave + kpx) * 32 + c;
+        const float* zs = smem + cur * STG + (W + 4) * 32 + (16 * wave + kpx) * 32 + c;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const float bv = zs[ks * 64];
+            if (dy == 2) bsum += bv;
+            if (valid) {
+#pragma unroll
+                for (int d = 0; d < 5; ++d)
+                    acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[(2 * ks + d) * 32], bv, acc[d], 0, 0, 0);
+            }
+        }
+        if (gnext < gr_end) store_row(smem + (cur ^ 1) * STG);
+        __syncthreads();
+        cur ^= 1;
+        gr = gnext;
+    }
+    // fold the 4 K-split accumulators through LDS, one tap at a time, into this block's partial slice
+    float* red = smem;                                  // [4][32][32]
+    float* pw = a.partial + (size_t)blk * (25 * 1024);
+    for (int d = 0; d < 5; ++d) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kpx;
+            red[wave * 1024 + row * 32 + c] = acc[d][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int idx = tid + n * 256;
+            pw[(dy * 5 + d) * 1024 + idx] += (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
+        }
+        __syncthreads();
+    }
+    if (dy == 2) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (kpx == 0) red[wave * 32 + c] = bsum;
+        __syncthreads();
+        if (tid < 32) {
+            float* pb = a.partial + (size_t)a.nblk * (25 * 1024) + (size_t)blk * 32;
+            pb[tid] += (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]);
+        }
+    }
+}
+
 __global__ void k_bww_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
                              int nblk, int cin, int cout, int IP, int OP, int accumulate) {
     const int nw = 25 * cin * cout;
@@ -505,7 +784,19 @@ extern "C" int sol_conv5x5(void* stream, const float* x, const float* packed, co
     const size_t lds = (size_t)(a.RPW + 4) * (a.TW + 4) * CP * sizeof(float);
     const int NT = pad_out(cout) / 16;
     hipStream_t s = (hipStream_t)stream;
-    if (cin == 32) {
+    if (cin == 32 && W % 64 == 0 && !getenv("SOL_CONV_NO_R3")) {
+        const int ntiles = B * H * (W / 64);
+        const size_t ldsr = ((size_t)3 * 2 * 68 * 32 + 2 * (size_t)5 * NT * 16 * 32) * sizeof(float);
+        const int grid3 = (ntiles + 2) / 3;
+        if (NT == 2) {
+            SOL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv5x5_r3<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
+            hipLaunchKernelGGL((k_conv5x5_r3<2>), dim3(grid3), dim3(768), ldsr, s, a, ntiles);
+        } else {
+            SOL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv5x5_r3<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
+            hipLaunchKernelGGL((k_conv5x5_r3<1>), dim3(grid3), dim3(768), ldsr, s, a, ntiles);
+        }
+    }
+    else if (cin == 32) {
         const size_t lds32 = ((size_t)(a.RPW + 4) * (a.TW + 4) * 32 + 2 * (size_t)NT * 16 * 32) * sizeof(float);
         if (NT == 2) {
             SOL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv5x5_c32<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
@@ -548,7 +839,11 @@ extern "C" int sol_conv5x5_bwd_weight(void* stream, const float* x, const float*
     const size_t lds = 2 * ((size_t)(W + 4) * CPX + (size_t)W * CPZ) * sizeof(float);   // double buffered rows
     const int grid = a.nblk * 5;
     hipStream_t s = (hipStream_t)stream;
-    if (cin == 32 && cout == 32) hipLaunchKernelGGL((k_conv5x5_bww<32, 32>), dim3(grid), dim3(256), lds, s, a);
+    if (cin == 32 && cout == 32 && W == 64 && !getenv("SOL_CONV_NO_BWW32")) {
+        const size_t lds3 = 2 * ((size_t)(64 + 4) * 32 + 64 * 32) * sizeof(float);
+        hipLaunchKernelGGL(k_conv5x5_bww32, dim3(grid), dim3(256), lds3, s, a);
+    }
+    else if (cin == 32 && cout == 32) hipLaunchKernelGGL((k_conv5x5_bww<32, 32>), dim3(grid), dim3(256), lds, s, a);
     else if (cin == 32 && cout == 2) hipLaunchKernelGGL((k_conv5x5_bww<32, 2>), dim3(grid), dim3(256), lds, s, a);
     else if (cin == 4 && cout == 32) hipLaunchKernelGGL((k_conv5x5_bww<4, 32>), dim3(grid), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((k_conv5x5_bww<4, 2>), dim3(grid), dim3(256), lds, s, a);
