@@ -28,6 +28,7 @@ def parse():
     p.add_argument("--res", type=int, default=64, help="cells in x (Y = 2*res)")
     p.add_argument("--batch", type=int, default=6, help="simulations per GPU")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-graph", action="store_true", help="launch the ~1000 kernels of a step eagerly instead of replaying the hipGraph")
     p.add_argument("--cpu-msteps", type=int, default=2, help="msteps of the bounded CPU-baseline sample")
     return p.parse_args()
 
@@ -86,13 +87,13 @@ def main():
     masks = ops.SceneMasks(active, inflow, bcv.reshape(Y + 1, X), bcm.reshape(Y + 1, X), dev)
     net = sol_amd.model_mars_moon(cin=3, cout=2, seed=0, device=dev)
     std_v = (0.2, 0.2)
-    tr = sol_amd.SolTrainer(net, masks, B, Y, X, ms, dom.dx[1], std_v, synthetic.STD_RE)
+    tr = sol_amd.SolTrainer(net, masks, B, Y, X, ms, dom.dx[1], std_v, synthetic.STD_RE, use_graph=not args.no_graph)
 
     f = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
     d0, vy0, vx0 = (f(t) for t in synthetic.state(B, Y, X, 1234 + rank))
     re = f(synthetic.reynolds(B))
     # spin-up: one solver step makes the random start state divergence free / consistent
-    cfgk = ops.karman_cfg(B, Y, X, dom.dx[1])
+    cfgk = ops.karman_cfg(B, Y, X, dom.dx[1], masks=masks)
     d0, vy0, vx0 = (t.detach().contiguous() for t in ops.karman_step(d0, vy0, vx0, re, cfgk, masks))
     # ground truth = plain solver roll-out of a slightly perturbed start state: the loss and its
     # gradients are non-zero but the training dynamics stay physical (random frames as targets

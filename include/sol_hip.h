@@ -57,14 +57,22 @@ typedef struct sol_karman_cfg {
     int32_t grad_pad;       /* 0: replicate (PhiFlow 1.x), 1: dirichlet0                */
     int32_t inflow_before;  /* 0: density += inflow*dt after advection (phi 1.x),
                                1: before advection (karman-2d-phi2/karman_train.py:182) */
+    int32_t coarse_n;       /* 0, or (Y/8)*(X/8): size of the coarse space of the CG preconditioner */
+    const float* coarse_inv;/* NULL (plain CG), or DEVICE [coarse_n,coarse_n]: inverse of P^T(-A)P for
+                               8x8-cell aggregates P of the scene's `active` mask, prepared by the host
+                               (see sol_karman_precond_supported).  Only the iteration count changes:
+                               the solve still converges to the same tolerance.                      */
 } sol_karman_cfg;
+
+/* 1 if the two-level CG preconditioner can be used for a Y x X grid, else 0 */
+int sol_karman_precond_supported(int32_t Y, int32_t X);
 
 /* active  [Y,X]  1 - obstacle mask (cell centres inside Obstacle geometries -> 0)
  * inflow  [Y,X]  inflow rate mask (Inflow(box[5:10,25:75]) -> 1 inside)
  * velBCy, velBCyMask  [Y+1,X] (bc_batch_stride 0) or [B,Y+1,X] (stride (Y+1)*X)
  * saved_vy/saved_vx: post-diffusion+BC velocity kept for the backward pass (NULL: inference)
  * feat_out [B,Y,X,4] (NULL to skip): fused to_feature (karman_train.py:77-86) scaled by
- *   feat_scale[3] = 1/std (l.416-419); channel 3 is zero padding.
+ *   feat_scale[3] = 1/std (l.416-419), a HOST array; channel 3 is zero padding.
  * iters [B]: CG iterations used per simulation (may be NULL).                           */
 int sol_karman_step_fwd(const sol_karman_cfg* cfg, void* stream,
                         const float* d_in, const float* vy_in, const float* vx_in,
@@ -181,6 +189,25 @@ int sol_train_fwd_bwd(const sol_train_cfg* cfg, void* stream,
                       float* grads, float* loss_steps,
                       float* d_final, float* vy_final, float* vx_final,
                       int32_t* iters_fwd, int32_t* iters_bwd);
+
+/* The same step as a replayable hipGraph: one host call per training step instead of ~1000 kernel
+ * launches.  All pointers are baked in at creation (re-create when a buffer moves); new data is
+ * fed by copying into the same buffers.  Internally the batch is split into chains of
+ * simulations that run on separate HIP streams (env SOL_STREAMS, default = B) so that the
+ * one-CU-per-simulation solver kernels overlap with the chip-wide convolutions.
+ * One training call at a time per process (the chains share an internal stream pool).          */
+typedef struct sol_train_graph sol_train_graph;
+int sol_train_graph_create(const sol_train_cfg* cfg, const float* params,
+                           const float* d0, const float* vy0, const float* vx0, const float* re,
+                           const float* active, const float* inflow,
+                           const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
+                           const float* gt_vy, const float* gt_vx,
+                           void* workspace, size_t workspace_bytes,
+                           float* grads, float* loss_steps,
+                           float* d_final, float* vy_final, float* vx_final,
+                           int32_t* iters_fwd, int32_t* iters_bwd, sol_train_graph** out);
+int sol_train_graph_launch(sol_train_graph* graph, void* stream);
+int sol_train_graph_destroy(sol_train_graph* graph);
 
 /* Forward only (karman_apply.py:138-158 roll-out without the frame dump): runs `nsteps`
  * solver+CNN steps in place of d/vy/vx.  workspace: sol_rollout_workspace_bytes().       */

@@ -25,7 +25,8 @@ class KarmanCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("Y", C.c_int32), ("X", C.c_int32),
                 ("dx", C.c_float), ("dt", C.c_float), ("res", C.c_float),
                 ("cg_rtol", C.c_float), ("cg_atol", C.c_float), ("cg_max_iter", C.c_int32),
-                ("grad_pad", C.c_int32), ("inflow_before", C.c_int32)]
+                ("grad_pad", C.c_int32), ("inflow_before", C.c_int32),
+                ("coarse_n", C.c_int32), ("coarse_inv", C.c_void_p)]
 
 
 class BurgersCfg(C.Structure):
@@ -44,6 +45,7 @@ _P = C.c_void_p
 _SIGS = {
     "sol_last_error": (C.c_char_p, []),
     "sol_version": (C.c_int, []),
+    "sol_karman_precond_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "sol_karman_step_fwd": (C.c_int, [C.POINTER(KarmanCfg), _P] + [_P] * 8 + [C.c_int64] + [_P] * 6 + [C.POINTER(C.c_float), _P]),
     "sol_karman_step_bwd": (C.c_int, [C.POINTER(KarmanCfg), _P] + [_P] * 5 + [C.c_int64] + [_P] * 3 + [C.POINTER(C.c_float)] + [_P] * 3),
     "sol_burgers_step_fwd": (C.c_int, [C.POINTER(BurgersCfg), _P] + [_P] * 10),
@@ -56,6 +58,9 @@ _SIGS = {
     "sol_conv5x5_bwd_weight_reduce": (C.c_int, [_P] * 4 + [C.c_int32] * 6),
     "sol_train_workspace_bytes": (C.c_size_t, [C.POINTER(TrainCfg)]),
     "sol_train_fwd_bwd": (C.c_int, [C.POINTER(TrainCfg), _P] + [_P] * 9 + [C.c_int64] + [_P] * 3 + [C.c_size_t] + [_P] * 7),
+    "sol_train_graph_create": (C.c_int, [C.POINTER(TrainCfg)] + [_P] * 9 + [C.c_int64] + [_P] * 3 + [C.c_size_t] + [_P] * 7 + [C.POINTER(C.c_void_p)]),
+    "sol_train_graph_launch": (C.c_int, [_P, _P]),
+    "sol_train_graph_destroy": (C.c_int, [_P]),
     "sol_rollout_workspace_bytes": (C.c_size_t, [C.POINTER(TrainCfg)]),
     "sol_rollout": (C.c_int, [C.POINTER(TrainCfg), _P] + [_P] * 9 + [C.c_int64, C.c_int32, _P, C.c_size_t, _P]),
     "sol_adam_tf_step": (C.c_int, [_P] * 5 + [C.c_int64, C.c_int32] + [C.c_float] * 5 + [C.POINTER(C.c_int64), C.c_int32, _P]),

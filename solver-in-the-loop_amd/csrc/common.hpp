@@ -8,6 +8,8 @@
 #include "../../include/sol_hip.h"
 
 int sol_set_error(int code, const char* fmt, ...);
+int sol_init_karman_kernels();
+int sol_init_conv_kernels();
 
 #define SOL_HIP_CHECK(expr)                                                                  \
     do {                                                                                     \

@@ -766,6 +766,18 @@ extern "C" int sol_conv5x5_pack(void* stream, const float* w_hwio, int32_t cin, 
     return SOL_OK;
 }
 
+int sol_init_conv_kernels() {
+    static int rc = [] {
+        const void* ks[] = {reinterpret_cast<const void*>(k_conv5x5_r3<1>), reinterpret_cast<const void*>(k_conv5x5_r3<2>),
+                            reinterpret_cast<const void*>(k_conv5x5_c32<1>), reinterpret_cast<const void*>(k_conv5x5_c32<2>)};
+        for (const void* k : ks)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return sol_set_error(SOL_ERR_HIP, "hipFuncSetAttribute(conv kernels) failed");
+        return SOL_OK;
+    }();
+    return rc;
+}
+
 extern "C" int sol_conv5x5(void* stream, const float* x, const float* packed, const float* bias,
                            const float* residual, const float* act_ref, float* y,
                            int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,
@@ -773,6 +785,7 @@ extern "C" int sol_conv5x5(void* stream, const float* x, const float* packed, co
     if (int e = check_shape(B, H, W, cin, cout)) return e;
     SOL_REQUIRE(x && packed && y, "sol_conv5x5: NULL pointer");
     SOL_REQUIRE(epilogue != SOL_EPI_DLRELU || act_ref, "sol_conv5x5: SOL_EPI_DLRELU needs act_ref");
+    if (int e = sol_init_conv_kernels()) return e;
     ConvArgs a{};
     a.x = x; a.wp = packed; a.bias = bias; a.res = residual; a.act = act_ref; a.y = y;
     a.B = B; a.H = H; a.W = W; a.CO = cout; a.epi = epilogue; a.slope = slope;
@@ -789,20 +802,16 @@ extern "C" int sol_conv5x5(void* stream, const float* x, const float* packed, co
         const size_t ldsr = ((size_t)3 * 2 * 68 * 32 + 2 * (size_t)5 * NT * 16 * 32) * sizeof(float);
         const int grid3 = (ntiles + 2) / 3;
         if (NT == 2) {
-            SOL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv5x5_r3<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
             hipLaunchKernelGGL((k_conv5x5_r3<2>), dim3(grid3), dim3(768), ldsr, s, a, ntiles);
         } else {
-            SOL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv5x5_r3<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
             hipLaunchKernelGGL((k_conv5x5_r3<1>), dim3(grid3), dim3(768), ldsr, s, a, ntiles);
         }
     }
     else if (cin == 32) {
         const size_t lds32 = ((size_t)(a.RPW + 4) * (a.TW + 4) * 32 + 2 * (size_t)NT * 16 * 32) * sizeof(float);
         if (NT == 2) {
-            SOL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv5x5_c32<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
             hipLaunchKernelGGL((k_conv5x5_c32<2>), dim3(grid), dim3(256), lds32, s, a);
         } else {
-            SOL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv5x5_c32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
             hipLaunchKernelGGL((k_conv5x5_c32<1>), dim3(grid), dim3(256), lds32, s, a);
         }
     }

@@ -27,8 +27,8 @@ struct StepArgs {
     float dt;
     float adt;     // dt*res*res  -> alpha_b = adt / Re_b   (karman_train.py:175)
     float rtol2, atol2;
-    int max_iter, grad_pad, inflow_before;
-    const float *d_in, *vy_in, *vx_in, *re, *active, *inflow, *bcv, *bcm;
+    int max_iter, grad_pad, inflow_before, dbg;
+    const float *d_in, *vy_in, *vx_in, *re, *active, *inflow, *bcv, *bcm, *cinv;
     long bc_stride;
     float *d_out, *vy_out, *vx_out, *saved_vy, *saved_vx, *feat;
     float fs0, fs1, fs2;
@@ -41,13 +41,13 @@ struct StepArgs {
 __host__ __device__ inline int al4(int n) { return (n + 3) & ~3; }
 
 struct Lds {
-    float *Avy, *Avx, *Bvy, *Bvx, *E, *red;
+    float *Avy, *Avx, *Bvy, *Bvx, *E, *red, *cs;
     unsigned char* act;
 };
 
 __host__ __device__ inline size_t lds_floats(int Y, int X, int cpt) {
     const int nVy = (Y + 1) * X, nVx = Y * (X + 1);
-    return 2 * (size_t)(al4(nVy) + al4(nVx)) + 4 * (size_t)(Y / cpt + 2) * X + 64;
+    return 2 * (size_t)(al4(nVy) + al4(nVx)) + 4 * (size_t)(Y / cpt + 2) * X + 64 + 4 * (size_t)al4(Y * X / 64);
 }
 __host__ inline size_t lds_bytes(int Y, int X, int cpt) { return lds_floats(Y, X, cpt) * 4 + (size_t)al4(Y * X); }
 
@@ -60,7 +60,8 @@ __device__ inline Lds carve(float* smem, int Y, int X, int cpt) {
     l.Bvx = l.Bvy + al4(nVy);
     l.E = l.Bvx + al4(nVx);
     l.red = l.E + 4 * (Y / cpt + 2) * X;
-    l.act = reinterpret_cast<unsigned char*>(l.red + 64);
+    l.cs = l.red + 64;                                    // coarse-space scratch: rc[2], rcM, zc
+    l.act = reinterpret_cast<unsigned char*>(l.cs + 4 * al4(Y * X / 64));
     return l;
 }
 
@@ -248,6 +249,222 @@ __device__ __forceinline__ int cg_solve(const Own& o, int X, const float (&dgf)[
     return it;
 }
 
+// two-value variant of cg_block_sum (one barrier)
+__device__ __forceinline__ void cg_block_sum2(float& v0, float& v1, float* slot) {
+    v0 = row_allsum(v0); v1 = row_allsum(v1);
+    v0 += dpp_mov<0x142, 0xa>(v0); v1 += dpp_mov<0x142, 0xa>(v1);
+    v0 += dpp_mov<0x143, 0xc>(v0); v1 += dpp_mov<0x143, 0xc>(v1);
+    const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v0), 63));
+    const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v1), 63));
+    slot[threadIdx.x >> 6] = s0;
+    slot[16 + (threadIdx.x >> 6)] = s1;
+    __syncthreads();
+    v0 = row_allsum(slot[threadIdx.x & 15]);
+    v1 = row_allsum(slot[16 + (threadIdx.x & 15)]);
+}
+// workgroup max of a non-negative value (one barrier; `slot` = 16 floats, stale entries must be >= 0 and <= result)
+__device__ __forceinline__ float block_max(float v, float* slot) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float m = 0.f;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; ++w) m = fmaxf(m, slot[w]);
+    return m;
+}
+__device__ __forceinline__ float sum8lanes(float v) {   // all-reduce over aligned groups of 8 lanes
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    return v;
+}
+
+// Two-level preconditioned CG.  M^-1 = D^-1 + P (P^T A P)^-1 P^T with piecewise-constant
+// aggregates of 8x8 cells (P) and the dense coarse inverse `cinv_g` [nc,nc] prepared by the host
+// for the scene geometry (nc = Y*X/64 = 128 at 128x64).  The coarse space removes the smooth
+// error modes that make plain CG need ~240 iterations on this grid: ~56 iterations instead, same
+// converged solution.  Still TWO barriers per iteration: the restriction is linear, so
+// P^T r_new = P^T r - alpha P^T(Mp) is formed from block sums published before the alpha barrier;
+// r.z = sum r^2/d + (P^T r).(zc) needs no per-cell z before the beta barrier; each thread keeps its
+// 32-entry slice of a coarse-inverse row in registers (4 threads per coarse row).
+template <int CPT, bool FULLROW, int CC>   // CC = coarse columns per thread = nc / (64/CPT): 32 at 128x64, 8 at 64x32
+__device__ __forceinline__ int pcg_solve(const Own& o, int Y, int X, const unsigned char* act,
+                                         const float (&dgf)[CPT], const float (&acf)[CPT], float (&rf)[CPT], float (&xf)[CPT],
+                                         float* E, float* red, float* cs, const float* __restrict__ cinv_g,
+                                         float rtol2, float atol2, int max_iter) {
+    constexpr int H = CPT / 2, NBS = CPT / 8, TPR = 64 / CPT, CPTc = CC;
+    const int nbx = X >> 3, nc = (Y >> 3) * nbx, ncp = al4(nc);
+    const int tid = threadIdx.x;
+    const int I = tid / TPR, q = tid % TPR;
+    const bool crow = I < nc;
+    f2 dg[H], ac[H], idg[H], r[H], x[H], p[H], Mp[H];
+    bool hasobst = false;
+#pragma unroll
+    for (int qq = 0; qq < H; ++qq) {
+        dg[qq] = (f2){dgf[2 * qq], dgf[2 * qq + 1]};
+        ac[qq] = (f2){acf[2 * qq], acf[2 * qq + 1]};
+        idg[qq] = (f2){1.f / dgf[2 * qq], 1.f / dgf[2 * qq + 1]};
+        r[qq] = (f2){rf[2 * qq], rf[2 * qq + 1]};
+        x[qq] = (f2){0.f, 0.f};
+        hasobst |= (acf[2 * qq] == 0.f) | (acf[2 * qq + 1] == 0.f);
+    }
+    const bool wobst = __ballot(hasobst && o.owner) != 0ull;
+    // this thread's slice of coarse-inverse row I (registers, constant over the solve)
+    f2 cinv[CC / 2];
+#pragma unroll
+    for (int c = 0; c < CC / 4; ++c) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (crow) v = reinterpret_cast<const float4*>(cinv_g + (size_t)I * nc + q * CC)[c];
+        cinv[2 * c] = (f2){v.x, v.y};
+        cinv[2 * c + 1] = (f2){v.z, v.w};
+    }
+    float* rcb = cs;               // [2][ncp]
+    float* rcM = cs + 2 * ncp;     // [ncp]
+    float* zc = cs + 3 * ncp;      // [ncp]
+    const int EW = (o.nstrips + 2) * X;
+    float* Ert = E; float* Erb = E + EW; float* Ept = E + 2 * EW; float* Epb = E + 3 * EW;
+    for (int k = tid; k < 4 * EW; k += blockDim.x) E[k] = 0.f;
+    for (int k = tid; k < 4 * ncp; k += blockDim.x) cs[k] = 0.f;
+    if (tid < 64) red[tid] = 0.f;
+    __syncthreads();
+    const bool own = FULLROW || o.owner;
+    const int eo = (o.strip + 1) * X + o.i;
+    const bool has_prev = own && o.strip > 0, has_next = own && o.strip < o.nstrips - 1;
+    const bool has_l = o.i > 0, has_r = o.i < X - 1;
+    const int bcol = o.i >> 3, brow0 = o.strip * NBS;
+    const int blk_prev = (brow0 - 1) * nbx + bcol, blk_next = (brow0 + NBS) * nbx + bcol;
+    auto dg_at = [&](int j, int i) {
+        const float n = acc_at(act, Y, X, j - 1, i) + acc_at(act, Y, X, j + 1, i) + acc_at(act, Y, X, j, i - 1) + acc_at(act, Y, X, j, i + 1);
+        return fmaxf(n, 1.f);
+    };
+    const float idg_prev = has_prev ? 1.f / dg_at(o.j0 - 1, o.i) : 0.f;
+    const float idg_next = has_next ? 1.f / dg_at(o.j0 + CPT, o.i) : 0.f;
+    const float ac_prev = has_prev ? (float)act[(o.j0 - 1) * X + o.i] : 0.f;     // prolongation is masked (P = active * indicator)
+    const float ac_next = has_next ? (float)act[(o.j0 + CPT) * X + o.i] : 0.f;
+    const bool blk_writer = own && (o.i & 7) == 0;
+
+    auto block_sums = [&](const f2 (&v)[H], float* dst) {    // dst[blk] = sum over the 8x8 aggregate
+#pragma unroll
+        for (int h = 0; h < NBS; ++h) {
+            f2 s2 = v[4 * h] + v[4 * h + 1] + v[4 * h + 2] + v[4 * h + 3];
+            const float s = sum8lanes(s2.x + s2.y);
+            if (blk_writer) dst[(brow0 + h) * nbx + bcol] = s;
+        }
+    };
+    // coarse solve: zc[I] = sum_J Cinv[I][J] * (rc_old[J] - alpha * rcM[J]); rc_new[I]; returns rc_new[I]*zc[I] on q == 0
+    auto coarse_solve = [&](const float* rco, float* rcn, float alpha) {
+        f2 acc2 = {0.f, 0.f};
+        const f2 nal = {-alpha, -alpha};
+#pragma unroll
+        for (int c = 0; c < CC / 4; ++c) {
+            const float4 a = reinterpret_cast<const float4*>(rco + q * CC)[c];
+            const float4 m = reinterpret_cast<const float4*>(rcM + q * CC)[c];
+            acc2 += cinv[2 * c] * ((f2){a.x, a.y} + nal * (f2){m.x, m.y});
+            acc2 += cinv[2 * c + 1] * ((f2){a.z, a.w} + nal * (f2){m.z, m.w});
+        }
+        float acc = acc2.x + acc2.y;
+        acc += dpp_mov<0xB1>(acc);
+        acc += dpp_mov<0x4E>(acc);
+        if (TPR == 8) acc += dpp_mov<0x141>(acc);
+        float cd = 0.f;
+        if (crow && q == 0) {
+            const float rn = rco[I] - alpha * rcM[I];
+            rcn[I] = rn;
+            zc[I] = acc;
+            cd = rn * acc;
+        }
+        return cd;
+    };
+
+    // ---- start: z0 = M^-1 r0, p0 = z0 -------------------------------------------------------
+    block_sums(r, rcb);                        // rc[0] = P^T r0   (rcM == 0, alpha irrelevant)
+    __syncthreads();
+    f2 part2 = {0.f, 0.f}, part3 = {0.f, 0.f};
+    float cd = coarse_solve(rcb, rcb + ncp, 0.f);   // also copies rc into buffer 1 -> use buffer 1 as "old" of iteration 0
+#pragma unroll
+    for (int qq = 0; qq < H; ++qq) { part3 += r[qq] * r[qq]; part2 += r[qq] * r[qq] * idg[qq]; }
+    if (own) { Ert[eo] = r[0].x; Erb[eo] = r[H - 1].y; }
+    float rz = part2.x + part2.y + cd, rr = part3.x + part3.y;
+    cg_block_sum2(rz, rr, red + 16);
+    {
+#pragma unroll
+        for (int h = 0; h < NBS; ++h) {
+            const float zch = zc[(brow0 + h) * nbx + bcol];
+#pragma unroll
+            for (int qq = 4 * h; qq < 4 * h + 4; ++qq) p[qq] = r[qq] * idg[qq] + (wobst ? ac[qq] * zch : (f2){zch, zch});
+        }
+    }
+    float hprev = has_prev ? Erb[eo - X] * idg_prev + ac_prev * zc[blk_prev] : 0.f;
+    float hnext = has_next ? Ert[eo + X] * idg_next + ac_next * zc[blk_next] : 0.f;
+    const float thresh = fmaxf(rtol2 * rr, atol2);
+    int it = 0;
+    while (rr > thresh && it < max_iter) {
+        float nb[CPT];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const float prev = k > 0 ? p[(k - 1) / 2][(k - 1) & 1] : hprev;
+            const float next = k < CPT - 1 ? p[(k + 1) / 2][(k + 1) & 1] : hnext;
+            nb[k] = prev + next;
+        }
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            float pl = dpp_mov<0x138>(p[k / 2][k & 1]);
+            if (!FULLROW) pl = has_l ? pl : 0.f;
+            nb[k] += pl;
+        }
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            float pr = dpp_mov<0x130>(p[k / 2][k & 1]);
+            if (!FULLROW) pr = has_r ? pr : 0.f;
+            nb[k] += pr;
+        }
+#pragma unroll
+        for (int qq = 0; qq < H; ++qq) Mp[qq] = dg[qq] * p[qq] - (f2){nb[2 * qq], nb[2 * qq + 1]};
+        if (wobst) {
+#pragma unroll
+            for (int qq = 0; qq < H; ++qq) Mp[qq] *= ac[qq];
+        }
+        part2 = (f2){0.f, 0.f};
+#pragma unroll
+        for (int qq = 0; qq < H; ++qq) part2 += p[qq] * Mp[qq];
+        block_sums(Mp, rcM);
+        const float pMp = cg_block_sum(part2.x + part2.y, red);            // barrier A (publishes P^T Mp)
+        if (!(pMp > 0.f)) break;
+        const float alpha = rz * __builtin_amdgcn_rcpf(pMp);
+        part2 = (f2){0.f, 0.f};
+        part3 = (f2){0.f, 0.f};
+#pragma unroll
+        for (int qq = 0; qq < H; ++qq) {
+            x[qq] += alpha * p[qq];
+            r[qq] -= alpha * Mp[qq];
+            const f2 r2 = r[qq] * r[qq];
+            part3 += r2;
+            part2 += r2 * idg[qq];
+        }
+        // iteration `it` reads rc buffer (it+1)&1 and writes buffer it&1
+        cd = coarse_solve(rcb + ((it + 1) & 1) * ncp, rcb + (it & 1) * ncp, alpha);
+        if (own) { Ert[eo] = r[0].x; Erb[eo] = r[H - 1].y; Ept[eo] = p[0].x; Epb[eo] = p[H - 1].y; }
+        float rzn = part2.x + part2.y + cd, rrn = part3.x + part3.y;
+        cg_block_sum2(rzn, rrn, red + 16);                                  // barrier B (publishes zc and the halo rows)
+        const float beta = rzn * __builtin_amdgcn_rcpf(rz);
+        rz = rzn;
+        rr = rrn;
+#pragma unroll
+        for (int h = 0; h < NBS; ++h) {
+            const float zch = zc[(brow0 + h) * nbx + bcol];
+#pragma unroll
+            for (int qq = 4 * h; qq < 4 * h + 4; ++qq) p[qq] = (r[qq] * idg[qq] + (wobst ? ac[qq] * zch : (f2){zch, zch})) + beta * p[qq];
+        }
+        hprev = has_prev ? (Erb[eo - X] * idg_prev + ac_prev * zc[blk_prev]) + beta * Epb[eo - X] : 0.f;
+        hnext = has_next ? (Ert[eo + X] * idg_next + ac_next * zc[blk_next]) + beta * Ept[eo + X] : 0.f;
+        ++it;
+    }
+#pragma unroll
+    for (int qq = 0; qq < H; ++qq) { xf[2 * qq] = x[qq].x; xf[2 * qq + 1] = x[qq].y; }
+    return it;
+}
+
 // per-cell matrix coefficients of the owned strip
 template <int CPT>
 __device__ __forceinline__ void cell_coeffs(const Own& o, const unsigned char* act, int Y, int X,
@@ -274,6 +491,8 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
     extern __shared__ __align__(16) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int Y = a.Y, X = a.X, N = Y * X, nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
+    const int lx = __ffs(X) - 1;                 // X is a power of two: k / X == k >> lx
+    const float invXP = 1.f / (float)XP;         // k / XP == (int)((k + 0.5) * invXP), exact for k < 2^22
     const Lds L = carve(smem, Y, X, CPT);
 
     // ---- phase 1: load inputs -------------------------------------------------------
@@ -287,12 +506,13 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
     __syncthreads();
 
     // ---- phase 2: explicit diffusion (replicate padding, dx = 1) + velocity BC ------
-    {
+    if (!(a.dbg & 8)) {
         const float alpha = a.adt / a.re[b];
         const float* bcv = a.bcv + (size_t)b * a.bc_stride;
         const float* bcm = a.bcm + (size_t)b * a.bc_stride;
+        #pragma unroll 4
         for (int k = tid; k < nVy; k += nthr) {
-            const int j = k / X, i = k - j * X;
+            const int j = k >> lx, i = k & (X - 1);
             const float c = L.Avy[k];
             const float lap = L.Avy[min(j + 1, Y) * X + i] + L.Avy[max(j - 1, 0) * X + i] +
                               L.Avy[j * X + min(i + 1, X - 1)] + L.Avy[j * X + max(i - 1, 0)] - 4.f * c;
@@ -301,8 +521,9 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
             L.Bvy[k] = v;
             if (a.saved_vy) a.saved_vy[(size_t)b * nVy + k] = v;
         }
+        #pragma unroll 4
         for (int k = tid; k < nVx; k += nthr) {
-            const int j = k / XP, i = k - j * XP;
+            const int j = (int)(((float)k + 0.5f) * invXP), i = k - j * XP;
             const float c = L.Avx[k];
             const float lap = L.Avx[min(j + 1, Y - 1) * XP + i] + L.Avx[max(j - 1, 0) * XP + i] +
                               L.Avx[j * XP + min(i + 1, X)] + L.Avx[j * XP + max(i - 1, 0)] - 4.f * c;
@@ -314,26 +535,30 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
     __syncthreads();
 
     // ---- phase 3: semi-Lagrangian advection (B -> A), hard-BC face mask fused --------
+    if (!(a.dbg & 1))
+    #pragma unroll 4
     for (int k = tid; k < nVy; k += nthr) {
-        const int j = k / X, i = k - j * X;
+        const int j = k >> lx, i = k & (X - 1);
         const float uy = L.Bvy[k];
         const int ja = max(j - 1, 0), jb = min(j, Y - 1);
         const float ux = 0.25f * (L.Bvx[ja * XP + i] + L.Bvx[ja * XP + i + 1] + L.Bvx[jb * XP + i] + L.Bvx[jb * XP + i + 1]);
         const Bil s = bil_clamp(Y + 1, X, j, -uy * a.dtdx, i, -ux * a.dtdx);
         L.Avy[k] = bil_eval(L.Bvy, X, s) * mask_y(L.act, Y, X, j, i);
     }
+    #pragma unroll 4
     for (int k = tid; k < nVx; k += nthr) {
-        const int j = k / XP, i = k - j * XP;
+        const int j = (int)(((float)k + 0.5f) * invXP), i = k - j * XP;
         const float ux = L.Bvx[k];
         const int ia = max(i - 1, 0), ib = min(i, X - 1);
         const float uy = 0.25f * (L.Bvy[j * X + ia] + L.Bvy[j * X + ib] + L.Bvy[(j + 1) * X + ia] + L.Bvy[(j + 1) * X + ib]);
         const Bil s = bil_clamp(Y, XP, j, -uy * a.dtdx, i, -ux * a.dtdx);
         L.Avx[k] = bil_eval(L.Bvx, XP, s) * mask_x(L.act, Y, X, j, i);
     }
-    if (a.d_out) {
+    if (a.d_out && !(a.dbg & 2)) {
         const float* gd = a.d_in + (size_t)b * N;
+        #pragma unroll 4
         for (int k = tid; k < N; k += nthr) {
-            const int j = k / X, i = k - j * X;
+            const int j = k >> lx, i = k & (X - 1);
             const float uy = 0.5f * (L.Bvy[k] + L.Bvy[k + X]);
             const float ux = 0.5f * (L.Bvx[j * XP + i] + L.Bvx[j * XP + i + 1]);
             const float oy = -uy * a.dtdx, ox = -ux * a.dtdx;
@@ -373,8 +598,17 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
             r[k] = -div;   // M p = -div  <=>  A p = div
         }
     }
-    const int it = X == 64 ? cg_solve<CPT, true>(o, X, dg, ac, r, x, L.E, L.red, a.rtol2, a.atol2, a.max_iter)
-                           : cg_solve<CPT, false>(o, X, dg, ac, r, x, L.E, L.red, a.rtol2, a.atol2, a.max_iter);
+    int it = 0;
+    bool solved = false;
+    if constexpr (CPT == 16) {     // the two-level preconditioner is instantiated for the 16-cell strips only
+        if (a.cinv) {
+            it = X == 64 ? pcg_solve<CPT, true, 32>(o, Y, X, L.act, dg, ac, r, x, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter)
+                         : pcg_solve<CPT, false, 8>(o, Y, X, L.act, dg, ac, r, x, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter);
+            solved = true;
+        }
+    }
+    if (!solved) it = X == 64 ? cg_solve<CPT, true>(o, X, dg, ac, r, x, L.E, L.red, a.rtol2, a.atol2, a.max_iter)
+                      : cg_solve<CPT, false>(o, X, dg, ac, r, x, L.E, L.red, a.rtol2, a.atol2, a.max_iter);
     if (a.iters && tid == 0) a.iters[b] = it;
 
     // ---- phase 6: v -= mask * grad p ;  outputs --------------------------------------
@@ -387,8 +621,9 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
     {
         float* gvy = a.vy_out + (size_t)b * nVy;
         float* gvx = a.vx_out + (size_t)b * nVx;
+        #pragma unroll 4
         for (int k = tid; k < nVy; k += nthr) {
-            const int j = k / X, i = k - j * X;
+            const int j = k >> lx, i = k & (X - 1);
             float g = 0.f;
             if (j >= 1 && j <= Y - 1) g = P[j * X + i] - P[(j - 1) * X + i];
             else if (a.grad_pad == 1) g = (j == 0) ? P[i] : -P[(Y - 1) * X + i];
@@ -396,8 +631,9 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
             L.Avy[k] = v;
             gvy[k] = v;
         }
+        #pragma unroll 4
         for (int k = tid; k < nVx; k += nthr) {
-            const int j = k / XP, i = k - j * XP;
+            const int j = (int)(((float)k + 0.5f) * invXP), i = k - j * XP;
             float g = 0.f;
             if (i >= 1 && i <= X - 1) g = P[j * X + i] - P[j * X + i - 1];
             else if (a.grad_pad == 1) g = (i == 0) ? P[j * X] : -P[j * X + X - 1];
@@ -410,8 +646,9 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
         __syncthreads();
         float4* gf = reinterpret_cast<float4*>(a.feat) + (size_t)b * N;
         const float rech = a.re[b] * a.fs2;
+        #pragma unroll 4
         for (int k = tid; k < N; k += nthr) {
-            const int j = k / X, i = k - j * X;
+            const int j = k >> lx, i = k & (X - 1);
             gf[k] = make_float4(L.Avy[k] * a.fs0, L.Avx[j * XP + i] * a.fs1, rech, 0.f);
         }
     }
@@ -426,6 +663,8 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
     extern __shared__ __align__(16) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int Y = a.Y, X = a.X, N = Y * X, nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
+    const int lx = __ffs(X) - 1;                 // X is a power of two: k / X == k >> lx
+    const float invXP = 1.f / (float)XP;         // k / XP == (int)((k + 0.5) * invXP), exact for k < 2^22
     const Lds L = carve(smem, Y, X, CPT);
     const bool dirichlet = a.grad_pad == 1;
 
@@ -434,13 +673,15 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
         const float* gy = a.g_vy_out + (size_t)b * nVy;
         const float* gx = a.g_vx_out + (size_t)b * nVx;
         const float* df = a.dfeat ? a.dfeat + (size_t)b * N * 2 : nullptr;
+        #pragma unroll 4
         for (int k = tid; k < nVy; k += nthr) {
             float g = gy[k];
             if (df && k < N) g += a.fs0 * df[2 * k];            // rows j < Y
             L.Avy[k] = g;
         }
+        #pragma unroll 4
         for (int k = tid; k < nVx; k += nthr) {
-            const int j = k / XP, i = k - j * XP;
+            const int j = (int)(((float)k + 0.5f) * invXP), i = k - j * XP;
             float g = gx[k];
             if (df && i < X) g += a.fs1 * df[2 * (j * X + i) + 1];
             L.Avx[k] = g;
@@ -466,8 +707,17 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
             r[k] = s;
         }
     }
-    const int it = X == 64 ? cg_solve<CPT, true>(o, X, dg, ac, r, z, L.E, L.red, a.rtol2, a.atol2, a.max_iter)
-                           : cg_solve<CPT, false>(o, X, dg, ac, r, z, L.E, L.red, a.rtol2, a.atol2, a.max_iter);
+    int it = 0;
+    bool solved = false;
+    if constexpr (CPT == 16) {     // the two-level preconditioner is instantiated for the 16-cell strips only
+        if (a.cinv) {
+            it = X == 64 ? pcg_solve<CPT, true, 32>(o, Y, X, L.act, dg, ac, r, z, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter)
+                         : pcg_solve<CPT, false, 8>(o, Y, X, L.act, dg, ac, r, z, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter);
+            solved = true;
+        }
+    }
+    if (!solved) it = X == 64 ? cg_solve<CPT, true>(o, X, dg, ac, r, z, L.E, L.red, a.rtol2, a.atol2, a.max_iter)
+                      : cg_solve<CPT, false>(o, X, dg, ac, r, z, L.E, L.red, a.rtol2, a.atol2, a.max_iter);
     if (a.iters && tid == 0) a.iters[b] = it;
 
     // ---- 3: g_adv = m * (g + D^T z), kept in registers ---------------------------------
@@ -483,14 +733,15 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
         const int k = tid + n * nthr;
         gy[n] = 0.f;
         gx[n] = 0.f;
+        if (a.dbg & 16) { gy[n] = 1.f; gx[n] = 1.f; continue; }
         if (k < nVy) {
-            const int j = k / X, i = k - j * X;
+            const int j = k >> lx, i = k & (X - 1);
             const float zp = j >= 1 ? Z[(j - 1) * X + i] : 0.f;
             const float zc = j <= Y - 1 ? Z[j * X + i] : 0.f;
             gy[n] = mask_y(L.act, Y, X, j, i) * (L.Avy[k] + (zp - zc));
         }
         if (k < nVx) {
-            const int j = k / XP, i = k - j * XP;
+            const int j = (int)(((float)k + 0.5f) * invXP), i = k - j * XP;
             const float zp = i >= 1 ? Z[j * X + i - 1] : 0.f;
             const float zc = i <= X - 1 ? Z[j * X + i] : 0.f;
             gx[n] = mask_x(L.act, Y, X, j, i) * (L.Avx[k] + (zp - zc));
@@ -499,20 +750,35 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
     __syncthreads();
 
     // ---- 4: stage the saved (post-diffusion) velocity, clear the accumulators ---------
+    // The scatter-add runs in int32 FIXED POINT: ds_add_f32 is ~37x slower than ds_add_u32 on gfx950
+    // (0.8 vs 30 lane-ops/ns/CU, tools/ubench/lds_atomic.hip; it was 159 of the 237 us of this kernel),
+    // and integer accumulation is order independent, i.e. the backward pass is bit-reproducible.
+    // scale = 2^31 / (16 * bound), bound = max|g| * max(1, 2*dt/dx*max|v|) >= any single contribution.
+    int* Iy = reinterpret_cast<int*>(L.Avy);
+    int* Ix = reinterpret_cast<int*>(L.Avx);
+    float smax = 0.f, gmax = 0.f;
     {
         const float* sy = a.saved_vy + (size_t)b * nVy;
         const float* sx = a.saved_vx + (size_t)b * nVx;
-        for (int k = tid; k < nVy; k += nthr) { L.Bvy[k] = sy[k]; L.Avy[k] = 0.f; }
-        for (int k = tid; k < nVx; k += nthr) { L.Bvx[k] = sx[k]; L.Avx[k] = 0.f; }
+        for (int k = tid; k < nVy; k += nthr) { const float v = sy[k]; L.Bvy[k] = v; Iy[k] = 0; smax = fmaxf(smax, fabsf(v)); }
+        for (int k = tid; k < nVx; k += nthr) { const float v = sx[k]; L.Bvx[k] = v; Ix[k] = 0; smax = fmaxf(smax, fabsf(v)); }
+#pragma unroll
+        for (int n = 0; n < MAXT; ++n) gmax = fmaxf(gmax, fmaxf(fabsf(gy[n]), fabsf(gx[n])));
     }
-    __syncthreads();
+    smax = block_max(smax, L.red);          // barrier: S staged, accumulators cleared
+    gmax = block_max(gmax, L.red + 16);
+    const float bound = 16.f * gmax * fmaxf(1.f, 2.f * a.dtdx * smax);
+    const float qs = bound > 0.f ? 2147483648.f / bound : 0.f;      // fixed-point scale
+    const float qi = bound > 0.f ? bound / 2147483648.f : 0.f;
+    auto fx = [&](float v) { return __float2int_rn(v * qs); };
 
-    // ---- 5: advection adjoint (scatter-add into LDS) -----------------------------------
+    // ---- 5: advection adjoint (integer scatter-add into LDS) ----------------------------
+    if (!(a.dbg & 32))
 #pragma unroll
     for (int n = 0; n < MAXT; ++n) {
         const int k = tid + n * nthr;
         if (k < nVy && gy[n] != 0.f) {
-            const int j = k / X, i = k - j * X;
+            const int j = k >> lx, i = k & (X - 1);
             const float g = gy[n];
             const float uy = L.Bvy[k];
             const int ja = max(j - 1, 0), jb = min(j, Y - 1);
@@ -520,21 +786,21 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
             const Bil s = bil_clamp(Y + 1, X, j, -uy * a.dtdx, i, -ux * a.dtdx);
             const float f00 = L.Bvy[s.j0 * X + s.i0], f01 = L.Bvy[s.j0 * X + s.i1];
             const float f10 = L.Bvy[s.j1 * X + s.i0], f11 = L.Bvy[s.j1 * X + s.i1];
-            atomicAdd(&L.Avy[s.j0 * X + s.i0], (1.f - s.wy) * (1.f - s.wx) * g);
-            atomicAdd(&L.Avy[s.j0 * X + s.i1], (1.f - s.wy) * s.wx * g);
-            atomicAdd(&L.Avy[s.j1 * X + s.i0], s.wy * (1.f - s.wx) * g);
-            atomicAdd(&L.Avy[s.j1 * X + s.i1], s.wy * s.wx * g);
+            atomicAdd(&Iy[s.j0 * X + s.i0], fx((1.f - s.wy) * (1.f - s.wx) * g));
+            atomicAdd(&Iy[s.j0 * X + s.i1], fx((1.f - s.wy) * s.wx * g));
+            atomicAdd(&Iy[s.j1 * X + s.i0], fx(s.wy * (1.f - s.wx) * g));
+            atomicAdd(&Iy[s.j1 * X + s.i1], fx(s.wy * s.wx * g));
             const float ddy = (1.f - s.wx) * (f10 - f00) + s.wx * (f11 - f01);
             const float ddx = (1.f - s.wy) * (f01 - f00) + s.wy * (f11 - f10);
-            const float guy = -a.dtdx * g * ddy, gux = -0.25f * a.dtdx * g * ddx;
-            atomicAdd(&L.Avy[k], guy);
-            atomicAdd(&L.Avx[ja * XP + i], gux);
-            atomicAdd(&L.Avx[ja * XP + i + 1], gux);
-            atomicAdd(&L.Avx[jb * XP + i], gux);
-            atomicAdd(&L.Avx[jb * XP + i + 1], gux);
+            const int guy = fx(-a.dtdx * g * ddy), gux = fx(-0.25f * a.dtdx * g * ddx);
+            atomicAdd(&Iy[k], guy);
+            atomicAdd(&Ix[ja * XP + i], gux);
+            atomicAdd(&Ix[ja * XP + i + 1], gux);
+            atomicAdd(&Ix[jb * XP + i], gux);
+            atomicAdd(&Ix[jb * XP + i + 1], gux);
         }
         if (k < nVx && gx[n] != 0.f) {
-            const int j = k / XP, i = k - j * XP;
+            const int j = (int)(((float)k + 0.5f) * invXP), i = k - j * XP;
             const float g = gx[n];
             const float ux = L.Bvx[k];
             const int ia = max(i - 1, 0), ib = min(i, X - 1);
@@ -542,23 +808,31 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
             const Bil s = bil_clamp(Y, XP, j, -uy * a.dtdx, i, -ux * a.dtdx);
             const float f00 = L.Bvx[s.j0 * XP + s.i0], f01 = L.Bvx[s.j0 * XP + s.i1];
             const float f10 = L.Bvx[s.j1 * XP + s.i0], f11 = L.Bvx[s.j1 * XP + s.i1];
-            atomicAdd(&L.Avx[s.j0 * XP + s.i0], (1.f - s.wy) * (1.f - s.wx) * g);
-            atomicAdd(&L.Avx[s.j0 * XP + s.i1], (1.f - s.wy) * s.wx * g);
-            atomicAdd(&L.Avx[s.j1 * XP + s.i0], s.wy * (1.f - s.wx) * g);
-            atomicAdd(&L.Avx[s.j1 * XP + s.i1], s.wy * s.wx * g);
+            atomicAdd(&Ix[s.j0 * XP + s.i0], fx((1.f - s.wy) * (1.f - s.wx) * g));
+            atomicAdd(&Ix[s.j0 * XP + s.i1], fx((1.f - s.wy) * s.wx * g));
+            atomicAdd(&Ix[s.j1 * XP + s.i0], fx(s.wy * (1.f - s.wx) * g));
+            atomicAdd(&Ix[s.j1 * XP + s.i1], fx(s.wy * s.wx * g));
             const float ddy = (1.f - s.wx) * (f10 - f00) + s.wx * (f11 - f01);
             const float ddx = (1.f - s.wy) * (f01 - f00) + s.wy * (f11 - f10);
-            const float gux = -a.dtdx * g * ddx, guy = -0.25f * a.dtdx * g * ddy;
-            atomicAdd(&L.Avx[k], gux);
-            atomicAdd(&L.Avy[j * X + ia], guy);
-            atomicAdd(&L.Avy[j * X + ib], guy);
-            atomicAdd(&L.Avy[(j + 1) * X + ia], guy);
-            atomicAdd(&L.Avy[(j + 1) * X + ib], guy);
+            const int gux = fx(-a.dtdx * g * ddx), guy = fx(-0.25f * a.dtdx * g * ddy);
+            atomicAdd(&Ix[k], gux);
+            atomicAdd(&Iy[j * X + ia], guy);
+            atomicAdd(&Iy[j * X + ib], guy);
+            atomicAdd(&Iy[(j + 1) * X + ia], guy);
+            atomicAdd(&Iy[(j + 1) * X + ib], guy);
         }
+    }
+    __syncthreads();
+    {   // back to float (in place, element-wise); |acc| > 2^30 would mean the 16x headroom was nearly used up
+        bool risky = false;
+        for (int k = tid; k < nVy; k += nthr) { const int q = Iy[k]; risky |= abs(q) > (1 << 30); L.Avy[k] = (float)q * qi; }
+        for (int k = tid; k < nVx; k += nthr) { const int q = Ix[k]; risky |= abs(q) > (1 << 30); L.Avx[k] = (float)q * qi; }
+        if (risky && a.iters) a.iters[b] = -1;      // reported by the host wrappers as an error
     }
     __syncthreads();
 
     // ---- 6: BC adjoint, then diffusion adjoint (the replicate Laplacian is symmetric) --
+    if (a.dbg & 64) return;
     {
         const float* bcm = a.bcm + (size_t)b * a.bc_stride;
         for (int k = tid; k < nVy; k += nthr) L.Avy[k] *= (1.f - bcm[k]);
@@ -568,15 +842,17 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
         const float alpha = a.adt / a.re[b];
         float* oy = a.g_vy_in + (size_t)b * nVy;
         float* ox = a.g_vx_in + (size_t)b * nVx;
+        #pragma unroll 4
         for (int k = tid; k < nVy; k += nthr) {
-            const int j = k / X, i = k - j * X;
+            const int j = k >> lx, i = k & (X - 1);
             const float c = L.Avy[k];
             const float lap = L.Avy[min(j + 1, Y) * X + i] + L.Avy[max(j - 1, 0) * X + i] +
                               L.Avy[j * X + min(i + 1, X - 1)] + L.Avy[j * X + max(i - 1, 0)] - 4.f * c;
             oy[k] = c + alpha * lap;
         }
+        #pragma unroll 4
         for (int k = tid; k < nVx; k += nthr) {
-            const int j = k / XP, i = k - j * XP;
+            const int j = (int)(((float)k + 0.5f) * invXP), i = k - j * XP;
             const float c = L.Avx[k];
             const float lap = L.Avx[min(j + 1, Y - 1) * XP + i] + L.Avx[max(j - 1, 0) * XP + i] +
                               L.Avx[j * XP + min(i + 1, X)] + L.Avx[j * XP + max(i - 1, 0)] - 4.f * c;
@@ -596,6 +872,15 @@ int pick_cpt(const sol_karman_cfg* c) {
     return cpt;
 }
 
+bool precond_ok(int Y, int X) {
+    if (Y % 8 || X % 8) return false;
+    const int nc = (Y / 8) * (X / 8);
+    const int cpt = (Y % 16 == 0 && X >= 16) ? 16 : 8;     // default strip height (SOL_CPT may lower it)
+    // kernels are instantiated for nc/4 == 32 columns per thread at X == 64 (128x64) and 8 at X == 32 (64x32)
+    if (cpt != 16) return false;
+    return (X == 64 && nc / 4 == 32) || (X == 32 && nc / 4 == 8);
+}
+
 int check_cfg(const sol_karman_cfg* c) {
     SOL_REQUIRE(c != nullptr, "cfg is NULL");
     SOL_REQUIRE(c->B >= 1, "B must be >= 1 (got %d)", c->B);
@@ -605,6 +890,10 @@ int check_cfg(const sol_karman_cfg* c) {
     SOL_REQUIRE((c->Y / cpt) * c->X <= (cpt == 16 ? 512 : 1024), "grid %dx%d exceeds one workgroup", c->Y, c->X);
     SOL_REQUIRE(lds_bytes(c->Y, c->X, cpt) <= 160 * 1024, "grid %dx%d does not fit the 160 KiB LDS", c->Y, c->X);
     SOL_REQUIRE(c->dx > 0.f && c->cg_max_iter >= 0, "dx must be > 0 and cg_max_iter >= 0");
+    if (c->coarse_inv) {
+        SOL_REQUIRE(precond_ok(c->Y, c->X) && cpt == 16, "the two-level CG preconditioner is not available for a %dx%d grid", c->Y, c->X);
+        SOL_REQUIRE(c->coarse_n == (c->Y / 8) * (c->X / 8), "coarse_n must be (Y/8)*(X/8) = %d (got %d)", (c->Y / 8) * (c->X / 8), c->coarse_n);
+    }
     return SOL_OK;
 }
 
@@ -618,20 +907,40 @@ void fill_common(StepArgs& a, const sol_karman_cfg* c) {
     a.max_iter = c->cg_max_iter;
     a.grad_pad = c->grad_pad;
     a.inflow_before = c->inflow_before;
+    a.cinv = c->coarse_inv;
+    a.dbg = getenv("SOL_DBG_SKIP") ? atoi(getenv("SOL_DBG_SKIP")) : 0;   // timing experiments only
 }
+
+}  // namespace
+
+// one-time: allow the full 160 KiB of dynamic LDS (not a stream operation -> done outside graph capture)
+int sol_init_karman_kernels() {
+    static int rc = [] {
+        const void* ks[] = {reinterpret_cast<const void*>(k_karman_fwd<8>), reinterpret_cast<const void*>(k_karman_fwd<16>),
+                            reinterpret_cast<const void*>(k_karman_bwd<8>), reinterpret_cast<const void*>(k_karman_bwd<16>)};
+        for (const void* k : ks)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return sol_set_error(SOL_ERR_HIP, "hipFuncSetAttribute(karman kernels) failed");
+        return SOL_OK;
+    }();
+    return rc;
+}
+
+namespace {
 
 template <typename K>
 int launch_step(K kernel, int cpt, const sol_karman_cfg* c, void* stream, const StepArgs& a) {
     const int threads = (int)align_up((size_t)(c->Y / cpt) * c->X, 64);
     const size_t lds = lds_bytes(c->Y, c->X, cpt);
-    SOL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (int e = sol_init_karman_kernels()) return e;
     hipLaunchKernelGGL(kernel, dim3(c->B), dim3(threads), lds, (hipStream_t)stream, a);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }
 
 }  // namespace
+
+extern "C" int sol_karman_precond_supported(int32_t Y, int32_t X) { return precond_ok(Y, X) ? 1 : 0; }
 
 extern "C" int sol_karman_step_fwd(const sol_karman_cfg* cfg, void* stream,
                                    const float* d_in, const float* vy_in, const float* vx_in,

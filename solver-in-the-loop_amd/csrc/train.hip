@@ -5,6 +5,7 @@
 // karman_apply.py:138-158.  The per-step order (step -> CNN correction -> add -> loss) and
 // the reverse sweep follow SURVEY.md appendix C.9.
 #include "common.hpp"
+#include <stdlib.h>
 
 thread_local char g_sol_err[512] = "";
 
@@ -235,16 +236,188 @@ extern "C" int sol_mars_moon_layer(int32_t l, int64_t* kernel_off, int64_t* bias
     return SOL_OK;
 }
 
-extern "C" size_t sol_train_workspace_bytes(const sol_train_cfg* cfg) {
-    if (!cfg) return 0;
-    Ws w;
-    return carve_ws(cfg, nullptr, w, true);
-}
-
 extern "C" size_t sol_rollout_workspace_bytes(const sol_train_cfg* cfg) {
     if (!cfg) return 0;
     Ws w;
     return carve_ws(cfg, nullptr, w, false);
+}
+
+namespace {
+
+// ---- sub-batch chains on their own HIP streams ----------------------------------------------
+// The simulations of a batch are independent through the whole unroll (only the weight gradient is
+// summed at the end), and the solver kernels occupy one CU per simulation for hundreds of
+// microseconds while the conv kernels want the whole chip.  The batch is therefore split into S
+// chains (S | B; env SOL_STREAMS, default 1) that run on S streams: the solver step of one simulation overlaps
+// with the convolutions of the others, and the prologue/epilogue of one conv launch with the MFMA
+// phase of another.  Each chain has its own workspace slice and weight-gradient partials.
+struct StreamPool {
+    hipStream_t s[8];
+    hipEvent_t fork, join[8];
+    bool ok;
+};
+StreamPool* pool() {
+    static StreamPool p = [] {
+        StreamPool q{};
+        q.ok = true;
+        for (int k = 0; k < 8; ++k) {
+            q.ok &= hipStreamCreateWithFlags(&q.s[k], hipStreamNonBlocking) == hipSuccess;
+            q.ok &= hipEventCreateWithFlags(&q.join[k], hipEventDisableTiming) == hipSuccess;
+        }
+        q.ok &= hipEventCreateWithFlags(&q.fork, hipEventDisableTiming) == hipSuccess;
+        return q;
+    }();
+    return &p;
+}
+
+int pick_chains(int B) {
+    int want = 1;   // measured on MI355X/ROCm 7.2: concurrent chains are SLOWER (57 -> 105..167 ms/step), see DESIGN.md
+    if (const char* e = getenv("SOL_STREAMS")) want = atoi(e);
+    if (want < 1) want = 1;
+    if (want > 8) want = 8;
+    while (B % want) --want;
+    return want;
+}
+
+struct TrainIO {
+    const float *params, *d0, *vy0, *vx0, *re, *active, *inflow, *bcv, *bcm, *gt_vy, *gt_vx;
+    int64_t bc_stride;
+    float *loss_steps, *d_final, *vy_final, *vx_final;
+    int32_t *iters_fwd, *iters_bwd;
+};
+
+// forward unroll + reverse sweep of the simulations [b0, b0 + c.karman.B) on stream hs
+int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, int b0, hipStream_t hs, const TrainIO& io) {
+    void* stream = hs;
+    const sol_karman_cfg* kc = &c->karman;
+    const int B = kc->B, Y = kc->Y, X = kc->X, ms = c->msteps;
+    const float fscale[3] = {1.f / c->std_v0, 1.f / c->std_v1, 1.f / c->std_re};
+    const int egrid = (int)((w.st_vy + w.st_vx + 255) / 256);
+    const size_t gVy = (size_t)Btot * w.nVy, gVx = (size_t)Btot * w.nVx;       // per-step stride of the gt frames
+    const float* d0 = io.d0 + (size_t)b0 * w.N;
+    const float* vy0 = io.vy0 + (size_t)b0 * w.nVy;
+    const float* vx0 = io.vx0 + (size_t)b0 * w.nVx;
+    const float* re = io.re + b0;
+    const float* bcv = io.bcv + (size_t)b0 * io.bc_stride;
+    const float* bcm = io.bcm + (size_t)b0 * io.bc_stride;
+    const float* gt_vy = io.gt_vy + (size_t)b0 * w.nVy;
+    const float* gt_vx = io.gt_vx + (size_t)b0 * w.nVx;
+    const float sl = c->lrelu_slope;
+    Ws wn = w;                         // packed weights / padded biases are shared by all chains
+    for (int l = 0; l < NL; ++l) { wn.wf[l] = shared.wf[l]; wn.wb[l] = shared.wb[l]; wn.bias[l] = shared.bias[l]; }
+
+    // ---------------- forward unroll ----------------
+    for (int i = 0; i < ms; ++i) {
+        const float* din = i == 0 ? d0 : w.d + (size_t)(i - 1) * w.st_d;
+        const float* vyin = i == 0 ? vy0 : w.vy + (size_t)(i - 1) * w.st_vy;
+        const float* vxin = i == 0 ? vx0 : w.vx + (size_t)(i - 1) * w.st_vx;
+        float* dcur = w.d + (size_t)i * w.st_d;
+        float* vycur = w.vy + (size_t)i * w.st_vy;
+        float* vxcur = w.vx + (size_t)i * w.st_vx;
+        float* feat = w.feat + (size_t)i * w.cells * 4;
+        if (int e = sol_karman_step_fwd(kc, stream, din, vyin, vxin, re, io.active, io.inflow, bcv, bcm, io.bc_stride,
+                                        dcur, vycur, vxcur, w.svy + (size_t)i * w.st_vy, w.svx + (size_t)i * w.st_vx,
+                                        feat, fscale, io.iters_fwd ? io.iters_fwd + (size_t)i * Btot + b0 : nullptr)) return e;
+        float* act[11];
+        for (int k = 0; k < 11; ++k) act[k] = w.acts + ((size_t)i * 11 + k) * w.cells * 32;
+        if (int e = net_forward(c, stream, wn, feat, act, w.O)) return e;
+        hipLaunchKernelGGL(k_correct_loss, dim3(egrid), dim3(256), 0, hs, vycur, vxcur, w.O,
+                           gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx,
+                           c->std_v0, c->std_v1, io.loss_steps + i, B, Y, X);
+        SOL_LAUNCH_CHECK();
+    }
+    if (io.d_final) SOL_HIP_CHECK(hipMemcpyAsync(io.d_final + (size_t)b0 * w.N, w.d + (size_t)(ms - 1) * w.st_d, w.st_d * sizeof(float), hipMemcpyDeviceToDevice, hs));
+    if (io.vy_final) SOL_HIP_CHECK(hipMemcpyAsync(io.vy_final + (size_t)b0 * w.nVy, w.vy + (size_t)(ms - 1) * w.st_vy, w.st_vy * sizeof(float), hipMemcpyDeviceToDevice, hs));
+    if (io.vx_final) SOL_HIP_CHECK(hipMemcpyAsync(io.vx_final + (size_t)b0 * w.nVx, w.vx + (size_t)(ms - 1) * w.st_vx, w.st_vx * sizeof(float), hipMemcpyDeviceToDevice, hs));
+
+    // ---------------- reverse sweep ----------------
+    int cur = 0;
+    for (int i = ms - 1; i >= 0; --i) {
+        float* gvy = w.gvy[cur];
+        float* gvx = w.gvx[cur];
+        const float* vycur = w.vy + (size_t)i * w.st_vy;
+        const float* vxcur = w.vx + (size_t)i * w.st_vx;
+        hipLaunchKernelGGL(k_seed, dim3(egrid), dim3(256), 0, hs, gvy, gvx, vycur, vxcur,
+                           gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx,
+                           c->std_v0, c->std_v1, 1.f / (float)ms, w.dO4, w.dO2, i == ms - 1 ? 1 : 0, B, Y, X);
+        SOL_LAUNCH_CHECK();
+        const float* feat = w.feat + (size_t)i * w.cells * 4;
+        const float* act[11];
+        for (int k = 0; k < 11; ++k) act[k] = w.acts + ((size_t)i * 11 + k) * w.cells * 32;
+        // output layer (cout 2)
+        if (int e = sol_conv5x5_bwd_weight(stream, act[10], w.dO2, w.part[11], B, Y, X, 32, 2)) return e;
+        if (int e = sol_conv5x5(stream, w.dO4, wn.wb[11], nullptr, nullptr, act[10], w.gA, B, Y, X, 4, 32, SOL_EPI_DLRELU, sl)) return e;
+        for (int k = 4; k >= 0; --k) {
+            const float* h = act[2 * k];
+            const float* a = act[1 + 2 * k];
+            if (int e = sol_conv5x5_bwd_weight(stream, a, w.gA, w.part[2 + 2 * k], B, Y, X, 32, 32)) return e;
+            if (int e = sol_conv5x5(stream, w.gA, wn.wb[2 + 2 * k], nullptr, nullptr, a, w.gB, B, Y, X, 32, 32, SOL_EPI_DLRELU, sl)) return e;
+            if (int e = sol_conv5x5_bwd_weight(stream, h, w.gB, w.part[1 + 2 * k], B, Y, X, 32, 32)) return e;
+            if (int e = sol_conv5x5(stream, w.gB, wn.wb[1 + 2 * k], nullptr, w.gA, h, w.gA, B, Y, X, 32, 32, SOL_EPI_DLRELU, sl)) return e;
+        }
+        if (int e = sol_conv5x5_bwd_weight(stream, feat, w.gA, w.part[0], B, Y, X, 4, 32)) return e;
+        if (i > 0) {
+            if (int e = sol_conv5x5(stream, w.gA, wn.wb[0], nullptr, nullptr, nullptr, w.dF, B, Y, X, 32, 2, SOL_EPI_NONE, sl)) return e;
+            if (int e = sol_karman_step_bwd(kc, stream, w.svy + (size_t)i * w.st_vy, w.svx + (size_t)i * w.st_vx, re, io.active,
+                                            bcm, io.bc_stride, gvy, gvx, w.dF, fscale, w.gvy[cur ^ 1], w.gvx[cur ^ 1],
+                                            io.iters_bwd ? io.iters_bwd + (size_t)i * Btot + b0 : nullptr)) return e;
+            cur ^= 1;
+        }
+    }
+    return SOL_OK;
+}
+
+int train_fwd_bwd_impl(const sol_train_cfg* cfg, hipStream_t hs, const TrainIO& io, void* workspace, size_t workspace_bytes, float* grads) {
+    const int B = cfg->karman.B, Y = cfg->karman.Y, X = cfg->karman.X, ms = cfg->msteps;
+    const int S = pick_chains(B);
+    sol_train_cfg sub = *cfg;
+    sub.karman.B = B / S;
+    Ws w[8];
+    const size_t sub_bytes = carve_ws(&sub, nullptr, w[0], true);
+    if (workspace_bytes < sub_bytes * S)
+        return sol_set_error(SOL_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, sub_bytes * S);
+    for (int k = 0; k < S; ++k) carve_ws(&sub, reinterpret_cast<float*>(static_cast<char*>(workspace) + k * sub_bytes), w[k], true);
+    if (int e = sol_init_karman_kernels()) return e;
+    if (int e = sol_init_conv_kernels()) return e;
+    StreamPool* sp = pool();
+    if (S > 1 && !sp->ok) return sol_set_error(SOL_ERR_HIP, "could not create the internal HIP streams/events");
+
+    if (int e = pack_all(cfg, hs, io.params, w[0], true)) return e;
+    SOL_HIP_CHECK(hipMemsetAsync(io.loss_steps, 0, ms * sizeof(float), hs));
+    for (int k = 0; k < S; ++k) {
+        for (int l = 0; l < NL; ++l) SOL_HIP_CHECK(hipMemsetAsync(w[k].part[l], 0, w[k].part_floats[l] * sizeof(float), hs));
+        SOL_HIP_CHECK(hipMemsetAsync(w[k].dO4, 0, w[k].cells * 4 * sizeof(float), hs));
+    }
+    if (io.iters_bwd) SOL_HIP_CHECK(hipMemsetAsync(io.iters_bwd, 0, B * sizeof(int32_t), hs));   // step 0 needs no adjoint
+    if (S == 1) {
+        if (int e = run_chain(&sub, w[0], w[0], B, 0, hs, io)) return e;
+    } else {
+        SOL_HIP_CHECK(hipEventRecord(sp->fork, hs));
+        for (int k = 0; k < S; ++k) {
+            SOL_HIP_CHECK(hipStreamWaitEvent(sp->s[k], sp->fork, 0));
+            if (int e = run_chain(&sub, w[k], w[0], B, k * (B / S), sp->s[k], io)) return e;
+            SOL_HIP_CHECK(hipEventRecord(sp->join[k], sp->s[k]));
+            SOL_HIP_CHECK(hipStreamWaitEvent(hs, sp->join[k], 0));
+        }
+    }
+    for (int l = 0; l < NL; ++l) {
+        const int cin = layer_cin(l), cout = layer_cout(l);
+        const int64_t koff = layer_koff(l), boff = koff + 25 * cin * cout;
+        for (int k = 0; k < S; ++k)
+            if (int e = sol_conv5x5_bwd_weight_reduce(hs, w[k].part[l], grads + koff, grads + boff, B / S, Y, X, cin, cout, k > 0)) return e;
+    }
+    return SOL_OK;
+}
+
+}  // namespace
+
+extern "C" size_t sol_train_workspace_bytes(const sol_train_cfg* cfg) {
+    if (!cfg || cfg->karman.B < 1) return 0;
+    const int S = pick_chains(cfg->karman.B);
+    sol_train_cfg sub = *cfg;
+    sub.karman.B = cfg->karman.B / S;
+    Ws w;
+    return carve_ws(&sub, nullptr, w, true) * S;
 }
 
 extern "C" int sol_train_fwd_bwd(const sol_train_cfg* cfg, void* stream, const float* params,
@@ -259,87 +432,64 @@ extern "C" int sol_train_fwd_bwd(const sol_train_cfg* cfg, void* stream, const f
     if (int e = check_train_cfg(cfg)) return e;
     SOL_REQUIRE(params && d0 && vy0 && vx0 && re && active && inflow && velBCy && velBCyMask && gt_vy && gt_vx &&
                 workspace && grads && loss_steps, "sol_train_fwd_bwd: NULL pointer argument");
-    Ws w;
-    const size_t need = carve_ws(cfg, static_cast<float*>(workspace), w, true);
-    if (workspace_bytes < need)
-        return sol_set_error(SOL_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
-    hipStream_t hs = (hipStream_t)stream;
-    const sol_karman_cfg* kc = &cfg->karman;
-    const int B = kc->B, Y = kc->Y, X = kc->X, ms = cfg->msteps;
-    const float fscale[3] = {1.f / cfg->std_v0, 1.f / cfg->std_v1, 1.f / cfg->std_re};
-    const int egrid = (int)((w.st_vy + w.st_vx + 255) / 256);
+    TrainIO io{params, d0, vy0, vx0, re, active, inflow, velBCy, velBCyMask, gt_vy, gt_vx, bc_batch_stride,
+               loss_steps, d_final, vy_final, vx_final, iters_fwd, iters_bwd};
+    return train_fwd_bwd_impl(cfg, (hipStream_t)stream, io, workspace, workspace_bytes, grads);
+}
 
-    if (int e = pack_all(cfg, stream, params, w, true)) return e;
-    for (int l = 0; l < NL; ++l) SOL_HIP_CHECK(hipMemsetAsync(w.part[l], 0, w.part_floats[l] * sizeof(float), hs));
-    SOL_HIP_CHECK(hipMemsetAsync(loss_steps, 0, ms * sizeof(float), hs));
-    SOL_HIP_CHECK(hipMemsetAsync(w.dO4, 0, w.cells * 4 * sizeof(float), hs));
+// ---- the same step as a replayable hipGraph (removes ~1000 host launches per step) --------------
+struct sol_train_graph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
 
-    // ---------------- forward unroll ----------------
-    for (int i = 0; i < ms; ++i) {
-        const float* din = i == 0 ? d0 : w.d + (size_t)(i - 1) * w.st_d;
-        const float* vyin = i == 0 ? vy0 : w.vy + (size_t)(i - 1) * w.st_vy;
-        const float* vxin = i == 0 ? vx0 : w.vx + (size_t)(i - 1) * w.st_vx;
-        float* dcur = w.d + (size_t)i * w.st_d;
-        float* vycur = w.vy + (size_t)i * w.st_vy;
-        float* vxcur = w.vx + (size_t)i * w.st_vx;
-        float* feat = w.feat + (size_t)i * w.cells * 4;
-        if (int e = sol_karman_step_fwd(kc, stream, din, vyin, vxin, re, active, inflow, velBCy, velBCyMask, bc_batch_stride,
-                                        dcur, vycur, vxcur, w.svy + (size_t)i * w.st_vy, w.svx + (size_t)i * w.st_vx,
-                                        feat, fscale, iters_fwd ? iters_fwd + (size_t)i * B : nullptr)) return e;
-        float* act[11];
-        for (int k = 0; k < 11; ++k) act[k] = w.acts + ((size_t)i * 11 + k) * w.cells * 32;
-        if (int e = net_forward(cfg, stream, w, feat, act, w.O)) return e;
-        hipLaunchKernelGGL(k_correct_loss, dim3(egrid), dim3(256), 0, hs, vycur, vxcur, w.O,
-                           gt_vy + (size_t)i * w.st_vy, gt_vx + (size_t)i * w.st_vx,
-                           cfg->std_v0, cfg->std_v1, loss_steps + i, B, Y, X);
-        SOL_LAUNCH_CHECK();
+extern "C" int sol_train_graph_create(const sol_train_cfg* cfg, const float* params,
+                                      const float* d0, const float* vy0, const float* vx0, const float* re,
+                                      const float* active, const float* inflow,
+                                      const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
+                                      const float* gt_vy, const float* gt_vx,
+                                      void* workspace, size_t workspace_bytes,
+                                      float* grads, float* loss_steps,
+                                      float* d_final, float* vy_final, float* vx_final,
+                                      int32_t* iters_fwd, int32_t* iters_bwd, sol_train_graph** out) {
+    if (int e = check_train_cfg(cfg)) return e;
+    SOL_REQUIRE(params && d0 && vy0 && vx0 && re && active && inflow && velBCy && velBCyMask && gt_vy && gt_vx &&
+                workspace && grads && loss_steps && out, "sol_train_graph_create: NULL pointer argument");
+    if (int e = sol_init_karman_kernels()) return e;
+    if (int e = sol_init_conv_kernels()) return e;
+    if (!pool()->ok) return sol_set_error(SOL_ERR_HIP, "could not create the internal HIP streams/events");
+    TrainIO io{params, d0, vy0, vx0, re, active, inflow, velBCy, velBCyMask, gt_vy, gt_vx, bc_batch_stride,
+               loss_steps, d_final, vy_final, vx_final, iters_fwd, iters_bwd};
+    hipStream_t cs;
+    SOL_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        hipStreamDestroy(cs);
+        return sol_set_error(SOL_ERR_HIP, "hipStreamBeginCapture failed");
     }
-    if (d_final) SOL_HIP_CHECK(hipMemcpyAsync(d_final, w.d + (size_t)(ms - 1) * w.st_d, w.st_d * sizeof(float), hipMemcpyDeviceToDevice, hs));
-    if (vy_final) SOL_HIP_CHECK(hipMemcpyAsync(vy_final, w.vy + (size_t)(ms - 1) * w.st_vy, w.st_vy * sizeof(float), hipMemcpyDeviceToDevice, hs));
-    if (vx_final) SOL_HIP_CHECK(hipMemcpyAsync(vx_final, w.vx + (size_t)(ms - 1) * w.st_vx, w.st_vx * sizeof(float), hipMemcpyDeviceToDevice, hs));
+    const int rc = train_fwd_bwd_impl(cfg, cs, io, workspace, workspace_bytes, grads);
+    const hipError_t ee = hipStreamEndCapture(cs, &graph);
+    hipStreamDestroy(cs);
+    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (ee != hipSuccess || !graph) return sol_set_error(SOL_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ee));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (ei != hipSuccess) { hipGraphDestroy(graph); return sol_set_error(SOL_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei)); }
+    *out = new sol_train_graph{graph, exec};
+    return SOL_OK;
+}
 
-    // ---------------- reverse sweep ----------------
-    const float sl = cfg->lrelu_slope;
-    int cur = 0;
-    for (int i = ms - 1; i >= 0; --i) {
-        float* gvy = w.gvy[cur];
-        float* gvx = w.gvx[cur];
-        const float* vycur = w.vy + (size_t)i * w.st_vy;
-        const float* vxcur = w.vx + (size_t)i * w.st_vx;
-        hipLaunchKernelGGL(k_seed, dim3(egrid), dim3(256), 0, hs, gvy, gvx, vycur, vxcur,
-                           gt_vy + (size_t)i * w.st_vy, gt_vx + (size_t)i * w.st_vx,
-                           cfg->std_v0, cfg->std_v1, 1.f / (float)ms, w.dO4, w.dO2, i == ms - 1 ? 1 : 0, B, Y, X);
-        SOL_LAUNCH_CHECK();
-        const float* feat = w.feat + (size_t)i * w.cells * 4;
-        const float* act[11];
-        for (int k = 0; k < 11; ++k) act[k] = w.acts + ((size_t)i * 11 + k) * w.cells * 32;
-        // output layer (cout 2)
-        if (int e = sol_conv5x5_bwd_weight(stream, act[10], w.dO2, w.part[11], B, Y, X, 32, 2)) return e;
-        if (int e = sol_conv5x5(stream, w.dO4, w.wb[11], nullptr, nullptr, act[10], w.gA, B, Y, X, 4, 32, SOL_EPI_DLRELU, sl)) return e;
-        for (int k = 4; k >= 0; --k) {
-            const float* h = act[2 * k];
-            const float* a = act[1 + 2 * k];
-            if (int e = sol_conv5x5_bwd_weight(stream, a, w.gA, w.part[2 + 2 * k], B, Y, X, 32, 32)) return e;
-            if (int e = sol_conv5x5(stream, w.gA, w.wb[2 + 2 * k], nullptr, nullptr, a, w.gB, B, Y, X, 32, 32, SOL_EPI_DLRELU, sl)) return e;
-            if (int e = sol_conv5x5_bwd_weight(stream, h, w.gB, w.part[1 + 2 * k], B, Y, X, 32, 32)) return e;
-            if (int e = sol_conv5x5(stream, w.gB, w.wb[1 + 2 * k], nullptr, w.gA, h, w.gA, B, Y, X, 32, 32, SOL_EPI_DLRELU, sl)) return e;
-        }
-        if (int e = sol_conv5x5_bwd_weight(stream, feat, w.gA, w.part[0], B, Y, X, 4, 32)) return e;
-        if (i > 0) {
-            if (int e = sol_conv5x5(stream, w.gA, w.wb[0], nullptr, nullptr, nullptr, w.dF, B, Y, X, 32, 2, SOL_EPI_NONE, sl)) return e;
-            if (int e = sol_karman_step_bwd(kc, stream, w.svy + (size_t)i * w.st_vy, w.svx + (size_t)i * w.st_vx, re, active,
-                                            velBCyMask, bc_batch_stride, gvy, gvx, w.dF, fscale,
-                                            w.gvy[cur ^ 1], w.gvx[cur ^ 1],
-                                            iters_bwd ? iters_bwd + (size_t)i * B : nullptr)) return e;
-            cur ^= 1;
-        }
-    }
-    if (iters_bwd) SOL_HIP_CHECK(hipMemsetAsync(iters_bwd, 0, B * sizeof(int32_t), hs));   // step 0 needs no adjoint
-    for (int l = 0; l < NL; ++l) {
-        const int cin = layer_cin(l), cout = layer_cout(l);
-        const int64_t koff = layer_koff(l), boff = koff + 25 * cin * cout;
-        if (int e = sol_conv5x5_bwd_weight_reduce(stream, w.part[l], grads + koff, grads + boff, B, Y, X, cin, cout, 0)) return e;
-    }
+extern "C" int sol_train_graph_launch(sol_train_graph* g, void* stream) {
+    SOL_REQUIRE(g && g->exec, "sol_train_graph_launch: NULL graph");
+    SOL_HIP_CHECK(hipGraphLaunch(g->exec, (hipStream_t)stream));
+    return SOL_OK;
+}
+
+extern "C" int sol_train_graph_destroy(sol_train_graph* g) {
+    if (!g) return SOL_OK;
+    if (g->exec) hipGraphExecDestroy(g->exec);
+    if (g->graph) hipGraphDestroy(g->graph);
+    delete g;
     return SOL_OK;
 }
 

@@ -65,7 +65,7 @@ class KarmanFlow:
         B = smoke._batch_size
         dev = smoke.density.data.device
         masks = self._masks(domain, velBCy, velBCyMask, dev)
-        cfg = ops.karman_cfg(B, Y, X, domain.dx[1], dt=dt, res=res, **self._solver)
+        cfg = ops.karman_cfg(B, Y, X, domain.dx[1], dt=dt, res=res, masks=masks, **self._solver)
         re_t = torch.as_tensor(re, dtype=torch.float32, device=dev).reshape(B)
         d = smoke.density.data.reshape(B, Y, X)
         vy = smoke.velocity.data[0].data.reshape(B, Y + 1, X)

@@ -5,6 +5,7 @@ These are the composable building blocks behind the reference-shaped Python surf
 Every function here calls libsol_hip.so; there is no CPU implementation.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -17,17 +18,24 @@ CONV_FWD, CONV_BWD_DATA = 0, 1
 
 
 def karman_cfg(B, Y, X, dx, dt=1.0, res=None, cg_rtol=1e-6, cg_atol=1e-9, cg_max_iter=2000,
-               grad_pad="replicate", inflow_order="after"):
-    return KarmanCfg(B, Y, X, float(dx), float(dt), float(X if res is None else res),
-                     float(cg_rtol), float(cg_atol), int(cg_max_iter),
-                     {"replicate": 0, "dirichlet0": 1}[grad_pad], {"after": 0, "before": 1}[inflow_order])
+               grad_pad="replicate", inflow_order="after", masks=None):
+    """sol_karman_cfg; `masks` (SceneMasks) supplies the coarse inverse of the CG preconditioner."""
+    cfg = KarmanCfg(B, Y, X, float(dx), float(dt), float(X if res is None else res),
+                    float(cg_rtol), float(cg_atol), int(cg_max_iter),
+                    {"replicate": 0, "dirichlet0": 1}[grad_pad], {"after": 0, "before": 1}[inflow_order], 0, None)
+    ci = getattr(masks, "coarse_inv", None)
+    if ci is not None:
+        cfg.coarse_n = ci.shape[0]
+        cfg.coarse_inv = ci.data_ptr()
+        cfg._keep = ci            # the struct holds a raw device pointer
+    return cfg
 
 
 class SceneMasks:
     """Device-resident constant masks of a scene: active (1 - obstacle), inflow rate, velBCy,
     velBCyMask (reference: KarmanFlow.__init__ karman_train.py:166-171 and :366-373)."""
 
-    def __init__(self, active, inflow, velBCy, velBCyMask, device="cuda"):
+    def __init__(self, active, inflow, velBCy, velBCyMask, device="cuda", precondition=True):
         self.active = _lib.f32(active, device)
         self.inflow = _lib.f32(inflow, device)
         self.velBCy = _lib.f32(velBCy, device)
@@ -36,6 +44,11 @@ class SceneMasks:
         n = (Y + 1) * X
         assert self.velBCy.numel() % n == 0 and self.velBCy.numel() == self.velBCyMask.numel()
         self.bc_stride = 0 if self.velBCy.numel() == n else n
+        # two-level CG preconditioner (host-prepared dense coarse inverse), when the grid allows it
+        self.coarse_inv = None
+        if precondition and not os.environ.get("SOL_NO_PRECOND") and _lib.load().sol_karman_precond_supported(Y, X):
+            from .precond import coarse_inverse
+            self.coarse_inv = _lib.f32(coarse_inverse(self.active.reshape(Y, X).cpu().numpy()), device)
 
 
 def _scale3(vals):

@@ -23,7 +23,7 @@ from .dist import DPStep
 
 class SolTrainer:
     def __init__(self, net, masks, B, Y, X, msteps, dx, std_v, std_re, dt=1.0, res=None,
-                 clip_grad=False, beta1=0.9, beta2=0.999, eps=1e-8, group=None,
+                 clip_grad=False, beta1=0.9, beta2=0.999, eps=1e-8, group=None, use_graph=True,
                  cg_rtol=1e-6, cg_atol=1e-9, cg_max_iter=2000, grad_pad="replicate", inflow_order="after"):
         _lib.require_gpu()
         self.lib = _lib.load()
@@ -31,7 +31,7 @@ class SolTrainer:
         self.net, self.masks = net, masks
         self.B, self.Y, self.X, self.msteps = B, Y, X, msteps
         kc = ops.karman_cfg(B, Y, X, dx, dt=dt, res=res, cg_rtol=cg_rtol, cg_atol=cg_atol,
-                            cg_max_iter=cg_max_iter, grad_pad=grad_pad, inflow_order=inflow_order)
+                            cg_max_iter=cg_max_iter, grad_pad=grad_pad, inflow_order=inflow_order, masks=masks)
         self.cfg = TrainCfg(kc, msteps, float(std_v[0]), float(std_v[1]), float(std_re), float(net.slope))
         dev = net.params.device
         self.device = dev
@@ -51,7 +51,17 @@ class SolTrainer:
         self.beta1, self.beta2, self.eps = beta1, beta2, eps
         self._offsets = (C.c_int64 * len(net.offsets))(*[int(o) for o in net.offsets])
         self.final = None
+        self.use_graph = use_graph
+        self._graph = None          # (key, handle): replayable hipGraph of the whole fwd+bwd
+        self._fin = None
         self._dp = DPStep(self._fwd_bwd_flat, self._apply_flat, group=group)
+
+    def __del__(self):
+        try:
+            if self._graph is not None:
+                self.lib.sol_train_graph_destroy(self._graph[1])
+        except Exception:
+            pass
 
     # ---- the two halves of a step -------------------------------------------------------
     def fwd_bwd(self, d0, vy0, vx0, re, gt_vy, gt_vx, want_final=False):
@@ -63,14 +73,28 @@ class SolTrainer:
         assert gt_vy.shape == (ms, B, Y + 1, X) and gt_vx.shape == (ms, B, Y, X + 1) and re.shape == (B,)
         fin = [None, None, None]
         if want_final:
-            fin = [torch.empty_like(d0), torch.empty_like(vy0), torch.empty_like(vx0)]
+            if self._fin is None:
+                self._fin = [torch.empty_like(d0), torch.empty_like(vy0), torch.empty_like(vx0)]
+            fin = self._fin
         mk = self.masks
-        check(self.lib.sol_train_fwd_bwd(
-            C.byref(self.cfg), stream(), ptr(self.net.params.detach()),
-            ptr(d0), ptr(vy0), ptr(vx0), ptr(re), ptr(mk.active), ptr(mk.inflow),
-            ptr(mk.velBCy), ptr(mk.velBCyMask), mk.bc_stride, ptr(gt_vy), ptr(gt_vx),
-            ptr(self.workspace), self.workspace_bytes, ptr(self.grads), ptr(self.loss_steps),
-            ptr(fin[0]), ptr(fin[1]), ptr(fin[2]), ptr(self.iters_fwd), ptr(self.iters_bwd)))
+        args = [ptr(self.net.params.detach()), ptr(d0), ptr(vy0), ptr(vx0), ptr(re), ptr(mk.active), ptr(mk.inflow),
+                ptr(mk.velBCy), ptr(mk.velBCyMask), mk.bc_stride, ptr(gt_vy), ptr(gt_vx),
+                ptr(self.workspace), self.workspace_bytes, ptr(self.grads), ptr(self.loss_steps),
+                ptr(fin[0]), ptr(fin[1]), ptr(fin[2]), ptr(self.iters_fwd), ptr(self.iters_bwd)]
+        if self.use_graph:
+            # all pointers are baked into the graph: re-capture only when a buffer moved
+            key = tuple(a.value if isinstance(a, C.c_void_p) else a for a in args)
+            if self._graph is None or self._graph[0] != key:
+                if self._graph is not None:
+                    check(self.lib.sol_train_graph_destroy(self._graph[1]))
+                    self._graph = None
+                h = C.c_void_p()
+                torch.cuda.synchronize()
+                check(self.lib.sol_train_graph_create(C.byref(self.cfg), *args, C.byref(h)))
+                self._graph = (key, h)
+            check(self.lib.sol_train_graph_launch(self._graph[1], stream()))
+        else:
+            check(self.lib.sol_train_fwd_bwd(C.byref(self.cfg), stream(), *args))
         self.final = fin if want_final else None
         return self.loss_steps.sum() / ms
 
@@ -116,7 +140,7 @@ class SolRollout:
         _lib.require_gpu()
         self.lib = _lib.load()
         self.net, self.masks, self.B = net, masks, B
-        kc = ops.karman_cfg(B, Y, X, dx, dt=dt, res=res, **solver)
+        kc = ops.karman_cfg(B, Y, X, dx, dt=dt, res=res, masks=masks, **solver)
         self.cfg = TrainCfg(kc, 1, float(std_v[0]), float(std_v[1]), float(std_re), float(net.slope))
         nbytes = self.lib.sol_rollout_workspace_bytes(C.byref(self.cfg))
         self.workspace = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=net.params.device)

@@ -42,7 +42,7 @@ def probe_step():
         wy = torch.randn(py.shape, generator=gen)
         wx = torch.randn(px.shape, generator=gen)
         ((py * wy).sum() + (px * wx).sum()).backward()
-        cfg = ops.karman_cfg(B, Y, X, g.dx)
+        cfg = ops.karman_cfg(B, Y, X, g.dx, masks=mk)
         hvy = vy.detach().float().to(dev).requires_grad_(True)
         hvx = vx.detach().float().to(dev).requires_grad_(True)
         info = {}

@@ -30,9 +30,9 @@ def f32(t):
     return torch.as_tensor(np.asarray(t), dtype=torch.float32).to(DEV).contiguous()
 
 
-def masks_for(Y, X):
+def masks_for(Y, X, precondition=True):
     g = o.geometry(Y, X)
-    return g, ops.SceneMasks(g.active, g.inflow, g.bc_mask, g.bc_mask)
+    return g, ops.SceneMasks(g.active, g.inflow, g.bc_mask, g.bc_mask, precondition=precondition)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -46,13 +46,15 @@ def _loaded_native_library():
 # ---------------------------------------------------------------------------------------------
 # solver step
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precond", [True, False])
 @pytest.mark.parametrize("name,kw", [("karman_step_16x8", {}), ("karman_step_64x32", {}),
                                      ("karman_step_16x8_dirichlet_before", dict(grad_pad="dirichlet0", inflow_order="before"))])
-def test_karman_step_against_golden(golden_dir, name, kw):
+def test_karman_step_against_golden(golden_dir, name, kw, precond):
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     B, Y, X = z["d"].shape
-    g, mk = masks_for(Y, X)
-    cfg = ops.karman_cfg(B, Y, X, g.dx, **kw)
+    g, mk = masks_for(Y, X, precond)
+    assert (mk.coarse_inv is not None) == (precond and Y >= 64)     # two-level CG only where the grid allows it
+    cfg = ops.karman_cfg(B, Y, X, g.dx, masks=mk, **kw)
     vy = f32(z["vy"]).requires_grad_(True)
     vx = f32(z["vx"]).requires_grad_(True)
     info = {}
@@ -63,10 +65,10 @@ def test_karman_step_against_golden(golden_dir, name, kw):
     assert int(info["iterations"].min()) > 5 and int(info["iterations"].max()) < 2000
 
 
-@pytest.mark.parametrize("B", [1, 2])
-def test_karman_step_full_size_against_oracle(B):
+@pytest.mark.parametrize("B,precond", [(1, True), (2, True), (2, False)])
+def test_karman_step_full_size_against_oracle(B, precond):
     Y, X = 128, 64
-    g, mk = masks_for(Y, X)
+    g, mk = masks_for(Y, X, precond)
     d, vy, vx = o.synthetic_state(B, Y, X, 1234)
     re = torch.tensor(o.RE_TRAIN[:B], dtype=torch.float64)
     vy = vy.clone().requires_grad_(True)
@@ -78,10 +80,13 @@ def test_karman_step_full_size_against_oracle(B):
     ((py * wy).sum() + (px * wx).sum()).backward()
     hvy = f32(vy.detach()).requires_grad_(True)
     hvx = f32(vx.detach()).requires_grad_(True)
-    hd, hpy, hpx = ops.karman_step(f32(d), hvy, hvx, f32(re), ops.karman_cfg(B, Y, X, g.dx), mk)
+    info = {}
+    hd, hpy, hpx = ops.karman_step(f32(d), hvy, hvx, f32(re), ops.karman_cfg(B, Y, X, g.dx, masks=mk), mk, info)
     ((hpy * f32(wy)).sum() + (hpx * f32(wx)).sum()).backward()
     assert rel(hd, d2) < TOL_FIELD and rel(hpy, py) < TOL_FIELD and rel(hpx, px) < TOL_FIELD
     assert rel(hvy.grad, vy.grad) < TOL_GRAD and rel(hvx.grad, vx.grad) < TOL_GRAD
+    its = int(info["iterations"].max())
+    assert (its < 100) if precond else (150 < its < 400)      # the coarse space cuts the iteration count ~4x
 
 
 def test_full_size_properties():
@@ -90,7 +95,7 @@ def test_full_size_properties():
     g, mk = masks_for(Y, X)
     d, vy, vx = (f32(t) for t in sol_amd.synthetic.state(B, Y, X, 1))
     re = f32(sol_amd.synthetic.reynolds(B))
-    cfg = ops.karman_cfg(B, Y, X, g.dx)
+    cfg = ops.karman_cfg(B, Y, X, g.dx, masks=mk)
     d2, py, px = ops.karman_step(d, vy, vx, re, cfg, mk)
     # (a) divergence free on interior fluid cells (boundary cells keep PhiFlow's replicate-pad quirk)
     div = (py[:, 1:, :] - py[:, :-1, :]) + (px[:, :, 1:] - px[:, :, :-1])

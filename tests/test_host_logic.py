@@ -92,3 +92,22 @@ def test_lr_schedule_and_sharding():
     assert sol_amd.dist.shard_range(48, 3, 8) == (18, 24)
     with pytest.raises(ValueError):
         sol_amd.dist.shard_range(10, 0, 4)
+
+
+def test_coarse_inverse_matches_galerkin_projection_of_the_oracle_matrix():
+    import scipy.sparse as sp
+    from sol_amd.precond import pressure_matrix_dense_coarse, coarse_inverse
+    Y, X = 64, 32
+    g = o.geometry(Y, X)
+    M = (-g.pressure_matrix()).tocsr()
+    N = Y * X
+    jj, ii = np.divmod(np.arange(N), X)
+    blk = (jj // 8) * (X // 8) + ii // 8
+    P = sp.csr_matrix((g.active.ravel(), (np.arange(N), blk)), shape=(N, (Y // 8) * (X // 8)))
+    ref = (P.T @ M @ P).toarray()
+    assert np.allclose(pressure_matrix_dense_coarse(g.active), ref, atol=1e-12)
+    ci = coarse_inverse(g.active)
+    assert ci.dtype == np.float32 and np.allclose(ci @ ref, np.eye(ref.shape[0]), atol=1e-4)
+    lib = sol_amd.load()
+    assert lib.sol_karman_precond_supported(128, 64) == 1 and lib.sol_karman_precond_supported(64, 32) == 1
+    assert lib.sol_karman_precond_supported(16, 8) == 0

@@ -14,6 +14,7 @@ p.add_argument("--rtol", type=float, default=1e-6)
 p.add_argument("--res", type=int, default=64)
 p.add_argument("--batch", type=int, default=6)
 p.add_argument("--bwd", action="store_true")
+p.add_argument("--maxiter", type=int, default=2000)
 a = p.parse_args()
 X, Y, B = a.res, 2 * a.res, a.batch
 dom = sol_amd.Domain([Y, X], box=sol_amd.box[0:200, 0:100])
@@ -24,7 +25,7 @@ masks = ops.SceneMasks(active, inflow, bcv.reshape(Y + 1, X), bcm.reshape(Y + 1,
 f = lambda t: t.to(device="cuda", dtype=torch.float32).contiguous()
 d0, vy0, vx0 = (f(t) for t in synthetic.state(B, Y, X, 1234))
 re = f(synthetic.reynolds(B))
-cfg = ops.karman_cfg(B, Y, X, dom.dx[1], cg_rtol=a.rtol)
+cfg = ops.karman_cfg(B, Y, X, dom.dx[1], cg_rtol=a.rtol, cg_max_iter=a.maxiter, masks=masks)
 d0, vy0, vx0 = (t.detach() for t in ops.karman_step(d0, vy0, vx0, re, cfg, masks))
 info = {}
 if a.bwd:
