@@ -389,26 +389,40 @@ __global__ void __launch_bounds__(768) k_conv5x5_r3(ConvArgs a, int ntiles) {
         }
         const float* hrow = halo + (dy & 1) * SLOT;
         const float* wbuf = Wt + (dy & 1) * WBUF;
-#pragma unroll
-        for (int dx = 0; dx < 5; ++dx) {
+        // register double buffering of the MFMA operands: the ds_reads of tap dx+1 are issued before the
+        // 8*NT MFMAs of tap dx, so one LDS latency per tap row is exposed instead of one per 4 MFMAs
+        float4 ao[2][2], bo[2][NT][2];
+        auto load_ops = [&](int dx, float4 (&ar)[2], float4 (&br)[NT][2]) {
             const int hc = pcc + dx;
             const float* ap = hrow + hc * 32;
             const int sa = swz(hc);
-            const float4 a0 = *reinterpret_cast<const float4*>(ap + ((g ^ sa) << 2));
-            const float4 a1 = *reinterpret_cast<const float4*>(ap + (((g + 4) ^ sa) << 2));
-            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            ar[0] = *reinterpret_cast<const float4*>(ap + ((g ^ sa) << 2));
+            ar[1] = *reinterpret_cast<const float4*>(ap + (((g + 4) ^ sa) << 2));
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int co = n * 16 + li;
                 const float* bp = wbuf + (dx * OP + co) * 32;
                 const int sb = swz(co);
-                const float4 b0 = *reinterpret_cast<const float4*>(bp + ((g ^ sb) << 2));
-                const float4 b1 = *reinterpret_cast<const float4*>(bp + (((g + 4) ^ sb) << 2));
+                br[n][0] = *reinterpret_cast<const float4*>(bp + ((g ^ sb) << 2));
+                br[n][1] = *reinterpret_cast<const float4*>(bp + (((g + 4) ^ sb) << 2));
+            }
+        };
+        load_ops(0, ao[0], bo[0]);
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+            if (dx < 4) load_ops(dx + 1, ao[(dx + 1) & 1], bo[(dx + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ds_reads above this tap's MFMAs
+            const float4 a0 = ao[dx & 1][0], a1 = ao[dx & 1][1];
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float4 b0 = bo[dx & 1][n][0], b1 = bo[dx & 1][n][1];
                 const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk)
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[kk], acc[n], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (dy < 4) {
             store_row((dy + 1) & 1, hv);
@@ -481,6 +495,9 @@ struct BwArgs {
     float* partial;
     int B, H, W, cin, cout;
     int nblk;
+    int nseg, rb;                 // nseg tensors of B*H rows each (the unrolled steps), rb image rows per workgroup
+    long x_seg, dz_seg;           // element strides between consecutive segments
+    int overwrite;                // 1: partial = acc (single launch), 0: partial += acc (accumulate over launches)
 };
 
 template <int CIN, int COUT>   // real channel counts: CIN in {3,4,32} staged as pad_in, COUT in {2,32}
@@ -509,8 +526,8 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww(BwArgs a) {
     for (int d = 0; d < 5; ++d) acc[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
 
-    const int R = a.B * H;
-    const int gr_end = min((blk + 1) * RB, R);
+    const int R = a.nseg * a.B * H, RPS = a.B * H;
+    const int gr_end = min((blk + 1) * a.rb, R);
     // rows this workgroup visits: dy == 2 always (bias needs every dz row), else only valid taps
     auto row_valid = [&](int gr) { const int y = gr % H, yy = y + dy - 2; return yy >= 0 && yy < H; };
     auto next_row = [&](int gr) { while (gr < gr_end && !(dy == 2 || row_valid(gr))) ++gr; return gr; };
@@ -518,9 +535,10 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww(BwArgs a) {
     float4 xr[NXR];
     float4 zr[NZR];
     auto load_row = [&](int gr) {
-        const int b = gr / H, y = gr - b * H, yy = y + dy - 2;
+        const int seg = gr / RPS, grs = gr - seg * RPS;
+        const int b = grs / H, y = grs - b * H, yy = y + dy - 2;
         const bool valid = yy >= 0 && yy < H;
-        const float4* gx = reinterpret_cast<const float4*>(a.x) + (size_t)(b * H + (valid ? yy : 0)) * W * XF4;
+        const float4* gx = reinterpret_cast<const float4*>(a.x + (size_t)seg * a.x_seg) + (size_t)(b * H + (valid ? yy : 0)) * W * XF4;
 #pragma unroll
         for (int n = 0; n < NXR; ++n) {
             const int e = tid + n * 256;
@@ -529,14 +547,14 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww(BwArgs a) {
             if (valid && px < W + 4 && xx >= 0 && xx < W) xr[n] = gx[xx * XF4 + c4];
         }
         if constexpr (COUT > 4) {
-            const float4* gz = reinterpret_cast<const float4*>(a.dz) + (size_t)(b * H + y) * W * (COUT / 4);
+            const float4* gz = reinterpret_cast<const float4*>(a.dz + (size_t)seg * a.dz_seg) + (size_t)(b * H + y) * W * (COUT / 4);
 #pragma unroll
             for (int n = 0; n < NZR; ++n) {
                 const int e = tid + n * 256;
                 zr[n] = e < W * (COUT / 4) ? gz[e] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
-            const float2* gz = reinterpret_cast<const float2*>(a.dz) + (size_t)(b * H + y) * W;
+            const float2* gz = reinterpret_cast<const float2*>(a.dz + (size_t)seg * a.dz_seg) + (size_t)(b * H + y) * W;
             const float2 v = tid < W ? gz[tid] : make_float2(0.f, 0.f);
             zr[0] = make_float4(v.x, v.y, 0.f, 0.f);
         }
@@ -562,7 +580,7 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww(BwArgs a) {
         }
     };
 
-    int gr = next_row(blk * RB);
+    int gr = next_row(blk * a.rb);
     int cur = 0;
     if (gr < gr_end) {
         load_row(gr);
@@ -607,7 +625,8 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww(BwArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ci = ta * 16 + 4 * g + r, co = tc * 16 + li;
-            pw[(tap * IP + ci) * OP + co] += acc[d][r];
+            float* dst = &pw[(tap * IP + ci) * OP + co];
+            *dst = a.overwrite ? acc[d][r] : *dst + acc[d][r];
         }
     }
     if (dy == 2 && ta == 0) {
@@ -615,7 +634,7 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww(BwArgs a) {
         bsum += __shfl_xor(bsum, 32, 64);
         if (g == 0) {
             float* pb = a.partial + (size_t)a.nblk * (25 * IP * OP) + (size_t)blk * OP;
-            pb[tc * 16 + li] += bsum;
+            pb[tc * 16 + li] = a.overwrite ? bsum : pb[tc * 16 + li] + bsum;
         }
     }
 }
@@ -640,22 +659,23 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww32(BwArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
     float bsum = 0.f;
-    const int R = a.B * H;
-    const int gr_end = min((blk + 1) * RB, R);
+    const int R = a.nseg * a.B * H, RPS = a.B * H;
+    const int gr_end = min((blk + 1) * a.rb, R);
     auto row_valid = [&](int gr) { const int y = gr % H, yy = y + dy - 2; return yy >= 0 && yy < H; };
     auto next_row = [&](int gr) { while (gr < gr_end && !(dy == 2 || row_valid(gr))) ++gr; return gr; };
     float4 xr[3], zr[2];
     auto load_row = [&](int gr) {
-        const int b = gr / H, y = gr - b * H, yy = y + dy - 2;
+        const int seg = gr / RPS, grs = gr - seg * RPS;
+        const int b = grs / H, y = grs - b * H, yy = y + dy - 2;
         const bool valid = yy >= 0 && yy < H;
-        const float4* gx = reinterpret_cast<const float4*>(a.x) + (size_t)(b * H + (valid ? yy : 0)) * W * 8;
+        const float4* gx = reinterpret_cast<const float4*>(a.x + (size_t)seg * a.x_seg) + (size_t)(b * H + (valid ? yy : 0)) * W * 8;
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
             const int e = tid + n * 256, px = e >> 3, c4 = e & 7, xx = px - 2;
             xr[n] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (valid && px < W + 4 && xx >= 0 && xx < W) xr[n] = gx[xx * 8 + c4];
         }
-        const float4* gz = reinterpret_cast<const float4*>(a.dz) + (size_t)(b * H + y) * W * 8;
+        const float4* gz = reinterpret_cast<const float4*>(a.dz + (size_t)seg * a.dz_seg) + (size_t)(b * H + y) * W * 8;
 #pragma unroll
         for (int n = 0; n < 2; ++n) zr[n] = gz[tid + n * 256];
     };
@@ -669,7 +689,7 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww32(BwArgs a) {
 #pragma unroll
         for (int n = 0; n < 2; ++n) zs4[tid + n * 256] = zr[n];
     };
-    int gr = next_row(blk * RB);
+    int gr = next_row(blk * a.rb);
     int cur = 0;
     if (gr < gr_end) { load_row(gr); store_row(smem); }
     __syncthreads();
@@ -707,7 +727,9 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww32(BwArgs a) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int idx = tid + n * 256;
-            pw[(dy * 5 + d) * 1024 + idx] += (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
+            const float v = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
+            float* dst = &pw[(dy * 5 + d) * 1024 + idx];
+            *dst = a.overwrite ? v : *dst + v;
         }
         __syncthreads();
     }
@@ -717,27 +739,184 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww32(BwArgs a) {
         __syncthreads();
         if (tid < 32) {
             float* pb = a.partial + (size_t)a.nblk * (25 * 1024) + (size_t)blk * 32;
-            pb[tid] += (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]);
+            const float v = (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]);
+            pb[tid] = a.overwrite ? v : pb[tid] + v;
         }
     }
 }
 
-__global__ void k_bww_reduce(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
-                             int nblk, int cin, int cout, int IP, int OP, int accumulate) {
+// Weight gradient of the two thin layers (first: 3(+1 pad) -> 32 channels, last: 32 -> 2) on
+// v_mfma_f32_32x32x2_f32 with the five dx taps folded into the otherwise empty matrix dimension:
+//   MODE 0 (cin 4, cout 32):  A[i = 4*dx+ci][k = px] = x[px+dx][ci],   B[k = px][j = co]      = dz[px][co]
+//   MODE 1 (cin 32, cout 2):  A[i = ci][k = q]       = x[q][ci],       B[k = q][j = 2*dx+co]  = dz[q-dx][co]
+// so one accumulator per tap row dy holds all five dx taps and a workgroup (4 waves, K split over the
+// pixels) keeps the 5 accumulators of ALL tap rows: x and dz are read once instead of 5 times, and the
+// MFMA count per row drops 10x/16x compared with the generic kernel (which spent as long on these
+// layers as on a full 32x32 one).  Rows are double buffered in LDS with register prefetch.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_conv5x5_bww_thin(BwArgs a) {
+    constexpr int W = 64;
+    constexpr int XC = MODE == 0 ? 4 : 32, ZC = MODE == 0 ? 32 : 2;            // channels per pixel of x / dz
+    constexpr int XROWS = MODE == 0 ? 5 : 1, ZROWS = MODE == 0 ? 1 : 5;        // rows staged per iteration
+    constexpr int XSZ = (W + 4) * XC;
+    constexpr int ZSZ = (MODE == 0 ? W + 4 : W + 8) * ZC;                      // MODE 1: dz rows staged with 4 zero pixels in front and behind
+    constexpr int STG = XROWS * XSZ + ZROWS * ZSZ;
+    constexpr int IP = MODE == 0 ? 16 : 32, OP = MODE == 0 ? 32 : 16;
+    constexpr int XF4 = XROWS * XSZ / 4, ZF4 = ZROWS * ZSZ / 4;                // float4 per stage
+    constexpr int NXR = (XF4 + 255) / 256, NZR = (ZF4 + 255) / 256;
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, kpx = lane >> 5;
+    const int H = a.H, blk = blockIdx.x;
+    f32x16 acc[5];
+#pragma unroll
+    for (int d = 0; d < 5; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+    float bsum = 0.f;
+    const int R = a.nseg * a.B * H, RPS = a.B * H;
+    const int gr_end = min((blk + 1) * a.rb, R);
+    float4 xr[NXR], zr[NZR];
+    // iteration row gr: MODE 0 = dz (output) row, needs x rows y+dy-2; MODE 1 = x (input) row, needs dz rows y+2-dy
+    auto load_row = [&](int gr) {
+        const int seg = gr / RPS, grs = gr - seg * RPS;
+        const int b = grs / H, y = grs - b * H;
+        const float* xb = a.x + (size_t)seg * a.x_seg + (size_t)b * H * W * XC;
+        const float* zb = a.dz + (size_t)seg * a.dz_seg + (size_t)b * H * W * ZC;
+#pragma unroll
+        for (int n = 0; n < NXR; ++n) {
+            const int e = tid + n * 256;              // float4 index inside the x stage
+            xr[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < XF4) {
+                const int row = e / (XSZ / 4), f = e - row * (XSZ / 4);
+                const int px = f / (XC / 4), c4 = f - px * (XC / 4), xx = px - 2;
+                const int yy = MODE == 0 ? y + row - 2 : y;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) xr[n] = reinterpret_cast<const float4*>(xb + ((size_t)yy * W + xx) * XC)[c4];
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NZR; ++n) {
+            const int e = tid + n * 256;
+            zr[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < ZF4) {
+                if (MODE == 0) {                      // one dz row, no halo: pixels 0..63 at stage pixels 0..63
+                    if (e < W * ZC / 4) zr[n] = reinterpret_cast<const float4*>(zb + (size_t)y * W * ZC)[e];
+                } else {                              // five dz rows y+2-dy, each [72 px][2] with pixel p at stage pixel p+4
+                    const int row = e / (ZSZ / 4), f = e - row * (ZSZ / 4);      // f: float4 = 2 pixels
+                    const int yy = y + 2 - row, p = 2 * f - 4;
+                    if (yy >= 0 && yy < H && p >= 0 && p < W) zr[n] = reinterpret_cast<const float4*>(zb + ((size_t)yy * W + p) * ZC)[0];
+                }
+            }
+        }
+    };
+    auto store_row = [&](float* buf) {
+#pragma unroll
+        for (int n = 0; n < NXR; ++n) { const int e = tid + n * 256; if (e < XF4) reinterpret_cast<float4*>(buf)[e] = xr[n]; }
+#pragma unroll
+        for (int n = 0; n < NZR; ++n) { const int e = tid + n * 256; if (e < ZF4) reinterpret_cast<float4*>(buf + XROWS * XSZ)[e] = zr[n]; }
+    };
+    int gr = blk * a.rb, cur = 0;
+    if (gr < gr_end) { load_row(gr); store_row(smem); }
+    __syncthreads();
+    for (; gr < gr_end; ++gr) {
+        if (gr + 1 < gr_end) load_row(gr + 1);
+        const float* xs = smem + cur * STG;
+        const float* zs = xs + XROWS * XSZ;
+        if (MODE == 0) {
+            // wave handles pixels [16*wave, 16*wave+16): 8 k-steps of 2 pixels
+            const int dxi = c >> 2, ci = c & 3;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int px = 16 * wave + 2 * ks + kpx;
+                const float bv = zs[px * 32 + c];
+                bsum += bv;
+#pragma unroll
+                for (int d = 0; d < 5; ++d) {        // tap row dy = d uses x row slot d (= image row y+d-2, zero if outside)
+                    const float av = c < 20 ? xs[d * XSZ + (px + dxi) * 4 + ci] : 0.f;
+                    acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[d], 0, 0, 0);
+                }
+            }
+        } else {
+            // K runs over the 68 halo pixels q of the x row: wave handles q in [17*wave, 17*wave+17) -> 9 k-steps (last half masked)
+            const int dxi = c >> 1, co = c & 1;
+#pragma unroll
+            for (int ks = 0; ks < 9; ++ks) {
+                const int qq = 17 * wave + 2 * ks + kpx;
+                const bool ok = 2 * ks + kpx < 17;
+                const float av = ok ? xs[qq * 32 + c] : 0.f;
+                // B[q][j=(dx,co)] = dz[q-2-dx+... ]: x halo pixel q is image pixel q-2; output pixel = q-2-(dx-2) = q-dx -> stage pixel q-dx+4
+#pragma unroll
+                for (int d = 0; d < 5; ++d) {        // tap row dy = d pairs x row y with dz row y+2-d (stage slot d)
+                    const float bv = (ok && c < 10) ? zs[d * ZSZ + (qq - dxi + 4) * 2 + co] : 0.f;
+                    if (d == 2 && c < 2) bsum += bv;  // dx = 0 columns of the dy = 2 slot: dz[q-... ] summed once per pixel
+                    acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[d], 0, 0, 0);
+                }
+            }
+        }
+        if (gr + 1 < gr_end) store_row(smem + (cur ^ 1) * STG);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // fold the 4 K-split accumulators through LDS, one tap row at a time
+    float* red = smem;                                  // [4][32][32]
+    float* pw = a.partial + (size_t)blk * (25 * IP * OP);
+    for (int d = 0; d < 5; ++d) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kpx;
+            red[wave * 1024 + row * 32 + c] = acc[d][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int idx = tid + n * 256, row = idx >> 5, col = idx & 31;
+            const float v = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
+            int tap, ci, co;
+            bool keep;
+            if (MODE == 0) { tap = d * 5 + (row >> 2); ci = row & 3; co = col; keep = row < 20; }
+            else { tap = d * 5 + (col >> 1); ci = row; co = col & 1; keep = col < 10; }
+            if (keep) {
+                float* dst = &pw[(tap * IP + ci) * OP + co];
+                *dst = a.overwrite ? v : *dst + v;
+            }
+        }
+        __syncthreads();
+    }
+    {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (kpx == 0) red[wave * 32 + c] = bsum;
+        __syncthreads();
+        const int nb = MODE == 0 ? 32 : 2;
+        if (tid < nb) {
+            float* pb = a.partial + (size_t)a.nblk * (25 * IP * OP) + (size_t)blk * OP;
+            const float v = (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]);
+            pb[tid] = a.overwrite ? v : pb[tid] + v;
+        }
+    }
+}
+
+// partial [nblk][25][IP][OP] (+ [nblk][OP] bias sums) -> dw [25][cin][cout], db [cout], deterministic:
+// stage 1 (to_dw = 0): grid.y chunks of `chunk` blocks are summed in parallel, the sum is written back into
+// the first block of the chunk; stage 2 (to_dw = 1): the chunk heads (stride `chunk`) are summed in order.
+__global__ void k_bww_reduce(float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
+                             int nblk, int cin, int cout, int IP, int OP, int chunk, int stride, int to_dw, int accumulate) {
     const int nw = 25 * cin * cout;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k0 = blockIdx.y * chunk * stride, k1 = min(k0 + chunk * stride, nblk);
     if (e < nw) {
         const int co = e % cout, ci = (e / cout) % cin, tap = e / (cout * cin);
         const size_t off = (size_t)(tap * IP + ci) * OP + co;
         float s = 0.f;
-        for (int k = 0; k < nblk; ++k) s += partial[(size_t)k * (25 * IP * OP) + off];
-        dw[e] = accumulate ? dw[e] + s : s;
+        for (int k = k0; k < k1; k += stride) s += partial[(size_t)k * (25 * IP * OP) + off];
+        if (to_dw) dw[e] = accumulate ? dw[e] + s : s;
+        else partial[(size_t)k0 * (25 * IP * OP) + off] = s;
     } else if (e < nw + cout) {
         const int co = e - nw;
-        const float* pb = partial + (size_t)nblk * (25 * IP * OP);
+        float* pb = partial + (size_t)nblk * (25 * IP * OP);
         float s = 0.f;
-        for (int k = 0; k < nblk; ++k) s += pb[(size_t)k * OP + co];
-        db[co] = accumulate ? db[co] + s : s;
+        for (int k = k0; k < k1; k += stride) s += pb[(size_t)k * OP + co];
+        if (to_dw) db[co] = accumulate ? db[co] + s : s;
+        else pb[(size_t)k0 * OP + co] = s;
     }
 }
 
@@ -821,33 +1000,61 @@ extern "C" int sol_conv5x5(void* stream, const float* x, const float* packed, co
     return SOL_OK;
 }
 
-static int bww_dims(int B, int H, int cin, int cout, int* nblk, int* IP, int* OP) {
-    *nblk = (B * H + RB - 1) / RB;
+static int bww_dims(int rows, int rb, int cin, int cout, int* nblk, int* IP, int* OP) {
+    *nblk = (rows + rb - 1) / rb;
     *IP = cin <= 4 ? 16 : 32;
     *OP = cout <= 16 ? 16 : 32;
     return 0;
 }
 
+// image rows per workgroup: 8 for a single tensor; for the batched (all unrolled steps in one launch)
+// form enough rows that ~1300-2600 workgroups exist and the partial buffer stays small
+static int pick_rb(int rows) {
+    int rb = RB;
+    while (rows / rb > 512) rb *= 2;
+    return rb;
+}
+
 extern "C" size_t sol_conv5x5_bwd_weight_ws_floats(int32_t B, int32_t H, int32_t /*W*/, int32_t cin, int32_t cout) {
     int nblk, IP, OP;
-    bww_dims(B, H, cin, cout, &nblk, &IP, &OP);
+    bww_dims(B * H, RB, cin, cout, &nblk, &IP, &OP);
     return (size_t)nblk * (25 * IP * OP + OP);
 }
 
-extern "C" int sol_conv5x5_bwd_weight(void* stream, const float* x, const float* dz, float* partial,
-                                      int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout) {
+size_t sol_bww_batched_ws_floats(int nseg, int B, int H, int cin, int cout) {
+    int nblk, IP, OP;
+    const int rows = nseg * B * H;
+    bww_dims(rows, pick_rb(rows), cin, cout, &nblk, &IP, &OP);
+    return (size_t)nblk * (25 * IP * OP + OP);
+}
+
+static int bww_launch(void* stream, const float* x, const float* dz, float* partial, int nseg, long x_seg, long dz_seg,
+                      int rb, int overwrite, int B, int H, int W, int cin, int cout) {
     SOL_REQUIRE(x && dz && partial, "sol_conv5x5_bwd_weight: NULL pointer");
     SOL_REQUIRE(B >= 1 && H >= 1 && W >= 4 && W % 4 == 0 && W <= 64, "sol_conv5x5_bwd_weight: need 4 <= W <= 64, W %% 4 == 0 (got %d)", W);
     SOL_REQUIRE((cin == 4 || cin == 32) && (cout == 2 || cout == 32),
                 "sol_conv5x5_bwd_weight: supported (cin,cout) are {4,32}x{2,32} (got %d,%d)", cin, cout);
     BwArgs a{};
     a.x = x; a.dz = dz; a.partial = partial; a.B = B; a.H = H; a.W = W; a.cin = cin; a.cout = cout;
+    a.nseg = nseg; a.rb = rb; a.x_seg = x_seg; a.dz_seg = dz_seg; a.overwrite = overwrite;
     int IP, OP;
-    bww_dims(B, H, cin, cout, &a.nblk, &IP, &OP);
+    bww_dims(nseg * B * H, rb, cin, cout, &a.nblk, &IP, &OP);
     const int CPX = cin == 4 ? 4 : 48, CPZ = cout <= 4 ? 4 : 48;
     const size_t lds = 2 * ((size_t)(W + 4) * CPX + (size_t)W * CPZ) * sizeof(float);   // double buffered rows
     const int grid = a.nblk * 5;
     hipStream_t s = (hipStream_t)stream;
+    if (W == 64 && ((cin == 4 && cout == 32) || (cin == 32 && cout == 2)) && !getenv("SOL_CONV_NO_THIN")) {
+        // all five tap rows in one workgroup: grid = nblk; LDS = 2 stages (>= the 16 KB fold buffer)
+        if (cin == 4) {
+            const size_t l0 = 2 * (size_t)(5 * 68 * 4 + 68 * 32) * sizeof(float);
+            hipLaunchKernelGGL(k_conv5x5_bww_thin<0>, dim3(a.nblk), dim3(256), l0, s, a);
+        } else {
+            const size_t l1 = 2 * (size_t)(68 * 32 + 5 * 72 * 2) * sizeof(float);
+            hipLaunchKernelGGL(k_conv5x5_bww_thin<1>, dim3(a.nblk), dim3(256), l1, s, a);
+        }
+        SOL_LAUNCH_CHECK();
+        return SOL_OK;
+    }
     if (cin == 32 && cout == 32 && W == 64 && !getenv("SOL_CONV_NO_BWW32")) {
         const size_t lds3 = 2 * ((size_t)(64 + 4) * 32 + 64 * 32) * sizeof(float);
         hipLaunchKernelGGL(k_conv5x5_bww32, dim3(grid), dim3(256), lds3, s, a);
@@ -860,16 +1067,45 @@ extern "C" int sol_conv5x5_bwd_weight(void* stream, const float* x, const float*
     return SOL_OK;
 }
 
-extern "C" int sol_conv5x5_bwd_weight_reduce(void* stream, const float* partial, float* dw_hwio, float* db,
-                                             int32_t B, int32_t H, int32_t /*W*/, int32_t cin, int32_t cout,
-                                             int32_t accumulate) {
+extern "C" int sol_conv5x5_bwd_weight(void* stream, const float* x, const float* dz, float* partial,
+                                      int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout) {
+    return bww_launch(stream, x, dz, partial, 1, 0, 0, RB, 0, B, H, W, cin, cout);
+}
+
+// all unrolled steps of one layer in ONE launch: segment s reads x + s*x_seg, dz + s*dz_seg (partial is overwritten)
+int sol_bww_batched(void* stream, const float* x, const float* dz, float* partial, int nseg, long x_seg, long dz_seg,
+                    int B, int H, int W, int cin, int cout) {
+    return bww_launch(stream, x, dz, partial, nseg, x_seg, dz_seg, pick_rb(nseg * B * H), 1, B, H, W, cin, cout);
+}
+
+static int bww_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int rows, int rb, int cin, int cout, int accumulate) {
     SOL_REQUIRE(partial && dw_hwio && db, "sol_conv5x5_bwd_weight_reduce: NULL pointer");
     SOL_REQUIRE(cin >= 1 && cin <= 32 && cout >= 1 && cout <= 32, "sol_conv5x5_bwd_weight_reduce: channels out of range");
     int nblk, IP, OP;
-    bww_dims(B, H, cin <= 4 ? 4 : 32, cout, &nblk, &IP, &OP);
+    bww_dims(rows, rb, cin <= 4 ? 4 : 32, cout, &nblk, &IP, &OP);
     const int total = 25 * cin * cout + cout;
-    hipLaunchKernelGGL(k_bww_reduce, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       partial, dw_hwio, db, nblk, cin, cout, IP, OP, accumulate);
+    float* pm = const_cast<float*>(partial);       // the caller's workspace: chunk sums are folded in place
+    const int chunk = 16, ny = (nblk + chunk - 1) / chunk;
+    hipStream_t hs = (hipStream_t)stream;
+    if (ny > 1) {
+        hipLaunchKernelGGL(k_bww_reduce, dim3((total + 255) / 256, ny), dim3(256), 0, hs, pm, dw_hwio, db, nblk, cin, cout, IP, OP, chunk, 1, 0, 0);
+        SOL_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_bww_reduce, dim3((total + 255) / 256, 1), dim3(256), 0, hs, pm, dw_hwio, db, nblk, cin, cout, IP, OP, ny, chunk, 1, accumulate);
+    } else {
+        hipLaunchKernelGGL(k_bww_reduce, dim3((total + 255) / 256, 1), dim3(256), 0, hs, pm, dw_hwio, db, nblk, cin, cout, IP, OP, nblk, 1, 1, accumulate);
+    }
     SOL_LAUNCH_CHECK();
     return SOL_OK;
+}
+
+extern "C" int sol_conv5x5_bwd_weight_reduce(void* stream, const float* partial, float* dw_hwio, float* db,
+                                             int32_t B, int32_t H, int32_t /*W*/, int32_t cin, int32_t cout,
+                                             int32_t accumulate) {
+    return bww_reduce(stream, partial, dw_hwio, db, B * H, RB, cin, cout, accumulate);
+}
+
+int sol_bww_batched_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int nseg, int B, int H,
+                           int cin, int cout, int accumulate) {
+    const int rows = nseg * B * H;
+    return bww_reduce(stream, partial, dw_hwio, db, rows, pick_rb(rows), cin, cout, accumulate);
 }

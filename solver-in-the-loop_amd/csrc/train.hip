@@ -146,7 +146,8 @@ struct Ws {
     float *acts;                   // [msteps][11][cells][32]
     float *O;                      // [cells][2]
     float *gA, *gB;                // [cells][32]
-    float *dO4, *dO2, *dF;         // [cells][4], [cells][2], [cells][2]
+    float *dO4, *dO2, *dF;         // [cells][4], [msteps][cells][2], [cells][2]
+    float *dzb;                    // [msteps][11][cells][32]: pre-activation gradients kept for the batched weight gradient
     float *gvy[2], *gvx[2];
     float *wf[NL], *wb[NL], *bias[NL];
     float *part[NL];
@@ -171,14 +172,15 @@ size_t carve_ws(const sol_train_cfg* c, float* base, Ws& w, bool training) {
     w.acts = take((size_t)ms * 11 * w.cells * 32);
     w.O = take(w.cells * 2);
     w.gA = take(w.cells * 32); w.gB = take(w.cells * 32);
-    w.dO4 = take(w.cells * 4); w.dO2 = take(w.cells * 2); w.dF = take(w.cells * 2);
+    w.dO4 = take(w.cells * 4); w.dO2 = take((size_t)ms * w.cells * 2); w.dF = take(w.cells * 2);
+    w.dzb = take(training ? (size_t)ms * 11 * w.cells * 32 : 0);
     for (int k = 0; k < 2; ++k) { w.gvy[k] = take(w.st_vy); w.gvx[k] = take(w.st_vx); }
     for (int l = 0; l < NL; ++l) {
         const int cin = layer_cin(l), cout = layer_cout(l);
         w.wf[l] = take(sol_conv5x5_packed_floats(cin == 3 ? 4 : cin, cout, SOL_CONV_FWD));
         w.wb[l] = take(sol_conv5x5_packed_floats(cout == 2 ? 4 : cout, cin, SOL_CONV_BWD_DATA));
         w.bias[l] = take(32);
-        w.part_floats[l] = training ? sol_conv5x5_bwd_weight_ws_floats(B, Y, X, cin == 3 ? 4 : cin, cout) : 0;
+        w.part_floats[l] = training ? sol_bww_batched_ws_floats(ms, B, Y, cin == 3 ? 4 : cin, cout) : 0;
         w.part[l] = take(w.part_floats[l]);
     }
     w.adam_scale = take(64);
@@ -331,39 +333,48 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
     if (io.vx_final) SOL_HIP_CHECK(hipMemcpyAsync(io.vx_final + (size_t)b0 * w.nVx, w.vx + (size_t)(ms - 1) * w.st_vx, w.st_vx * sizeof(float), hipMemcpyDeviceToDevice, hs));
 
     // ---------------- reverse sweep ----------------
+    // The weight gradients of the 32 unrolled steps are NOT computed step by step: every pre-activation
+    // gradient dz is kept (2.2 GB at C3, HBM is 288 GB) and each layer's dW is ONE launch over all steps
+    // after the sweep (K = 32x more pixels per launch: no per-step prologue/epilogue/partial traffic).
     int cur = 0;
+    const size_t cl32 = w.cells * 32;
     for (int i = ms - 1; i >= 0; --i) {
         float* gvy = w.gvy[cur];
         float* gvx = w.gvx[cur];
         const float* vycur = w.vy + (size_t)i * w.st_vy;
         const float* vxcur = w.vx + (size_t)i * w.st_vx;
+        float* dO2 = w.dO2 + (size_t)i * w.cells * 2;
         hipLaunchKernelGGL(k_seed, dim3(egrid), dim3(256), 0, hs, gvy, gvx, vycur, vxcur,
                            gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx,
-                           c->std_v0, c->std_v1, 1.f / (float)ms, w.dO4, w.dO2, i == ms - 1 ? 1 : 0, B, Y, X);
+                           c->std_v0, c->std_v1, 1.f / (float)ms, w.dO4, dO2, i == ms - 1 ? 1 : 0, B, Y, X);
         SOL_LAUNCH_CHECK();
-        const float* feat = w.feat + (size_t)i * w.cells * 4;
         const float* act[11];
-        for (int k = 0; k < 11; ++k) act[k] = w.acts + ((size_t)i * 11 + k) * w.cells * 32;
-        // output layer (cout 2)
-        if (int e = sol_conv5x5_bwd_weight(stream, act[10], w.dO2, w.part[11], B, Y, X, 32, 2)) return e;
-        if (int e = sol_conv5x5(stream, w.dO4, wn.wb[11], nullptr, nullptr, act[10], w.gA, B, Y, X, 4, 32, SOL_EPI_DLRELU, sl)) return e;
+        float* D[11];
+        for (int k = 0; k < 11; ++k) {
+            act[k] = w.acts + ((size_t)i * 11 + k) * cl32;
+            D[k] = w.dzb + ((size_t)i * 11 + k) * cl32;
+        }
+        if (int e = sol_conv5x5(stream, w.dO4, wn.wb[11], nullptr, nullptr, act[10], D[10], B, Y, X, 4, 32, SOL_EPI_DLRELU, sl)) return e;
         for (int k = 4; k >= 0; --k) {
             const float* h = act[2 * k];
             const float* a = act[1 + 2 * k];
-            if (int e = sol_conv5x5_bwd_weight(stream, a, w.gA, w.part[2 + 2 * k], B, Y, X, 32, 32)) return e;
-            if (int e = sol_conv5x5(stream, w.gA, wn.wb[2 + 2 * k], nullptr, nullptr, a, w.gB, B, Y, X, 32, 32, SOL_EPI_DLRELU, sl)) return e;
-            if (int e = sol_conv5x5_bwd_weight(stream, h, w.gB, w.part[1 + 2 * k], B, Y, X, 32, 32)) return e;
-            if (int e = sol_conv5x5(stream, w.gB, wn.wb[1 + 2 * k], nullptr, w.gA, h, w.gA, B, Y, X, 32, 32, SOL_EPI_DLRELU, sl)) return e;
+            if (int e = sol_conv5x5(stream, D[2 + 2 * k], wn.wb[2 + 2 * k], nullptr, nullptr, a, D[1 + 2 * k], B, Y, X, 32, 32, SOL_EPI_DLRELU, sl)) return e;
+            if (int e = sol_conv5x5(stream, D[1 + 2 * k], wn.wb[1 + 2 * k], nullptr, D[2 + 2 * k], h, D[2 * k], B, Y, X, 32, 32, SOL_EPI_DLRELU, sl)) return e;
         }
-        if (int e = sol_conv5x5_bwd_weight(stream, feat, w.gA, w.part[0], B, Y, X, 4, 32)) return e;
         if (i > 0) {
-            if (int e = sol_conv5x5(stream, w.gA, wn.wb[0], nullptr, nullptr, nullptr, w.dF, B, Y, X, 32, 2, SOL_EPI_NONE, sl)) return e;
+            if (int e = sol_conv5x5(stream, D[0], wn.wb[0], nullptr, nullptr, nullptr, w.dF, B, Y, X, 32, 2, SOL_EPI_NONE, sl)) return e;
             if (int e = sol_karman_step_bwd(kc, stream, w.svy + (size_t)i * w.st_vy, w.svx + (size_t)i * w.st_vx, re, io.active,
                                             bcm, io.bc_stride, gvy, gvx, w.dF, fscale, w.gvy[cur ^ 1], w.gvx[cur ^ 1],
                                             io.iters_bwd ? io.iters_bwd + (size_t)i * Btot + b0 : nullptr)) return e;
             cur ^= 1;
         }
     }
+    // ---------------- weight gradients, one launch per layer over all unrolled steps ----------------
+    const long seg32 = (long)(11 * cl32);
+    if (int e = sol_bww_batched(stream, w.feat, w.dzb, w.part[0], ms, (long)(w.cells * 4), seg32, B, Y, X, 4, 32)) return e;
+    for (int l = 1; l <= 10; ++l)
+        if (int e = sol_bww_batched(stream, w.acts + (size_t)(l - 1) * cl32, w.dzb + (size_t)l * cl32, w.part[l], ms, seg32, seg32, B, Y, X, 32, 32)) return e;
+    if (int e = sol_bww_batched(stream, w.acts + (size_t)10 * cl32, w.dO2, w.part[11], ms, seg32, (long)(w.cells * 2), B, Y, X, 32, 2)) return e;
     return SOL_OK;
 }
 
@@ -385,7 +396,6 @@ int train_fwd_bwd_impl(const sol_train_cfg* cfg, hipStream_t hs, const TrainIO& 
     if (int e = pack_all(cfg, hs, io.params, w[0], true)) return e;
     SOL_HIP_CHECK(hipMemsetAsync(io.loss_steps, 0, ms * sizeof(float), hs));
     for (int k = 0; k < S; ++k) {
-        for (int l = 0; l < NL; ++l) SOL_HIP_CHECK(hipMemsetAsync(w[k].part[l], 0, w[k].part_floats[l] * sizeof(float), hs));
         SOL_HIP_CHECK(hipMemsetAsync(w[k].dO4, 0, w[k].cells * 4 * sizeof(float), hs));
     }
     if (io.iters_bwd) SOL_HIP_CHECK(hipMemsetAsync(io.iters_bwd, 0, B * sizeof(int32_t), hs));   // step 0 needs no adjoint
@@ -404,7 +414,7 @@ int train_fwd_bwd_impl(const sol_train_cfg* cfg, hipStream_t hs, const TrainIO& 
         const int cin = layer_cin(l), cout = layer_cout(l);
         const int64_t koff = layer_koff(l), boff = koff + 25 * cin * cout;
         for (int k = 0; k < S; ++k)
-            if (int e = sol_conv5x5_bwd_weight_reduce(hs, w[k].part[l], grads + koff, grads + boff, B / S, Y, X, cin, cout, k > 0)) return e;
+            if (int e = sol_bww_batched_reduce(hs, w[k].part[l], grads + koff, grads + boff, ms, B / S, Y, cin, cout, k > 0)) return e;
     }
     return SOL_OK;
 }

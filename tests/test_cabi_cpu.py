@@ -72,7 +72,8 @@ def test_workspace_sizes_and_layer_table(lib):
     tc = _lib.TrainCfg(ops.karman_cfg(6, 128, 64, 1.5625), 32, 0.2, 0.2, 1.0, 0.3)
     nb = lib.sol_train_workspace_bytes(C.byref(tc))
     # dominated by 11 x 32-channel activations per sim-step: 32*11*6*8192*32*4 B = 2.2 GB
-    assert 2.2e9 < nb < 2.8e9
+    # + the kept pre-activation gradients (same size) for the batched weight gradient
+    assert 4.4e9 < nb < 5.2e9
     assert lib.sol_rollout_workspace_bytes(C.byref(tc)) < nb / 20
     import torch
     net = sol_amd.model_mars_moon(cin=3, cout=2, device="cpu")
