@@ -75,6 +75,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     sol_amd._lib.require_gpu()
+    local = local % torch.cuda.device_count()      # (single-GPU debugging of the N>1 path: ranks share device 0)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     X = args.res
