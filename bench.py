@@ -170,12 +170,22 @@ def main():
         flop_conv = 2.0 * 25 * 32 * 32 * B * N
         fwd_b, bwd_b, kf_tr, kb_tr = tr.solver_algorithmic_bytes()
         conv_flops_step = 3.0 * 520000.0 * N * B * ms
-        roof_solver = {"kernel": "k_karman_fwd", "bound": "hbm", "achieved": bytes_step / t_step / 1e9, "peak": 8000.0,
-                       "unit": "GB/s", "frac": bytes_step / t_step / 8e12, "traffic": None,
-                       "launch_us": t_step * 1e6, "cg_iters": k_f, "algorithmic_bytes_per_launch": bytes_step}
-        roof_conv = {"kernel": "k_conv5x5<32,2>", "bound": "mfma", "achieved": flop_conv / t_conv / 1e12, "peak": 157.3,
-                     "unit": "TFLOP/s", "frac": flop_conv / t_conv / 157.3e12, "traffic": None,
-                     "launch_us": t_conv * 1e6, "flop_per_launch": flop_conv}
+        # `traffic`: HBM bytes per launch from rocprofv3 PMC passes of the same kernels at this shape
+        # (profiles/r01_pmc_traffic.txt: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE); constants, not live
+        c3 = (Y, X, B) == (128, 64, 6)
+        roof_solver = {"kernel": "k_karman_fwd<16>", "bound": "hbm", "achieved": bytes_step / t_step / 1e9, "peak": 8000.0,
+                       "unit": "GB/s", "frac": bytes_step / t_step / 8e12,
+                       "traffic": (2 * 1158.1 + 1041.2) * 1024 if c3 else None,
+                       "launch_us": t_step * 1e6, "cg_iters": k_f, "algorithmic_bytes_per_launch": bytes_step,
+                       "note": "LDS-resident: the algorithmic bytes (SURVEY 8d formula with the measured CG iterations of the "
+                               "two-level preconditioned solve) never reach HBM; the kernel is issue/latency bound on 6 CUs"}
+        roof_conv = {"kernel": "k_conv5x5_r3<2>", "bound": "mfma", "achieved": flop_conv / t_conv / 1e12, "peak": 157.3,
+                     "unit": "TFLOP/s", "frac": flop_conv / t_conv / 157.3e12,
+                     "traffic": (2 * 9107.9 + 6144.0) * 1024 if c3 else None,
+                     "launch_us": t_conv * 1e6, "flop_per_launch": flop_conv,
+                     "measured_fp32_mfma_ceiling_random_operands_TFLOPs": 92.5,
+                     "note": "fp32 MFMA (v_mfma_f32_16x16x4_f32) reaches 153 TF only on constant operands; with random operands "
+                             "the same micro-benchmark gives 92 TF (profiles/r01_ubench_notes.txt)"}
         # dominant kernel by time inside one training step: conv fwd+bwd (36 launches/sim-step of ~t_conv)
         t_convs = 36 * ms * t_conv
         t_solver = 2 * ms * t_step

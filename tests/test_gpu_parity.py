@@ -322,3 +322,39 @@ def test_burgers_step_against_golden(golden_dir):
     ny, nx = ops.burgers_step(vy.detach(), vx.detach(), None, None, cfg, circ)
     zy, zx = ops.burgers_step(vy.detach(), vx.detach(), torch.zeros_like(vy), torch.zeros_like(vx), cfg, circ)
     assert torch.equal(ny, zy) and torch.equal(nx, zx)
+
+
+# ---------------------------------------------------------------------------------------------
+# scripts: data generation -> training -> roll-out on a tiny scene (flags of the reference scripts)
+# ---------------------------------------------------------------------------------------------
+def test_scripts_end_to_end(tmp_path):
+    import importlib.util
+    import pickle
+    sdir = os.path.join(os.path.dirname(os.path.abspath(sol_amd.__file__)), "scripts")
+    import sys
+    sys.path.insert(0, sdir)
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location("sol_script_" + name, os.path.join(sdir, name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    data = str(tmp_path / "set")
+    for re_nr in (1.6e5, 3.2e5):
+        p = load("karman").main(["-o", data, "-r", "32", "-t", "14", "-s", "1", "--re", str(re_nr)])
+        assert len([f for f in os.listdir(p) if f.startswith("velo_")]) == 12
+    tf = str(tmp_path / "tf")
+    loss = load("karman_train").main(["--train", data, "-s", "1", "-n", "2", "-b", "2", "-t", "12", "-m", "2", "-e", "1",
+                                      "--lr", "1e-4", "--tf", tf, "--seed", "0"])
+    assert loss is not None and np.isfinite(loss)
+    assert os.path.isfile(tf + "/model.pt") and os.path.isfile(tf + "/dataStats.pickle")
+    with open(tf + "/dataStats.pickle", "rb") as f:
+        st = pickle.load(f)
+    assert len(st["std"][1]) == 2 and st["ext.std"][0] > 0
+    out = load("karman_apply").main(["-r", "32", "-t", "4", "-o", str(tmp_path / "run"), "--stats", tf + "/dataStats.pickle",
+                                     "--model", tf + "/model.pt", "--re", "2.4e5"])
+    from sol_amd import scene
+    v = scene.read_zipped_array(out + "/velTf_000003.npz")
+    c = scene.read_zipped_array(out + "/corTf_000003.npz")
+    assert v.shape == (1, 65, 33, 2) and c.shape == (1, 65, 33, 2) and np.isfinite(v).all() and np.abs(c).max() > 0
