@@ -12,7 +12,8 @@ from . import ops, dist  # noqa: F401
 from .karman import KarmanFlow, to_feature, to_staggered, lr_schedule, velocity_bc_masks  # noqa: F401
 from .model import model_mars_moon, MarsMoon, ConvNet  # noqa: F401
 from .trainer import SolTrainer, SolRollout  # noqa: F401
-from . import synthetic  # noqa: F401
+from . import synthetic, scene, burgers  # noqa: F401
+from .burgers import BurgersTest, TFAdam  # noqa: F401
 
 __version__ = "0.1.0"
 

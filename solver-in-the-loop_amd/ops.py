@@ -140,6 +140,7 @@ class Conv5x5Fn(torch.autograd.Function):
         x = _lib.f32(x); w = _lib.f32(w); b = _lib.f32(b)
         cin_k = 4 if cin <= 4 else 32
         assert cin in (1, 2, 3, 4, 32), "conv5x5 supports <=4 or 32 input channels"
+        ctx.cin_w = cin
         xk = _pad_channels(x, cin_k)
         packed = _pack(w, cin, cout, CONV_FWD)
         res = None if residual is None else _lib.f32(residual)

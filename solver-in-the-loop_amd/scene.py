@@ -165,3 +165,42 @@ class PhifDataset:
                             for j in range(consecutive_frames + 1)]
         ext = [self.extConstChannelPerSim[self.dataSims[s]][0] for (s, _) in sel]
         return [frames(0), frames(1), ext]
+
+
+class BurgersDataset(PhifDataset):
+    """burgers/burgers_train.py:189-324: frames hold (velocity, force) staggered tensors [1,Y+1,X+1,2]."""
+
+    def __init__(self, dirpath, num_frames, num_sims=None, batch_size=1, print_fn=print, skip_preprocessing=False, scale=4):
+        self.dataSims = sorted(glob.glob(dirpath + "/sim_0*"))[0:num_sims]
+        self.pathsVel = [sorted(glob.glob(s + "/velo_0*.npz")) for s in self.dataSims]
+        self.pathsFrc = [sorted(glob.glob(s + "/forc_0*.npz")) for s in self.dataSims]
+        self.dataFrms = [np.arange(num_frames) for _ in self.dataSims]
+        self.batchSize = batch_size
+        self.epoch, self.epochIdx, self.batch, self.batchIdx, self.step, self.stepIdx = None, 0, None, 0, None, 0
+        self.printFn = print_fn
+        self.numOfSims = len(self.dataSims) if num_sims is None else num_sims
+        self.numOfBatchs = self.numOfSims // self.batchSize
+        self.numOfFrames = num_frames
+        self.numOfSteps = num_frames
+        if not skip_preprocessing and scale > 1:
+            for j in range(len(self.dataSims)):
+                for i in range(num_frames):
+                    for paths in (self.pathsVel, self.pathsFrc):
+                        write_zipped_array(self.filenameToDownscaled(paths[j][i]), downsample_staggered(read_zipped_array(paths[j][i]), scale))
+        name = self.filenameToDownscaled if scale > 1 else (lambda p: p)
+        self.dataPreloaded = {
+            s: [(read_zipped_array(name(self.pathsVel[j][i])).astype(np.float32),
+                 read_zipped_array(name(self.pathsFrc[j][i])).astype(np.float32)) for i in range(num_frames)]
+            for j, s in enumerate(self.dataSims)}
+        self.resolution = [v - 1 for v in self.dataPreloaded[self.dataSims[0]][0][0].shape[1:3]]     # SMAC grid -> cells
+        std = lambda k, c: np.std(np.concatenate([np.absolute(self.dataPreloaded[s][i][k][..., c].reshape(-1))
+                                                  for s in self.dataSims for i in range(num_frames)]))
+        self.dataStats = {"std": ((std(0, 0), std(0, 1)), (std(1, 0), std(1, 1)))}
+        self.printFn("Loaded {} samples".format(self.numOfSims * self.numOfFrames))
+        self.printFn(self.dataStats)
+
+    def getData(self, consecutive_frames, with_skip=1):
+        sel = [self.epoch[self.batchIdx + i][self.stepIdx] for i in range(self.batchSize)]
+        frames = lambda k: [np.concatenate([self.dataPreloaded[self.dataSims[s]][f + j * with_skip][k] for (s, f) in sel], axis=0)
+                            for j in range(consecutive_frames + 1)]
+        return [frames(0), frames(1)]

@@ -358,3 +358,38 @@ def test_scripts_end_to_end(tmp_path):
     v = scene.read_zipped_array(out + "/velTf_000003.npz")
     c = scene.read_zipped_array(out + "/corTf_000003.npz")
     assert v.shape == (1, 65, 33, 2) and c.shape == (1, 65, 33, 2) and np.isfinite(v).all() and np.abs(c).max() > 0
+
+
+def test_burgers_training_script(tmp_path):
+    """BASELINE configs[0]: burgers 32x32, msteps=1 -- the reference's script shape on the HIP ops."""
+    import importlib.util
+    import pickle
+    from sol_amd import scene
+    sdir = os.path.join(os.path.dirname(os.path.abspath(sol_amd.__file__)), "scripts")
+    import sys
+    sys.path.insert(0, sdir)
+    spec = importlib.util.spec_from_file_location("sol_script_burgers_train", os.path.join(sdir, "burgers_train.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    # tiny synthetic set: forced Burgers roll-outs by the HIP step itself (data generation proper is out of scope)
+    B, Y, X, frames, dt = 1, 32, 32, 8, 0.1
+    dom = sol_amd.Domain([Y, X], box=sol_amd.box([32, 32]), boundaries=sol_amd.PERIODIC)
+    sim = sol_amd.BurgersTest()
+    gen = torch.Generator().manual_seed(0)
+    for s in range(2):
+        path = scene.scene_create(str(tmp_path / "set"))
+        with open(path + "/params.pickle", "wb") as f:
+            pickle.dump({"seed": s}, f)
+        v = f32(0.3 * sol_amd.synthetic._smooth(torch.randn(B, Y + 1, X + 1, generator=gen, dtype=torch.float64))).unsqueeze(-1).repeat(1, 1, 1, 2)
+        st = sol_amd.BurgersVelocitySMAC(dom, velocity=v, batch_size=B)
+        for i in range(frames):
+            fr_t = f32(0.15 * sol_amd.synthetic._smooth(torch.randn(B, Y + 1, X + 1, generator=gen, dtype=torch.float64))).unsqueeze(-1).repeat(1, 1, 1, 2)
+            fr = sol_amd.BurgersVelocitySMAC(dom, velocity=fr_t, batch_size=B)
+            scene.scene_write(path, [st.velocity.staggered_tensor().cpu().numpy(), fr.velocity.staggered_tensor().cpu().numpy()], ["velo", "forc"], i)
+            with torch.no_grad():
+                st = sim.step_with_f(st, fr, dt=dt)
+    tf = str(tmp_path / "tf")
+    loss = mod.main(["--train", str(tmp_path / "set"), "-s", "1", "-n", "2", "-b", "2", "-t", str(frames), "-m", "1", "-e", "1",
+                     "--lr", "1e-4", "--dt", str(dt), "--tf", tf])
+    assert loss is not None and np.isfinite(loss)
+    assert os.path.isfile(tf + "/model.pt") and os.path.isfile(tf + "/model_epoch0001.pt")
