@@ -11,8 +11,8 @@ int sol_set_error(int code, const char* fmt, ...);
 int sol_init_karman_kernels();
 int sol_init_conv_kernels();
 size_t sol_bww_batched_ws_floats(int nseg, int B, int H, int cin, int cout);
-int sol_bww_batched(void* stream, const float* x, const float* dz, float* partial, int nseg, long x_seg, long dz_seg,
-                    int B, int H, int W, int cin, int cout);
+int sol_bww_batched(void* stream, const float* x, const float* dz, float* partial, int nseg, int nseg_layout, int overwrite,
+                    long x_seg, long dz_seg, int B, int H, int W, int cin, int cout);
 int sol_bww_batched_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int nseg, int B, int H,
                            int cin, int cout, int accumulate);
 

@@ -1029,7 +1029,7 @@ size_t sol_bww_batched_ws_floats(int nseg, int B, int H, int cin, int cout) {
 }
 
 static int bww_launch(void* stream, const float* x, const float* dz, float* partial, int nseg, long x_seg, long dz_seg,
-                      int rb, int overwrite, int B, int H, int W, int cin, int cout) {
+                      int rb, int overwrite, int B, int H, int W, int cin, int cout, int nblk_layout = 0) {
     SOL_REQUIRE(x && dz && partial, "sol_conv5x5_bwd_weight: NULL pointer");
     SOL_REQUIRE(B >= 1 && H >= 1 && W >= 4 && W % 4 == 0 && W <= 64, "sol_conv5x5_bwd_weight: need 4 <= W <= 64, W %% 4 == 0 (got %d)", W);
     SOL_REQUIRE((cin == 4 || cin == 32) && (cout == 2 || cout == 32),
@@ -1039,18 +1039,20 @@ static int bww_launch(void* stream, const float* x, const float* dz, float* part
     a.nseg = nseg; a.rb = rb; a.x_seg = x_seg; a.dz_seg = dz_seg; a.overwrite = overwrite;
     int IP, OP;
     bww_dims(nseg * B * H, rb, cin, cout, &a.nblk, &IP, &OP);
+    const int nblk_run = a.nblk;                    // workgroups needed for this launch's rows
+    if (nblk_layout > 0) a.nblk = nblk_layout;      // partial buffer laid out for a (larger) reference launch
     const int CPX = cin == 4 ? 4 : 48, CPZ = cout <= 4 ? 4 : 48;
     const size_t lds = 2 * ((size_t)(W + 4) * CPX + (size_t)W * CPZ) * sizeof(float);   // double buffered rows
-    const int grid = a.nblk * 5;
+    const int grid = nblk_run * 5;
     hipStream_t s = (hipStream_t)stream;
     if (W == 64 && ((cin == 4 && cout == 32) || (cin == 32 && cout == 2)) && !getenv("SOL_CONV_NO_THIN")) {
         // all five tap rows in one workgroup: grid = nblk; LDS = 2 stages (>= the 16 KB fold buffer)
         if (cin == 4) {
             const size_t l0 = 2 * (size_t)(5 * 68 * 4 + 68 * 32) * sizeof(float);
-            hipLaunchKernelGGL(k_conv5x5_bww_thin<0>, dim3(a.nblk), dim3(256), l0, s, a);
+            hipLaunchKernelGGL(k_conv5x5_bww_thin<0>, dim3(nblk_run), dim3(256), l0, s, a);
         } else {
             const size_t l1 = 2 * (size_t)(68 * 32 + 5 * 72 * 2) * sizeof(float);
-            hipLaunchKernelGGL(k_conv5x5_bww_thin<1>, dim3(a.nblk), dim3(256), l1, s, a);
+            hipLaunchKernelGGL(k_conv5x5_bww_thin<1>, dim3(nblk_run), dim3(256), l1, s, a);
         }
         SOL_LAUNCH_CHECK();
         return SOL_OK;
@@ -1072,10 +1074,15 @@ extern "C" int sol_conv5x5_bwd_weight(void* stream, const float* x, const float*
     return bww_launch(stream, x, dz, partial, 1, 0, 0, RB, 0, B, H, W, cin, cout);
 }
 
-// all unrolled steps of one layer in ONE launch: segment s reads x + s*x_seg, dz + s*dz_seg (partial is overwritten)
-int sol_bww_batched(void* stream, const float* x, const float* dz, float* partial, int nseg, long x_seg, long dz_seg,
-                    int B, int H, int W, int cin, int cout) {
-    return bww_launch(stream, x, dz, partial, nseg, x_seg, dz_seg, pick_rb(nseg * B * H), 1, B, H, W, cin, cout);
+// `nseg` unrolled steps of one layer in ONE launch: segment s reads x + s*x_seg, dz + s*dz_seg.  The partial
+// buffer is laid out for `nseg_layout` >= nseg segments (several chunk launches accumulate into it:
+// overwrite = 1 for the first chunk, 0 afterwards).
+int sol_bww_batched(void* stream, const float* x, const float* dz, float* partial, int nseg, int nseg_layout, int overwrite,
+                    long x_seg, long dz_seg, int B, int H, int W, int cin, int cout) {
+    const int rb = pick_rb(nseg_layout * B * H);
+    int nblk, IP, OP;
+    bww_dims(nseg_layout * B * H, rb, cin, cout, &nblk, &IP, &OP);
+    return bww_launch(stream, x, dz, partial, nseg, x_seg, dz_seg, rb, overwrite, B, H, W, cin, cout, nblk);
 }
 
 static int bww_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int rows, int rb, int cin, int cout, int accumulate) {

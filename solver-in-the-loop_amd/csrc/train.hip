@@ -23,6 +23,7 @@ extern "C" int sol_version(void) { return 100; }
 namespace {
 
 constexpr int NL = 12;   // conv layers of model_mars_moon
+int pick_bww_chunk(int ms);
 inline int layer_cin(int l) { return l == 0 ? 3 : 32; }
 inline int layer_cout(int l) { return l == NL - 1 ? 2 : 32; }
 inline int64_t layer_koff(int l) {
@@ -180,7 +181,7 @@ size_t carve_ws(const sol_train_cfg* c, float* base, Ws& w, bool training) {
         w.wf[l] = take(sol_conv5x5_packed_floats(cin == 3 ? 4 : cin, cout, SOL_CONV_FWD));
         w.wb[l] = take(sol_conv5x5_packed_floats(cout == 2 ? 4 : cout, cin, SOL_CONV_BWD_DATA));
         w.bias[l] = take(32);
-        w.part_floats[l] = training ? sol_bww_batched_ws_floats(ms, B, Y, cin == 3 ? 4 : cin, cout) : 0;
+        w.part_floats[l] = training ? sol_bww_batched_ws_floats(pick_bww_chunk(ms), B, Y, cin == 3 ? 4 : cin, cout) : 0;
         w.part[l] = take(w.part_floats[l]);
     }
     w.adam_scale = take(64);
@@ -272,6 +273,17 @@ StreamPool* pool() {
     return &p;
 }
 
+// Default: ONE weight-gradient launch per layer over all unrolled steps, after the sweep (chunk = msteps).
+// SOL_BWW_CHUNK=n covers n steps per launch on a side stream, meant to fill the ~250 CUs that idle while the
+// one-workgroup-per-simulation solver adjoint runs; measured on MI355X/ROCm 7.2 it does NOT overlap
+// (39.8 ms vs 38.3 ms per step, eager and graph alike), so it is off.
+int pick_bww_chunk(int ms) {
+    int ch = 0;
+    if (const char* e = getenv("SOL_BWW_CHUNK")) ch = atoi(e);
+    if (ch <= 0 || ch > ms) ch = ms;
+    return ch;
+}
+
 int pick_chains(int B) {
     int want = 1;   // measured on MI355X/ROCm 7.2: concurrent chains are SLOWER (57 -> 105..167 ms/step), see DESIGN.md
     if (const char* e = getenv("SOL_STREAMS")) want = atoi(e);
@@ -338,6 +350,11 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
     // after the sweep (K = 32x more pixels per launch: no per-step prologue/epilogue/partial traffic).
     int cur = 0;
     const size_t cl32 = w.cells * 32;
+    const long seg32 = (long)(11 * cl32);
+    const int CH = pick_bww_chunk(ms);
+    const bool use_side = CH < ms && pool()->ok && !getenv("SOL_BWW_NO_SIDE");
+    hipStream_t side = pool()->s[7];
+    bool side_used = false;
     for (int i = ms - 1; i >= 0; --i) {
         float* gvy = w.gvy[cur];
         float* gvx = w.gvx[cur];
@@ -361,6 +378,24 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
             if (int e = sol_conv5x5(stream, D[2 + 2 * k], wn.wb[2 + 2 * k], nullptr, nullptr, a, D[1 + 2 * k], B, Y, X, 32, 32, SOL_EPI_DLRELU, sl)) return e;
             if (int e = sol_conv5x5(stream, D[1 + 2 * k], wn.wb[1 + 2 * k], nullptr, D[2 + 2 * k], h, D[2 * k], B, Y, X, 32, 32, SOL_EPI_DLRELU, sl)) return e;
         }
+        if (i % CH == 0) {
+            // every dz of steps [i, i+CH) is final: their weight gradients go to the side stream
+            const int n = (i + CH <= ms ? CH : ms - i), first = (i + CH >= ms) ? 1 : 0;
+            hipStream_t bs = hs;
+            if (use_side) {
+                SOL_HIP_CHECK(hipEventRecord(pool()->fork, hs));
+                SOL_HIP_CHECK(hipStreamWaitEvent(side, pool()->fork, 0));
+                bs = side;
+                side_used = true;
+            }
+            const float* feat_i = w.feat + (size_t)i * w.cells * 4;
+            const float* acts_i = w.acts + (size_t)i * 11 * cl32;
+            const float* dz_i = w.dzb + (size_t)i * 11 * cl32;
+            if (int e = sol_bww_batched(bs, feat_i, dz_i, w.part[0], n, CH, first, (long)(w.cells * 4), seg32, B, Y, X, 4, 32)) return e;
+            for (int l = 1; l <= 10; ++l)
+                if (int e = sol_bww_batched(bs, acts_i + (size_t)(l - 1) * cl32, dz_i + (size_t)l * cl32, w.part[l], n, CH, first, seg32, seg32, B, Y, X, 32, 32)) return e;
+            if (int e = sol_bww_batched(bs, acts_i + (size_t)10 * cl32, w.dO2 + (size_t)i * w.cells * 2, w.part[11], n, CH, first, seg32, (long)(w.cells * 2), B, Y, X, 32, 2)) return e;
+        }
         if (i > 0) {
             if (int e = sol_conv5x5(stream, D[0], wn.wb[0], nullptr, nullptr, nullptr, w.dF, B, Y, X, 32, 2, SOL_EPI_NONE, sl)) return e;
             if (int e = sol_karman_step_bwd(kc, stream, w.svy + (size_t)i * w.st_vy, w.svx + (size_t)i * w.st_vx, re, io.active,
@@ -369,12 +404,10 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
             cur ^= 1;
         }
     }
-    // ---------------- weight gradients, one launch per layer over all unrolled steps ----------------
-    const long seg32 = (long)(11 * cl32);
-    if (int e = sol_bww_batched(stream, w.feat, w.dzb, w.part[0], ms, (long)(w.cells * 4), seg32, B, Y, X, 4, 32)) return e;
-    for (int l = 1; l <= 10; ++l)
-        if (int e = sol_bww_batched(stream, w.acts + (size_t)(l - 1) * cl32, w.dzb + (size_t)l * cl32, w.part[l], ms, seg32, seg32, B, Y, X, 32, 32)) return e;
-    if (int e = sol_bww_batched(stream, w.acts + (size_t)10 * cl32, w.dO2, w.part[11], ms, seg32, (long)(w.cells * 2), B, Y, X, 32, 2)) return e;
+    if (side_used) {      // join the side stream
+        SOL_HIP_CHECK(hipEventRecord(pool()->join[7], side));
+        SOL_HIP_CHECK(hipStreamWaitEvent(hs, pool()->join[7], 0));
+    }
     return SOL_OK;
 }
 
@@ -414,7 +447,7 @@ int train_fwd_bwd_impl(const sol_train_cfg* cfg, hipStream_t hs, const TrainIO& 
         const int cin = layer_cin(l), cout = layer_cout(l);
         const int64_t koff = layer_koff(l), boff = koff + 25 * cin * cout;
         for (int k = 0; k < S; ++k)
-            if (int e = sol_bww_batched_reduce(hs, w[k].part[l], grads + koff, grads + boff, ms, B / S, Y, cin, cout, k > 0)) return e;
+            if (int e = sol_bww_batched_reduce(hs, w[k].part[l], grads + koff, grads + boff, pick_bww_chunk(ms), B / S, Y, cin, cout, k > 0)) return e;
     }
     return SOL_OK;
 }
@@ -474,17 +507,17 @@ extern "C" int sol_train_graph_create(const sol_train_cfg* cfg, const float* par
     SOL_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     hipGraph_t graph = nullptr;
     if (hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed) != hipSuccess) {
-        hipStreamDestroy(cs);
+        (void)hipStreamDestroy(cs);
         return sol_set_error(SOL_ERR_HIP, "hipStreamBeginCapture failed");
     }
     const int rc = train_fwd_bwd_impl(cfg, cs, io, workspace, workspace_bytes, grads);
     const hipError_t ee = hipStreamEndCapture(cs, &graph);
-    hipStreamDestroy(cs);
-    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+    (void)hipStreamDestroy(cs);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (ee != hipSuccess || !graph) return sol_set_error(SOL_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ee));
     hipGraphExec_t exec = nullptr;
     const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (ei != hipSuccess) { hipGraphDestroy(graph); return sol_set_error(SOL_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei)); }
+    if (ei != hipSuccess) { (void)hipGraphDestroy(graph); return sol_set_error(SOL_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei)); }
     *out = new sol_train_graph{graph, exec};
     return SOL_OK;
 }
@@ -497,8 +530,8 @@ extern "C" int sol_train_graph_launch(sol_train_graph* g, void* stream) {
 
 extern "C" int sol_train_graph_destroy(sol_train_graph* g) {
     if (!g) return SOL_OK;
-    if (g->exec) hipGraphExecDestroy(g->exec);
-    if (g->graph) hipGraphDestroy(g->graph);
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
     delete g;
     return SOL_OK;
 }

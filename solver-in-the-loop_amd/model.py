@@ -99,10 +99,36 @@ class MarsMoon(ConvNet):
         return ops.conv5x5(h, p[22], p[23], None, False, s)
 
 
+class Mercury(ConvNet):
+    """model_mercury, karman_train.py:92-99: Conv5x5(cin->32)+ReLU, Conv5x5(32->64)+ReLU, Conv5x5(64->2).
+    The conv kernels are built for <= 32 channels per side, so the 64-channel layer runs as two 32-channel
+    halves (output split for 32->64, input split + residual accumulation for 64->2).  Per-op path only."""
+    name = "mercury"
+    slope = 0.0                                      # ReLU = LeakyReLU with slope 0
+
+    @staticmethod
+    def channels(cin, cout):
+        return [cin, 32, 64, cout]
+
+    def __call__(self, x, flat=None):
+        p = self.tensors(flat)
+        h = ops.conv5x5(x, p[0], p[1], None, True, 0.0)
+        ha = ops.conv5x5(h, p[2][..., :32].contiguous(), p[3][:32].contiguous(), None, True, 0.0)
+        hb = ops.conv5x5(h, p[2][..., 32:].contiguous(), p[3][32:].contiguous(), None, True, 0.0)
+        oa = ops.conv5x5(ha, p[4][:, :, :32].contiguous(), p[5], None, False, 0.0)
+        return ops.conv5x5(hb, p[4][:, :, 32:].contiguous(), torch.zeros_like(p[5]), oa, False, 0.0)
+
+
+def model_mercury(tensor_in=None, cin=3, cout=2, seed=0, device="cuda"):
+    if tensor_in is not None:
+        cin = tensor_in.shape[-1]
+    return Mercury(cin, cout, seed, device)
+
+
 def model_mars_moon(tensor_in=None, cin=3, cout=2, seed=0, device="cuda"):
     if tensor_in is not None:
         cin = tensor_in.shape[-1]
     return MarsMoon(cin, cout, seed, device)
 
 
-MODELS = {"mars_moon": MarsMoon}
+MODELS = {"mars_moon": MarsMoon, "mercury": Mercury}

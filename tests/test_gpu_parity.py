@@ -393,3 +393,25 @@ def test_burgers_training_script(tmp_path):
                      "--lr", "1e-4", "--dt", str(dt), "--tf", tf])
     assert loss is not None and np.isfinite(loss)
     assert os.path.isfile(tf + "/model.pt") and os.path.isfile(tf + "/model_epoch0001.pt")
+
+
+def test_model_mercury_against_torch_reference():
+    """model_mercury (karman_train.py:92-99) on the split 32-channel kernels vs plain fp64 torch convs."""
+    net = sol_amd.model_mercury(cin=3, cout=2, seed=5)
+    assert net.n_params == 25 * 3 * 32 + 32 + 25 * 32 * 64 + 64 + 25 * 64 * 2 + 2
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 16, 8, 3, generator=gen, dtype=torch.float64)
+    ws = [torch.as_tensor(w, dtype=torch.float64).requires_grad_(True) for w in net.get_weights()]
+    ws[1].data += 0.1
+    ws[3].data -= 0.05
+    net.set_weights([w.detach().numpy() for w in ws])
+    h = torch.relu(o._conv(x, ws[0], ws[1]))
+    h = torch.relu(o._conv(h, ws[2], ws[3]))
+    y = o._conv(h, ws[4], ws[5])
+    gy = torch.randn(y.shape, generator=gen, dtype=torch.float64)
+    (y * gy).sum().backward()
+    hy = net(f32(x))
+    (hy * f32(gy)).sum().backward()
+    assert rel(hy, y) < 2e-6
+    gref = torch.cat([w.grad.reshape(-1) for w in ws])
+    assert rel(net.params.grad, gref) < 5e-6
