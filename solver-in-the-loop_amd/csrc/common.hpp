@@ -16,6 +16,21 @@ int sol_bww_batched(void* stream, const float* x, const float* dz, float* partia
 int sol_bww_batched_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int nseg, int B, int H,
                            int cin, int cout, int accumulate);
 
+// forward / backward-data convolution arguments (conv5x5.hip, conv5x5_sb.hip)
+struct ConvArgs {
+    const float *x, *wp, *bias, *res, *act;
+    float* y;
+    int B, H, W, CO;   // CO = real number of stored output channels
+    int epi;
+    float slope;
+    int TW, RPW, tiles_x;
+    const void* wsb;   // split-bf16 weight planes (second section of the packed buffer), cin == 32 only
+};
+// split-bf16 section of the packed weights and the kernels that consume it (conv5x5_sb.hip)
+size_t sol_conv_sb_packed_floats(int OP);
+int sol_conv_sb_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int mode, void* out);
+int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles);
+
 #define SOL_HIP_CHECK(expr)                                                                  \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \

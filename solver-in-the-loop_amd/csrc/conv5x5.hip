@@ -3,8 +3,10 @@
 //
 // Replaces keras.layers.Conv2D(filters, 5, padding='same') (+bias, LeakyReLU, residual add)
 // of model_mars_moon (/root/reference/karman-2d/karman_train.py:101-138) and TF's conv
-// gradients.  fp32 in / fp32 accumulate (v_mfma_f32_16x16x4_f32): bf16 would break the 1e-5
-// parity bar of the solver-in-the-loop loss.
+// gradients.  fp32 in / fp32 accumulate (v_mfma_f32_16x16x4_f32): plain bf16 would break the 1e-5
+// parity bar of the solver-in-the-loop loss.  The 32-channel, W % 64 == 0 shapes run on the
+// fp32-equivalent split-bf16 kernels of conv5x5_sb.hip by default; the kernels here serve the
+// other shapes (and SOL_CONV_NO_SB=1).
 //
 // Implicit GEMM, per workgroup: M = 64 output pixels (4 waves x 16), N = 16*NT output
 // channels, K = 25 taps x CIN.  The input halo tile is staged once in LDS (pixel stride
@@ -48,15 +50,7 @@ __global__ void k_pack(const float* __restrict__ w, float* __restrict__ packed, 
 // ------------------------------------------------------------------------------------
 // forward / backward-data kernel
 // ------------------------------------------------------------------------------------
-struct ConvArgs {
-    const float *x, *wp, *bias, *res, *act;
-    float* y;
-    int B, H, W, CO;   // CO = real number of stored output channels
-    int epi;
-    float slope;
-    int TW, RPW, tiles_x;
-};
-
+// ConvArgs: common.hpp
 template <int CIN, int NT>
 __global__ void __launch_bounds__(256) k_conv5x5(ConvArgs a) {
     constexpr int CP = CIN == 4 ? 4 : 36;   // LDS pixel stride in floats
@@ -932,7 +926,8 @@ int check_shape(int B, int H, int W, int cin, int cout) {
 }  // namespace
 
 extern "C" size_t sol_conv5x5_packed_floats(int32_t cin, int32_t cout, int32_t /*mode*/) {
-    return (size_t)25 * pad_in(cin) * pad_out(cout);
+    // fp32 section (all shapes) + split-bf16 planes for the 32-input-channel kernels (conv5x5_sb.hip)
+    return (size_t)25 * pad_in(cin) * pad_out(cout) + (pad_in(cin) == 32 ? sol_conv_sb_packed_floats(pad_out(cout)) : 0);
 }
 
 extern "C" int sol_conv5x5_pack(void* stream, const float* w_hwio, int32_t cin, int32_t cout, int32_t mode, float* packed) {
@@ -942,6 +937,7 @@ extern "C" int sol_conv5x5_pack(void* stream, const float* w_hwio, int32_t cin, 
     const int total = 25 * pad_in(cin) * pad_out(cout);
     hipLaunchKernelGGL(k_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_hwio, packed, cin, cout, mode);
     SOL_LAUNCH_CHECK();
+    if (pad_in(cin) == 32) return sol_conv_sb_pack((hipStream_t)stream, w_hwio, cin, cout, mode, packed + total);
     return SOL_OK;
 }
 
@@ -976,6 +972,11 @@ extern "C" int sol_conv5x5(void* stream, const float* x, const float* packed, co
     const size_t lds = (size_t)(a.RPW + 4) * (a.TW + 4) * CP * sizeof(float);
     const int NT = pad_out(cout) / 16;
     hipStream_t s = (hipStream_t)stream;
+    static const bool use_sb = !getenv("SOL_CONV_NO_SB");
+    if (cin == 32 && W % 64 == 0 && use_sb) {
+        a.wsb = packed + (size_t)25 * 32 * pad_out(cout);
+        return sol_conv_sb_launch(s, a, NT, B * H * (W / 64));
+    }
     if (cin == 32 && W % 64 == 0 && !getenv("SOL_CONV_NO_R3")) {
         const int ntiles = B * H * (W / 64);
         const size_t ldsr = ((size_t)3 * 2 * 68 * 32 + 2 * (size_t)5 * NT * 16 * 32) * sizeof(float);

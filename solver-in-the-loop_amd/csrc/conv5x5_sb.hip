@@ -1,0 +1,306 @@
+// 5x5 SAME convolution, 32 input channels, on the gfx950 bf16 matrix cores with fp32-EQUIVALENT
+// arithmetic ("split bf16", the bf16 analogue of 3xTF32): every fp32 operand v is written as the
+// exact-to-2^-27 sum of three bf16 numbers v = v1 + v2 + v3 (v1 = rn(v), v2 = rn(v - v1),
+// v3 = rn(v - v1 - v2); the subtractions are exact in fp32) and a product a*b is accumulated as the
+// six bf16 x bf16 MFMA products whose weight is >= 2^-18:  a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1.
+// bf16 x bf16 products are exact in fp32 and the MFMA accumulates in fp32, so the result differs from
+// an fp32 FMA chain by O(2^-24) per term -- the parity tests hold it to the same tolerances as the
+// fp32-MFMA kernels of conv5x5.hip (which remain for the other shapes and as SOL_CONV_NO_SB=1).
+//
+// Why: v_mfma_f32_16x16x4_f32 sustains 92 TFLOP/s on random operands on this part, while
+// v_mfma_f32_16x16x32_bf16 sustains 1580 TFLOP/s (tools/ubench/mfma_bf16_rand.hip): six bf16
+// products per fp32 product are still 2.8x the fp32 matrix-core rate.
+//
+// Replaces the same keras.layers.Conv2D(32, 5, padding='same') (+bias, LeakyReLU, residual add) of
+// model_mars_moon (/root/reference/karman-2d/karman_train.py:101-138) as conv5x5.hip does.
+//
+// Work decomposition = k_conv5x5_r3 (three independent 64-pixel row tiles per workgroup, 12 waves,
+// one workgroup per CU at 128x64 x 6): per tap row dy the tile's halo row is split into its three
+// bf16 planes while it is staged into LDS (2-slot ring), the weights arrive pre-split from the
+// packed buffer ([dy][dx][plane][cout][cin] bf16, already in LDS image order) and are double
+// buffered per tap row.  One tap = ONE K = 32 MFMA per split product: lane (li, g) holds
+// A[pixel li][cin 8g..8g+7] and B[cin 8g..8g+7][cout li] as one 16-byte ds_read_b128 each.
+// LDS rows are 64 B per pixel / per cout; the 16-B chunk index is XOR-ed with ((idx >> 2) & 1) << 1,
+// which makes every ds_read_b128 lane group of the CDNA4 LDS (MI355X_MICROARCH.md, LDS table) hit 16
+// distinct bank quads for all five dx shifts (brute-forced, tools/lds_swizzle_search.py).
+#include "common.hpp"
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__host__ __device__ __forceinline__ int swzb(int idx) { return ((idx >> 2) & 1) << 1; }
+
+// two fp32 -> packed pair of bf16 (round to nearest even), low half = first element
+__device__ __forceinline__ unsigned pk_bf16(float x, float y) {
+    const f32x2 f = {x, y};
+    const bf16x2 b = __builtin_convertvector(f, bf16x2);
+    return __builtin_bit_cast(unsigned, b);
+}
+__device__ __forceinline__ float bf_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+
+// (x, y) -> three packed bf16 pairs with x = x1 + x2 + x3 (+ O(2^-27 x))
+__device__ __forceinline__ void split3(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = pk_bf16(x, y);
+    const float rx = x - bf_lo(p1), ry = y - bf_hi(p1);
+    p2 = pk_bf16(rx, ry);
+    p3 = pk_bf16(rx - bf_lo(p2), ry - bf_hi(p2));
+}
+
+// ------------------------------------------------------------------------------------
+// weight packing: out[dy][dx][plane][o][chunk s][j] (bf16), chunk s holds cin 8*(s ^ swzb(o)) + j
+// FWD / BWD_DATA source index as k_pack (conv5x5.hip); `cin` = 32 channels of the convolution being run
+// ------------------------------------------------------------------------------------
+__global__ void k_pack_sb(const float* __restrict__ w, unsigned short* __restrict__ out, int cin, int cout, int OP, int mode) {
+    const int total = 25 * OP * 16;   // pairs of channels
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int jp = e & 3, s = (e >> 2) & 3, o = (e >> 4) % OP, tap = e / (16 * OP);
+        const int i0 = 8 * (s ^ swzb(o)) + 2 * jp;
+        float v[2] = {0.f, 0.f};
+        for (int q = 0; q < 2; ++q) {
+            const int i = i0 + q;
+            if (i < cin && o < cout)
+                v[q] = mode == SOL_CONV_FWD ? w[(tap * cin + i) * cout + o] : w[((24 - tap) * cout + o) * cin + i];
+        }
+        unsigned p[3];
+        split3(v[0], v[1], p[0], p[1], p[2]);
+        for (int pl = 0; pl < 3; ++pl) {
+            const size_t idx = ((((size_t)tap * 3 + pl) * OP + o) * 4 + s) * 8 + 2 * jp;
+            *reinterpret_cast<unsigned*>(out + idx) = p[pl];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// forward / backward-data kernel, W % 64 == 0, CIN = 32
+// ------------------------------------------------------------------------------------
+template <int NT, int NPROD>
+__global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int ntiles) {
+    constexpr int OP = NT * 16;
+    constexpr int HWP = 68;                       // halo pixels per row (64 + 4)
+    constexpr int PLANE = HWP * 64;               // bytes per bf16 plane of one halo row
+    constexpr int SLOT = 3 * PLANE;               // bytes per halo row
+    constexpr int WPL = OP * 64;                  // bytes per (dx, plane) weight block
+    constexpr int WBUF = 5 * 3 * WPL;             // bytes per tap-row weight phase
+    extern __shared__ __align__(16) unsigned char smem_sb[];
+    const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = tid & 63, wave = (tid >> 6) & 3;
+    const int g = lane >> 4, li = lane & 15;
+    const int H = a.H, W = a.W;
+    const int tile = blockIdx.x * 3 + grp;
+    const bool tvalid = tile < ntiles;
+    const int tx = tvalid ? tile % a.tiles_x : 0;
+    const int gy = tvalid ? tile / a.tiles_x : 0;     // global row index b*H + y
+    const int b = gy / H, y = gy - b * H, x0 = tx * 64;
+    unsigned char* halo = smem_sb + grp * 2 * SLOT;   // [2][3 planes][68][64 B], private to the tile
+    unsigned char* Wt = smem_sb + 3 * 2 * SLOT;       // [2][5][3 planes][OP][64 B], shared
+    const float4* gx = reinterpret_cast<const float4*>(a.x);
+    const uint4* gw = reinterpret_cast<const uint4*>(a.wsb);
+    constexpr int HPT = 3;                            // 544 float4 per halo row / 256 threads
+    constexpr int WV = WBUF / 16;                     // uint4 per weight phase
+    constexpr int WPT = (WV + 767) / 768;
+
+    auto load_row = [&](int dy, float4 (&v)[HPT]) {
+        const int yy = y + dy - 2;
+#pragma unroll
+        for (int n = 0; n < HPT; ++n) {
+            const int e = t + n * 256;
+            v[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < HWP * 8) {
+                const int hc = e >> 3, c4 = e & 7, xx = x0 + hc - 2;
+                if (tvalid && yy >= 0 && yy < H && xx >= 0 && xx < W) v[n] = gx[((size_t)(b * H + yy) * W + xx) * 8 + c4];
+            }
+        }
+    };
+    auto store_row = [&](int slot, const float4 (&v)[HPT]) {
+        unsigned char* dst = halo + slot * SLOT;
+#pragma unroll
+        for (int n = 0; n < HPT; ++n) {
+            const int e = t + n * 256;
+            if (e < HWP * 8) {
+                const int hc = e >> 3, c4 = e & 7;
+                unsigned p[3][2];
+                split3(v[n].x, v[n].y, p[0][0], p[1][0], p[2][0]);
+                split3(v[n].z, v[n].w, p[0][1], p[1][1], p[2][1]);
+                unsigned char* q = dst + hc * 64 + ((((c4 >> 1) ^ swzb(hc)) << 4) | ((c4 & 1) << 3));
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(q + pl * PLANE) = make_uint2(p[pl][0], p[pl][1]);
+            }
+        }
+    };
+    auto load_w = [&](int dy, uint4 (&v)[WPT]) {
+#pragma unroll
+        for (int n = 0; n < WPT; ++n) {
+            const int e = tid + n * 768;
+            v[n] = e < WV ? gw[(size_t)dy * WV + e] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_w = [&](int buf, const uint4 (&v)[WPT]) {
+        uint4* dst = reinterpret_cast<uint4*>(Wt + buf * WBUF);
+#pragma unroll
+        for (int n = 0; n < WPT; ++n) {
+            const int e = tid + n * 768;
+            if (e < WV) dst[e] = v[n];
+        }
+    };
+
+    {   // prologue: tap row 0
+        float4 hv[HPT];
+        uint4 wv[WPT];
+        load_row(0, hv);
+        load_w(0, wv);
+        store_row(0, hv);
+        store_w(0, wv);
+    }
+    __syncthreads();
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int pcc = wave * 16 + li;                   // this lane's A-row pixel inside the tile
+    // split products in order of increasing weight (small terms first)
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+
+#pragma unroll 1
+    for (int dy = 0; dy < 5; ++dy) {
+        float4 hv[HPT];
+        uint4 wv[WPT];
+        if (dy < 4) {
+            load_row(dy + 1, hv);
+            load_w(dy + 1, wv);
+        }
+        const unsigned char* hrow = halo + (dy & 1) * SLOT;
+        const unsigned char* wbuf = Wt + (dy & 1) * WBUF;
+        uint4 ao[2][3], bo[2][NT][3];
+        auto load_ops = [&](int dx, uint4 (&ar)[3], uint4 (&br)[NT][3]) {
+            const int hc = pcc + dx;
+            const unsigned char* ap = hrow + hc * 64 + ((g ^ swzb(hc)) << 4);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) ar[pl] = *reinterpret_cast<const uint4*>(ap + pl * PLANE);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int co = n * 16 + li;
+                const unsigned char* bp = wbuf + dx * 3 * WPL + co * 64 + ((g ^ swzb(co)) << 4);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) br[n][pl] = *reinterpret_cast<const uint4*>(bp + pl * WPL);
+            }
+        };
+        load_ops(0, ao[0], bo[0]);
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+            if (dx < 4) load_ops(dx + 1, ao[(dx + 1) & 1], bo[(dx + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ds_reads above this tap's MFMAs
+#pragma unroll
+            for (int pr = 6 - NPROD; pr < 6; ++pr) {
+                const bf16x8 av = __builtin_bit_cast(bf16x8, ao[dx & 1][PA[pr]]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const bf16x8 bv = __builtin_bit_cast(bf16x8, bo[dx & 1][n][PB[pr]]);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[n], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (dy < 4) {
+            store_row((dy + 1) & 1, hv);
+            store_w((dy + 1) & 1, wv);
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: transpose the wave's [16 px][OP] tile through LDS (the tile's halo ring is free
+    //      after the last barrier) so that every lane moves 16-byte pieces of full 128-byte pixels ----
+    if (a.CO == OP) {
+        float* tb = reinterpret_cast<float*>(halo) + wave * (16 * OP);   // 16 px x OP floats per wave
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const float bias = a.bias ? a.bias[n * 16 + li] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tb[(4 * g + r) * OP + n * 16 + li] = acc[n][r] + bias;
+        }
+        // same-wave LDS round trip: the compiler's s_waitcnt lgkmcnt orders write -> read
+        if (tvalid) {
+            constexpr int F4 = 16 * OP / 4 / 64;          // float4 per lane
+#pragma unroll
+            for (int n = 0; n < F4; ++n) {
+                const int e = lane + n * 64;              // float4 index inside the tile
+                const int px = e / (OP / 4), c4 = e % (OP / 4);
+                float4 v = *reinterpret_cast<const float4*>(&tb[px * OP + c4 * 4]);
+                const size_t o4 = ((size_t)gy * W + x0 + wave * 16 + px) * (OP / 4) + c4;
+                if (a.res) { const float4 q = reinterpret_cast<const float4*>(a.res)[o4]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+                if (a.epi == SOL_EPI_LRELU) {
+                    v.x = v.x > 0.f ? v.x : a.slope * v.x; v.y = v.y > 0.f ? v.y : a.slope * v.y;
+                    v.z = v.z > 0.f ? v.z : a.slope * v.z; v.w = v.w > 0.f ? v.w : a.slope * v.w;
+                } else if (a.epi == SOL_EPI_DLRELU) {
+                    const float4 q = reinterpret_cast<const float4*>(a.act)[o4];
+                    v.x *= q.x > 0.f ? 1.f : a.slope; v.y *= q.y > 0.f ? 1.f : a.slope;
+                    v.z *= q.z > 0.f ? 1.f : a.slope; v.w *= q.w > 0.f ? 1.f : a.slope;
+                }
+                reinterpret_cast<float4*>(a.y)[o4] = v;
+            }
+        }
+        return;
+    }
+    if (!tvalid) return;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = n * 16 + li;
+        if (co >= a.CO) continue;
+        const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cc = wave * 16 + 4 * g + r;
+            const size_t o = ((size_t)gy * W + x0 + cc) * a.CO + co;
+            float v = acc[n][r] + bias;
+            if (a.res) v += a.res[o];
+            if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
+            else if (a.epi == SOL_EPI_DLRELU) v *= (a.act[o] > 0.f ? 1.f : a.slope);
+            a.y[o] = v;
+        }
+    }
+}
+
+constexpr size_t sb_lds(int OP) { return (size_t)3 * 2 * 3 * 68 * 64 + 2 * (size_t)5 * 3 * OP * 64; }
+
+int init_sb_kernels() {
+    static int rc = [] {
+        const void* ks[] = {reinterpret_cast<const void*>(k_conv5x5_sb<1, 6>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 6>),
+                            reinterpret_cast<const void*>(k_conv5x5_sb<1, 3>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 3>)};
+        for (const void* k : ks)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return sol_set_error(SOL_ERR_HIP, "hipFuncSetAttribute(split-bf16 conv kernels) failed");
+        return SOL_OK;
+    }();
+    return rc;
+}
+
+}  // namespace
+
+size_t sol_conv_sb_packed_floats(int OP) { return (size_t)25 * 3 * OP * 16; }   // 25 taps x 3 planes x OP x 32 bf16
+
+int sol_conv_sb_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int mode, void* out) {
+    const int OP = cout <= 16 ? 16 : 32;
+    const int total = 25 * OP * 16;
+    hipLaunchKernelGGL(k_pack_sb, dim3((total + 255) / 256), dim3(256), 0, s, w_hwio, reinterpret_cast<unsigned short*>(out), cin, cout, OP, mode);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
+// SOL_CONV_SPLIT=3 runs the three leading products only (~2^-17 relative error per product): an
+// experiment knob, NOT the default and not what bench.py or the parity tests use.
+int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles) {
+    if (int e = init_sb_kernels()) return e;
+    static const int nprod = [] { const char* v = getenv("SOL_CONV_SPLIT"); return v && atoi(v) == 3 ? 3 : 6; }();
+    const int grid3 = (ntiles + 2) / 3;
+    const size_t lds = sb_lds(NT * 16);
+    if (NT == 2 && nprod == 6) hipLaunchKernelGGL((k_conv5x5_sb<2, 6>), dim3(grid3), dim3(768), lds, s, a, ntiles);
+    else if (NT == 2) hipLaunchKernelGGL((k_conv5x5_sb<2, 3>), dim3(grid3), dim3(768), lds, s, a, ntiles);
+    else if (nprod == 6) hipLaunchKernelGGL((k_conv5x5_sb<1, 6>), dim3(grid3), dim3(768), lds, s, a, ntiles);
+    else hipLaunchKernelGGL((k_conv5x5_sb<1, 3>), dim3(grid3), dim3(768), lds, s, a, ntiles);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}

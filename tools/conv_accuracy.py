@@ -1,0 +1,30 @@
+#!/usr/bin/env python
+"""Accuracy + time of the 32->32 conv forward against a float64 torch convolution on the GPU.
+Run under SOL_CONV_NO_SB=1 (fp32 MFMA), default (split-bf16 x6) and SOL_CONV_SPLIT=3 to compare."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import sol_amd
+from sol_amd import ops
+
+torch.manual_seed(0)
+for (B, Y, X, cout) in [(6, 128, 64, 32), (2, 128, 64, 2), (1, 16, 64, 32)]:
+    x = torch.randn(B, Y, X, 32, device="cuda")
+    w = torch.randn(5, 5, 32, cout, device="cuda") * 0.05
+    bias = torch.randn(cout, device="cuda") * 0.1
+    packed = ops._pack(w, 32, cout, ops.CONV_FWD)
+    y = ops.conv5x5_raw(x, packed, bias, None, None, cout, ops.EPI_NONE, 0.3)
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), bias.double(), padding=2).permute(0, 2, 3, 1)
+    err = ((y.double() - ref).norm() / ref.norm()).item()
+    mx = ((y.double() - ref).abs().max() / ref.abs().max()).item()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn = lambda: ops.conv5x5_raw(x, packed, bias, None, None, cout, ops.EPI_LRELU, 0.3)
+    fn(); torch.cuda.synchronize(); e0.record()
+    for _ in range(50):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 50 * 1e3
+    print("B%d %dx%d 32->%d: rel L2 %.3e  max/max %.3e  %.1f us  %.1f TF (env NO_SB=%s SPLIT=%s)" % (
+        B, Y, X, cout, err, mx, us, 2.0 * 25 * 32 * cout * B * Y * X / us / 1e6,
+        os.environ.get("SOL_CONV_NO_SB"), os.environ.get("SOL_CONV_SPLIT")))
