@@ -26,6 +26,17 @@ struct ConvArgs {
     int TW, RPW, tiles_x;
     const void* wsb;   // split-bf16 weight planes (second section of the packed buffer), cin == 32 only
 };
+// backward-weight arguments
+struct BwArgs {
+    const float *x, *dz;
+    float* partial;
+    int B, H, W, cin, cout;
+    int nblk;
+    int nseg, rb;                 // nseg tensors of B*H rows each (the unrolled steps), rb image rows per workgroup
+    long x_seg, dz_seg;           // element strides between consecutive segments
+    int overwrite;                // 1: partial = acc (single launch), 0: partial += acc (accumulate over launches)
+};
+int sol_bww_sb_launch(hipStream_t s, const BwArgs& a, int nblk_run);
 // split-bf16 section of the packed weights and the kernels that consume it (conv5x5_sb.hip)
 size_t sol_conv_sb_packed_floats(int OP);
 int sol_conv_sb_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int mode, void* out);

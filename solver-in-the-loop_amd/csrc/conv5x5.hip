@@ -484,15 +484,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_r3(ConvArgs a, int ntiles) {
 // (no atomics; the slice is owned by the workgroup index, calls on one stream serialise).
 constexpr int RB = 8;   // image rows per workgroup
 
-struct BwArgs {
-    const float *x, *dz;
-    float* partial;
-    int B, H, W, cin, cout;
-    int nblk;
-    int nseg, rb;                 // nseg tensors of B*H rows each (the unrolled steps), rb image rows per workgroup
-    long x_seg, dz_seg;           // element strides between consecutive segments
-    int overwrite;                // 1: partial = acc (single launch), 0: partial += acc (accumulate over launches)
-};
+// BwArgs: common.hpp
 
 template <int CIN, int COUT>   // real channel counts: CIN in {3,4,32} staged as pad_in, COUT in {2,32}
 __global__ void __launch_bounds__(256) k_conv5x5_bww(BwArgs a) {
@@ -1011,9 +1003,8 @@ static int bww_dims(int rows, int rb, int cin, int cout, int* nblk, int* IP, int
 // image rows per workgroup: 8 for a single tensor; for the batched (all unrolled steps in one launch)
 // form enough rows that ~1300-2600 workgroups exist and the partial buffer stays small
 static int pick_rb(int rows) {
-    int rb = RB;
-    while (rows / rb > 512) rb *= 2;
-    return rb;
+    if (rows > 4096) return (rows + 255) / 256;   // one workgroup per CU (the split-bf16 kernel owns a CU's LDS)
+    return RB;
 }
 
 extern "C" size_t sol_conv5x5_bwd_weight_ws_floats(int32_t B, int32_t H, int32_t /*W*/, int32_t cin, int32_t cout) {
@@ -1058,6 +1049,8 @@ static int bww_launch(void* stream, const float* x, const float* dz, float* part
         SOL_LAUNCH_CHECK();
         return SOL_OK;
     }
+    static const bool use_sb = !getenv("SOL_CONV_NO_SB");
+    if (cin == 32 && cout == 32 && W == 64 && use_sb) return sol_bww_sb_launch(s, a, nblk_run);
     if (cin == 32 && cout == 32 && W == 64 && !getenv("SOL_CONV_NO_BWW32")) {
         const size_t lds3 = 2 * ((size_t)(64 + 4) * 32 + 64 * 32) * sizeof(float);
         hipLaunchKernelGGL(k_conv5x5_bww32, dim3(grid), dim3(256), lds3, s, a);

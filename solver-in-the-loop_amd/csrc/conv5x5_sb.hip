@@ -264,11 +264,197 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int ntiles) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------
+// backward-weight, 32 -> 32 channels, W == 64:  dW[dy][dx][ci][co] = sum_px x[y+dy-2][px+dx-2][ci] * dz[y][px][co]
+// ------------------------------------------------------------------------------------
+// GEMM per tap with K = pixels: A[m = ci][k = px] = x^T, B[k = px][n = co] = dz.  The K = 32 bf16 MFMA
+// wants 8 consecutive PIXELS of one channel per lane, so rows are transposed to [channel][pixel] bf16
+// planes while they are split and staged (4 px x 4 ch per thread item, ds_write_b64).  One workgroup
+// (8 waves) owns `rb` consecutive image rows and ALL 25 taps: an x row is staged once and meets the five
+// dz rows y+2-dy of a 6-slot dz ring, so x and dz are read, split and staged once instead of five times.
+// Wave = (ci tile, co tile, pixel half): 25 accumulator tiles each; the two pixel halves are folded
+// through LDS at the end.  The dx shift along K is done in registers: a lane reads pixels 8g..8g+11 of
+// its channel (b128 + b64) and builds the five shifted operands with v_alignbit (dx odd) or by register
+// renaming (dx even) -- no unaligned LDS access and the x operand is reused for all five tap rows.
+// LDS rows: x 16 chunks of 16 B per channel (68 px used), chunk ^= ci & 15; dz 8 chunks, chunk ^= (co >> 1) & 7
+// (both conflict-free for the CDNA4 ds_read_b128 lane groups).
+constexpr int BW_XPL = 32 * 256, BW_XST = 3 * BW_XPL;     // bytes: x plane / x row stage
+constexpr int BW_ZPL = 32 * 128, BW_ZST = 3 * BW_ZPL;     // bytes: dz plane / dz row stage
+constexpr int BW_LDS = 2 * BW_XST + 6 * BW_ZST;           // 122,880 B
+
+__global__ void __launch_bounds__(512) k_conv5x5_bww_sb(BwArgs a) {
+    constexpr int W = 64;
+    extern __shared__ __align__(16) unsigned char smem_sb[];
+    unsigned char* const XS = smem_sb;
+    unsigned char* const ZS = smem_sb + 2 * BW_XST;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int mt = wave & 1, nt = (wave >> 1) & 1, kb = wave >> 2;
+    const int H = a.H, blk = blockIdx.x;
+    const int R = a.nseg * a.B * H, RPS = a.B * H;
+    const int r0 = blk * a.rb, r1 = min(r0 + a.rb, R);
+
+    // staging roles: threads 0..135 move x items (halo pixel group of 4, channel quad), 256..383 dz items
+    const bool xrole = tid < 136, zrole = tid >= 256 && tid < 384;
+    const int it = xrole ? tid : tid - 256;
+    const int pxg = it >> 3, c4 = it & 7;
+    float4 sv[4];
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+
+    auto row_ptr = [&](const float* base, long seg_stride, int gr) {
+        const int seg = gr / RPS, grs = gr - seg * RPS;
+        return reinterpret_cast<const float4*>(base + (size_t)seg * seg_stride) + (size_t)grs * W * 8;
+    };
+    auto load_x = [&](int gr) {
+        const float4* gx = row_ptr(a.x, a.x_seg, gr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xx = 4 * pxg - 2 + j;
+            sv[j] = (xx >= 0 && xx < W) ? gx[xx * 8 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto load_z = [&](int gz) {
+        const float4* gzp = row_ptr(a.dz, a.dz_seg, gz);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sv[j] = gzp[(4 * pxg + j) * 8 + c4];
+    };
+    // split the 4 px x 4 ch item and write it transposed: per channel one 8-byte piece (4 pixels) per plane
+    auto store_item = [&](unsigned char* base, int plane_bytes, int row_bytes, bool is_x) {
+        const float e[4][4] = {{sv[0].x, sv[1].x, sv[2].x, sv[3].x}, {sv[0].y, sv[1].y, sv[2].y, sv[3].y},
+                               {sv[0].z, sv[1].z, sv[2].z, sv[3].z}, {sv[0].w, sv[1].w, sv[2].w, sv[3].w}};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ch = 4 * c4 + c;
+            unsigned p[3][2];
+            split3(e[c][0], e[c][1], p[0][0], p[1][0], p[2][0]);
+            split3(e[c][2], e[c][3], p[0][1], p[1][1], p[2][1]);
+            const int sw = is_x ? (ch & 15) : ((ch >> 1) & 7);
+            unsigned char* q = base + ch * row_bytes + ((((pxg >> 1) ^ sw) << 4) | ((pxg & 1) << 3));
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(q + pl * plane_bytes) = make_uint2(p[pl][0], p[pl][1]);
+        }
+    };
+    auto store_x = [&](int gr) { store_item(XS + (gr & 1) * BW_XST, BW_XPL, 256, true); };
+    auto store_z = [&](int gz) {
+        store_item(ZS + ((gz + 6) % 6) * BW_ZST, BW_ZPL, 128, false);
+        if (gz >= r0 && gz < r1) {   // bias gradient: every owned dz row is staged exactly once
+            bs[0] += (sv[0].x + sv[1].x) + (sv[2].x + sv[3].x);
+            bs[1] += (sv[0].y + sv[1].y) + (sv[2].y + sv[3].y);
+            bs[2] += (sv[0].z + sv[1].z) + (sv[2].z + sv[3].z);
+            bs[3] += (sv[0].w + sv[1].w) + (sv[2].w + sv[3].w);
+        }
+    };
+
+    // ---- prologue: dz rows r0-2 .. r0+2 and x row r0 ------------------------------------------
+    if (xrole) { load_x(r0); store_x(r0); }
+    if (zrole) {   // all five loads in flight before the first split (the accumulators are not live yet)
+        float4 pv[5][4];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int gz = r0 - 2 + k;
+            if (gz >= 0 && gz < R) { load_z(gz); for (int j = 0; j < 4; ++j) pv[k][j] = sv[j]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int gz = r0 - 2 + k;
+            if (gz >= 0 && gz < R) { for (int j = 0; j < 4; ++j) sv[j] = pv[k][j]; store_z(gz); }
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[25];
+#pragma unroll
+    for (int tp = 0; tp < 25; ++tp) acc[tp] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+    const int c0 = 4 * kb + g;
+
+#pragma unroll 1
+    for (int gr = r0; gr < r1; ++gr) {
+        const int y = gr % H;
+        const bool nx = gr + 1 < r1, nz = gr + 3 < R && gr + 3 <= r1 + 1;
+        if (xrole && nx) load_x(gr + 1);
+        if (zrole && nz) load_z(gr + 3);
+
+        // x operand of this lane: pixels 8*c0 .. 8*c0+11 (halo coordinates) of channel 16*mt + li, three planes
+        uint4 A[3][5];
+        {
+            const unsigned char* xs = XS + (gr & 1) * BW_XST + (16 * mt + li) * 256;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const uint4 q = *reinterpret_cast<const uint4*>(xs + pl * BW_XPL + ((c0 ^ li) << 4));
+                const uint2 e = *reinterpret_cast<const uint2*>(xs + pl * BW_XPL + (((c0 + 1) ^ li) << 4));
+                A[pl][0] = q;
+                A[pl][2] = make_uint4(q.y, q.z, q.w, e.x);
+                A[pl][4] = make_uint4(q.z, q.w, e.x, e.y);
+                A[pl][1] = make_uint4(__builtin_amdgcn_alignbit(q.y, q.x, 16), __builtin_amdgcn_alignbit(q.z, q.y, 16),
+                                      __builtin_amdgcn_alignbit(q.w, q.z, 16), __builtin_amdgcn_alignbit(e.x, q.w, 16));
+                A[pl][3] = make_uint4(__builtin_amdgcn_alignbit(q.z, q.y, 16), __builtin_amdgcn_alignbit(q.w, q.z, 16),
+                                      __builtin_amdgcn_alignbit(e.x, q.w, 16), __builtin_amdgcn_alignbit(e.y, e.x, 16));
+            }
+        }
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy) {
+            const int yz = y + 2 - dy;
+            if (yz < 0 || yz >= H) continue;            // workgroup uniform
+            const int gz = gr + 2 - dy;
+            const unsigned char* zs = ZS + ((gz + 6) % 6) * BW_ZST + (16 * nt + li) * 128 + ((c0 ^ ((li >> 1) & 7)) << 4);
+            bf16x8 Bv[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) Bv[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(zs + pl * BW_ZPL));
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                for (int dx = 0; dx < 5; ++dx)
+                    acc[dy * 5 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[PA[pr]][dx]), Bv[PB[pr]],
+                                                                               acc[dy * 5 + dx], 0, 0, 0);
+        }
+        if (xrole && nx) store_x(gr + 1);
+        if (zrole && nz) store_z(gr + 3);
+        __syncthreads();
+    }
+
+    // ---- fold the two pixel halves through LDS and add into this block's partial slice --------
+    float* red = reinterpret_cast<float*>(smem_sb);      // [4 waves][25 taps][256]
+    if (kb == 1) {
+#pragma unroll
+        for (int tp = 0; tp < 25; ++tp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((wave & 3) * 25 + tp) * 256 + (4 * g + r) * 16 + li] = acc[tp][r];
+    }
+    __syncthreads();
+    if (kb == 0) {
+        float* pw = a.partial + (size_t)blk * (25 * 1024);
+#pragma unroll
+        for (int tp = 0; tp < 25; ++tp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[tp][r] + red[((wave & 3) * 25 + tp) * 256 + (4 * g + r) * 16 + li];
+                float* dst = &pw[(tp * 32 + 16 * mt + 4 * g + r) * 32 + 16 * nt + li];
+                *dst = a.overwrite ? v : *dst + v;
+            }
+    }
+    __syncthreads();
+    float* redb = reinterpret_cast<float*>(smem_sb);     // [128 dz items][4]
+    if (zrole) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) redb[it * 4 + c] = bs[c];
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float v = 0.f;
+        for (int p = 0; p < 16; ++p) v += redb[((p << 3) | (tid >> 2)) * 4 + (tid & 3)];
+        float* pb = a.partial + (size_t)a.nblk * (25 * 1024) + (size_t)blk * 32;
+        pb[tid] = a.overwrite ? v : pb[tid] + v;
+    }
+}
+
 constexpr size_t sb_lds(int OP) { return (size_t)3 * 2 * 3 * 68 * 64 + 2 * (size_t)5 * 3 * OP * 64; }
 
 int init_sb_kernels() {
     static int rc = [] {
-        const void* ks[] = {reinterpret_cast<const void*>(k_conv5x5_sb<1, 6>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 6>),
+        const void* ks[] = {reinterpret_cast<const void*>(k_conv5x5_bww_sb), reinterpret_cast<const void*>(k_conv5x5_sb<1, 6>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 6>),
                             reinterpret_cast<const void*>(k_conv5x5_sb<1, 3>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 3>)};
         for (const void* k : ks)
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -301,6 +487,13 @@ int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles) {
     else if (NT == 2) hipLaunchKernelGGL((k_conv5x5_sb<2, 3>), dim3(grid3), dim3(768), lds, s, a, ntiles);
     else if (nprod == 6) hipLaunchKernelGGL((k_conv5x5_sb<1, 6>), dim3(grid3), dim3(768), lds, s, a, ntiles);
     else hipLaunchKernelGGL((k_conv5x5_sb<1, 3>), dim3(grid3), dim3(768), lds, s, a, ntiles);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
+int sol_bww_sb_launch(hipStream_t s, const BwArgs& a, int nblk_run) {
+    if (int e = init_sb_kernels()) return e;
+    hipLaunchKernelGGL(k_conv5x5_bww_sb, dim3(nblk_run), dim3(512), BW_LDS, s, a);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }

@@ -36,7 +36,9 @@ struct StepArgs {
     // backward only
     const float *g_vy_out, *g_vx_out, *dfeat;
     float *g_vy_in, *g_vx_in;
+    long long* prof;   // SOL_STEP_PROF=1: phase time stamps of workgroup 0 (100 MHz wall clock), debugging only
 };
+#define SOL_STAMP(i) do { if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[i] = wall_clock64(); } while (0)
 
 __host__ __device__ inline int al4(int n) { return (n + 3) & ~3; }
 
@@ -495,6 +497,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
     const float invXP = 1.f / (float)XP;         // k / XP == (int)((k + 0.5) * invXP), exact for k < 2^22
     const Lds L = carve(smem, Y, X, CPT);
 
+    SOL_STAMP(0);
     // ---- phase 1: load inputs -------------------------------------------------------
     {
         const float* gvy = a.vy_in + (size_t)b * nVy;
@@ -504,6 +507,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
         for (int k = tid; k < N; k += nthr) L.act[k] = a.active[k] != 0.f ? 1 : 0;
     }
     __syncthreads();
+    SOL_STAMP(1);
 
     // ---- phase 2: explicit diffusion (replicate padding, dx = 1) + velocity BC ------
     if (!(a.dbg & 8)) {
@@ -533,6 +537,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
         }
     }
     __syncthreads();
+    SOL_STAMP(2);
 
     // ---- phase 3: semi-Lagrangian advection (B -> A), hard-BC face mask fused --------
     if (!(a.dbg & 1))
@@ -554,6 +559,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
         const Bil s = bil_clamp(Y, XP, j, -uy * a.dtdx, i, -ux * a.dtdx);
         L.Avx[k] = bil_eval(L.Bvx, XP, s) * mask_x(L.act, Y, X, j, i);
     }
+    SOL_STAMP(3);
     if (a.d_out && !(a.dbg & 2)) {
         const float* gd = a.d_in + (size_t)b * N;
         #pragma unroll 4
@@ -584,6 +590,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
         }
     }
     __syncthreads();
+    SOL_STAMP(4);
 
     // ---- phase 4/5: divergence + CG pressure solve ----------------------------------
     const Own o = ownership<CPT>(Y, X);
@@ -600,6 +607,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
     }
     int it = 0;
     bool solved = false;
+    SOL_STAMP(5);
     if constexpr (CPT == 16) {     // the two-level preconditioner is instantiated for the 16-cell strips only
         if (a.cinv) {
             it = X == 64 ? pcg_solve<CPT, true, 32>(o, Y, X, L.act, dg, ac, r, x, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter)
@@ -610,6 +618,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
     if (!solved) it = X == 64 ? cg_solve<CPT, true>(o, X, dg, ac, r, x, L.E, L.red, a.rtol2, a.atol2, a.max_iter)
                       : cg_solve<CPT, false>(o, X, dg, ac, r, x, L.E, L.red, a.rtol2, a.atol2, a.max_iter);
     if (a.iters && tid == 0) a.iters[b] = it;
+    SOL_STAMP(6);
 
     // ---- phase 6: v -= mask * grad p ;  outputs --------------------------------------
     float* P = L.Bvy;   // region B is free after the advection
@@ -642,6 +651,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
             gvx[k] = v;
         }
     }
+    SOL_STAMP(7);
     if (a.feat) {   // fused to_feature + 1/std scaling (karman_train.py:77-86,416-419)
         __syncthreads();
         float4* gf = reinterpret_cast<float4*>(a.feat) + (size_t)b * N;
@@ -652,6 +662,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
             gf[k] = make_float4(L.Avy[k] * a.fs0, L.Avx[j * XP + i] * a.fs1, rech, 0.f);
         }
     }
+    SOL_STAMP(8);
 }
 
 // ------------------------------------------------------------------------------------
@@ -668,6 +679,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
     const Lds L = carve(smem, Y, X, CPT);
     const bool dirichlet = a.grad_pad == 1;
 
+    SOL_STAMP(0);
     // ---- 1: load incoming gradient (+ feature gradient) ------------------------------
     {
         const float* gy = a.g_vy_out + (size_t)b * nVy;
@@ -689,6 +701,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
         for (int k = tid; k < N; k += nthr) L.act[k] = a.active[k] != 0.f ? 1 : 0;
     }
     __syncthreads();
+    SOL_STAMP(1);
 
     // ---- 2: projection adjoint:  M z = G^T (m * g) -----------------------------------
     const Own o = ownership<CPT>(Y, X);
@@ -709,6 +722,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
     }
     int it = 0;
     bool solved = false;
+    SOL_STAMP(2);
     if constexpr (CPT == 16) {     // the two-level preconditioner is instantiated for the 16-cell strips only
         if (a.cinv) {
             it = X == 64 ? pcg_solve<CPT, true, 32>(o, Y, X, L.act, dg, ac, r, z, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter)
@@ -719,6 +733,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
     if (!solved) it = X == 64 ? cg_solve<CPT, true>(o, X, dg, ac, r, z, L.E, L.red, a.rtol2, a.atol2, a.max_iter)
                       : cg_solve<CPT, false>(o, X, dg, ac, r, z, L.E, L.red, a.rtol2, a.atol2, a.max_iter);
     if (a.iters && tid == 0) a.iters[b] = it;
+    SOL_STAMP(3);
 
     // ---- 3: g_adv = m * (g + D^T z), kept in registers ---------------------------------
     float* Z = L.Bvy;
@@ -748,6 +763,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
         }
     }
     __syncthreads();
+    SOL_STAMP(4);
 
     // ---- 4: stage the saved (post-diffusion) velocity, clear the accumulators ---------
     // The scatter-add runs in int32 FIXED POINT: ds_add_f32 is ~37x slower than ds_add_u32 on gfx950
@@ -772,6 +788,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
     const float qi = bound > 0.f ? bound / 2147483648.f : 0.f;
     auto fx = [&](float v) { return __float2int_rn(v * qs); };
 
+    SOL_STAMP(5);
     // ---- 5: advection adjoint (integer scatter-add into LDS) ----------------------------
     if (!(a.dbg & 32))
 #pragma unroll
@@ -823,6 +840,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
         }
     }
     __syncthreads();
+    SOL_STAMP(6);
     {   // back to float (in place, element-wise); |acc| > 2^30 would mean the 16x headroom was nearly used up
         bool risky = false;
         for (int k = tid; k < nVy; k += nthr) { const int q = Iy[k]; risky |= abs(q) > (1 << 30); L.Avy[k] = (float)q * qi; }
@@ -831,6 +849,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
     }
     __syncthreads();
 
+    SOL_STAMP(7);
     // ---- 6: BC adjoint, then diffusion adjoint (the replicate Laplacian is symmetric) --
     if (a.dbg & 64) return;
     {
@@ -859,6 +878,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
             ox[k] = c + alpha * lap;
         }
     }
+    SOL_STAMP(8);
 }
 
 // strip height: 16 cells per thread when the grid allows it (fewer waves -> less per-wave
@@ -929,12 +949,27 @@ int sol_init_karman_kernels() {
 namespace {
 
 template <typename K>
-int launch_step(K kernel, int cpt, const sol_karman_cfg* c, void* stream, const StepArgs& a) {
+int launch_step(K kernel, int cpt, const sol_karman_cfg* c, void* stream, const StepArgs& a0) {
     const int threads = (int)align_up((size_t)(c->Y / cpt) * c->X, 64);
     const size_t lds = lds_bytes(c->Y, c->X, cpt);
     if (int e = sol_init_karman_kernels()) return e;
+    StepArgs a = a0;
+    static const bool prof = getenv("SOL_STEP_PROF") != nullptr;     // debugging: synchronous, prints phase times
+    static long long* pbuf = nullptr;
+    if (prof) {
+        if (!pbuf) SOL_HIP_CHECK(hipMalloc(&pbuf, 16 * sizeof(long long)));
+        a.prof = pbuf;
+    }
     hipLaunchKernelGGL(kernel, dim3(c->B), dim3(threads), lds, (hipStream_t)stream, a);
     SOL_LAUNCH_CHECK();
+    if (prof) {
+        long long h[16];
+        SOL_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+        SOL_HIP_CHECK(hipMemcpy(h, pbuf, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[SOL_STEP_PROF %s] us per phase:", a.g_vy_in ? "bwd" : "fwd");
+        for (int i = 1; i <= 8; ++i) fprintf(stderr, " %.2f", (double)(h[i] - h[i - 1]) * 0.01);
+        fprintf(stderr, "  total %.2f\n", (double)(h[8] - h[0]) * 0.01);
+    }
     return SOL_OK;
 }
 

@@ -28,3 +28,34 @@ for (B, Y, X, cout) in [(6, 128, 64, 32), (2, 128, 64, 2), (1, 16, 64, 32)]:
     print("B%d %dx%d 32->%d: rel L2 %.3e  max/max %.3e  %.1f us  %.1f TF (env NO_SB=%s SPLIT=%s)" % (
         B, Y, X, cout, err, mx, us, 2.0 * 25 * 32 * cout * B * Y * X / us / 1e6,
         os.environ.get("SOL_CONV_NO_SB"), os.environ.get("SOL_CONV_SPLIT")))
+
+# ---- backward-weight 32x32 against float64 -------------------------------------------------
+import ctypes as C
+from sol_amd import _lib
+from sol_amd._lib import ptr, stream, check
+lib = _lib.load()
+for (B, Y, X) in [(2, 128, 64), (6, 128, 64), (24, 128, 64)]:
+    x = torch.randn(B, Y, X, 32, device="cuda")
+    dz = torch.randn(B, Y, X, 32, device="cuda")
+    nws = lib.sol_conv5x5_bwd_weight_ws_floats(B, Y, X, 32, 32)
+    part = torch.zeros(nws, device="cuda")
+    dw = torch.zeros(5, 5, 32, 32, device="cuda")
+    db = torch.zeros(32, device="cuda")
+    check(lib.sol_conv5x5_bwd_weight(stream(), ptr(x), ptr(dz), ptr(part), B, Y, X, 32, 32))
+    check(lib.sol_conv5x5_bwd_weight_reduce(stream(), ptr(part), ptr(dw), ptr(db), B, Y, X, 32, 32, 0))
+    xd = x.double().permute(0, 3, 1, 2).requires_grad_(False)
+    wd = torch.zeros(32, 32, 5, 5, dtype=torch.float64, device="cuda", requires_grad=True)
+    bd = torch.zeros(32, dtype=torch.float64, device="cuda", requires_grad=True)
+    yy = torch.nn.functional.conv2d(xd, wd, bd, padding=2)
+    (yy * dz.double().permute(0, 3, 1, 2)).sum().backward()
+    ref = wd.grad.permute(2, 3, 1, 0)
+    e_w = ((dw.double() - ref).norm() / ref.norm()).item()
+    e_b = ((db.double() - bd.grad).norm() / bd.grad.norm()).item()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn = lambda: check(lib.sol_conv5x5_bwd_weight(stream(), ptr(x), ptr(dz), ptr(part), B, Y, X, 32, 32))
+    fn(); torch.cuda.synchronize(); e0.record()
+    for _ in range(20):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    print("bww B%d %dx%d: dw rel L2 %.3e  db rel %.3e  %.1f us  %.1f TF" % (B, Y, X, e_w, e_b, us, 2.0 * 25 * 1024 * B * Y * X / us / 1e6))
