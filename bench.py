@@ -173,12 +173,31 @@ def main():
         # `traffic`: HBM bytes per launch from rocprofv3 PMC passes of the same kernels at this shape
         # (profiles/r01_pmc_traffic.txt: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE); constants, not live
         c3 = (Y, X, B) == (128, 64, 6)
+        direct = getattr(masks, "direct", None) is not None
         roof_solver = {"kernel": "k_karman_fwd<16>", "bound": "hbm", "achieved": bytes_step / t_step / 1e9, "peak": 8000.0,
                        "unit": "GB/s", "frac": bytes_step / t_step / 8e12,
                        "traffic": (2 * 1158.1 + 1041.2) * 1024 if c3 else None,
                        "launch_us": t_step * 1e6, "cg_iters": k_f, "algorithmic_bytes_per_launch": bytes_step,
-                       "note": "LDS-resident: the algorithmic bytes (SURVEY 8d formula with the measured CG iterations of the "
-                               "two-level preconditioned solve) never reach HBM; the kernel is issue/latency bound on 6 CUs"}
+                       "pressure_solver": "direct (sine-transform diagonalisation + capacitance correction, no iteration)" if direct
+                                          else "two-level preconditioned CG",
+                       "note": "LDS-resident, one workgroup (CU) per simulation: B = %d simulations occupy %d of 256 CUs, so the "
+                               "fraction of the CHIP's HBM roofline is bounded by B/256; the algorithmic bytes (SURVEY 8d formula, "
+                               "CG term with the measured iteration count: 0 for the direct solver) never reach HBM" % (B, B)}
+        # the same kernel with one simulation per CU (256 simulations): what the LDS-resident design delivers per chip
+        try:
+            Bf = 256
+            df, vyf, vxf = (t[:1].expand(Bf, -1, -1).contiguous() for t in (d0, vy0, vx0))
+            ref_ = re[:1].expand(Bf).contiguous()
+            cfgf = ops.karman_cfg(Bf, Y, X, dom.dx[1], masks=masks)
+            infof = {}
+            t_full = time_call(lambda: ops.karman_step(df, vyf, vxf, ref_, cfgf, masks, infof), 10)
+            kff = float(infof["iterations"].double().mean().item())
+            bytes_full = 4.0 * (10 * Nf + 9 * N + 11.0 * N * kff) * Bf
+            roof_solver["full_chip_256_sims"] = {"launch_us": t_full * 1e6, "sim_steps_per_s": Bf / t_full,
+                                                 "algorithmic_GBps": bytes_full / t_full / 1e9, "frac_of_hbm_peak": bytes_full / t_full / 8e12}
+            del df, vyf, vxf
+        except Exception as e:
+            roof_solver["full_chip_256_sims"] = {"error": str(e)}
         roof_conv = {"kernel": "k_conv5x5_r3<2>", "bound": "mfma", "achieved": flop_conv / t_conv / 1e12, "peak": 157.3,
                      "unit": "TFLOP/s", "frac": flop_conv / t_conv / 157.3e12,
                      "traffic": (2 * 9107.9 + 6144.0) * 1024 if c3 else None,

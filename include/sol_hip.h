@@ -62,10 +62,19 @@ typedef struct sol_karman_cfg {
                                8x8-cell aggregates P of the scene's `active` mask, prepared by the host
                                (see sol_karman_precond_supported).  Only the iteration count changes:
                                the solve still converges to the same tolerance.                      */
+    int32_t direct_n;       /* 0, or the number of 32-bit words of `direct`                                   */
+    const float* direct;    /* NULL, or DEVICE blob of the DIRECT pressure solver (PhiFlow's PressureSolver plug
+                               point, KarmanFlow(pressure_solver=...) karman_train.py:167): fast diagonalisation
+                               of the rectangle Laplacian by sine transforms + a dense capacitance correction for
+                               the obstacle cells, prepared by the host for the scene's `active` mask (layout:
+                               precond.direct_solver_blob).  Takes precedence over the CG; no iteration, the
+                               solution equals the converged CG solution up to fp32 round-off.                */
 } sol_karman_cfg;
 
 /* 1 if the two-level CG preconditioner can be used for a Y x X grid, else 0 */
 int sol_karman_precond_supported(int32_t Y, int32_t X);
+/* 1 if the direct pressure solver is built for a Y x X grid (128 x 64), else 0 */
+int sol_karman_direct_supported(int32_t Y, int32_t X);
 
 /* active  [Y,X]  1 - obstacle mask (cell centres inside Obstacle geometries -> 0)
  * inflow  [Y,X]  inflow rate mask (Inflow(box[5:10,25:75]) -> 1 inside)

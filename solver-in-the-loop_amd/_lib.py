@@ -26,7 +26,8 @@ class KarmanCfg(C.Structure):
                 ("dx", C.c_float), ("dt", C.c_float), ("res", C.c_float),
                 ("cg_rtol", C.c_float), ("cg_atol", C.c_float), ("cg_max_iter", C.c_int32),
                 ("grad_pad", C.c_int32), ("inflow_before", C.c_int32),
-                ("coarse_n", C.c_int32), ("coarse_inv", C.c_void_p)]
+                ("coarse_n", C.c_int32), ("coarse_inv", C.c_void_p),
+                ("direct_n", C.c_int32), ("direct", C.c_void_p)]
 
 
 class BurgersCfg(C.Structure):
@@ -45,6 +46,7 @@ _P = C.c_void_p
 _SIGS = {
     "sol_last_error": (C.c_char_p, []),
     "sol_version": (C.c_int, []),
+    "sol_karman_direct_supported": (C.c_int, [C.c_int32] * 2),
     "sol_karman_precond_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "sol_karman_step_fwd": (C.c_int, [C.POINTER(KarmanCfg), _P] + [_P] * 8 + [C.c_int64] + [_P] * 6 + [C.POINTER(C.c_float), _P]),
     "sol_karman_step_bwd": (C.c_int, [C.POINTER(KarmanCfg), _P] + [_P] * 5 + [C.c_int64] + [_P] * 3 + [C.POINTER(C.c_float)] + [_P] * 3),

@@ -28,8 +28,12 @@ class KarmanFlow:
 
     def __init__(self, pressure_solver=None, make_input_divfree=False, make_output_divfree=True,
                  cg_rtol=1e-6, cg_atol=1e-9, cg_max_iter=2000, grad_pad="replicate", inflow_order="after"):
-        if pressure_solver is not None:
-            raise NotImplementedError("the pressure solve is the fused LDS-resident CG of libsol_hip.so")
+        # the reference's plug point: None = this build's default ("auto": the direct solver where the grid and the
+        # scene allow it, else the two-level preconditioned CG), or one of "direct" / "cg"
+        if pressure_solver not in (None, "auto", "direct", "cg"):
+            raise NotImplementedError("pressure_solver must be None, 'auto', 'direct' or 'cg': the pressure solve is fused "
+                                      "into the LDS-resident solver step of libsol_hip.so")
+        self._pressure_solver = pressure_solver or "auto"
         if make_input_divfree or not make_output_divfree:
             raise NotImplementedError("only (make_input_divfree=False, make_output_divfree=True) is on the reference path")
         self.infl = Inflow(box[5:10, 25:75])
@@ -55,7 +59,7 @@ class KarmanFlow:
             bcm = np.asarray(velBCyMask, dtype=np.float64).reshape(-1, Y + 1, X)
             if bcv.shape[0] > 1 and np.all(bcv == bcv[0:1]) and np.all(bcm == bcm[0:1]):
                 bcv, bcm = bcv[0:1], bcm[0:1]
-            self._cache[key] = ops.SceneMasks(active, inflow, bcv, bcm, device)
+            self._cache[key] = ops.SceneMasks(active, inflow, bcv, bcm, device, pressure_solver=self._pressure_solver)
         return self._cache[key]
 
     def step(self, smoke, re, res, velBCy, velBCyMask, dt=1.0, gravity=None):

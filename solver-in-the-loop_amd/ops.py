@@ -22,12 +22,16 @@ def karman_cfg(B, Y, X, dx, dt=1.0, res=None, cg_rtol=1e-6, cg_atol=1e-9, cg_max
     """sol_karman_cfg; `masks` (SceneMasks) supplies the coarse inverse of the CG preconditioner."""
     cfg = KarmanCfg(B, Y, X, float(dx), float(dt), float(X if res is None else res),
                     float(cg_rtol), float(cg_atol), int(cg_max_iter),
-                    {"replicate": 0, "dirichlet0": 1}[grad_pad], {"after": 0, "before": 1}[inflow_order], 0, None)
+                    {"replicate": 0, "dirichlet0": 1}[grad_pad], {"after": 0, "before": 1}[inflow_order], 0, None, 0, None)
     ci = getattr(masks, "coarse_inv", None)
     if ci is not None:
         cfg.coarse_n = ci.shape[0]
         cfg.coarse_inv = ci.data_ptr()
-        cfg._keep = ci            # the struct holds a raw device pointer
+    db = getattr(masks, "direct", None)
+    if db is not None:
+        cfg.direct_n = db.numel()
+        cfg.direct = db.data_ptr()
+    cfg._keep = (ci, db)          # the struct holds raw device pointers
     return cfg
 
 
@@ -35,7 +39,7 @@ class SceneMasks:
     """Device-resident constant masks of a scene: active (1 - obstacle), inflow rate, velBCy,
     velBCyMask (reference: KarmanFlow.__init__ karman_train.py:166-171 and :366-373)."""
 
-    def __init__(self, active, inflow, velBCy, velBCyMask, device="cuda", precondition=True):
+    def __init__(self, active, inflow, velBCy, velBCyMask, device="cuda", precondition=True, pressure_solver="auto"):
         self.active = _lib.f32(active, device)
         self.inflow = _lib.f32(inflow, device)
         self.velBCy = _lib.f32(velBCy, device)
@@ -49,6 +53,19 @@ class SceneMasks:
         if precondition and not os.environ.get("SOL_NO_PRECOND") and _lib.load().sol_karman_precond_supported(Y, X):
             from .precond import coarse_inverse
             self.coarse_inv = _lib.f32(coarse_inverse(self.active.reshape(Y, X).cpu().numpy()), device)
+        # direct pressure solver (fast diagonalisation + capacitance correction) where it is built and the
+        # scene qualifies; pressure_solver="cg" (or SOL_PRESSURE_SOLVER=cg) keeps the (preconditioned) CG
+        self.direct = None
+        want = os.environ.get("SOL_PRESSURE_SOLVER", pressure_solver)
+        if want not in ("auto", "direct", "cg"):
+            raise ValueError("pressure_solver must be 'auto', 'direct' or 'cg' (got %r)" % (want,))
+        if want != "cg" and _lib.load().sol_karman_direct_supported(Y, X):
+            from .precond import direct_solver_blob
+            blob = direct_solver_blob(self.active.reshape(Y, X).cpu().numpy())
+            if blob is not None:
+                self.direct = torch.from_numpy(blob).to(device)
+        if want == "direct" and self.direct is None:
+            raise ValueError("the direct pressure solver does not support this scene (%dx%d)" % (Y, X))
 
 
 def _scale3(vals):

@@ -41,3 +41,126 @@ def coarse_inverse(active, block=8):
     empty = np.diag(Ac) == 0
     Ac[empty, empty] = 1.0
     return np.linalg.inv(Ac).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# Direct pressure solver: fast diagonalisation of the rectangle + capacitance correction
+# ---------------------------------------------------------------------------------------------
+# On the OPEN rectangle without obstacle M is the 5-point Dirichlet Laplacian M_r = T_Y (x) I + I (x) T_X,
+# diagonalised by the orthonormal sine transforms Q_Y, Q_X:  M_r^-1 = (Q_Y (x) Q_X) diag(1/lam) (Q_Y (x) Q_X).
+# The obstacle changes M only on the set S of obstacle cells and their neighbours (164 cells at
+# 128x64, inside one 16x16 window):  M = M_r + U_S E_SS U_S^T.  Then
+#     x = G (b - U_S E_SS x_S),   x_S = (I + G_SS E_SS)^-1 (G b)_S,   G = M_r^-1
+# i.e. one forward transform, a window-sized dense correction, one inverse transform: NO iteration,
+# same solution as the converged CG up to fp32 round-off (csrc/karman_step.hip: fd_solve).
+FD_MAGIC = 0x46443031          # "FD01"
+FD_HEADER = 16                 # int32 words
+FD_WIN = 16                    # window edge (cells)
+
+
+def dst_matrix(n):
+    k = np.arange(1, n + 1)
+    return np.sqrt(2.0 / (n + 1)) * np.sin(np.pi * np.outer(k, k) / (n + 1))
+
+
+def scene_matrix(active):
+    """Dense float64 M = -A of the scene (small grids / setup only)."""
+    act = (np.asarray(active, dtype=np.float64) != 0).astype(np.float64)
+    Y, X = act.shape
+    N = Y * X
+    acc = np.pad(act, 1, mode="edge")
+    diag = np.maximum(acc[0:Y, 1:X + 1] + acc[2:Y + 2, 1:X + 1] + acc[1:Y + 1, 0:X] + acc[1:Y + 1, 2:X + 2], 1.0)
+    idx = np.arange(N).reshape(Y, X)
+    M = np.zeros((N, N))
+    M[idx.ravel(), idx.ravel()] = diag.ravel()
+    for sj, si in ((1, 0), (0, 1)):
+        a = (act[0:Y - sj, 0:X - si] * act[sj:Y, si:X]).ravel()
+        r = idx[0:Y - sj, 0:X - si].ravel()
+        c = idx[sj:Y, si:X].ravel()
+        M[r, c] -= a
+        M[c, r] -= a
+    return M
+
+
+def _perturbation(active):
+    """Sparse difference E = M - M_r as {(row, col): value} restricted to its support set S."""
+    act = (np.asarray(active, dtype=np.float64) != 0).astype(np.float64)
+    Y, X = act.shape
+    acc = np.pad(act, 1, mode="edge")
+    diag = np.maximum(acc[0:Y, 1:X + 1] + acc[2:Y + 2, 1:X + 1] + acc[1:Y + 1, 0:X] + acc[1:Y + 1, 2:X + 2], 1.0)
+    ent = {}
+    for j, i in zip(*np.nonzero(diag != 4.0)):
+        ent[(j * X + i, j * X + i)] = diag[j, i] - 4.0
+    for sj, si in ((1, 0), (0, 1)):
+        a = act[0:Y - sj, 0:X - si] * act[sj:Y, si:X]
+        for j, i in zip(*np.nonzero(a != 1.0)):
+            r, c = j * X + i, (j + sj) * X + (i + si)
+            ent[(r, c)] = ent[(c, r)] = 1.0 - a[j, i]      # M has -a, M_r has -1
+    return ent
+
+
+def direct_solver_blob(active):
+    """float32 blob consumed by sol_karman_cfg.direct, or None when the scene does not qualify
+    (perturbed cells do not fit one 16x16 window, or the capacitance system is ill conditioned).
+
+    layout (32-bit words): header[16] = {magic, Y, X, wy0, wx0, nS, SP, ...};  Qy[Y*Y];  Qx[X*X];
+    invlamT[X*Y] (= 1/lam[m][c] stored [c][m]);  KpT[SP*SP] (K' = E_SS (I + G_SS E_SS)^-1, stored
+    transposed, zero padded);  sidx[SP] int32 (window-local index j'*16 + i', -1 = padding)."""
+    act = (np.asarray(active, dtype=np.float64) != 0).astype(np.float64)
+    Y, X = act.shape
+    ent = _perturbation(act)
+    if not ent:
+        return None
+    S = np.array(sorted({r for r, _ in ent}), dtype=np.int64)
+    js, is_ = S // X, S % X
+    if js.max() - js.min() >= FD_WIN or is_.max() - is_.min() >= FD_WIN or Y < FD_WIN or X < FD_WIN:
+        return None
+    wy0 = int(min(js.min(), Y - FD_WIN))
+    wx0 = int(min(is_.min(), X - FD_WIN))
+    nS = len(S)
+    SP = (nS + 63) // 64 * 64
+    pos = {int(s): n for n, s in enumerate(S)}
+    ESS = np.zeros((nS, nS))
+    for (r, c), v in ent.items():
+        ESS[pos[r], pos[c]] = v
+    Qy, Qx = dst_matrix(Y), dst_matrix(X)
+    lam = (2 - 2 * np.cos(np.pi * np.arange(1, Y + 1) / (Y + 1)))[:, None] + (2 - 2 * np.cos(np.pi * np.arange(1, X + 1) / (X + 1)))[None, :]
+    # G_SS[s, t] = sum_{m,c} Qy[js,m] Qx[is,c] / lam[m,c] * Qy[jt,m] Qx[it,c]
+    Fy, Fx = Qy[js, :], Qx[is_, :]                                # [nS, Y], [nS, X]
+    F = (Fy[:, :, None] * Fx[:, None, :]).reshape(nS, Y * X)
+    GSS = (F / lam.reshape(1, Y * X)) @ F.T
+    cap = np.eye(nS) + GSS @ ESS
+    if np.linalg.cond(cap) > 1e6:
+        return None
+    Kp = ESS @ np.linalg.inv(cap)
+    KpT = np.zeros((SP, SP))
+    KpT[:nS, :nS] = Kp.T
+    sidx = np.full(SP, -1, dtype=np.int32)
+    sidx[:nS] = ((js - wy0) * FD_WIN + (is_ - wx0)).astype(np.int32)
+    header = np.zeros(FD_HEADER, dtype=np.int32)
+    header[:7] = [FD_MAGIC, Y, X, wy0, wx0, nS, SP]
+    parts = [header.view(np.float32), Qy.astype(np.float32).ravel(), Qx.astype(np.float32).ravel(),
+             (1.0 / lam).T.astype(np.float32).ravel(), KpT.astype(np.float32).ravel(), sidx.view(np.float32)]
+    return np.concatenate(parts)
+
+
+def direct_solve_reference(blob, b):
+    """float64 numpy restatement of the device algorithm on the blob (used by the CPU tests)."""
+    hdr = blob[:FD_HEADER].view(np.int32)
+    assert hdr[0] == FD_MAGIC
+    Y, X, wy0, wx0, nS, SP = (int(v) for v in hdr[1:7])
+    o = FD_HEADER
+    Qy = blob[o:o + Y * Y].astype(np.float64).reshape(Y, Y); o += Y * Y
+    Qx = blob[o:o + X * X].astype(np.float64).reshape(X, X); o += X * X
+    il = blob[o:o + X * Y].astype(np.float64).reshape(X, Y).T; o += X * Y
+    KpT = blob[o:o + SP * SP].astype(np.float64).reshape(SP, SP); o += SP * SP
+    sidx = blob[o:o + SP].view(np.int32)
+    T2 = (Qy @ b @ Qx) * il
+    x0w = Qy[wy0:wy0 + FD_WIN, :] @ T2 @ Qx[:, wx0:wx0 + FD_WIN]
+    xs = np.where(sidx >= 0, x0w.ravel()[np.maximum(sidx, 0)], 0.0)
+    c = KpT.T @ xs
+    w2 = np.zeros(FD_WIN * FD_WIN)
+    w2[sidx[sidx >= 0]] = -c[sidx >= 0]
+    w2 = w2.reshape(FD_WIN, FD_WIN)
+    T2 = T2 + il * (Qy[:, wy0:wy0 + FD_WIN] @ w2 @ Qx[wx0:wx0 + FD_WIN, :])
+    return Qy @ T2 @ Qx

@@ -122,7 +122,8 @@ class SolTrainer:
     # ---- algorithmic traffic of the solver part ---------------------
     def solver_algorithmic_bytes(self):
         """4*(10*Nf + 9*N + 11*N*k) per forward sample-step and 4*(2*(10*Nf+9*N) + 11*N*k_bwd)
-        per backward sample-step with the MEASURED CG iteration counts."""
+        per backward sample-step with the MEASURED CG iteration counts (k = 0 with the direct solver:
+        only the stencil / advection traffic of SURVEY 8d remains)."""
         N = self.Y * self.X
         Nf = (self.Y + 1) * self.X + self.Y * (self.X + 1)
         kf = self.iters_fwd.double().sum().item()

@@ -30,9 +30,9 @@ def f32(t):
     return torch.as_tensor(np.asarray(t), dtype=torch.float32).to(DEV).contiguous()
 
 
-def masks_for(Y, X, precondition=True):
+def masks_for(Y, X, precondition=True, pressure_solver="auto"):
     g = o.geometry(Y, X)
-    return g, ops.SceneMasks(g.active, g.inflow, g.bc_mask, g.bc_mask, precondition=precondition)
+    return g, ops.SceneMasks(g.active, g.inflow, g.bc_mask, g.bc_mask, precondition=precondition, pressure_solver=pressure_solver)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -54,6 +54,7 @@ def test_karman_step_against_golden(golden_dir, name, kw, precond):
     B, Y, X = z["d"].shape
     g, mk = masks_for(Y, X, precond)
     assert (mk.coarse_inv is not None) == (precond and Y >= 64)     # two-level CG only where the grid allows it
+    assert mk.direct is None                                        # the direct solver is built for 128x64
     cfg = ops.karman_cfg(B, Y, X, g.dx, masks=mk, **kw)
     vy = f32(z["vy"]).requires_grad_(True)
     vx = f32(z["vx"]).requires_grad_(True)
@@ -65,10 +66,14 @@ def test_karman_step_against_golden(golden_dir, name, kw, precond):
     assert int(info["iterations"].min()) > 5 and int(info["iterations"].max()) < 2000
 
 
-@pytest.mark.parametrize("B,precond", [(1, True), (2, True), (2, False)])
-def test_karman_step_full_size_against_oracle(B, precond):
+@pytest.mark.parametrize("B,solver", [(1, "direct"), (2, "direct"), (1, "pcg"), (2, "pcg"), (2, "cg")])
+def test_karman_step_full_size_against_oracle(B, solver):
+    """The three PressureSolver implementations (direct = fast diagonalisation + capacitance correction,
+    two-level preconditioned CG, plain CG) against the exactly solved oracle."""
     Y, X = 128, 64
-    g, mk = masks_for(Y, X, precond)
+    precond = solver != "cg"
+    g, mk = masks_for(Y, X, precond, "direct" if solver == "direct" else "cg")
+    assert (mk.direct is not None) == (solver == "direct")
     d, vy, vx = o.synthetic_state(B, Y, X, 1234)
     re = torch.tensor(o.RE_TRAIN[:B], dtype=torch.float64)
     vy = vy.clone().requires_grad_(True)
@@ -86,7 +91,10 @@ def test_karman_step_full_size_against_oracle(B, precond):
     assert rel(hd, d2) < TOL_FIELD and rel(hpy, py) < TOL_FIELD and rel(hpx, px) < TOL_FIELD
     assert rel(hvy.grad, vy.grad) < TOL_GRAD and rel(hvx.grad, vx.grad) < TOL_GRAD
     its = int(info["iterations"].max())
-    assert (its < 100) if precond else (150 < its < 400)      # the coarse space cuts the iteration count ~4x
+    if solver == "direct":
+        assert its == 0                                       # no iteration at all
+    else:
+        assert (its < 100) if precond else (150 < its < 400)  # the coarse space cuts the iteration count ~4x
 
 
 def test_full_size_properties():

@@ -111,3 +111,25 @@ def test_coarse_inverse_matches_galerkin_projection_of_the_oracle_matrix():
     lib = sol_amd.load()
     assert lib.sol_karman_precond_supported(128, 64) == 1 and lib.sol_karman_precond_supported(64, 32) == 1
     assert lib.sol_karman_precond_supported(16, 8) == 0
+
+
+def test_direct_solver_blob_reproduces_the_exact_pressure_solve():
+    """precond.direct_solver_blob: sine-transform diagonalisation of the rectangle + capacitance
+    correction for the obstacle == the oracle's sparse LU solve of the same matrix."""
+    import scipy.sparse.linalg as spl
+    from sol_amd import precond
+    for (Y, X) in [(128, 64), (32, 16)]:
+        g = o.geometry(Y, X)
+        blob = precond.direct_solver_blob(g.active)
+        hdr = blob[:precond.FD_HEADER].view(np.int32)
+        assert hdr[0] == precond.FD_MAGIC and (hdr[1], hdr[2]) == (Y, X) and hdr[5] <= hdr[6] <= 256
+        M = (-g.pressure_matrix()).tocsc()
+        rng = np.random.default_rng(0)
+        b = rng.standard_normal((Y, X)) * np.asarray(g.active).reshape(Y, X)
+        exact = spl.splu(M).solve(b.ravel()).reshape(Y, X)
+        x = precond.direct_solve_reference(blob, b)
+        assert np.linalg.norm(x - exact) < 5e-6 * np.linalg.norm(exact)      # blob is stored in fp32
+    assert np.array_equal(precond.scene_matrix(o.geometry(32, 16).active), (-o.geometry(32, 16).pressure_matrix()).toarray())
+    # a scene whose modified cells do not fit one 16x16 window is refused (-> CG)
+    act = np.ones((128, 64)); act[10:12, 10:12] = 0; act[100:102, 40:42] = 0
+    assert precond.direct_solver_blob(act) is None
