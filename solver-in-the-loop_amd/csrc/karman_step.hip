@@ -504,34 +504,62 @@ __device__ __forceinline__ FdView fd_view(const float* __restrict__ blob) {
     v.sidx = reinterpret_cast<const int*>(v.KpT + (size_t)v.SP * v.SP);
     return v;
 }
-// out rows 16w+2q, 16w+2q+1 (column n) = sum_k Q[k][16w + ..] * buf[k][n]      (Q symmetric, wave-uniform row slices)
-__device__ __forceinline__ void fd_ytrans(const float* __restrict__ Q, const float* buf, int w, int n, f2 (&acc)[8]) {
+// Sine-transform symmetry: Q[NK-1-k][j] = (-1)^j Q[k][j] and Q[k][NK-1-j] = (-1)^k Q[k][j], so with
+// s_k = v_k + v_{NK-1-k}, d_k = v_k - v_{NK-1-k} (k < NK/2):
+//     out[j]      = sum_k Q[k][j] * (j even ? s_k : d_k)
+//     out[NK-1-j] = sum_k (-1)^k Q[k][j] * (j even ? d_k : s_k)
+// i.e. HALF the multiply-adds and only the [NK/2 x NK/2] corner of Q is read (16 KB of Qy, 4 KB of Qx: the
+// wave-uniform s_load stream stays inside the scalar cache).  A thread produces the 8 outputs j = 8*g8 + r and
+// their 8 mirrors NK-1-j:  lo[q] = (out[8g8+2q], out[8g8+2q+1]),  hi[q] = (out[NK-1-(8g8+2q)], out[NK-1-(8g8+2q+1)]).
+// Input element k of the thread is bp[k * SK].
+template <int NK, int SK>
+__device__ __forceinline__ void fd_trans(const float* __restrict__ Q, const float* bp, int g8, f2 (&lo)[4], f2 (&hi)[4]) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = (f2){0.f, 0.f};
-    fd_cfp Qw = (fd_cfp)(Q + 16 * w);
-    const float* bp = buf + n;
+    for (int q = 0; q < 4; ++q) { lo[q] = (f2){0.f, 0.f}; hi[q] = (f2){0.f, 0.f}; }
+    fd_cfp Qg = (fd_cfp)(Q + 8 * g8);
 #pragma unroll 4
-    for (int k = 0; k < FD_Y; ++k) {
-        const float v = bp[k * FD_LD];
-        const f2 vv = {v, v};
-        fd_cf2p qr = (fd_cf2p)(Qw + (size_t)k * FD_Y);
+    for (int k = 0; k < NK / 2; k += 2) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] += qr[q] * vv;
+        for (int kk = 0; kk < 2; ++kk) {
+            const float va = bp[(k + kk) * SK], vb = bp[(NK - 1 - k - kk) * SK];
+            const float sk = va + vb, dk = va - vb;
+            const f2 sd = {sk, dk};
+            const f2 ds = kk == 0 ? (f2){dk, sk} : (f2){-dk, -sk};      // (-1)^k
+            fd_cf2p qr = (fd_cf2p)(Qg + (size_t)(k + kk) * NK);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { lo[q] += qr[q] * sd; hi[q] += qr[q] * ds; }
+        }
     }
 }
-// out columns 16cb+2q, +1 (row m) = sum_n buf[m][n] * Q[n][16cb + ..]
-__device__ __forceinline__ void fd_xtrans(const float* __restrict__ Q, const float* buf, int m, int cb, f2 (&acc)[8]) {
+
+// Same transform with the wave's coefficient slice Q[k < NK/2][8*g8 .. 8*g8+7] held in VGPRs (element 8k+r in register
+// (8k+r) >> 6, lane (8k+r) & 63; loaded once per kernel by fd_load_slice) and moved to SGPR pairs with v_readlane: the
+// 16 KB corner of Qy does not stay in the scalar cache, and an s_load miss costs more than 8 extra VALU instructions.
+template <int NK>
+__device__ __forceinline__ void fd_load_slice(const float* __restrict__ Q, int g8, float (&sl)[NK / 16]) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = (f2){0.f, 0.f};
-    fd_cfp Qc = (fd_cfp)(Q + 16 * cb);
-    const float* bp = buf + m * FD_LD;
-#pragma unroll 4
-    for (int n = 0; n < FD_X; ++n) {
-        const float v = bp[n];
-        const f2 vv = {v, v};
-        fd_cf2p qr = (fd_cf2p)(Qc + (size_t)n * FD_X);
+    for (int j = 0; j < NK / 16; ++j) sl[j] = Q[(size_t)(8 * j + (lane >> 3)) * NK + 8 * g8 + (lane & 7)];
+}
+template <int NK, int SK>
+__device__ __forceinline__ void fd_trans_rl(const float (&sl)[NK / 16], const float* bp, f2 (&lo)[4], f2 (&hi)[4]) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] += qr[q] * vv;
+    for (int q = 0; q < 4; ++q) { lo[q] = (f2){0.f, 0.f}; hi[q] = (f2){0.f, 0.f}; }
+#pragma unroll
+    for (int k = 0; k < NK / 2; ++k) {
+        const float va = bp[k * SK], vb = bp[(NK - 1 - k) * SK];
+        const float sk = va + vb, dk = va - vb;
+        const f2 sd = {sk, dk};
+        const f2 ds = (k & 1) == 0 ? (f2){dk, sk} : (f2){-dk, -sk};      // (-1)^k
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = 8 * k + 2 * q;
+            const float q0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sl[e >> 6]), e & 63));
+            const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sl[(e + 1) >> 6]), (e + 1) & 63));
+            const f2 qq = {q0, q1};
+            lo[q] += qq * sd;
+            hi[q] += qq * ds;
+        }
     }
 }
 
@@ -544,8 +572,9 @@ __device__ __forceinline__ float fd_prefetch(const float* __restrict__ blob, int
     return s;
 }
 
-// rhs in rf[] (strip layout: rows 16*wave + k, column lane), solution out in xf[].  buf = 2*FD_BUF floats of LDS.
-__device__ __forceinline__ void fd_solve(const float* __restrict__ blob, float* buf, const float (&rf)[16], float (&xf)[16], long long* prof) {
+// rhs in rf[] (strip layout: rows 16*wave + k, column lane); returns the solution as a [128][64] LDS array (inside buf,
+// complete for every thread).  buf = 2*FD_BUF floats of LDS.
+__device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, float* buf, const float (&rf)[16], long long* prof) {
 #define FD_STAMP(i) do { if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[i] = wall_clock64(); } while (0)
     const FdView F = fd_view(blob);
     float* B0 = buf;
@@ -558,28 +587,38 @@ __device__ __forceinline__ void fd_solve(const float* __restrict__ blob, float* 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = tid & 127, cb = __builtin_amdgcn_readfirstlane(tid >> 7);
-    f2 acc[8];
+    f2 lo[4], hi[4];
+    float qys[FD_Y / 16];                // this wave's slice of Qy (L2-warm: fd_prefetch), in flight behind the first barrier
+    fd_load_slice<FD_Y>(F.Qy, w, qys);
 
     // ---- forward transform: T2 = (Qy b Qx) / lam ---------------------------------------
 #pragma unroll
     for (int k = 0; k < 16; ++k) B0[(16 * w + k) * FD_LD + lane] = rf[k];
     __syncthreads();
-    fd_ytrans(F.Qy, B0, w, lane, acc);
+    fd_trans_rl<FD_Y, FD_LD>(qys, B0 + lane, lo, hi);          // rows 8w+r and 127-(8w+r), column lane
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { B0[(16 * w + 2 * q) * FD_LD + lane] = acc[q].x; B0[(16 * w + 2 * q + 1) * FD_LD + lane] = acc[q].y; }
+    for (int q = 0; q < 4; ++q) {
+        const int r0 = 8 * w + 2 * q;
+        B0[r0 * FD_LD + lane] = lo[q].x; B0[(r0 + 1) * FD_LD + lane] = lo[q].y;
+        B0[(FD_Y - 1 - r0) * FD_LD + lane] = hi[q].x; B0[(FD_Y - 2 - r0) * FD_LD + lane] = hi[q].y;
+    }
     __syncthreads();
-    fd_xtrans(F.Qx, B0, m, cb, acc);
+    fd_trans<FD_X, 1>(F.Qx, B0 + m * FD_LD, cb, lo, hi);       // row m, columns 8cb+r and 63-(8cb+r)
+    // this thread's 16 spectral coefficients: index 2q+e -> column 8cb+2q+e, 8+2q+e -> column 63-(8cb+2q+e)
     float t2[16], il[16];
+    int col[16];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int c = 16 * cb + 2 * q;
-        il[2 * q] = F.ilT[c * FD_Y + m];
-        il[2 * q + 1] = F.ilT[(c + 1) * FD_Y + m];
-        t2[2 * q] = acc[q].x * il[2 * q];
-        t2[2 * q + 1] = acc[q].y * il[2 * q + 1];
-        B1[m * FD_LD + c] = t2[2 * q];
-        B1[m * FD_LD + c + 1] = t2[2 * q + 1];
+    for (int q = 0; q < 4; ++q) {
+        col[2 * q] = 8 * cb + 2 * q; col[2 * q + 1] = col[2 * q] + 1;
+        col[8 + 2 * q] = FD_X - 1 - col[2 * q]; col[8 + 2 * q + 1] = FD_X - 2 - col[2 * q];
+        t2[2 * q] = lo[q].x; t2[2 * q + 1] = lo[q].y; t2[8 + 2 * q] = hi[q].x; t2[8 + 2 * q + 1] = hi[q].y;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        il[e] = F.ilT[col[e] * FD_Y + m];
+        t2[e] *= il[e];
+        B1[m * FD_LD + col[e]] = t2[e];
     }
     __syncthreads();                     // B1 = T2, B0 free
     FD_STAMP(9);
@@ -653,37 +692,54 @@ __device__ __forceinline__ void fd_solve(const float* __restrict__ blob, float* 
     __syncthreads();
     FD_STAMP(13);
     {
+        // T2[m][c] += il * sum_i' t2w[m][i'] Qx[wx0+i'][c] for this thread's 16 columns (8 contiguous + their 8 mirrors)
+        f2 al[4], ah[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = (f2){0.f, 0.f};
-        fd_cfp Qc = (fd_cfp)(F.Qx + (size_t)F.wx0 * FD_X + 16 * cb);
+        for (int q = 0; q < 4; ++q) { al[q] = (f2){0.f, 0.f}; ah[q] = (f2){0.f, 0.f}; }
+        fd_cfp Ql = (fd_cfp)(F.Qx + (size_t)F.wx0 * FD_X + 8 * cb);
+        fd_cfp Qh = (fd_cfp)(F.Qx + (size_t)F.wx0 * FD_X + (FD_X - 8 - 8 * cb));
         const float* up = U + m * FD_ULD;
 #pragma unroll 4
         for (int iw = 0; iw < FD_WIN; ++iw) {
             const float v = up[iw];
             const f2 vv = {v, v};
-            fd_cf2p qr = (fd_cf2p)(Qc + (size_t)iw * FD_X);
+            fd_cfp ql = Ql + (size_t)iw * FD_X;
+            fd_cfp qh = Qh + (size_t)iw * FD_X;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] += qr[q] * vv;
+            for (int q = 0; q < 4; ++q) {
+                al[q] += (f2){ql[2 * q], ql[2 * q + 1]} * vv;
+                ah[q] += (f2){qh[7 - 2 * q], qh[6 - 2 * q]} * vv;       // columns 63-(8cb+2q), 62-(8cb+2q)
+            }
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int c = 16 * cb + 2 * q;
-            B1[m * FD_LD + c] = t2[2 * q] + il[2 * q] * acc[q].x;
-            B1[m * FD_LD + c + 1] = t2[2 * q + 1] + il[2 * q + 1] * acc[q].y;
+        for (int q = 0; q < 4; ++q) {
+            t2[2 * q] += il[2 * q] * al[q].x; t2[2 * q + 1] += il[2 * q + 1] * al[q].y;
+            t2[8 + 2 * q] += il[8 + 2 * q] * ah[q].x; t2[8 + 2 * q + 1] += il[8 + 2 * q + 1] * ah[q].y;
         }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) B1[m * FD_LD + col[e]] = t2[e];
     }
     __syncthreads();
     FD_STAMP(14);
-    // ---- inverse transform: x = Qy (T2 Qx) ------------------------------------------------
-    fd_xtrans(F.Qx, B1, m, cb, acc);
+    // ---- inverse transform: x = Qy (T2 Qx), written to B1 as [128][64] for the caller ---------------
+    fd_trans<FD_X, 1>(F.Qx, B1 + m * FD_LD, cb, lo, hi);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { B0[m * FD_LD + 16 * cb + 2 * q] = acc[q].x; B0[m * FD_LD + 16 * cb + 2 * q + 1] = acc[q].y; }
-    __syncthreads();
+    for (int q = 0; q < 4; ++q) {
+        const int c0 = 8 * cb + 2 * q;
+        B0[m * FD_LD + c0] = lo[q].x; B0[m * FD_LD + c0 + 1] = lo[q].y;
+        B0[m * FD_LD + FD_X - 1 - c0] = hi[q].x; B0[m * FD_LD + FD_X - 2 - c0] = hi[q].y;
+    }
+    __syncthreads();                     // B0 = T3; every read of B1 (T2) is done
     FD_STAMP(15);
-    fd_ytrans(F.Qy, B0, w, lane, acc);
+    fd_trans_rl<FD_Y, FD_LD>(qys, B0 + lane, lo, hi);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { xf[2 * q] = acc[q].x; xf[2 * q + 1] = acc[q].y; }
-    __syncthreads();                     // the caller reuses the buffers
+    for (int q = 0; q < 4; ++q) {
+        const int r0 = 8 * w + 2 * q;
+        B1[r0 * FD_X + lane] = lo[q].x; B1[(r0 + 1) * FD_X + lane] = lo[q].y;
+        B1[(FD_Y - 1 - r0) * FD_X + lane] = hi[q].x; B1[(FD_Y - 2 - r0) * FD_X + lane] = hi[q].y;
+    }
+    __syncthreads();                     // solution complete in LDS
+    return B1;
 }
 
 // per-cell matrix coefficients of the owned strip
@@ -835,10 +891,11 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
     }
     int it = 0;
     bool solved = false;
+    float* Pfd = nullptr;           // direct solver: the solution arrives as an LDS array
     SOL_STAMP(5);
     if constexpr (CPT == 16) {     // direct solver / two-level preconditioner: 16-cell strips only
         if (a.fd) {                // host guarantees Y == 128, X == 64
-            fd_solve(a.fd, L.Bvy, r, x, a.prof);
+            Pfd = fd_solve(a.fd, L.Bvy, r, a.prof);
             solved = true;
         } else
         if (a.cinv) {
@@ -854,11 +911,14 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
 
     // ---- phase 6: v -= mask * grad p ;  outputs --------------------------------------
     float* P = L.Bvy;   // region B is free after the advection
-    if (o.owner) {
+    if (Pfd) P = Pfd;
+    else {
+        if (o.owner) {
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) P[(o.j0 + k) * X + o.i] = x[k];
+            for (int k = 0; k < CPT; ++k) P[(o.j0 + k) * X + o.i] = x[k];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     {
         float* gvy = a.vy_out + (size_t)b * nVy;
         float* gvx = a.vx_out + (size_t)b * nVx;
@@ -963,10 +1023,11 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
     }
     int it = 0;
     bool solved = false;
+    float* Pfd = nullptr;
     SOL_STAMP(2);
     if constexpr (CPT == 16) {     // direct solver / two-level preconditioner: 16-cell strips only
         if (a.fd) {
-            fd_solve(a.fd, L.Bvy, r, z, a.prof);
+            Pfd = fd_solve(a.fd, L.Bvy, r, a.prof);
             solved = true;
         } else
         if (a.cinv) {
@@ -982,11 +1043,14 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
 
     // ---- 3: g_adv = m * (g + D^T z), kept in registers ---------------------------------
     float* Z = L.Bvy;
-    if (o.owner) {
+    if (Pfd) Z = Pfd;
+    else {
+        if (o.owner) {
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) Z[(o.j0 + k) * X + o.i] = z[k];
+            for (int k = 0; k < CPT; ++k) Z[(o.j0 + k) * X + o.i] = z[k];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     float gy[MAXT], gx[MAXT];
 #pragma unroll
     for (int n = 0; n < MAXT; ++n) {
