@@ -198,13 +198,21 @@ def main():
             del df, vyf, vxf
         except Exception as e:
             roof_solver["full_chip_256_sims"] = {"error": str(e)}
-        roof_conv = {"kernel": "k_conv5x5_r3<2>", "bound": "mfma", "achieved": flop_conv / t_conv / 1e12, "peak": 157.3,
+        sb = not os.environ.get("SOL_CONV_NO_SB")
+        roof_conv = {"kernel": "k_conv5x5_sb<2,6>" if sb else "k_conv5x5_r3<2>", "bound": "mfma",
+                     "achieved": flop_conv / t_conv / 1e12, "peak": 157.3,
                      "unit": "TFLOP/s", "frac": flop_conv / t_conv / 157.3e12,
                      "traffic": (2 * 9107.9 + 6144.0) * 1024 if c3 else None,
                      "launch_us": t_conv * 1e6, "flop_per_launch": flop_conv,
-                     "measured_fp32_mfma_ceiling_random_operands_TFLOPs": 92.5,
-                     "note": "fp32 MFMA (v_mfma_f32_16x16x4_f32) reaches 153 TF only on constant operands; with random operands "
-                             "the same micro-benchmark gives 92 TF (profiles/r01_ubench_notes.txt)"}
+                     "note": "achieved = ALGORITHMIC fp32 conv FLOPs / launch time against the dense fp32 MFMA peak (dtype f32). "
+                             "fp32 MFMA itself sustains only 92 TF on random operands (profiles/r01_ubench_notes.txt); the kernel "
+                             "therefore runs the fp32-equivalent split-bf16 form (6 bf16 MFMA products per fp32 product, error "
+                             "4e-7 vs 5e-7 of the fp32 MFMA kernel)." if sb else
+                             "fp32 MFMA (v_mfma_f32_16x16x4_f32): 153 TF on constant operands, 92 TF on random operands"}
+        if sb:
+            roof_conv["executed_bf16_mfma_TFLOPs"] = 6.0 * flop_conv / t_conv / 1e12
+            roof_conv["frac_of_bf16_dense_peak_2500"] = 6.0 * flop_conv / t_conv / 2.5e15
+            roof_conv["measured_bf16_mfma_ceiling_random_operands_TFLOPs"] = 1584.0
         # dominant kernel by time inside one training step: conv fwd+bwd (36 launches/sim-step of ~t_conv)
         t_convs = 36 * ms * t_conv
         t_solver = 2 * ms * t_step

@@ -846,7 +846,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
     SOL_STAMP(3);
     if (a.d_out && !(a.dbg & 2)) {
         const float* gd = a.d_in + (size_t)b * N;
-        #pragma unroll 4
+        #pragma unroll 8
         for (int k = tid; k < N; k += nthr) {
             const int j = k >> lx, i = k & (X - 1);
             const float uy = 0.5f * (L.Bvy[k] + L.Bvy[k + X]);
