@@ -486,7 +486,7 @@ __device__ __forceinline__ int pcg_solve(const Own& o, int Y, int X, const unsig
 typedef const float __attribute__((address_space(4)))* fd_cfp;
 typedef const f2 __attribute__((address_space(4)))* fd_cf2p;
 struct FdView {
-    const float *Qy, *Qx, *ilT, *KpT;
+    const float *Qy, *Qx, *ilT, *KpT, *QxW;
     const int* sidx;
     int wy0, wx0, SP;
 };
@@ -502,6 +502,7 @@ __device__ __forceinline__ FdView fd_view(const float* __restrict__ blob) {
     v.ilT = v.Qx + FD_X * FD_X;
     v.KpT = v.ilT + FD_X * FD_Y;
     v.sidx = reinterpret_cast<const int*>(v.KpT + (size_t)v.SP * v.SP);
+    v.QxW = reinterpret_cast<const float*>(v.sidx + v.SP);
     return v;
 }
 // Sine-transform symmetry: Q[NK-1-k][j] = (-1)^j Q[k][j] and Q[k][NK-1-j] = (-1)^k Q[k][j], so with
@@ -574,7 +575,7 @@ __device__ __forceinline__ float fd_prefetch(const float* __restrict__ blob, int
 
 // rhs in rf[] (strip layout: rows 16*wave + k, column lane); returns the solution as a [128][64] LDS array (inside buf,
 // complete for every thread).  buf = 2*FD_BUF floats of LDS.
-__device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, float* buf, const float (&rf)[16], long long* prof) {
+__device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const float (&qys)[FD_Y / 16], float* buf, const float (&rf)[16], long long* prof) {
 #define FD_STAMP(i) do { if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[i] = wall_clock64(); } while (0)
     const FdView F = fd_view(blob);
     float* B0 = buf;
@@ -588,8 +589,6 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, float
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = tid & 127, cb = __builtin_amdgcn_readfirstlane(tid >> 7);
     f2 lo[4], hi[4];
-    float qys[FD_Y / 16];                // this wave's slice of Qy (L2-warm: fd_prefetch), in flight behind the first barrier
-    fd_load_slice<FD_Y>(F.Qy, w, qys);
 
     // ---- forward transform: T2 = (Qy b Qx) / lam ---------------------------------------
 #pragma unroll
@@ -626,13 +625,13 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, float
     // ---- window values of G b:  u = T2 Qx[:, win] ;  x0w = Qy[win, :] u ----------------------
     {
         f2 u0 = {0.f, 0.f}, u1 = {0.f, 0.f};
-        fd_cfp Qc = (fd_cfp)(F.Qx + F.wx0 + 4 * cb);
+        fd_cfp Qc = (fd_cfp)(F.QxW + 4 * cb);           // QxW[c][i'] = Qx[c][wx0 + i']: 64 B per c
         const float* bp = B1 + m * FD_LD;
 #pragma unroll 8
         for (int c = 0; c < FD_X; ++c) {
             const float v = bp[c];
             const f2 vv = {v, v};
-            fd_cfp qr = Qc + (size_t)c * FD_X;
+            fd_cfp qr = Qc + (size_t)c * FD_WIN;
             u0 += (f2){qr[0], qr[1]} * vv;
             u1 += (f2){qr[2], qr[3]} * vv;
         }
@@ -763,7 +762,9 @@ __device__ __forceinline__ void cell_coeffs(const Own& o, const unsigned char* a
 // ------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------
-template <int CPT>
+// SOLVER: 0 = plain CG, 1 = two-level preconditioned CG, 2 = direct (fast diagonalisation); separate instantiations keep
+// each variant's register allocation independent (1 and 2 exist for the 16-cell strips only)
+template <int CPT, int SOLVER>
 __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs a) {
     extern __shared__ __align__(16) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -774,7 +775,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
 
     SOL_STAMP(0);
     float fdp = 0.f;
-    if constexpr (CPT == 16) { if (a.fd) fdp = fd_prefetch(a.fd, a.fd_n); }
+    if constexpr (SOLVER == 2) fdp = fd_prefetch(a.fd, a.fd_n);
     // ---- phase 1: load inputs (all global loads in flight before the first LDS store) ---
     {
         constexpr int MAXL = CPT + 1;          // (Y+1)*X / (Y*X/CPT) <= CPT + 1 for Y >= CPT
@@ -877,6 +878,10 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
     SOL_STAMP(4);
 
     // ---- phase 4/5: divergence + CG pressure solve ----------------------------------
+    float qys[FD_Y / 16];           // direct solver: this wave's slice of Qy (L2-warm: fd_prefetch), in flight behind the setup
+#pragma unroll
+    for (int j = 0; j < FD_Y / 16; ++j) qys[j] = 0.f;
+    if constexpr (SOLVER == 2) fd_load_slice<FD_Y>(a.fd + 16, __builtin_amdgcn_readfirstlane(tid >> 6), qys);
     const Own o = ownership<CPT>(Y, X);
     float dg[CPT], ac[CPT], r[CPT], x[CPT];
     cell_coeffs<CPT>(o, L.act, Y, X, dg, ac);
@@ -890,28 +895,23 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
         }
     }
     int it = 0;
-    bool solved = false;
     float* Pfd = nullptr;           // direct solver: the solution arrives as an LDS array
     SOL_STAMP(5);
-    if constexpr (CPT == 16) {     // direct solver / two-level preconditioner: 16-cell strips only
-        if (a.fd) {                // host guarantees Y == 128, X == 64
-            Pfd = fd_solve(a.fd, L.Bvy, r, a.prof);
-            solved = true;
-        } else
-        if (a.cinv) {
-            it = X == 64 ? pcg_solve<CPT, true, 32>(o, Y, X, L.act, dg, ac, r, x, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter)
-                         : pcg_solve<CPT, false, 8>(o, Y, X, L.act, dg, ac, r, x, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter);
-            solved = true;
-        }
+    if constexpr (SOLVER == 2) {            // host guarantees Y == 128, X == 64
+        Pfd = fd_solve(a.fd, qys, L.Bvy, r, a.prof);
+    } else if constexpr (SOLVER == 1) {
+        it = X == 64 ? pcg_solve<CPT, true, 32>(o, Y, X, L.act, dg, ac, r, x, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter)
+                     : pcg_solve<CPT, false, 8>(o, Y, X, L.act, dg, ac, r, x, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter);
+    } else {
+        it = X == 64 ? cg_solve<CPT, true>(o, X, dg, ac, r, x, L.E, L.red, a.rtol2, a.atol2, a.max_iter)
+                     : cg_solve<CPT, false>(o, X, dg, ac, r, x, L.E, L.red, a.rtol2, a.atol2, a.max_iter);
     }
-    if (!solved) it = X == 64 ? cg_solve<CPT, true>(o, X, dg, ac, r, x, L.E, L.red, a.rtol2, a.atol2, a.max_iter)
-                      : cg_solve<CPT, false>(o, X, dg, ac, r, x, L.E, L.red, a.rtol2, a.atol2, a.max_iter);
     if (a.iters && tid == 0) a.iters[b] = it;
     SOL_STAMP(6);
 
     // ---- phase 6: v -= mask * grad p ;  outputs --------------------------------------
     float* P = L.Bvy;   // region B is free after the advection
-    if (Pfd) P = Pfd;
+    if constexpr (SOLVER == 2) P = Pfd;
     else {
         if (o.owner) {
 #pragma unroll
@@ -961,7 +961,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
 // ------------------------------------------------------------------------------------
 // backward (adjoint w.r.t. the input velocity)
 // ------------------------------------------------------------------------------------
-template <int CPT>
+template <int CPT, int SOLVER>
 __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs a) {
     constexpr int MAXT = CPT + 1;   // face targets per thread: (Y+1)*X / (Y*X/CPT) <= CPT+1 for Y >= CPT
     extern __shared__ __align__(16) float smem[];
@@ -974,7 +974,7 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
 
     SOL_STAMP(0);
     float fdp = 0.f;
-    if constexpr (CPT == 16) { if (a.fd) fdp = fd_prefetch(a.fd, a.fd_n); }
+    if constexpr (SOLVER == 2) fdp = fd_prefetch(a.fd, a.fd_n);
     // ---- 1: load incoming gradient (+ feature gradient): all global loads in flight first --------
     {
         const float* gy = a.g_vy_out + (size_t)b * nVy;
@@ -1005,6 +1005,10 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
     SOL_STAMP(1);
 
     // ---- 2: projection adjoint:  M z = G^T (m * g) -----------------------------------
+    float qys[FD_Y / 16];
+#pragma unroll
+    for (int j = 0; j < FD_Y / 16; ++j) qys[j] = 0.f;
+    if constexpr (SOLVER == 2) fd_load_slice<FD_Y>(a.fd + 16, __builtin_amdgcn_readfirstlane(tid >> 6), qys);
     const Own o = ownership<CPT>(Y, X);
     float dg[CPT], ac[CPT], r[CPT], z[CPT];
     cell_coeffs<CPT>(o, L.act, Y, X, dg, ac);
@@ -1022,28 +1026,23 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
         }
     }
     int it = 0;
-    bool solved = false;
     float* Pfd = nullptr;
     SOL_STAMP(2);
-    if constexpr (CPT == 16) {     // direct solver / two-level preconditioner: 16-cell strips only
-        if (a.fd) {
-            Pfd = fd_solve(a.fd, L.Bvy, r, a.prof);
-            solved = true;
-        } else
-        if (a.cinv) {
-            it = X == 64 ? pcg_solve<CPT, true, 32>(o, Y, X, L.act, dg, ac, r, z, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter)
-                         : pcg_solve<CPT, false, 8>(o, Y, X, L.act, dg, ac, r, z, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter);
-            solved = true;
-        }
+    if constexpr (SOLVER == 2) {            // host guarantees Y == 128, X == 64
+        Pfd = fd_solve(a.fd, qys, L.Bvy, r, a.prof);
+    } else if constexpr (SOLVER == 1) {
+        it = X == 64 ? pcg_solve<CPT, true, 32>(o, Y, X, L.act, dg, ac, r, z, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter)
+                     : pcg_solve<CPT, false, 8>(o, Y, X, L.act, dg, ac, r, z, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter);
+    } else {
+        it = X == 64 ? cg_solve<CPT, true>(o, X, dg, ac, r, z, L.E, L.red, a.rtol2, a.atol2, a.max_iter)
+                     : cg_solve<CPT, false>(o, X, dg, ac, r, z, L.E, L.red, a.rtol2, a.atol2, a.max_iter);
     }
-    if (!solved) it = X == 64 ? cg_solve<CPT, true>(o, X, dg, ac, r, z, L.E, L.red, a.rtol2, a.atol2, a.max_iter)
-                      : cg_solve<CPT, false>(o, X, dg, ac, r, z, L.E, L.red, a.rtol2, a.atol2, a.max_iter);
     if (a.iters && tid == 0) a.iters[b] = it;
     SOL_STAMP(3);
 
     // ---- 3: g_adv = m * (g + D^T z), kept in registers ---------------------------------
     float* Z = L.Bvy;
-    if (Pfd) Z = Pfd;
+    if constexpr (SOLVER == 2) Z = Pfd;
     else {
         if (o.owner) {
 #pragma unroll
@@ -1230,7 +1229,7 @@ int check_cfg(const sol_karman_cfg* c) {
     SOL_REQUIRE(c->dx > 0.f && c->cg_max_iter >= 0, "dx must be > 0 and cg_max_iter >= 0");
     if (c->direct) {
         SOL_REQUIRE(c->Y == FD_Y && c->X == FD_X && cpt == 16, "the direct pressure solver is built for 128x64 grids only (got %dx%d)", c->Y, c->X);
-        SOL_REQUIRE(c->direct_n >= 16 + FD_Y * FD_Y + FD_X * FD_X + FD_X * FD_Y + 64 * 64 + 64,
+        SOL_REQUIRE(c->direct_n >= 16 + FD_Y * FD_Y + FD_X * FD_X + FD_X * FD_Y + 64 * 64 + 64 + FD_X * FD_WIN,
                     "direct_n = %d is too small for a direct-solver blob", c->direct_n);
     }
     if (c->coarse_inv) {
@@ -1261,8 +1260,10 @@ void fill_common(StepArgs& a, const sol_karman_cfg* c) {
 // one-time: allow the full 160 KiB of dynamic LDS (not a stream operation -> done outside graph capture)
 int sol_init_karman_kernels() {
     static int rc = [] {
-        const void* ks[] = {reinterpret_cast<const void*>(k_karman_fwd<8>), reinterpret_cast<const void*>(k_karman_fwd<16>),
-                            reinterpret_cast<const void*>(k_karman_bwd<8>), reinterpret_cast<const void*>(k_karman_bwd<16>)};
+        const void* ks[] = {reinterpret_cast<const void*>(k_karman_fwd<8, 0>), reinterpret_cast<const void*>(k_karman_bwd<8, 0>),
+                            reinterpret_cast<const void*>(k_karman_fwd<16, 0>), reinterpret_cast<const void*>(k_karman_bwd<16, 0>),
+                            reinterpret_cast<const void*>(k_karman_fwd<16, 1>), reinterpret_cast<const void*>(k_karman_bwd<16, 1>),
+                            reinterpret_cast<const void*>(k_karman_fwd<16, 2>), reinterpret_cast<const void*>(k_karman_bwd<16, 2>)};
         for (const void* k : ks)
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return sol_set_error(SOL_ERR_HIP, "hipFuncSetAttribute(karman kernels) failed");
@@ -1330,7 +1331,10 @@ extern "C" int sol_karman_step_fwd(const sol_karman_cfg* cfg, void* stream,
     if (feat_scale) { a.fs0 = feat_scale[0]; a.fs1 = feat_scale[1]; a.fs2 = feat_scale[2]; }
     a.iters = iters;
     const int cpt = pick_cpt(cfg);
-    return cpt == 16 ? launch_step(k_karman_fwd<16>, 16, cfg, stream, a) : launch_step(k_karman_fwd<8>, 8, cfg, stream, a);
+    if (cpt != 16) return launch_step(k_karman_fwd<8, 0>, 8, cfg, stream, a);
+    if (a.fd) return launch_step(k_karman_fwd<16, 2>, 16, cfg, stream, a);
+    if (a.cinv) return launch_step(k_karman_fwd<16, 1>, 16, cfg, stream, a);
+    return launch_step(k_karman_fwd<16, 0>, 16, cfg, stream, a);
 }
 
 extern "C" int sol_karman_step_bwd(const sol_karman_cfg* cfg, void* stream,
@@ -1352,5 +1356,8 @@ extern "C" int sol_karman_step_bwd(const sol_karman_cfg* cfg, void* stream,
     if (feat_scale) { a.fs0 = feat_scale[0]; a.fs1 = feat_scale[1]; a.fs2 = feat_scale[2]; }
     a.g_vy_in = g_vy_in; a.g_vx_in = g_vx_in; a.iters = iters;
     const int cpt = pick_cpt(cfg);
-    return cpt == 16 ? launch_step(k_karman_bwd<16>, 16, cfg, stream, a) : launch_step(k_karman_bwd<8>, 8, cfg, stream, a);
+    if (cpt != 16) return launch_step(k_karman_bwd<8, 0>, 8, cfg, stream, a);
+    if (a.fd) return launch_step(k_karman_bwd<16, 2>, 16, cfg, stream, a);
+    if (a.cinv) return launch_step(k_karman_bwd<16, 1>, 16, cfg, stream, a);
+    return launch_step(k_karman_bwd<16, 0>, 16, cfg, stream, a);
 }

@@ -53,7 +53,7 @@ def coarse_inverse(active, block=8):
 #     x = G (b - U_S E_SS x_S),   x_S = (I + G_SS E_SS)^-1 (G b)_S,   G = M_r^-1
 # i.e. one forward transform, a window-sized dense correction, one inverse transform: NO iteration,
 # same solution as the converged CG up to fp32 round-off (csrc/karman_step.hip: fd_solve).
-FD_MAGIC = 0x46443031          # "FD01"
+FD_MAGIC = 0x46443032          # "FD02"
 FD_HEADER = 16                 # int32 words
 FD_WIN = 16                    # window edge (cells)
 
@@ -105,7 +105,8 @@ def direct_solver_blob(active):
 
     layout (32-bit words): header[16] = {magic, Y, X, wy0, wx0, nS, SP, ...};  Qy[Y*Y];  Qx[X*X];
     invlamT[X*Y] (= 1/lam[m][c] stored [c][m]);  KpT[SP*SP] (K' = E_SS (I + G_SS E_SS)^-1, stored
-    transposed, zero padded);  sidx[SP] int32 (window-local index j'*16 + i', -1 = padding)."""
+    transposed, zero padded);  sidx[SP] int32 (window-local index j'*16 + i', -1 = padding);
+    QxW[X*16] (= Qx[c][wx0 + i'], the window columns of Qx as one compact 4 KB slab)."""
     act = (np.asarray(active, dtype=np.float64) != 0).astype(np.float64)
     Y, X = act.shape
     ent = _perturbation(act)
@@ -140,7 +141,8 @@ def direct_solver_blob(active):
     header = np.zeros(FD_HEADER, dtype=np.int32)
     header[:7] = [FD_MAGIC, Y, X, wy0, wx0, nS, SP]
     parts = [header.view(np.float32), Qy.astype(np.float32).ravel(), Qx.astype(np.float32).ravel(),
-             (1.0 / lam).T.astype(np.float32).ravel(), KpT.astype(np.float32).ravel(), sidx.view(np.float32)]
+             (1.0 / lam).T.astype(np.float32).ravel(), KpT.astype(np.float32).ravel(), sidx.view(np.float32),
+             np.ascontiguousarray(Qx[:, wx0:wx0 + FD_WIN]).astype(np.float32).ravel()]
     return np.concatenate(parts)
 
 
