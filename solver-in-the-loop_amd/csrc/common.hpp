@@ -10,6 +10,8 @@
 int sol_set_error(int code, const char* fmt, ...);
 int sol_init_karman_kernels();
 int sol_init_conv_kernels();
+int sol_density_chain(const sol_karman_cfg* c, void* stream, int ms, const float* d0, const float* svy, const float* svx,
+                      long st_vy, long st_vx, const float* inflow, float* d_steps, long st_d, float* d_final);
 size_t sol_bww_batched_ws_floats(int nseg, int B, int H, int cin, int cout);
 int sol_bww_batched(void* stream, const float* x, const float* dz, float* partial, int nseg, int nseg_layout, int overwrite,
                     long x_seg, long dz_seg, int B, int H, int W, int cin, int cout);

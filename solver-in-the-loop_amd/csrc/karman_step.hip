@@ -1198,6 +1198,69 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
     if (fdp == 1.2345678e-30f && a.iters) a.iters[b] = -2;      // never true: keeps the prefetch loads alive
 }
 
+// ------------------------------------------------------------------------------------
+// Passive tracer chain (training path)
+// ------------------------------------------------------------------------------------
+// The density never feeds the velocity (buoyancy_factor = 0, karman_train.py:363): its advection only needs the
+// post-diffusion velocities that the forward unroll keeps anyway (saved_vy / saved_vx).  In the training path the
+// msteps density advections therefore leave the critical path: ONE launch, one workgroup per simulation, density
+// ping-pong in LDS, on a side stream behind the forward unroll (the fused step kernels are launched with d_out =
+// NULL).  Same arithmetic as phase 3 of k_karman_fwd.
+struct DensArgs {
+    int B, Y, X, ms, inflow_before;
+    float dtdx, dt;
+    const float *d0, *svy, *svx, *inflow;
+    long st_vy, st_vx, st_d;        // strides between consecutive steps (floats)
+    float* d_steps;                 // [ms][B][N] or NULL: every intermediate density
+    float* d_final;                 // [B][N] or NULL
+};
+
+__global__ void __launch_bounds__(1024) k_density_chain(DensArgs a) {
+    extern __shared__ __align__(16) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int Y = a.Y, X = a.X, N = Y * X, XP = X + 1;
+    const int lx = __ffs(X) - 1;
+    float* D0 = smem;
+    float* D1 = smem + N;
+    for (int k = tid; k < N; k += nthr) D0[k] = a.d0[(size_t)b * N + k];
+    __syncthreads();
+    for (int s = 0; s < a.ms; ++s) {
+        const float* sy = a.svy + (size_t)s * a.st_vy + (size_t)b * (Y + 1) * X;
+        const float* sx = a.svx + (size_t)s * a.st_vx + (size_t)b * Y * XP;
+        const float* src = (s & 1) ? D1 : D0;
+        float* dst = (s & 1) ? D0 : D1;
+#pragma unroll 4
+        for (int k = tid; k < N; k += nthr) {
+            const int j = k >> lx, i = k & (X - 1);
+            const float uy = 0.5f * (sy[k] + sy[k + X]);
+            const float ux = 0.5f * (sx[j * XP + i] + sx[j * XP + i + 1]);
+            const float oy = -uy * a.dtdx, ox = -ux * a.dtdx;
+            const float fy = floorf(oy), fx = floorf(ox);
+            const float wy = oy - fy, wx = ox - fx;
+            const int j0 = j + (int)fy, i0 = i + (int)fx;
+            float f[2][2];
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+                for (int di = 0; di < 2; ++di) {
+                    const int jj = j0 + dj, ii = i0 + di;
+                    float v = 0.f;   // extrapolation 'constant': one ring of zero ghost cells
+                    if (jj >= 0 && jj < Y && ii >= 0 && ii < X) {
+                        v = src[jj * X + ii];
+                        if (a.inflow_before) v += a.inflow[jj * X + ii];
+                    }
+                    f[dj][di] = v;
+                }
+            float v = (1.f - wy) * ((1.f - wx) * f[0][0] + wx * f[0][1]) + wy * ((1.f - wx) * f[1][0] + wx * f[1][1]);
+            if (!a.inflow_before) v += a.inflow[k] * a.dt;
+            dst[k] = v;
+            if (a.d_steps) a.d_steps[(size_t)s * a.st_d + (size_t)b * N + k] = v;
+            if (a.d_final && s == a.ms - 1) a.d_final[(size_t)b * N + k] = v;
+        }
+        __syncthreads();
+    }
+}
+
 // strip height: 16 cells per thread when the grid allows it (fewer waves -> less per-wave
 // reduction overhead in the issue-bound CG loop), 8 otherwise.  SOL_CPT=8|16 overrides.
 int pick_cpt(const sol_karman_cfg* c) {
@@ -1306,6 +1369,27 @@ int launch_step(K kernel, int cpt, const sol_karman_cfg* c, void* stream, const 
 }
 
 }  // namespace
+
+// internal (train.hip): the msteps density advections of the unrolled loop as one launch
+int sol_density_chain(const sol_karman_cfg* c, void* stream, int ms, const float* d0, const float* svy, const float* svx,
+                      long st_vy, long st_vx, const float* inflow, float* d_steps, long st_d, float* d_final) {
+    if (int e = check_cfg(c)) return e;
+    SOL_REQUIRE(d0 && svy && svx && inflow && ms >= 1, "sol_density_chain: NULL pointer argument");
+    const size_t lds = 2 * (size_t)c->Y * c->X * sizeof(float);
+    SOL_REQUIRE(lds <= 160 * 1024, "sol_density_chain: grid does not fit the LDS");
+    static int rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k_density_chain), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                        ? SOL_OK : sol_set_error(SOL_ERR_HIP, "hipFuncSetAttribute(k_density_chain) failed");
+    if (rc) return rc;
+    DensArgs a{};
+    a.B = c->B; a.Y = c->Y; a.X = c->X; a.ms = ms; a.inflow_before = c->inflow_before;
+    a.dtdx = c->dt / c->dx; a.dt = c->dt;
+    a.d0 = d0; a.svy = svy; a.svx = svx; a.inflow = inflow; a.st_vy = st_vy; a.st_vx = st_vx; a.st_d = st_d;
+    a.d_steps = d_steps; a.d_final = d_final;
+    const int threads = c->Y * c->X >= 1024 ? 1024 : (int)align_up((size_t)c->Y * c->X, 64);
+    hipLaunchKernelGGL(k_density_chain, dim3(c->B), dim3(threads), lds, (hipStream_t)stream, a);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
 
 extern "C" int sol_karman_precond_supported(int32_t Y, int32_t X) { return precond_ok(Y, X) ? 1 : 0; }
 extern "C" int sol_karman_direct_supported(int32_t Y, int32_t X) { return (Y == FD_Y && X == FD_X) ? 1 : 0; }

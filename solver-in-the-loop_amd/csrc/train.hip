@@ -321,6 +321,7 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
     for (int l = 0; l < NL; ++l) { wn.wf[l] = shared.wf[l]; wn.wb[l] = shared.wb[l]; wn.bias[l] = shared.bias[l]; }
 
     // ---------------- forward unroll ----------------
+    const bool dens_inline = getenv("SOL_DENSITY_INLINE") != nullptr;
     for (int i = 0; i < ms; ++i) {
         const float* din = i == 0 ? d0 : w.d + (size_t)(i - 1) * w.st_d;
         const float* vyin = i == 0 ? vy0 : w.vy + (size_t)(i - 1) * w.st_vy;
@@ -329,8 +330,9 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         float* vycur = w.vy + (size_t)i * w.st_vy;
         float* vxcur = w.vx + (size_t)i * w.st_vx;
         float* feat = w.feat + (size_t)i * w.cells * 4;
+        // the passive density is advected off the critical path (sol_density_chain below): d_out = NULL here
         if (int e = sol_karman_step_fwd(kc, stream, din, vyin, vxin, re, io.active, io.inflow, bcv, bcm, io.bc_stride,
-                                        dcur, vycur, vxcur, w.svy + (size_t)i * w.st_vy, w.svx + (size_t)i * w.st_vx,
+                                        dens_inline ? dcur : nullptr, vycur, vxcur, w.svy + (size_t)i * w.st_vy, w.svx + (size_t)i * w.st_vx,
                                         feat, fscale, io.iters_fwd ? io.iters_fwd + (size_t)i * Btot + b0 : nullptr)) return e;
         float* act[11];
         for (int k = 0; k < 11; ++k) act[k] = w.acts + ((size_t)i * 11 + k) * w.cells * 32;
@@ -340,7 +342,15 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
                            c->std_v0, c->std_v1, io.loss_steps + i, B, Y, X);
         SOL_LAUNCH_CHECK();
     }
-    if (io.d_final) SOL_HIP_CHECK(hipMemcpyAsync(io.d_final + (size_t)b0 * w.N, w.d + (size_t)(ms - 1) * w.st_d, w.st_d * sizeof(float), hipMemcpyDeviceToDevice, hs));
+    if (dens_inline) {
+        if (io.d_final) SOL_HIP_CHECK(hipMemcpyAsync(io.d_final + (size_t)b0 * w.N, w.d + (size_t)(ms - 1) * w.st_d, w.st_d * sizeof(float), hipMemcpyDeviceToDevice, hs));
+    } else if (io.d_final) {
+        // all saved velocities exist now: the whole density chain is ONE launch (one workgroup per simulation, ~0.1 ms).
+        // On the main stream: as a concurrent graph branch it takes 6 CUs away from the 256-workgroup conv launches,
+        // which then need a second round (measured +1.2 ms per step).
+        if (int e = sol_density_chain(kc, stream, ms, d0, w.svy, w.svx, (long)w.st_vy, (long)w.st_vx, io.inflow, nullptr, (long)w.st_d,
+                                      io.d_final + (size_t)b0 * w.N)) return e;
+    }
     if (io.vy_final) SOL_HIP_CHECK(hipMemcpyAsync(io.vy_final + (size_t)b0 * w.nVy, w.vy + (size_t)(ms - 1) * w.st_vy, w.st_vy * sizeof(float), hipMemcpyDeviceToDevice, hs));
     if (io.vx_final) SOL_HIP_CHECK(hipMemcpyAsync(io.vx_final + (size_t)b0 * w.nVx, w.vx + (size_t)(ms - 1) * w.st_vx, w.st_vx * sizeof(float), hipMemcpyDeviceToDevice, hs));
 

@@ -54,6 +54,7 @@ class SolTrainer:
         self.use_graph = use_graph
         self._graph = None          # (key, handle): replayable hipGraph of the whole fwd+bwd
         self._fin = None
+        self._want_final = False
         self._dp = DPStep(self._fwd_bwd_flat, self._apply_flat, group=group)
 
     def __del__(self):
@@ -108,15 +109,18 @@ class SolTrainer:
 
     # ---- data-parallel composition --------------------------------------------------------
     def _fwd_bwd_flat(self, *batch):
-        loss = self.fwd_bwd(*batch)
+        loss = self.fwd_bwd(*batch, want_final=self._want_final)
         return loss, self.grads
 
     def _apply_flat(self, grads, lr):
         assert grads is self.grads
         self.apply_gradients(lr)
 
-    def train_step(self, d0, vy0, vx0, re, gt_vy, gt_vx, lr):
-        """One training step on this rank's shard; returns the GLOBAL loss tensor."""
+    def train_step(self, d0, vy0, vx0, re, gt_vy, gt_vx, lr, want_final=False):
+        """One training step on this rank's shard; returns the GLOBAL loss tensor.  want_final=True also produces
+        the state after the last unrolled step in self.final = [density, vy, vx] (this is what makes the engine
+        advect the passive density at all: like the TF graph of the reference, nothing that no output needs is run)."""
+        self._want_final = want_final
         return self._dp(d0, vy0, vx0, re, gt_vy, gt_vx, lr=lr)
 
     # ---- algorithmic traffic of the solver part (SURVEY.md section 8d) ---------------------
