@@ -171,12 +171,12 @@ def main():
         fwd_b, bwd_b, kf_tr, kb_tr = tr.solver_algorithmic_bytes()
         conv_flops_step = 3.0 * 520000.0 * N * B * ms
         # `traffic`: HBM bytes per launch from rocprofv3 PMC passes of the same kernels at this shape
-        # (profiles/r01_pmc_traffic.txt: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE); constants, not live
+        # (profiles/r01_pmc_traffic_v2.txt: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE); constants, not live
         c3 = (Y, X, B) == (128, 64, 6)
         direct = getattr(masks, "direct", None) is not None
         roof_solver = {"kernel": "k_karman_fwd<16>", "bound": "hbm", "achieved": bytes_step / t_step / 1e9, "peak": 8000.0,
                        "unit": "GB/s", "frac": bytes_step / t_step / 8e12,
-                       "traffic": (2 * 1158.1 + 1041.2) * 1024 if c3 else None,
+                       "traffic": ((2 * 1812.2 + 969.2) * 1024 if direct else (2 * 1158.1 + 1041.2) * 1024) if c3 else None,
                        "launch_us": t_step * 1e6, "cg_iters": k_f, "algorithmic_bytes_per_launch": bytes_step,
                        "pressure_solver": "direct (sine-transform diagonalisation + capacitance correction, no iteration)" if direct
                                           else "two-level preconditioned CG",
@@ -202,7 +202,7 @@ def main():
         roof_conv = {"kernel": "k_conv5x5_sb<2,6>" if sb else "k_conv5x5_r3<2>", "bound": "mfma",
                      "achieved": flop_conv / t_conv / 1e12, "peak": 157.3,
                      "unit": "TFLOP/s", "frac": flop_conv / t_conv / 157.3e12,
-                     "traffic": (2 * 9107.9 + 6144.0) * 1024 if c3 else None,
+                     "traffic": ((2 * 9314.4 if sb else 2 * 9107.9) + 6144.0) * 1024 if c3 else None,
                      "launch_us": t_conv * 1e6, "flop_per_launch": flop_conv,
                      "note": "achieved = ALGORITHMIC fp32 conv FLOPs / launch time against the dense fp32 MFMA peak (dtype f32). "
                              "fp32 MFMA itself sustains only 92 TF on random operands (profiles/r01_ubench_notes.txt); the kernel "

@@ -1216,6 +1216,7 @@ struct DensArgs {
 };
 
 __global__ void __launch_bounds__(1024) k_density_chain(DensArgs a) {
+    constexpr int MC = 8;            // cells per thread: N <= 8192 with 1024 threads (host checks)
     extern __shared__ __align__(16) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int Y = a.Y, X = a.X, N = Y * X, XP = X + 1;
@@ -1223,18 +1224,33 @@ __global__ void __launch_bounds__(1024) k_density_chain(DensArgs a) {
     float* D0 = smem;
     float* D1 = smem + N;
     for (int k = tid; k < N; k += nthr) D0[k] = a.d0[(size_t)b * N + k];
-    __syncthreads();
-    for (int s = 0; s < a.ms; ++s) {
+    float infl[MC], uy[MC], ux[MC];
+#pragma unroll
+    for (int n = 0; n < MC; ++n) { const int k = tid + n * nthr; infl[n] = k < N ? a.inflow[k] : 0.f; }
+    // cell-centre velocity of step s: global loads, software pipelined one step ahead of the LDS work
+    auto load_u = [&](int s, float (&vy)[MC], float (&vx)[MC]) {
         const float* sy = a.svy + (size_t)s * a.st_vy + (size_t)b * (Y + 1) * X;
         const float* sx = a.svx + (size_t)s * a.st_vx + (size_t)b * Y * XP;
+#pragma unroll
+        for (int n = 0; n < MC; ++n) {
+            const int k = min(tid + n * nthr, N - 1), j = k >> lx, i = k & (X - 1);
+            vy[n] = 0.5f * (sy[k] + sy[k + X]);
+            vx[n] = 0.5f * (sx[j * XP + i] + sx[j * XP + i + 1]);
+        }
+    };
+    load_u(0, uy, ux);
+    __syncthreads();
+    for (int s = 0; s < a.ms; ++s) {
+        float uyn[MC], uxn[MC];
+        if (s + 1 < a.ms) load_u(s + 1, uyn, uxn);
         const float* src = (s & 1) ? D1 : D0;
         float* dst = (s & 1) ? D0 : D1;
-#pragma unroll 4
-        for (int k = tid; k < N; k += nthr) {
+#pragma unroll
+        for (int n = 0; n < MC; ++n) {
+            const int k = tid + n * nthr;
+            if (k >= N) continue;
             const int j = k >> lx, i = k & (X - 1);
-            const float uy = 0.5f * (sy[k] + sy[k + X]);
-            const float ux = 0.5f * (sx[j * XP + i] + sx[j * XP + i + 1]);
-            const float oy = -uy * a.dtdx, ox = -ux * a.dtdx;
+            const float oy = -uy[n] * a.dtdx, ox = -ux[n] * a.dtdx;
             const float fy = floorf(oy), fx = floorf(ox);
             const float wy = oy - fy, wx = ox - fx;
             const int j0 = j + (int)fy, i0 = i + (int)fx;
@@ -1252,10 +1268,14 @@ __global__ void __launch_bounds__(1024) k_density_chain(DensArgs a) {
                     f[dj][di] = v;
                 }
             float v = (1.f - wy) * ((1.f - wx) * f[0][0] + wx * f[0][1]) + wy * ((1.f - wx) * f[1][0] + wx * f[1][1]);
-            if (!a.inflow_before) v += a.inflow[k] * a.dt;
+            if (!a.inflow_before) v += infl[n] * a.dt;
             dst[k] = v;
             if (a.d_steps) a.d_steps[(size_t)s * a.st_d + (size_t)b * N + k] = v;
             if (a.d_final && s == a.ms - 1) a.d_final[(size_t)b * N + k] = v;
+        }
+        if (s + 1 < a.ms) {
+#pragma unroll
+            for (int n = 0; n < MC; ++n) { uy[n] = uyn[n]; ux[n] = uxn[n]; }
         }
         __syncthreads();
     }
@@ -1386,6 +1406,7 @@ int sol_density_chain(const sol_karman_cfg* c, void* stream, int ms, const float
     a.d0 = d0; a.svy = svy; a.svx = svx; a.inflow = inflow; a.st_vy = st_vy; a.st_vx = st_vx; a.st_d = st_d;
     a.d_steps = d_steps; a.d_final = d_final;
     const int threads = c->Y * c->X >= 1024 ? 1024 : (int)align_up((size_t)c->Y * c->X, 64);
+    SOL_REQUIRE((size_t)c->Y * c->X <= (size_t)8 * threads, "sol_density_chain: grid too large");
     hipLaunchKernelGGL(k_density_chain, dim3(c->B), dim3(threads), lds, (hipStream_t)stream, a);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
