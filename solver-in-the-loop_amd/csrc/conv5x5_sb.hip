@@ -14,9 +14,9 @@
 // Replaces the same keras.layers.Conv2D(32, 5, padding='same') (+bias, LeakyReLU, residual add) of
 // model_mars_moon (/root/reference/karman-2d/karman_train.py:101-138) as conv5x5.hip does.
 //
-// Work decomposition = k_conv5x5_r3 (three independent 64-pixel row tiles per workgroup, 12 waves,
-// one workgroup per CU at 128x64 x 6): per tap row dy the tile's halo row is split into its three
-// bf16 planes while it is staged into LDS (2-slot ring), the weights arrive pre-split from the
+// Work decomposition: three CONSECUTIVE 64-pixel image rows per workgroup (12 waves, one workgroup per CU
+// at 128x64 x 6).  They need seven input rows; each is split into its three bf16 planes and staged ONCE
+// into a shared 4-slot LDS ring (one new row per tap row instead of three), the weights arrive pre-split from the
 // packed buffer ([dy][dx][plane][cout][cin] bf16, already in LDS image order) and are double
 // buffered per tap row.  One tap = ONE K = 32 MFMA per split product: lane (li, g) holds
 // A[pixel li][cin 8g..8g+7] and B[cin 8g..8g+7][cout li] as one 16-byte ds_read_b128 each.
@@ -80,7 +80,7 @@ __global__ void k_pack_sb(const float* __restrict__ w, unsigned short* __restric
 // forward / backward-data kernel, W % 64 == 0, CIN = 32
 // ------------------------------------------------------------------------------------
 template <int NT, int NPROD>
-__global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int ntiles) {
+__global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     constexpr int OP = NT * 16;
     constexpr int HWP = 68;                       // halo pixels per row (64 + 4)
     constexpr int PLANE = HWP * 64;               // bytes per bf16 plane of one halo row
@@ -91,45 +91,39 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int ntiles) {
     const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = tid & 63, wave = (tid >> 6) & 3;
     const int g = lane >> 4, li = lane & 15;
     const int H = a.H, W = a.W;
-    const int tile = blockIdx.x * 3 + grp;
-    const bool tvalid = tile < ntiles;
-    const int tx = tvalid ? tile % a.tiles_x : 0;
-    const int gy = tvalid ? tile / a.tiles_x : 0;     // global row index b*H + y
-    const int b = gy / H, y = gy - b * H, x0 = tx * 64;
-    unsigned char* halo = smem_sb + grp * 2 * SLOT;   // [2][3 planes][68][64 B], private to the tile
-    unsigned char* Wt = smem_sb + 3 * 2 * SLOT;       // [2][5][3 planes][OP][64 B], shared
+    // workgroup = three CONSECUTIVE global image rows G0 .. G0+2 (row = b*H + y) of one 64-pixel column block:
+    // they need the seven input rows G0-2 .. G0+4, each of which is staged ONCE into a shared 4-slot ring
+    // (row r lives in slot (r - G0 + 2) & 3); a tile skips the tap rows whose input row belongs to another image.
+    const int tx = blockIdx.x % a.tiles_x, G0 = (blockIdx.x / a.tiles_x) * 3;
+    const int gy = G0 + grp;                          // this tile's global row
+    const bool tvalid = gy < nrows;
+    const int b = (tvalid ? gy : 0) / H, x0 = tx * 64;
+    const int row_lo = b * H, row_hi = row_lo + H;    // rows of this tile's image
+    unsigned char* ring = smem_sb;                    // [4][3 planes][68][64 B], shared by the three tiles
+    unsigned char* Wt = smem_sb + 4 * SLOT;           // [2][5][3 planes][OP][64 B], shared
     const float4* gx = reinterpret_cast<const float4*>(a.x);
     const uint4* gw = reinterpret_cast<const uint4*>(a.wsb);
-    constexpr int HPT = 3;                            // 544 float4 per halo row / 256 threads
     constexpr int WV = WBUF / 16;                     // uint4 per weight phase
     constexpr int WPT = (WV + 767) / 768;
 
-    auto load_row = [&](int dy, float4 (&v)[HPT]) {
-        const int yy = y + dy - 2;
-#pragma unroll
-        for (int n = 0; n < HPT; ++n) {
-            const int e = t + n * 256;
-            v[n] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < HWP * 8) {
-                const int hc = e >> 3, c4 = e & 7, xx = x0 + hc - 2;
-                if (tvalid && yy >= 0 && yy < H && xx >= 0 && xx < W) v[n] = gx[((size_t)(b * H + yy) * W + xx) * 8 + c4];
-            }
+    // one float4 (4 channels of one halo pixel) of global row `gr` per thread (threads 0..543)
+    auto load_row = [&](int gr, int e) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < HWP * 8) {
+            const int hc = e >> 3, c4 = e & 7, xx = x0 + hc - 2;
+            if (gr >= 0 && gr < nrows && xx >= 0 && xx < W) v = gx[((size_t)gr * W + xx) * 8 + c4];
         }
+        return v;
     };
-    auto store_row = [&](int slot, const float4 (&v)[HPT]) {
-        unsigned char* dst = halo + slot * SLOT;
+    auto store_row = [&](int slot, const float4& v, int e) {
+        if (e < HWP * 8) {
+            const int hc = e >> 3, c4 = e & 7;
+            unsigned p[3][2];
+            split3(v.x, v.y, p[0][0], p[1][0], p[2][0]);
+            split3(v.z, v.w, p[0][1], p[1][1], p[2][1]);
+            unsigned char* q = ring + slot * SLOT + hc * 64 + ((((c4 >> 1) ^ swzb(hc)) << 4) | ((c4 & 1) << 3));
 #pragma unroll
-        for (int n = 0; n < HPT; ++n) {
-            const int e = t + n * 256;
-            if (e < HWP * 8) {
-                const int hc = e >> 3, c4 = e & 7;
-                unsigned p[3][2];
-                split3(v[n].x, v[n].y, p[0][0], p[1][0], p[2][0]);
-                split3(v[n].z, v[n].w, p[0][1], p[1][1], p[2][1]);
-                unsigned char* q = dst + hc * 64 + ((((c4 >> 1) ^ swzb(hc)) << 4) | ((c4 & 1) << 3));
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(q + pl * PLANE) = make_uint2(p[pl][0], p[pl][1]);
-            }
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(q + pl * PLANE) = make_uint2(p[pl][0], p[pl][1]);
         }
     };
     auto load_w = [&](int dy, uint4 (&v)[WPT]) {
@@ -148,12 +142,14 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int ntiles) {
         }
     };
 
-    {   // prologue: tap row 0
-        float4 hv[HPT];
+    {   // prologue: input rows G0-2, G0-1, G0 (one per tile group, 3 float4 per thread) and the weights of tap row 0
+        float4 hv[3];
         uint4 wv[WPT];
-        load_row(0, hv);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) hv[n] = load_row(G0 - 2 + grp, t + n * 256);
         load_w(0, wv);
-        store_row(0, hv);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) store_row(grp, hv[n], t + n * 256);
         store_w(0, wv);
     }
     __syncthreads();
@@ -168,50 +164,54 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int ntiles) {
 
 #pragma unroll 1
     for (int dy = 0; dy < 5; ++dy) {
-        float4 hv[HPT];
+        float4 hv;
         uint4 wv[WPT];
         if (dy < 4) {
-            load_row(dy + 1, hv);
+            hv = load_row(G0 + dy + 1, tid);          // the one new input row of the next tap row: G0-2 + (dy+1) + 2
             load_w(dy + 1, wv);
         }
-        const unsigned char* hrow = halo + (dy & 1) * SLOT;
-        const unsigned char* wbuf = Wt + (dy & 1) * WBUF;
-        uint4 ao[2][3], bo[2][NT][3];
-        auto load_ops = [&](int dx, uint4 (&ar)[3], uint4 (&br)[NT][3]) {
-            const int hc = pcc + dx;
-            const unsigned char* ap = hrow + hc * 64 + ((g ^ swzb(hc)) << 4);
+        const int src = gy + dy - 2;                  // input row of this tile for this tap row
+        if (tvalid && src >= row_lo && src < row_hi) {            // wave uniform
+            const unsigned char* hrow = ring + ((grp + dy) & 3) * SLOT;
+            const unsigned char* wbuf = Wt + (dy & 1) * WBUF;
+            uint4 ao[2][3], bo[2][NT][3];
+            auto load_ops = [&](int dx, uint4 (&ar)[3], uint4 (&br)[NT][3]) {
+                const int hc = pcc + dx;
+                const unsigned char* ap = hrow + hc * 64 + ((g ^ swzb(hc)) << 4);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) ar[pl] = *reinterpret_cast<const uint4*>(ap + pl * PLANE);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int co = n * 16 + li;
-                const unsigned char* bp = wbuf + dx * 3 * WPL + co * 64 + ((g ^ swzb(co)) << 4);
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) br[n][pl] = *reinterpret_cast<const uint4*>(bp + pl * WPL);
-            }
-        };
-        load_ops(0, ao[0], bo[0]);
-#pragma unroll
-        for (int dx = 0; dx < 5; ++dx) {
-            if (dx < 4) load_ops(dx + 1, ao[(dx + 1) & 1], bo[(dx + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ds_reads above this tap's MFMAs
-#pragma unroll
-            for (int pr = 6 - NPROD; pr < 6; ++pr) {
-                const bf16x8 av = __builtin_bit_cast(bf16x8, ao[dx & 1][PA[pr]]);
+                for (int pl = 0; pl < 3; ++pl) ar[pl] = *reinterpret_cast<const uint4*>(ap + pl * PLANE);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const bf16x8 bv = __builtin_bit_cast(bf16x8, bo[dx & 1][n][PB[pr]]);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[n], 0, 0, 0);
+                    const int co = n * 16 + li;
+                    const unsigned char* bp = wbuf + dx * 3 * WPL + co * 64 + ((g ^ swzb(co)) << 4);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) br[n][pl] = *reinterpret_cast<const uint4*>(bp + pl * WPL);
                 }
+            };
+            load_ops(0, ao[0], bo[0]);
+#pragma unroll
+            for (int dx = 0; dx < 5; ++dx) {
+                if (dx < 4) load_ops(dx + 1, ao[(dx + 1) & 1], bo[(dx + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ds_reads above this tap's MFMAs
+#pragma unroll
+                for (int pr = 6 - NPROD; pr < 6; ++pr) {
+                    const bf16x8 av = __builtin_bit_cast(bf16x8, ao[dx & 1][PA[pr]]);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const bf16x8 bv = __builtin_bit_cast(bf16x8, bo[dx & 1][n][PB[pr]]);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[n], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         if (dy < 4) {
-            store_row((dy + 1) & 1, hv);
+            store_row((dy + 3) & 3, hv, tid);          // slot of row G0 + dy + 1; its previous tenant (row G0+dy-3) is dead
             store_w((dy + 1) & 1, wv);
         }
         __syncthreads();
     }
+    unsigned char* halo = ring + (size_t)grp * 4 * 16 * OP * sizeof(float);   // epilogue scratch: 4 waves x [16 px][OP] floats per tile
     // ---- epilogue: transpose the wave's [16 px][OP] tile through LDS (the tile's halo ring is free
     //      after the last barrier) so that every lane moves 16-byte pieces of full 128-byte pixels ----
     if (a.CO == OP) {
@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(512) k_conv5x5_bww_sb(BwArgs a) {
     }
 }
 
-constexpr size_t sb_lds(int OP) { return (size_t)3 * 2 * 3 * 68 * 64 + 2 * (size_t)5 * 3 * OP * 64; }
+constexpr size_t sb_lds(int OP) { return (size_t)4 * 3 * 68 * 64 + 2 * (size_t)5 * 3 * OP * 64; }
 
 int init_sb_kernels() {
     static int rc = [] {
@@ -481,12 +481,13 @@ int sol_conv_sb_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int 
 int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles) {
     if (int e = init_sb_kernels()) return e;
     static const int nprod = [] { const char* v = getenv("SOL_CONV_SPLIT"); return v && atoi(v) == 3 ? 3 : 6; }();
-    const int grid3 = (ntiles + 2) / 3;
+    const int nrows = ntiles / a.tiles_x;             // global image rows B*H
+    const int grid3 = ((nrows + 2) / 3) * a.tiles_x;  // three consecutive rows of one column block per workgroup
     const size_t lds = sb_lds(NT * 16);
-    if (NT == 2 && nprod == 6) hipLaunchKernelGGL((k_conv5x5_sb<2, 6>), dim3(grid3), dim3(768), lds, s, a, ntiles);
-    else if (NT == 2) hipLaunchKernelGGL((k_conv5x5_sb<2, 3>), dim3(grid3), dim3(768), lds, s, a, ntiles);
-    else if (nprod == 6) hipLaunchKernelGGL((k_conv5x5_sb<1, 6>), dim3(grid3), dim3(768), lds, s, a, ntiles);
-    else hipLaunchKernelGGL((k_conv5x5_sb<1, 3>), dim3(grid3), dim3(768), lds, s, a, ntiles);
+    if (NT == 2 && nprod == 6) hipLaunchKernelGGL((k_conv5x5_sb<2, 6>), dim3(grid3), dim3(768), lds, s, a, nrows);
+    else if (NT == 2) hipLaunchKernelGGL((k_conv5x5_sb<2, 3>), dim3(grid3), dim3(768), lds, s, a, nrows);
+    else if (nprod == 6) hipLaunchKernelGGL((k_conv5x5_sb<1, 6>), dim3(grid3), dim3(768), lds, s, a, nrows);
+    else hipLaunchKernelGGL((k_conv5x5_sb<1, 3>), dim3(grid3), dim3(768), lds, s, a, nrows);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }
