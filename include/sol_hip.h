@@ -158,6 +158,18 @@ int sol_conv5x5(void* stream, const float* x, const float* packed, const float* 
                 int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,
                 int32_t epilogue, float slope);
 
+/* sol_conv5x5 with per-tensor absmax bookkeeping: `x_absmax` / `y_absmax` are DEVICE arrays of 64 uint32 slots whose
+ * maximum holds the bit pattern of max|x| / max|y| (non-negative floats compare like unsigned integers).
+ * y_absmax (or NULL): slots are raised with atomic max by this launch (the caller zeroes them once per tensor).
+ * x_absmax (or NULL): when given for a 32-input-channel, W % 64 == 0 convolution, the fp32 products are evaluated as
+ * THREE fp16 MFMA products of operands scaled by a power of two derived from the absmax (22-bit operand splits, fp32
+ * accumulation; error relative to max|x| max|w| like the fp32 kernel's) instead of six bf16 products.  The producer of x
+ * publishes its absmax in the unrolled training graph, so no extra pass over the data exists. */
+int sol_conv5x5_scaled(void* stream, const float* x, const float* packed, const float* bias,
+                       const float* residual, const float* act_ref, float* y,
+                       int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,
+                       int32_t epilogue, float slope, const uint32_t* x_absmax, uint32_t* y_absmax);
+
 /* dW[5,5,cin,cout] += sum_px x[px+tap] * dz[px];  db[cout] += sum_px dz[px].
  * `partial` is a caller workspace of sol_conv5x5_bwd_weight_ws_floats() floats that the
  * caller zeroes once and may reuse to ACCUMULATE over many calls (the unrolled steps share

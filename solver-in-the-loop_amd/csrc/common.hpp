@@ -27,7 +27,11 @@ struct ConvArgs {
     float slope;
     int TW, RPW, tiles_x;
     const void* wsb;   // split-bf16 weight planes (second section of the packed buffer), cin == 32 only
+    const void* wsh;   // split-fp16 weight planes + header (third section), cin == 32 only
+    const unsigned* xmax;   // [64] slots, max over them = bits of max|x| (non-negative float) -> fp16 path; NULL: bf16 path
+    unsigned* ymax;         // [64] slots updated with max|y| (atomic max on the float bits), or NULL
 };
+constexpr int SOL_AMAX_SLOTS = 64;
 // backward-weight arguments
 struct BwArgs {
     const float *x, *dz;
@@ -41,6 +45,10 @@ struct BwArgs {
 int sol_bww_sb_launch(hipStream_t s, const BwArgs& a, int nblk_run);
 // split-bf16 section of the packed weights and the kernels that consume it (conv5x5_sb.hip)
 size_t sol_conv_sb_packed_floats(int OP);
+size_t sol_conv_sh_packed_floats(int OP);
+int sol_pack_jobs(hipStream_t s, int n, const float* const* w, float* const* out, float* const* bias_out, const float* const* bias_in,
+                  const int* cin, const int* cout, const int* mode);
+int sol_conv_sh_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int mode, void* out);
 int sol_conv_sb_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int mode, void* out);
 int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles);
 
@@ -78,5 +86,30 @@ __device__ __forceinline__ float block_sum(float v, float* red, int slot) {
     for (int w = 0; w < nw; ++w) s += r[w];
     return s;
 }
+
+// max over the 64 slots of an absmax array (bits of non-negative floats) -> power-of-two scale 2^shift with
+// max * 2^shift in [2^14, 2^15), and its inverse
+__device__ __forceinline__ void amax_scale(const unsigned* slots, float& scale, float& inv) {
+    unsigned m = slots[threadIdx.x & 63];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+    int e = (int)(m >> 23) - 127;                     // max in [2^e, 2^(e+1))
+    e = m == 0u ? 0 : min(max(e, -100), 100);
+    scale = __uint_as_float((unsigned)(14 - e + 127) << 23);
+    inv = __uint_as_float((unsigned)(e - 14 + 127) << 23);
+}
+// one atomic per workgroup: `v` = this thread's max|y|; `red` = 16 floats of LDS
+__device__ __forceinline__ void amax_publish(float v, unsigned* slots, float* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
+        atomicMax(&slots[blockIdx.x & (SOL_AMAX_SLOTS - 1)], __float_as_uint(m));
+    }
+}
+
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(256) k_conv5x5(ConvArgs a) {
     }
 
     // ---- epilogue: bias, residual, LeakyReLU / LeakyReLU' ---------------------------------
+    float vmax = 0.f;                                // max|y| of this thread (a.ymax)
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int co = n * 16 + li;
@@ -144,8 +145,13 @@ __global__ void __launch_bounds__(256) k_conv5x5(ConvArgs a) {
             if (a.res) v += a.res[o];
             if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
             else if (a.epi == SOL_EPI_DLRELU) v *= (a.act[o] > 0.f ? 1.f : a.slope);
+            vmax = fmaxf(vmax, fabsf(v));
             a.y[o] = v;
         }
+    }
+    if (a.ymax) {                                    // workgroup uniform
+        __syncthreads();
+        amax_publish(vmax, a.ymax, smem);
     }
 }
 
@@ -267,6 +273,7 @@ __global__ void __launch_bounds__(256) k_conv5x5_c32(ConvArgs a) {
     }
 
     // ---- epilogue: bias, residual, LeakyReLU / LeakyReLU' ---------------------------------
+    float vmax = 0.f;                                // max|y| of this thread (a.ymax)
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int co = n * 16 + li;
@@ -281,8 +288,13 @@ __global__ void __launch_bounds__(256) k_conv5x5_c32(ConvArgs a) {
             if (a.res) v += a.res[o];
             if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
             else if (a.epi == SOL_EPI_DLRELU) v *= (a.act[o] > 0.f ? 1.f : a.slope);
+            vmax = fmaxf(vmax, fabsf(v));
             a.y[o] = v;
         }
+    }
+    if (a.ymax) {                                    // workgroup uniform
+        __syncthreads();
+        amax_publish(vmax, a.ymax, smem);
     }
 }
 
@@ -919,7 +931,8 @@ int check_shape(int B, int H, int W, int cin, int cout) {
 
 extern "C" size_t sol_conv5x5_packed_floats(int32_t cin, int32_t cout, int32_t /*mode*/) {
     // fp32 section (all shapes) + split-bf16 planes for the 32-input-channel kernels (conv5x5_sb.hip)
-    return (size_t)25 * pad_in(cin) * pad_out(cout) + (pad_in(cin) == 32 ? sol_conv_sb_packed_floats(pad_out(cout)) : 0);
+    return (size_t)25 * pad_in(cin) * pad_out(cout) +
+           (pad_in(cin) == 32 ? sol_conv_sb_packed_floats(pad_out(cout)) + sol_conv_sh_packed_floats(pad_out(cout)) : 0);
 }
 
 extern "C" int sol_conv5x5_pack(void* stream, const float* w_hwio, int32_t cin, int32_t cout, int32_t mode, float* packed) {
@@ -929,7 +942,10 @@ extern "C" int sol_conv5x5_pack(void* stream, const float* w_hwio, int32_t cin, 
     const int total = 25 * pad_in(cin) * pad_out(cout);
     hipLaunchKernelGGL(k_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_hwio, packed, cin, cout, mode);
     SOL_LAUNCH_CHECK();
-    if (pad_in(cin) == 32) return sol_conv_sb_pack((hipStream_t)stream, w_hwio, cin, cout, mode, packed + total);
+    if (pad_in(cin) == 32) {
+        if (int e = sol_conv_sb_pack((hipStream_t)stream, w_hwio, cin, cout, mode, packed + total)) return e;
+        return sol_conv_sh_pack((hipStream_t)stream, w_hwio, cin, cout, mode, packed + total + sol_conv_sb_packed_floats(pad_out(cout)));
+    }
     return SOL_OK;
 }
 
@@ -945,10 +961,10 @@ int sol_init_conv_kernels() {
     return rc;
 }
 
-extern "C" int sol_conv5x5(void* stream, const float* x, const float* packed, const float* bias,
-                           const float* residual, const float* act_ref, float* y,
-                           int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,
-                           int32_t epilogue, float slope) {
+static int conv_impl(void* stream, const float* x, const float* packed, const float* bias,
+                     const float* residual, const float* act_ref, float* y,
+                     int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,
+                     int32_t epilogue, float slope, const uint32_t* x_absmax, uint32_t* y_absmax) {
     if (int e = check_shape(B, H, W, cin, cout)) return e;
     SOL_REQUIRE(x && packed && y, "sol_conv5x5: NULL pointer");
     SOL_REQUIRE(epilogue != SOL_EPI_DLRELU || act_ref, "sol_conv5x5: SOL_EPI_DLRELU needs act_ref");
@@ -965,8 +981,12 @@ extern "C" int sol_conv5x5(void* stream, const float* x, const float* packed, co
     const int NT = pad_out(cout) / 16;
     hipStream_t s = (hipStream_t)stream;
     static const bool use_sb = !getenv("SOL_CONV_NO_SB");
+    static const bool use_sh = !getenv("SOL_CONV_NO_FP16");
+    if (use_sb) a.ymax = y_absmax;                  // published by the split kernels and the thin fp32 kernel below
     if (cin == 32 && W % 64 == 0 && use_sb) {
         a.wsb = packed + (size_t)25 * 32 * pad_out(cout);
+        a.wsh = packed + (size_t)25 * 32 * pad_out(cout) + sol_conv_sb_packed_floats(pad_out(cout));
+        a.xmax = use_sh ? x_absmax : nullptr;       // absmax of x known -> fp16 three-product kernel, else bf16 six-product
         return sol_conv_sb_launch(s, a, NT, B * H * (W / 64));
     }
     if (cin == 32 && W % 64 == 0 && !getenv("SOL_CONV_NO_R3")) {
@@ -991,6 +1011,20 @@ extern "C" int sol_conv5x5(void* stream, const float* x, const float* packed, co
     else hipLaunchKernelGGL((k_conv5x5<4, 1>), dim3(grid), dim3(256), lds, s, a);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
+}
+
+extern "C" int sol_conv5x5(void* stream, const float* x, const float* packed, const float* bias,
+                           const float* residual, const float* act_ref, float* y,
+                           int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,
+                           int32_t epilogue, float slope) {
+    return conv_impl(stream, x, packed, bias, residual, act_ref, y, B, H, W, cin, cout, epilogue, slope, nullptr, nullptr);
+}
+
+extern "C" int sol_conv5x5_scaled(void* stream, const float* x, const float* packed, const float* bias,
+                                  const float* residual, const float* act_ref, float* y,
+                                  int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,
+                                  int32_t epilogue, float slope, const uint32_t* x_absmax, uint32_t* y_absmax) {
+    return conv_impl(stream, x, packed, bias, residual, act_ref, y, B, H, W, cin, cout, epilogue, slope, x_absmax, y_absmax);
 }
 
 static int bww_dims(int rows, int rb, int cin, int cout, int* nblk, int* IP, int* OP) {

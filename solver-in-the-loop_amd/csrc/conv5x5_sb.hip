@@ -52,6 +52,56 @@ __device__ __forceinline__ void split3(float x, float y, unsigned& p1, unsigned&
     p3 = pk_bf16(rx - bf_lo(p2), ry - bf_hi(p2));
 }
 
+// ---- split fp16 ("KIND 2"): v * 2^shift = h1 + h2 / 2048 with two fp16 numbers (22 significant bits), 2^shift chosen per
+// TENSOR from its max|v| so that the scaled tensor spans fp16's 29 normal binades below 2^15.  Three MFMA products
+// (h1h1 into one accumulator, h1h2' + h2'h1 into a second one that is folded in with 2^-11 at the end): the dropped
+// terms are <= 2^-22 relative to max|a| max|b| -- an ABSOLUTE error bound per tensor, which is what the relative-L2
+// parity criterion measures (float64 check: 7.5e-8 before the fp32 accumulation, tools/conv_accuracy.py).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pk_f16(float x, float y) {
+    const f32x2 f = {x, y};
+    const f16x2 h = __builtin_convertvector(f, f16x2);
+    return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ void split2h(float x, float y, float scale, unsigned& p1, unsigned& p2) {
+    const float xs = x * scale, ys = y * scale;
+    p1 = pk_f16(xs, ys);
+    const f16x2 h = __builtin_bit_cast(f16x2, p1);
+    p2 = pk_f16((xs - (float)h.x) * 2048.f, (ys - (float)h.y) * 2048.f);
+}
+__global__ void k_absmax(const float* __restrict__ x, size_t n, unsigned* __restrict__ slots) {
+    __shared__ float red[16];
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+    amax_publish(m, slots, red);
+}
+
+// fp16 weight planes: header {2^shift_w, 2^-shift_w, 0, 0} then out[dy][dx][plane 2][o][chunk s][j]
+__global__ void k_pack_sh(const float* __restrict__ w, const unsigned* __restrict__ wmax, float* __restrict__ hdr,
+                          unsigned short* __restrict__ out, int cin, int cout, int OP, int mode) {
+    float sc, inv;
+    amax_scale(wmax, sc, inv);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[0] = sc; hdr[1] = inv; hdr[2] = 0.f; hdr[3] = 0.f; }
+    const int total = 25 * OP * 16;   // pairs of channels
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int jp = e & 3, s = (e >> 2) & 3, o = (e >> 4) % OP, tap = e / (16 * OP);
+        const int i0 = 8 * (s ^ swzb(o)) + 2 * jp;
+        float v[2] = {0.f, 0.f};
+        for (int q = 0; q < 2; ++q) {
+            const int i = i0 + q;
+            if (i < cin && o < cout)
+                v[q] = mode == SOL_CONV_FWD ? w[(tap * cin + i) * cout + o] : w[((24 - tap) * cout + o) * cin + i];
+        }
+        unsigned p[2];
+        split2h(v[0], v[1], sc, p[0], p[1]);
+        for (int pl = 0; pl < 2; ++pl) {
+            const size_t idx = ((((size_t)tap * 2 + pl) * OP + o) * 4 + s) * 8 + 2 * jp;
+            *reinterpret_cast<unsigned*>(out + idx) = p[pl];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // weight packing: out[dy][dx][plane][o][chunk s][j] (bf16), chunk s holds cin 8*(s ^ swzb(o)) + j
 // FWD / BWD_DATA source index as k_pack (conv5x5.hip); `cin` = 32 channels of the convolution being run
@@ -79,14 +129,17 @@ __global__ void k_pack_sb(const float* __restrict__ w, unsigned short* __restric
 // ------------------------------------------------------------------------------------
 // forward / backward-data kernel, W % 64 == 0, CIN = 32
 // ------------------------------------------------------------------------------------
-template <int NT, int NPROD>
+// KIND 0: bf16, six products (default without absmax);  1: bf16, three leading products (experiment);
+// KIND 2: fp16, three products, per-tensor power-of-two scaling (needs a.xmax)
+template <int NT, int KIND>
 __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     constexpr int OP = NT * 16;
     constexpr int HWP = 68;                       // halo pixels per row (64 + 4)
     constexpr int PLANE = HWP * 64;               // bytes per bf16 plane of one halo row
-    constexpr int SLOT = 3 * PLANE;               // bytes per halo row
+    constexpr int NPL = KIND == 2 ? 2 : 3;        // operand planes
+    constexpr int SLOT = NPL * PLANE;             // bytes per halo row
     constexpr int WPL = OP * 64;                  // bytes per (dx, plane) weight block
-    constexpr int WBUF = 5 * 3 * WPL;             // bytes per tap-row weight phase
+    constexpr int WBUF = 5 * NPL * WPL;           // bytes per tap-row weight phase
     extern __shared__ __align__(16) unsigned char smem_sb[];
     const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = tid & 63, wave = (tid >> 6) & 3;
     const int g = lane >> 4, li = lane & 15;
@@ -102,7 +155,13 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     unsigned char* ring = smem_sb;                    // [4][3 planes][68][64 B], shared by the three tiles
     unsigned char* Wt = smem_sb + 4 * SLOT;           // [2][5][3 planes][OP][64 B], shared
     const float4* gx = reinterpret_cast<const float4*>(a.x);
-    const uint4* gw = reinterpret_cast<const uint4*>(a.wsb);
+    const uint4* gw = KIND == 2 ? reinterpret_cast<const uint4*>(a.wsh) + 1 : reinterpret_cast<const uint4*>(a.wsb);
+    float sa = 1.f, out_scale = 1.f;                  // KIND 2: input scale 2^shift and 2^-(shift_x + shift_w)
+    if constexpr (KIND == 2) {
+        float sai;
+        amax_scale(a.xmax, sa, sai);
+        out_scale = sai * reinterpret_cast<const float*>(a.wsh)[1];
+    }
     constexpr int WV = WBUF / 16;                     // uint4 per weight phase
     constexpr int WPT = (WV + 767) / 768;
 
@@ -119,11 +178,16 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
         if (e < HWP * 8) {
             const int hc = e >> 3, c4 = e & 7;
             unsigned p[3][2];
-            split3(v.x, v.y, p[0][0], p[1][0], p[2][0]);
-            split3(v.z, v.w, p[0][1], p[1][1], p[2][1]);
+            if constexpr (KIND == 2) {
+                split2h(v.x, v.y, sa, p[0][0], p[1][0]);
+                split2h(v.z, v.w, sa, p[0][1], p[1][1]);
+            } else {
+                split3(v.x, v.y, p[0][0], p[1][0], p[2][0]);
+                split3(v.z, v.w, p[0][1], p[1][1], p[2][1]);
+            }
             unsigned char* q = ring + slot * SLOT + hc * 64 + ((((c4 >> 1) ^ swzb(hc)) << 4) | ((c4 & 1) << 3));
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(q + pl * PLANE) = make_uint2(p[pl][0], p[pl][1]);
+            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint2*>(q + pl * PLANE) = make_uint2(p[pl][0], p[pl][1]);
         }
     };
     auto load_w = [&](int dy, uint4 (&v)[WPT]) {
@@ -154,9 +218,9 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     }
     __syncthreads();
 
-    f32x4 acc[NT];
+    f32x4 acc[NT], acl[NT];                           // acl: KIND 2 accumulator of the 2^-11 weighted cross terms
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NT; ++n) { acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; acl[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const int pcc = wave * 16 + li;                   // this lane's A-row pixel inside the tile
     // split products in order of increasing weight (small terms first)
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
@@ -174,18 +238,18 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
         if (tvalid && src >= row_lo && src < row_hi) {            // wave uniform
             const unsigned char* hrow = ring + ((grp + dy) & 3) * SLOT;
             const unsigned char* wbuf = Wt + (dy & 1) * WBUF;
-            uint4 ao[2][3], bo[2][NT][3];
-            auto load_ops = [&](int dx, uint4 (&ar)[3], uint4 (&br)[NT][3]) {
+            uint4 ao[2][NPL], bo[2][NT][NPL];
+            auto load_ops = [&](int dx, uint4 (&ar)[NPL], uint4 (&br)[NT][NPL]) {
                 const int hc = pcc + dx;
                 const unsigned char* ap = hrow + hc * 64 + ((g ^ swzb(hc)) << 4);
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) ar[pl] = *reinterpret_cast<const uint4*>(ap + pl * PLANE);
+                for (int pl = 0; pl < NPL; ++pl) ar[pl] = *reinterpret_cast<const uint4*>(ap + pl * PLANE);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     const int co = n * 16 + li;
-                    const unsigned char* bp = wbuf + dx * 3 * WPL + co * 64 + ((g ^ swzb(co)) << 4);
+                    const unsigned char* bp = wbuf + dx * NPL * WPL + co * 64 + ((g ^ swzb(co)) << 4);
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) br[n][pl] = *reinterpret_cast<const uint4*>(bp + pl * WPL);
+                    for (int pl = 0; pl < NPL; ++pl) br[n][pl] = *reinterpret_cast<const uint4*>(bp + pl * WPL);
                 }
             };
             load_ops(0, ao[0], bo[0]);
@@ -193,13 +257,24 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
             for (int dx = 0; dx < 5; ++dx) {
                 if (dx < 4) load_ops(dx + 1, ao[(dx + 1) & 1], bo[(dx + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ds_reads above this tap's MFMAs
-#pragma unroll
-                for (int pr = 6 - NPROD; pr < 6; ++pr) {
-                    const bf16x8 av = __builtin_bit_cast(bf16x8, ao[dx & 1][PA[pr]]);
+                if constexpr (KIND == 2) {
+                    const f16x8 a1 = __builtin_bit_cast(f16x8, ao[dx & 1][0]), a2 = __builtin_bit_cast(f16x8, ao[dx & 1][NPL - 1]);
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
-                        const bf16x8 bv = __builtin_bit_cast(bf16x8, bo[dx & 1][n][PB[pr]]);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[n], 0, 0, 0);
+                        const f16x8 b1 = __builtin_bit_cast(f16x8, bo[dx & 1][n][0]), b2 = __builtin_bit_cast(f16x8, bo[dx & 1][n][NPL - 1]);
+                        acl[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, acl[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, acc[n], 0, 0, 0);
+                        acl[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, acl[n], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int pr = (KIND == 1 ? 3 : 0); pr < 6; ++pr) {
+                        const bf16x8 av = __builtin_bit_cast(bf16x8, ao[dx & 1][PA[pr]]);
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            const bf16x8 bv = __builtin_bit_cast(bf16x8, bo[dx & 1][n][PB[pr]]);
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[n], 0, 0, 0);
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -211,9 +286,16 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
         }
         __syncthreads();
     }
+    if constexpr (KIND == 2) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[n][r] = (acc[n][r] + acl[n][r] * (1.f / 2048.f)) * out_scale;
+    }
     unsigned char* halo = ring + (size_t)grp * 4 * 16 * OP * sizeof(float);   // epilogue scratch: 4 waves x [16 px][OP] floats per tile
-    // ---- epilogue: transpose the wave's [16 px][OP] tile through LDS (the tile's halo ring is free
-    //      after the last barrier) so that every lane moves 16-byte pieces of full 128-byte pixels ----
+    float vmax = 0.f;                                 // max|y| of this thread (for a.ymax)
+    // ---- epilogue: transpose the wave's [16 px][OP] tile through LDS (the ring is free after the last
+    //      barrier) so that every lane moves 16-byte pieces of full 128-byte pixels ----
     if (a.CO == OP) {
         float* tb = reinterpret_cast<float*>(halo) + wave * (16 * OP);   // 16 px x OP floats per wave
 #pragma unroll
@@ -240,27 +322,32 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
                     v.x *= q.x > 0.f ? 1.f : a.slope; v.y *= q.y > 0.f ? 1.f : a.slope;
                     v.z *= q.z > 0.f ? 1.f : a.slope; v.w *= q.w > 0.f ? 1.f : a.slope;
                 }
+                vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
                 reinterpret_cast<float4*>(a.y)[o4] = v;
             }
         }
-        return;
-    }
-    if (!tvalid) return;
+    } else if (tvalid) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int co = n * 16 + li;
-        if (co >= a.CO) continue;
-        const float bias = a.bias ? a.bias[co] : 0.f;
+        for (int n = 0; n < NT; ++n) {
+            const int co = n * 16 + li;
+            if (co >= a.CO) continue;
+            const float bias = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int cc = wave * 16 + 4 * g + r;
-            const size_t o = ((size_t)gy * W + x0 + cc) * a.CO + co;
-            float v = acc[n][r] + bias;
-            if (a.res) v += a.res[o];
-            if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
-            else if (a.epi == SOL_EPI_DLRELU) v *= (a.act[o] > 0.f ? 1.f : a.slope);
-            a.y[o] = v;
+            for (int r = 0; r < 4; ++r) {
+                const int cc = wave * 16 + 4 * g + r;
+                const size_t o = ((size_t)gy * W + x0 + cc) * a.CO + co;
+                float v = acc[n][r] + bias;
+                if (a.res) v += a.res[o];
+                if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
+                else if (a.epi == SOL_EPI_DLRELU) v *= (a.act[o] > 0.f ? 1.f : a.slope);
+                vmax = fmaxf(vmax, fabsf(v));
+                a.y[o] = v;
+            }
         }
+    }
+    if (a.ymax) {                                     // workgroup uniform
+        __syncthreads();                              // the scratch below overlaps the transposition buffers
+        amax_publish(vmax, a.ymax, reinterpret_cast<float*>(smem_sb));
     }
 }
 
@@ -450,12 +537,73 @@ __global__ void __launch_bounds__(512) k_conv5x5_bww_sb(BwArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------
+// all layers, all operand forms, one launch (training / roll-out path)
+// ------------------------------------------------------------------------------------
+// Job = (layer, mode).  Every workgroup of a job first finds the layer's max|w| itself (<= 25,600 values), then packs
+// its share of the three sections of the job's buffer: fp32 [tap][o][i], bf16 planes, fp16 header + planes
+// (layouts as k_pack / k_pack_sb / k_pack_sh).  Replaces ~130 tiny launches per training step.
+struct PackJob { const float* w; float* out; float* bias_out; const float* bias_in; int cin, cout, mode; };   // cin/cout of the convolution being RUN
+struct PackJobs { PackJob j[24]; int n; };
+constexpr int PACK_WG = 8;        // workgroups per job
+
+__device__ __forceinline__ float pack_src(const PackJob& jb, int tap, int i, int o) {
+    if (i >= jb.cin || o >= jb.cout) return 0.f;
+    return jb.mode == SOL_CONV_FWD ? jb.w[(tap * jb.cin + i) * jb.cout + o] : jb.w[((24 - tap) * jb.cout + o) * jb.cin + i];
+}
+
+__global__ void __launch_bounds__(256) k_pack_jobs(PackJobs jobs) {
+    __shared__ float red[8];
+    const PackJob jb = jobs.j[blockIdx.x / PACK_WG];
+    const int part = blockIdx.x % PACK_WG, tid = threadIdx.x;
+    const int IP = jb.cin <= 4 ? 4 : 32, OP = jb.cout <= 16 ? 16 : 32;
+    // fp32 section
+    const int total = 25 * OP * IP;
+    for (int e = part * 256 + tid; e < total; e += PACK_WG * 256) {
+        const int i = e % IP, o = (e / IP) % OP, tap = e / (IP * OP);
+        jb.out[e] = pack_src(jb, tap, i, o);
+    }
+    if (part == 0 && jb.bias_out && tid < 32) jb.bias_out[tid] = (jb.bias_in && tid < jb.cout) ? jb.bias_in[tid] : 0.f;
+    if (IP != 32) return;
+    // max |w| of the layer (every workgroup of the job computes the same value)
+    float m = 0.f;
+    for (int e = tid; e < 25 * jb.cin * jb.cout; e += 256) m = fmaxf(m, fabsf(jb.w[e]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const unsigned mb = __float_as_uint(m);
+    int ex = (int)(mb >> 23) - 127;
+    ex = mb == 0u ? 0 : min(max(ex, -100), 100);
+    const float sc = __uint_as_float((unsigned)(14 - ex + 127) << 23), inv = __uint_as_float((unsigned)(ex - 14 + 127) << 23);
+    unsigned short* sb = reinterpret_cast<unsigned short*>(jb.out + total);
+    float* hdr = jb.out + total + (size_t)25 * 3 * OP * 16;
+    unsigned short* sh = reinterpret_cast<unsigned short*>(hdr + 4);
+    if (part == 0 && tid == 0) { hdr[0] = sc; hdr[1] = inv; hdr[2] = 0.f; hdr[3] = 0.f; }
+    const int pairs = 25 * OP * 16;
+    for (int e = part * 256 + tid; e < pairs; e += PACK_WG * 256) {
+        const int jp = e & 3, s = (e >> 2) & 3, o = (e >> 4) % OP, tap = e / (16 * OP);
+        const int i0 = 8 * (s ^ swzb(o)) + 2 * jp;
+        const float v0 = pack_src(jb, tap, i0, o), v1 = pack_src(jb, tap, i0 + 1, o);
+        unsigned p[3], h[2];
+        split3(v0, v1, p[0], p[1], p[2]);
+        split2h(v0, v1, sc, h[0], h[1]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<unsigned*>(sb + ((((size_t)tap * 3 + pl) * OP + o) * 4 + s) * 8 + 2 * jp) = p[pl];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<unsigned*>(sh + ((((size_t)tap * 2 + pl) * OP + o) * 4 + s) * 8 + 2 * jp) = h[pl];
+    }
+}
+
 constexpr size_t sb_lds(int OP) { return (size_t)4 * 3 * 68 * 64 + 2 * (size_t)5 * 3 * OP * 64; }
 
 int init_sb_kernels() {
     static int rc = [] {
-        const void* ks[] = {reinterpret_cast<const void*>(k_conv5x5_bww_sb), reinterpret_cast<const void*>(k_conv5x5_sb<1, 6>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 6>),
-                            reinterpret_cast<const void*>(k_conv5x5_sb<1, 3>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 3>)};
+        const void* ks[] = {reinterpret_cast<const void*>(k_conv5x5_bww_sb), reinterpret_cast<const void*>(k_conv5x5_sb<1, 0>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 0>),
+                            reinterpret_cast<const void*>(k_conv5x5_sb<1, 1>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 1>),
+                            reinterpret_cast<const void*>(k_conv5x5_sb<1, 2>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 2>)};
         for (const void* k : ks)
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return sol_set_error(SOL_ERR_HIP, "hipFuncSetAttribute(split-bf16 conv kernels) failed");
@@ -476,6 +624,22 @@ int sol_conv_sb_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int 
     return SOL_OK;
 }
 
+// fp16 section: header (4 floats) + 25 taps x 2 planes x OP x 32 fp16, + 64 absmax slots of the weights (scratch)
+size_t sol_conv_sh_packed_floats(int OP) { return 4 + (size_t)25 * 2 * OP * 16 + SOL_AMAX_SLOTS; }
+
+int sol_conv_sh_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int mode, void* out) {
+    const int OP = cout <= 16 ? 16 : 32;
+    float* hdr = reinterpret_cast<float*>(out);
+    unsigned* slots = reinterpret_cast<unsigned*>(hdr + 4 + (size_t)25 * 2 * OP * 16);
+    SOL_HIP_CHECK(hipMemsetAsync(slots, 0, SOL_AMAX_SLOTS * sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_absmax, dim3(8), dim3(256), 0, s, w_hwio, (size_t)25 * cin * cout, slots);
+    SOL_LAUNCH_CHECK();
+    const int total = 25 * OP * 16;
+    hipLaunchKernelGGL(k_pack_sh, dim3((total + 255) / 256), dim3(256), 0, s, w_hwio, slots, hdr, reinterpret_cast<unsigned short*>(hdr + 4), cin, cout, OP, mode);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
 // SOL_CONV_SPLIT=3 runs the three leading products only (~2^-17 relative error per product): an
 // experiment knob, NOT the default and not what bench.py or the parity tests use.
 int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles) {
@@ -484,10 +648,14 @@ int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles) {
     const int nrows = ntiles / a.tiles_x;             // global image rows B*H
     const int grid3 = ((nrows + 2) / 3) * a.tiles_x;  // three consecutive rows of one column block per workgroup
     const size_t lds = sb_lds(NT * 16);
-    if (NT == 2 && nprod == 6) hipLaunchKernelGGL((k_conv5x5_sb<2, 6>), dim3(grid3), dim3(768), lds, s, a, nrows);
-    else if (NT == 2) hipLaunchKernelGGL((k_conv5x5_sb<2, 3>), dim3(grid3), dim3(768), lds, s, a, nrows);
-    else if (nprod == 6) hipLaunchKernelGGL((k_conv5x5_sb<1, 6>), dim3(grid3), dim3(768), lds, s, a, nrows);
-    else hipLaunchKernelGGL((k_conv5x5_sb<1, 3>), dim3(grid3), dim3(768), lds, s, a, nrows);
+    if (a.xmax) {                                     // per-tensor absmax known: fp16 three-product kernels
+        if (NT == 2) hipLaunchKernelGGL((k_conv5x5_sb<2, 2>), dim3(grid3), dim3(768), lds, s, a, nrows);
+        else hipLaunchKernelGGL((k_conv5x5_sb<1, 2>), dim3(grid3), dim3(768), lds, s, a, nrows);
+    }
+    else if (NT == 2 && nprod == 6) hipLaunchKernelGGL((k_conv5x5_sb<2, 0>), dim3(grid3), dim3(768), lds, s, a, nrows);
+    else if (NT == 2) hipLaunchKernelGGL((k_conv5x5_sb<2, 1>), dim3(grid3), dim3(768), lds, s, a, nrows);
+    else if (nprod == 6) hipLaunchKernelGGL((k_conv5x5_sb<1, 0>), dim3(grid3), dim3(768), lds, s, a, nrows);
+    else hipLaunchKernelGGL((k_conv5x5_sb<1, 1>), dim3(grid3), dim3(768), lds, s, a, nrows);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }
@@ -495,6 +663,18 @@ int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles) {
 int sol_bww_sb_launch(hipStream_t s, const BwArgs& a, int nblk_run) {
     if (int e = init_sb_kernels()) return e;
     hipLaunchKernelGGL(k_conv5x5_bww_sb, dim3(nblk_run), dim3(512), BW_LDS, s, a);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
+// internal (train.hip): pack `n` (layer, mode) jobs in one launch; out buffers sized by sol_conv5x5_packed_floats
+int sol_pack_jobs(hipStream_t s, int n, const float* const* w, float* const* out, float* const* bias_out, const float* const* bias_in,
+                  const int* cin, const int* cout, const int* mode) {
+    SOL_REQUIRE(n >= 1 && n <= 24, "sol_pack_jobs: 1..24 jobs (got %d)", n);
+    PackJobs jobs{};
+    jobs.n = n;
+    for (int k = 0; k < n; ++k) jobs.j[k] = PackJob{w[k], out[k], bias_out[k], bias_in[k], cin[k], cout[k], mode[k]};
+    hipLaunchKernelGGL(k_pack_jobs, dim3(n * PACK_WG), dim3(256), 0, s, jobs);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }

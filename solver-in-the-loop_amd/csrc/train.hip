@@ -149,6 +149,8 @@ struct Ws {
     float *gA, *gB;                // [cells][32]
     float *dO4, *dO2, *dF;         // [cells][4], [msteps][cells][2], [cells][2]
     float *dzb;                    // [msteps][11][cells][32]: pre-activation gradients kept for the batched weight gradient
+    uint32_t *amax_act, *amax_dz;  // [msteps][11][64]: absmax slots of every 32-channel activation / gradient tensor
+    size_t amax_words;             // (both arrays are contiguous: one memset per training step)
     float *gvy[2], *gvx[2];
     float *wf[NL], *wb[NL], *bias[NL];
     float *part[NL];
@@ -175,6 +177,9 @@ size_t carve_ws(const sol_train_cfg* c, float* base, Ws& w, bool training) {
     w.gA = take(w.cells * 32); w.gB = take(w.cells * 32);
     w.dO4 = take(w.cells * 4); w.dO2 = take((size_t)ms * w.cells * 2); w.dF = take(w.cells * 2);
     w.dzb = take(training ? (size_t)ms * 11 * w.cells * 32 : 0);
+    w.amax_words = (size_t)ms * 11 * SOL_AMAX_SLOTS;
+    w.amax_act = reinterpret_cast<uint32_t*>(take(w.amax_words));
+    w.amax_dz = reinterpret_cast<uint32_t*>(take(training ? w.amax_words : 0));
     for (int k = 0; k < 2; ++k) { w.gvy[k] = take(w.st_vy); w.gvx[k] = take(w.st_vx); }
     for (int l = 0; l < NL; ++l) {
         const int cin = layer_cin(l), cout = layer_cout(l);
@@ -190,31 +195,36 @@ size_t carve_ws(const sol_train_cfg* c, float* base, Ws& w, bool training) {
 }
 
 int pack_all(const sol_train_cfg* /*c*/, void* stream, const float* params, Ws& w, bool bwd) {
+    // every layer, forward and backward-data form, fp32 + split-bf16 + split-fp16 sections and the padded biases: ONE launch
+    const float* src[24]; float* out[24]; float* bo[24]; const float* bi[24];
+    int cin[24], cout[24], mode[24], n = 0;
     for (int l = 0; l < NL; ++l) {
-        const int cin = layer_cin(l), cout = layer_cout(l);
-        const int64_t koff = layer_koff(l), boff = koff + 25 * cin * cout;
-        if (int e = sol_conv5x5_pack(stream, params + koff, cin, cout, SOL_CONV_FWD, w.wf[l])) return e;
-        if (bwd) {
-            // run-conv of backward-data: input channels = forward cout, output channels = forward cin
-            if (int e = sol_conv5x5_pack(stream, params + koff, cout, cin, SOL_CONV_BWD_DATA, w.wb[l])) return e;
+        const int ci = layer_cin(l), co = layer_cout(l);
+        const int64_t koff = layer_koff(l), boff = koff + 25 * ci * co;
+        src[n] = params + koff; out[n] = w.wf[l]; bo[n] = w.bias[l]; bi[n] = params + boff; cin[n] = ci; cout[n] = co; mode[n] = SOL_CONV_FWD; ++n;
+        if (bwd) {   // run-conv of backward-data: input channels = forward cout, output channels = forward cin
+            src[n] = params + koff; out[n] = w.wb[l]; bo[n] = nullptr; bi[n] = nullptr; cin[n] = co; cout[n] = ci; mode[n] = SOL_CONV_BWD_DATA; ++n;
         }
-        hipLaunchKernelGGL(k_pad_bias, dim3(1), dim3(64), 0, (hipStream_t)stream, params, w.bias[l], boff, cout);
-        SOL_LAUNCH_CHECK();
     }
-    return SOL_OK;
+    return sol_pack_jobs((hipStream_t)stream, n, src, out, bo, bi, cin, cout, mode);
 }
 
 // CNN forward (model_mars_moon, karman_train.py:101-138).  acts: 11 buffers [cells][32].
-int net_forward(const sol_train_cfg* c, void* s, const Ws& w, const float* feat, float* const* act, float* O) {
+// amax: [11][64] absmax slots of act[0..10] (zeroed by the caller): every producer publishes max|y| and every
+// 32-channel consumer derives its fp16 operand scale from it (sol_conv5x5_scaled).
+int net_forward(const sol_train_cfg* c, void* s, const Ws& w, const float* feat, float* const* act, float* O, uint32_t* amax) {
     const int B = c->karman.B, Y = c->karman.Y, X = c->karman.X;
     const float sl = c->lrelu_slope;
-    if (int e = sol_conv5x5(s, feat, w.wf[0], w.bias[0], nullptr, nullptr, act[0], B, Y, X, 4, 32, SOL_EPI_LRELU, sl)) return e;
+    auto am = [&](int k) { return amax ? amax + (size_t)k * SOL_AMAX_SLOTS : nullptr; };
+    if (int e = sol_conv5x5_scaled(s, feat, w.wf[0], w.bias[0], nullptr, nullptr, act[0], B, Y, X, 4, 32, SOL_EPI_LRELU, sl, nullptr, am(0))) return e;
     for (int k = 0; k < 5; ++k) {
         const float* h = act[2 * k];
-        if (int e = sol_conv5x5(s, h, w.wf[1 + 2 * k], w.bias[1 + 2 * k], nullptr, nullptr, act[1 + 2 * k], B, Y, X, 32, 32, SOL_EPI_LRELU, sl)) return e;
-        if (int e = sol_conv5x5(s, act[1 + 2 * k], w.wf[2 + 2 * k], w.bias[2 + 2 * k], h, nullptr, act[2 + 2 * k], B, Y, X, 32, 32, SOL_EPI_LRELU, sl)) return e;
+        if (int e = sol_conv5x5_scaled(s, h, w.wf[1 + 2 * k], w.bias[1 + 2 * k], nullptr, nullptr, act[1 + 2 * k], B, Y, X, 32, 32, SOL_EPI_LRELU, sl,
+                                       am(2 * k), am(1 + 2 * k))) return e;
+        if (int e = sol_conv5x5_scaled(s, act[1 + 2 * k], w.wf[2 + 2 * k], w.bias[2 + 2 * k], h, nullptr, act[2 + 2 * k], B, Y, X, 32, 32, SOL_EPI_LRELU, sl,
+                                       am(1 + 2 * k), am(2 + 2 * k))) return e;
     }
-    return sol_conv5x5(s, act[10], w.wf[11], w.bias[11], nullptr, nullptr, O, B, Y, X, 32, 2, SOL_EPI_NONE, sl);
+    return sol_conv5x5_scaled(s, act[10], w.wf[11], w.bias[11], nullptr, nullptr, O, B, Y, X, 32, 2, SOL_EPI_NONE, sl, am(10), nullptr);
 }
 
 int check_train_cfg(const sol_train_cfg* c) {
@@ -336,7 +346,7 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
                                         feat, fscale, io.iters_fwd ? io.iters_fwd + (size_t)i * Btot + b0 : nullptr)) return e;
         float* act[11];
         for (int k = 0; k < 11; ++k) act[k] = w.acts + ((size_t)i * 11 + k) * w.cells * 32;
-        if (int e = net_forward(c, stream, wn, feat, act, w.O)) return e;
+        if (int e = net_forward(c, stream, wn, feat, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS)) return e;
         hipLaunchKernelGGL(k_correct_loss, dim3(egrid), dim3(256), 0, hs, vycur, vxcur, w.O,
                            gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx,
                            c->std_v0, c->std_v1, io.loss_steps + i, B, Y, X);
@@ -381,12 +391,16 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
             act[k] = w.acts + ((size_t)i * 11 + k) * cl32;
             D[k] = w.dzb + ((size_t)i * 11 + k) * cl32;
         }
-        if (int e = sol_conv5x5(stream, w.dO4, wn.wb[11], nullptr, nullptr, act[10], D[10], B, Y, X, 4, 32, SOL_EPI_DLRELU, sl)) return e;
+        uint32_t* amd = w.amax_dz + (size_t)i * 11 * SOL_AMAX_SLOTS;
+        auto am = [&](int k) { return amd + (size_t)k * SOL_AMAX_SLOTS; };
+        if (int e = sol_conv5x5_scaled(stream, w.dO4, wn.wb[11], nullptr, nullptr, act[10], D[10], B, Y, X, 4, 32, SOL_EPI_DLRELU, sl, nullptr, am(10))) return e;
         for (int k = 4; k >= 0; --k) {
             const float* h = act[2 * k];
             const float* a = act[1 + 2 * k];
-            if (int e = sol_conv5x5(stream, D[2 + 2 * k], wn.wb[2 + 2 * k], nullptr, nullptr, a, D[1 + 2 * k], B, Y, X, 32, 32, SOL_EPI_DLRELU, sl)) return e;
-            if (int e = sol_conv5x5(stream, D[1 + 2 * k], wn.wb[1 + 2 * k], nullptr, D[2 + 2 * k], h, D[2 * k], B, Y, X, 32, 32, SOL_EPI_DLRELU, sl)) return e;
+            if (int e = sol_conv5x5_scaled(stream, D[2 + 2 * k], wn.wb[2 + 2 * k], nullptr, nullptr, a, D[1 + 2 * k], B, Y, X, 32, 32, SOL_EPI_DLRELU, sl,
+                                           am(2 + 2 * k), am(1 + 2 * k))) return e;
+            if (int e = sol_conv5x5_scaled(stream, D[1 + 2 * k], wn.wb[1 + 2 * k], nullptr, D[2 + 2 * k], h, D[2 * k], B, Y, X, 32, 32, SOL_EPI_DLRELU, sl,
+                                           am(1 + 2 * k), am(2 * k))) return e;
         }
         if (i % CH == 0) {
             // every dz of steps [i, i+CH) is final: their weight gradients go to the side stream
@@ -407,7 +421,7 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
             if (int e = sol_bww_batched(bs, acts_i + (size_t)10 * cl32, w.dO2 + (size_t)i * w.cells * 2, w.part[11], n, CH, first, seg32, (long)(w.cells * 2), B, Y, X, 32, 2)) return e;
         }
         if (i > 0) {
-            if (int e = sol_conv5x5(stream, D[0], wn.wb[0], nullptr, nullptr, nullptr, w.dF, B, Y, X, 32, 2, SOL_EPI_NONE, sl)) return e;
+            if (int e = sol_conv5x5_scaled(stream, D[0], wn.wb[0], nullptr, nullptr, nullptr, w.dF, B, Y, X, 32, 2, SOL_EPI_NONE, sl, am(0), nullptr)) return e;
             if (int e = sol_karman_step_bwd(kc, stream, w.svy + (size_t)i * w.st_vy, w.svx + (size_t)i * w.st_vx, re, io.active,
                                             bcm, io.bc_stride, gvy, gvx, w.dF, fscale, w.gvy[cur ^ 1], w.gvx[cur ^ 1],
                                             io.iters_bwd ? io.iters_bwd + (size_t)i * Btot + b0 : nullptr)) return e;
@@ -440,6 +454,7 @@ int train_fwd_bwd_impl(const sol_train_cfg* cfg, hipStream_t hs, const TrainIO& 
     SOL_HIP_CHECK(hipMemsetAsync(io.loss_steps, 0, ms * sizeof(float), hs));
     for (int k = 0; k < S; ++k) {
         SOL_HIP_CHECK(hipMemsetAsync(w[k].dO4, 0, w[k].cells * 4 * sizeof(float), hs));
+        SOL_HIP_CHECK(hipMemsetAsync(w[k].amax_act, 0, 2 * w[k].amax_words * sizeof(uint32_t), hs));   // activation + gradient absmax slots
     }
     if (io.iters_bwd) SOL_HIP_CHECK(hipMemsetAsync(io.iters_bwd, 0, B * sizeof(int32_t), hs));   // step 0 needs no adjoint
     if (S == 1) {
@@ -573,7 +588,8 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
         if (int e = sol_karman_step_fwd(kc, stream, d, vy, vx, re, active, inflow, velBCy, velBCyMask, bc_batch_stride,
                                         w.d, w.vy, w.vx, nullptr, nullptr, w.feat, fscale,
                                         iters ? iters + (size_t)i * B : nullptr)) return e;
-        if (int e = net_forward(cfg, stream, w, w.feat, act, w.O)) return e;
+        SOL_HIP_CHECK(hipMemsetAsync(w.amax_act, 0, (size_t)11 * SOL_AMAX_SLOTS * sizeof(uint32_t), hs));
+        if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, w.amax_act)) return e;
         hipLaunchKernelGGL(k_correct_loss, dim3(egrid), dim3(256), 0, hs, w.vy, w.vx, w.O,
                            (const float*)nullptr, (const float*)nullptr, cfg->std_v0, cfg->std_v1, (float*)nullptr, B, Y, X);
         SOL_LAUNCH_CHECK();

@@ -59,3 +59,33 @@ for (B, Y, X) in [(2, 128, 64), (6, 128, 64), (24, 128, 64)]:
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     print("bww B%d %dx%d: dw rel L2 %.3e  db rel %.3e  %.1f us  %.1f TF" % (B, Y, X, e_w, e_b, us, 2.0 * 25 * 1024 * B * Y * X / us / 1e6))
+
+# ---- fp16 three-product path (sol_conv5x5_scaled with the absmax of x) ----------------------------
+print("fp16 x3 path (sol_conv5x5_scaled):")
+for (B, Y, X, cout, dist) in [(6, 128, 64, 32, "normal"), (6, 128, 64, 32, "wide"), (2, 128, 64, 2, "normal"), (1, 16, 64, 32, "tiny")]:
+    x = torch.randn(B, Y, X, 32, device="cuda")
+    if dist == "wide":
+        x = x * torch.exp(3 * torch.randn_like(x))
+    if dist == "tiny":
+        x = x * 1e-7
+    w = torch.randn(5, 5, 32, cout, device="cuda") * 0.05
+    bias = torch.randn(cout, device="cuda") * (1e-9 if dist == "tiny" else 0.1)
+    packed = ops._pack(w, 32, cout, ops.CONV_FWD)
+    xmax = torch.zeros(64, dtype=torch.int32, device="cuda")
+    xmax[0] = int(x.abs().max().view(torch.int32).item())
+    ymax = torch.zeros(64, dtype=torch.int32, device="cuda")
+    y = torch.empty(B, Y, X, cout, device="cuda")
+    call = lambda: check(lib.sol_conv5x5_scaled(stream(), ptr(x), ptr(packed), ptr(bias), None, None, ptr(y), B, Y, X, 32, cout,
+                                                 ops.EPI_NONE, 0.3, ptr(xmax), ptr(ymax)))
+    call()
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), bias.double(), padding=2).permute(0, 2, 3, 1)
+    err = ((y.double() - ref).norm() / ref.norm()).item()
+    got_max = float(ymax.max().view(torch.float32).item())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    call(); torch.cuda.synchronize(); e0.record()
+    for _ in range(50):
+        call()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 50 * 1e3
+    print("  B%d %dx%d 32->%d %-6s: rel L2 %.3e  ymax %.6g (true %.6g)  %.1f us  %.1f TF" % (
+        B, Y, X, cout, dist, err, got_max, float(y.abs().max()), us, 2.0 * 25 * 32 * cout * B * Y * X / us / 1e6))
