@@ -14,7 +14,8 @@ int sol_density_chain(const sol_karman_cfg* c, void* stream, int ms, const float
                       long st_vy, long st_vx, const float* inflow, float* d_steps, long st_d, float* d_final);
 size_t sol_bww_batched_ws_floats(int nseg, int B, int H, int cin, int cout);
 int sol_bww_batched(void* stream, const float* x, const float* dz, float* partial, int nseg, int nseg_layout, int overwrite,
-                    long x_seg, long dz_seg, int B, int H, int W, int cin, int cout);
+                    long x_seg, long dz_seg, int B, int H, int W, int cin, int cout,
+                    const unsigned* xmax = nullptr, const unsigned* zmax = nullptr, long xmax_seg = 0, long zmax_seg = 0);
 int sol_bww_batched_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int nseg, int B, int H,
                            int cin, int cout, int accumulate);
 
@@ -41,6 +42,8 @@ struct BwArgs {
     int nseg, rb;                 // nseg tensors of B*H rows each (the unrolled steps), rb image rows per workgroup
     long x_seg, dz_seg;           // element strides between consecutive segments
     int overwrite;                // 1: partial = acc (single launch), 0: partial += acc (accumulate over launches)
+    const unsigned *xmax, *zmax;  // absmax slots of segment 0 of x / dz (NULL: bf16 six-product kernel) ...
+    long xmax_seg, zmax_seg;      // ... and their strides (uint32 words) between consecutive segments
 };
 int sol_bww_sb_launch(hipStream_t s, const BwArgs& a, int nblk_run);
 // split-bf16 section of the packed weights and the kernels that consume it (conv5x5_sb.hip)

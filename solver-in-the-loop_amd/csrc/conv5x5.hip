@@ -1055,7 +1055,8 @@ size_t sol_bww_batched_ws_floats(int nseg, int B, int H, int cin, int cout) {
 }
 
 static int bww_launch(void* stream, const float* x, const float* dz, float* partial, int nseg, long x_seg, long dz_seg,
-                      int rb, int overwrite, int B, int H, int W, int cin, int cout, int nblk_layout = 0) {
+                      int rb, int overwrite, int B, int H, int W, int cin, int cout, int nblk_layout = 0,
+                      const unsigned* xmax = nullptr, const unsigned* zmax = nullptr, long xmax_seg = 0, long zmax_seg = 0) {
     SOL_REQUIRE(x && dz && partial, "sol_conv5x5_bwd_weight: NULL pointer");
     SOL_REQUIRE(B >= 1 && H >= 1 && W >= 4 && W % 4 == 0 && W <= 64, "sol_conv5x5_bwd_weight: need 4 <= W <= 64, W %% 4 == 0 (got %d)", W);
     SOL_REQUIRE((cin == 4 || cin == 32) && (cout == 2 || cout == 32),
@@ -1063,6 +1064,7 @@ static int bww_launch(void* stream, const float* x, const float* dz, float* part
     BwArgs a{};
     a.x = x; a.dz = dz; a.partial = partial; a.B = B; a.H = H; a.W = W; a.cin = cin; a.cout = cout;
     a.nseg = nseg; a.rb = rb; a.x_seg = x_seg; a.dz_seg = dz_seg; a.overwrite = overwrite;
+    a.xmax = xmax; a.zmax = zmax; a.xmax_seg = xmax_seg; a.zmax_seg = zmax_seg;
     int IP, OP;
     bww_dims(nseg * B * H, rb, cin, cout, &a.nblk, &IP, &OP);
     const int nblk_run = a.nblk;                    // workgroups needed for this launch's rows
@@ -1106,11 +1108,12 @@ extern "C" int sol_conv5x5_bwd_weight(void* stream, const float* x, const float*
 // buffer is laid out for `nseg_layout` >= nseg segments (several chunk launches accumulate into it:
 // overwrite = 1 for the first chunk, 0 afterwards).
 int sol_bww_batched(void* stream, const float* x, const float* dz, float* partial, int nseg, int nseg_layout, int overwrite,
-                    long x_seg, long dz_seg, int B, int H, int W, int cin, int cout) {
+                    long x_seg, long dz_seg, int B, int H, int W, int cin, int cout,
+                    const unsigned* xmax, const unsigned* zmax, long xmax_seg, long zmax_seg) {
     const int rb = pick_rb(nseg_layout * B * H);
     int nblk, IP, OP;
     bww_dims(nseg_layout * B * H, rb, cin, cout, &nblk, &IP, &OP);
-    return bww_launch(stream, x, dz, partial, nseg, x_seg, dz_seg, rb, overwrite, B, H, W, cin, cout, nblk);
+    return bww_launch(stream, x, dz, partial, nseg, x_seg, dz_seg, rb, overwrite, B, H, W, cin, cout, nblk, xmax, zmax, xmax_seg, zmax_seg);
 }
 
 static int bww_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int rows, int rb, int cin, int cout, int accumulate) {

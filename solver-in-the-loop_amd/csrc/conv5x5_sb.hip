@@ -70,6 +70,15 @@ __device__ __forceinline__ void split2h(float x, float y, float scale, unsigned&
     const f16x2 h = __builtin_bit_cast(f16x2, p1);
     p2 = pk_f16((xs - (float)h.x) * 2048.f, (ys - (float)h.y) * 2048.f);
 }
+// KIND-2 split of the weight-gradient kernel: lo plane NOT pre-scaled (one accumulator for all three products);
+// elements below 2^-19 of the tensor maximum lose their lo part to fp16 underflow -- an absolute error < 2^-30 max|v|.
+__device__ __forceinline__ void split2u(float x, float y, float scale, unsigned& p1, unsigned& p2) {
+    const float xs = x * scale, ys = y * scale;
+    p1 = pk_f16(xs, ys);
+    const f16x2 h = __builtin_bit_cast(f16x2, p1);
+    p2 = pk_f16(xs - (float)h.x, ys - (float)h.y);
+}
+
 __global__ void k_absmax(const float* __restrict__ x, size_t n, unsigned* __restrict__ slots) {
     __shared__ float red[16];
     float m = 0.f;
@@ -366,12 +375,17 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
 // renaming (dx even) -- no unaligned LDS access and the x operand is reused for all five tap rows.
 // LDS rows: x 16 chunks of 16 B per channel (68 px used), chunk ^= ci & 15; dz 8 chunks, chunk ^= (co >> 1) & 7
 // (both conflict-free for the CDNA4 ds_read_b128 lane groups).
-constexpr int BW_XPL = 32 * 256, BW_XST = 3 * BW_XPL;     // bytes: x plane / x row stage
-constexpr int BW_ZPL = 32 * 128, BW_ZST = 3 * BW_ZPL;     // bytes: dz plane / dz row stage
-constexpr int BW_LDS = 2 * BW_XST + 6 * BW_ZST;           // 122,880 B
+constexpr int BW_XPL = 32 * 256;                          // bytes: x plane of one row stage
+constexpr int BW_ZPL = 32 * 128;                          // bytes: dz plane of one row stage
+constexpr int BW_LDS = 2 * 3 * BW_XPL + 6 * 3 * BW_ZPL;   // 122,880 B (three planes; also >= the 102,400 B fold buffer)
 
+// KIND 0: bf16 planes x3, six products;  KIND 2: fp16 planes x2 scaled per segment by the absmax of x / dz, three products
+// (the host guarantees that a workgroup's rows lie in ONE segment)
+template <int KIND>
 __global__ void __launch_bounds__(512) k_conv5x5_bww_sb(BwArgs a) {
     constexpr int W = 64;
+    constexpr int NPL = KIND == 2 ? 2 : 3;
+    constexpr int BW_XST = NPL * BW_XPL, BW_ZST = NPL * BW_ZPL;
     extern __shared__ __align__(16) unsigned char smem_sb[];
     unsigned char* const XS = smem_sb;
     unsigned char* const ZS = smem_sb + 2 * BW_XST;
@@ -388,6 +402,14 @@ __global__ void __launch_bounds__(512) k_conv5x5_bww_sb(BwArgs a) {
     const int pxg = it >> 3, c4 = it & 7;
     float4 sv[4];
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    float sx = 1.f, sz = 1.f, out_scale = 1.f;
+    if constexpr (KIND == 2) {
+        const int seg0 = r0 / RPS;
+        float ix, iz;
+        amax_scale(a.xmax + (size_t)seg0 * a.xmax_seg, sx, ix);
+        amax_scale(a.zmax + (size_t)seg0 * a.zmax_seg, sz, iz);
+        out_scale = ix * iz;
+    }
 
     auto row_ptr = [&](const float* base, long seg_stride, int gr) {
         const int seg = gr / RPS, grs = gr - seg * RPS;
@@ -414,12 +436,18 @@ __global__ void __launch_bounds__(512) k_conv5x5_bww_sb(BwArgs a) {
         for (int c = 0; c < 4; ++c) {
             const int ch = 4 * c4 + c;
             unsigned p[3][2];
-            split3(e[c][0], e[c][1], p[0][0], p[1][0], p[2][0]);
-            split3(e[c][2], e[c][3], p[0][1], p[1][1], p[2][1]);
+            if constexpr (KIND == 2) {
+                const float sc = is_x ? sx : sz;
+                split2u(e[c][0], e[c][1], sc, p[0][0], p[1][0]);
+                split2u(e[c][2], e[c][3], sc, p[0][1], p[1][1]);
+            } else {
+                split3(e[c][0], e[c][1], p[0][0], p[1][0], p[2][0]);
+                split3(e[c][2], e[c][3], p[0][1], p[1][1], p[2][1]);
+            }
             const int sw = is_x ? (ch & 15) : ((ch >> 1) & 7);
             unsigned char* q = base + ch * row_bytes + ((((pxg >> 1) ^ sw) << 4) | ((pxg & 1) << 3));
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(q + pl * plane_bytes) = make_uint2(p[pl][0], p[pl][1]);
+            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint2*>(q + pl * plane_bytes) = make_uint2(p[pl][0], p[pl][1]);
         }
     };
     auto store_x = [&](int gr) { store_item(XS + (gr & 1) * BW_XST, BW_XPL, 256, true); };
@@ -465,11 +493,11 @@ __global__ void __launch_bounds__(512) k_conv5x5_bww_sb(BwArgs a) {
         if (zrole && nz) load_z(gr + 3);
 
         // x operand of this lane: pixels 8*c0 .. 8*c0+11 (halo coordinates) of channel 16*mt + li, three planes
-        uint4 A[3][5];
+        uint4 A[NPL][5];
         {
             const unsigned char* xs = XS + (gr & 1) * BW_XST + (16 * mt + li) * 256;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NPL; ++pl) {
                 const uint4 q = *reinterpret_cast<const uint4*>(xs + pl * BW_XPL + ((c0 ^ li) << 4));
                 const uint2 e = *reinterpret_cast<const uint2*>(xs + pl * BW_XPL + (((c0 + 1) ^ li) << 4));
                 A[pl][0] = q;
@@ -487,15 +515,25 @@ __global__ void __launch_bounds__(512) k_conv5x5_bww_sb(BwArgs a) {
             if (yz < 0 || yz >= H) continue;            // workgroup uniform
             const int gz = gr + 2 - dy;
             const unsigned char* zs = ZS + ((gz + 6) % 6) * BW_ZST + (16 * nt + li) * 128 + ((c0 ^ ((li >> 1) & 7)) << 4);
-            bf16x8 Bv[3];
+            uint4 Bv[NPL];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) Bv[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(zs + pl * BW_ZPL));
+            for (int pl = 0; pl < NPL; ++pl) Bv[pl] = *reinterpret_cast<const uint4*>(zs + pl * BW_ZPL);
+            if constexpr (KIND == 2) {
+                constexpr int QA[3] = {1, 0, 0}, QB[3] = {0, 1, 0};     // a2 b1, a1 b2, a1 b1
 #pragma unroll
-            for (int pr = 0; pr < 6; ++pr)
+                for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
-                for (int dx = 0; dx < 5; ++dx)
-                    acc[dy * 5 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[PA[pr]][dx]), Bv[PB[pr]],
-                                                                               acc[dy * 5 + dx], 0, 0, 0);
+                    for (int dx = 0; dx < 5; ++dx)
+                        acc[dy * 5 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[QA[pr]][dx]), __builtin_bit_cast(f16x8, Bv[QB[pr]]),
+                                                                                  acc[dy * 5 + dx], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                    for (int dx = 0; dx < 5; ++dx)
+                        acc[dy * 5 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[PA[pr]][dx]), __builtin_bit_cast(bf16x8, Bv[PB[pr]]),
+                                                                                   acc[dy * 5 + dx], 0, 0, 0);
+            }
         }
         if (xrole && nx) store_x(gr + 1);
         if (zrole && nz) store_z(gr + 3);
@@ -517,7 +555,7 @@ __global__ void __launch_bounds__(512) k_conv5x5_bww_sb(BwArgs a) {
         for (int tp = 0; tp < 25; ++tp)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = acc[tp][r] + red[((wave & 3) * 25 + tp) * 256 + (4 * g + r) * 16 + li];
+                const float v = (acc[tp][r] + red[((wave & 3) * 25 + tp) * 256 + (4 * g + r) * 16 + li]) * out_scale;
                 float* dst = &pw[(tp * 32 + 16 * mt + 4 * g + r) * 32 + 16 * nt + li];
                 *dst = a.overwrite ? v : *dst + v;
             }
@@ -601,7 +639,7 @@ constexpr size_t sb_lds(int OP) { return (size_t)4 * 3 * 68 * 64 + 2 * (size_t)5
 
 int init_sb_kernels() {
     static int rc = [] {
-        const void* ks[] = {reinterpret_cast<const void*>(k_conv5x5_bww_sb), reinterpret_cast<const void*>(k_conv5x5_sb<1, 0>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 0>),
+        const void* ks[] = {reinterpret_cast<const void*>(k_conv5x5_bww_sb<0>), reinterpret_cast<const void*>(k_conv5x5_bww_sb<2>), reinterpret_cast<const void*>(k_conv5x5_sb<1, 0>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 0>),
                             reinterpret_cast<const void*>(k_conv5x5_sb<1, 1>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 1>),
                             reinterpret_cast<const void*>(k_conv5x5_sb<1, 2>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 2>)};
         for (const void* k : ks)
@@ -662,7 +700,10 @@ int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles) {
 
 int sol_bww_sb_launch(hipStream_t s, const BwArgs& a, int nblk_run) {
     if (int e = init_sb_kernels()) return e;
-    hipLaunchKernelGGL(k_conv5x5_bww_sb, dim3(nblk_run), dim3(512), BW_LDS, s, a);
+    static const bool use_sh = !getenv("SOL_CONV_NO_FP16");
+    // fp16 three-product kernel: absmax of both operands known and no workgroup straddles two segments
+    if (use_sh && a.xmax && a.zmax && (a.B * a.H) % a.rb == 0) hipLaunchKernelGGL(k_conv5x5_bww_sb<2>, dim3(nblk_run), dim3(512), BW_LDS, s, a);
+    else hipLaunchKernelGGL(k_conv5x5_bww_sb<0>, dim3(nblk_run), dim3(512), BW_LDS, s, a);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }

@@ -416,8 +416,11 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
             const float* acts_i = w.acts + (size_t)i * 11 * cl32;
             const float* dz_i = w.dzb + (size_t)i * 11 * cl32;
             if (int e = sol_bww_batched(bs, feat_i, dz_i, w.part[0], n, CH, first, (long)(w.cells * 4), seg32, B, Y, X, 4, 32)) return e;
+            const long amseg = 11 * SOL_AMAX_SLOTS;      // absmax slots: [step][11][64]
             for (int l = 1; l <= 10; ++l)
-                if (int e = sol_bww_batched(bs, acts_i + (size_t)(l - 1) * cl32, dz_i + (size_t)l * cl32, w.part[l], n, CH, first, seg32, seg32, B, Y, X, 32, 32)) return e;
+                if (int e = sol_bww_batched(bs, acts_i + (size_t)(l - 1) * cl32, dz_i + (size_t)l * cl32, w.part[l], n, CH, first, seg32, seg32, B, Y, X, 32, 32,
+                                            w.amax_act + ((size_t)i * 11 + (l - 1)) * SOL_AMAX_SLOTS, w.amax_dz + ((size_t)i * 11 + l) * SOL_AMAX_SLOTS,
+                                            amseg, amseg)) return e;
             if (int e = sol_bww_batched(bs, acts_i + (size_t)10 * cl32, w.dO2 + (size_t)i * w.cells * 2, w.part[11], n, CH, first, seg32, (long)(w.cells * 2), B, Y, X, 32, 2)) return e;
         }
         if (i > 0) {
