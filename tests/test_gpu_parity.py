@@ -238,6 +238,61 @@ def test_train_step_c2_config_and_adam(clip):
     assert rel(upd, upd_ref) < 1e-3
 
 
+def test_train_step_full_size_against_oracle():
+    """BASELINE configs[2] grid (128x64) through the fused trainer: direct pressure solver, fp16/bf16 split-MFMA convolutions
+    scaled by the absmax the producer kernels publish, weight gradients batched over the unrolled steps, density chain --
+    loss, per-step losses, the full gradient and the final state against the float64 oracle (B=2, msteps=2)."""
+    B, Y, X, ms = 2, 128, 64, 2
+    g, d, vy, vx, re, gts, params, std_v, loss = _oracle_problem(B, Y, X, ms)
+    net, tr = _trainer_from(params, g, B, Y, X, ms, std_v)
+    assert tr.masks.direct is not None
+    hl = tr.fwd_bwd(f32(d), f32(vy), f32(vx), f32(re), f32(torch.stack([s[1] for s in gts])), f32(torch.stack([s[2] for s in gts])),
+                    want_final=True)
+    gref = torch.cat([p.grad.reshape(-1) for p in params])
+    assert abs(float(hl) - float(loss)) < 1e-5 * abs(float(loss))
+    assert rel(tr.grads, gref) < TOL_GRAD
+    off = net.offsets
+    per_tensor = [rel(tr.grads[off[k]:off[k + 1]], params[k].grad.reshape(-1)) for k in range(len(params))]
+    assert max(per_tensor) < 3 * TOL_GRAD, per_tensor
+    assert int(tr.iters_fwd.max()) == 0 and int(tr.iters_bwd.max()) == 0          # direct solver: no CG iterations
+    # final state: roll the oracle forward with the same weights
+    with torch.no_grad():
+        rd, ry, rx = d, vy, vx
+        for _ in range(ms):
+            rd, ry, rx = o.karman_step(rd, ry, rx, re, g)
+            cy, cx = o.correction([p.detach() for p in params], ry, rx, re, std_v, o.STD_RE)
+            ry, rx = ry + cy, rx + cx
+    assert rel(tr.final[1], ry) < TOL_FIELD and rel(tr.final[2], rx) < TOL_FIELD and rel(tr.final[0], rd) < TOL_FIELD
+
+
+def test_conv5x5_scaled_fp16_path_against_float64():
+    """sol_conv5x5_scaled: three fp16 MFMA products with the power-of-two scale from the absmax slots, for well and
+    badly conditioned dynamic ranges; also checks the absmax the kernel publishes for its own output."""
+    import ctypes as C
+    from sol_amd._lib import ptr, stream, check
+    lib = sol_amd.load()
+    gen = torch.Generator().manual_seed(11)
+    for scale, heavy in [(1.0, False), (1e-6, False), (3e4, False), (1.0, True)]:
+        B, Y, X, cout = 2, 32, 64, 32
+        x = torch.randn(B, Y, X, 32, generator=gen)
+        if heavy:
+            x = x * torch.exp(2.0 * torch.randn(B, Y, X, 32, generator=gen))
+        x = (x * scale).float().to(DEV)
+        w = (torch.randn(5, 5, 32, cout, generator=gen) * 0.05).float().to(DEV)
+        bias = torch.zeros(cout, dtype=torch.float32, device=DEV)
+        packed = ops._pack(w, 32, cout, ops.CONV_FWD)
+        xmax = torch.zeros(64, dtype=torch.int32, device=DEV)
+        xmax[5] = int(x.abs().max().view(torch.int32).item())              # any slot: the consumer takes the max over all 64
+        ymax = torch.zeros(64, dtype=torch.int32, device=DEV)
+        y = torch.empty(B, Y, X, cout, dtype=torch.float32, device=DEV)
+        check(lib.sol_conv5x5_scaled(stream(), ptr(x), ptr(packed), ptr(bias), None, None, ptr(y), B, Y, X, 32, cout,
+                                     ops.EPI_LRELU, 0.3, ptr(xmax), ptr(ymax)))
+        ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), None, padding=2).permute(0, 2, 3, 1)
+        ref = torch.nn.functional.leaky_relu(ref, 0.3)
+        assert rel(y, ref) < 1e-6, (scale, heavy, rel(y, ref))
+        assert float(ymax.max().view(torch.float32).item()) == float(y.abs().max())
+
+
 def test_per_op_autograd_path_equals_fused_trainer():
     """The reference-shaped Python surface (KarmanFlow.step, to_feature, model, to_staggered) composed
     with torch autograd must give the same loss and gradient as the fused C++ training step."""
