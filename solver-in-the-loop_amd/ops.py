@@ -147,6 +147,24 @@ def conv5x5_raw(x, packed, bias, residual, act_ref, cout, epilogue, slope):
     return y
 
 
+def absmax_slots(x):
+    """[64] int32 slots holding the bit pattern of max|x| (the form sol_conv5x5_scaled consumes).  In the fused
+    trainer the producing kernel publishes this; here it costs one reduction pass."""
+    slots = torch.zeros(64, dtype=torch.int32, device=x.device)
+    slots[0] = x.detach().abs().max().to(torch.float32).view(torch.int32)
+    return slots
+
+
+def conv5x5_scaled_raw(x, packed, bias, residual, act_ref, cout, epilogue, slope, x_absmax, y_absmax=None):
+    """sol_conv5x5_scaled: fp16 three-product MFMA path when x_absmax is given (32 input channels, W % 64 == 0)."""
+    lib = _lib.load()
+    B, H, W, cin = x.shape
+    y = torch.empty(B, H, W, cout, dtype=torch.float32, device=x.device)
+    check(lib.sol_conv5x5_scaled(stream(), ptr(x), ptr(packed), ptr(bias), ptr(residual), ptr(act_ref), ptr(y),
+                                 B, H, W, cin, cout, epilogue, float(slope), ptr(x_absmax), ptr(y_absmax)))
+    return y
+
+
 class Conv5x5Fn(torch.autograd.Function):
     """y = act(conv5x5_same(x, w) + b (+ residual)), NHWC, w in Keras HWIO layout."""
 
