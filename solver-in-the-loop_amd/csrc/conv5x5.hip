@@ -131,22 +131,54 @@ __global__ void __launch_bounds__(256) k_conv5x5(ConvArgs a) {
 
     // ---- epilogue: bias, residual, LeakyReLU / LeakyReLU' ---------------------------------
     float vmax = 0.f;                                // max|y| of this thread (a.ymax)
+    if (CIN == 4 && a.CO == OP && TW == 64) {
+        // thin first layer / last backward-data layer (4 -> 32 channels): the launch is bound by its 6 MB of output, so the
+        // wave's [16 px][OP] tile is transposed through LDS and leaves as 16-byte pieces of full 128-byte pixels
+        __syncthreads();                             // every wave is done with the halo tile
+        float* tb = smem + wave * (16 * OP);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int co = n * 16 + li;
-        if (co >= a.CO) continue;
-        const float bias = a.bias ? a.bias[co] : 0.f;
+        for (int n = 0; n < NT; ++n) {
+            const float bias = a.bias ? a.bias[n * 16 + li] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qq = wave * 16 + 4 * g + r;
-            const int rr = qq / TW, cc = qq - rr * TW;
-            const size_t o = ((size_t)(b * H + y0 + rr) * W + x0 + cc) * a.CO + co;
-            float v = acc[n][r] + bias;
-            if (a.res) v += a.res[o];
-            if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
-            else if (a.epi == SOL_EPI_DLRELU) v *= (a.act[o] > 0.f ? 1.f : a.slope);
-            vmax = fmaxf(vmax, fabsf(v));
-            a.y[o] = v;
+            for (int r = 0; r < 4; ++r) tb[(4 * g + r) * OP + n * 16 + li] = acc[n][r] + bias;
+        }
+        constexpr int F4 = 16 * OP / 4 / 64;          // float4 per lane
+#pragma unroll
+        for (int n = 0; n < F4; ++n) {
+            const int e = lane + n * 64;
+            const int px = e / (OP / 4), c4 = e % (OP / 4);
+            float4 v = *reinterpret_cast<const float4*>(&tb[px * OP + c4 * 4]);
+            const size_t o4 = ((size_t)(b * H + y0) * W + x0 + wave * 16 + px) * (OP / 4) + c4;
+            if (a.res) { const float4 q = reinterpret_cast<const float4*>(a.res)[o4]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+            if (a.epi == SOL_EPI_LRELU) {
+                v.x = v.x > 0.f ? v.x : a.slope * v.x; v.y = v.y > 0.f ? v.y : a.slope * v.y;
+                v.z = v.z > 0.f ? v.z : a.slope * v.z; v.w = v.w > 0.f ? v.w : a.slope * v.w;
+            } else if (a.epi == SOL_EPI_DLRELU) {
+                const float4 q = reinterpret_cast<const float4*>(a.act)[o4];
+                v.x *= q.x > 0.f ? 1.f : a.slope; v.y *= q.y > 0.f ? 1.f : a.slope;
+                v.z *= q.z > 0.f ? 1.f : a.slope; v.w *= q.w > 0.f ? 1.f : a.slope;
+            }
+            vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            reinterpret_cast<float4*>(a.y)[o4] = v;
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = n * 16 + li;
+            if (co >= a.CO) continue;
+            const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = wave * 16 + 4 * g + r;
+                const int rr = qq / TW, cc = qq - rr * TW;
+                const size_t o = ((size_t)(b * H + y0 + rr) * W + x0 + cc) * a.CO + co;
+                float v = acc[n][r] + bias;
+                if (a.res) v += a.res[o];
+                if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
+                else if (a.epi == SOL_EPI_DLRELU) v *= (a.act[o] > 0.f ? 1.f : a.slope);
+                vmax = fmaxf(vmax, fabsf(v));
+                a.y[o] = v;
+            }
         }
     }
     if (a.ymax) {                                    // workgroup uniform
@@ -977,7 +1009,8 @@ static int conv_impl(void* stream, const float* x, const float* packed, const fl
     a.tiles_x = W / a.TW;
     const int grid = B * (H / a.RPW) * a.tiles_x;
     const int CP = cin == 4 ? 4 : 36;
-    const size_t lds = (size_t)(a.RPW + 4) * (a.TW + 4) * CP * sizeof(float);
+    size_t lds = (size_t)(a.RPW + 4) * (a.TW + 4) * CP * sizeof(float);
+    if (cin == 4 && lds < 4 * 16 * 32 * sizeof(float)) lds = 4 * 16 * 32 * sizeof(float);   // epilogue transposition buffers
     const int NT = pad_out(cout) / 16;
     hipStream_t s = (hipStream_t)stream;
     static const bool use_sb = !getenv("SOL_CONV_NO_SB");

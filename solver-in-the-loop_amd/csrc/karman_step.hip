@@ -1157,22 +1157,20 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
     }
     __syncthreads();
     SOL_STAMP(6);
-    {   // back to float (in place, element-wise); |acc| > 2^30 would mean the 16x headroom was nearly used up
+    {   // back to float (in place, element-wise) fused with the BC adjoint; |acc| > 2^30 would mean the 16x headroom was nearly used up
         bool risky = false;
-        for (int k = tid; k < nVy; k += nthr) { const int q = Iy[k]; risky |= abs(q) > (1 << 30); L.Avy[k] = (float)q * qi; }
+        const float* bcm = a.bcm + (size_t)b * a.bc_stride;
+        #pragma unroll 4
+        for (int k = tid; k < nVy; k += nthr) { const int q = Iy[k]; risky |= abs(q) > (1 << 30); L.Avy[k] = (float)q * qi * (1.f - bcm[k]); }
+        #pragma unroll 4
         for (int k = tid; k < nVx; k += nthr) { const int q = Ix[k]; risky |= abs(q) > (1 << 30); L.Avx[k] = (float)q * qi; }
         if (risky && a.iters) a.iters[b] = -1;      // reported by the host wrappers as an error
     }
     __syncthreads();
 
     SOL_STAMP(7);
-    // ---- 6: BC adjoint, then diffusion adjoint (the replicate Laplacian is symmetric) --
+    // ---- 6: diffusion adjoint (the replicate Laplacian is symmetric) --
     if (a.dbg & 64) return;
-    {
-        const float* bcm = a.bcm + (size_t)b * a.bc_stride;
-        for (int k = tid; k < nVy; k += nthr) L.Avy[k] *= (1.f - bcm[k]);
-    }
-    __syncthreads();
     {
         const float alpha = a.adt / a.re[b];
         float* oy = a.g_vy_in + (size_t)b * nVy;
