@@ -290,7 +290,8 @@ def test_conv5x5_scaled_fp16_path_against_float64():
         ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), None, padding=2).permute(0, 2, 3, 1)
         ref = torch.nn.functional.leaky_relu(ref, 0.3)
         assert rel(y, ref) < 1e-6, (scale, heavy, rel(y, ref))
-        assert float(ymax.max().view(torch.float32).item()) == float(y.abs().max())
+        if not os.environ.get("SOL_CONV_NO_SB"):        # the fp32 fallback kernels neither consume nor publish the absmax
+            assert float(ymax.max().view(torch.float32).item()) == float(y.abs().max())
 
 
 def test_per_op_autograd_path_equals_fused_trainer():
