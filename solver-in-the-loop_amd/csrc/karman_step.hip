@@ -777,15 +777,20 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
     float fdp = 0.f;
     if constexpr (SOLVER == 2) fdp = fd_prefetch(a.fd, a.fd_n);
     // ---- phase 1: load inputs (all global loads in flight before the first LDS store) ---
+    constexpr int MAXL = CPT + 1;              // (Y+1)*X / (Y*X/CPT) <= CPT + 1 for Y >= CPT
+    float bcv_r[MAXL], bcm_r[MAXL];            // velocity BC of this thread's v_y faces: loaded here, used by phase 2
     {
-        constexpr int MAXL = CPT + 1;          // (Y+1)*X / (Y*X/CPT) <= CPT + 1 for Y >= CPT
         const float* gvy = a.vy_in + (size_t)b * nVy;
         const float* gvx = a.vx_in + (size_t)b * nVx;
+        const float* bcv = a.bcv + (size_t)b * a.bc_stride;
+        const float* bcm = a.bcm + (size_t)b * a.bc_stride;
         float ty[MAXL], tx[MAXL], ta[CPT];
 #pragma unroll
         for (int n = 0; n < MAXL; ++n) { const int k = tid + n * nthr; ty[n] = gvy[min(k, nVy - 1)]; tx[n] = gvx[min(k, nVx - 1)]; }   // branch-free: clamped index
 #pragma unroll
         for (int n = 0; n < CPT; ++n) { const int k = tid + n * nthr; ta[n] = a.active[min(k, N - 1)]; }
+#pragma unroll
+        for (int n = 0; n < MAXL; ++n) { const int k = min(tid + n * nthr, nVy - 1); bcv_r[n] = bcv[k]; bcm_r[n] = bcm[k]; }
 #pragma unroll
         for (int n = 0; n < MAXL; ++n) { const int k = tid + n * nthr; if (k < nVy) L.Avy[k] = ty[n]; if (k < nVx) L.Avx[k] = tx[n]; }
 #pragma unroll
@@ -797,16 +802,16 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
     // ---- phase 2: explicit diffusion (replicate padding, dx = 1) + velocity BC ------
     if (!(a.dbg & 8)) {
         const float alpha = a.adt / a.re[b];
-        const float* bcv = a.bcv + (size_t)b * a.bc_stride;
-        const float* bcm = a.bcm + (size_t)b * a.bc_stride;
-        #pragma unroll 4
-        for (int k = tid; k < nVy; k += nthr) {
+#pragma unroll
+        for (int n = 0; n < MAXL; ++n) {           // compile-time trip count: the BC values sit in registers
+            const int k = tid + n * nthr;
+            if (k >= nVy) continue;
             const int j = k >> lx, i = k & (X - 1);
             const float c = L.Avy[k];
             const float lap = L.Avy[min(j + 1, Y) * X + i] + L.Avy[max(j - 1, 0) * X + i] +
                               L.Avy[j * X + min(i + 1, X - 1)] + L.Avy[j * X + max(i - 1, 0)] - 4.f * c;
             float v = c + alpha * lap;
-            v = v * (1.f - bcm[k]) + bcv[k];
+            v = v * (1.f - bcm_r[n]) + bcv_r[n];
             L.Bvy[k] = v;
             if (a.saved_vy) a.saved_vy[(size_t)b * nVy + k] = v;
         }
