@@ -76,6 +76,21 @@ int sol_karman_precond_supported(int32_t Y, int32_t X);
 /* 1 if the direct pressure solver is built for a Y x X grid (128 x 64), else 0 */
 int sol_karman_direct_supported(int32_t Y, int32_t X);
 
+/* Forward step for grids beyond the one-workgroup kernels (the reference generates its data at 256 x 128:
+ * karman-2d/karman.py:98-159, Makefile:19-28 `-r 128`).  Same arithmetic and argument meaning as sol_karman_step_fwd,
+ * decomposed into chip-wide launches on global memory; the pressure system is solved DIRECTLY, so cfg.direct (blob
+ * with a 16/32/64 window, precond.direct_solver_blob(active, max_window=64)) is required.  Forward only: no saved
+ * state, no adjoint.  Outputs must not alias inputs.  `workspace`: DEVICE scratch of
+ * sol_karman_step_large_workspace_bytes(cfg) bytes. */
+size_t sol_karman_step_large_workspace_bytes(const sol_karman_cfg* cfg);
+int sol_karman_step_fwd_large(const sol_karman_cfg* cfg, void* stream,
+                              const float* d_in, const float* vy_in, const float* vx_in,
+                              const float* re, const float* active, const float* inflow,
+                              const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
+                              float* d_out, float* vy_out, float* vx_out,
+                              float* feat_out, const float* feat_scale,
+                              void* workspace, size_t workspace_bytes);
+
 /* active  [Y,X]  1 - obstacle mask (cell centres inside Obstacle geometries -> 0)
  * inflow  [Y,X]  inflow rate mask (Inflow(box[5:10,25:75]) -> 1 inside)
  * velBCy, velBCyMask  [Y+1,X] (bc_batch_stride 0) or [B,Y+1,X] (stride (Y+1)*X)

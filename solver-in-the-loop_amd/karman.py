@@ -75,7 +75,18 @@ class KarmanFlow:
         vy = smoke.velocity.data[0].data.reshape(B, Y + 1, X)
         vx = smoke.velocity.data[1].data.reshape(B, Y, X + 1)
         info = {}
-        d2, vy2, vx2 = ops.karman_step(d, vy, vx, re_t, cfg, masks, info)
+        if masks.large:
+            # beyond the one-workgroup kernels (data generation at 256 x 128, karman.py:98-159): forward-only path
+            if masks.direct is None:
+                raise ValueError("grids larger than 128x64 need the direct pressure solver (scene not supported / pressure_solver='cg')")
+            if torch.is_grad_enabled() and (vy.requires_grad or vx.requires_grad):
+                raise NotImplementedError("the large-grid solver step (%dx%d) is forward only" % (Y, X))
+            if getattr(self, "_large_ws", None) is None or self._large_ws[0] != (B, Y, X, str(dev)):
+                n = ops._lib.load().sol_karman_step_large_workspace_bytes(ops.C.byref(cfg))
+                self._large_ws = ((B, Y, X, str(dev)), torch.empty((n + 3) // 4, dtype=torch.float32, device=dev))
+            d2, vy2, vx2 = ops.karman_step_large(d, vy, vx, re_t, cfg, masks, self._large_ws[1])
+        else:
+            d2, vy2, vx2 = ops.karman_step(d, vy, vx, re_t, cfg, masks, info)
         self.solve_info = info
         return smoke.copied_with(density=d2.reshape(B, Y, X, 1),
                                  velocity=StaggeredGrid([vy2.reshape(B, Y + 1, X, 1), vx2.reshape(B, Y, X + 1, 1)],

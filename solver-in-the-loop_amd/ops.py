@@ -50,7 +50,7 @@ class SceneMasks:
         self.bc_stride = 0 if self.velBCy.numel() == n else n
         # two-level CG preconditioner (host-prepared dense coarse inverse), when the grid allows it
         self.coarse_inv = None
-        if precondition and not os.environ.get("SOL_NO_PRECOND") and _lib.load().sol_karman_precond_supported(Y, X):
+        if precondition and not os.environ.get("SOL_NO_PRECOND") and Y * X <= 8192 and _lib.load().sol_karman_precond_supported(Y, X):
             from .precond import coarse_inverse
             self.coarse_inv = _lib.f32(coarse_inverse(self.active.reshape(Y, X).cpu().numpy()), device)
         # direct pressure solver (fast diagonalisation + capacitance correction) where it is built and the
@@ -59,13 +59,33 @@ class SceneMasks:
         want = os.environ.get("SOL_PRESSURE_SOLVER", pressure_solver)
         if want not in ("auto", "direct", "cg"):
             raise ValueError("pressure_solver must be 'auto', 'direct' or 'cg' (got %r)" % (want,))
-        if want != "cg" and _lib.load().sol_karman_direct_supported(Y, X):
+        self.large = Y * X > 8192 or X > 64          # beyond the one-workgroup kernels: forward-only multi-launch path
+        if want != "cg" and (self.large or _lib.load().sol_karman_direct_supported(Y, X)):
             from .precond import direct_solver_blob
-            blob = direct_solver_blob(self.active.reshape(Y, X).cpu().numpy())
+            blob = direct_solver_blob(self.active.reshape(Y, X).cpu().numpy(), max_window=64 if self.large else 16)
             if blob is not None:
                 self.direct = torch.from_numpy(blob).to(device)
         if want == "direct" and self.direct is None:
             raise ValueError("the direct pressure solver does not support this scene (%dx%d)" % (Y, X))
+
+
+def karman_step_large(d, vy, vx, re, cfg, masks, workspace=None):
+    """Forward-only step for grids beyond the one-workgroup kernels (data generation at 256 x 128,
+    /root/reference/karman-2d/karman.py:98-159): sol_karman_step_fwd_large.  Returns (d, vy, vx) after the step."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    d, vy, vx, re = (_lib.f32(t) for t in (d, vy, vx, re))
+    B, Y, X = cfg.B, cfg.Y, cfg.X
+    assert vy.shape == (B, Y + 1, X) and vx.shape == (B, Y, X + 1) and d.shape == (B, Y, X) and re.shape == (B,)
+    nbytes = lib.sol_karman_step_large_workspace_bytes(C.byref(cfg))
+    if workspace is None or workspace.numel() * 4 < nbytes:
+        workspace = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=vy.device)
+    d_out, vy_out, vx_out = torch.empty_like(d), torch.empty_like(vy), torch.empty_like(vx)
+    check(lib.sol_karman_step_fwd_large(C.byref(cfg), stream(), ptr(d), ptr(vy), ptr(vx), ptr(re),
+                                        ptr(masks.active), ptr(masks.inflow), ptr(masks.velBCy), ptr(masks.velBCyMask),
+                                        masks.bc_stride, ptr(d_out), ptr(vy_out), ptr(vx_out), None, None,
+                                        ptr(workspace), workspace.numel() * 4))
+    return d_out, vy_out, vx_out
 
 
 def _scale3(vals):

@@ -55,7 +55,7 @@ def coarse_inverse(active, block=8):
 # same solution as the converged CG up to fp32 round-off (csrc/karman_step.hip: fd_solve).
 FD_MAGIC = 0x46443032          # "FD02"
 FD_HEADER = 16                 # int32 words
-FD_WIN = 16                    # window edge (cells)
+FD_WIN = 16                    # window edge (cells) of the one-workgroup kernels; the large-grid path takes 16/32/64
 
 
 def dst_matrix(n):
@@ -99,14 +99,15 @@ def _perturbation(active):
     return ent
 
 
-def direct_solver_blob(active):
+def direct_solver_blob(active, max_window=FD_WIN):
     """float32 blob consumed by sol_karman_cfg.direct, or None when the scene does not qualify
-    (perturbed cells do not fit one 16x16 window, or the capacitance system is ill conditioned).
+    (perturbed cells do not fit one window, or the capacitance system is ill conditioned).  The window edge is the
+    smallest of 16, 32, 64 (<= max_window) that holds the perturbed cells; it is stored in header[7].
 
-    layout (32-bit words): header[16] = {magic, Y, X, wy0, wx0, nS, SP, ...};  Qy[Y*Y];  Qx[X*X];
+    layout (32-bit words): header[16] = {magic, Y, X, wy0, wx0, nS, SP, win, ...};  Qy[Y*Y];  Qx[X*X];
     invlamT[X*Y] (= 1/lam[m][c] stored [c][m]);  KpT[SP*SP] (K' = E_SS (I + G_SS E_SS)^-1, stored
-    transposed, zero padded);  sidx[SP] int32 (window-local index j'*16 + i', -1 = padding);
-    QxW[X*16] (= Qx[c][wx0 + i'], the window columns of Qx as one compact 4 KB slab)."""
+    transposed, zero padded);  sidx[SP] int32 (window-local index j'*win + i', -1 = padding);
+    QxW[X*win] (= Qx[c][wx0 + i'], the window columns of Qx as one compact slab)."""
     act = (np.asarray(active, dtype=np.float64) != 0).astype(np.float64)
     Y, X = act.shape
     ent = _perturbation(act)
@@ -114,10 +115,12 @@ def direct_solver_blob(active):
         return None
     S = np.array(sorted({r for r, _ in ent}), dtype=np.int64)
     js, is_ = S // X, S % X
-    if js.max() - js.min() >= FD_WIN or is_.max() - is_.min() >= FD_WIN or Y < FD_WIN or X < FD_WIN:
+    span = int(max(js.max() - js.min(), is_.max() - is_.min())) + 1
+    win = next((w for w in (16, 32, 64) if w >= span and w <= max_window), None)
+    if win is None or Y < win or X < win:
         return None
-    wy0 = int(min(js.min(), Y - FD_WIN))
-    wx0 = int(min(is_.min(), X - FD_WIN))
+    wy0 = int(min(js.min(), Y - win))
+    wx0 = int(min(is_.min(), X - win))
     nS = len(S)
     SP = (nS + 63) // 64 * 64
     pos = {int(s): n for n, s in enumerate(S)}
@@ -137,12 +140,12 @@ def direct_solver_blob(active):
     KpT = np.zeros((SP, SP))
     KpT[:nS, :nS] = Kp.T
     sidx = np.full(SP, -1, dtype=np.int32)
-    sidx[:nS] = ((js - wy0) * FD_WIN + (is_ - wx0)).astype(np.int32)
+    sidx[:nS] = ((js - wy0) * win + (is_ - wx0)).astype(np.int32)
     header = np.zeros(FD_HEADER, dtype=np.int32)
-    header[:7] = [FD_MAGIC, Y, X, wy0, wx0, nS, SP]
+    header[:8] = [FD_MAGIC, Y, X, wy0, wx0, nS, SP, win]
     parts = [header.view(np.float32), Qy.astype(np.float32).ravel(), Qx.astype(np.float32).ravel(),
              (1.0 / lam).T.astype(np.float32).ravel(), KpT.astype(np.float32).ravel(), sidx.view(np.float32),
-             np.ascontiguousarray(Qx[:, wx0:wx0 + FD_WIN]).astype(np.float32).ravel()]
+             np.ascontiguousarray(Qx[:, wx0:wx0 + win]).astype(np.float32).ravel()]
     return np.concatenate(parts)
 
 
@@ -151,6 +154,7 @@ def direct_solve_reference(blob, b):
     hdr = blob[:FD_HEADER].view(np.int32)
     assert hdr[0] == FD_MAGIC
     Y, X, wy0, wx0, nS, SP = (int(v) for v in hdr[1:7])
+    FD_WIN = int(hdr[7])
     o = FD_HEADER
     Qy = blob[o:o + Y * Y].astype(np.float64).reshape(Y, Y); o += Y * Y
     Qx = blob[o:o + X * X].astype(np.float64).reshape(X, X); o += X * X

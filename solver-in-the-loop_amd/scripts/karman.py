@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """karman-2d data generation -- same flags as /root/reference/karman-2d/karman.py:33-47, the loop of
 :138-159 on the fused HIP solver step (one kernel launch per frame, state stays on the GPU).
-Grid limit of the one-workgroup-per-simulation kernel: -r <= 64 (the reference's 256x128 `-r 128`
-reference solutions are the "next" row of SURVEY.md section 8f-3)."""
+-r <= 64 runs the fused one-workgroup-per-simulation kernel; larger grids (the reference's 256x128 `-r 128`
+reference solutions, Makefile:19-28) run the forward-only multi-launch path with the direct pressure solver."""
 import argparse
 import pickle
 

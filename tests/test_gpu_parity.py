@@ -422,6 +422,15 @@ def test_scripts_end_to_end(tmp_path):
     v = scene.read_zipped_array(out + "/velTf_000003.npz")
     c = scene.read_zipped_array(out + "/corTf_000003.npz")
     assert v.shape == (1, 65, 33, 2) and c.shape == (1, 65, 33, 2) and np.isfinite(v).all() and np.abs(c).max() > 0
+    # the reference's own data-generation chain (Makefile:19-44): hi-res run at -r 128 (256 x 128, forward-only large-grid
+    # path), then a 4x down-sampled lo-res run started from one of its frames
+    hi = load("karman").main(["-o", str(tmp_path / "hires"), "-r", "128", "-t", "6", "-s", "2", "--re", "1.6e5"])
+    vh = scene.read_zipped_array(hi + "/velo_000005.npz")
+    assert vh.shape == (1, 257, 129, 2) and np.isfinite(vh).all()
+    lo = load("karman").main(["-o", str(tmp_path / "lores"), "-r", "32", "-t", "4", "-s", "0", "-d", "4", "--re", "1.6e5",
+                              "--initdH", hi + "/dens_000005.npz", "--initvH", hi + "/velo_000005.npz"])
+    vl = scene.read_zipped_array(lo + "/velo_000003.npz")
+    assert vl.shape == (1, 65, 33, 2) and np.isfinite(vl).all()
 
 
 def test_burgers_training_script(tmp_path):
@@ -479,3 +488,31 @@ def test_model_mercury_against_torch_reference():
     assert rel(hy, y) < 2e-6
     gref = torch.cat([w.grad.reshape(-1) for w in ws])
     assert rel(net.params.grad, gref) < 5e-6
+
+
+def test_large_grid_forward_step_against_oracle():
+    """the reference generates its data at 256 x 128 (karman.py -r 128).  Forward-only multi-launch step with
+    the direct pressure solver (window 32) against the float64 oracle, two consecutive steps, and through KarmanFlow.step."""
+    B, Y, X = 2, 256, 128
+    g = o.geometry(Y, X)
+    mk = ops.SceneMasks(g.active, g.inflow, g.bc_mask, g.bc_mask)
+    assert mk.large and mk.direct is not None and mk.coarse_inv is None
+    d, vy, vx = o.synthetic_state(B, Y, X, 77)
+    re = torch.tensor(o.RE_TRAIN[:B], dtype=torch.float64)
+    cfg = ops.karman_cfg(B, Y, X, g.dx, masks=mk)
+    hd, hy, hx = f32(d), f32(vy), f32(vx)
+    rd, ry, rx = d, vy, vx
+    for _ in range(2):
+        rd, ry, rx = o.karman_step(rd, ry, rx, re, g)
+        hd, hy, hx = ops.karman_step_large(hd, hy, hx, f32(re), cfg, mk)
+        assert rel(hy, ry) < TOL_FIELD and rel(hx, rx) < TOL_FIELD and rel(hd, rd) < TOL_FIELD
+    # the reference-shaped surface dispatches to the same path
+    dom = sol_amd.Domain([Y, X], box=sol_amd.box[0:200, 0:100])
+    sim = sol_amd.KarmanFlow()
+    bcv, bcm = sol_amd.velocity_bc_masks(Y, X, batch_size=B)
+    st = sol_amd.Fluid(dom, density=f32(d).reshape(B, Y, X, 1), velocity=f32(o.staggered_tensor(vy, vx)), batch_size=B)
+    with torch.no_grad():
+        st = sim.step(st, re=f32(re), res=X, velBCy=bcv, velBCyMask=bcm)
+    r1 = o.karman_step(d, vy, vx, re, g)
+    assert rel(st.velocity.data[0].data.reshape(B, Y + 1, X), r1[1]) < TOL_FIELD
+    assert rel(st.velocity.data[1].data.reshape(B, Y, X + 1), r1[2]) < TOL_FIELD
