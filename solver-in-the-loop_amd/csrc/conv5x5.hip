@@ -67,6 +67,15 @@ __global__ void __launch_bounds__(256) k_conv5x5(ConvArgs a) {
     const int b = blk / rows_blk;
     const int y0 = ty * RPW, x0 = tx * TW;
 
+    // thin layers: this lane's B operands of all 25 taps are loaded before the halo staging (their latency hides behind it)
+    float bw4[CIN == 4 ? 25 : 1][NT];
+    if constexpr (CIN == 4) {
+        const float* wbase = a.wp + (size_t)li * 4 + g;
+#pragma unroll
+        for (int tap = 0; tap < 25; ++tap)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bw4[tap][n] = wbase[((size_t)tap * OP + n * 16) * 4];
+    }
     // ---- stage the zero padded halo tile -------------------------------------------------
     {
         constexpr int C4 = CIN / 4;
@@ -116,16 +125,12 @@ __global__ void __launch_bounds__(256) k_conv5x5(ConvArgs a) {
         }
     } else {   // CIN == 4: one MFMA per tap, lane group g = channel
         const float* abase = &smem[(prr * HW + pcc) * CP + g];
-        const float* wbase = a.wp + (size_t)li * 4 + g;
 #pragma unroll
         for (int tap = 0; tap < 25; ++tap) {
             const int dy = tap / 5, dx = tap - dy * 5;
             const float av = abase[(dy * HW + dx) * CP];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const float bv = wbase[((size_t)tap * OP + n * 16) * 4];
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[n], 0, 0, 0);
-            }
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw4[tap][n], acc[n], 0, 0, 0);
         }
     }
 

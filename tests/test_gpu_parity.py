@@ -292,6 +292,15 @@ def test_conv5x5_scaled_fp16_path_against_float64():
         assert rel(y, ref) < 1e-6, (scale, heavy, rel(y, ref))
         if not os.environ.get("SOL_CONV_NO_SB"):        # the fp32 fallback kernels neither consume nor publish the absmax
             assert float(ymax.max().view(torch.float32).item()) == float(y.abs().max())
+    # degenerate tensor: all-zero input (absmax 0 -> scale of 1) gives exactly act(bias)
+    B, Y, X, cout = 1, 16, 64, 32
+    x = torch.zeros(B, Y, X, 32, dtype=torch.float32, device=DEV)
+    w = (torch.randn(5, 5, 32, cout, generator=gen) * 0.05).float().to(DEV)
+    bias = torch.linspace(-1, 1, cout, dtype=torch.float32).to(DEV)
+    y = torch.empty(B, Y, X, cout, dtype=torch.float32, device=DEV)
+    check(lib.sol_conv5x5_scaled(stream(), ptr(x), ptr(ops._pack(w, 32, cout, ops.CONV_FWD)), ptr(bias), None, None, ptr(y), B, Y, X, 32, cout,
+                                 ops.EPI_LRELU, 0.3, ptr(torch.zeros(64, dtype=torch.int32, device=DEV)), None))
+    assert torch.equal(y, torch.nn.functional.leaky_relu(bias, 0.3).expand(B, Y, X, cout))
 
 
 def test_per_op_autograd_path_equals_fused_trainer():
