@@ -80,7 +80,8 @@ int sol_karman_direct_supported(int32_t Y, int32_t X);
  * karman-2d/karman.py:98-159, Makefile:19-28 `-r 128`).  Same arithmetic and argument meaning as sol_karman_step_fwd,
  * decomposed into chip-wide launches on global memory; the pressure system is solved DIRECTLY, so cfg.direct (blob
  * with a 16/32/64 window, precond.direct_solver_blob(active, max_window=64)) is required.  Forward only: no saved
- * state, no adjoint.  Outputs must not alias inputs.  `workspace`: DEVICE scratch of
+ * state, no adjoint.  Outputs must not alias inputs.  `direct_header_host`: HOST copy of the first 16 words of the blob
+ * (grid, window origin/size, number of perturbed cells: they size the launches).  `workspace`: DEVICE scratch of
  * sol_karman_step_large_workspace_bytes(cfg) bytes. */
 size_t sol_karman_step_large_workspace_bytes(const sol_karman_cfg* cfg);
 int sol_karman_step_fwd_large(const sol_karman_cfg* cfg, void* stream,
@@ -89,6 +90,7 @@ int sol_karman_step_fwd_large(const sol_karman_cfg* cfg, void* stream,
                               const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
                               float* d_out, float* vy_out, float* vx_out,
                               float* feat_out, const float* feat_scale,
+                              const int32_t* direct_header_host,
                               void* workspace, size_t workspace_bytes);
 
 /* active  [Y,X]  1 - obstacle mask (cell centres inside Obstacle geometries -> 0)

@@ -48,7 +48,7 @@ _SIGS = {
     "sol_version": (C.c_int, []),
     "sol_karman_direct_supported": (C.c_int, [C.c_int32] * 2),
     "sol_karman_step_large_workspace_bytes": (C.c_size_t, [_P]),
-    "sol_karman_step_fwd_large": (C.c_int, [_P] * 10 + [C.c_int64] + [_P] * 6 + [C.c_size_t]),
+    "sol_karman_step_fwd_large": (C.c_int, [_P] * 10 + [C.c_int64] + [_P] * 7 + [C.c_size_t]),
     "sol_karman_precond_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "sol_karman_step_fwd": (C.c_int, [C.POINTER(KarmanCfg), _P] + [_P] * 8 + [C.c_int64] + [_P] * 6 + [C.POINTER(C.c_float), _P]),
     "sol_karman_step_bwd": (C.c_int, [C.POINTER(KarmanCfg), _P] + [_P] * 5 + [C.c_int64] + [_P] * 3 + [C.POINTER(C.c_float)] + [_P] * 3),

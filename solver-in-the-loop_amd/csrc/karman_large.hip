@@ -252,21 +252,6 @@ __global__ void k_l_capacitance(const float* __restrict__ x0w, const float* __re
 
 struct Header { int Y, X, wy0, wx0, nS, SP, win; };
 
-int read_header(const float* blob, Header& h) {
-    // cached per blob pointer: one synchronous 64-byte copy the first time a blob is seen
-    static const float* last = nullptr;
-    static Header cached{};
-    if (blob != last) {
-        int raw[FDL_HEADER];
-        SOL_HIP_CHECK(hipMemcpy(raw, blob, sizeof(raw), hipMemcpyDeviceToHost));
-        SOL_REQUIRE(raw[0] == 0x46443032, "direct-solver blob: bad magic");
-        cached = Header{raw[1], raw[2], raw[3], raw[4], raw[5], raw[6], raw[7]};
-        last = blob;
-    }
-    h = cached;
-    return SOL_OK;
-}
-
 int gemm(hipStream_t s, int batch, const float* A, int lda, long sA, const float* Bm, int ldb, long sB, float* C, int ldc, long sC,
          int M, int N, int K, int accumulate) {
     GArgs g{A, Bm, nullptr, C, M, N, K, lda, ldb, ldc, 0, sA, sB, sC, accumulate};
@@ -291,6 +276,7 @@ extern "C" int sol_karman_step_fwd_large(const sol_karman_cfg* c, void* stream,
                                          const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
                                          float* d_out, float* vy_out, float* vx_out,
                                          float* feat_out, const float* feat_scale,
+                                         const int32_t* direct_header_host,
                                          void* workspace, size_t workspace_bytes) {
     SOL_REQUIRE(c != nullptr, "cfg is NULL");
     SOL_REQUIRE(c->B >= 1 && c->Y >= 16 && c->X >= 16, "sol_karman_step_fwd_large: B >= 1, Y, X >= 16 (got %d, %d, %d)", c->B, c->Y, c->X);
@@ -300,8 +286,11 @@ extern "C" int sol_karman_step_fwd_large(const sol_karman_cfg* c, void* stream,
     SOL_REQUIRE(c->direct && c->direct_n > 0, "sol_karman_step_fwd_large needs the direct-solver blob (cfg.direct)");
     SOL_REQUIRE(workspace_bytes >= sol_karman_step_large_workspace_bytes(c), "workspace too small");
     SOL_REQUIRE(vy_in != vy_out && vx_in != vx_out && d_in != d_out, "sol_karman_step_fwd_large: outputs must not alias the inputs");
-    Header h;
-    if (int e = read_header(c->direct, h)) return e;
+    SOL_REQUIRE(direct_header_host && direct_header_host[0] == 0x46443032, "sol_karman_step_fwd_large: direct_header_host must be the first 16 words of the blob (host copy)");
+    const Header h{direct_header_host[1], direct_header_host[2], direct_header_host[3], direct_header_host[4],
+                   direct_header_host[5], direct_header_host[6], direct_header_host[7]};
+    SOL_REQUIRE(h.SP >= h.nS && h.SP <= 4096 && h.wy0 >= 0 && h.wx0 >= 0 && h.wy0 + h.win <= c->Y && h.wx0 + h.win <= c->X,
+                "direct-solver blob header is inconsistent");
     SOL_REQUIRE(h.Y == c->Y && h.X == c->X, "direct-solver blob is for a %dx%d grid, cfg is %dx%d", h.Y, h.X, c->Y, c->X);
     SOL_REQUIRE(h.win == 16 || h.win == 32 || h.win == 64, "direct-solver blob: unsupported window %d", h.win);
     const int B = c->B, Y = c->Y, X = c->X, N = Y * X, win = h.win, SP = h.SP;

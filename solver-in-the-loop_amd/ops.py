@@ -56,6 +56,7 @@ class SceneMasks:
         # direct pressure solver (fast diagonalisation + capacitance correction) where it is built and the
         # scene qualifies; pressure_solver="cg" (or SOL_PRESSURE_SOLVER=cg) keeps the (preconditioned) CG
         self.direct = None
+        self.direct_header = None
         want = os.environ.get("SOL_PRESSURE_SOLVER", pressure_solver)
         if want not in ("auto", "direct", "cg"):
             raise ValueError("pressure_solver must be 'auto', 'direct' or 'cg' (got %r)" % (want,))
@@ -65,6 +66,7 @@ class SceneMasks:
             blob = direct_solver_blob(self.active.reshape(Y, X).cpu().numpy(), max_window=64 if self.large else 16)
             if blob is not None:
                 self.direct = torch.from_numpy(blob).to(device)
+                self.direct_header = np.ascontiguousarray(blob[:16].view(np.int32))      # host copy: sizes the large-grid launches
         if want == "direct" and self.direct is None:
             raise ValueError("the direct pressure solver does not support this scene (%dx%d)" % (Y, X))
 
@@ -84,7 +86,7 @@ def karman_step_large(d, vy, vx, re, cfg, masks, workspace=None):
     check(lib.sol_karman_step_fwd_large(C.byref(cfg), stream(), ptr(d), ptr(vy), ptr(vx), ptr(re),
                                         ptr(masks.active), ptr(masks.inflow), ptr(masks.velBCy), ptr(masks.velBCyMask),
                                         masks.bc_stride, ptr(d_out), ptr(vy_out), ptr(vx_out), None, None,
-                                        ptr(workspace), workspace.numel() * 4))
+                                        masks.direct_header.ctypes.data_as(C.c_void_p), ptr(workspace), workspace.numel() * 4))
     return d_out, vy_out, vx_out
 
 
