@@ -31,10 +31,20 @@ def _stale():
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link libsol_hip.so.  Returns the path."""
+    """Compile every HIP source for gfx950 and link libsol_hip.so.  Returns the path.
+    Serialised by a lock file: several ranks of one node may import the package at the same time."""
     if not force and not _stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
+    import fcntl
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():          # another process built it while this one waited
+            return LIB
+        return _build_locked(verbose)
+
+
+def _build_locked(verbose):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
