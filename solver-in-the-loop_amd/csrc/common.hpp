@@ -46,6 +46,18 @@ struct BwArgs {
     long xmax_seg, zmax_seg;      // ... and their strides (uint32 words) between consecutive segments
 };
 int sol_bww_sb_launch(hipStream_t s, const BwArgs& a, int nblk_run);
+int sol_karman_step_bwd_fused(const sol_karman_cfg* cfg, void* stream,
+                              const float* saved_vy, const float* saved_vx, const float* re, const float* active,
+                              const float* velBCyMask, int64_t bc_batch_stride,
+                              const float* g_vy_out, const float* g_vx_out, const float* dfeat, const float* feat_scale,
+                              float* g_vy_in, float* g_vx_in, int32_t* iters, const BwArgs* bw, int nbw, int wg_per);
+int sol_karman_bwd_fusable(const sol_karman_cfg* cfg);
+int sol_bww_jobs_launch(void* stream, const BwArgs* bw, int nbw, int wg_per);
+// weight-gradient job description for one layer of ONE unrolled step with `rb` rows per workgroup (train.hip -> fused launch)
+int sol_bww_step_job(BwArgs* out, const float* x, const float* dz, float* partial, int overwrite, int B, int H, int W, int rb,
+                     const unsigned* xmax, const unsigned* zmax);
+int sol_bww_step_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int B, int H, int rb, int cin, int cout, int accumulate);
+size_t sol_bww_step_ws_floats(int B, int H, int rb);
 // split-bf16 section of the packed weights and the kernels that consume it (conv5x5_sb.hip)
 size_t sol_conv_sb_packed_floats(int OP);
 size_t sol_conv_sh_packed_floats(int OP);

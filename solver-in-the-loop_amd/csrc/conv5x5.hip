@@ -1180,6 +1180,27 @@ extern "C" int sol_conv5x5_bwd_weight_reduce(void* stream, const float* partial,
     return bww_reduce(stream, partial, dw_hwio, db, B * H, RB, cin, cout, accumulate);
 }
 
+// ---- per-step jobs for the fused solver-adjoint + weight-gradient launch (32 -> 32 layers, W == 64) ----------------
+// One job = one layer of ONE unrolled step, `rb` image rows per workgroup; the partial buffer has (B*H)/rb blocks and is
+// accumulated over the steps of the reverse sweep (overwrite = 1 for the first one), then reduced once.
+size_t sol_bww_step_ws_floats(int B, int H, int rb) { return (size_t)((B * H) / rb) * (25 * 32 * 32 + 32); }
+
+int sol_bww_step_job(BwArgs* out, const float* x, const float* dz, float* partial, int overwrite, int B, int H, int W, int rb,
+                     const unsigned* xmax, const unsigned* zmax) {
+    SOL_REQUIRE(out && x && dz && partial && xmax && zmax, "sol_bww_step_job: NULL pointer");
+    SOL_REQUIRE(W == 64 && rb >= 1 && (B * H) % rb == 0, "sol_bww_step_job: W == 64 and rb | B*H required (W=%d, B*H=%d, rb=%d)", W, B * H, rb);
+    BwArgs a{};
+    a.x = x; a.dz = dz; a.partial = partial; a.B = B; a.H = H; a.W = W; a.cin = 32; a.cout = 32;
+    a.nblk = (B * H) / rb; a.nseg = 1; a.rb = rb; a.x_seg = 0; a.dz_seg = 0; a.overwrite = overwrite;
+    a.xmax = xmax; a.zmax = zmax; a.xmax_seg = 0; a.zmax_seg = 0;
+    *out = a;
+    return SOL_OK;
+}
+
+int sol_bww_step_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int B, int H, int rb, int cin, int cout, int accumulate) {
+    return bww_reduce(stream, partial, dw_hwio, db, B * H, rb, cin, cout, accumulate);
+}
+
 int sol_bww_batched_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int nseg, int B, int H,
                            int cin, int cout, int accumulate) {
     const int rows = nseg * B * H;

@@ -11,7 +11,7 @@
 // x-neighbours are one lane away (wave shift) and only the strip end rows are exchanged
 // through LDS (2 floats per thread per iteration).  The dot products are wave64 shuffles
 // plus one LDS slot per wave.
-#include "common.hpp"
+#include "split_kernels.hpp"
 #include <stdlib.h>
 
 namespace {
@@ -967,9 +967,8 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
 // backward (adjoint w.r.t. the input velocity)
 // ------------------------------------------------------------------------------------
 template <int CPT, int SOLVER>
-__global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs a) {
+__device__ __forceinline__ void karman_bwd_body(const StepArgs& a, float* smem) {
     constexpr int MAXT = CPT + 1;   // face targets per thread: (Y+1)*X / (Y*X/CPT) <= CPT+1 for Y >= CPT
-    extern __shared__ __align__(16) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int Y = a.Y, X = a.X, N = Y * X, nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
     const int lx = __ffs(X) - 1;                 // X is a power of two: k / X == k >> lx
@@ -1201,6 +1200,30 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs 
     if (fdp == 1.2345678e-30f && a.iters) a.iters[b] = -2;      // never true: keeps the prefetch loads alive
 }
 
+template <int CPT, int SOLVER>
+__global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_bwd(StepArgs a) {
+    extern __shared__ __align__(16) float smem[];
+    karman_bwd_body<CPT, SOLVER>(a, smem);
+}
+
+// Horizontal fusion: the solver adjoint of an unrolled step occupies ONE CU per simulation for its whole duration
+// (6 of 256 at C3) and nothing else of the reverse sweep can run meanwhile (it waits for this kernel's output).  The
+// weight gradients of the step, whose dz tensors are complete by then, have no consumer until the end of the sweep:
+// their workgroups ride in the SAME launch (blocks >= B), sized to last about as long as the adjoint (32 rows each).
+struct BwPack {
+    BwArgs a[12];
+    int n, wg_per;          // n gradient jobs (layers) of wg_per workgroups each
+};
+__global__ void __launch_bounds__(512) k_karman_bwd_bww(StepArgs a, BwPack bw) {
+    extern __shared__ __align__(16) float smem[];
+    if ((int)blockIdx.x < a.B) {
+        karman_bwd_body<16, 2>(a, smem);
+    } else {
+        const int idx = (int)blockIdx.x - a.B;
+        sbk::bww_sb_body<2>(bw.a[idx / bw.wg_per], idx % bw.wg_per, reinterpret_cast<unsigned char*>(smem));
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Passive tracer chain (training path)
 // ------------------------------------------------------------------------------------
@@ -1349,7 +1372,8 @@ int sol_init_karman_kernels() {
         const void* ks[] = {reinterpret_cast<const void*>(k_karman_fwd<8, 0>), reinterpret_cast<const void*>(k_karman_bwd<8, 0>),
                             reinterpret_cast<const void*>(k_karman_fwd<16, 0>), reinterpret_cast<const void*>(k_karman_bwd<16, 0>),
                             reinterpret_cast<const void*>(k_karman_fwd<16, 1>), reinterpret_cast<const void*>(k_karman_bwd<16, 1>),
-                            reinterpret_cast<const void*>(k_karman_fwd<16, 2>), reinterpret_cast<const void*>(k_karman_bwd<16, 2>)};
+                            reinterpret_cast<const void*>(k_karman_fwd<16, 2>), reinterpret_cast<const void*>(k_karman_bwd<16, 2>),
+                            reinterpret_cast<const void*>(k_karman_bwd_bww)};
         for (const void* k : ks)
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return sol_set_error(SOL_ERR_HIP, "hipFuncSetAttribute(karman kernels) failed");
@@ -1445,13 +1469,14 @@ extern "C" int sol_karman_step_fwd(const sol_karman_cfg* cfg, void* stream,
     return launch_step(k_karman_fwd<16, 0>, 16, cfg, stream, a);
 }
 
-extern "C" int sol_karman_step_bwd(const sol_karman_cfg* cfg, void* stream,
-                                   const float* saved_vy, const float* saved_vx,
-                                   const float* re, const float* active,
-                                   const float* velBCyMask, int64_t bc_batch_stride,
-                                   const float* g_vy_out, const float* g_vx_out,
-                                   const float* dfeat, const float* feat_scale,
-                                   float* g_vy_in, float* g_vx_in, int32_t* iters) {
+static int step_bwd_impl(const sol_karman_cfg* cfg, void* stream,
+                         const float* saved_vy, const float* saved_vx,
+                         const float* re, const float* active,
+                         const float* velBCyMask, int64_t bc_batch_stride,
+                         const float* g_vy_out, const float* g_vx_out,
+                         const float* dfeat, const float* feat_scale,
+                         float* g_vy_in, float* g_vx_in, int32_t* iters,
+                         const BwArgs* bw, int nbw, int wg_per) {
     if (int e = check_cfg(cfg)) return e;
     SOL_REQUIRE(saved_vy && saved_vx && re && active && velBCyMask && g_vy_out && g_vx_out && g_vy_in && g_vx_in,
                 "sol_karman_step_bwd: NULL pointer argument");
@@ -1464,8 +1489,58 @@ extern "C" int sol_karman_step_bwd(const sol_karman_cfg* cfg, void* stream,
     if (feat_scale) { a.fs0 = feat_scale[0]; a.fs1 = feat_scale[1]; a.fs2 = feat_scale[2]; }
     a.g_vy_in = g_vy_in; a.g_vx_in = g_vx_in; a.iters = iters;
     const int cpt = pick_cpt(cfg);
+    if (nbw > 0) {      // weight-gradient workgroups ride in the adjoint's launch (direct-solver kernels, 16-cell strips)
+        SOL_REQUIRE(cpt == 16 && a.fd && nbw <= 12 && wg_per >= 1, "fused adjoint + weight-gradient launch: unsupported configuration");
+        if (int e = sol_init_karman_kernels()) return e;
+        BwPack pk{};
+        for (int k = 0; k < nbw; ++k) pk.a[k] = bw[k];
+        pk.n = nbw; pk.wg_per = wg_per;
+        size_t lds = lds_bytes(cfg->Y, cfg->X, 16);
+        if (lds < (size_t)sbk::BW_LDS) lds = sbk::BW_LDS;
+        hipLaunchKernelGGL(k_karman_bwd_bww, dim3(cfg->B + nbw * wg_per), dim3(512), lds, (hipStream_t)stream, a, pk);
+        SOL_LAUNCH_CHECK();
+        return SOL_OK;
+    }
     if (cpt != 16) return launch_step(k_karman_bwd<8, 0>, 8, cfg, stream, a);
     if (a.fd) return launch_step(k_karman_bwd<16, 2>, 16, cfg, stream, a);
     if (a.cinv) return launch_step(k_karman_bwd<16, 1>, 16, cfg, stream, a);
     return launch_step(k_karman_bwd<16, 0>, 16, cfg, stream, a);
+}
+
+extern "C" int sol_karman_step_bwd(const sol_karman_cfg* cfg, void* stream,
+                                   const float* saved_vy, const float* saved_vx,
+                                   const float* re, const float* active,
+                                   const float* velBCyMask, int64_t bc_batch_stride,
+                                   const float* g_vy_out, const float* g_vx_out,
+                                   const float* dfeat, const float* feat_scale,
+                                   float* g_vy_in, float* g_vx_in, int32_t* iters) {
+    return step_bwd_impl(cfg, stream, saved_vy, saved_vx, re, active, velBCyMask, bc_batch_stride, g_vy_out, g_vx_out, dfeat, feat_scale,
+                         g_vy_in, g_vx_in, iters, nullptr, 0, 0);
+}
+
+// internal (train.hip): the solver adjoint with `nbw` weight-gradient jobs of `wg_per` workgroups each in the same launch
+int sol_karman_step_bwd_fused(const sol_karman_cfg* cfg, void* stream,
+                              const float* saved_vy, const float* saved_vx, const float* re, const float* active,
+                              const float* velBCyMask, int64_t bc_batch_stride,
+                              const float* g_vy_out, const float* g_vx_out, const float* dfeat, const float* feat_scale,
+                              float* g_vy_in, float* g_vx_in, int32_t* iters, const BwArgs* bw, int nbw, int wg_per) {
+    return step_bwd_impl(cfg, stream, saved_vy, saved_vx, re, active, velBCyMask, bc_batch_stride, g_vy_out, g_vx_out, dfeat, feat_scale,
+                         g_vy_in, g_vx_in, iters, bw, nbw, wg_per);
+}
+// weight-gradient jobs alone (the first step of the unroll has no solver adjoint): same kernel, no solver workgroups
+int sol_bww_jobs_launch(void* stream, const BwArgs* bw, int nbw, int wg_per) {
+    SOL_REQUIRE(bw && nbw >= 1 && nbw <= 12 && wg_per >= 1, "sol_bww_jobs_launch: bad arguments");
+    if (int e = sol_init_karman_kernels()) return e;
+    StepArgs a{};
+    a.B = 0;
+    BwPack pk{};
+    for (int k = 0; k < nbw; ++k) pk.a[k] = bw[k];
+    pk.n = nbw; pk.wg_per = wg_per;
+    hipLaunchKernelGGL(k_karman_bwd_bww, dim3(nbw * wg_per), dim3(512), (size_t)sbk::BW_LDS, (hipStream_t)stream, a, pk);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+// 1 if the fused adjoint + weight-gradient launch exists for this configuration
+int sol_karman_bwd_fusable(const sol_karman_cfg* cfg) {
+    return cfg && cfg->direct && cfg->Y == FD_Y && cfg->X == FD_X && pick_cpt(cfg) == 16;
 }

@@ -1,0 +1,275 @@
+// Split-operand helpers and the weight-gradient workgroup body of the 16-bit MFMA kernels, shared by conv5x5_sb.hip
+// (stand-alone launches) and karman_step.hip (the weight gradients of an unrolled step ride in the SAME launch as
+// that step's solver adjoint: 6 of 256 CUs would otherwise idle for its whole duration).
+#pragma once
+#include "common.hpp"
+
+namespace sbk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__host__ __device__ __forceinline__ int swzb(int idx) { return ((idx >> 2) & 1) << 1; }
+
+// two fp32 -> packed pair of bf16 (round to nearest even), low half = first element
+__device__ __forceinline__ unsigned pk_bf16(float x, float y) {
+    const f32x2 f = {x, y};
+    const bf16x2 b = __builtin_convertvector(f, bf16x2);
+    return __builtin_bit_cast(unsigned, b);
+}
+__device__ __forceinline__ float bf_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+
+// (x, y) -> three packed bf16 pairs with x = x1 + x2 + x3 (+ O(2^-27 x))
+__device__ __forceinline__ void split3(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = pk_bf16(x, y);
+    const float rx = x - bf_lo(p1), ry = y - bf_hi(p1);
+    p2 = pk_bf16(rx, ry);
+    p3 = pk_bf16(rx - bf_lo(p2), ry - bf_hi(p2));
+}
+
+// ---- split fp16 ("KIND 2"): v * 2^shift = h1 + h2 / 2048 with two fp16 numbers (22 significant bits), 2^shift chosen per
+// TENSOR from its max|v| so that the scaled tensor spans fp16's 29 normal binades below 2^15.  Three MFMA products
+// (h1h1 into one accumulator, h1h2' + h2'h1 into a second one that is folded in with 2^-11 at the end): the dropped
+// terms are <= 2^-22 relative to max|a| max|b| -- an ABSOLUTE error bound per tensor, which is what the relative-L2
+// parity criterion measures (float64 check: 7.5e-8 before the fp32 accumulation, tools/conv_accuracy.py).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pk_f16(float x, float y) {
+    const f32x2 f = {x, y};
+    const f16x2 h = __builtin_convertvector(f, f16x2);
+    return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ void split2h(float x, float y, float scale, unsigned& p1, unsigned& p2) {
+    const float xs = x * scale, ys = y * scale;
+    p1 = pk_f16(xs, ys);
+    const f16x2 h = __builtin_bit_cast(f16x2, p1);
+    p2 = pk_f16((xs - (float)h.x) * 2048.f, (ys - (float)h.y) * 2048.f);
+}
+// KIND-2 split of the weight-gradient kernel: lo plane NOT pre-scaled (one accumulator for all three products);
+// elements below 2^-19 of the tensor maximum lose their lo part to fp16 underflow -- an absolute error < 2^-30 max|v|.
+__device__ __forceinline__ void split2u(float x, float y, float scale, unsigned& p1, unsigned& p2) {
+    const float xs = x * scale, ys = y * scale;
+    p1 = pk_f16(xs, ys);
+    const f16x2 h = __builtin_bit_cast(f16x2, p1);
+    p2 = pk_f16(xs - (float)h.x, ys - (float)h.y);
+}
+
+// ------------------------------------------------------------------------------------
+// backward-weight, 32 -> 32 channels, W == 64:  dW[dy][dx][ci][co] = sum_px x[y+dy-2][px+dx-2][ci] * dz[y][px][co]
+// ------------------------------------------------------------------------------------
+// GEMM per tap with K = pixels: A[m = ci][k = px] = x^T, B[k = px][n = co] = dz.  The K = 32 bf16 MFMA
+// wants 8 consecutive PIXELS of one channel per lane, so rows are transposed to [channel][pixel] bf16
+// planes while they are split and staged (4 px x 4 ch per thread item, ds_write_b64).  One workgroup
+// (8 waves) owns `rb` consecutive image rows and ALL 25 taps: an x row is staged once and meets the five
+// dz rows y+2-dy of a 6-slot dz ring, so x and dz are read, split and staged once instead of five times.
+// Wave = (ci tile, co tile, pixel half): 25 accumulator tiles each; the two pixel halves are folded
+// through LDS at the end.  The dx shift along K is done in registers: a lane reads pixels 8g..8g+11 of
+// its channel (b128 + b64) and builds the five shifted operands with v_alignbit (dx odd) or by register
+// renaming (dx even) -- no unaligned LDS access and the x operand is reused for all five tap rows.
+// LDS rows: x 16 chunks of 16 B per channel (68 px used), chunk ^= ci & 15; dz 8 chunks, chunk ^= (co >> 1) & 7
+// (both conflict-free for the CDNA4 ds_read_b128 lane groups).
+constexpr int BW_XPL = 32 * 256;                          // bytes: x plane of one row stage
+constexpr int BW_ZPL = 32 * 128;                          // bytes: dz plane of one row stage
+constexpr int BW_LDS = 2 * 3 * BW_XPL + 6 * 3 * BW_ZPL;   // 122,880 B (three planes; also >= the 102,400 B fold buffer)
+
+// KIND 0: bf16 planes x3, six products;  KIND 2: fp16 planes x2 scaled per segment by the absmax of x / dz, three products
+// (the host guarantees that a workgroup's rows lie in ONE segment)
+template <int KIND>
+__device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsigned char* smem_sb) {
+    constexpr int W = 64;
+    constexpr int NPL = KIND == 2 ? 2 : 3;
+    constexpr int BW_XST = NPL * BW_XPL, BW_ZST = NPL * BW_ZPL;
+    unsigned char* const XS = smem_sb;
+    unsigned char* const ZS = smem_sb + 2 * BW_XST;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int mt = wave & 1, nt = (wave >> 1) & 1, kb = wave >> 2;
+    const int H = a.H;
+    const int R = a.nseg * a.B * H, RPS = a.B * H;
+    const int r0 = blk * a.rb, r1 = min(r0 + a.rb, R);
+
+    // staging roles: threads 0..135 move x items (halo pixel group of 4, channel quad), 256..383 dz items
+    const bool xrole = tid < 136, zrole = tid >= 256 && tid < 384;
+    const int it = xrole ? tid : tid - 256;
+    const int pxg = it >> 3, c4 = it & 7;
+    float4 sv[4];
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    float sx = 1.f, sz = 1.f, out_scale = 1.f;
+    if constexpr (KIND == 2) {
+        const int seg0 = r0 / RPS;
+        float ix, iz;
+        amax_scale(a.xmax + (size_t)seg0 * a.xmax_seg, sx, ix);
+        amax_scale(a.zmax + (size_t)seg0 * a.zmax_seg, sz, iz);
+        out_scale = ix * iz;
+    }
+
+    auto row_ptr = [&](const float* base, long seg_stride, int gr) {
+        const int seg = gr / RPS, grs = gr - seg * RPS;
+        return reinterpret_cast<const float4*>(base + (size_t)seg * seg_stride) + (size_t)grs * W * 8;
+    };
+    auto load_x = [&](int gr) {
+        const float4* gx = row_ptr(a.x, a.x_seg, gr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xx = 4 * pxg - 2 + j;
+            sv[j] = (xx >= 0 && xx < W) ? gx[xx * 8 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto load_z = [&](int gz) {
+        const float4* gzp = row_ptr(a.dz, a.dz_seg, gz);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sv[j] = gzp[(4 * pxg + j) * 8 + c4];
+    };
+    // split the 4 px x 4 ch item and write it transposed: per channel one 8-byte piece (4 pixels) per plane
+    auto store_item = [&](unsigned char* base, int plane_bytes, int row_bytes, bool is_x) {
+        const float e[4][4] = {{sv[0].x, sv[1].x, sv[2].x, sv[3].x}, {sv[0].y, sv[1].y, sv[2].y, sv[3].y},
+                               {sv[0].z, sv[1].z, sv[2].z, sv[3].z}, {sv[0].w, sv[1].w, sv[2].w, sv[3].w}};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ch = 4 * c4 + c;
+            unsigned p[3][2];
+            if constexpr (KIND == 2) {
+                const float sc = is_x ? sx : sz;
+                split2u(e[c][0], e[c][1], sc, p[0][0], p[1][0]);
+                split2u(e[c][2], e[c][3], sc, p[0][1], p[1][1]);
+            } else {
+                split3(e[c][0], e[c][1], p[0][0], p[1][0], p[2][0]);
+                split3(e[c][2], e[c][3], p[0][1], p[1][1], p[2][1]);
+            }
+            const int sw = is_x ? (ch & 15) : ((ch >> 1) & 7);
+            unsigned char* q = base + ch * row_bytes + ((((pxg >> 1) ^ sw) << 4) | ((pxg & 1) << 3));
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint2*>(q + pl * plane_bytes) = make_uint2(p[pl][0], p[pl][1]);
+        }
+    };
+    auto store_x = [&](int gr) { store_item(XS + (gr & 1) * BW_XST, BW_XPL, 256, true); };
+    auto store_z = [&](int gz) {
+        store_item(ZS + ((gz + 6) % 6) * BW_ZST, BW_ZPL, 128, false);
+        if (gz >= r0 && gz < r1) {   // bias gradient: every owned dz row is staged exactly once
+            bs[0] += (sv[0].x + sv[1].x) + (sv[2].x + sv[3].x);
+            bs[1] += (sv[0].y + sv[1].y) + (sv[2].y + sv[3].y);
+            bs[2] += (sv[0].z + sv[1].z) + (sv[2].z + sv[3].z);
+            bs[3] += (sv[0].w + sv[1].w) + (sv[2].w + sv[3].w);
+        }
+    };
+
+    // ---- prologue: dz rows r0-2 .. r0+2 and x row r0 ------------------------------------------
+    if (xrole) { load_x(r0); store_x(r0); }
+    if (zrole) {   // all five loads in flight before the first split (the accumulators are not live yet)
+        float4 pv[5][4];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int gz = r0 - 2 + k;
+            if (gz >= 0 && gz < R) { load_z(gz); for (int j = 0; j < 4; ++j) pv[k][j] = sv[j]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int gz = r0 - 2 + k;
+            if (gz >= 0 && gz < R) { for (int j = 0; j < 4; ++j) sv[j] = pv[k][j]; store_z(gz); }
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[25];
+#pragma unroll
+    for (int tp = 0; tp < 25; ++tp) acc[tp] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+    const int c0 = 4 * kb + g;
+
+#pragma unroll 1
+    for (int gr = r0; gr < r1; ++gr) {
+        const int y = gr % H;
+        const bool nx = gr + 1 < r1, nz = gr + 3 < R && gr + 3 <= r1 + 1;
+        if (xrole && nx) load_x(gr + 1);
+        if (zrole && nz) load_z(gr + 3);
+
+        // x operand of this lane: pixels 8*c0 .. 8*c0+11 (halo coordinates) of channel 16*mt + li, three planes
+        uint4 A[NPL][5];
+        {
+            const unsigned char* xs = XS + (gr & 1) * BW_XST + (16 * mt + li) * 256;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                const uint4 q = *reinterpret_cast<const uint4*>(xs + pl * BW_XPL + ((c0 ^ li) << 4));
+                const uint2 e = *reinterpret_cast<const uint2*>(xs + pl * BW_XPL + (((c0 + 1) ^ li) << 4));
+                A[pl][0] = q;
+                A[pl][2] = make_uint4(q.y, q.z, q.w, e.x);
+                A[pl][4] = make_uint4(q.z, q.w, e.x, e.y);
+                A[pl][1] = make_uint4(__builtin_amdgcn_alignbit(q.y, q.x, 16), __builtin_amdgcn_alignbit(q.z, q.y, 16),
+                                      __builtin_amdgcn_alignbit(q.w, q.z, 16), __builtin_amdgcn_alignbit(e.x, q.w, 16));
+                A[pl][3] = make_uint4(__builtin_amdgcn_alignbit(q.z, q.y, 16), __builtin_amdgcn_alignbit(q.w, q.z, 16),
+                                      __builtin_amdgcn_alignbit(e.x, q.w, 16), __builtin_amdgcn_alignbit(e.y, e.x, 16));
+            }
+        }
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy) {
+            const int yz = y + 2 - dy;
+            if (yz < 0 || yz >= H) continue;            // workgroup uniform
+            const int gz = gr + 2 - dy;
+            const unsigned char* zs = ZS + ((gz + 6) % 6) * BW_ZST + (16 * nt + li) * 128 + ((c0 ^ ((li >> 1) & 7)) << 4);
+            uint4 Bv[NPL];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) Bv[pl] = *reinterpret_cast<const uint4*>(zs + pl * BW_ZPL);
+            if constexpr (KIND == 2) {
+                constexpr int QA[3] = {1, 0, 0}, QB[3] = {0, 1, 0};     // a2 b1, a1 b2, a1 b1
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                    for (int dx = 0; dx < 5; ++dx)
+                        acc[dy * 5 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[QA[pr]][dx]), __builtin_bit_cast(f16x8, Bv[QB[pr]]),
+                                                                                  acc[dy * 5 + dx], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                    for (int dx = 0; dx < 5; ++dx)
+                        acc[dy * 5 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[PA[pr]][dx]), __builtin_bit_cast(bf16x8, Bv[PB[pr]]),
+                                                                                   acc[dy * 5 + dx], 0, 0, 0);
+            }
+        }
+        if (xrole && nx) store_x(gr + 1);
+        if (zrole && nz) store_z(gr + 3);
+        __syncthreads();
+    }
+
+    // ---- fold the two pixel halves through LDS and add into this block's partial slice --------
+    float* red = reinterpret_cast<float*>(smem_sb);      // [4 waves][25 taps][256]
+    if (kb == 1) {
+#pragma unroll
+        for (int tp = 0; tp < 25; ++tp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((wave & 3) * 25 + tp) * 256 + (4 * g + r) * 16 + li] = acc[tp][r];
+    }
+    __syncthreads();
+    if (kb == 0) {
+        float* pw = a.partial + (size_t)blk * (25 * 1024);
+#pragma unroll
+        for (int tp = 0; tp < 25; ++tp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = (acc[tp][r] + red[((wave & 3) * 25 + tp) * 256 + (4 * g + r) * 16 + li]) * out_scale;
+                float* dst = &pw[(tp * 32 + 16 * mt + 4 * g + r) * 32 + 16 * nt + li];
+                *dst = a.overwrite ? v : *dst + v;
+            }
+    }
+    __syncthreads();
+    float* redb = reinterpret_cast<float*>(smem_sb);     // [128 dz items][4]
+    if (zrole) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) redb[it * 4 + c] = bs[c];
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float v = 0.f;
+        for (int p = 0; p < 16; ++p) v += redb[((p << 3) | (tid >> 2)) * 4 + (tid & 3)];
+        float* pb = a.partial + (size_t)a.nblk * (25 * 1024) + (size_t)blk * 32;
+        pb[tid] = a.overwrite ? v : pb[tid] + v;
+    }
+}
+
+
+
+}  // namespace sbk

@@ -310,6 +310,13 @@ struct TrainIO {
     int32_t *iters_fwd, *iters_bwd;
 };
 
+// same predicate as `fuse` in run_chain (the reduce at the end must know the partial layout)
+bool train_fused(const sol_train_cfg* c, const Ws& w, int ms) {
+    const sol_karman_cfg* kc = &c->karman;
+    return pick_bww_chunk(ms) == ms && kc->X == 64 && (kc->B * kc->Y) % 32 == 0 && sol_karman_bwd_fusable(kc) && !getenv("SOL_BWW_NO_FUSE") &&
+           !getenv("SOL_CONV_NO_SB") && !getenv("SOL_CONV_NO_FP16") && sol_bww_step_ws_floats(kc->B, kc->Y, 32) <= w.part_floats[1];
+}
+
 // forward unroll + reverse sweep of the simulations [b0, b0 + c.karman.B) on stream hs
 int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, int b0, hipStream_t hs, const TrainIO& io) {
     void* stream = hs;
@@ -372,6 +379,12 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
     const size_t cl32 = w.cells * 32;
     const long seg32 = (long)(11 * cl32);
     const int CH = pick_bww_chunk(ms);
+    // weight gradients of the 32 -> 32 layers ride in the solver-adjoint launches (see k_karman_bwd_bww): 32 rows per workgroup
+    constexpr int FRB = 32;
+    const bool fuse = CH == ms && X == 64 && (B * Y) % FRB == 0 && sol_karman_bwd_fusable(kc) && !getenv("SOL_BWW_NO_FUSE") &&
+                      !getenv("SOL_CONV_NO_SB") && !getenv("SOL_CONV_NO_FP16") &&
+                      sol_bww_step_ws_floats(B, Y, FRB) <= w.part_floats[1];
+    const int wg_per = (B * Y) / FRB;
     const bool use_side = CH < ms && pool()->ok && !getenv("SOL_BWW_NO_SIDE");
     hipStream_t side = pool()->s[7];
     bool side_used = false;
@@ -417,18 +430,27 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
             const float* dz_i = w.dzb + (size_t)i * 11 * cl32;
             if (int e = sol_bww_batched(bs, feat_i, dz_i, w.part[0], n, CH, first, (long)(w.cells * 4), seg32, B, Y, X, 4, 32)) return e;
             const long amseg = 11 * SOL_AMAX_SLOTS;      // absmax slots: [step][11][64]
-            for (int l = 1; l <= 10; ++l)
+            for (int l = 1; l <= 10 && !fuse; ++l)
                 if (int e = sol_bww_batched(bs, acts_i + (size_t)(l - 1) * cl32, dz_i + (size_t)l * cl32, w.part[l], n, CH, first, seg32, seg32, B, Y, X, 32, 32,
                                             w.amax_act + ((size_t)i * 11 + (l - 1)) * SOL_AMAX_SLOTS, w.amax_dz + ((size_t)i * 11 + l) * SOL_AMAX_SLOTS,
                                             amseg, amseg)) return e;
             if (int e = sol_bww_batched(bs, acts_i + (size_t)10 * cl32, w.dO2 + (size_t)i * w.cells * 2, w.part[11], n, CH, first, seg32, (long)(w.cells * 2), B, Y, X, 32, 2)) return e;
         }
+        BwArgs jobs[10];
+        if (fuse) {       // this step's dz tensors are complete: one job per 32 -> 32 layer
+            for (int l = 1; l <= 10; ++l)
+                if (int e = sol_bww_step_job(&jobs[l - 1], act[l - 1], D[l], w.part[l], i == ms - 1 ? 1 : 0, B, Y, X, FRB,
+                                             w.amax_act + ((size_t)i * 11 + (l - 1)) * SOL_AMAX_SLOTS, am(l))) return e;
+        }
         if (i > 0) {
             if (int e = sol_conv5x5_scaled(stream, D[0], wn.wb[0], nullptr, nullptr, nullptr, w.dF, B, Y, X, 32, 2, SOL_EPI_NONE, sl, am(0), nullptr)) return e;
-            if (int e = sol_karman_step_bwd(kc, stream, w.svy + (size_t)i * w.st_vy, w.svx + (size_t)i * w.st_vx, re, io.active,
-                                            bcm, io.bc_stride, gvy, gvx, w.dF, fscale, w.gvy[cur ^ 1], w.gvx[cur ^ 1],
-                                            io.iters_bwd ? io.iters_bwd + (size_t)i * Btot + b0 : nullptr)) return e;
+            if (int e = sol_karman_step_bwd_fused(kc, stream, w.svy + (size_t)i * w.st_vy, w.svx + (size_t)i * w.st_vx, re, io.active,
+                                                  bcm, io.bc_stride, gvy, gvx, w.dF, fscale, w.gvy[cur ^ 1], w.gvx[cur ^ 1],
+                                                  io.iters_bwd ? io.iters_bwd + (size_t)i * Btot + b0 : nullptr,
+                                                  jobs, fuse ? 10 : 0, wg_per)) return e;
             cur ^= 1;
+        } else if (fuse) {
+            if (int e = sol_bww_jobs_launch(stream, jobs, 10, wg_per)) return e;     // step 0 has no adjoint to ride with
         }
     }
     if (side_used) {      // join the side stream
@@ -474,8 +496,11 @@ int train_fwd_bwd_impl(const sol_train_cfg* cfg, hipStream_t hs, const TrainIO& 
     for (int l = 0; l < NL; ++l) {
         const int cin = layer_cin(l), cout = layer_cout(l);
         const int64_t koff = layer_koff(l), boff = koff + 25 * cin * cout;
-        for (int k = 0; k < S; ++k)
-            if (int e = sol_bww_batched_reduce(hs, w[k].part[l], grads + koff, grads + boff, pick_bww_chunk(ms), B / S, Y, cin, cout, k > 0)) return e;
+        const bool fused = l >= 1 && l <= 10 && train_fused(&sub, w[0], ms);
+        for (int k = 0; k < S; ++k) {
+            if (fused) { if (int e = sol_bww_step_reduce(hs, w[k].part[l], grads + koff, grads + boff, B / S, Y, 32, cin, cout, k > 0)) return e; }
+            else if (int e = sol_bww_batched_reduce(hs, w[k].part[l], grads + koff, grads + boff, pick_bww_chunk(ms), B / S, Y, cin, cout, k > 0)) return e;
+        }
     }
     return SOL_OK;
 }
