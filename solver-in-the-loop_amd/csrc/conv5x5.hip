@@ -1074,8 +1074,9 @@ static int bww_dims(int rows, int rb, int cin, int cout, int* nblk, int* IP, int
 
 // image rows per workgroup: 8 for a single tensor; for the batched (all unrolled steps in one launch)
 // form enough rows that ~1300-2600 workgroups exist and the partial buffer stays small
-static int pick_rb(int rows) {
-    if (rows > 4096) return (rows + 255) / 256;   // one workgroup per CU (the split-bf16 kernel owns a CU's LDS)
+static int pick_rb(int rows, int cin = 32, int cout = 32) {
+    const bool thin = cin <= 4 || cout <= 4;      // thin layers: 4-wave workgroups with 20 KB of LDS, latency bound per row:
+    if (rows > 4096) return thin ? (rows + 1023) / 1024 : (rows + 255) / 256;   // 4 workgroups per CU there; one per CU for the split kernels (they own a CU's LDS)
     return RB;
 }
 
@@ -1088,7 +1089,7 @@ extern "C" size_t sol_conv5x5_bwd_weight_ws_floats(int32_t B, int32_t H, int32_t
 size_t sol_bww_batched_ws_floats(int nseg, int B, int H, int cin, int cout) {
     int nblk, IP, OP;
     const int rows = nseg * B * H;
-    bww_dims(rows, pick_rb(rows), cin, cout, &nblk, &IP, &OP);
+    bww_dims(rows, pick_rb(rows, cin, cout), cin, cout, &nblk, &IP, &OP);
     return (size_t)nblk * (25 * IP * OP + OP);
 }
 
@@ -1148,7 +1149,7 @@ extern "C" int sol_conv5x5_bwd_weight(void* stream, const float* x, const float*
 int sol_bww_batched(void* stream, const float* x, const float* dz, float* partial, int nseg, int nseg_layout, int overwrite,
                     long x_seg, long dz_seg, int B, int H, int W, int cin, int cout,
                     const unsigned* xmax, const unsigned* zmax, long xmax_seg, long zmax_seg) {
-    const int rb = pick_rb(nseg_layout * B * H);
+    const int rb = pick_rb(nseg_layout * B * H, cin, cout);
     int nblk, IP, OP;
     bww_dims(nseg_layout * B * H, rb, cin, cout, &nblk, &IP, &OP);
     return bww_launch(stream, x, dz, partial, nseg, x_seg, dz_seg, rb, overwrite, B, H, W, cin, cout, nblk, xmax, zmax, xmax_seg, zmax_seg);
@@ -1204,5 +1205,5 @@ int sol_bww_step_reduce(void* stream, const float* partial, float* dw_hwio, floa
 int sol_bww_batched_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int nseg, int B, int H,
                            int cin, int cout, int accumulate) {
     const int rows = nseg * B * H;
-    return bww_reduce(stream, partial, dw_hwio, db, rows, pick_rb(rows), cin, cout, accumulate);
+    return bww_reduce(stream, partial, dw_hwio, db, rows, pick_rb(rows, cin <= 4 ? 4 : 32, cout), cin, cout, accumulate);
 }
