@@ -52,6 +52,13 @@ int sol_karman_step_bwd_fused(const sol_karman_cfg* cfg, void* stream,
                               const float* g_vy_out, const float* g_vx_out, const float* dfeat, const float* feat_scale,
                               float* g_vy_in, float* g_vx_in, int32_t* iters, const BwArgs* bw, int nbw, int wg_per);
 int sol_karman_bwd_fusable(const sol_karman_cfg* cfg);
+int sol_karman_step_fwd_dens(const sol_karman_cfg* cfg, void* stream,
+                             const float* vy_in, const float* vx_in, const float* re, const float* active, const float* inflow,
+                             const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
+                             float* vy_out, float* vx_out, float* saved_vy, float* saved_vx,
+                             float* feat_out, const float* feat_scale, int32_t* iters,
+                             const float* dens_d_in, const float* dens_svy, const float* dens_svx, float* dens_d_out);
+int sol_density_step(const sol_karman_cfg* c, void* stream, const float* d_in, const float* svy, const float* svx, const float* inflow, float* d_out);
 int sol_bww_jobs_launch(void* stream, const BwArgs* bw, int nbw, int wg_per);
 // weight-gradient job description for one layer of ONE unrolled step with `rb` rows per workgroup (train.hip -> fused launch)
 int sol_bww_step_job(BwArgs* out, const float* x, const float* dz, float* partial, int overwrite, int B, int H, int W, int rb,

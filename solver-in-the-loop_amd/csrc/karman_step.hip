@@ -765,8 +765,7 @@ __device__ __forceinline__ void cell_coeffs(const Own& o, const unsigned char* a
 // SOLVER: 0 = plain CG, 1 = two-level preconditioned CG, 2 = direct (fast diagonalisation); separate instantiations keep
 // each variant's register allocation independent (1 and 2 exist for the 16-cell strips only)
 template <int CPT, int SOLVER>
-__global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs a) {
-    extern __shared__ __align__(16) float smem[];
+__device__ __forceinline__ void karman_fwd_body(const StepArgs& a, float* smem) {
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int Y = a.Y, X = a.X, N = Y * X, nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
     const int lx = __ffs(X) - 1;                 // X is a power of two: k / X == k >> lx
@@ -962,6 +961,60 @@ __global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs 
     SOL_STAMP(8);
     if (fdp == 1.2345678e-30f && a.iters) a.iters[b] = -2;      // never true: keeps the prefetch loads alive
 }
+
+template <int CPT, int SOLVER>
+__global__ void __launch_bounds__(CPT == 16 ? 512 : 1024) k_karman_fwd(StepArgs a) {
+    extern __shared__ __align__(16) float smem[];
+    karman_fwd_body<CPT, SOLVER>(a, smem);
+}
+
+// One advection step of the passive density of ONE simulation straight from global memory (same arithmetic as phase 3 /
+// k_density_chain).  In the training graph these workgroups ride in the NEXT step's solver launch (k_karman_fwd_dens): the
+// density of step i-1 only needs the saved post-diffusion velocity of step i-1, and 250 CUs idle during a solver launch.
+struct DensStep {
+    int B, Y, X, inflow_before;
+    float dtdx, dt;
+    const float *d_in, *svy, *svx, *inflow;   // [B][...] of the step being advected
+    float* d_out;
+};
+__device__ __forceinline__ void density_step_body(const DensStep& q, int b) {
+    const int Y = q.Y, X = q.X, N = Y * X, XP = X + 1;
+    const float* gd = q.d_in + (size_t)b * N;
+    const float* sy = q.svy + (size_t)b * (Y + 1) * X;
+    const float* sx = q.svx + (size_t)b * Y * XP;
+#pragma unroll 4
+    for (int k = threadIdx.x; k < N; k += blockDim.x) {
+        const int j = k / X, i = k - j * X;
+        const float uy = 0.5f * (sy[k] + sy[k + X]);
+        const float ux = 0.5f * (sx[j * XP + i] + sx[j * XP + i + 1]);
+        const float oy = -uy * q.dtdx, ox = -ux * q.dtdx;
+        const float fy = floorf(oy), fx = floorf(ox);
+        const float wy = oy - fy, wx = ox - fx;
+        const int j0 = j + (int)fy, i0 = i + (int)fx;
+        float f[2][2];
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+            for (int di = 0; di < 2; ++di) {
+                const int jj = j0 + dj, ii = i0 + di;
+                float v = 0.f;   // extrapolation 'constant': one ring of zero ghost cells
+                if (jj >= 0 && jj < Y && ii >= 0 && ii < X) {
+                    v = gd[jj * X + ii];
+                    if (q.inflow_before) v += q.inflow[jj * X + ii];
+                }
+                f[dj][di] = v;
+            }
+        float v = (1.f - wy) * ((1.f - wx) * f[0][0] + wx * f[0][1]) + wy * ((1.f - wx) * f[1][0] + wx * f[1][1]);
+        if (!q.inflow_before) v += q.inflow[k] * q.dt;
+        q.d_out[(size_t)b * N + k] = v;
+    }
+}
+__global__ void __launch_bounds__(512) k_karman_fwd_dens(StepArgs a, DensStep q) {
+    extern __shared__ __align__(16) float smem[];
+    if ((int)blockIdx.x < a.B) karman_fwd_body<16, 2>(a, smem);
+    else density_step_body(q, (int)blockIdx.x - a.B);
+}
+__global__ void __launch_bounds__(512) k_density_step(DensStep q) { density_step_body(q, blockIdx.x); }
 
 // ------------------------------------------------------------------------------------
 // backward (adjoint w.r.t. the input velocity)
@@ -1373,7 +1426,7 @@ int sol_init_karman_kernels() {
                             reinterpret_cast<const void*>(k_karman_fwd<16, 0>), reinterpret_cast<const void*>(k_karman_bwd<16, 0>),
                             reinterpret_cast<const void*>(k_karman_fwd<16, 1>), reinterpret_cast<const void*>(k_karman_bwd<16, 1>),
                             reinterpret_cast<const void*>(k_karman_fwd<16, 2>), reinterpret_cast<const void*>(k_karman_bwd<16, 2>),
-                            reinterpret_cast<const void*>(k_karman_bwd_bww)};
+                            reinterpret_cast<const void*>(k_karman_bwd_bww), reinterpret_cast<const void*>(k_karman_fwd_dens)};
         for (const void* k : ks)
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return sol_set_error(SOL_ERR_HIP, "hipFuncSetAttribute(karman kernels) failed");
@@ -1442,13 +1495,14 @@ int sol_density_chain(const sol_karman_cfg* c, void* stream, int ms, const float
 extern "C" int sol_karman_precond_supported(int32_t Y, int32_t X) { return precond_ok(Y, X) ? 1 : 0; }
 extern "C" int sol_karman_direct_supported(int32_t Y, int32_t X) { return (Y == FD_Y && X == FD_X) ? 1 : 0; }
 
-extern "C" int sol_karman_step_fwd(const sol_karman_cfg* cfg, void* stream,
+static int step_fwd_impl(const sol_karman_cfg* cfg, void* stream,
                                    const float* d_in, const float* vy_in, const float* vx_in,
                                    const float* re, const float* active, const float* inflow,
                                    const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
                                    float* d_out, float* vy_out, float* vx_out,
                                    float* saved_vy, float* saved_vx,
-                                   float* feat_out, const float* feat_scale, int32_t* iters) {
+                                   float* feat_out, const float* feat_scale, int32_t* iters,
+                                   const float* dens_d_in, const float* dens_svy, const float* dens_svx, float* dens_d_out) {
     if (int e = check_cfg(cfg)) return e;
     SOL_REQUIRE(vy_in && vx_in && re && active && velBCy && velBCyMask && vy_out && vx_out,
                 "sol_karman_step_fwd: NULL pointer argument");
@@ -1463,10 +1517,48 @@ extern "C" int sol_karman_step_fwd(const sol_karman_cfg* cfg, void* stream,
     if (feat_scale) { a.fs0 = feat_scale[0]; a.fs1 = feat_scale[1]; a.fs2 = feat_scale[2]; }
     a.iters = iters;
     const int cpt = pick_cpt(cfg);
+    if (dens_d_out) {   // density workgroups of the PREVIOUS step ride in this launch (direct-solver kernels only)
+        SOL_REQUIRE(cpt == 16 && a.fd && dens_d_in && dens_svy && dens_svx && inflow, "fused solver + density launch: unsupported configuration");
+        if (int e = sol_init_karman_kernels()) return e;
+        DensStep q{cfg->B, cfg->Y, cfg->X, cfg->inflow_before, cfg->dt / cfg->dx, cfg->dt, dens_d_in, dens_svy, dens_svx, inflow, dens_d_out};
+        hipLaunchKernelGGL(k_karman_fwd_dens, dim3(2 * cfg->B), dim3(512), lds_bytes(cfg->Y, cfg->X, 16), (hipStream_t)stream, a, q);
+        SOL_LAUNCH_CHECK();
+        return SOL_OK;
+    }
     if (cpt != 16) return launch_step(k_karman_fwd<8, 0>, 8, cfg, stream, a);
     if (a.fd) return launch_step(k_karman_fwd<16, 2>, 16, cfg, stream, a);
     if (a.cinv) return launch_step(k_karman_fwd<16, 1>, 16, cfg, stream, a);
     return launch_step(k_karman_fwd<16, 0>, 16, cfg, stream, a);
+}
+
+extern "C" int sol_karman_step_fwd(const sol_karman_cfg* cfg, void* stream,
+                                   const float* d_in, const float* vy_in, const float* vx_in,
+                                   const float* re, const float* active, const float* inflow,
+                                   const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
+                                   float* d_out, float* vy_out, float* vx_out,
+                                   float* saved_vy, float* saved_vx,
+                                   float* feat_out, const float* feat_scale, int32_t* iters) {
+    return step_fwd_impl(cfg, stream, d_in, vy_in, vx_in, re, active, inflow, velBCy, velBCyMask, bc_batch_stride, d_out, vy_out, vx_out,
+                         saved_vy, saved_vx, feat_out, feat_scale, iters, nullptr, nullptr, nullptr, nullptr);
+}
+
+// internal (train.hip): the solver step with the density advection of the previous step in the same launch
+int sol_karman_step_fwd_dens(const sol_karman_cfg* cfg, void* stream,
+                             const float* vy_in, const float* vx_in, const float* re, const float* active, const float* inflow,
+                             const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
+                             float* vy_out, float* vx_out, float* saved_vy, float* saved_vx,
+                             float* feat_out, const float* feat_scale, int32_t* iters,
+                             const float* dens_d_in, const float* dens_svy, const float* dens_svx, float* dens_d_out) {
+    return step_fwd_impl(cfg, stream, nullptr, vy_in, vx_in, re, active, inflow, velBCy, velBCyMask, bc_batch_stride, nullptr, vy_out, vx_out,
+                         saved_vy, saved_vx, feat_out, feat_scale, iters, dens_d_in, dens_svy, dens_svx, dens_d_out);
+}
+// internal: one density step alone (the last step of the unroll)
+int sol_density_step(const sol_karman_cfg* c, void* stream, const float* d_in, const float* svy, const float* svx, const float* inflow, float* d_out) {
+    SOL_REQUIRE(c && d_in && svy && svx && inflow && d_out, "sol_density_step: NULL pointer argument");
+    DensStep q{c->B, c->Y, c->X, c->inflow_before, c->dt / c->dx, c->dt, d_in, svy, svx, inflow, d_out};
+    hipLaunchKernelGGL(k_density_step, dim3(c->B), dim3(512), 0, (hipStream_t)stream, q);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
 }
 
 static int step_bwd_impl(const sol_karman_cfg* cfg, void* stream,

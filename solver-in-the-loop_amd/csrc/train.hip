@@ -339,6 +339,7 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
 
     // ---------------- forward unroll ----------------
     const bool dens_inline = getenv("SOL_DENSITY_INLINE") != nullptr;
+    const bool dens_fused = !dens_inline && io.d_final && sol_karman_bwd_fusable(kc) && !getenv("SOL_DENSITY_NO_FUSE");
     for (int i = 0; i < ms; ++i) {
         const float* din = i == 0 ? d0 : w.d + (size_t)(i - 1) * w.st_d;
         const float* vyin = i == 0 ? vy0 : w.vy + (size_t)(i - 1) * w.st_vy;
@@ -347,10 +348,19 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         float* vycur = w.vy + (size_t)i * w.st_vy;
         float* vxcur = w.vx + (size_t)i * w.st_vx;
         float* feat = w.feat + (size_t)i * w.cells * 4;
-        // the passive density is advected off the critical path (sol_density_chain below): d_out = NULL here
-        if (int e = sol_karman_step_fwd(kc, stream, din, vyin, vxin, re, io.active, io.inflow, bcv, bcm, io.bc_stride,
-                                        dens_inline ? dcur : nullptr, vycur, vxcur, w.svy + (size_t)i * w.st_vy, w.svx + (size_t)i * w.st_vx,
-                                        feat, fscale, io.iters_fwd ? io.iters_fwd + (size_t)i * Btot + b0 : nullptr)) return e;
+        // The passive density leaves the critical path.  With the direct-solver kernels the density advection of step
+        // i-1 (it only needs that step's saved velocity) rides in the solver launch of step i as B extra workgroups;
+        // otherwise the whole chain is one launch after the unroll (sol_density_chain below).
+        float* svy_i = w.svy + (size_t)i * w.st_vy;
+        float* svx_i = w.svx + (size_t)i * w.st_vx;
+        int32_t* it_i = io.iters_fwd ? io.iters_fwd + (size_t)i * Btot + b0 : nullptr;
+        if (dens_fused && i >= 1) {
+            const float* dprev = i == 1 ? d0 : w.d + (size_t)(i - 2) * w.st_d;
+            if (int e = sol_karman_step_fwd_dens(kc, stream, vyin, vxin, re, io.active, io.inflow, bcv, bcm, io.bc_stride, vycur, vxcur, svy_i, svx_i,
+                                                 feat, fscale, it_i, dprev, w.svy + (size_t)(i - 1) * w.st_vy, w.svx + (size_t)(i - 1) * w.st_vx,
+                                                 w.d + (size_t)(i - 1) * w.st_d)) return e;
+        } else if (int e = sol_karman_step_fwd(kc, stream, din, vyin, vxin, re, io.active, io.inflow, bcv, bcm, io.bc_stride,
+                                               dens_inline ? dcur : nullptr, vycur, vxcur, svy_i, svx_i, feat, fscale, it_i)) return e;
         float* act[11];
         for (int k = 0; k < 11; ++k) act[k] = w.acts + ((size_t)i * 11 + k) * w.cells * 32;
         if (int e = net_forward(c, stream, wn, feat, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS)) return e;
@@ -361,10 +371,14 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
     }
     if (dens_inline) {
         if (io.d_final) SOL_HIP_CHECK(hipMemcpyAsync(io.d_final + (size_t)b0 * w.N, w.d + (size_t)(ms - 1) * w.st_d, w.st_d * sizeof(float), hipMemcpyDeviceToDevice, hs));
+    } else if (dens_fused) {
+        // steps 0 .. ms-2 were advected inside the solver launches; the last one has no launch to ride with
+        const float* dprev = ms == 1 ? d0 : w.d + (size_t)(ms - 2) * w.st_d;
+        if (int e = sol_density_step(kc, stream, dprev, w.svy + (size_t)(ms - 1) * w.st_vy, w.svx + (size_t)(ms - 1) * w.st_vx, io.inflow,
+                                     io.d_final + (size_t)b0 * w.N)) return e;
     } else if (io.d_final) {
-        // all saved velocities exist now: the whole density chain is ONE launch (one workgroup per simulation, ~0.1 ms).
-        // On the main stream: as a concurrent graph branch it takes 6 CUs away from the 256-workgroup conv launches,
-        // which then need a second round (measured +1.2 ms per step).
+        // all saved velocities exist now: the whole density chain is ONE launch (one workgroup per simulation, ~0.3 ms)
+        // on the main stream (as a concurrent graph branch it takes 6 CUs away from the 256-workgroup conv launches)
         if (int e = sol_density_chain(kc, stream, ms, d0, w.svy, w.svx, (long)w.st_vy, (long)w.st_vx, io.inflow, nullptr, (long)w.st_d,
                                       io.d_final + (size_t)b0 * w.N)) return e;
     }
