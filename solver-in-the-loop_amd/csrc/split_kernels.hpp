@@ -244,16 +244,25 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
             for (int r = 0; r < 4; ++r) red[((wave & 3) * 25 + tp) * 256 + (4 * g + r) * 16 + li] = acc[tp][r];
     }
     __syncthreads();
-    if (kb == 0) {
-        float* pw = a.partial + (size_t)blk * (25 * 1024);
+    if (kb == 0) {      // second pixel half added in LDS, scaled: red = this block's complete [tile][tap][16 ci][16 co] sums
 #pragma unroll
         for (int tp = 0; tp < 25; ++tp)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = (acc[tp][r] + red[((wave & 3) * 25 + tp) * 256 + (4 * g + r) * 16 + li]) * out_scale;
-                float* dst = &pw[(tp * 32 + 16 * mt + 4 * g + r) * 32 + 16 * nt + li];
-                *dst = a.overwrite ? v : *dst + v;
+                float* q = &red[((wave & 3) * 25 + tp) * 256 + (4 * g + r) * 16 + li];
+                *q = (acc[tp][r] + *q) * out_scale;
             }
+    }
+    __syncthreads();
+    {   // all 512 threads move 16-byte pieces (4 consecutive co of one ci) into the block's partial slice
+        float* pw = a.partial + (size_t)blk * (25 * 1024);
+        for (int e = tid; e < 4 * 25 * 64; e += 512) {
+            const int c4 = e & 3, row = (e >> 2) & 15, tp = (e >> 6) % 25, wt = e / (25 * 64);      // wt = (mt, nt) tile
+            const float4 v = *reinterpret_cast<const float4*>(&red[(wt * 25 + tp) * 256 + row * 16 + c4 * 4]);
+            float4* dst = reinterpret_cast<float4*>(&pw[(tp * 32 + 16 * (wt & 1) + row) * 32 + 16 * (wt >> 1) + c4 * 4]);
+            if (a.overwrite) *dst = v;
+            else { const float4 o = *dst; *dst = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w); }
+        }
     }
     __syncthreads();
     float* redb = reinterpret_cast<float*>(smem_sb);     // [128 dz items][4]
