@@ -91,11 +91,12 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
     const int R = a.nseg * a.B * H, RPS = a.B * H;
     const int r0 = blk * a.rb, r1 = min(r0 + a.rb, R);
 
-    // staging roles: threads 0..135 move x items (halo pixel group of 4, channel quad), 256..383 dz items
-    const bool xrole = tid < 136, zrole = tid >= 256 && tid < 384;
+    // staging roles, one item = 2 pixels x 4 channels: threads 0..255 move the x items of halo pixels 0..63 (and threads
+    // 0..15 a second one for halo pixels 64..67), threads 256..511 the dz items -- every wave carries an equal share
+    const bool xrole = tid < 256, zrole = !xrole, xrole2 = tid < 16;
     const int it = xrole ? tid : tid - 256;
-    const int pxg = it >> 3, c4 = it & 7;
-    float4 sv[4];
+    const int pxg = it >> 3, c4 = it & 7;          // 2-pixel group, channel quad
+    float4 sv[2], sv2[2];
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
     float sx = 1.f, sz = 1.f, out_scale = 1.f;
     if constexpr (KIND == 2) {
@@ -113,62 +114,65 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
     auto load_x = [&](int gr) {
         const float4* gx = row_ptr(a.x, a.x_seg, gr);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int xx = 4 * pxg - 2 + j;
+        for (int j = 0; j < 2; ++j) {
+            const int xx = 2 * pxg - 2 + j;
             sv[j] = (xx >= 0 && xx < W) ? gx[xx * 8 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (xrole2) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int xx = 2 * (32 + pxg) - 2 + j;       // halo pixels 64..67 -> image pixels 62..65
+                sv2[j] = xx < W ? gx[xx * 8 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
     auto load_z = [&](int gz) {
         const float4* gzp = row_ptr(a.dz, a.dz_seg, gz);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sv[j] = gzp[(4 * pxg + j) * 8 + c4];
+        for (int j = 0; j < 2; ++j) sv[j] = gzp[(2 * pxg + j) * 8 + c4];
     };
-    // split the 4 px x 4 ch item and write it transposed: per channel one 8-byte piece (4 pixels) per plane
-    auto store_item = [&](unsigned char* base, int plane_bytes, int row_bytes, bool is_x) {
-        const float e[4][4] = {{sv[0].x, sv[1].x, sv[2].x, sv[3].x}, {sv[0].y, sv[1].y, sv[2].y, sv[3].y},
-                               {sv[0].z, sv[1].z, sv[2].z, sv[3].z}, {sv[0].w, sv[1].w, sv[2].w, sv[3].w}};
+    // split the 2 px x 4 ch item and write it transposed: per channel one 4-byte piece (2 pixels) per plane
+    auto store_item = [&](const float4 (&v)[2], int pg, unsigned char* base, int plane_bytes, int row_bytes, bool is_x) {
+        const float e[4][2] = {{v[0].x, v[1].x}, {v[0].y, v[1].y}, {v[0].z, v[1].z}, {v[0].w, v[1].w}};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int ch = 4 * c4 + c;
-            unsigned p[3][2];
-            if constexpr (KIND == 2) {
-                const float sc = is_x ? sx : sz;
-                split2u(e[c][0], e[c][1], sc, p[0][0], p[1][0]);
-                split2u(e[c][2], e[c][3], sc, p[0][1], p[1][1]);
-            } else {
-                split3(e[c][0], e[c][1], p[0][0], p[1][0], p[2][0]);
-                split3(e[c][2], e[c][3], p[0][1], p[1][1], p[2][1]);
-            }
+            unsigned p[3];
+            if constexpr (KIND == 2) split2u(e[c][0], e[c][1], is_x ? sx : sz, p[0], p[1]);
+            else split3(e[c][0], e[c][1], p[0], p[1], p[2]);
             const int sw = is_x ? (ch & 15) : ((ch >> 1) & 7);
-            unsigned char* q = base + ch * row_bytes + ((((pxg >> 1) ^ sw) << 4) | ((pxg & 1) << 3));
+            unsigned char* q = base + ch * row_bytes + ((((pg >> 2) ^ sw) << 4) | ((pg & 3) << 2));
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint2*>(q + pl * plane_bytes) = make_uint2(p[pl][0], p[pl][1]);
+            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<unsigned*>(q + pl * plane_bytes) = p[pl];
         }
     };
-    auto store_x = [&](int gr) { store_item(XS + (gr & 1) * BW_XST, BW_XPL, 256, true); };
+    auto store_x = [&](int gr) {
+        store_item(sv, pxg, XS + (gr & 1) * BW_XST, BW_XPL, 256, true);
+        if (xrole2) store_item(sv2, 32 + pxg, XS + (gr & 1) * BW_XST, BW_XPL, 256, true);
+    };
     auto store_z = [&](int gz) {
-        store_item(ZS + ((gz + 6) % 6) * BW_ZST, BW_ZPL, 128, false);
+        store_item(sv, pxg, ZS + ((gz + 6) % 6) * BW_ZST, BW_ZPL, 128, false);
         if (gz >= r0 && gz < r1) {   // bias gradient: every owned dz row is staged exactly once
-            bs[0] += (sv[0].x + sv[1].x) + (sv[2].x + sv[3].x);
-            bs[1] += (sv[0].y + sv[1].y) + (sv[2].y + sv[3].y);
-            bs[2] += (sv[0].z + sv[1].z) + (sv[2].z + sv[3].z);
-            bs[3] += (sv[0].w + sv[1].w) + (sv[2].w + sv[3].w);
+            bs[0] += sv[0].x + sv[1].x;
+            bs[1] += sv[0].y + sv[1].y;
+            bs[2] += sv[0].z + sv[1].z;
+            bs[3] += sv[0].w + sv[1].w;
         }
     };
 
     // ---- prologue: dz rows r0-2 .. r0+2 and x row r0 ------------------------------------------
     if (xrole) { load_x(r0); store_x(r0); }
     if (zrole) {   // all five loads in flight before the first split (the accumulators are not live yet)
-        float4 pv[5][4];
+        float4 pv[5][2];
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             const int gz = r0 - 2 + k;
-            if (gz >= 0 && gz < R) { load_z(gz); for (int j = 0; j < 4; ++j) pv[k][j] = sv[j]; }
+            if (gz >= 0 && gz < R) { load_z(gz); for (int j = 0; j < 2; ++j) pv[k][j] = sv[j]; }
         }
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             const int gz = r0 - 2 + k;
-            if (gz >= 0 && gz < R) { for (int j = 0; j < 4; ++j) sv[j] = pv[k][j]; store_z(gz); }
+            if (gz >= 0 && gz < R) { for (int j = 0; j < 2; ++j) sv[j] = pv[k][j]; store_z(gz); }
         }
     }
     __syncthreads();
@@ -265,7 +269,7 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
         }
     }
     __syncthreads();
-    float* redb = reinterpret_cast<float*>(smem_sb);     // [128 dz items][4]
+    float* redb = reinterpret_cast<float*>(smem_sb);     // [256 dz items][4]
     if (zrole) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) redb[it * 4 + c] = bs[c];
@@ -273,7 +277,7 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
     __syncthreads();
     if (tid < 32) {
         float v = 0.f;
-        for (int p = 0; p < 16; ++p) v += redb[((p << 3) | (tid >> 2)) * 4 + (tid & 3)];
+        for (int p = 0; p < 32; ++p) v += redb[((p << 3) | (tid >> 2)) * 4 + (tid & 3)];
         float* pb = a.partial + (size_t)a.nblk * (25 * 1024) + (size_t)blk * 32;
         pb[tid] = a.overwrite ? v : pb[tid] + v;
     }
