@@ -175,13 +175,16 @@ int sol_conv5x5(void* stream, const float* x, const float* packed, const float* 
                 int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,
                 int32_t epilogue, float slope);
 
-/* sol_conv5x5 with per-tensor absmax bookkeeping: `x_absmax` / `y_absmax` are DEVICE arrays of 64 uint32 slots whose
- * maximum holds the bit pattern of max|x| / max|y| (non-negative floats compare like unsigned integers).
+/* sol_conv5x5 with per-tensor absmax bookkeeping: `x_absmax` / `y_absmax` are DEVICE arrays of SOL_ABSMAX_SLOTS
+ * uint32 slots (16-byte aligned; one slot per workgroup of a full-chip launch, because same-address atomics serialise
+ * in the L2) whose maximum holds the bit pattern of max|x| / max|y| (non-negative floats compare like unsigned integers).
  * y_absmax (or NULL): slots are raised with atomic max by this launch (the caller zeroes them once per tensor).
  * x_absmax (or NULL): when given for a 32-input-channel, W % 64 == 0 convolution, the fp32 products are evaluated as
  * THREE fp16 MFMA products of operands scaled by a power of two derived from the absmax (22-bit operand splits, fp32
  * accumulation; error relative to max|x| max|w| like the fp32 kernel's) instead of six bf16 products.  The producer of x
  * publishes its absmax in the unrolled training graph, so no extra pass over the data exists. */
+#define SOL_ABSMAX_SLOTS 256
+int32_t sol_absmax_slots(void);   /* == SOL_ABSMAX_SLOTS of the library that was loaded */
 int sol_conv5x5_scaled(void* stream, const float* x, const float* packed, const float* bias,
                        const float* residual, const float* act_ref, float* y,
                        int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,

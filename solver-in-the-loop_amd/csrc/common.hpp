@@ -29,10 +29,10 @@ struct ConvArgs {
     int TW, RPW, tiles_x;
     const void* wsb;   // split-bf16 weight planes (second section of the packed buffer), cin == 32 only
     const void* wsh;   // split-fp16 weight planes + header (third section), cin == 32 only
-    const unsigned* xmax;   // [64] slots, max over them = bits of max|x| (non-negative float) -> fp16 path; NULL: bf16 path
-    unsigned* ymax;         // [64] slots updated with max|y| (atomic max on the float bits), or NULL
+    const unsigned* xmax;   // [SOL_AMAX_SLOTS] slots, max over them = bits of max|x| (non-negative float) -> fp16 path; NULL: bf16 path
+    unsigned* ymax;         // [SOL_AMAX_SLOTS] slots updated with max|y| (atomic max on the float bits), or NULL
 };
-constexpr int SOL_AMAX_SLOTS = 64;
+constexpr int SOL_AMAX_SLOTS = 256;   // one per workgroup of a 256-WG launch: same-address atomics serialise in L2 (~0.3 us each)
 // backward-weight arguments
 struct BwArgs {
     const float *x, *dz;
@@ -109,10 +109,12 @@ __device__ __forceinline__ float block_sum(float v, float* red, int slot) {
     return s;
 }
 
-// max over the 64 slots of an absmax array (bits of non-negative floats) -> power-of-two scale 2^shift with
+// max over the SOL_AMAX_SLOTS slots of an absmax array (bits of non-negative floats) -> power-of-two scale 2^shift with
 // max * 2^shift in [2^14, 2^15), and its inverse
 __device__ __forceinline__ void amax_scale(const unsigned* slots, float& scale, float& inv) {
-    unsigned m = slots[threadIdx.x & 63];
+    static_assert(SOL_AMAX_SLOTS == 256, "one uint4 per lane");
+    const uint4 q = reinterpret_cast<const uint4*>(slots)[threadIdx.x & 63];
+    unsigned m = max(max(q.x, q.y), max(q.z, q.w));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
     int e = (int)(m >> 23) - 127;                     // max in [2^e, 2^(e+1))

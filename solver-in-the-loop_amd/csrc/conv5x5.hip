@@ -966,6 +966,11 @@ int check_shape(int B, int H, int W, int cin, int cout) {
 
 }  // namespace
 
+extern "C" int32_t sol_absmax_slots(void) {
+    static_assert(SOL_AMAX_SLOTS == SOL_ABSMAX_SLOTS, "include/sol_hip.h and common.hpp disagree");
+    return SOL_AMAX_SLOTS;
+}
+
 extern "C" size_t sol_conv5x5_packed_floats(int32_t cin, int32_t cout, int32_t /*mode*/) {
     // fp32 section (all shapes) + split-bf16 planes for the 32-input-channel kernels (conv5x5_sb.hip)
     return (size_t)25 * pad_in(cin) * pad_out(cout) +

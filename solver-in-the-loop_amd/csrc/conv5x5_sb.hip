@@ -405,7 +405,7 @@ int sol_conv_sb_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int 
     return SOL_OK;
 }
 
-// fp16 section: header (4 floats) + 25 taps x 2 planes x OP x 32 fp16, + 64 absmax slots of the weights (scratch)
+// fp16 section: header (4 floats) + 25 taps x 2 planes x OP x 32 fp16, + SOL_AMAX_SLOTS absmax slots of the weights (scratch)
 size_t sol_conv_sh_packed_floats(int OP) { return 4 + (size_t)25 * 2 * OP * 16 + SOL_AMAX_SLOTS; }
 
 int sol_conv_sh_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int mode, void* out) {

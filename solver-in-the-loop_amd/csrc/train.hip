@@ -149,7 +149,7 @@ struct Ws {
     float *gA, *gB;                // [cells][32]
     float *dO4, *dO2, *dF;         // [cells][4], [msteps][cells][2], [cells][2]
     float *dzb;                    // [msteps][11][cells][32]: pre-activation gradients kept for the batched weight gradient
-    uint32_t *amax_act, *amax_dz;  // [msteps][11][64]: absmax slots of every 32-channel activation / gradient tensor
+    uint32_t *amax_act, *amax_dz;  // [msteps][11][SOL_AMAX_SLOTS]: absmax slots of every 32-channel activation / gradient tensor
     size_t amax_words;             // (both arrays are contiguous: one memset per training step)
     float *gvy[2], *gvx[2];
     float *wf[NL], *wb[NL], *bias[NL];
@@ -210,7 +210,7 @@ int pack_all(const sol_train_cfg* /*c*/, void* stream, const float* params, Ws& 
 }
 
 // CNN forward (model_mars_moon, karman_train.py:101-138).  acts: 11 buffers [cells][32].
-// amax: [11][64] absmax slots of act[0..10] (zeroed by the caller): every producer publishes max|y| and every
+// amax: [11][SOL_AMAX_SLOTS] absmax slots of act[0..10] (zeroed by the caller): every producer publishes max|y| and every
 // 32-channel consumer derives its fp16 operand scale from it (sol_conv5x5_scaled).
 int net_forward(const sol_train_cfg* c, void* s, const Ws& w, const float* feat, float* const* act, float* O, uint32_t* amax) {
     const int B = c->karman.B, Y = c->karman.Y, X = c->karman.X;
@@ -443,7 +443,7 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
             const float* acts_i = w.acts + (size_t)i * 11 * cl32;
             const float* dz_i = w.dzb + (size_t)i * 11 * cl32;
             if (int e = sol_bww_batched(bs, feat_i, dz_i, w.part[0], n, CH, first, (long)(w.cells * 4), seg32, B, Y, X, 4, 32)) return e;
-            const long amseg = 11 * SOL_AMAX_SLOTS;      // absmax slots: [step][11][64]
+            const long amseg = 11 * SOL_AMAX_SLOTS;      // absmax slots: [step][11][SOL_AMAX_SLOTS]
             for (int l = 1; l <= 10 && !fuse; ++l)
                 if (int e = sol_bww_batched(bs, acts_i + (size_t)(l - 1) * cl32, dz_i + (size_t)l * cl32, w.part[l], n, CH, first, seg32, seg32, B, Y, X, 32, 32,
                                             w.amax_act + ((size_t)i * 11 + (l - 1)) * SOL_AMAX_SLOTS, w.amax_dz + ((size_t)i * 11 + l) * SOL_AMAX_SLOTS,

@@ -281,9 +281,9 @@ def test_conv5x5_scaled_fp16_path_against_float64():
         w = (torch.randn(5, 5, 32, cout, generator=gen) * 0.05).float().to(DEV)
         bias = torch.zeros(cout, dtype=torch.float32, device=DEV)
         packed = ops._pack(w, 32, cout, ops.CONV_FWD)
-        xmax = torch.zeros(64, dtype=torch.int32, device=DEV)
+        xmax = torch.zeros(ops.AMAX_SLOTS, dtype=torch.int32, device=DEV)
         xmax[5] = int(x.abs().max().view(torch.int32).item())              # any slot: the consumer takes the max over all 64
-        ymax = torch.zeros(64, dtype=torch.int32, device=DEV)
+        ymax = torch.zeros(ops.AMAX_SLOTS, dtype=torch.int32, device=DEV)
         y = torch.empty(B, Y, X, cout, dtype=torch.float32, device=DEV)
         check(lib.sol_conv5x5_scaled(stream(), ptr(x), ptr(packed), ptr(bias), None, None, ptr(y), B, Y, X, 32, cout,
                                      ops.EPI_LRELU, 0.3, ptr(xmax), ptr(ymax)))
@@ -299,7 +299,7 @@ def test_conv5x5_scaled_fp16_path_against_float64():
     bias = torch.linspace(-1, 1, cout, dtype=torch.float32).to(DEV)
     y = torch.empty(B, Y, X, cout, dtype=torch.float32, device=DEV)
     check(lib.sol_conv5x5_scaled(stream(), ptr(x), ptr(ops._pack(w, 32, cout, ops.CONV_FWD)), ptr(bias), None, None, ptr(y), B, Y, X, 32, cout,
-                                 ops.EPI_LRELU, 0.3, ptr(torch.zeros(64, dtype=torch.int32, device=DEV)), None))
+                                 ops.EPI_LRELU, 0.3, ptr(torch.zeros(ops.AMAX_SLOTS, dtype=torch.int32, device=DEV)), None))
     assert torch.equal(y, torch.nn.functional.leaky_relu(bias, 0.3).expand(B, Y, X, cout))
 
 

@@ -71,9 +71,9 @@ for (B, Y, X, cout, dist) in [(6, 128, 64, 32, "normal"), (6, 128, 64, 32, "wide
     w = torch.randn(5, 5, 32, cout, device="cuda") * 0.05
     bias = torch.randn(cout, device="cuda") * (1e-9 if dist == "tiny" else 0.1)
     packed = ops._pack(w, 32, cout, ops.CONV_FWD)
-    xmax = torch.zeros(64, dtype=torch.int32, device="cuda")
+    xmax = torch.zeros(ops.AMAX_SLOTS, dtype=torch.int32, device="cuda")
     xmax[0] = int(x.abs().max().view(torch.int32).item())
-    ymax = torch.zeros(64, dtype=torch.int32, device="cuda")
+    ymax = torch.zeros(ops.AMAX_SLOTS, dtype=torch.int32, device="cuda")
     y = torch.empty(B, Y, X, cout, device="cuda")
     call = lambda: check(lib.sol_conv5x5_scaled(stream(), ptr(x), ptr(packed), ptr(bias), None, None, ptr(y), B, Y, X, 32, cout,
                                                  ops.EPI_NONE, 0.3, ptr(xmax), ptr(ymax)))
