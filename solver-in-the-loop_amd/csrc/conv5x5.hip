@@ -67,15 +67,6 @@ __global__ void __launch_bounds__(256) k_conv5x5(ConvArgs a) {
     const int b = blk / rows_blk;
     const int y0 = ty * RPW, x0 = tx * TW;
 
-    // thin layers: this lane's B operands of all 25 taps are loaded before the halo staging (their latency hides behind it)
-    float bw4[CIN == 4 ? 25 : 1][NT];
-    if constexpr (CIN == 4) {
-        const float* wbase = a.wp + (size_t)li * 4 + g;
-#pragma unroll
-        for (int tap = 0; tap < 25; ++tap)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) bw4[tap][n] = wbase[((size_t)tap * OP + n * 16) * 4];
-    }
     // ---- stage the zero padded halo tile -------------------------------------------------
     {
         constexpr int C4 = CIN / 4;
@@ -88,6 +79,13 @@ __global__ void __launch_bounds__(256) k_conv5x5(ConvArgs a) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = gx[((size_t)(b * H + yy) * W + xx) * C4 + c4];
             *reinterpret_cast<float4*>(&smem[pix * CP + c4 * 4]) = v;
+        }
+        // thin layers: the 25 x OP x 4 weight block goes through LDS with 16-byte loads.  (Per-lane dword loads of the B
+        // operands -- 50 per lane, the same 12.8 KB in all 3072 waves -- kept the texture path busy for 6.5 us of a 12.3 us launch.)
+        if constexpr (CIN == 4) {
+            const float4* gw = reinterpret_cast<const float4*>(a.wp);
+            float* wl = smem + npix * CP;
+            for (int e = tid; e < 25 * OP; e += 256) *reinterpret_cast<float4*>(&wl[e * 4]) = gw[e];
         }
     }
     __syncthreads();
@@ -125,12 +123,13 @@ __global__ void __launch_bounds__(256) k_conv5x5(ConvArgs a) {
         }
     } else {   // CIN == 4: one MFMA per tap, lane group g = channel
         const float* abase = &smem[(prr * HW + pcc) * CP + g];
+        const float* wl = smem + (RPW + 4) * HW * CP + li * 4 + g;
 #pragma unroll
         for (int tap = 0; tap < 25; ++tap) {
             const int dy = tap / 5, dx = tap - dy * 5;
             const float av = abase[(dy * HW + dx) * CP];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw4[tap][n], acc[n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wl[(tap * OP + n * 16) * 4], acc[n], 0, 0, 0);
         }
     }
 
@@ -1020,7 +1019,10 @@ static int conv_impl(void* stream, const float* x, const float* packed, const fl
     const int grid = B * (H / a.RPW) * a.tiles_x;
     const int CP = cin == 4 ? 4 : 36;
     size_t lds = (size_t)(a.RPW + 4) * (a.TW + 4) * CP * sizeof(float);
-    if (cin == 4 && lds < 4 * 16 * 32 * sizeof(float)) lds = 4 * 16 * 32 * sizeof(float);   // epilogue transposition buffers
+    if (cin == 4) {
+        lds += (size_t)25 * pad_out(cout) * 4 * sizeof(float);                                // weight block
+        if (lds < 4 * 16 * 32 * sizeof(float)) lds = 4 * 16 * 32 * sizeof(float);             // epilogue transposition buffers
+    }
     const int NT = pad_out(cout) / 16;
     hipStream_t s = (hipStream_t)stream;
     static const bool use_sb = !getenv("SOL_CONV_NO_SB");
