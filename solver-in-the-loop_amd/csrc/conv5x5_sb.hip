@@ -91,6 +91,20 @@ __global__ void k_pack_sb(const float* __restrict__ w, unsigned short* __restric
 // ------------------------------------------------------------------------------------
 // KIND 0: bf16, six products (default without absmax);  1: bf16, three leading products (experiment);
 // KIND 2: fp16, three products, per-tensor power-of-two scaling (needs a.xmax)
+// -DSOL_CONV_PROF (tools/conv_phase_probe.py builds such a library next to the product one): phase stamps (100 MHz
+// s_memrealtime, thread 0 of every workgroup, 16 per workgroup) into the buffer set with sol_conv_prof_set().
+// -DSOL_CONV_TRUNC=0|1|2 (tools/conv_variants.py): return at kernel entry / after the prologue / after the tap-row loop.
+#ifdef SOL_CONV_PROF
+__device__ long long* g_conv_prof = nullptr;
+extern "C" int sol_conv_prof_set(long long* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_conv_prof), &buf, sizeof(buf)) == hipSuccess ? 0 : -1; }
+#define SOL_CSTAMP(k) do { if (threadIdx.x == 0 && g_conv_prof) g_conv_prof[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SOL_CSTAMP(k) do { } while (0)
+#endif
+#ifndef SOL_CONV_TRUNC
+#define SOL_CONV_TRUNC 9
+#endif
+
 template <int NT, int KIND>
 __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     constexpr int OP = NT * 16;
@@ -101,6 +115,8 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     constexpr int WPL = OP * 64;                  // bytes per (dx, plane) weight block
     constexpr int WBUF = 5 * NPL * WPL;           // bytes per tap-row weight phase
     extern __shared__ __align__(16) unsigned char smem_sb[];
+    if (SOL_CONV_TRUNC == 0) return;
+    SOL_CSTAMP(0);
     const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = tid & 63, wave = (tid >> 6) & 3;
     const int g = lane >> 4, li = lane & 15;
     const int H = a.H, W = a.W;
@@ -122,6 +138,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
         amax_scale(a.xmax, sa, sai);
         out_scale = sai * reinterpret_cast<const float*>(a.wsh)[1];
     }
+    SOL_CSTAMP(10);
     constexpr int WV = WBUF / 16;                     // uint4 per weight phase
     constexpr int WPT = (WV + 767) / 768;
 
@@ -177,6 +194,8 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
         store_w(0, wv);
     }
     __syncthreads();
+    SOL_CSTAMP(1);
+    if (SOL_CONV_TRUNC == 1) return;
 
     f32x4 acc[NT], acl[NT];                           // acl: KIND 2 accumulator of the 2^-11 weighted cross terms
 #pragma unroll
@@ -245,7 +264,9 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
             store_w((dy + 1) & 1, wv);
         }
         __syncthreads();
+        SOL_CSTAMP(2 + dy);
     }
+    if (SOL_CONV_TRUNC == 2) { if (acc[0][0] + acc[NT - 1][3] == 1.2345f) a.y[tid] = acl[0][1]; return; }
     if constexpr (KIND == 2) {
 #pragma unroll
         for (int n = 0; n < NT; ++n)
@@ -305,10 +326,16 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
             }
         }
     }
+    SOL_CSTAMP(7);
     if (a.ymax) {                                     // workgroup uniform
         __syncthreads();                              // the scratch below overlaps the transposition buffers
         amax_publish(vmax, a.ymax, reinterpret_cast<float*>(smem_sb));
     }
+    SOL_CSTAMP(8);
+#ifdef SOL_CONV_PROF
+    __builtin_amdgcn_s_waitcnt(0);
+    SOL_CSTAMP(9);
+#endif
 }
 
 

@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(256) k_thin(const float* __restrict__ x, const
 #pragma unroll
     for (int tap = 0; tap < 25; ++tap)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) bw4[tap][n] = VAR == 3 || VAR == 5 ? (float)(tap + n + lane) : wbase[((size_t)tap * OP + n * 16) * 4];
+        for (int n = 0; n < NT; ++n) bw4[tap][n] = VAR == 3 || VAR >= 5 ? (float)(tap + n + lane) : wbase[((size_t)tap * OP + n * 16) * 4];
     if (VAR != 4) {
         const float4* gx = reinterpret_cast<const float4*>(x);
         for (int e = tid; e < 5 * HW; e += 256) {
@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(256) k_thin(const float* __restrict__ x, const
             *reinterpret_cast<float4*>(&smem[e * 4]) = v;
         }
     }
-    if (VAR == 5) {
+    if (VAR >= 5) {
         const float4* gw = reinterpret_cast<const float4*>(wp);
         for (int e = tid; e < 800; e += 256) *reinterpret_cast<float4*>(&smem[1360 + e * 4]) = gw[e];
     }
@@ -43,6 +43,19 @@ __global__ void __launch_bounds__(256) k_thin(const float* __restrict__ x, const
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* abase = &smem[q * 4 + g];
+    if (VAR == 6) {
+        float av[25], bv[25][NT];
+#pragma unroll
+        for (int tap = 0; tap < 25; ++tap) {
+            av[tap] = abase[((tap / 5) * HW + tap % 5) * 4];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bv[tap][n] = smem[1360 + (tap * OP + n * 16 + li) * 4 + g];
+        }
+#pragma unroll
+        for (int tap = 0; tap < 25; ++tap)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap], bv[tap][n], acc[n], 0, 0, 0);
+    } else
 #pragma unroll
     for (int tap = 0; tap < 25; ++tap) {
         const int dy = tap / 5, dx = tap - dy * 5;
@@ -113,5 +126,6 @@ int main() {
     run<3>("no weight loads", x, wp, bias, y, st);
     run<4>("no halo loads", x, wp, bias, y, st);
     run<5>("weights through LDS", x, wp, bias, y, st);
+    run<6>("LDS weights, preloaded", x, wp, bias, y, st);
     return 0;
 }
