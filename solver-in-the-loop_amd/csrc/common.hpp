@@ -136,4 +136,17 @@ __device__ __forceinline__ void amax_publish(float v, unsigned* slots, float* re
 }
 
 
+// barrier-free form: `lds2` = {running max, wave counter}, zeroed before the kernel's first barrier.  Every wave folds its max
+// into lds2[0] (LDS integer atomics are cheap) and counts itself; the LDS unit executes these in arrival order, so the wave
+// that draws the last ticket reads the complete workgroup max and issues the single global atomic.  Nobody waits for anybody.
+__device__ __forceinline__ void amax_publish_last(float v, unsigned* slots, unsigned* lds2) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&lds2[0], __float_as_uint(v));
+        const unsigned ticket = atomicAdd(&lds2[1], 1u);
+        if (ticket == (blockDim.x >> 6) - 1) atomicMax(&slots[blockIdx.x & (SOL_AMAX_SLOTS - 1)], atomicMax(&lds2[0], 0u));
+    }
+}
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -114,9 +114,11 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     constexpr int SLOT = NPL * PLANE;             // bytes per halo row
     constexpr int WPL = OP * 64;                  // bytes per (dx, plane) weight block
     constexpr int WBUF = 5 * NPL * WPL;           // bytes per tap-row weight phase
+    constexpr int AMAX_LDS = 4 * SLOT + 2 * WBUF;  // two words behind the ring and the weight buffers: workgroup max|y|, wave counter
     extern __shared__ __align__(16) unsigned char smem_sb[];
     if (SOL_CONV_TRUNC == 0) return;
     SOL_CSTAMP(0);
+    if (threadIdx.x == 0) *reinterpret_cast<uint2*>(smem_sb + AMAX_LDS) = make_uint2(0u, 0u);      // see amax_publish_last
     const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = tid & 63, wave = (tid >> 6) & 3;
     const int g = lane >> 4, li = lane & 15;
     const int H = a.H, W = a.W;
@@ -327,10 +329,8 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
         }
     }
     SOL_CSTAMP(7);
-    if (a.ymax) {                                     // workgroup uniform
-        __syncthreads();                              // the scratch below overlaps the transposition buffers
-        amax_publish(vmax, a.ymax, reinterpret_cast<float*>(smem_sb));
-    }
+    // no barrier: the last wave publishes (two barriers + a serial 12-value reduction cost 0.5 us per launch)
+    if (a.ymax) amax_publish_last(vmax, a.ymax, reinterpret_cast<unsigned*>(smem_sb + AMAX_LDS));
     SOL_CSTAMP(8);
 #ifdef SOL_CONV_PROF
     __builtin_amdgcn_s_waitcnt(0);
@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(256) k_pack_jobs(PackJobs jobs) {
     }
 }
 
-constexpr size_t sb_lds(int OP) { return (size_t)4 * 3 * 68 * 64 + 2 * (size_t)5 * 3 * OP * 64; }
+constexpr size_t sb_lds(int OP) { return (size_t)4 * 3 * 68 * 64 + 2 * (size_t)5 * 3 * OP * 64 + 16; }
 
 int init_sb_kernels() {
     static int rc = [] {
