@@ -776,24 +776,35 @@ __device__ __forceinline__ void karman_fwd_body(const StepArgs& a, float* smem) 
     float fdp = 0.f;
     if constexpr (SOLVER == 2) fdp = fd_prefetch(a.fd, a.fd_n);
     // ---- phase 1: load inputs (all global loads in flight before the first LDS store) ---
-    constexpr int MAXL = CPT + 1;              // (Y+1)*X / (Y*X/CPT) <= CPT + 1 for Y >= CPT
-    float bcv_r[MAXL], bcm_r[MAXL];            // velocity BC of this thread's v_y faces: loaded here, used by phase 2
+    // 16-byte loads: a dword load costs the texture path as much per wave as a dwordx4 one, and this phase is nothing else
+    // (X, Y are multiples of 4, so every array and every batch offset is 16-byte aligned and a v_y quad stays in one row)
+    constexpr int NV = (CPT + 1 + 3) / 4;      // float4 items of a (Y+1) x X field per thread
+    const int nQy = nVy >> 2, nQx = nVx >> 2;
+    float4 bcv_r[NV], bcm_r[NV];               // velocity BC of this thread's v_y quads: loaded here, used by phase 2
     {
-        const float* gvy = a.vy_in + (size_t)b * nVy;
-        const float* gvx = a.vx_in + (size_t)b * nVx;
-        const float* bcv = a.bcv + (size_t)b * a.bc_stride;
-        const float* bcm = a.bcm + (size_t)b * a.bc_stride;
-        float ty[MAXL], tx[MAXL], ta[CPT];
+        const float4* gvy = reinterpret_cast<const float4*>(a.vy_in + (size_t)b * nVy);
+        const float4* gvx = reinterpret_cast<const float4*>(a.vx_in + (size_t)b * nVx);
+        const float4* bcv = reinterpret_cast<const float4*>(a.bcv + (size_t)b * a.bc_stride);
+        const float4* bcm = reinterpret_cast<const float4*>(a.bcm + (size_t)b * a.bc_stride);
+        const float4* gact = reinterpret_cast<const float4*>(a.active);
+        float4 ty[NV], tx[NV], ta[CPT / 4];
 #pragma unroll
-        for (int n = 0; n < MAXL; ++n) { const int k = tid + n * nthr; ty[n] = gvy[min(k, nVy - 1)]; tx[n] = gvx[min(k, nVx - 1)]; }   // branch-free: clamped index
+        for (int n = 0; n < NV; ++n) { const int q = tid + n * nthr; ty[n] = gvy[min(q, nQy - 1)]; tx[n] = gvx[min(q, nQx - 1)]; }   // branch-free: clamped index
 #pragma unroll
-        for (int n = 0; n < CPT; ++n) { const int k = tid + n * nthr; ta[n] = a.active[min(k, N - 1)]; }
+        for (int n = 0; n < CPT / 4; ++n) ta[n] = gact[min(tid + n * nthr, (N >> 2) - 1)];
 #pragma unroll
-        for (int n = 0; n < MAXL; ++n) { const int k = min(tid + n * nthr, nVy - 1); bcv_r[n] = bcv[k]; bcm_r[n] = bcm[k]; }
+        for (int n = 0; n < NV; ++n) { const int q = min(tid + n * nthr, nQy - 1); bcv_r[n] = bcv[q]; bcm_r[n] = bcm[q]; }
 #pragma unroll
-        for (int n = 0; n < MAXL; ++n) { const int k = tid + n * nthr; if (k < nVy) L.Avy[k] = ty[n]; if (k < nVx) L.Avx[k] = tx[n]; }
+        for (int n = 0; n < NV; ++n) {
+            const int q = tid + n * nthr;
+            if (q < nQy) reinterpret_cast<float4*>(L.Avy)[q] = ty[n];
+            if (q < nQx) reinterpret_cast<float4*>(L.Avx)[q] = tx[n];
+        }
 #pragma unroll
-        for (int n = 0; n < CPT; ++n) { const int k = tid + n * nthr; if (k < N) L.act[k] = ta[n] != 0.f ? 1 : 0; }
+        for (int n = 0; n < CPT / 4; ++n) {
+            const int q = tid + n * nthr;
+            if (q < (N >> 2)) reinterpret_cast<uchar4*>(L.act)[q] = make_uchar4(ta[n].x != 0.f, ta[n].y != 0.f, ta[n].z != 0.f, ta[n].w != 0.f);
+        }
     }
     __syncthreads();
     SOL_STAMP(1);
@@ -802,17 +813,23 @@ __device__ __forceinline__ void karman_fwd_body(const StepArgs& a, float* smem) 
     if (!(a.dbg & 8)) {
         const float alpha = a.adt / a.re[b];
 #pragma unroll
-        for (int n = 0; n < MAXL; ++n) {           // compile-time trip count: the BC values sit in registers
-            const int k = tid + n * nthr;
-            if (k >= nVy) continue;
-            const int j = k >> lx, i = k & (X - 1);
-            const float c = L.Avy[k];
-            const float lap = L.Avy[min(j + 1, Y) * X + i] + L.Avy[max(j - 1, 0) * X + i] +
-                              L.Avy[j * X + min(i + 1, X - 1)] + L.Avy[j * X + max(i - 1, 0)] - 4.f * c;
-            float v = c + alpha * lap;
-            v = v * (1.f - bcm_r[n]) + bcv_r[n];
-            L.Bvy[k] = v;
-            if (a.saved_vy) a.saved_vy[(size_t)b * nVy + k] = v;
+        for (int n = 0; n < NV; ++n) {             // compile-time trip count: the BC values sit in registers
+            const int q = tid + n * nthr;
+            if (q >= nQy) continue;
+            const int k = q << 2, j = k >> lx, i = k & (X - 1);
+            const float4 c = reinterpret_cast<const float4*>(L.Avy)[q];
+            const float4 up = *reinterpret_cast<const float4*>(&L.Avy[min(j + 1, Y) * X + i]);
+            const float4 dn = *reinterpret_cast<const float4*>(&L.Avy[max(j - 1, 0) * X + i]);
+            const float rt = L.Avy[j * X + min(i + 4, X - 1)], lf = L.Avy[j * X + max(i - 1, 0)];
+            float4 v;                               // summation order as in the scalar form: ((up + down) + right) + left - 4 c
+            v.x = c.x + alpha * (up.x + dn.x + c.y + lf - 4.f * c.x);
+            v.y = c.y + alpha * (up.y + dn.y + c.z + c.x - 4.f * c.y);
+            v.z = c.z + alpha * (up.z + dn.z + c.w + c.y - 4.f * c.z);
+            v.w = c.w + alpha * (up.w + dn.w + rt + c.z - 4.f * c.w);
+            v.x = v.x * (1.f - bcm_r[n].x) + bcv_r[n].x; v.y = v.y * (1.f - bcm_r[n].y) + bcv_r[n].y;
+            v.z = v.z * (1.f - bcm_r[n].z) + bcv_r[n].z; v.w = v.w * (1.f - bcm_r[n].w) + bcv_r[n].w;
+            reinterpret_cast<float4*>(L.Bvy)[q] = v;
+            if (a.saved_vy) reinterpret_cast<float4*>(a.saved_vy + (size_t)b * nVy)[q] = v;
         }
         #pragma unroll 4
         for (int k = tid; k < nVx; k += nthr) {
@@ -926,15 +943,23 @@ __device__ __forceinline__ void karman_fwd_body(const StepArgs& a, float* smem) 
     {
         float* gvy = a.vy_out + (size_t)b * nVy;
         float* gvx = a.vx_out + (size_t)b * nVx;
-        #pragma unroll 4
-        for (int k = tid; k < nVy; k += nthr) {
-            const int j = k >> lx, i = k & (X - 1);
-            float g = 0.f;
-            if (j >= 1 && j <= Y - 1) g = P[j * X + i] - P[(j - 1) * X + i];
-            else if (a.grad_pad == 1) g = (j == 0) ? P[i] : -P[(Y - 1) * X + i];
-            const float v = L.Avy[k] - mask_y(L.act, Y, X, j, i) * g;
-            L.Avy[k] = v;
-            gvy[k] = v;
+        #pragma unroll 2
+        for (int q = tid; q < nQy; q += nthr) {        // four faces of one row at a time
+            const int k = q << 2, j = k >> lx, i = k & (X - 1);
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j >= 1 && j <= Y - 1) {
+                const float4 p1 = *reinterpret_cast<const float4*>(&P[j * X + i]), p0 = *reinterpret_cast<const float4*>(&P[(j - 1) * X + i]);
+                g = make_float4(p1.x - p0.x, p1.y - p0.y, p1.z - p0.z, p1.w - p0.w);
+            } else if (a.grad_pad == 1) {
+                const float4 p = *reinterpret_cast<const float4*>(&P[(j == 0 ? 0 : Y - 1) * X + i]);
+                g = j == 0 ? p : make_float4(-p.x, -p.y, -p.z, -p.w);
+            }
+            const uchar4 m0 = *reinterpret_cast<const uchar4*>(&L.act[max(j - 1, 0) * X + i]), m1 = *reinterpret_cast<const uchar4*>(&L.act[min(j, Y - 1) * X + i]);
+            float4 v = reinterpret_cast<const float4*>(L.Avy)[q];
+            v.x -= (float)min(m0.x, m1.x) * g.x; v.y -= (float)min(m0.y, m1.y) * g.y;
+            v.z -= (float)min(m0.z, m1.z) * g.z; v.w -= (float)min(m0.w, m1.w) * g.w;
+            reinterpret_cast<float4*>(L.Avy)[q] = v;
+            reinterpret_cast<float4*>(gvy)[q] = v;
         }
         #pragma unroll 4
         for (int k = tid; k < nVx; k += nthr) {
@@ -1037,26 +1062,47 @@ __device__ __forceinline__ void karman_bwd_body(const StepArgs& a, float* smem) 
         const float* gy = a.g_vy_out + (size_t)b * nVy;
         const float* gx = a.g_vx_out + (size_t)b * nVx;
         const float* df = a.dfeat ? a.dfeat + (size_t)b * N * 2 : nullptr;
-        float ty[MAXT], tx[MAXT], ta[CPT];
+        // v_y gradient, its feature gradient (channel 0 of two float4 = four cells) and the cell mask in 16-byte pieces;
+        // the v_x part keeps the per-face form (rows of X+1 faces: its cell index is not the face index)
+        constexpr int NV = (CPT + 1 + 3) / 4;
+        const int nQy = nVy >> 2;
+        const float4* gy4 = reinterpret_cast<const float4*>(gy);
+        const float4* df4 = reinterpret_cast<const float4*>(df);
+        const float4* gact = reinterpret_cast<const float4*>(a.active);
+        float4 ty[NV], ta[CPT / 4];
+        float tx[MAXT];
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int q = min(tid + n * nthr, nQy - 1);                                               // branch-free: clamped indices
+            ty[n] = gy4[q];
+            if (df) {                                                                                 // workgroup uniform
+                const int qd = min(q, (N >> 2) - 1);
+                const float4 f0 = df4[2 * qd], f1 = df4[2 * qd + 1];
+                const float w = (q << 2) < N ? a.fs0 : 0.f;                                           // rows j < Y
+                ty[n].x += w * f0.x; ty[n].y += w * f0.z; ty[n].z += w * f1.x; ty[n].w += w * f1.z;
+            }
+        }
 #pragma unroll
         for (int n = 0; n < MAXT; ++n) {
-            const int k = tid + n * nthr;
-            const int ky = min(k, nVy - 1), kx = min(k, nVx - 1);                                     // branch-free: clamped indices
+            const int kx = min(tid + n * nthr, nVx - 1);
             const int j = (int)(((float)kx + 0.5f) * invXP), i = kx - j * XP;
-            ty[n] = gy[ky];
             tx[n] = gx[kx];
-            if (df) {                                                                                 // workgroup uniform
-                const float fy = df[2 * min(ky, N - 1)], fxv = df[2 * (j * X + min(i, X - 1)) + 1];
-                ty[n] += ky < N ? a.fs0 * fy : 0.f;                                                   // rows j < Y
+            if (df) {
+                const float fxv = df[2 * (j * X + min(i, X - 1)) + 1];
                 tx[n] += i < X ? a.fs1 * fxv : 0.f;
             }
         }
 #pragma unroll
-        for (int n = 0; n < CPT; ++n) { const int k = tid + n * nthr; ta[n] = a.active[min(k, N - 1)]; }
+        for (int n = 0; n < CPT / 4; ++n) ta[n] = gact[min(tid + n * nthr, (N >> 2) - 1)];
 #pragma unroll
-        for (int n = 0; n < MAXT; ++n) { const int k = tid + n * nthr; if (k < nVy) L.Avy[k] = ty[n]; if (k < nVx) L.Avx[k] = tx[n]; }
+        for (int n = 0; n < NV; ++n) { const int q = tid + n * nthr; if (q < nQy) reinterpret_cast<float4*>(L.Avy)[q] = ty[n]; }
 #pragma unroll
-        for (int n = 0; n < CPT; ++n) { const int k = tid + n * nthr; if (k < N) L.act[k] = ta[n] != 0.f ? 1 : 0; }
+        for (int n = 0; n < MAXT; ++n) { const int k = tid + n * nthr; if (k < nVx) L.Avx[k] = tx[n]; }
+#pragma unroll
+        for (int n = 0; n < CPT / 4; ++n) {
+            const int q = tid + n * nthr;
+            if (q < (N >> 2)) reinterpret_cast<uchar4*>(L.act)[q] = make_uchar4(ta[n].x != 0.f, ta[n].y != 0.f, ta[n].z != 0.f, ta[n].w != 0.f);
+        }
     }
     __syncthreads();
     SOL_STAMP(1);
@@ -1139,17 +1185,24 @@ __device__ __forceinline__ void karman_bwd_body(const StepArgs& a, float* smem) 
     int* Ix = reinterpret_cast<int*>(L.Avx);
     float smax = 0.f, gmax = 0.f;
     {
-        const float* sy = a.saved_vy + (size_t)b * nVy;
-        const float* sx = a.saved_vx + (size_t)b * nVx;
-        float ty[MAXT], tx[MAXT];
+        constexpr int NV = (CPT + 1 + 3) / 4;       // float4 items of a (Y+1) x X field per thread (flat 16-byte copies)
+        const int nQy = nVy >> 2, nQx = nVx >> 2;
+        const float4* sy = reinterpret_cast<const float4*>(a.saved_vy + (size_t)b * nVy);
+        const float4* sx = reinterpret_cast<const float4*>(a.saved_vx + (size_t)b * nVx);
+        float4 ty[NV], tx[NV];
 #pragma unroll
-        for (int n = 0; n < MAXT; ++n) { const int k = tid + n * nthr; ty[n] = k < nVy ? sy[min(k, nVy - 1)] : 0.f; tx[n] = k < nVx ? sx[min(k, nVx - 1)] : 0.f; }
+        for (int n = 0; n < NV; ++n) { const int q = tid + n * nthr; ty[n] = sy[min(q, nQy - 1)]; tx[n] = sx[min(q, nQx - 1)]; }
 #pragma unroll
-        for (int n = 0; n < MAXT; ++n) {
-            const int k = tid + n * nthr;
-            if (k < nVy) { L.Bvy[k] = ty[n]; Iy[k] = 0; }
-            if (k < nVx) { L.Bvx[k] = tx[n]; Ix[k] = 0; }
-            smax = fmaxf(smax, fmaxf(fabsf(ty[n]), fabsf(tx[n])));
+        for (int n = 0; n < NV; ++n) {
+            const int q = tid + n * nthr;
+            if (q < nQy) {
+                reinterpret_cast<float4*>(L.Bvy)[q] = ty[n]; reinterpret_cast<int4*>(Iy)[q] = make_int4(0, 0, 0, 0);
+                smax = fmaxf(smax, fmaxf(fmaxf(fabsf(ty[n].x), fabsf(ty[n].y)), fmaxf(fabsf(ty[n].z), fabsf(ty[n].w))));
+            }
+            if (q < nQx) {
+                reinterpret_cast<float4*>(L.Bvx)[q] = tx[n]; reinterpret_cast<int4*>(Ix)[q] = make_int4(0, 0, 0, 0);
+                smax = fmaxf(smax, fmaxf(fmaxf(fabsf(tx[n].x), fabsf(tx[n].y)), fmaxf(fabsf(tx[n].z), fabsf(tx[n].w))));
+            }
         }
 #pragma unroll
         for (int n = 0; n < MAXT; ++n) gmax = fmaxf(gmax, fmaxf(fabsf(gy[n]), fabsf(gx[n])));
@@ -1217,10 +1270,21 @@ __device__ __forceinline__ void karman_bwd_body(const StepArgs& a, float* smem) 
     {   // back to float (in place, element-wise) fused with the BC adjoint; |acc| > 2^30 would mean the 16x headroom was nearly used up
         bool risky = false;
         const float* bcm = a.bcm + (size_t)b * a.bc_stride;
-        #pragma unroll 4
-        for (int k = tid; k < nVy; k += nthr) { const int q = Iy[k]; risky |= abs(q) > (1 << 30); L.Avy[k] = (float)q * qi * (1.f - bcm[k]); }
-        #pragma unroll 4
-        for (int k = tid; k < nVx; k += nthr) { const int q = Ix[k]; risky |= abs(q) > (1 << 30); L.Avx[k] = (float)q * qi; }
+        const float4* bcm4 = reinterpret_cast<const float4*>(bcm);
+        #pragma unroll 2
+        for (int q = tid; q < (nVy >> 2); q += nthr) {
+            const int4 v = reinterpret_cast<const int4*>(Iy)[q];
+            const float4 m = bcm4[q];
+            risky |= max(max(abs(v.x), abs(v.y)), max(abs(v.z), abs(v.w))) > (1 << 30);
+            reinterpret_cast<float4*>(L.Avy)[q] = make_float4((float)v.x * qi * (1.f - m.x), (float)v.y * qi * (1.f - m.y),
+                                                              (float)v.z * qi * (1.f - m.z), (float)v.w * qi * (1.f - m.w));
+        }
+        #pragma unroll 2
+        for (int q = tid; q < (nVx >> 2); q += nthr) {
+            const int4 v = reinterpret_cast<const int4*>(Ix)[q];
+            risky |= max(max(abs(v.x), abs(v.y)), max(abs(v.z), abs(v.w))) > (1 << 30);
+            reinterpret_cast<float4*>(L.Avx)[q] = make_float4((float)v.x * qi, (float)v.y * qi, (float)v.z * qi, (float)v.w * qi);
+        }
         if (risky && a.iters) a.iters[b] = -1;      // reported by the host wrappers as an error
     }
     __syncthreads();
@@ -1232,13 +1296,15 @@ __device__ __forceinline__ void karman_bwd_body(const StepArgs& a, float* smem) 
         const float alpha = a.adt / a.re[b];
         float* oy = a.g_vy_in + (size_t)b * nVy;
         float* ox = a.g_vx_in + (size_t)b * nVx;
-        #pragma unroll 4
-        for (int k = tid; k < nVy; k += nthr) {
-            const int j = k >> lx, i = k & (X - 1);
-            const float c = L.Avy[k];
-            const float lap = L.Avy[min(j + 1, Y) * X + i] + L.Avy[max(j - 1, 0) * X + i] +
-                              L.Avy[j * X + min(i + 1, X - 1)] + L.Avy[j * X + max(i - 1, 0)] - 4.f * c;
-            oy[k] = c + alpha * lap;
+        #pragma unroll 2
+        for (int q = tid; q < (nVy >> 2); q += nthr) {      // four faces of one row; summation order of the scalar form
+            const int k = q << 2, j = k >> lx, i = k & (X - 1);
+            const float4 c = reinterpret_cast<const float4*>(L.Avy)[q];
+            const float4 up = *reinterpret_cast<const float4*>(&L.Avy[min(j + 1, Y) * X + i]);
+            const float4 dn = *reinterpret_cast<const float4*>(&L.Avy[max(j - 1, 0) * X + i]);
+            const float rt = L.Avy[j * X + min(i + 4, X - 1)], lf = L.Avy[j * X + max(i - 1, 0)];
+            reinterpret_cast<float4*>(oy)[q] = make_float4(c.x + alpha * (up.x + dn.x + c.y + lf - 4.f * c.x), c.y + alpha * (up.y + dn.y + c.z + c.x - 4.f * c.y),
+                                                           c.z + alpha * (up.z + dn.z + c.w + c.y - 4.f * c.z), c.w + alpha * (up.w + dn.w + rt + c.z - 4.f * c.w));
         }
         #pragma unroll 4
         for (int k = tid; k < nVx; k += nthr) {
