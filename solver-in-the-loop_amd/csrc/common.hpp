@@ -12,6 +12,12 @@ int sol_init_karman_kernels();
 int sol_init_conv_kernels();
 int sol_density_chain(const sol_karman_cfg* c, void* stream, int ms, const float* d0, const float* svy, const float* svx,
                       long st_vy, long st_vx, const float* inflow, float* d_steps, long st_d, float* d_final);
+// internal (train.hip): last CNN layer (32 -> 2, no activation) fused with `velocity += std * to_staggered(output)` and the
+// l2 loss of the step (karman_train.py:413-447); needs the split-precision kernels (sol_conv_correct_fusable)
+bool sol_conv_correct_fusable(int W);
+int sol_conv5x5_correct(void* stream, const float* x, const float* packed, const float* bias, int B, int H, int W,
+                        const unsigned* x_absmax, float* vy, float* vx, const float* gt_vy, const float* gt_vx,
+                        float s0, float s1, float* loss);
 size_t sol_bww_batched_ws_floats(int nseg, int B, int H, int cin, int cout);
 int sol_bww_batched(void* stream, const float* x, const float* dz, float* partial, int nseg, int nseg_layout, int overwrite,
                     long x_seg, long dz_seg, int B, int H, int W, int cin, int cout,
@@ -31,6 +37,11 @@ struct ConvArgs {
     const void* wsh;   // split-fp16 weight planes + header (third section), cin == 32 only
     const unsigned* xmax;   // [SOL_AMAX_SLOTS] slots, max over them = bits of max|x| (non-negative float) -> fp16 path; NULL: bf16 path
     unsigned* ymax;         // [SOL_AMAX_SLOTS] slots updated with max|y| (atomic max on the float bits), or NULL
+    // trainer only (sol_conv5x5_correct): the 32 -> 2 layer applies its output as the velocity correction instead of storing it
+    float *cvy, *cvx;               // staggered velocity [B,H+1,W] / [B,H,W+1], updated in place (channel 0 -> v_y rows < H, 1 -> v_x columns < W)
+    const float *gty, *gtx;         // ground-truth frames for the l2 loss, or NULL
+    float cs0, cs1;                 // std_v
+    float* closs;                   // += 0.5 * sum(((gt - v) / std)^2) over ALL faces, or NULL
 };
 constexpr int SOL_AMAX_SLOTS = 256;   // one per workgroup of a 256-WG launch: same-address atomics serialise in L2 (~0.3 us each)
 // backward-weight arguments

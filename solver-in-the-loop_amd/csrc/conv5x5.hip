@@ -1065,6 +1065,27 @@ extern "C" int sol_conv5x5(void* stream, const float* x, const float* packed, co
     return conv_impl(stream, x, packed, bias, residual, act_ref, y, B, H, W, cin, cout, epilogue, slope, nullptr, nullptr);
 }
 
+bool sol_conv_correct_fusable(int W) {
+    static const bool ok = !getenv("SOL_CONV_NO_SB") && !getenv("SOL_CONV_NO_FP16") && !getenv("SOL_CORRECT_NO_FUSE");
+    return ok && W % 64 == 0;
+}
+
+int sol_conv5x5_correct(void* stream, const float* x, const float* packed, const float* bias, int B, int H, int W,
+                        const unsigned* x_absmax, float* vy, float* vx, const float* gt_vy, const float* gt_vx,
+                        float s0, float s1, float* loss) {
+    if (int e = check_shape(B, H, W, 32, 2)) return e;
+    SOL_REQUIRE(x && packed && x_absmax && vy && vx && sol_conv_correct_fusable(W), "sol_conv5x5_correct: bad arguments");
+    if (int e = sol_init_conv_kernels()) return e;
+    ConvArgs a{};
+    a.x = x; a.wp = packed; a.bias = bias; a.B = B; a.H = H; a.W = W; a.CO = 2; a.epi = SOL_EPI_NONE;
+    a.TW = 64; a.RPW = 1; a.tiles_x = W / 64;
+    a.wsb = packed + (size_t)25 * 32 * pad_out(2);
+    a.wsh = packed + (size_t)25 * 32 * pad_out(2) + sol_conv_sb_packed_floats(pad_out(2));
+    a.xmax = x_absmax;
+    a.cvy = vy; a.cvx = vx; a.gty = gt_vy; a.gtx = gt_vx; a.cs0 = s0; a.cs1 = s1; a.closs = loss;
+    return sol_conv_sb_launch((hipStream_t)stream, a, 1, B * H * (W / 64));
+}
+
 extern "C" int sol_conv5x5_scaled(void* stream, const float* x, const float* packed, const float* bias,
                                   const float* residual, const float* act_ref, float* y,
                                   int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,

@@ -309,6 +309,37 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
                 reinterpret_cast<float4*>(a.y)[o4] = v;
             }
         }
+    } else if (a.cvy) {
+        // correction mode (32 -> 2 layer of the trainer): lanes li = 0 / 1 hold output channel 0 / 1 of pixels 4g..4g+3 of the
+        // wave's 16-pixel segment; the output is applied to the staggered velocity and never stored.  The faces without a
+        // correction (v_y row H, v_x column W) only enter the loss: the owner of the image's last row / of column W-1 adds them.
+        float lsum = 0.f;
+        if (tvalid && li < 2) {
+            const int jj = gy - b * H, nVy = (H + 1) * W, nVx = H * (W + 1);
+            const float bias = a.bias ? a.bias[li] : 0.f;
+            const float s = li == 0 ? a.cs0 : a.cs1;
+            float* vf = li == 0 ? a.cvy + (size_t)b * nVy + (size_t)jj * W : a.cvx + (size_t)b * nVx + (size_t)jj * (W + 1);
+            const float* gt = li == 0 ? (a.gty ? a.gty + (size_t)b * nVy + (size_t)jj * W : nullptr)
+                                      : (a.gtx ? a.gtx + (size_t)b * nVx + (size_t)jj * (W + 1) : nullptr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = x0 + wave * 16 + 4 * g + r;
+                const float v = vf[i] + s * (acc[0][r] + bias);
+                vf[i] = v;
+                if (gt) { const float d = (gt[i] - v) / s; lsum += 0.5f * d * d; }
+                if (gt && li == 0 && jj == H - 1) { const float d = (gt[W + i] - vf[W + i]) / s; lsum += 0.5f * d * d; }   // v_y row H
+                if (gt && li == 1 && i == W - 1) { const float d = (gt[W] - vf[W]) / s; lsum += 0.5f * d * d; }            // v_x column W
+            }
+        }
+        if (a.closs) {                                // workgroup uniform: wave sums -> LDS -> the last wave adds to the step's loss
+            lsum = wave_sum(lsum);
+            float* acc2 = reinterpret_cast<float*>(smem_sb + AMAX_LDS);
+            if (lane == 0) {
+                atomicAdd(&acc2[0], lsum);
+                const unsigned ticket = atomicAdd(reinterpret_cast<unsigned*>(acc2) + 1, 1u);
+                if (ticket == (blockDim.x >> 6) - 1) atomicAdd(a.closs, atomicAdd(&acc2[0], 0.f));
+            }
+        }
     } else if (tvalid) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {

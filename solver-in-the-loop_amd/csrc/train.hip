@@ -212,7 +212,9 @@ int pack_all(const sol_train_cfg* /*c*/, void* stream, const float* params, Ws& 
 // CNN forward (model_mars_moon, karman_train.py:101-138).  acts: 11 buffers [cells][32].
 // amax: [11][SOL_AMAX_SLOTS] absmax slots of act[0..10] (zeroed by the caller): every producer publishes max|y| and every
 // 32-channel consumer derives its fp16 operand scale from it (sol_conv5x5_scaled).
-int net_forward(const sol_train_cfg* c, void* s, const Ws& w, const float* feat, float* const* act, float* O, uint32_t* amax) {
+// corr != nullptr: the last layer applies its output to the velocity and accumulates the loss (sol_conv5x5_correct) instead of storing O
+struct Correct { float *vy, *vx; const float *gt_vy, *gt_vx; float* loss; };
+int net_forward(const sol_train_cfg* c, void* s, const Ws& w, const float* feat, float* const* act, float* O, uint32_t* amax, const Correct* corr = nullptr) {
     const int B = c->karman.B, Y = c->karman.Y, X = c->karman.X;
     const float sl = c->lrelu_slope;
     auto am = [&](int k) { return amax ? amax + (size_t)k * SOL_AMAX_SLOTS : nullptr; };
@@ -224,6 +226,9 @@ int net_forward(const sol_train_cfg* c, void* s, const Ws& w, const float* feat,
         if (int e = sol_conv5x5_scaled(s, act[1 + 2 * k], w.wf[2 + 2 * k], w.bias[2 + 2 * k], h, nullptr, act[2 + 2 * k], B, Y, X, 32, 32, SOL_EPI_LRELU, sl,
                                        am(1 + 2 * k), am(2 + 2 * k))) return e;
     }
+    if (corr)
+        return sol_conv5x5_correct(s, act[10], w.wf[11], w.bias[11], B, Y, X, am(10), corr->vy, corr->vx, corr->gt_vy, corr->gt_vx,
+                                   c->std_v0, c->std_v1, corr->loss);
     return sol_conv5x5_scaled(s, act[10], w.wf[11], w.bias[11], nullptr, nullptr, O, B, Y, X, 32, 2, SOL_EPI_NONE, sl, am(10), nullptr);
 }
 
@@ -363,11 +368,16 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
                                                dens_inline ? dcur : nullptr, vycur, vxcur, svy_i, svx_i, feat, fscale, it_i)) return e;
         float* act[11];
         for (int k = 0; k < 11; ++k) act[k] = w.acts + ((size_t)i * 11 + k) * w.cells * 32;
-        if (int e = net_forward(c, stream, wn, feat, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS)) return e;
-        hipLaunchKernelGGL(k_correct_loss, dim3(egrid), dim3(256), 0, hs, vycur, vxcur, w.O,
-                           gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx,
-                           c->std_v0, c->std_v1, io.loss_steps + i, B, Y, X);
-        SOL_LAUNCH_CHECK();
+        if (sol_conv_correct_fusable(X)) {            // correction + loss ride in the epilogue of the last CNN layer
+            const Correct corr{vycur, vxcur, gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx, io.loss_steps + i};
+            if (int e = net_forward(c, stream, wn, feat, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS, &corr)) return e;
+        } else {
+            if (int e = net_forward(c, stream, wn, feat, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS)) return e;
+            hipLaunchKernelGGL(k_correct_loss, dim3(egrid), dim3(256), 0, hs, vycur, vxcur, w.O,
+                               gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx,
+                               c->std_v0, c->std_v1, io.loss_steps + i, B, Y, X);
+            SOL_LAUNCH_CHECK();
+        }
     }
     if (dens_inline) {
         if (io.d_final) SOL_HIP_CHECK(hipMemcpyAsync(io.d_final + (size_t)b0 * w.N, w.d + (size_t)(ms - 1) * w.st_d, w.st_d * sizeof(float), hipMemcpyDeviceToDevice, hs));
@@ -631,10 +641,15 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
                                         w.d, w.vy, w.vx, nullptr, nullptr, w.feat, fscale,
                                         iters ? iters + (size_t)i * B : nullptr)) return e;
         SOL_HIP_CHECK(hipMemsetAsync(w.amax_act, 0, (size_t)11 * SOL_AMAX_SLOTS * sizeof(uint32_t), hs));
-        if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, w.amax_act)) return e;
-        hipLaunchKernelGGL(k_correct_loss, dim3(egrid), dim3(256), 0, hs, w.vy, w.vx, w.O,
-                           (const float*)nullptr, (const float*)nullptr, cfg->std_v0, cfg->std_v1, (float*)nullptr, B, Y, X);
-        SOL_LAUNCH_CHECK();
+        if (sol_conv_correct_fusable(X)) {
+            const Correct corr{w.vy, w.vx, nullptr, nullptr, nullptr};
+            if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, w.amax_act, &corr)) return e;
+        } else {
+            if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, w.amax_act)) return e;
+            hipLaunchKernelGGL(k_correct_loss, dim3(egrid), dim3(256), 0, hs, w.vy, w.vx, w.O,
+                               (const float*)nullptr, (const float*)nullptr, cfg->std_v0, cfg->std_v1, (float*)nullptr, B, Y, X);
+            SOL_LAUNCH_CHECK();
+        }
         SOL_HIP_CHECK(hipMemcpyAsync(d, w.d, w.st_d * sizeof(float), hipMemcpyDeviceToDevice, hs));
         SOL_HIP_CHECK(hipMemcpyAsync(vy, w.vy, w.st_vy * sizeof(float), hipMemcpyDeviceToDevice, hs));
         SOL_HIP_CHECK(hipMemcpyAsync(vx, w.vx, w.st_vx * sizeof(float), hipMemcpyDeviceToDevice, hs));
