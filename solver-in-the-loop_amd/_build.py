@@ -22,12 +22,32 @@ def _hipcc():
     raise RuntimeError("hipcc not found (need ROCm to build libsol_hip.so)")
 
 
+STAMP = os.path.join(LIBDIR, "libsol_hip.sources.sha1")
+
+
+def _source_hash():
+    """Content hash of everything the library is built from (sources, headers, flags): a copy of the tree that scrambles
+    the modification times (rsync without -t, a fresh checkout next to a shipped .so) must not trigger a rebuild on every
+    rank of a node, and an edited source must trigger one whatever its time stamp says."""
+    import hashlib
+    h = hashlib.sha1(repr((FLAGS, sorted(EXTRA.items()), SOURCES)).encode())
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, "..", "include", "sol_hip.h")]
+    for d in deps:
+        if os.path.isfile(d):
+            h.update(os.path.basename(d).encode())
+            with open(d, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "sol_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    try:
+        with open(STAMP) as f:
+            return f.read().strip() != _source_hash()
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=False):
@@ -68,6 +88,8 @@ def _build_locked(verbose):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout)
+    with open(STAMP, "w") as f:
+        f.write(_source_hash() + "\n")
     return LIB
 
 
