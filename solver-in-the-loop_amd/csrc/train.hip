@@ -159,6 +159,8 @@ struct Ws {
     size_t total_floats;
 };
 
+constexpr int ROLLOUT_AMAX_SETS = 8;      // roll-out: absmax slot sets used round robin, zeroed by ONE memset per 8 steps
+
 size_t carve_ws(const sol_train_cfg* c, float* base, Ws& w, bool training) {
     const int B = c->karman.B, Y = c->karman.Y, X = c->karman.X;
     const int ms = training ? c->msteps : 1;
@@ -177,7 +179,7 @@ size_t carve_ws(const sol_train_cfg* c, float* base, Ws& w, bool training) {
     w.gA = take(w.cells * 32); w.gB = take(w.cells * 32);
     w.dO4 = take(w.cells * 4); w.dO2 = take((size_t)ms * w.cells * 2); w.dF = take(w.cells * 2);
     w.dzb = take(training ? (size_t)ms * 11 * w.cells * 32 : 0);
-    w.amax_words = (size_t)ms * 11 * SOL_AMAX_SLOTS;
+    w.amax_words = (size_t)(training ? ms : ROLLOUT_AMAX_SETS) * 11 * SOL_AMAX_SLOTS;
     w.amax_act = reinterpret_cast<uint32_t*>(take(w.amax_words));
     w.amax_dz = reinterpret_cast<uint32_t*>(take(training ? w.amax_words : 0));
     for (int k = 0; k < 2; ++k) { w.gvy[k] = take(w.st_vy); w.gvx[k] = take(w.st_vx); }
@@ -635,21 +637,27 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
     float* act[11];
     // two ping-pong activation buffers suffice without the backward pass (+1 for the skip input)
     for (int k = 0; k < 11; ++k) act[k] = w.acts + (size_t)(k % 3) * w.cells * 32;
+    // the state ping-pongs between the caller's buffers and the workspace (no copy-back per step); an odd step count ends
+    // with one copy into the caller's buffers
     for (int i = 0; i < nsteps; ++i) {
-        // the step reads its inputs fully into LDS before writing outputs -> safe in place
-        if (int e = sol_karman_step_fwd(kc, stream, d, vy, vx, re, active, inflow, velBCy, velBCyMask, bc_batch_stride,
-                                        w.d, w.vy, w.vx, nullptr, nullptr, w.feat, fscale,
+        float* sd = (i & 1) ? w.d : d;   float* svy = (i & 1) ? w.vy : vy;   float* svx = (i & 1) ? w.vx : vx;
+        float* td = (i & 1) ? d : w.d;   float* tvy = (i & 1) ? vy : w.vy;   float* tvx = (i & 1) ? vx : w.vx;
+        if (int e = sol_karman_step_fwd(kc, stream, sd, svy, svx, re, active, inflow, velBCy, velBCyMask, bc_batch_stride,
+                                        td, tvy, tvx, nullptr, nullptr, w.feat, fscale,
                                         iters ? iters + (size_t)i * B : nullptr)) return e;
-        SOL_HIP_CHECK(hipMemsetAsync(w.amax_act, 0, (size_t)11 * SOL_AMAX_SLOTS * sizeof(uint32_t), hs));
+        if (i % ROLLOUT_AMAX_SETS == 0) SOL_HIP_CHECK(hipMemsetAsync(w.amax_act, 0, w.amax_words * sizeof(uint32_t), hs));
+        uint32_t* amax = w.amax_act + (size_t)(i % ROLLOUT_AMAX_SETS) * 11 * SOL_AMAX_SLOTS;
         if (sol_conv_correct_fusable(X)) {
-            const Correct corr{w.vy, w.vx, nullptr, nullptr, nullptr};
-            if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, w.amax_act, &corr)) return e;
+            const Correct corr{tvy, tvx, nullptr, nullptr, nullptr};
+            if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, amax, &corr)) return e;
         } else {
-            if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, w.amax_act)) return e;
-            hipLaunchKernelGGL(k_correct_loss, dim3(egrid), dim3(256), 0, hs, w.vy, w.vx, w.O,
+            if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, amax)) return e;
+            hipLaunchKernelGGL(k_correct_loss, dim3(egrid), dim3(256), 0, hs, tvy, tvx, w.O,
                                (const float*)nullptr, (const float*)nullptr, cfg->std_v0, cfg->std_v1, (float*)nullptr, B, Y, X);
             SOL_LAUNCH_CHECK();
         }
+    }
+    if (nsteps & 1) {
         SOL_HIP_CHECK(hipMemcpyAsync(d, w.d, w.st_d * sizeof(float), hipMemcpyDeviceToDevice, hs));
         SOL_HIP_CHECK(hipMemcpyAsync(vy, w.vy, w.st_vy * sizeof(float), hipMemcpyDeviceToDevice, hs));
         SOL_HIP_CHECK(hipMemcpyAsync(vx, w.vx, w.st_vx * sizeof(float), hipMemcpyDeviceToDevice, hs));

@@ -352,8 +352,11 @@ def test_shard_gradients_sum_to_the_large_batch_gradient():
     assert rel(acc, full.grads) < 1e-5
 
 
-def test_rollout_against_oracle():
-    B, Y, X, n = 1, 64, 32, 3
+@pytest.mark.parametrize("Y,X,n", [(64, 32, 3), (64, 32, 10), (128, 64, 2)])
+def test_rollout_against_oracle(Y, X, n):
+    """odd / even step counts (the state ping-pongs between the caller's buffers and the workspace), more steps than absmax
+    slot sets, and the 128x64 path whose last CNN layer applies the correction itself"""
+    B = 1
     g = o.geometry(Y, X)
     d, vy, vx = o.synthetic_state(B, Y, X, 21)
     re = torch.tensor([o.RE_TRAIN[2]], dtype=torch.float64)
@@ -369,7 +372,8 @@ def test_rollout_against_oracle():
     ro = sol_amd.SolRollout(net, mk, B, Y, X, g.dx, std_v, o.STD_RE)
     hd, hy, hx = f32(d), f32(vy), f32(vx)
     its = ro.run(hd, hy, hx, f32(re), n)
-    assert its.shape == (n, B) and int(its.min()) > 5
+    assert its.shape == (n, B)
+    assert int(its.min()) > 5 or mk.direct is not None      # the direct solver reports 0 iterations
     assert rel(hy, ry) < TOL_FIELD and rel(hx, rx) < TOL_FIELD and rel(hd, rd) < TOL_FIELD
 
 
