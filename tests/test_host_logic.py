@@ -133,3 +133,23 @@ def test_direct_solver_blob_reproduces_the_exact_pressure_solve():
     # a scene whose modified cells do not fit one 16x16 window is refused (-> CG)
     act = np.ones((128, 64)); act[10:12, 10:12] = 0; act[100:102, 40:42] = 0
     assert precond.direct_solver_blob(act) is None
+
+
+def test_library_staleness_is_decided_by_source_content(tmp_path, monkeypatch):
+    """_build._stale(): a shipped library is current iff the recorded hash equals the hash of the sources, whatever the
+    modification times say (a tree copied without time stamps must not rebuild on every rank of a node)."""
+    import os
+    from sol_amd import _build
+    lib = tmp_path / "libsol_hip.so"
+    stamp = tmp_path / "libsol_hip.sources.sha1"
+    monkeypatch.setattr(_build, "LIB", str(lib))
+    monkeypatch.setattr(_build, "STAMP", str(stamp))
+    assert _build._stale()                              # no library
+    lib.write_bytes(b"x")
+    assert _build._stale()                              # library without a stamp
+    stamp.write_text(_build._source_hash() + "\n")
+    assert not _build._stale()
+    os.utime(lib, (0, 0))                               # older than every source: still current
+    assert not _build._stale()
+    stamp.write_text("0" * 40 + "\n")
+    assert _build._stale()                              # sources changed since the build
