@@ -1,7 +1,6 @@
 """Reference-shaped Python surface of the Burgers path (/root/reference/burgers/burgers_train.py):
 to_feature / to_feature_noforce (l.75-92), BurgersTest.step / step_with_f (l.178-187), and the TF1
 AdamOptimizer used at l.437 as a small optimizer object over the flat parameter buffer."""
-import ctypes as C
 
 import torch
 

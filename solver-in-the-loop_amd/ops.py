@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import KarmanCfg, BurgersCfg, check, ptr, stream
+from ._lib import KarmanCfg, check, ptr, stream
 
 EPI_NONE, EPI_LRELU, EPI_DLRELU = 0, 1, 2
 CONV_FWD, CONV_BWD_DATA = 0, 1

@@ -13,7 +13,6 @@ equal the large-batch gradient) and an identical Adam update on every rank.
 """
 import ctypes as C
 
-import numpy as np
 import torch
 
 from . import _lib, ops
