@@ -105,6 +105,18 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// XCD-aware tile order: the hardware deals consecutive workgroup ids round robin to the 8 XCDs (each with its own L2), so
+// workgroup w runs on XCD w % 8.  Mapping it to tile (w % 8) * (n / 8) + w / 8 gives every XCD one CONTIGUOUS block of
+// image rows: a convolution's halo rows, and the rows the previous layer's launch wrote, are then in the SAME L2 except
+// at the 8 block seams.  (n not a multiple of 8: identity.)
+__device__ __forceinline__ int xcd_tile(int w, int n) {
+#ifdef SOL_NO_XCD_REMAP
+    return w;
+#else
+    return (n & 7) == 0 ? (w & 7) * (n >> 3) + (w >> 3) : w;
+#endif
+}
+
 // Workgroup all-reduce through LDS.  `red` holds 2 x 32 floats; `slot` alternates 0/1
 // between consecutive calls so that no extra barrier is needed against the previous use.
 // Every thread returns the bit-identical sum (same summation order), so branches on it

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) k_conv5x5(ConvArgs a) {
     const int g = lane >> 4, li = lane & 15;
     const int H = a.H, W = a.W, TW = a.TW, RPW = a.RPW;
     const int HW = TW + 4;   // halo width in pixels
-    int blk = blockIdx.x;
+    int blk = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = blk % a.tiles_x; blk /= a.tiles_x;
     const int rows_blk = H / RPW;
     const int ty = blk % rows_blk;

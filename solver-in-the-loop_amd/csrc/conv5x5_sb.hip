@@ -125,7 +125,8 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     // workgroup = three CONSECUTIVE global image rows G0 .. G0+2 (row = b*H + y) of one 64-pixel column block:
     // they need the seven input rows G0-2 .. G0+4, each of which is staged ONCE into a shared 4-slot ring
     // (row r lives in slot (r - G0 + 2) & 3); a tile skips the tap rows whose input row belongs to another image.
-    const int tx = blockIdx.x % a.tiles_x, G0 = (blockIdx.x / a.tiles_x) * 3;
+    const int bx = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx = bx % a.tiles_x, G0 = (bx / a.tiles_x) * 3;
     const int gy = G0 + grp;                          // this tile's global row
     const bool tvalid = gy < nrows;
     const int b = (tvalid ? gy : 0) / H, x0 = tx * 64;
