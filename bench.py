@@ -175,12 +175,12 @@ def main():
         fwd_b, bwd_b, kf_tr, kb_tr = tr.solver_algorithmic_bytes()
         conv_flops_step = 3.0 * 520000.0 * N * B * ms
         # `traffic`: HBM bytes per launch from rocprofv3 PMC passes of the same kernels at this shape
-        # (profiles/r01_pmc_traffic_v2.txt: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE); constants, not live
+        # (profiles/r01_pmc_traffic_v3.txt: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE); constants, not live
         c3 = (Y, X, B) == (128, 64, 6)
         direct = getattr(masks, "direct", None) is not None
         roof_solver = {"kernel": "k_karman_fwd<16>", "bound": "hbm", "achieved": bytes_step / t_step / 1e9, "peak": 8000.0,
                        "unit": "GB/s", "frac": bytes_step / t_step / 8e12,
-                       "traffic": ((2 * 1812.2 + 969.2) * 1024 if direct else (2 * 1158.1 + 1041.2) * 1024) if c3 else None,
+                       "traffic": ((2 * 1781.0 + 999.5) * 1024 if direct else (2 * 1158.1 + 1041.2) * 1024) if c3 else None,
                        "launch_us": t_step * 1e6, "cg_iters": k_f, "algorithmic_bytes_per_launch": bytes_step,
                        "pressure_solver": "direct (sine-transform diagonalisation + capacitance correction, no iteration)" if direct
                                           else "two-level preconditioned CG",
@@ -208,7 +208,7 @@ def main():
         roof_conv = {"kernel": ("k_conv5x5_sb<2,2> (fp16 x3)" if fp16 else "k_conv5x5_sb<2,0> (bf16 x6)") if sb else "k_conv5x5_r3<2>", "bound": "mfma",
                      "achieved": flop_conv / t_conv / 1e12, "peak": peak_eq,
                      "unit": "TFLOP/s", "frac": flop_conv / t_conv / (peak_eq * 1e12),
-                     "traffic": ((2 * 7612.5 + 6152.0 if fp16 else 2 * 9314.4 + 6144.0) if sb else 2 * 9107.9 + 6144.0) * 1024 if c3 else None,
+                     "traffic": ((2 * 6638.8 + 6151.8 if fp16 else 2 * 9314.4 + 6144.0) if sb else 2 * 9107.9 + 6144.0) * 1024 if c3 else None,
                      "launch_us": t_conv * 1e6, "flop_per_launch": flop_conv,
                      "note": ("achieved = ALGORITHMIC fp32 conv FLOPs / launch time.  The kernel evaluates every fp32 product as %d exact 16-bit "
                               "MFMA products with fp32 accumulation (operands split into %s; error vs float64 %s against 5e-7 for the fp32 MFMA "
