@@ -1338,8 +1338,18 @@ __global__ void __launch_bounds__(512) k_karman_bwd_bww(StepArgs a, BwPack bw) {
     if ((int)blockIdx.x < a.B) {
         karman_bwd_body<16, 2>(a, smem);
     } else {
-        const int idx = (int)blockIdx.x - a.B;
-        sbk::bww_sb_body<2>(bw.a[idx / bw.wg_per], idx % bw.wg_per, reinterpret_cast<unsigned char*>(smem));
+        // XCD-aware job order (workgroup u runs on XCD u % 8): the 32-row blocks of image rows 96x .. 96x+95 -- what XCD x's
+        // convolution workgroups wrote (xcd_tile) -- are handed to the gradient workgroups of XCD x, layer after layer
+        int idx = (int)blockIdx.x - a.B, job = idx / bw.wg_per, sub = idx % bw.wg_per;
+#ifndef SOL_NO_XCD_REMAP
+        if ((bw.wg_per & 7) == 0) {
+            const int u = (int)blockIdx.x, x = u & 7, per = bw.wg_per >> 3;
+            const int s = (u - (a.B + ((x - a.B) & 7))) >> 3;          // rank of this workgroup among the gradient workgroups of XCD x
+            job = s / per;
+            sub = x * per + s % per;
+        }
+#endif
+        sbk::bww_sb_body<2>(bw.a[job], sub, reinterpret_cast<unsigned char*>(smem));
     }
 }
 
