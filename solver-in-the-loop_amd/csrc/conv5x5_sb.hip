@@ -208,10 +208,32 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
     constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
 
+    // the epilogue's residual / activation-reference operands (NT == 2 path) are fetched during the last tap rows: in the
+    // training pipeline they come from HBM (the forward activations are hundreds of launches old), a 2 us round trip that
+    // otherwise sits between the last MFMA and the first store
+    constexpr int EF4 = 16 * OP / 4 / 64;             // float4 per lane of the wave's [16 px][OP] tile
+    float4 pres[EF4], pact[EF4];
+#pragma unroll
+    for (int n = 0; n < EF4; ++n) { pres[n] = make_float4(0.f, 0.f, 0.f, 0.f); pact[n] = make_float4(1.f, 1.f, 1.f, 1.f); }
+#ifndef SOL_CONV_LATE_EPI                             // (A/B switch: 14.85 -> 14.77 ms per training step)
+    constexpr bool EPI_PREFETCH = true;
+#else
+    constexpr bool EPI_PREFETCH = false;
+#endif
+
 #pragma unroll 1
     for (int dy = 0; dy < 5; ++dy) {
         float4 hv;
         uint4 wv[WPT];
+        if (EPI_PREFETCH && dy == 3 && tvalid && a.CO == OP) {
+#pragma unroll
+            for (int n = 0; n < EF4; ++n) {
+                const int e = lane + n * 64, px = e / (OP / 4), c4 = e % (OP / 4);
+                const size_t o4 = ((size_t)gy * W + x0 + wave * 16 + px) * (OP / 4) + c4;
+                if (a.res) pres[n] = reinterpret_cast<const float4*>(a.res)[o4];
+                if (a.epi == SOL_EPI_DLRELU) pact[n] = reinterpret_cast<const float4*>(a.act)[o4];
+            }
+        }
         if (dy < 4) {
             hv = load_row(G0 + dy + 1, tid);          // the one new input row of the next tap row: G0-2 + (dy+1) + 2
             load_w(dy + 1, wv);
@@ -297,12 +319,12 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
                 const int px = e / (OP / 4), c4 = e % (OP / 4);
                 float4 v = *reinterpret_cast<const float4*>(&tb[px * OP + c4 * 4]);
                 const size_t o4 = ((size_t)gy * W + x0 + wave * 16 + px) * (OP / 4) + c4;
-                if (a.res) { const float4 q = reinterpret_cast<const float4*>(a.res)[o4]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+                if (a.res) { const float4 q = EPI_PREFETCH ? pres[n] : reinterpret_cast<const float4*>(a.res)[o4]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
                 if (a.epi == SOL_EPI_LRELU) {
                     v.x = v.x > 0.f ? v.x : a.slope * v.x; v.y = v.y > 0.f ? v.y : a.slope * v.y;
                     v.z = v.z > 0.f ? v.z : a.slope * v.z; v.w = v.w > 0.f ? v.w : a.slope * v.w;
                 } else if (a.epi == SOL_EPI_DLRELU) {
-                    const float4 q = reinterpret_cast<const float4*>(a.act)[o4];
+                    const float4 q = EPI_PREFETCH ? pact[n] : reinterpret_cast<const float4*>(a.act)[o4];
                     v.x *= q.x > 0.f ? 1.f : a.slope; v.y *= q.y > 0.f ? 1.f : a.slope;
                     v.z *= q.z > 0.f ? 1.f : a.slope; v.w *= q.w > 0.f ? 1.f : a.slope;
                 }
