@@ -12,8 +12,11 @@
  *   - every function returns 0 on success, <0 on error; sol_last_error() gives the text
  *     (thread local).  Nothing is allocated inside: all buffers, including workspaces,
  *     are caller-owned DEVICE pointers (fp32 unless noted).
- *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on that stream and
- *     thread-safe with respect to distinct streams (no global mutable state).
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on that stream.  The only
+ *     process-wide mutable state is the option table behind sol_set_option() (kernel-variant
+ *     selection, read at every call) and the launch profiler (sol_prof_begin/end); the library never
+ *     reads the environment.  Calls on distinct streams are thread-safe as long as no thread changes
+ *     an option or profiles concurrently.
  *   - layouts: density d [B,Y,X]; v_y [B,Y+1,X]; v_x [B,Y,X+1]  (component 0 = y, the
  *     reference's `velocity.data[0]`, karman_train.py:367); images NHWC; conv kernels
  *     HWIO (Keras layout); `params`/`grads` = Keras get_weights() order, flattened.
@@ -37,6 +40,26 @@ extern "C" {
 
 const char* sol_last_error(void);
 int sol_version(void);
+/* sizeof() of the ABI structs below, for bindings that mirror them (ctypes): a stale library is detected at load time */
+int sol_abi_sizes(int32_t* karman_cfg, int32_t* burgers_cfg, int32_t* train_cfg);
+
+/* Kernel-variant options (process wide; defaults in parentheses).  The reference's knob of this kind is the
+ * `pressure_solver=` argument of KarmanFlow (karman_train.py:167) and the `--cuda` switch (:51); everything else is
+ * new.  Unknown names / out-of-range values return SOL_ERR_ARG.
+ *   conv_precision (0)  0: fp32-equivalent split arithmetic on the 16-bit matrix pipe (fp16 x3 where the operand's absmax
+ *                          is known, bf16 x6 otherwise); 1: bf16 x6 always; 2: strict fp32 MFMA (v_mfma_f32_*_f32) everywhere
+ *   cnn_persistent (1)  the 12 CNN layers of a pass as one cooperative launch where the shape allows it
+ *   bww_fuse (1), correct_fuse (1), density_mode (0), conv_thin (1), conv_r3 (1), conv_bww32 (1): fusion / kernel choices
+ *   bww_chunk (0), bww_side (1), streams (1), cpt (0), conv_split3 (0), dbg_skip (0), step_prof (0): experiments, debugging */
+int sol_set_option(const char* name, int32_t value);
+int sol_get_option(const char* name, int32_t* value);
+
+/* Launch profiler: between sol_prof_begin() and sol_prof_end() every kernel the library launches (eagerly, not under
+ * stream capture) carries its own pair of HIP events on the stream it is launched on (hipExtLaunchKernelGGL start/stop:
+ * the dispatch's begin/end timestamps, the quantity rocprofv3 --kernel-trace reports).  sol_prof_end synchronises the
+ * device and returns the number n of distinct kernels; names (n x 64 chars), total_us[n], calls[n] are HOST arrays. */
+int sol_prof_begin(void);
+int sol_prof_end(int32_t max_classes, char* names, double* total_us, int32_t* calls);
 
 /* ------------------------------------------------------------------------------------
  * Solver step:  KarmanFlow.step  (karman-2d/karman_train.py:173-185) =
@@ -151,7 +174,9 @@ int sol_burgers_step_bwd(const sol_burgers_cfg* cfg, void* stream,
                          float* g_vy_in, float* g_vx_in);
 
 /* ------------------------------------------------------------------------------------
- * 5x5 SAME convolution, NHWC fp32, on fp32 MFMA (v_mfma_f32_16x16x4_f32).
+ * 5x5 SAME convolution, NHWC fp32 tensors.  32-input-channel layers with W % 64 == 0 evaluate their fp32 products as
+ * exact 16-bit MFMA products of operand splits with fp32 accumulation (option conv_precision; 2 = fp32 MFMA
+ * v_mfma_f32_16x16x4_f32 throughout); the thin 3->32 / 32->2 layers and other shapes run on fp32 MFMA.
  * Replaces keras.layers.Conv2D(filters, 5, padding='same') + LeakyReLU / add
  * (karman_train.py:101-138) and its TF gradients.
  * ---------------------------------------------------------------------------------- */
@@ -233,9 +258,8 @@ int sol_train_fwd_bwd(const sol_train_cfg* cfg, void* stream,
 
 /* The same step as a replayable hipGraph: one host call per training step instead of ~1000 kernel
  * launches.  All pointers are baked in at creation (re-create when a buffer moves); new data is
- * fed by copying into the same buffers.  Internally the batch is split into chains of
- * simulations that run on separate HIP streams (env SOL_STREAMS, default = B) so that the
- * one-CU-per-simulation solver kernels overlap with the chip-wide convolutions.
+ * fed by copying into the same buffers.  (Option `streams` > 1 splits the batch into chains of
+ * simulations on separate internal HIP streams; measured slower on MI355X, default 1.)
  * One training call at a time per process (the chains share an internal stream pool).          */
 typedef struct sol_train_graph sol_train_graph;
 int sol_train_graph_create(const sol_train_cfg* cfg, const float* params,
@@ -267,6 +291,22 @@ int sol_adam_tf_step(void* stream, float* params, const float* grads, float* m, 
                      int64_t n, int32_t t, float lr, float beta1, float beta2, float eps,
                      float clip_norm, const int64_t* tensor_offsets, int32_t n_tensors,
                      float* scratch /* >= n_tensors floats, device */);
+
+/* ------------------------------------------------------------------------------------
+ * Data-parallel exchange (new capability; the reference is single device, karman_train.py:22,49):
+ * the gradients of independent simulations add (the loss is a batch SUM, karman_train.py:430), so N ranks, one per
+ * GPU, run the full unroll on their shard and SUM the flat gradient once per training step over RCCL / xGMI.
+ * RCCL is bound at run time (dlopen librccl.so.1); nothing here is needed on one GPU.
+ *   rank 0: sol_comm_unique_id(id) -> the host distributes the 128 bytes (any side channel) ->
+ *   every rank: sol_comm_init(id, nranks, rank, &comm) with ITS device current -> sol_allreduce_grads per step.
+ * ---------------------------------------------------------------------------------- */
+#define SOL_COMM_ID_BYTES 128
+typedef struct sol_comm sol_comm;
+int sol_comm_unique_id(char* id /* [SOL_COMM_ID_BYTES], host */);
+int sol_comm_init(const char* id, int32_t nranks, int32_t rank, sol_comm** out);
+/* in-place SUM over all ranks of flat_grad[count] (device fp32), asynchronous on `stream` */
+int sol_allreduce_grads(sol_comm* comm, void* stream, float* flat_grad, int64_t count);
+int sol_comm_destroy(sol_comm* comm);
 
 /* offsets (in floats) of layer l's kernel / bias inside the flat mars_moon parameter
  * vector; l in [0,12).  cin/cout may be NULL.                                            */

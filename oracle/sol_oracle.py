@@ -541,3 +541,32 @@ def synthetic_state(B, Y, X, seed, dtype=torch.float64, project_it=True):
 
 RE_TRAIN = [160000.0, 320000.0, 640000.0, 1280000.0, 2560000.0, 5120000.0]   # karman-2d/Makefile:22
 STD_RE = float(np.std(RE_TRAIN))
+
+
+# --------------------------------------------------------------------------------------
+# the synthetic SOL-<msteps> training workload bench.py times (BASELINE.json configs[2])
+# --------------------------------------------------------------------------------------
+def bench_workload(B, Y, X, msteps, rank=0, gt_perturb=0.05, last_layer_scale=0.01):
+    """Inputs of the benchmark / SOL-32 fixture, generated in float64 and rounded to fp32 values:
+    start state = seeded smooth noise (seed 1234+rank, NOT projected) passed through one solver step
+    (spin-up: divergence free and consistent with the boundary conditions); ground truth = plain solver
+    roll-out of the start state perturbed by 0.05 x a second noise field (seed 4321+rank); weights =
+    init_params(0) with the output layer scaled by 0.01 (an untrained Glorot corrector fed back through 32
+    solver steps blows the roll-out up).  bench.py builds the same workload with the HIP solver step."""
+    r32 = lambda t: t.detach().float().double()
+    g = geometry(Y, X)
+    re = torch.tensor([RE_TRAIN[i % len(RE_TRAIN)] for i in range(B)], dtype=torch.float64)
+    d, vy, vx = (r32(t) for t in synthetic_state(B, Y, X, 1234 + rank, project_it=False))
+    with torch.no_grad():
+        d0, vy0, vx0 = (r32(t) for t in karman_step(d, vy, vx, re, g))
+        _, py, px = (r32(t) for t in synthetic_state(B, Y, X, 4321 + rank, project_it=False))
+        gd, gy, gx = d0, r32(vy0 + gt_perturb * (py - 1.0)), r32(vx0 + gt_perturb * px)
+        gts_y, gts_x = [], []
+        for _ in range(msteps):
+            gd, gy, gx = (r32(t) for t in karman_step(gd, gy, gx, re, g))
+            gts_y.append(gy)
+            gts_x.append(gx)
+    params = [r32(p) for p in init_params(0)]
+    params[22] = r32(params[22] * last_layer_scale)
+    return {"geom": g, "re": re, "d0": d0, "vy0": vy0, "vx0": vx0, "gt_vy": gts_y, "gt_vx": gts_x, "params": params,
+            "std_v": (0.2, 0.2), "std_re": STD_RE}

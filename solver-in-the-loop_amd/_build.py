@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsol_hip.so")
-SOURCES = ["karman_step.hip", "karman_large.hip", "burgers_step.hip", "conv5x5.hip", "conv5x5_sb.hip", "train.hip"]
+SOURCES = ["karman_step.hip", "karman_large.hip", "burgers_step.hip", "conv5x5.hip", "conv5x5_sb.hip", "train.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 # the CG loop packs its vector updates by hand (float2); the SLP vectoriser only adds v_mov traffic there
 EXTRA = {"karman_step.hip": ["-fno-slp-vectorize"]}
@@ -20,6 +20,14 @@ def _hipcc():
         if cand and os.path.exists(cand):
             return cand
     raise RuntimeError("hipcc not found (need ROCm to build libsol_hip.so)")
+
+
+def have_hipcc():
+    try:
+        _hipcc()
+        return True
+    except RuntimeError:
+        return False
 
 
 STAMP = os.path.join(LIBDIR, "libsol_hip.sources.sha1")
@@ -84,7 +92,7 @@ def _build_locked(verbose):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, out))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", LIB]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout)

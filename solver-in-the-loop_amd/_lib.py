@@ -46,6 +46,11 @@ _P = C.c_void_p
 _SIGS = {
     "sol_last_error": (C.c_char_p, []),
     "sol_version": (C.c_int, []),
+    "sol_abi_sizes": (C.c_int, [C.POINTER(C.c_int32)] * 3),
+    "sol_set_option": (C.c_int, [C.c_char_p, C.c_int32]),
+    "sol_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
+    "sol_prof_begin": (C.c_int, []),
+    "sol_prof_end": (C.c_int, [C.c_int32, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "sol_karman_direct_supported": (C.c_int, [C.c_int32] * 2),
     "sol_karman_step_large_workspace_bytes": (C.c_size_t, [_P]),
     "sol_karman_step_fwd_large": (C.c_int, [_P] * 10 + [C.c_int64] + [_P] * 7 + [C.c_size_t]),
@@ -70,6 +75,10 @@ _SIGS = {
     "sol_rollout_workspace_bytes": (C.c_size_t, [C.POINTER(TrainCfg)]),
     "sol_rollout": (C.c_int, [C.POINTER(TrainCfg), _P] + [_P] * 9 + [C.c_int64, C.c_int32, _P, C.c_size_t, _P]),
     "sol_adam_tf_step": (C.c_int, [_P] * 5 + [C.c_int64, C.c_int32] + [C.c_float] * 5 + [C.POINTER(C.c_int64), C.c_int32, _P]),
+    "sol_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "sol_comm_init": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "sol_allreduce_grads": (C.c_int, [_P, _P, _P, C.c_int64]),
+    "sol_comm_destroy": (C.c_int, [_P]),
     "sol_mars_moon_layer": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 
@@ -88,24 +97,92 @@ def lib_path():
     return _build.LIB
 
 
+ABI_VERSION = 200     # sol_version() of the library these bindings were written against
+
+# Debugging overrides: environment variable -> (option, value).  Read ONCE here, in Python, when the library is loaded;
+# the library itself never reads the environment (options are set through sol_set_option, include/sol_hip.h).
+_ENV_OPTIONS = {
+    "SOL_CONV_NO_SB": ("conv_precision", 2), "SOL_CONV_NO_FP16": ("conv_precision", 1), "SOL_CONV_SPLIT3": ("conv_split3", 1),
+    "SOL_CONV_NO_R3": ("conv_r3", 0), "SOL_CONV_NO_THIN": ("conv_thin", 0), "SOL_CONV_NO_BWW32": ("conv_bww32", 0),
+    "SOL_CORRECT_NO_FUSE": ("correct_fuse", 0), "SOL_BWW_NO_FUSE": ("bww_fuse", 0), "SOL_BWW_NO_SIDE": ("bww_side", 0),
+    "SOL_DENSITY_INLINE": ("density_mode", 1), "SOL_DENSITY_NO_FUSE": ("density_mode", 2), "SOL_STEP_PROF": ("step_prof", 1),
+    "SOL_CNN_NO_PERSISTENT": ("cnn_persistent", 0),
+}
+_ENV_INT_OPTIONS = {"SOL_BWW_CHUNK": "bww_chunk", "SOL_STREAMS": "streams", "SOL_CPT": "cpt", "SOL_DBG_SKIP": "dbg_skip"}
+
+
 def load():
     """Load (building on demand when hipcc is available) and type the library."""
     global _lib
     if _lib is not None:
         return _lib
     path = _build.LIB
-    if not os.path.exists(path):
+    if _build._stale():
+        # missing, or built from other sources than the ones in the tree (content hash): rebuild, or refuse to load a
+        # library whose struct layouts / signatures may differ from the ctypes mirror in this file
         try:
             _build.build()
         except Exception as e:  # no silent fallback: the HIP extension IS the product
-            raise SolError("libsol_hip.so is missing and could not be built: %s" % e)
+            if not os.path.exists(path):
+                raise SolError("libsol_hip.so is missing and could not be built: %s" % e)
+            if _build.have_hipcc():
+                raise SolError("libsol_hip.so is stale and the rebuild failed: %s" % e)
+            # no compiler on this box (a GPU box running a shipped library): the ABI checks below decide
     lib = C.CDLL(path)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)     # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.sol_version() != ABI_VERSION:
+        raise SolError("libsol_hip.so reports ABI version %d, these bindings need %d: rebuild (python -m sol_amd._build --force)"
+                       % (lib.sol_version(), ABI_VERSION))
+    kc, bc, tc = C.c_int32(), C.c_int32(), C.c_int32()
+    lib.sol_abi_sizes(C.byref(kc), C.byref(bc), C.byref(tc))
+    if (kc.value, bc.value, tc.value) != (C.sizeof(KarmanCfg), C.sizeof(BurgersCfg), C.sizeof(TrainCfg)):
+        raise SolError("struct layout mismatch between libsol_hip.so %r and the ctypes mirror %r"
+                       % ((kc.value, bc.value, tc.value), (C.sizeof(KarmanCfg), C.sizeof(BurgersCfg), C.sizeof(TrainCfg))))
     _lib = lib
+    for env, (opt, val) in _ENV_OPTIONS.items():
+        if os.environ.get(env):
+            set_option(opt, val)
+    for env, opt in _ENV_INT_OPTIONS.items():
+        if os.environ.get(env):
+            set_option(opt, int(os.environ[env]))
     return lib
+
+
+def set_option(name, value):
+    """sol_set_option: process-wide kernel-variant option (see include/sol_hip.h)."""
+    check(load().sol_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    v = C.c_int32()
+    check(load().sol_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
+class profile:
+    """with profile() as p: ...eager library calls...  ->  p.kernels = {name: (calls, total_us)}.
+    Per-launch HIP events on the launch stream (sol_prof_begin / sol_prof_end)."""
+    MAXC = 64
+
+    def __enter__(self):
+        check(load().sol_prof_begin())
+        self.kernels = {}
+        return self
+
+    def __exit__(self, *exc):
+        names = C.create_string_buffer(self.MAXC * 64)
+        tot = (C.c_double * self.MAXC)()
+        calls = (C.c_int32 * self.MAXC)()
+        n = load().sol_prof_end(self.MAXC, names, tot, calls)
+        if n < 0:
+            check(n)
+        for k in range(n):
+            nm = names.raw[k * 64:(k + 1) * 64].split(b"\0")[0].decode()
+            self.kernels[nm] = (calls[k], tot[k])
+        return False
 
 
 def check(code):

@@ -248,7 +248,7 @@ int blaunch(K kernel, const sol_burgers_cfg* c, void* stream, const BArgs& a) {
         return 0;
     }();
     if (rc_attr) return sol_set_error(SOL_ERR_HIP, "hipFuncSetAttribute(burgers kernels) failed");
-    hipLaunchKernelGGL(kernel, dim3(c->B), dim3(NT), lds, (hipStream_t)stream, a);
+    SOL_LAUNCH_NAMED("k_burgers", kernel, dim3(c->B), dim3(NT), lds, (hipStream_t)stream, a);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }

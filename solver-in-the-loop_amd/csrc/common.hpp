@@ -1,6 +1,7 @@
 // Shared helpers for the gfx950 kernels of libsol_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -84,6 +85,46 @@ int sol_pack_jobs(hipStream_t s, int n, const float* const* w, float* const* out
 int sol_conv_sh_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int mode, void* out);
 int sol_conv_sb_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int mode, void* out);
 int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles);
+
+// ---- process-wide options (sol_set_option / sol_get_option, include/sol_hip.h) ----------------------------------
+// Read at every call (plain ints, no caching in function-local statics), so a host may switch e.g. the convolution
+// precision between two trainers of one process.  The library itself never reads the environment.
+struct SolOptions {
+    int conv_precision;   // 0 split (default): fp16 x3 where the operand's absmax is known, bf16 x6 otherwise; 1: bf16 x6 always; 2: strict fp32 MFMA
+    int conv_split3;      // experiment: three leading bf16 products only (NOT fp32 equivalent)
+    int conv_r3;          // 1: 3-row fp32 MFMA kernel for 32-channel layers (strict path)
+    int conv_thin;        // 1: folded-tap fp32 kernels for the thin weight gradients
+    int conv_bww32;       // 1: 32x32x2 fp32 MFMA weight gradient (strict path)
+    int correct_fuse;     // 1: correction + loss in the last CNN layer's epilogue
+    int bww_fuse;         // 1: 32->32 weight gradients ride in the solver-adjoint launches
+    int bww_chunk;        // 0: one weight-gradient launch per layer over all unrolled steps; n: chunks of n steps
+    int bww_side;         // 1: chunked weight gradients on a side stream
+    int streams;          // sub-batch chains on separate streams (measured slower; default 1)
+    int density_mode;     // 0: density advection rides in the next solver launch; 1: inline in the step kernel; 2: one chain launch after the unroll
+    int cpt;              // 0: automatic strip height of the CG kernels, 8 / 16: forced
+    int dbg_skip;         // timing experiments only
+    int step_prof;        // debugging: synchronous phase times of the solver step kernels on stderr
+    int cnn_persistent;   // 1: the 12 CNN layers of a pass as ONE cooperative launch where the shape allows it
+};
+SolOptions& sol_opt();
+
+// ---- launch profiler (sol_prof_begin / sol_prof_end) ---------------------------------------------------------------
+// While active, every kernel launched through SOL_LAUNCH carries its own start/stop HIP events (hipExtLaunchKernelGGL:
+// the dispatch packet's begin / end timestamps, i.e. what rocprofv3 --kernel-trace reports) on the stream it is
+// launched on.  Not usable under stream capture: the trainer's eager path is profiled.
+bool sol_prof_events(const char* name, hipEvent_t* a, hipEvent_t* b);
+extern bool g_sol_prof_on;
+
+template <typename... KA, typename... A>
+inline void sol_launch_impl(const char* name, void (*kernel)(KA...), dim3 g, dim3 b, size_t lds, hipStream_t s, A&&... args) {
+    hipEvent_t ea, eb;
+    if (g_sol_prof_on && sol_prof_events(name, &ea, &eb))
+        hipExtLaunchKernelGGL(kernel, g, b, (uint32_t)lds, s, ea, eb, 0u, static_cast<KA>(args)...);
+    else
+        hipLaunchKernelGGL(kernel, g, b, lds, s, static_cast<KA>(args)...);
+}
+#define SOL_LAUNCH(kernel, ...) sol_launch_impl(#kernel, kernel, __VA_ARGS__)
+#define SOL_LAUNCH_NAMED(name, kernel, ...) sol_launch_impl(name, kernel, __VA_ARGS__)
 
 #define SOL_HIP_CHECK(expr)                                                                  \
     do {                                                                                     \

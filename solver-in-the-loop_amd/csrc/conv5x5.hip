@@ -981,7 +981,7 @@ extern "C" int sol_conv5x5_pack(void* stream, const float* w_hwio, int32_t cin, 
     SOL_REQUIRE(cin >= 1 && cin <= 32 && cout >= 1 && cout <= 32, "sol_conv5x5_pack: channels out of range");
     SOL_REQUIRE(mode == SOL_CONV_FWD || mode == SOL_CONV_BWD_DATA, "sol_conv5x5_pack: bad mode %d", mode);
     const int total = 25 * pad_in(cin) * pad_out(cout);
-    hipLaunchKernelGGL(k_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_hwio, packed, cin, cout, mode);
+    SOL_LAUNCH(k_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_hwio, packed, cin, cout, mode);
     SOL_LAUNCH_CHECK();
     if (pad_in(cin) == 32) {
         if (int e = sol_conv_sb_pack((hipStream_t)stream, w_hwio, cin, cout, mode, packed + total)) return e;
@@ -1025,8 +1025,8 @@ static int conv_impl(void* stream, const float* x, const float* packed, const fl
     }
     const int NT = pad_out(cout) / 16;
     hipStream_t s = (hipStream_t)stream;
-    static const bool use_sb = !getenv("SOL_CONV_NO_SB");
-    static const bool use_sh = !getenv("SOL_CONV_NO_FP16");
+    const bool use_sb = sol_opt().conv_precision != 2;
+    const bool use_sh = sol_opt().conv_precision == 0;
     if (use_sb) a.ymax = y_absmax;                  // published by the split kernels and the thin fp32 kernel below
     if (cin == 32 && W % 64 == 0 && use_sb) {
         a.wsb = packed + (size_t)25 * 32 * pad_out(cout);
@@ -1034,26 +1034,26 @@ static int conv_impl(void* stream, const float* x, const float* packed, const fl
         a.xmax = use_sh ? x_absmax : nullptr;       // absmax of x known -> fp16 three-product kernel, else bf16 six-product
         return sol_conv_sb_launch(s, a, NT, B * H * (W / 64));
     }
-    if (cin == 32 && W % 64 == 0 && !getenv("SOL_CONV_NO_R3")) {
+    if (cin == 32 && W % 64 == 0 && sol_opt().conv_r3) {
         const int ntiles = B * H * (W / 64);
         const size_t ldsr = ((size_t)3 * 2 * 68 * 32 + 2 * (size_t)5 * NT * 16 * 32) * sizeof(float);
         const int grid3 = (ntiles + 2) / 3;
         if (NT == 2) {
-            hipLaunchKernelGGL((k_conv5x5_r3<2>), dim3(grid3), dim3(768), ldsr, s, a, ntiles);
+            SOL_LAUNCH((k_conv5x5_r3<2>), dim3(grid3), dim3(768), ldsr, s, a, ntiles);
         } else {
-            hipLaunchKernelGGL((k_conv5x5_r3<1>), dim3(grid3), dim3(768), ldsr, s, a, ntiles);
+            SOL_LAUNCH((k_conv5x5_r3<1>), dim3(grid3), dim3(768), ldsr, s, a, ntiles);
         }
     }
     else if (cin == 32) {
         const size_t lds32 = ((size_t)(a.RPW + 4) * (a.TW + 4) * 32 + 2 * (size_t)NT * 16 * 32) * sizeof(float);
         if (NT == 2) {
-            hipLaunchKernelGGL((k_conv5x5_c32<2>), dim3(grid), dim3(256), lds32, s, a);
+            SOL_LAUNCH((k_conv5x5_c32<2>), dim3(grid), dim3(256), lds32, s, a);
         } else {
-            hipLaunchKernelGGL((k_conv5x5_c32<1>), dim3(grid), dim3(256), lds32, s, a);
+            SOL_LAUNCH((k_conv5x5_c32<1>), dim3(grid), dim3(256), lds32, s, a);
         }
     }
-    else if (cin == 4 && NT == 2) hipLaunchKernelGGL((k_conv5x5<4, 2>), dim3(grid), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((k_conv5x5<4, 1>), dim3(grid), dim3(256), lds, s, a);
+    else if (cin == 4 && NT == 2) SOL_LAUNCH((k_conv5x5<4, 2>), dim3(grid), dim3(256), lds, s, a);
+    else SOL_LAUNCH((k_conv5x5<4, 1>), dim3(grid), dim3(256), lds, s, a);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }
@@ -1066,8 +1066,7 @@ extern "C" int sol_conv5x5(void* stream, const float* x, const float* packed, co
 }
 
 bool sol_conv_correct_fusable(int W) {
-    static const bool ok = !getenv("SOL_CONV_NO_SB") && !getenv("SOL_CONV_NO_FP16") && !getenv("SOL_CORRECT_NO_FUSE");
-    return ok && W % 64 == 0;
+    return sol_opt().conv_precision == 0 && sol_opt().correct_fuse && W % 64 == 0;
 }
 
 int sol_conv5x5_correct(void* stream, const float* x, const float* packed, const float* bias, int B, int H, int W,
@@ -1140,28 +1139,27 @@ static int bww_launch(void* stream, const float* x, const float* dz, float* part
     const size_t lds = 2 * ((size_t)(W + 4) * CPX + (size_t)W * CPZ) * sizeof(float);   // double buffered rows
     const int grid = nblk_run * 5;
     hipStream_t s = (hipStream_t)stream;
-    if (W == 64 && ((cin == 4 && cout == 32) || (cin == 32 && cout == 2)) && !getenv("SOL_CONV_NO_THIN")) {
+    if (W == 64 && ((cin == 4 && cout == 32) || (cin == 32 && cout == 2)) && sol_opt().conv_thin) {
         // all five tap rows in one workgroup: grid = nblk; LDS = 2 stages (>= the 16 KB fold buffer)
         if (cin == 4) {
             const size_t l0 = 2 * (size_t)(5 * 68 * 4 + 68 * 32) * sizeof(float);
-            hipLaunchKernelGGL(k_conv5x5_bww_thin<0>, dim3(nblk_run), dim3(256), l0, s, a);
+            SOL_LAUNCH(k_conv5x5_bww_thin<0>, dim3(nblk_run), dim3(256), l0, s, a);
         } else {
             const size_t l1 = 2 * (size_t)(68 * 32 + 5 * 72 * 2) * sizeof(float);
-            hipLaunchKernelGGL(k_conv5x5_bww_thin<1>, dim3(nblk_run), dim3(256), l1, s, a);
+            SOL_LAUNCH(k_conv5x5_bww_thin<1>, dim3(nblk_run), dim3(256), l1, s, a);
         }
         SOL_LAUNCH_CHECK();
         return SOL_OK;
     }
-    static const bool use_sb = !getenv("SOL_CONV_NO_SB");
-    if (cin == 32 && cout == 32 && W == 64 && use_sb) return sol_bww_sb_launch(s, a, nblk_run);
-    if (cin == 32 && cout == 32 && W == 64 && !getenv("SOL_CONV_NO_BWW32")) {
+    if (cin == 32 && cout == 32 && W == 64 && sol_opt().conv_precision != 2) return sol_bww_sb_launch(s, a, nblk_run);
+    if (cin == 32 && cout == 32 && W == 64 && sol_opt().conv_bww32) {
         const size_t lds3 = 2 * ((size_t)(64 + 4) * 32 + 64 * 32) * sizeof(float);
-        hipLaunchKernelGGL(k_conv5x5_bww32, dim3(grid), dim3(256), lds3, s, a);
+        SOL_LAUNCH(k_conv5x5_bww32, dim3(grid), dim3(256), lds3, s, a);
     }
-    else if (cin == 32 && cout == 32) hipLaunchKernelGGL((k_conv5x5_bww<32, 32>), dim3(grid), dim3(256), lds, s, a);
-    else if (cin == 32 && cout == 2) hipLaunchKernelGGL((k_conv5x5_bww<32, 2>), dim3(grid), dim3(256), lds, s, a);
-    else if (cin == 4 && cout == 32) hipLaunchKernelGGL((k_conv5x5_bww<4, 32>), dim3(grid), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((k_conv5x5_bww<4, 2>), dim3(grid), dim3(256), lds, s, a);
+    else if (cin == 32 && cout == 32) SOL_LAUNCH((k_conv5x5_bww<32, 32>), dim3(grid), dim3(256), lds, s, a);
+    else if (cin == 32 && cout == 2) SOL_LAUNCH((k_conv5x5_bww<32, 2>), dim3(grid), dim3(256), lds, s, a);
+    else if (cin == 4 && cout == 32) SOL_LAUNCH((k_conv5x5_bww<4, 32>), dim3(grid), dim3(256), lds, s, a);
+    else SOL_LAUNCH((k_conv5x5_bww<4, 2>), dim3(grid), dim3(256), lds, s, a);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }
@@ -1193,11 +1191,11 @@ static int bww_reduce(void* stream, const float* partial, float* dw_hwio, float*
     const int chunk = 16, ny = (nblk + chunk - 1) / chunk;
     hipStream_t hs = (hipStream_t)stream;
     if (ny > 1) {
-        hipLaunchKernelGGL(k_bww_reduce, dim3((total + 255) / 256, ny), dim3(256), 0, hs, pm, dw_hwio, db, nblk, cin, cout, IP, OP, chunk, 1, 0, 0);
+        SOL_LAUNCH(k_bww_reduce, dim3((total + 255) / 256, ny), dim3(256), 0, hs, pm, dw_hwio, db, nblk, cin, cout, IP, OP, chunk, 1, 0, 0);
         SOL_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_bww_reduce, dim3((total + 255) / 256, 1), dim3(256), 0, hs, pm, dw_hwio, db, nblk, cin, cout, IP, OP, ny, chunk, 1, accumulate);
+        SOL_LAUNCH(k_bww_reduce, dim3((total + 255) / 256, 1), dim3(256), 0, hs, pm, dw_hwio, db, nblk, cin, cout, IP, OP, ny, chunk, 1, accumulate);
     } else {
-        hipLaunchKernelGGL(k_bww_reduce, dim3((total + 255) / 256, 1), dim3(256), 0, hs, pm, dw_hwio, db, nblk, cin, cout, IP, OP, nblk, 1, 1, accumulate);
+        SOL_LAUNCH(k_bww_reduce, dim3((total + 255) / 256, 1), dim3(256), 0, hs, pm, dw_hwio, db, nblk, cin, cout, IP, OP, nblk, 1, 1, accumulate);
     }
     SOL_LAUNCH_CHECK();
     return SOL_OK;

@@ -481,7 +481,7 @@ size_t sol_conv_sb_packed_floats(int OP) { return (size_t)25 * 3 * OP * 16; }   
 int sol_conv_sb_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int mode, void* out) {
     const int OP = cout <= 16 ? 16 : 32;
     const int total = 25 * OP * 16;
-    hipLaunchKernelGGL(k_pack_sb, dim3((total + 255) / 256), dim3(256), 0, s, w_hwio, reinterpret_cast<unsigned short*>(out), cin, cout, OP, mode);
+    SOL_LAUNCH(k_pack_sb, dim3((total + 255) / 256), dim3(256), 0, s, w_hwio, reinterpret_cast<unsigned short*>(out), cin, cout, OP, mode);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }
@@ -494,10 +494,10 @@ int sol_conv_sh_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int 
     float* hdr = reinterpret_cast<float*>(out);
     unsigned* slots = reinterpret_cast<unsigned*>(hdr + 4 + (size_t)25 * 2 * OP * 16);
     SOL_HIP_CHECK(hipMemsetAsync(slots, 0, SOL_AMAX_SLOTS * sizeof(unsigned), s));
-    hipLaunchKernelGGL(k_absmax, dim3(8), dim3(256), 0, s, w_hwio, (size_t)25 * cin * cout, slots);
+    SOL_LAUNCH(k_absmax, dim3(8), dim3(256), 0, s, w_hwio, (size_t)25 * cin * cout, slots);
     SOL_LAUNCH_CHECK();
     const int total = 25 * OP * 16;
-    hipLaunchKernelGGL(k_pack_sh, dim3((total + 255) / 256), dim3(256), 0, s, w_hwio, slots, hdr, reinterpret_cast<unsigned short*>(hdr + 4), cin, cout, OP, mode);
+    SOL_LAUNCH(k_pack_sh, dim3((total + 255) / 256), dim3(256), 0, s, w_hwio, slots, hdr, reinterpret_cast<unsigned short*>(hdr + 4), cin, cout, OP, mode);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }
@@ -506,28 +506,28 @@ int sol_conv_sh_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int 
 // experiment knob, NOT the default and not what bench.py or the parity tests use.
 int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles) {
     if (int e = init_sb_kernels()) return e;
-    static const int nprod = [] { const char* v = getenv("SOL_CONV_SPLIT"); return v && atoi(v) == 3 ? 3 : 6; }();
+    const int nprod = sol_opt().conv_split3 ? 3 : 6;
     const int nrows = ntiles / a.tiles_x;             // global image rows B*H
     const int grid3 = ((nrows + 2) / 3) * a.tiles_x;  // three consecutive rows of one column block per workgroup
     const size_t lds = sb_lds(NT * 16);
     if (a.xmax) {                                     // per-tensor absmax known: fp16 three-product kernels
-        if (NT == 2) hipLaunchKernelGGL((k_conv5x5_sb<2, 2>), dim3(grid3), dim3(768), lds, s, a, nrows);
-        else hipLaunchKernelGGL((k_conv5x5_sb<1, 2>), dim3(grid3), dim3(768), lds, s, a, nrows);
+        if (NT == 2) SOL_LAUNCH((k_conv5x5_sb<2, 2>), dim3(grid3), dim3(768), lds, s, a, nrows);
+        else SOL_LAUNCH((k_conv5x5_sb<1, 2>), dim3(grid3), dim3(768), lds, s, a, nrows);
     }
-    else if (NT == 2 && nprod == 6) hipLaunchKernelGGL((k_conv5x5_sb<2, 0>), dim3(grid3), dim3(768), lds, s, a, nrows);
-    else if (NT == 2) hipLaunchKernelGGL((k_conv5x5_sb<2, 1>), dim3(grid3), dim3(768), lds, s, a, nrows);
-    else if (nprod == 6) hipLaunchKernelGGL((k_conv5x5_sb<1, 0>), dim3(grid3), dim3(768), lds, s, a, nrows);
-    else hipLaunchKernelGGL((k_conv5x5_sb<1, 1>), dim3(grid3), dim3(768), lds, s, a, nrows);
+    else if (NT == 2 && nprod == 6) SOL_LAUNCH((k_conv5x5_sb<2, 0>), dim3(grid3), dim3(768), lds, s, a, nrows);
+    else if (NT == 2) SOL_LAUNCH((k_conv5x5_sb<2, 1>), dim3(grid3), dim3(768), lds, s, a, nrows);
+    else if (nprod == 6) SOL_LAUNCH((k_conv5x5_sb<1, 0>), dim3(grid3), dim3(768), lds, s, a, nrows);
+    else SOL_LAUNCH((k_conv5x5_sb<1, 1>), dim3(grid3), dim3(768), lds, s, a, nrows);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }
 
 int sol_bww_sb_launch(hipStream_t s, const BwArgs& a, int nblk_run) {
     if (int e = init_sb_kernels()) return e;
-    static const bool use_sh = !getenv("SOL_CONV_NO_FP16");
+    const bool use_sh = sol_opt().conv_precision == 0;
     // fp16 three-product kernel: absmax of both operands known and no workgroup straddles two segments
-    if (use_sh && a.xmax && a.zmax && (a.B * a.H) % a.rb == 0) hipLaunchKernelGGL(k_conv5x5_bww_sb<2>, dim3(nblk_run), dim3(512), BW_LDS, s, a);
-    else hipLaunchKernelGGL(k_conv5x5_bww_sb<0>, dim3(nblk_run), dim3(512), BW_LDS, s, a);
+    if (use_sh && a.xmax && a.zmax && (a.B * a.H) % a.rb == 0) SOL_LAUNCH(k_conv5x5_bww_sb<2>, dim3(nblk_run), dim3(512), BW_LDS, s, a);
+    else SOL_LAUNCH(k_conv5x5_bww_sb<0>, dim3(nblk_run), dim3(512), BW_LDS, s, a);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }
@@ -539,7 +539,7 @@ int sol_pack_jobs(hipStream_t s, int n, const float* const* w, float* const* out
     PackJobs jobs{};
     jobs.n = n;
     for (int k = 0; k < n; ++k) jobs.j[k] = PackJob{w[k], out[k], bias_out[k], bias_in[k], cin[k], cout[k], mode[k]};
-    hipLaunchKernelGGL(k_pack_jobs, dim3(n * PACK_WG), dim3(256), 0, s, jobs);
+    SOL_LAUNCH(k_pack_jobs, dim3(n * PACK_WG), dim3(256), 0, s, jobs);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }

@@ -255,7 +255,7 @@ struct Header { int Y, X, wy0, wx0, nS, SP, win; };
 int gemm(hipStream_t s, int batch, const float* A, int lda, long sA, const float* Bm, int ldb, long sB, float* C, int ldc, long sC,
          int M, int N, int K, int accumulate) {
     GArgs g{A, Bm, nullptr, C, M, N, K, lda, ldb, ldc, 0, sA, sB, sC, accumulate};
-    hipLaunchKernelGGL(k_l_gemm, dim3((N + 63) / 64, (M + 63) / 64, batch), dim3(256), 0, s, g);
+    SOL_LAUNCH(k_l_gemm, dim3((N + 63) / 64, (M + 63) / 64, batch), dim3(256), 0, s, g);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }
@@ -322,9 +322,9 @@ extern "C" int sol_karman_step_fwd_large(const sol_karman_cfg* c, void* stream,
     a.d_out = d_out; a.vy_out = vy_out; a.vx_out = vx_out; a.svy = svy; a.svx = svx; a.rhs = T0; a.feat = feat_out; a.p = T0;
     if (feat_scale) { a.fs0 = feat_scale[0]; a.fs1 = feat_scale[1]; a.fs2 = feat_scale[2]; }
     const int faces = (Y + 1) * X + Y * (X + 1);
-    hipLaunchKernelGGL(k_l_diffuse, dim3((faces + 255) / 256, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_l_advect, dim3((faces + N + 255) / 256, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_l_div, dim3((N + 255) / 256, B), dim3(256), 0, s, a);
+    SOL_LAUNCH(k_l_diffuse, dim3((faces + 255) / 256, B), dim3(256), 0, s, a);
+    SOL_LAUNCH(k_l_advect, dim3((faces + N + 255) / 256, B), dim3(256), 0, s, a);
+    SOL_LAUNCH(k_l_div, dim3((N + 255) / 256, B), dim3(256), 0, s, a);
     SOL_LAUNCH_CHECK();
 
     // ---- direct pressure solve.  All matrices row-major [Y][X] per simulation; Qy, Qx symmetric.
@@ -332,21 +332,21 @@ extern "C" int sol_karman_step_fwd_large(const sol_karman_cfg* c, void* stream,
     // T1 = Qy rhs ;  T2 = (T1 Qx) / lam
     if (int e = gemm(s, B, Qy, Y, 0, T0, X, sN, T1, X, sN, Y, X, Y, 0)) return e;
     if (int e = gemm(s, B, T1, X, sN, Qx, X, 0, T2, X, sN, Y, X, X, 0)) return e;
-    hipLaunchKernelGGL(k_l_scale, dim3((N + 255) / 256, B), dim3(256), 0, s, T2, (const float*)nullptr, ilT, Y, X);
+    SOL_LAUNCH(k_l_scale, dim3((N + 255) / 256, B), dim3(256), 0, s, T2, (const float*)nullptr, ilT, Y, X);
     // window values of G b: U = T2 Qx[:, win] ; X0 = Qy[win, :] U
     if (int e = gemm(s, B, T2, X, sN, QxW, win, 0, U, win, sU, Y, win, X, 0)) return e;
     if (int e = gemm(s, B, Qy + (size_t)h.wy0 * Y, Y, 0, U, win, sU, X0, win, sW, win, win, Y, 0)) return e;
     // W2 = -scatter(K' gather(X0))
-    hipLaunchKernelGGL(k_l_capacitance, dim3(B), dim3(256), SP * sizeof(float), s, X0, KpT, sidx, W2, SP, win);
+    SOL_LAUNCH(k_l_capacitance, dim3(B), dim3(256), SP * sizeof(float), s, X0, KpT, sidx, W2, SP, win);
     SOL_LAUNCH_CHECK();
     // spectral coefficients of the correction: V = Qy[:, win] W2 ; T2 += ((V Qx[win, :])) / lam
     if (int e = gemm(s, B, Qy + h.wy0, Y, 0, W2, win, sW, V, win, sU, Y, win, win, 0)) return e;
     if (int e = gemm(s, B, V, win, sU, Qx + (size_t)h.wx0 * X, X, 0, T1, X, sN, Y, X, win, 0)) return e;
-    hipLaunchKernelGGL(k_l_scale, dim3((N + 255) / 256, B), dim3(256), 0, s, T2, (const float*)T1, ilT, Y, X);
+    SOL_LAUNCH(k_l_scale, dim3((N + 255) / 256, B), dim3(256), 0, s, T2, (const float*)T1, ilT, Y, X);
     // p = Qy (T2 Qx)
     if (int e = gemm(s, B, T2, X, sN, Qx, X, 0, T1, X, sN, Y, X, X, 0)) return e;
     if (int e = gemm(s, B, Qy, Y, 0, T1, X, sN, T0, X, sN, Y, X, Y, 0)) return e;
-    hipLaunchKernelGGL(k_l_project, dim3((faces + 255) / 256, B), dim3(256), 0, s, a);
+    SOL_LAUNCH(k_l_project, dim3((faces + 255) / 256, B), dim3(256), 0, s, a);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }

@@ -1440,10 +1440,8 @@ __global__ void __launch_bounds__(1024) k_density_chain(DensArgs a) {
 // reduction overhead in the issue-bound CG loop), 8 otherwise.  SOL_CPT=8|16 overrides.
 int pick_cpt(const sol_karman_cfg* c) {
     int cpt = (c->Y % 16 == 0 && c->X >= 16) ? 16 : 8;
-    if (const char* e = getenv("SOL_CPT")) {
-        const int v = atoi(e);
-        if (v == 8 || (v == 16 && c->Y % 16 == 0 && c->X >= 16)) cpt = v;
-    }
+    const int v = sol_opt().cpt;
+    if (v == 8 || (v == 16 && c->Y % 16 == 0 && c->X >= 16)) cpt = v;
     return cpt;
 }
 
@@ -1490,7 +1488,7 @@ void fill_common(StepArgs& a, const sol_karman_cfg* c) {
     a.cinv = c->coarse_inv;
     a.fd = c->direct;
     a.fd_n = c->direct_n;
-    a.dbg = getenv("SOL_DBG_SKIP") ? atoi(getenv("SOL_DBG_SKIP")) : 0;   // timing experiments only
+    a.dbg = sol_opt().dbg_skip;   // timing experiments only
 }
 
 }  // namespace
@@ -1519,13 +1517,13 @@ int launch_step(K kernel, int cpt, const sol_karman_cfg* c, void* stream, const 
     const size_t lds = lds_bytes(c->Y, c->X, cpt);
     if (int e = sol_init_karman_kernels()) return e;
     StepArgs a = a0;
-    static const bool prof = getenv("SOL_STEP_PROF") != nullptr;     // debugging: synchronous, prints phase times
+    const bool prof = sol_opt().step_prof != 0;     // debugging: synchronous, prints phase times
     static long long* pbuf = nullptr;
     if (prof) {
         if (!pbuf) SOL_HIP_CHECK(hipMalloc(&pbuf, 16 * sizeof(long long)));
         a.prof = pbuf;
     }
-    hipLaunchKernelGGL(kernel, dim3(c->B), dim3(threads), lds, (hipStream_t)stream, a);
+    SOL_LAUNCH_NAMED(a.g_vy_in ? "k_karman_bwd" : "k_karman_fwd", kernel, dim3(c->B), dim3(threads), lds, (hipStream_t)stream, a);
     SOL_LAUNCH_CHECK();
     if (prof) {
         long long h[16];
@@ -1563,7 +1561,7 @@ int sol_density_chain(const sol_karman_cfg* c, void* stream, int ms, const float
     a.d_steps = d_steps; a.d_final = d_final;
     const int threads = c->Y * c->X >= 1024 ? 1024 : (int)align_up((size_t)c->Y * c->X, 64);
     SOL_REQUIRE((size_t)c->Y * c->X <= (size_t)8 * threads, "sol_density_chain: grid too large");
-    hipLaunchKernelGGL(k_density_chain, dim3(c->B), dim3(threads), lds, (hipStream_t)stream, a);
+    SOL_LAUNCH(k_density_chain, dim3(c->B), dim3(threads), lds, (hipStream_t)stream, a);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }
@@ -1597,7 +1595,7 @@ static int step_fwd_impl(const sol_karman_cfg* cfg, void* stream,
         SOL_REQUIRE(cpt == 16 && a.fd && dens_d_in && dens_svy && dens_svx && inflow, "fused solver + density launch: unsupported configuration");
         if (int e = sol_init_karman_kernels()) return e;
         DensStep q{cfg->B, cfg->Y, cfg->X, cfg->inflow_before, cfg->dt / cfg->dx, cfg->dt, dens_d_in, dens_svy, dens_svx, inflow, dens_d_out};
-        hipLaunchKernelGGL(k_karman_fwd_dens, dim3(2 * cfg->B), dim3(512), lds_bytes(cfg->Y, cfg->X, 16), (hipStream_t)stream, a, q);
+        SOL_LAUNCH(k_karman_fwd_dens, dim3(2 * cfg->B), dim3(512), lds_bytes(cfg->Y, cfg->X, 16), (hipStream_t)stream, a, q);
         SOL_LAUNCH_CHECK();
         return SOL_OK;
     }
@@ -1632,7 +1630,7 @@ int sol_karman_step_fwd_dens(const sol_karman_cfg* cfg, void* stream,
 int sol_density_step(const sol_karman_cfg* c, void* stream, const float* d_in, const float* svy, const float* svx, const float* inflow, float* d_out) {
     SOL_REQUIRE(c && d_in && svy && svx && inflow && d_out, "sol_density_step: NULL pointer argument");
     DensStep q{c->B, c->Y, c->X, c->inflow_before, c->dt / c->dx, c->dt, d_in, svy, svx, inflow, d_out};
-    hipLaunchKernelGGL(k_density_step, dim3(c->B), dim3(512), 0, (hipStream_t)stream, q);
+    SOL_LAUNCH(k_density_step, dim3(c->B), dim3(512), 0, (hipStream_t)stream, q);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }
@@ -1665,7 +1663,7 @@ static int step_bwd_impl(const sol_karman_cfg* cfg, void* stream,
         pk.n = nbw; pk.wg_per = wg_per;
         size_t lds = lds_bytes(cfg->Y, cfg->X, 16);
         if (lds < (size_t)sbk::BW_LDS) lds = sbk::BW_LDS;
-        hipLaunchKernelGGL(k_karman_bwd_bww, dim3(cfg->B + nbw * wg_per), dim3(512), lds, (hipStream_t)stream, a, pk);
+        SOL_LAUNCH(k_karman_bwd_bww, dim3(cfg->B + nbw * wg_per), dim3(512), lds, (hipStream_t)stream, a, pk);
         SOL_LAUNCH_CHECK();
         return SOL_OK;
     }
@@ -1704,7 +1702,7 @@ int sol_bww_jobs_launch(void* stream, const BwArgs* bw, int nbw, int wg_per) {
     BwPack pk{};
     for (int k = 0; k < nbw; ++k) pk.a[k] = bw[k];
     pk.n = nbw; pk.wg_per = wg_per;
-    hipLaunchKernelGGL(k_karman_bwd_bww, dim3(nbw * wg_per), dim3(512), (size_t)sbk::BW_LDS, (hipStream_t)stream, a, pk);
+    SOL_LAUNCH(k_karman_bwd_bww, dim3(nbw * wg_per), dim3(512), (size_t)sbk::BW_LDS, (hipStream_t)stream, a, pk);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }

@@ -6,6 +6,8 @@
 // the reverse sweep follow SURVEY.md appendix C.9.
 #include "common.hpp"
 #include <stdlib.h>
+#include <string.h>
+#include <vector>
 
 thread_local char g_sol_err[512] = "";
 
@@ -18,7 +20,111 @@ int sol_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* sol_last_error(void) { return g_sol_err; }
-extern "C" int sol_version(void) { return 100; }
+extern "C" int sol_version(void) { return 200; }
+// sizes of the ABI structs: the ctypes mirror in _lib.py checks them at load time
+extern "C" int sol_abi_sizes(int32_t* karman_cfg, int32_t* burgers_cfg, int32_t* train_cfg) {
+    if (karman_cfg) *karman_cfg = (int32_t)sizeof(sol_karman_cfg);
+    if (burgers_cfg) *burgers_cfg = (int32_t)sizeof(sol_burgers_cfg);
+    if (train_cfg) *train_cfg = (int32_t)sizeof(sol_train_cfg);
+    return SOL_OK;
+}
+
+// ---- options --------------------------------------------------------------------------------
+SolOptions& sol_opt() {
+    static SolOptions o = [] {
+        SolOptions d{};
+        d.conv_precision = 0; d.conv_split3 = 0; d.conv_r3 = 1; d.conv_thin = 1; d.conv_bww32 = 1;
+        d.correct_fuse = 1; d.bww_fuse = 1; d.bww_chunk = 0; d.bww_side = 1; d.streams = 1;
+        d.density_mode = 0; d.cpt = 0; d.dbg_skip = 0; d.step_prof = 0; d.cnn_persistent = 1;
+        return d;
+    }();
+    return o;
+}
+
+namespace {
+struct OptName { const char* name; int SolOptions::*field; int lo, hi; };
+const OptName OPT_NAMES[] = {
+    {"conv_precision", &SolOptions::conv_precision, 0, 2}, {"conv_split3", &SolOptions::conv_split3, 0, 1},
+    {"conv_r3", &SolOptions::conv_r3, 0, 1}, {"conv_thin", &SolOptions::conv_thin, 0, 1}, {"conv_bww32", &SolOptions::conv_bww32, 0, 1},
+    {"correct_fuse", &SolOptions::correct_fuse, 0, 1}, {"bww_fuse", &SolOptions::bww_fuse, 0, 1},
+    {"bww_chunk", &SolOptions::bww_chunk, 0, 1024}, {"bww_side", &SolOptions::bww_side, 0, 1}, {"streams", &SolOptions::streams, 1, 8},
+    {"density_mode", &SolOptions::density_mode, 0, 2}, {"cpt", &SolOptions::cpt, 0, 16}, {"dbg_skip", &SolOptions::dbg_skip, 0, 1 << 30},
+    {"step_prof", &SolOptions::step_prof, 0, 1}, {"cnn_persistent", &SolOptions::cnn_persistent, 0, 1},
+};
+}  // namespace
+
+extern "C" int sol_set_option(const char* name, int32_t value) {
+    SOL_REQUIRE(name != nullptr, "sol_set_option: NULL name");
+    for (const OptName& o : OPT_NAMES)
+        if (!strcmp(o.name, name)) {
+            SOL_REQUIRE(value >= o.lo && value <= o.hi, "sol_set_option: %s must be in [%d, %d] (got %d)", name, o.lo, o.hi, value);
+            sol_opt().*(o.field) = value;
+            return SOL_OK;
+        }
+    return sol_set_error(SOL_ERR_ARG, "sol_set_option: unknown option '%s'", name);
+}
+
+extern "C" int sol_get_option(const char* name, int32_t* value) {
+    SOL_REQUIRE(name != nullptr && value != nullptr, "sol_get_option: NULL argument");
+    for (const OptName& o : OPT_NAMES)
+        if (!strcmp(o.name, name)) { *value = sol_opt().*(o.field); return SOL_OK; }
+    return sol_set_error(SOL_ERR_ARG, "sol_get_option: unknown option '%s'", name);
+}
+
+// ---- launch profiler ------------------------------------------------------------------------
+bool g_sol_prof_on = false;
+namespace {
+struct ProfRec { const char* name; hipEvent_t a, b; };
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+size_t g_prof_used = 0;
+}  // namespace
+
+bool sol_prof_events(const char* name, hipEvent_t* a, hipEvent_t* b) {
+    while (g_prof_pool.size() < g_prof_used + 2) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return false;
+        g_prof_pool.push_back(e);
+    }
+    *a = g_prof_pool[g_prof_used++];
+    *b = g_prof_pool[g_prof_used++];
+    g_prof_recs.push_back(ProfRec{name, *a, *b});
+    return true;
+}
+
+extern "C" int sol_prof_begin(void) {
+    g_prof_recs.clear();
+    g_prof_used = 0;
+    g_sol_prof_on = true;
+    return SOL_OK;
+}
+
+// Stops profiling, waits for the device and sums the records per kernel name.  names: max_classes x 64 chars.
+// Returns the number of classes (<= max_classes) or < 0.
+extern "C" int sol_prof_end(int32_t max_classes, char* names, double* total_us, int32_t* calls) {
+    g_sol_prof_on = false;
+    SOL_REQUIRE(max_classes >= 1 && names && total_us && calls, "sol_prof_end: bad arguments");
+    SOL_HIP_CHECK(hipDeviceSynchronize());
+    int n = 0;
+    for (const ProfRec& r : g_prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) { (void)hipGetLastError(); continue; }
+        int k = 0;
+        while (k < n && strncmp(names + (size_t)k * 64, r.name, 63)) ++k;
+        if (k == n) {
+            if (n == max_classes) continue;
+            strncpy(names + (size_t)k * 64, r.name, 63);
+            names[(size_t)k * 64 + 63] = 0;
+            total_us[k] = 0.0; calls[k] = 0;
+            ++n;
+        }
+        total_us[k] += (double)ms * 1e3;
+        calls[k] += 1;
+    }
+    g_prof_recs.clear();
+    g_prof_used = 0;
+    return n;
+}
 
 namespace {
 
@@ -295,15 +401,13 @@ StreamPool* pool() {
 // one-workgroup-per-simulation solver adjoint runs; measured on MI355X/ROCm 7.2 it does NOT overlap
 // (39.8 ms vs 38.3 ms per step, eager and graph alike), so it is off.
 int pick_bww_chunk(int ms) {
-    int ch = 0;
-    if (const char* e = getenv("SOL_BWW_CHUNK")) ch = atoi(e);
+    int ch = sol_opt().bww_chunk;
     if (ch <= 0 || ch > ms) ch = ms;
     return ch;
 }
 
 int pick_chains(int B) {
-    int want = 1;   // measured on MI355X/ROCm 7.2: concurrent chains are SLOWER (57 -> 105..167 ms/step), see DESIGN.md
-    if (const char* e = getenv("SOL_STREAMS")) want = atoi(e);
+    int want = sol_opt().streams;   // default 1; measured on MI355X/ROCm 7.2: concurrent chains are SLOWER (57 -> 105..167 ms/step), see DESIGN.md
     if (want < 1) want = 1;
     if (want > 8) want = 8;
     while (B % want) --want;
@@ -320,8 +424,8 @@ struct TrainIO {
 // same predicate as `fuse` in run_chain (the reduce at the end must know the partial layout)
 bool train_fused(const sol_train_cfg* c, const Ws& w, int ms) {
     const sol_karman_cfg* kc = &c->karman;
-    return pick_bww_chunk(ms) == ms && kc->X == 64 && (kc->B * kc->Y) % 32 == 0 && sol_karman_bwd_fusable(kc) && !getenv("SOL_BWW_NO_FUSE") &&
-           !getenv("SOL_CONV_NO_SB") && !getenv("SOL_CONV_NO_FP16") && sol_bww_step_ws_floats(kc->B, kc->Y, 32) <= w.part_floats[1];
+    return pick_bww_chunk(ms) == ms && kc->X == 64 && (kc->B * kc->Y) % 32 == 0 && sol_karman_bwd_fusable(kc) && sol_opt().bww_fuse &&
+           sol_opt().conv_precision == 0 && sol_bww_step_ws_floats(kc->B, kc->Y, 32) <= w.part_floats[1];
 }
 
 // forward unroll + reverse sweep of the simulations [b0, b0 + c.karman.B) on stream hs
@@ -345,8 +449,8 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
     for (int l = 0; l < NL; ++l) { wn.wf[l] = shared.wf[l]; wn.wb[l] = shared.wb[l]; wn.bias[l] = shared.bias[l]; }
 
     // ---------------- forward unroll ----------------
-    const bool dens_inline = getenv("SOL_DENSITY_INLINE") != nullptr;
-    const bool dens_fused = !dens_inline && io.d_final && sol_karman_bwd_fusable(kc) && !getenv("SOL_DENSITY_NO_FUSE");
+    const bool dens_inline = sol_opt().density_mode == 1;
+    const bool dens_fused = !dens_inline && io.d_final && sol_karman_bwd_fusable(kc) && sol_opt().density_mode == 0;
     for (int i = 0; i < ms; ++i) {
         const float* din = i == 0 ? d0 : w.d + (size_t)(i - 1) * w.st_d;
         const float* vyin = i == 0 ? vy0 : w.vy + (size_t)(i - 1) * w.st_vy;
@@ -375,7 +479,7 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
             if (int e = net_forward(c, stream, wn, feat, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS, &corr)) return e;
         } else {
             if (int e = net_forward(c, stream, wn, feat, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS)) return e;
-            hipLaunchKernelGGL(k_correct_loss, dim3(egrid), dim3(256), 0, hs, vycur, vxcur, w.O,
+            SOL_LAUNCH(k_correct_loss, dim3(egrid), dim3(256), 0, hs, vycur, vxcur, w.O,
                                gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx,
                                c->std_v0, c->std_v1, io.loss_steps + i, B, Y, X);
             SOL_LAUNCH_CHECK();
@@ -407,11 +511,11 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
     const int CH = pick_bww_chunk(ms);
     // weight gradients of the 32 -> 32 layers ride in the solver-adjoint launches (see k_karman_bwd_bww): 32 rows per workgroup
     constexpr int FRB = 32;
-    const bool fuse = CH == ms && X == 64 && (B * Y) % FRB == 0 && sol_karman_bwd_fusable(kc) && !getenv("SOL_BWW_NO_FUSE") &&
-                      !getenv("SOL_CONV_NO_SB") && !getenv("SOL_CONV_NO_FP16") &&
+    const bool fuse = CH == ms && X == 64 && (B * Y) % FRB == 0 && sol_karman_bwd_fusable(kc) && sol_opt().bww_fuse &&
+                      sol_opt().conv_precision == 0 &&
                       sol_bww_step_ws_floats(B, Y, FRB) <= w.part_floats[1];
     const int wg_per = (B * Y) / FRB;
-    const bool use_side = CH < ms && pool()->ok && !getenv("SOL_BWW_NO_SIDE");
+    const bool use_side = CH < ms && pool()->ok && sol_opt().bww_side;
     hipStream_t side = pool()->s[7];
     bool side_used = false;
     for (int i = ms - 1; i >= 0; --i) {
@@ -420,7 +524,7 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         const float* vycur = w.vy + (size_t)i * w.st_vy;
         const float* vxcur = w.vx + (size_t)i * w.st_vx;
         float* dO2 = w.dO2 + (size_t)i * w.cells * 2;
-        hipLaunchKernelGGL(k_seed, dim3(egrid), dim3(256), 0, hs, gvy, gvx, vycur, vxcur,
+        SOL_LAUNCH(k_seed, dim3(egrid), dim3(256), 0, hs, gvy, gvx, vycur, vxcur,
                            gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx,
                            c->std_v0, c->std_v1, 1.f / (float)ms, w.dO4, dO2, i == ms - 1 ? 1 : 0, B, Y, X);
         SOL_LAUNCH_CHECK();
@@ -652,7 +756,7 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
             if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, amax, &corr)) return e;
         } else {
             if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, amax)) return e;
-            hipLaunchKernelGGL(k_correct_loss, dim3(egrid), dim3(256), 0, hs, tvy, tvx, w.O,
+            SOL_LAUNCH(k_correct_loss, dim3(egrid), dim3(256), 0, hs, tvy, tvx, w.O,
                                (const float*)nullptr, (const float*)nullptr, cfg->std_v0, cfg->std_v1, (float*)nullptr, B, Y, X);
             SOL_LAUNCH_CHECK();
         }
@@ -677,14 +781,14 @@ extern "C" int sol_adam_tf_step(void* stream, float* params, const float* grads,
         T.n = n_tensors;
         for (int k = 0; k <= n_tensors; ++k) T.off[k] = tensor_offsets[k];
         for (int k = 0; k < n_tensors; ++k) {
-            hipLaunchKernelGGL(k_tensor_scale, dim3(1), dim3(256), 0, hs, grads, scratch + k, T.off[k], T.off[k + 1] - T.off[k], clip_norm);
+            SOL_LAUNCH(k_tensor_scale, dim3(1), dim3(256), 0, hs, grads, scratch + k, T.off[k], T.off[k + 1] - T.off[k], clip_norm);
             SOL_LAUNCH_CHECK();
         }
         scale = scratch;
     }
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
     const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, hs, params, grads, m, v, n, (float)lr_t, beta1, beta2, eps, scale, T);
+    SOL_LAUNCH(k_adam, dim3(grid), dim3(256), 0, hs, params, grads, m, v, n, (float)lr_t, beta1, beta2, eps, scale, T);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }

@@ -52,17 +52,61 @@ def allreduce_sum_(flat, group=None):
     return flat
 
 
+class SolComm:
+    """RCCL communicator owned by libsol_hip.so (sol_comm_init / sol_allreduce_grads, include/sol_hip.h): the exchange
+    step of the path without torch in the data path.  The 128-byte unique id travels over the already initialised
+    torch.distributed group (any backend).  Must be created with this rank's device current."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        from . import _lib
+        self._lib, self._C = _lib, C
+        lib = _lib.load()
+        world = world_size(group)
+        rank = dist.get_rank(group) if world > 1 else 0
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(lib.sol_comm_unique_id(buf))
+        ids = [buf.raw]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self.handle = C.c_void_p()
+        _lib.check(lib.sol_comm_init(ids[0], world, rank, C.byref(self.handle)))
+        self.world, self.rank = world, rank
+
+    def allreduce_sum_(self, flat):
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+        self._lib.check(self._lib.load().sol_allreduce_grads(self.handle, self._lib.stream(), self._lib.ptr(flat), flat.numel()))
+        return flat
+
+    def close(self):
+        if self.handle:
+            self._lib.load().sol_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DPStep:
     """train step = local fwd_bwd -> all-reduce(SUM) grads (+ loss) -> identical optimizer
     update on every rank.  `fwd_bwd(*batch) -> (loss_tensor, flat_grads)`, `apply(grads, lr)`."""
 
-    def __init__(self, fwd_bwd, apply, group=None):
-        self.fwd_bwd, self.apply, self.group = fwd_bwd, apply, group
+    def __init__(self, fwd_bwd, apply, group=None, comm=None):
+        """comm: optional SolComm -- the gradient all-reduce then goes through sol_allreduce_grads (the library's own
+        RCCL communicator) instead of torch.distributed.all_reduce; both are RCCL on the GPU."""
+        self.fwd_bwd, self.apply, self.group, self.comm = fwd_bwd, apply, group, comm
 
     def __call__(self, *batch, lr):
         loss, grads = self.fwd_bwd(*batch)
         if world_size(self.group) > 1:
-            allreduce_sum_(grads, self.group)
+            if self.comm is not None:
+                self.comm.allreduce_sum_(grads)
+            else:
+                allreduce_sum_(grads, self.group)
             loss = loss.clone()
             allreduce_sum_(loss, self.group)
         self.apply(grads, lr)

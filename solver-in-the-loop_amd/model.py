@@ -60,6 +60,13 @@ class ConvNet:
         with torch.no_grad():
             self.params.copy_(torch.as_tensor(flat, device=self.params.device))
 
+    def clone(self):
+        """Independent copy (own parameter buffer) on the same device."""
+        other = type(self)(self.cin, self.cout, 0, self.params.device)
+        with torch.no_grad():
+            other.params.copy_(self.params)
+        return other
+
     def save(self, path):
         torch.save({"name": self.name, "cin": self.cin, "cout": self.cout,
                     "weights": [torch.as_tensor(w) for w in self.get_weights()]}, path)

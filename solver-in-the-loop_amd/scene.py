@@ -33,7 +33,34 @@ def write_zipped_array(filename, array):
         array = array[0, ...]
     if array.shape[-1] != 1:
         array = array[..., ::-1]
-    np.savez_compressed(filename, array)
+    # atomic: several processes (ranks of a data-parallel job, a second run on the same directory) may look at the
+    # same ds_*.npz path; a reader must never see a half-written archive
+    if not filename.endswith(".npz"):
+        filename += ".npz"
+    tmp = os.path.join(os.path.dirname(filename) or ".", ".tmp%d_%s" % (os.getpid(), os.path.basename(filename)))
+    np.savez_compressed(tmp, array)
+    os.replace(tmp, filename)
+
+
+def _dist_rank_world():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    return 0, 1
+
+
+def preprocess_on_rank0(work):
+    """Runs `work()` (the down-scaling pass that writes ds_*.npz next to the raw frames) on rank 0 only and makes
+    every other rank of a data-parallel job wait for it: all ranks share one dataset directory."""
+    rank, world = _dist_rank_world()
+    if rank == 0:
+        work()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
 
 
 def scene_dir(base, index):
@@ -113,13 +140,15 @@ class PhifDataset:
         self.numOfFrames = num_frames
         self.numOfSteps = num_frames
         if not skip_preprocessing and scale > 1:
-            self.printFn("Pre-processing: Loading data from {} = {} and save down-scaled data".format(dirpath, self.dataSims))
-            for j in range(len(self.dataSims)):
-                for i in range(num_frames):
-                    for paths, fn in ((self.pathsDen, downsample), (self.pathsVel, downsample_staggered)):
-                        dst = self.filenameToDownscaled(paths[j][i])
-                        if not os.path.isfile(dst):
-                            write_zipped_array(dst, fn(read_zipped_array(paths[j][i]), scale))
+            def work():
+                self.printFn("Pre-processing: Loading data from {} = {} and save down-scaled data".format(dirpath, self.dataSims))
+                for j in range(len(self.dataSims)):
+                    for i in range(num_frames):
+                        for paths, fn in ((self.pathsDen, downsample), (self.pathsVel, downsample_staggered)):
+                            dst = self.filenameToDownscaled(paths[j][i])
+                            if not os.path.isfile(dst):
+                                write_zipped_array(dst, fn(read_zipped_array(paths[j][i]), scale))
+            preprocess_on_rank0(work)
         name = self.filenameToDownscaled if scale > 1 else (lambda p: p)
         self.printFn("Preload: Loading data from {} = {}".format(dirpath, self.dataSims))
         self.dataPreloaded = {
@@ -183,10 +212,12 @@ class BurgersDataset(PhifDataset):
         self.numOfFrames = num_frames
         self.numOfSteps = num_frames
         if not skip_preprocessing and scale > 1:
-            for j in range(len(self.dataSims)):
-                for i in range(num_frames):
-                    for paths in (self.pathsVel, self.pathsFrc):
-                        write_zipped_array(self.filenameToDownscaled(paths[j][i]), downsample_staggered(read_zipped_array(paths[j][i]), scale))
+            def work():
+                for j in range(len(self.dataSims)):
+                    for i in range(num_frames):
+                        for paths in (self.pathsVel, self.pathsFrc):
+                            write_zipped_array(self.filenameToDownscaled(paths[j][i]), downsample_staggered(read_zipped_array(paths[j][i]), scale))
+            preprocess_on_rank0(work)
         name = self.filenameToDownscaled if scale > 1 else (lambda p: p)
         self.dataPreloaded = {
             s: [(read_zipped_array(name(self.pathsVel[j][i])).astype(np.float32),

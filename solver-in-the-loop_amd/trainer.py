@@ -23,9 +23,16 @@ from .dist import DPStep
 class SolTrainer:
     def __init__(self, net, masks, B, Y, X, msteps, dx, std_v, std_re, dt=1.0, res=None,
                  clip_grad=False, beta1=0.9, beta2=0.999, eps=1e-8, group=None, use_graph=True,
-                 cg_rtol=1e-6, cg_atol=1e-9, cg_max_iter=2000, grad_pad="replicate", inflow_order="after"):
+                 cg_rtol=1e-6, cg_atol=1e-9, cg_max_iter=2000, grad_pad="replicate", inflow_order="after",
+                 conv_precision="split", comm=None):
+        """conv_precision: arithmetic of the 32-channel convolutions (library option `conv_precision`):
+        "split" (default) fp32-equivalent fp16x3 / bf16x6 operand splits on the 16-bit matrix pipe, "bf16x6",
+        or "fp32" = strict fp32 MFMA.  The option is process wide in the library; every call of this trainer sets
+        it, so trainers of different precision can alternate in one process."""
         _lib.require_gpu()
         self.lib = _lib.load()
+        self.conv_precision = {"split": 0, "bf16x6": 1, "fp32": 2}[conv_precision]
+        _lib.set_option("conv_precision", self.conv_precision)
         assert net.name == "mars_moon", "the fused trainer implements model_mars_moon (the reference default)"
         self.net, self.masks = net, masks
         self.B, self.Y, self.X, self.msteps = B, Y, X, msteps
@@ -52,9 +59,12 @@ class SolTrainer:
         self.final = None
         self.use_graph = use_graph
         self._graph = None          # (key, handle): replayable hipGraph of the whole fwd+bwd
+        self._captures = 0          # graph (re)captures so far
+        self._stage = None          # internal input buffers, used once the caller's buffers turn out not to be persistent
         self._fin = None
         self._want_final = False
-        self._dp = DPStep(self._fwd_bwd_flat, self._apply_flat, group=group)
+        self._eager = False
+        self._dp = DPStep(self._fwd_bwd_flat, self._apply_flat, group=group, comm=comm)
 
     def __del__(self):
         try:
@@ -64,13 +74,22 @@ class SolTrainer:
             pass
 
     # ---- the two halves of a step -------------------------------------------------------
-    def fwd_bwd(self, d0, vy0, vx0, re, gt_vy, gt_vx, want_final=False):
+    def fwd_bwd(self, d0, vy0, vx0, re, gt_vy, gt_vx, want_final=False, eager=False):
         """Inputs: d0 [B,Y,X], vy0 [B,Y+1,X], vx0 [B,Y,X+1], re [B], gt_vy [msteps,B,Y+1,X],
         gt_vx [msteps,B,Y,X+1] (fp32 CUDA, contiguous).  Fills self.grads / self.loss_steps and
-        returns the scalar loss tensor (sum of per-step l2 losses / msteps, karman_train.py:436)."""
+        returns the scalar loss tensor (sum of per-step l2 losses / msteps, karman_train.py:436).
+        The hipGraph bakes the input pointers in: pass PERSISTENT buffers (copy new data into them) for zero-copy
+        replays.  Buffers that move are detected; after the third re-capture the trainer copies the inputs into
+        internal staging buffers instead (one D2D copy of the batch per step, ~20 MB at C3) and keeps one graph.
+        eager=True launches the kernels one by one (profiling, debugging) whatever use_graph says."""
         B, Y, X, ms = self.B, self.Y, self.X, self.msteps
         assert vy0.shape == (B, Y + 1, X) and vx0.shape == (B, Y, X + 1) and d0.shape == (B, Y, X)
         assert gt_vy.shape == (ms, B, Y + 1, X) and gt_vx.shape == (ms, B, Y, X + 1) and re.shape == (B,)
+        _lib.set_option("conv_precision", self.conv_precision)
+        if self._stage is not None and not eager:
+            for dst, src in zip(self._stage, (d0, vy0, vx0, re, gt_vy, gt_vx)):
+                dst.copy_(src)
+            d0, vy0, vx0, re, gt_vy, gt_vx = self._stage
         fin = [None, None, None]
         if want_final:
             if self._fin is None:
@@ -81,10 +100,16 @@ class SolTrainer:
                 ptr(mk.velBCy), ptr(mk.velBCyMask), mk.bc_stride, ptr(gt_vy), ptr(gt_vx),
                 ptr(self.workspace), self.workspace_bytes, ptr(self.grads), ptr(self.loss_steps),
                 ptr(fin[0]), ptr(fin[1]), ptr(fin[2]), ptr(self.iters_fwd), ptr(self.iters_bwd)]
-        if self.use_graph:
+        if self.use_graph and not eager:
             # all pointers are baked into the graph: re-capture only when a buffer moved
             key = tuple(a.value if isinstance(a, C.c_void_p) else a for a in args)
             if self._graph is None or self._graph[0] != key:
+                self._captures += 1
+                if self._captures == 4 and self._stage is None:
+                    # the caller passes fresh tensors every step: stop re-capturing (each capture is a device-wide
+                    # synchronisation + ~1000 node instantiations), stage the inputs instead
+                    self._stage = [t.clone() for t in (d0, vy0, vx0, re, gt_vy, gt_vx)]
+                    return self.fwd_bwd(d0, vy0, vx0, re, gt_vy, gt_vx, want_final=want_final)
                 if self._graph is not None:
                     check(self.lib.sol_train_graph_destroy(self._graph[1]))
                     self._graph = None
@@ -108,18 +133,19 @@ class SolTrainer:
 
     # ---- data-parallel composition --------------------------------------------------------
     def _fwd_bwd_flat(self, *batch):
-        loss = self.fwd_bwd(*batch, want_final=self._want_final)
+        loss = self.fwd_bwd(*batch, want_final=self._want_final, eager=self._eager)
         return loss, self.grads
 
     def _apply_flat(self, grads, lr):
         assert grads is self.grads
         self.apply_gradients(lr)
 
-    def train_step(self, d0, vy0, vx0, re, gt_vy, gt_vx, lr, want_final=False):
+    def train_step(self, d0, vy0, vx0, re, gt_vy, gt_vx, lr, want_final=False, eager=False):
         """One training step on this rank's shard; returns the GLOBAL loss tensor.  want_final=True also produces
         the state after the last unrolled step in self.final = [density, vy, vx] (this is what makes the engine
         advect the passive density at all: like the TF graph of the reference, nothing that no output needs is run)."""
         self._want_final = want_final
+        self._eager = eager
         return self._dp(d0, vy0, vx0, re, gt_vy, gt_vx, lr=lr)
 
     # ---- algorithmic traffic of the solver part (SURVEY.md section 8d) ---------------------

@@ -1,0 +1,54 @@
+"""Rank process of tests/test_gpu_parity.py::test_data_parallel_two_ranks_one_gpu (and of the CPU gloo test's GPU twin):
+SolTrainer under torch.distributed with world_size 2, both ranks on cuda:0 (RCCL refuses two ranks on one device, so the
+transport is gloo; the trainer, the shard arithmetic, the SUM all-reduce semantics and the replicated Adam update are
+the ones the RCCL path uses).  Usage: RANK/WORLD_SIZE/MASTER_* in the env, argv[1] = output .npz prefix."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import sol_amd                      # noqa: E402
+import sol_oracle as o              # noqa: E402
+from sol_amd import ops             # noqa: E402
+
+
+def problem(Bg, Y, X, ms):
+    """global batch of Bg simulations (float64 CPU tensors), identical on every rank"""
+    g = o.geometry(Y, X)
+    d, vy, vx = o.synthetic_state(Bg, Y, X, 1234)
+    re = torch.tensor([o.RE_TRAIN[i % 6] for i in range(Bg)], dtype=torch.float64)
+    gts = [o.synthetic_state(Bg, Y, X, 4321 + i, project_it=False) for i in range(ms)]
+    return g, d, vy, vx, re, torch.stack([s[1] for s in gts]), torch.stack([s[2] for s in gts])
+
+
+def run(Bg, Y, X, ms, rank, world, group=None, steps=2, lr=1e-4):
+    dev = "cuda:0"
+    g, d, vy, vx, re, gty, gtx = problem(Bg, Y, X, ms)
+    lo, hi = sol_amd.dist.shard_range(Bg, rank, world)
+    f = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+    mk = ops.SceneMasks(g.active, g.inflow, g.bc_mask, g.bc_mask, dev)
+    net = sol_amd.model_mars_moon(cin=3, cout=2, seed=0, device=dev)
+    tr = sol_amd.SolTrainer(net, mk, hi - lo, Y, X, ms, g.dx, (0.2, 0.25), o.STD_RE, group=group)
+    args = (f(d[lo:hi]), f(vy[lo:hi]), f(vx[lo:hi]), f(re[lo:hi]), f(gty[:, lo:hi]), f(gtx[:, lo:hi]))
+    losses, grads0 = [], None
+    for s in range(steps):
+        losses.append(float(tr.train_step(*args, lr=lr)))
+        if s == 0:
+            grads0 = tr.grads.detach().cpu().numpy().copy()       # after the all-reduce: the GLOBAL gradient
+    torch.cuda.synchronize()
+    return np.array(losses), grads0, net.params.detach().cpu().numpy()
+
+
+if __name__ == "__main__":
+    rank, world, _ = sol_amd.dist.init_from_env("gloo")
+    Bg, Y, X, ms = (int(v) for v in sys.argv[2:6])
+    losses, grads0, params = run(Bg, Y, X, ms, rank, world)
+    np.savez(sys.argv[1] + "_rank%d.npz" % rank, losses=losses, grads0=grads0, params=params)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()

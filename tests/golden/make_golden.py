@@ -82,7 +82,44 @@ def train_case(B=2, Y=16, X=8, ms=2):
                 vy_final=n(states[-1][1]), vx_final=n(states[-1][2]), d_final=n(states[-1][0]))
 
 
+def sol32_case(B=6, Y=128, X=64, ms=32, adam_steps=3, lr=1e-4):
+    """BASELINE.json configs[2] at its real depth: the workload bench.py times (oracle.bench_workload), one float64
+    forward + autograd backward per Adam step.  ~2 min per step on 8 cores.  Stored: the loss after 0..adam_steps-1
+    updates, and for the FIRST step the 32 per-step losses, per-tensor gradient norms, every 16th gradient element and
+    the final state (fp32).  Inputs are NOT stored (13 MB of ground-truth frames): the test regenerates them with the same
+    oracle call, which is deterministic to float64 rounding."""
+    import time
+    w = o.bench_workload(B, Y, X, ms)
+    params = [p.clone().requires_grad_(True) for p in w["params"]]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    out = {}
+    traj = []
+    for t in range(1, adam_steps + 1):
+        t0 = time.time()
+        loss, losses, states = o.unrolled_loss(params, w["d0"], w["vy0"], w["vx0"], w["re"], w["gt_vy"], w["gt_vx"], w["geom"],
+                                               w["std_v"], w["std_re"], return_states=True)
+        grads = torch.autograd.grad(loss, params)
+        traj.append(float(loss))
+        print("adam step %d: loss %.6f  (%.0f s)" % (t, float(loss), time.time() - t0), flush=True)
+        if t == 1:
+            n = lambda a: a.detach().numpy().astype(np.float32)
+            flat = np.concatenate([g.numpy().ravel() for g in grads])
+            out.update(loss_steps=np.array([float(l) for l in losses]), grad_norms=np.array([float(g.norm()) for g in grads]),
+                       grads_sub16=flat[::16].astype(np.float32), grad_l2=float(np.sqrt((flat * flat).sum())),
+                       vy_final=n(states[-1][1]), vx_final=n(states[-1][2]), d_final=n(states[-1][0]))
+        with torch.no_grad():
+            ps, m, v = o.adam_tf([p.detach() for p in params], list(grads), m, v, t, lr)
+        params = [p.clone().requires_grad_(True) for p in ps]
+        del loss, losses, states, grads
+    out.update(loss_traj=np.array(traj), lr=lr, B=B, Y=Y, X=X, msteps=ms)
+    return out
+
+
 if __name__ == "__main__":
+    if "--sol32" in sys.argv:          # the 6-minute fixture is generated on request only
+        np.savez_compressed(os.path.join(HERE, "train_128x64_sol32.npz"), **sol32_case())
+        sys.exit(0)
     np.savez_compressed(os.path.join(HERE, "karman_step_16x8.npz"), **step_case(2, 16, 8, 1234))
     np.savez_compressed(os.path.join(HERE, "karman_step_64x32.npz"), **step_case(3, 64, 32, 1234))
     np.savez_compressed(os.path.join(HERE, "karman_step_16x8_dirichlet_before.npz"),

@@ -529,3 +529,151 @@ def test_large_grid_forward_step_against_oracle():
     r1 = o.karman_step(d, vy, vx, re, g)
     assert rel(st.velocity.data[0].data.reshape(B, Y + 1, X), r1[1]) < TOL_FIELD
     assert rel(st.velocity.data[1].data.reshape(B, Y, X + 1), r1[2]) < TOL_FIELD
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs[2] at its real depth, through the hipGraph
+# ---------------------------------------------------------------------------------------------
+def test_sol32_bench_workload_against_golden(golden_dir):
+    """karman-2d 128x64, B=6, msteps=32 (the workload bench.py times) through the REPLAYED hipGraph: 32-step unroll, absmax
+    slot rotation, weight gradients batched over / fused into the 32 adjoint launches, density riding in the forward
+    launches -- against the float64 oracle fixture (tests/golden/make_golden.py --sol32): loss, the 32 per-step losses,
+    per-tensor gradient norms, every 16th gradient element, the final state, and the loss after each of 3 Adam steps at
+    lr 1e-4 (2386.489 -> 118279.49 -> 11700.69: the divergent trajectory the round-1 driver bench ran into)."""
+    z = np.load(os.path.join(golden_dir, "train_128x64_sol32.npz"))
+    B, Y, X, ms = int(z["B"]), int(z["Y"]), int(z["X"]), int(z["msteps"])
+    w = o.bench_workload(B, Y, X, ms)                         # inputs: regenerated (deterministic float64), not stored
+    net, tr = _trainer_from(w["params"], w["geom"], B, Y, X, ms, w["std_v"])
+    assert tr.use_graph and tr.masks.direct is not None
+    args = (f32(w["d0"]), f32(w["vy0"]), f32(w["vx0"]), f32(w["re"]), f32(torch.stack(w["gt_vy"])), f32(torch.stack(w["gt_vx"])))
+    traj = []
+    for t in range(len(z["loss_traj"])):
+        loss = tr.fwd_bwd(*args, want_final=True)
+        traj.append(float(loss))
+        if t == 0:
+            assert tr._graph is not None
+            assert np.allclose(tr.loss_steps.cpu().numpy(), z["loss_steps"], rtol=2e-5)
+            assert rel(tr.grads[::16], z["grads_sub16"]) < TOL_GRAD
+            assert abs(float(tr.grads.double().norm()) - float(z["grad_l2"])) < 1e-4 * float(z["grad_l2"])
+            norms = np.array([float(tr.grads[net.offsets[k]:net.offsets[k + 1]].double().norm()) for k in range(24)])
+            assert np.allclose(norms, z["grad_norms"], rtol=3e-4), np.abs(norms / z["grad_norms"] - 1).max()
+            assert rel(tr.final[1], z["vy_final"]) < TOL_FIELD and rel(tr.final[2], z["vx_final"]) < TOL_FIELD
+            assert rel(tr.final[0], z["d_final"]) < TOL_FIELD
+        tr.apply_gradients(float(z["lr"]))
+    assert tr._captures == 1                                  # one graph, replayed
+    assert np.allclose(traj, z["loss_traj"], rtol=5e-5), (traj, z["loss_traj"])
+
+
+# ---------------------------------------------------------------------------------------------
+# precision equivalence of the split-operand convolution
+# ---------------------------------------------------------------------------------------------
+def test_split_conv_error_not_worse_than_fp32_mfma():
+    """On the same inputs the fp16x3 split kernel (and the bf16x6 one) must not be less accurate than the strict fp32-MFMA
+    kernel, measured against a float64 convolution per CLASS of output elements (deciles of |reference|), not only in
+    relative L2 -- including an input whose left half is 1e-3 of its right half (small outputs next to large ones) and a
+    heavy-tailed one."""
+    from sol_amd import _lib
+    gen = torch.Generator().manual_seed(5)
+    B, Y, X = 2, 64, 64
+    cases = {"normal": torch.randn(B, Y, X, 32, generator=gen),
+             "heavy": torch.randn(B, Y, X, 32, generator=gen) * torch.exp(2.0 * torch.randn(B, Y, X, 32, generator=gen))}
+    mixed = torch.randn(B, Y, X, 32, generator=gen)
+    mixed[:, :, :32] *= 1e-3
+    cases["mixed_1e-3"] = mixed
+    w = (torch.randn(5, 5, 32, 32, generator=gen) * 0.05).float().to(DEV)
+    bias = torch.zeros(32, dtype=torch.float32, device=DEV)
+    packed = ops._pack(w, 32, 32, ops.CONV_FWD)
+    saved = _lib.get_option("conv_precision")
+    try:
+        for name, x in cases.items():
+            x = x.float().to(DEV)
+            ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), None, padding=2).permute(0, 2, 3, 1)
+            _lib.set_option("conv_precision", 0)
+            y_h = ops.conv5x5_scaled_raw(x, packed, bias, None, None, 32, ops.EPI_NONE, 0.3, ops.absmax_slots(x))   # fp16 x3
+            y_b = ops.conv5x5_raw(x, packed, bias, None, None, 32, ops.EPI_NONE, 0.3)                               # bf16 x6
+            _lib.set_option("conv_precision", 2)
+            y_f = ops.conv5x5_raw(x, packed, bias, None, None, 32, ops.EPI_NONE, 0.3)                               # fp32 MFMA
+            assert not torch.equal(y_f, y_h) and not torch.equal(y_f, y_b)          # three different kernels did run
+            order = ref.abs().reshape(-1).argsort()
+            n = order.numel()
+            for q in range(10):
+                idx = order[q * n // 10:(q + 1) * n // 10]
+                r = ref.reshape(-1)[idx]
+                e = {k: (v.double().reshape(-1)[idx] - r) for k, v in (("fp16x3", y_h), ("bf16x6", y_b), ("fp32", y_f))}
+                rms = {k: float(v.pow(2).mean().sqrt()) for k, v in e.items()}
+                mx = {k: float(v.abs().max()) for k, v in e.items()}
+                for k in ("fp16x3", "bf16x6"):
+                    assert rms[k] <= 1.5 * rms["fp32"], (name, q, k, rms)
+                    assert mx[k] <= 2.0 * mx["fp32"], (name, q, k, mx)
+            assert rel(y_h, ref) <= 1.5 * rel(y_f, ref) and rel(y_b, ref) <= 1.5 * rel(y_f, ref)
+    finally:
+        _lib.set_option("conv_precision", saved)
+
+
+def test_options_and_launch_profiler():
+    """sol_set_option / sol_get_option reject unknown names and out-of-range values; the launch profiler sees the kernels of
+    an eager training step with per-launch HIP events."""
+    from sol_amd import _lib
+    lib = sol_amd.load()
+    assert _lib.get_option("conv_precision") in (0, 1, 2)
+    with pytest.raises(sol_amd.SolError):
+        _lib.set_option("no_such_option", 1)
+    with pytest.raises(sol_amd.SolError):
+        _lib.set_option("conv_precision", 7)
+    B, Y, X, ms = 2, 128, 64, 2
+    g, d, vy, vx, re, gts, params, std_v, loss = _oracle_problem(B, Y, X, ms)
+    net, tr = _trainer_from(params, g, B, Y, X, ms, std_v)
+    args = (f32(d), f32(vy), f32(vx), f32(re), f32(torch.stack([s[1] for s in gts])), f32(torch.stack([s[2] for s in gts])))
+    with _lib.profile() as p:
+        hl = tr.fwd_bwd(*args, eager=True)
+    assert abs(float(hl) - float(loss)) < 1e-5 * abs(float(loss))
+    names = {k.strip("()"): v for k, v in p.kernels.items()}
+    assert names["k_conv5x5_sb<2, 2>"][0] == ms * (10 + 10)        # ten 32->32 layers, forward + backward-data, per unrolled step
+    assert all(c > 0 and t > 0 for c, t in names.values())
+    assert lib.sol_version() == _lib.ABI_VERSION
+
+
+# ---------------------------------------------------------------------------------------------
+# data parallel: two ranks, one device
+# ---------------------------------------------------------------------------------------------
+def test_data_parallel_two_ranks_one_gpu(tmp_path):
+    """SolTrainer with world_size 2 (both ranks on cuda:0, gloo transport: RCCL refuses two ranks per device) against
+    the single-process large batch: the all-reduced gradient equals the global-batch gradient, the loss is the global loss
+    and both replicas hold bit-identical weights after two Adam steps."""
+    import subprocess
+    import sys
+    import socket
+    import dp_worker
+    Bg, Y, X, ms = 4, 64, 32, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    prefix = str(tmp_path / "dp")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(os.path.dirname(__file__), "dp_worker.py"), prefix, str(Bg), str(Y), str(X), str(ms)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    r0, r1 = (np.load(prefix + "_rank%d.npz" % r) for r in range(2))
+    assert np.array_equal(r0["params"], r1["params"])               # replicas stay bit-identical
+    assert np.array_equal(r0["grads0"], r1["grads0"]) and np.array_equal(r0["losses"], r1["losses"])
+    losses, grads0, params = dp_worker.run(Bg, Y, X, ms, 0, 1)      # single process, global batch
+    assert np.allclose(r0["losses"], losses, rtol=2e-5)
+    assert rel(torch.as_tensor(r0["grads0"]), torch.as_tensor(grads0)) < 2e-5
+    assert rel(torch.as_tensor(r0["params"]), torch.as_tensor(params)) < 1e-5
+
+
+def test_library_rccl_communicator_single_rank():
+    """sol_comm_unique_id / sol_comm_init / sol_allreduce_grads / sol_comm_destroy (the library's own RCCL communicator)
+    with one rank: the plumbing the N-GPU path uses, as far as a 1-GPU box can exercise it (SUM over one rank = identity)."""
+    from sol_amd.dist import SolComm
+    comm = SolComm()
+    assert comm.world == 1 and comm.rank == 0
+    g = torch.randn(sol_amd.model_mars_moon(cin=3, cout=2, seed=0).n_params, device=DEV)
+    ref = g.clone()
+    comm.allreduce_sum_(g)
+    torch.cuda.synchronize()
+    assert torch.equal(g, ref)
+    comm.close()

@@ -1,11 +1,19 @@
 #!/usr/bin/env python
 """Mean counter value per (kernel, grid size) from a rocprofv3 --pmc run written with --output-format csv.
-Usage: python tools/pmc_summary.py <dir with *counter_collection.csv> [substring filter]"""
-import csv, glob, os, re, sys
+Usage: python tools/pmc_summary.py <dir with *counter_collection.csv> [substring filter] [--json out.json]
+--json writes {"kernels": {"<kernel>|<grid>": {"<counter>": mean, "dispatches": n}}} -- the file bench.py reads its
+roofline `traffic` from (profiles/r02_pmc_traffic.json); several runs (one counter each) merge into one file."""
+import csv, glob, json, os, re, sys
 from collections import defaultdict
 
-root = sys.argv[1]
-flt = sys.argv[2] if len(sys.argv) > 2 else ""
+argv = list(sys.argv[1:])
+jout = None
+if "--json" in argv:
+    k = argv.index("--json")
+    jout = argv[k + 1]
+    del argv[k:k + 2]
+root = argv[0]
+flt = argv[1] if len(argv) > 1 else ""
 acc = defaultdict(lambda: [0.0, 0])
 for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     with open(path) as f:
@@ -20,3 +28,15 @@ for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recur
             a[1] += 1
 for (name, grid, ctr), (s, n) in sorted(acc.items()):
     print("%-50s grid %-8s %-12s mean %12.1f over %d dispatches" % (name, grid, ctr, s / n, n))
+if jout:
+    tab = {"kernels": {}}
+    if os.path.exists(jout):
+        with open(jout) as f:
+            tab = json.load(f)
+    for (name, grid, ctr), (s, n) in sorted(acc.items()):
+        e = tab["kernels"].setdefault("%s|%s" % (name, grid), {})
+        e[ctr] = s / n
+        e["dispatches"] = n
+    tab["unit"] = "as reported by rocprofv3 (FETCH_SIZE / WRITE_SIZE: KB per dispatch; gfx950: FETCH_SIZE under-counts wide reads 2x)"
+    with open(jout, "w") as f:
+        json.dump(tab, f, indent=1, sort_keys=True)
