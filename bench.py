@@ -152,12 +152,12 @@ def timed_steps(wl, lr, steps, warmup, barrier, trainer=None):
 
 
 def profile_kernels(wl, lr, trainer=None):
-    """One EAGER training step with a pair of HIP events around every kernel launch (on the launch stream):
+    """One EAGER forward + reverse sweep with a pair of HIP events around every kernel launch (on the launch stream):
     {kernel: {"calls", "avg_us", "total_us"}}.  Same kernels, same order and same (cold) operands as the replayed graph."""
     from sol_amd import _lib
     tr = trainer or wl.trainer
-    with _lib.profile() as p:
-        tr.train_step(wl.d0, wl.vy0, wl.vx0, wl.re, wl.gt_vy, wl.gt_vx, lr, want_final=True, eager=True)
+    with _lib.profile() as p:          # forward + reverse sweep only: no collective (this runs on rank 0 alone), no optimizer update
+        tr.fwd_bwd(wl.d0, wl.vy0, wl.vx0, wl.re, wl.gt_vy, wl.gt_vx, want_final=True, eager=True)
     return {k.strip("()"): {"calls": c, "avg_us": t / max(c, 1), "total_us": t} for k, (c, t) in p.kernels.items()}
 
 
@@ -338,7 +338,7 @@ def main():
                                      "conv_fp32_equiv_TFLOPs_of_step": 3.0 * 520000.0 * N * B * ms / (ms_per_step * 1e-3) / 1e12},
             "data_parallel": dp,
         }
-        if not args.no_extras:
+        if not args.no_extras and world == 1:       # single-GPU extras (they train / roll out on rank 0 only: no collectives allowed here)
             # the same kernel with one simulation per CU (256 simulations): what the LDS-resident design delivers per chip
             try:
                 Bf = 256

@@ -105,6 +105,7 @@ struct SolOptions {
     int dbg_skip;         // timing experiments only
     int step_prof;        // debugging: synchronous phase times of the solver step kernels on stderr
     int cnn_persistent;   // 1: the 12 CNN layers of a pass as ONE cooperative launch where the shape allows it
+    int graph_stream;     // 1: sol_train_graph_launch replays on an internal stream fenced by events against the caller's stream
 };
 SolOptions& sol_opt();
 

@@ -35,7 +35,7 @@ SolOptions& sol_opt() {
         SolOptions d{};
         d.conv_precision = 0; d.conv_split3 = 0; d.conv_r3 = 1; d.conv_thin = 1; d.conv_bww32 = 1;
         d.correct_fuse = 1; d.bww_fuse = 1; d.bww_chunk = 0; d.bww_side = 1; d.streams = 1;
-        d.density_mode = 0; d.cpt = 0; d.dbg_skip = 0; d.step_prof = 0; d.cnn_persistent = 1;
+        d.density_mode = 0; d.cpt = 0; d.dbg_skip = 0; d.step_prof = 0; d.cnn_persistent = 1; d.graph_stream = 0;
         return d;
     }();
     return o;
@@ -50,6 +50,7 @@ const OptName OPT_NAMES[] = {
     {"bww_chunk", &SolOptions::bww_chunk, 0, 1024}, {"bww_side", &SolOptions::bww_side, 0, 1}, {"streams", &SolOptions::streams, 1, 8},
     {"density_mode", &SolOptions::density_mode, 0, 2}, {"cpt", &SolOptions::cpt, 0, 16}, {"dbg_skip", &SolOptions::dbg_skip, 0, 1 << 30},
     {"step_prof", &SolOptions::step_prof, 0, 1}, {"cnn_persistent", &SolOptions::cnn_persistent, 0, 1},
+    {"graph_stream", &SolOptions::graph_stream, 0, 1},
 };
 }  // namespace
 
@@ -202,6 +203,47 @@ __global__ void k_seed(float* __restrict__ gvy, float* __restrict__ gvx, const f
         }
     }
 }
+
+// ---- zero-fill / copy of several regions in ONE launch -------------------------------------------
+// The training graph contains NO memset / memcpy nodes: on ROCm 7.2 a replayed hipGraph whose memset nodes follow a
+// large device-to-host copy on the same stream filled with garbage instead of zeros (tools/debug_sol32c.py: identical
+// garbage losses on consecutive replays after a 200 KB .cpu() of a trainer buffer; eager hipMemsetAsync is fine).
+// Kernels are immune, and one launch replaces four to seven nodes.
+struct MemJobs {
+    uint32_t* dst[8];
+    const uint32_t* src[8];     // nullptr: fill with zero
+    size_t words[8];
+    int n;
+};
+__global__ void k_mem_jobs(MemJobs j) {
+    for (int k = 0; k < j.n; ++k) {
+        uint32_t* d = j.dst[k];
+        const uint32_t* s = j.src[k];
+        const size_t n = j.words[k];
+        const size_t n4 = (((uintptr_t)d | (uintptr_t)s) & 15) == 0 ? n / 4 : 0;      // 16-byte pieces when both are aligned
+        for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x)
+            reinterpret_cast<uint4*>(d)[e] = s ? reinterpret_cast<const uint4*>(s)[e] : make_uint4(0u, 0u, 0u, 0u);
+        for (size_t e = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+            d[e] = s ? s[e] : 0u;
+    }
+}
+struct MemList {
+    MemJobs j{};
+    void zero(void* p, size_t bytes) { copy(p, nullptr, bytes); }
+    void copy(void* d, const void* s, size_t bytes) {
+        if (!d || bytes == 0 || j.n >= 8) return;
+        j.dst[j.n] = static_cast<uint32_t*>(d); j.src[j.n] = static_cast<const uint32_t*>(s); j.words[j.n] = bytes / 4; ++j.n;
+    }
+    int launch(hipStream_t hs) {
+        if (j.n == 0) return SOL_OK;
+        size_t mx = 0;
+        for (int k = 0; k < j.n; ++k) mx = j.words[k] > mx ? j.words[k] : mx;
+        const int grid = (int)((mx / 4 + 255) / 256 < 1 ? 1 : ((mx / 4 + 255) / 256 > 512 ? 512 : (mx / 4 + 255) / 256));
+        SOL_LAUNCH(k_mem_jobs, dim3(grid), dim3(256), 0, hs, j);
+        SOL_LAUNCH_CHECK();
+        return SOL_OK;
+    }
+};
 
 __global__ void k_pad_bias(const float* __restrict__ params, float* __restrict__ biasp, int64_t boff, int cout) {
     const int t = threadIdx.x;
@@ -485,8 +527,9 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
             SOL_LAUNCH_CHECK();
         }
     }
+    MemList fin;
     if (dens_inline) {
-        if (io.d_final) SOL_HIP_CHECK(hipMemcpyAsync(io.d_final + (size_t)b0 * w.N, w.d + (size_t)(ms - 1) * w.st_d, w.st_d * sizeof(float), hipMemcpyDeviceToDevice, hs));
+        if (io.d_final) fin.copy(io.d_final + (size_t)b0 * w.N, w.d + (size_t)(ms - 1) * w.st_d, w.st_d * sizeof(float));
     } else if (dens_fused) {
         // steps 0 .. ms-2 were advected inside the solver launches; the last one has no launch to ride with
         const float* dprev = ms == 1 ? d0 : w.d + (size_t)(ms - 2) * w.st_d;
@@ -498,8 +541,9 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         if (int e = sol_density_chain(kc, stream, ms, d0, w.svy, w.svx, (long)w.st_vy, (long)w.st_vx, io.inflow, nullptr, (long)w.st_d,
                                       io.d_final + (size_t)b0 * w.N)) return e;
     }
-    if (io.vy_final) SOL_HIP_CHECK(hipMemcpyAsync(io.vy_final + (size_t)b0 * w.nVy, w.vy + (size_t)(ms - 1) * w.st_vy, w.st_vy * sizeof(float), hipMemcpyDeviceToDevice, hs));
-    if (io.vx_final) SOL_HIP_CHECK(hipMemcpyAsync(io.vx_final + (size_t)b0 * w.nVx, w.vx + (size_t)(ms - 1) * w.st_vx, w.st_vx * sizeof(float), hipMemcpyDeviceToDevice, hs));
+    if (io.vy_final) fin.copy(io.vy_final + (size_t)b0 * w.nVy, w.vy + (size_t)(ms - 1) * w.st_vy, w.st_vy * sizeof(float));
+    if (io.vx_final) fin.copy(io.vx_final + (size_t)b0 * w.nVx, w.vx + (size_t)(ms - 1) * w.st_vx, w.st_vx * sizeof(float));
+    if (int e = fin.launch(hs)) return e;
 
     // ---------------- reverse sweep ----------------
     // The weight gradients of the 32 unrolled steps are NOT computed step by step: every pre-activation
@@ -606,12 +650,16 @@ int train_fwd_bwd_impl(const sol_train_cfg* cfg, hipStream_t hs, const TrainIO& 
     if (S > 1 && !sp->ok) return sol_set_error(SOL_ERR_HIP, "could not create the internal HIP streams/events");
 
     if (int e = pack_all(cfg, hs, io.params, w[0], true)) return e;
-    SOL_HIP_CHECK(hipMemsetAsync(io.loss_steps, 0, ms * sizeof(float), hs));
     for (int k = 0; k < S; ++k) {
-        SOL_HIP_CHECK(hipMemsetAsync(w[k].dO4, 0, w[k].cells * 4 * sizeof(float), hs));
-        SOL_HIP_CHECK(hipMemsetAsync(w[k].amax_act, 0, 2 * w[k].amax_words * sizeof(uint32_t), hs));   // activation + gradient absmax slots
+        MemList z;
+        if (k == 0) {
+            z.zero(io.loss_steps, ms * sizeof(float));
+            z.zero(io.iters_bwd, B * sizeof(int32_t));                                 // step 0 needs no adjoint
+        }
+        z.zero(w[k].dO4, w[k].cells * 4 * sizeof(float));
+        z.zero(w[k].amax_act, 2 * w[k].amax_words * sizeof(uint32_t));                 // activation + gradient absmax slots
+        if (int e = z.launch(hs)) return e;
     }
-    if (io.iters_bwd) SOL_HIP_CHECK(hipMemsetAsync(io.iters_bwd, 0, B * sizeof(int32_t), hs));   // step 0 needs no adjoint
     if (S == 1) {
         if (int e = run_chain(&sub, w[0], w[0], B, 0, hs, io)) return e;
     } else {
@@ -707,7 +755,19 @@ extern "C" int sol_train_graph_create(const sol_train_cfg* cfg, const float* par
 
 extern "C" int sol_train_graph_launch(sol_train_graph* g, void* stream) {
     SOL_REQUIRE(g && g->exec, "sol_train_graph_launch: NULL graph");
-    SOL_HIP_CHECK(hipGraphLaunch(g->exec, (hipStream_t)stream));
+    hipStream_t s = (hipStream_t)stream;
+    if (sol_opt().graph_stream) {
+        // replay on an internal non-blocking stream, fenced against the caller's stream with two events
+        StreamPool* sp = pool();
+        SOL_REQUIRE(sp->ok, "internal streams unavailable");
+        SOL_HIP_CHECK(hipEventRecord(sp->fork, s));
+        SOL_HIP_CHECK(hipStreamWaitEvent(sp->s[6], sp->fork, 0));
+        SOL_HIP_CHECK(hipGraphLaunch(g->exec, sp->s[6]));
+        SOL_HIP_CHECK(hipEventRecord(sp->join[6], sp->s[6]));
+        SOL_HIP_CHECK(hipStreamWaitEvent(s, sp->join[6], 0));
+        return SOL_OK;
+    }
+    SOL_HIP_CHECK(hipGraphLaunch(g->exec, s));
     return SOL_OK;
 }
 
@@ -749,7 +809,11 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
         if (int e = sol_karman_step_fwd(kc, stream, sd, svy, svx, re, active, inflow, velBCy, velBCyMask, bc_batch_stride,
                                         td, tvy, tvx, nullptr, nullptr, w.feat, fscale,
                                         iters ? iters + (size_t)i * B : nullptr)) return e;
-        if (i % ROLLOUT_AMAX_SETS == 0) SOL_HIP_CHECK(hipMemsetAsync(w.amax_act, 0, w.amax_words * sizeof(uint32_t), hs));
+        if (i % ROLLOUT_AMAX_SETS == 0) {
+            MemList z;
+            z.zero(w.amax_act, w.amax_words * sizeof(uint32_t));
+            if (int e = z.launch(hs)) return e;
+        }
         uint32_t* amax = w.amax_act + (size_t)(i % ROLLOUT_AMAX_SETS) * 11 * SOL_AMAX_SLOTS;
         if (sol_conv_correct_fusable(X)) {
             const Correct corr{tvy, tvx, nullptr, nullptr, nullptr};
@@ -762,9 +826,11 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
         }
     }
     if (nsteps & 1) {
-        SOL_HIP_CHECK(hipMemcpyAsync(d, w.d, w.st_d * sizeof(float), hipMemcpyDeviceToDevice, hs));
-        SOL_HIP_CHECK(hipMemcpyAsync(vy, w.vy, w.st_vy * sizeof(float), hipMemcpyDeviceToDevice, hs));
-        SOL_HIP_CHECK(hipMemcpyAsync(vx, w.vx, w.st_vx * sizeof(float), hipMemcpyDeviceToDevice, hs));
+        MemList c;
+        c.copy(d, w.d, w.st_d * sizeof(float));
+        c.copy(vy, w.vy, w.st_vy * sizeof(float));
+        c.copy(vx, w.vx, w.st_vx * sizeof(float));
+        if (int e = c.launch(hs)) return e;
     }
     return SOL_OK;
 }

@@ -559,7 +559,12 @@ def test_sol32_bench_workload_against_golden(golden_dir):
             assert np.allclose(norms, z["grad_norms"], rtol=3e-4), np.abs(norms / z["grad_norms"] - 1).max()
             assert rel(tr.final[1], z["vy_final"]) < TOL_FIELD and rel(tr.final[2], z["vx_final"]) < TOL_FIELD
             assert rel(tr.final[0], z["d_final"]) < TOL_FIELD
+            # the first TF-Adam update in closed form: m = 0.1 g, v = 0.001 g^2, lr_t = lr sqrt(1 - 0.999) / (1 - 0.9)
+            g64, p64 = tr.grads.double(), net.params.detach().double()
+            expect = p64 - float(z["lr"]) * (1 - 0.999) ** 0.5 / (1 - 0.9) * 0.1 * g64 / ((0.001 * g64 * g64).sqrt() + 1e-8)
         tr.apply_gradients(float(z["lr"]))
+        if t == 0:
+            assert rel(net.params.detach(), expect) < 1e-6
     assert tr._captures == 1                                  # one graph, replayed
     assert np.allclose(traj, z["loss_traj"], rtol=5e-5), (traj, z["loss_traj"])
 
@@ -671,7 +676,7 @@ def test_library_rccl_communicator_single_rank():
     from sol_amd.dist import SolComm
     comm = SolComm()
     assert comm.world == 1 and comm.rank == 0
-    g = torch.randn(sol_amd.model_mars_moon(cin=3, cout=2, seed=0).n_params, device=DEV)
+    g = torch.randn(sol_amd.model_mars_moon(cin=3, cout=2, seed=0).n_params, device=DEV, dtype=torch.float32)
     ref = g.clone()
     comm.allreduce_sum_(g)
     torch.cuda.synchronize()
