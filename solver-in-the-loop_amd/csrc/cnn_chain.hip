@@ -1,0 +1,409 @@
+// The 32 -> 32 layers of one CNN pass (model_mars_moon, /root/reference/karman-2d/karman_train.py:101-138: ten 5x5 SAME
+// convolutions between the thin first and last layer; the reverse sweep's backward-data pass has the same shape) as ONE
+// launch.  One workgroup per CU keeps its three image rows in LDS from layer to layer; only the two halo rows above and
+// below cross workgroups, through global memory with one flag per (layer, workgroup):
+//
+//   producer  epilogue stores its three output rows WRITE-THROUGH (16-byte sc1 buffer stores: the tensors are needed in HBM
+//             anyway -- saved activations / pre-activation gradients); every wave drains (s_waitcnt vmcnt(0)) behind the FIRST
+//             tap step of the next layer, then ONE lane stores the flag (relaxed, agent scope);
+//   consumer  loads both neighbours' flags relaxed at the start of tap step 1, checks them at tap step 2 (spins only if a
+//             neighbour is late), reads the four halo rows with sc1 loads (L2 served; the producer's sc1 stores left no stale
+//             line behind), splits them during tap step 2.
+//   (MI355X_MICROARCH.md, inter-workgroup visibility; cdna_hip_programming.md guideline 16, form R1.)
+//
+// A layer's 15 (output row, tap row) pairs run own-rows-first: steps 0..2 need only the workgroup's own input rows
+// (row G0+s for all three tiles with tap row dy = 2+s-t), steps 3..4 the halo rows -- 4 us of MFMA work cover the
+// neighbours' publish + the halo fetch.  What a kernel boundary used to cost per layer (dispatch, write drain, prologue
+// round trips: ~5 us of a 13.5 us launch) is gone.
+//
+// Arithmetic: the fp16 three-product split of conv5x5_sb.hip (KIND 2) with the power-of-two operand scale taken per
+// image ROW instead of per tensor (a per-tensor maximum would be a grid-wide dependency between layers): every (tile, tap
+// row) pair accumulates into fresh accumulators that are folded in with the row's 2^-shift.  Never less accurate than the
+// per-tensor form.  Weight planes: the packed fp16 section (conv5x5_sb.hip k_pack_jobs), all five tap-row sets resident.
+#include "split_kernels.hpp"
+
+namespace {
+
+using namespace sbk;
+
+constexpr int CH_HWP = 68;                          // halo pixels per row
+constexpr int CH_PLANE = CH_HWP * 64;               // bytes per fp16 plane of a row
+constexpr int CH_SLOT = 2 * CH_PLANE;               // 8,704 B per row (hi + lo plane)
+constexpr int CH_WPL = 32 * 64;                     // bytes per (dx, plane) weight block
+constexpr int CH_WBUF = 5 * 2 * CH_WPL;             // 20,480 B per tap-row weight set
+constexpr int CH_W_OFF = 7 * CH_SLOT;               // 60,928
+constexpr int CH_MISC_OFF = CH_W_OFF + 5 * CH_WBUF; // 163,328
+constexpr int CH_LDS = CH_MISC_OFF + 128;           // 163,456 of 163,840
+constexpr int CH_SPIN_LIMIT = 1 << 17;
+// relative input row rr = row - (G0 - 2) in 0..6 -> LDS slot: the four halo rows first (contiguous: the epilogue's
+// transposition buffers alias them), then the own rows
+__device__ __forceinline__ int ch_slot(int rr) { return rr < 2 ? rr : (rr < 5 ? rr + 2 : rr - 3); }
+
+// misc words: [0..6] row max bits, [8] workgroup absmax, [9] wave ticket, [16..22] row 2^-shift (float)
+__device__ __forceinline__ void ch_scale(unsigned m, float& scale, float& inv) {
+    int e = (int)(m >> 23) - 127;
+    e = m == 0u ? 0 : min(max(e, -100), 100);
+    scale = __uint_as_float((unsigned)(14 - e + 127) << 23);
+    inv = __uint_as_float((unsigned)(e - 14 + 127) << 23);
+}
+__device__ __forceinline__ unsigned ch_max4(const float4& v) {
+    return __float_as_uint(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(768) k_cnn_chain(ChainArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_ch[];
+    unsigned char* const rows = smem_ch;
+    unsigned char* const wts = smem_ch + CH_W_OFF;
+    unsigned* const misc = reinterpret_cast<unsigned*>(smem_ch + CH_MISC_OFF);
+    float* const rowinv = reinterpret_cast<float*>(misc + 16);
+    const int tid = threadIdx.x, grp = tid >> 8, lane = tid & 63, wave = (tid >> 6) & 3;
+    const int g = lane >> 4, li = lane & 15;
+    const int H = a.H;
+    constexpr int W = 64;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int G0 = tile * 3, gy = G0 + grp;
+    const bool tvalid = gy < a.nrows;
+    const int b = (tvalid ? gy : 0) / H;
+    const int row_lo = b * H, row_hi = row_lo + H;
+    const bool has_up = tile > 0, has_dn = tile + 1 < a.ntiles;
+    const size_t tensor_bytes = (size_t)a.nrows * W * 32 * sizeof(float);
+    const int pcc = wave * 16 + li;
+
+    if (tid < 32) misc[tid] = 0u;
+
+    // ---- helpers -----------------------------------------------------------------------------
+    // item e in [0, 544): 4 channels (c4) of halo pixel hc of one row
+    auto item_off = [&](int gr, int e) -> int {          // byte offset inside a [rows][64][32] tensor, or -1 (zero fill)
+        const int hc = e >> 3, c4 = e & 7, xx = hc - 2;
+        if (gr < 0 || gr >= a.nrows || xx < 0 || xx >= W) return -1;
+        return ((gr * W + xx) * 8 + c4) * 16;
+    };
+    auto write_item = [&](int rr, int e, const float4& v, float sc) {
+        const int hc = e >> 3, c4 = e & 7;
+        unsigned p0[2], p1[2];
+        split2h(v.x, v.y, sc, p0[0], p1[0]);
+        split2h(v.z, v.w, sc, p0[1], p1[1]);
+        unsigned char* q = rows + ch_slot(rr) * CH_SLOT + hc * 64 + ((((c4 >> 1) ^ swzb(hc)) << 4) | ((c4 & 1) << 3));
+        *reinterpret_cast<uint2*>(q) = make_uint2(p0[0], p0[1]);
+        *reinterpret_cast<uint2*>(q + CH_PLANE) = make_uint2(p1[0], p1[1]);
+    };
+    constexpr int WV = CH_WBUF / 16;                  // 1280 uint4 per set
+    auto load_wset = [&](const uint4* gw, int dy, uint4 (&v)[2]) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int e = tid + n * 768;
+            v[n] = e < WV ? gw[(size_t)dy * WV + e] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_wset = [&](int dy, const uint4 (&v)[2]) {
+        uint4* dst = reinterpret_cast<uint4*>(wts + dy * CH_WBUF);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int e = tid + n * 768;
+            if (e < WV) dst[e] = v[n];
+        }
+    };
+
+    f32x4 total[2];
+    // one (tile, tap row) pair: 5 taps x 3 split products x 2 column tiles, folded into `total` with the row's 2^-shift
+    auto do_step = [&](int dy, int rr) {
+        const int src = G0 - 2 + rr;                  // input row
+        if (!(tvalid && src >= row_lo && src < row_hi)) return;     // wave uniform
+        const unsigned char* hrow = rows + ch_slot(rr) * CH_SLOT;
+        const unsigned char* wbuf = wts + dy * CH_WBUF;
+        f32x4 acc[2], acl[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) { acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; acl[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        uint4 ao[2][2], bo[2][2][2];
+        auto load_ops = [&](int dx, uint4 (&ar)[2], uint4 (&br)[2][2]) {
+            const int hc = pcc + dx;
+            const unsigned char* ap = hrow + hc * 64 + ((g ^ swzb(hc)) << 4);
+            ar[0] = *reinterpret_cast<const uint4*>(ap);
+            ar[1] = *reinterpret_cast<const uint4*>(ap + CH_PLANE);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int co = n * 16 + li;
+                const unsigned char* bp = wbuf + dx * 2 * CH_WPL + co * 64 + ((g ^ swzb(co)) << 4);
+                br[n][0] = *reinterpret_cast<const uint4*>(bp);
+                br[n][1] = *reinterpret_cast<const uint4*>(bp + CH_WPL);
+            }
+        };
+        load_ops(0, ao[0], bo[0]);
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+            if (dx < 4) load_ops(dx + 1, ao[(dx + 1) & 1], bo[(dx + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const f16x8 a1 = __builtin_bit_cast(f16x8, ao[dx & 1][0]), a2 = __builtin_bit_cast(f16x8, ao[dx & 1][1]);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const f16x8 b1 = __builtin_bit_cast(f16x8, bo[dx & 1][n][0]), b2 = __builtin_bit_cast(f16x8, bo[dx & 1][n][1]);
+                acl[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, acl[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, acc[n], 0, 0, 0);
+                acl[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, acl[n], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float ri = rowinv[rr];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) total[n][r] += (acc[n][r] + acl[n][r] * (1.f / 2048.f)) * ri;
+    };
+
+    // ---- chain prologue: the seven input rows of the first layer (written by an earlier launch: plain loads) and its
+    //      weight sets 0..3 ----
+    __syncthreads();                                  // misc zeroed
+    {
+        const float4* gx = reinterpret_cast<const float4*>(a.x0);
+        float4 hv[5];
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+            const int e = tid + n * 768;
+            hv[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < 7 * 544) {
+                const int rr = e / 544, off = item_off(G0 - 2 + rr, e - rr * 544);
+                if (off >= 0) hv[n] = gx[off >> 4];
+            }
+        }
+        const uint4* gw0 = reinterpret_cast<const uint4*>(a.L[0].wsh) + 1;
+        uint4 wv[2][2];
+        load_wset(gw0, 0, wv[0]);
+        load_wset(gw0, 1, wv[1]);
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+            const int e = tid + n * 768;
+            if (e < 7 * 544) atomicMax(&misc[e / 544], ch_max4(hv[n]));
+        }
+        store_wset(0, wv[0]);
+        store_wset(1, wv[1]);
+        load_wset(gw0, 2, wv[0]);
+        load_wset(gw0, 3, wv[1]);
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+            const int e = tid + n * 768;
+            if (e < 7 * 544) {
+                const int rr = e / 544;
+                float sc, inv;
+                ch_scale(misc[rr], sc, inv);
+                write_item(rr, e - rr * 544, hv[n], sc);
+                if (e - rr * 544 == 0) rowinv[rr] = inv;
+            }
+        }
+        store_wset(2, wv[0]);
+        store_wset(3, wv[1]);
+        __syncthreads();
+    }
+
+#pragma unroll 1
+    for (int l = 0; l < a.nl; ++l) {
+        const ChainLayer L = a.L[l];
+        const bool more = l + 1 < a.nl;
+        const uint4* gw = reinterpret_cast<const uint4*>(L.wsh) + 1;
+        const uint4* gwn = more ? reinterpret_cast<const uint4*>(a.L[l + 1].wsh) + 1 : gw;
+        const float winv = reinterpret_cast<const float*>(L.wsh)[1];
+        unsigned* fl_prev = l > 0 ? a.flags + (size_t)(l - 1) * a.ntiles : nullptr;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) total[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        unsigned fu = 1u, fd = 1u;
+        float4 pres[2], pact[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) { pres[n] = make_float4(0.f, 0.f, 0.f, 0.f); pact[n] = make_float4(1.f, 1.f, 1.f, 1.f); }
+        // Five tap steps.  Steps 0..2: all three tiles read the own row G0+s (tap row dy = 2+s-t); steps 3, 4: the halo rows.
+        // One rolled loop (one copy of the MFMA body; the staging registers `stg` serve a different load in every step):
+        //   s   loads issued before the MFMAs                    stored / done after them
+        //   0   this layer's weight set 4                        set 4; drain; barrier; publish the PREVIOUS layer's flag
+        //   1   the neighbours' flags (relaxed)                  barrier
+        //   2   [flags checked] the four halo rows (sc1)         row maxima; barrier; split + stage the halo rows; barrier
+        //   3   next layer's set 2; residual / act reference     set 2; barrier
+        //   4   next layer's sets 1 and 3                        sets 1, 3; barrier
+        // (next layer's set 0 follows in the epilogue: it is the last one this layer reads.)
+#pragma unroll 1
+        for (int s = 0; s < 5; ++s) {
+            uint4 stg[4];
+            if (s == 0) {
+                load_wset(gw, 4, reinterpret_cast<uint4(&)[2]>(stg[0]));
+            } else if (s == 1) {
+                if (l > 0) {
+                    if (has_up) fu = __hip_atomic_load(&fl_prev[tile - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (has_dn) fd = __hip_atomic_load(&fl_prev[tile + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else if (s == 2) {
+                if (l > 0) {
+                    unsigned spins = 0;
+                    while (!(__builtin_amdgcn_readfirstlane(fu) && __builtin_amdgcn_readfirstlane(fd))) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (has_up) fu = __hip_atomic_load(&fl_prev[tile - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (has_dn) fd = __hip_atomic_load(&fl_prev[tile + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (++spins > CH_SPIN_LIMIT) {        // a neighbour never arrived (not resident?): flag the launch and go on
+                            if (lane == 0) atomicOr(a.err, 1u);
+                            break;
+                        }
+                    }
+                    // the producer stored write-through (sc1) and drained before the flag: sc1 loads read fresh data
+                    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.L[l - 1].y), 0, (int)tensor_bytes, 0x00020000);
+#pragma unroll
+                    for (int n = 0; n < 3; ++n) {
+                        const int e = tid + n * 768;
+                        stg[n] = make_uint4(0u, 0u, 0u, 0u);
+                        if (e < 4 * 544) {
+                            const int k = e / 544, rr = k < 2 ? k : k + 3, off = item_off(G0 - 2 + rr, e - k * 544);
+                            if (off >= 0) stg[n] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 16));
+                        }
+                    }
+                }
+            } else if (s == 3) {
+                if (more) load_wset(gwn, 2, reinterpret_cast<uint4(&)[2]>(stg[0]));
+                if (tvalid) {
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const int e = lane + n * 64, px = e >> 3, c4 = e & 7;
+                        const size_t o4 = ((size_t)gy * W + wave * 16 + px) * 8 + c4;
+                        if (L.res) pres[n] = reinterpret_cast<const float4*>(L.res)[o4];
+                        if (L.epi == SOL_EPI_DLRELU) pact[n] = reinterpret_cast<const float4*>(L.act)[o4];
+                    }
+                }
+            } else {
+                if (more) { load_wset(gwn, 1, reinterpret_cast<uint4(&)[2]>(stg[0])); load_wset(gwn, 3, reinterpret_cast<uint4(&)[2]>(stg[2])); }
+            }
+
+            int dy, rr;
+            if (s < 3) { dy = 2 + s - grp; rr = 2 + s; }
+            else if (s == 3) { dy = grp == 0 ? 1 : (grp == 1 ? 4 : 3); rr = grp == 0 ? 1 : 5; }
+            else { dy = grp == 2 ? 4 : 0; rr = grp == 0 ? 0 : (grp == 1 ? 1 : 6); }
+            do_step(dy, rr);
+
+            if (s == 0) {
+                store_wset(4, reinterpret_cast<uint4(&)[2]>(stg[0]));
+                if (tid == 0) {      // bookkeeping words of this layer (last read before the previous layer's final barrier)
+                    misc[0] = 0u; misc[1] = 0u; misc[5] = 0u; misc[6] = 0u;      // halo row maxima
+                    misc[2] = 0u; misc[3] = 0u; misc[4] = 0u;                    // own (output) row maxima
+                    misc[8] = 0u; misc[9] = 0u;                                  // per-tensor absmax, wave ticket
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every wave: the previous layer's output stores have landed
+                __syncthreads();
+                if (l > 0 && tid == 0) __hip_atomic_store(&fl_prev[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (s == 2) {
+                if (l > 0) {
+#pragma unroll
+                    for (int n = 0; n < 3; ++n) {
+                        const int e = tid + n * 768;
+                        if (e < 4 * 544) { const int k = e / 544; atomicMax(&misc[k < 2 ? k : k + 3], ch_max4(__builtin_bit_cast(float4, stg[n]))); }
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int n = 0; n < 3; ++n) {
+                        const int e = tid + n * 768;
+                        if (e < 4 * 544) {
+                            const int k = e / 544, r2 = k < 2 ? k : k + 3;
+                            float sc, inv;
+                            ch_scale(misc[r2], sc, inv);
+                            write_item(r2, e - k * 544, __builtin_bit_cast(float4, stg[n]), sc);
+                            if (e - k * 544 == 0) rowinv[r2] = inv;
+                        }
+                    }
+                }
+                __syncthreads();
+            } else {
+                if (s == 3 && more) store_wset(2, reinterpret_cast<uint4(&)[2]>(stg[0]));
+                if (s == 4 && more) { store_wset(1, reinterpret_cast<uint4(&)[2]>(stg[0])); store_wset(3, reinterpret_cast<uint4(&)[2]>(stg[2])); }
+                __syncthreads();
+            }
+        }
+        // ---------------- epilogue ----------------------------------------------------------------------
+        {
+            uint4 wv[2];
+            if (more) load_wset(gwn, 0, wv);
+            float* tb = reinterpret_cast<float*>(rows) + (grp * 4 + wave) * (16 * 32);      // aliases the (dead) halo slots
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const float bias = L.bias ? L.bias[n * 16 + li] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tb[(4 * g + r) * 32 + n * 16 + li] = total[n][r] * winv + bias;
+            }
+            float4 v[2];
+            float vmax = 0.f;
+            const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(L.y, 0, (int)tensor_bytes, 0x00020000);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int e = lane + n * 64, px = e >> 3, c4 = e & 7;
+                float4 q = *reinterpret_cast<const float4*>(&tb[px * 32 + c4 * 4]);      // same-wave LDS round trip
+                q.x += pres[n].x; q.y += pres[n].y; q.z += pres[n].z; q.w += pres[n].w;
+                if (L.epi == SOL_EPI_LRELU) {
+                    q.x = q.x > 0.f ? q.x : a.slope * q.x; q.y = q.y > 0.f ? q.y : a.slope * q.y;
+                    q.z = q.z > 0.f ? q.z : a.slope * q.z; q.w = q.w > 0.f ? q.w : a.slope * q.w;
+                } else if (L.epi == SOL_EPI_DLRELU) {
+                    q.x *= pact[n].x > 0.f ? 1.f : a.slope; q.y *= pact[n].y > 0.f ? 1.f : a.slope;
+                    q.z *= pact[n].z > 0.f ? 1.f : a.slope; q.w *= pact[n].w > 0.f ? 1.f : a.slope;
+                }
+                v[n] = q;
+                vmax = fmaxf(vmax, __uint_as_float(ch_max4(q)));
+                if (tvalid) {
+                    const int off = (((gy * W) + wave * 16 + px) * 8 + c4) * 16;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q), rout, off, 0, 16);       // write-through
+                }
+            }
+            float rm = vmax;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) rm = fmaxf(rm, __shfl_xor(rm, off, 64));
+            if (lane == 0) atomicMax(&misc[2 + grp], __float_as_uint(rm));
+            if (L.ymax) amax_publish_last(tvalid ? vmax : 0.f, L.ymax, misc + 8);
+            if (more) store_wset(0, wv);
+            __syncthreads();
+            if (more) {          // own rows of the next layer's input: split in place with the row's scale
+                float sc, inv;
+                ch_scale(misc[2 + grp], sc, inv);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int e = lane + n * 64, px = e >> 3, c4 = e & 7;
+                    write_item(2 + grp, (wave * 16 + px + 2) * 8 + c4, tvalid ? v[n] : make_float4(0.f, 0.f, 0.f, 0.f), sc);
+                }
+                if ((tid & 255) == 0) rowinv[2 + grp] = inv;
+                __syncthreads();
+            }
+        }
+    }
+}
+
+int init_chain_kernel() {
+    static int rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k_cnn_chain), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                        ? SOL_OK : sol_set_error(SOL_ERR_HIP, "hipFuncSetAttribute(k_cnn_chain) failed");
+    return rc;
+}
+
+int chain_cus() {
+    static int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return cus;
+    }();
+    return n;
+}
+
+}  // namespace
+
+// one workgroup per CU, all co-resident: the chain needs ceil(B*H/3) <= #CUs
+bool sol_cnn_chain_usable(int B, int H, int W) {
+    if (!sol_opt().cnn_persistent || sol_opt().conv_precision != 0 || W != 64) return false;
+    const int ntiles = (B * H + 2) / 3;
+    return ntiles >= 2 && ntiles <= chain_cus();
+}
+
+size_t sol_cnn_chain_flag_words(int B, int H, int nl) { return (size_t)nl * ((B * H + 2) / 3) + 64; }
+
+// flags: sol_cnn_chain_flag_words() zeroed words (the last 64: error word); layers: nl descriptors
+int sol_cnn_chain_launch(hipStream_t s, const ChainLayer* layers, int nl, const float* x0, unsigned* flags, int B, int H, int W, float slope) {
+    SOL_REQUIRE(layers && nl >= 1 && nl <= SOL_CHAIN_MAXL && x0 && flags && sol_cnn_chain_usable(B, H, W), "sol_cnn_chain_launch: bad arguments");
+    if (int e = init_chain_kernel()) return e;
+    ChainArgs a{};
+    for (int l = 0; l < nl; ++l) a.L[l] = layers[l];
+    a.nl = nl; a.x0 = x0; a.flags = flags; a.B = B; a.H = H; a.nrows = B * H; a.ntiles = (B * H + 2) / 3; a.slope = slope;
+    a.err = flags + (size_t)nl * a.ntiles;
+    SOL_LAUNCH(k_cnn_chain, dim3(a.ntiles), dim3(768), (size_t)CH_LDS, s, a);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}

@@ -58,6 +58,31 @@ struct BwArgs {
     long xmax_seg, zmax_seg;      // ... and their strides (uint32 words) between consecutive segments
 };
 int sol_bww_sb_launch(hipStream_t s, const BwArgs& a, int nblk_run);
+// ---- persistent chain of 32 -> 32 layers (cnn_chain.hip) ----
+constexpr int SOL_CHAIN_MAXL = 12;
+struct ChainLayer {
+    const void* wsh;        // fp16 section of the packed weights: header {2^shift, 2^-shift, 0, 0} + planes [dy][dx][2][32 co][64 B]
+    const float* bias;      // [32] or NULL
+    const float* res;       // residual tensor [rows][64][32] or NULL
+    const float* act;       // activation reference (SOL_EPI_DLRELU) or NULL
+    float* y;               // output [rows][64][32]
+    unsigned* ymax;         // per-tensor absmax slots (consumed by the weight-gradient kernels and the thin last layer) or NULL
+    int epi;
+};
+struct ChainArgs {
+    ChainLayer L[SOL_CHAIN_MAXL];
+    int nl;
+    const float* x0;        // input of the first layer
+    unsigned* flags;        // [nl][ntiles], zero at launch
+    unsigned* err;          // |= 1 when a neighbour's flag never arrived
+    int B, H, nrows, ntiles;
+    float slope;
+};
+bool sol_cnn_chain_usable(int B, int H, int W);
+size_t sol_cnn_chain_flag_words(int B, int H, int nl);
+int sol_cnn_chain_launch(hipStream_t s, const ChainLayer* layers, int nl, const float* x0, unsigned* flags, int B, int H, int W, float slope);
+// fp16 section of a packed 32-input-channel weight buffer (sol_conv5x5_packed_floats layout)
+const void* sol_conv_packed_wsh(const float* packed, int cout);
 int sol_karman_step_bwd_fused(const sol_karman_cfg* cfg, void* stream,
                               const float* saved_vy, const float* saved_vx, const float* re, const float* active,
                               const float* velBCyMask, int64_t bc_batch_stride,

@@ -1065,6 +1065,10 @@ extern "C" int sol_conv5x5(void* stream, const float* x, const float* packed, co
     return conv_impl(stream, x, packed, bias, residual, act_ref, y, B, H, W, cin, cout, epilogue, slope, nullptr, nullptr);
 }
 
+const void* sol_conv_packed_wsh(const float* packed, int cout) {
+    return packed + (size_t)25 * 32 * pad_out(cout) + sol_conv_sb_packed_floats(pad_out(cout));
+}
+
 bool sol_conv_correct_fusable(int W) {
     return sol_opt().conv_precision == 0 && sol_opt().correct_fuse && W % 64 == 0;
 }

@@ -299,6 +299,8 @@ struct Ws {
     float *dzb;                    // [msteps][11][cells][32]: pre-activation gradients kept for the batched weight gradient
     uint32_t *amax_act, *amax_dz;  // [msteps][11][SOL_AMAX_SLOTS]: absmax slots of every 32-channel activation / gradient tensor
     size_t amax_words;             // (both arrays are contiguous: one memset per training step)
+    uint32_t* chain_flags;         // [msteps (or ROLLOUT_AMAX_SETS)][2 passes][chain_words]: hand-off flags of the persistent CNN launches
+    size_t chain_words;            // words per chain launch (0: chain not usable for this shape)
     float *gvy[2], *gvx[2];
     float *wf[NL], *wb[NL], *bias[NL];
     float *part[NL];
@@ -330,6 +332,8 @@ size_t carve_ws(const sol_train_cfg* c, float* base, Ws& w, bool training) {
     w.amax_words = (size_t)(training ? ms : ROLLOUT_AMAX_SETS) * 11 * SOL_AMAX_SLOTS;
     w.amax_act = reinterpret_cast<uint32_t*>(take(w.amax_words));
     w.amax_dz = reinterpret_cast<uint32_t*>(take(training ? w.amax_words : 0));
+    w.chain_words = sol_cnn_chain_flag_words(B, Y, 10);      // carved whatever the options say: the workspace size must not depend on them
+    w.chain_flags = reinterpret_cast<uint32_t*>(take((size_t)(training ? ms : ROLLOUT_AMAX_SETS) * 2 * w.chain_words));
     for (int k = 0; k < 2; ++k) { w.gvy[k] = take(w.st_vy); w.gvx[k] = take(w.st_vx); }
     for (int l = 0; l < NL; ++l) {
         const int cin = layer_cin(l), cout = layer_cout(l);
@@ -364,11 +368,21 @@ int pack_all(const sol_train_cfg* /*c*/, void* stream, const float* params, Ws& 
 // 32-channel consumer derives its fp16 operand scale from it (sol_conv5x5_scaled).
 // corr != nullptr: the last layer applies its output to the velocity and accumulates the loss (sol_conv5x5_correct) instead of storing O
 struct Correct { float *vy, *vx; const float *gt_vy, *gt_vx; float* loss; };
-int net_forward(const sol_train_cfg* c, void* s, const Ws& w, const float* feat, float* const* act, float* O, uint32_t* amax, const Correct* corr = nullptr) {
+int net_forward(const sol_train_cfg* c, void* s, const Ws& w, const float* feat, float* const* act, float* O, uint32_t* amax, const Correct* corr = nullptr,
+                uint32_t* chain_flags = nullptr) {
     const int B = c->karman.B, Y = c->karman.Y, X = c->karman.X;
     const float sl = c->lrelu_slope;
     auto am = [&](int k) { return amax ? amax + (size_t)k * SOL_AMAX_SLOTS : nullptr; };
     if (int e = sol_conv5x5_scaled(s, feat, w.wf[0], w.bias[0], nullptr, nullptr, act[0], B, Y, X, 4, 32, SOL_EPI_LRELU, sl, nullptr, am(0))) return e;
+    if (amax && chain_flags && sol_cnn_chain_usable(B, Y, X)) {
+        // layers 1..10 as ONE persistent launch (cnn_chain.hip)
+        ChainLayer L[10];
+        for (int k = 0; k < 5; ++k) {
+            L[2 * k] = ChainLayer{sol_conv_packed_wsh(w.wf[1 + 2 * k], 32), w.bias[1 + 2 * k], nullptr, nullptr, act[1 + 2 * k], am(1 + 2 * k), SOL_EPI_LRELU};
+            L[2 * k + 1] = ChainLayer{sol_conv_packed_wsh(w.wf[2 + 2 * k], 32), w.bias[2 + 2 * k], act[2 * k], nullptr, act[2 + 2 * k], am(2 + 2 * k), SOL_EPI_LRELU};
+        }
+        if (int e = sol_cnn_chain_launch((hipStream_t)s, L, 10, act[0], chain_flags, B, Y, X, sl)) return e;
+    } else
     for (int k = 0; k < 5; ++k) {
         const float* h = act[2 * k];
         if (int e = sol_conv5x5_scaled(s, h, w.wf[1 + 2 * k], w.bias[1 + 2 * k], nullptr, nullptr, act[1 + 2 * k], B, Y, X, 32, 32, SOL_EPI_LRELU, sl,
@@ -518,9 +532,9 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         for (int k = 0; k < 11; ++k) act[k] = w.acts + ((size_t)i * 11 + k) * w.cells * 32;
         if (sol_conv_correct_fusable(X)) {            // correction + loss ride in the epilogue of the last CNN layer
             const Correct corr{vycur, vxcur, gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx, io.loss_steps + i};
-            if (int e = net_forward(c, stream, wn, feat, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS, &corr)) return e;
+            if (int e = net_forward(c, stream, wn, feat, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS, &corr, w.chain_flags + (size_t)(2 * i) * w.chain_words)) return e;
         } else {
-            if (int e = net_forward(c, stream, wn, feat, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS)) return e;
+            if (int e = net_forward(c, stream, wn, feat, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS, nullptr, w.chain_flags + (size_t)(2 * i) * w.chain_words)) return e;
             SOL_LAUNCH(k_correct_loss, dim3(egrid), dim3(256), 0, hs, vycur, vxcur, w.O,
                                gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx,
                                c->std_v0, c->std_v1, io.loss_steps + i, B, Y, X);
@@ -581,6 +595,15 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         uint32_t* amd = w.amax_dz + (size_t)i * 11 * SOL_AMAX_SLOTS;
         auto am = [&](int k) { return amd + (size_t)k * SOL_AMAX_SLOTS; };
         if (int e = sol_conv5x5_scaled(stream, w.dO4, wn.wb[11], nullptr, nullptr, act[10], D[10], B, Y, X, 4, 32, SOL_EPI_DLRELU, sl, nullptr, am(10))) return e;
+        if (sol_cnn_chain_usable(B, Y, X)) {
+            // the ten backward-data convolutions as ONE persistent launch
+            ChainLayer L[10];
+            for (int k = 4, n = 0; k >= 0; --k) {
+                L[n++] = ChainLayer{sol_conv_packed_wsh(wn.wb[2 + 2 * k], 32), nullptr, nullptr, act[1 + 2 * k], D[1 + 2 * k], am(1 + 2 * k), SOL_EPI_DLRELU};
+                L[n++] = ChainLayer{sol_conv_packed_wsh(wn.wb[1 + 2 * k], 32), nullptr, D[2 + 2 * k], act[2 * k], D[2 * k], am(2 * k), SOL_EPI_DLRELU};
+            }
+            if (int e = sol_cnn_chain_launch(hs, L, 10, D[10], w.chain_flags + (size_t)(2 * i + 1) * w.chain_words, B, Y, X, sl)) return e;
+        } else
         for (int k = 4; k >= 0; --k) {
             const float* h = act[2 * k];
             const float* a = act[1 + 2 * k];
@@ -658,6 +681,7 @@ int train_fwd_bwd_impl(const sol_train_cfg* cfg, hipStream_t hs, const TrainIO& 
         }
         z.zero(w[k].dO4, w[k].cells * 4 * sizeof(float));
         z.zero(w[k].amax_act, 2 * w[k].amax_words * sizeof(uint32_t));                 // activation + gradient absmax slots
+        z.zero(w[k].chain_flags, (size_t)ms * 2 * w[k].chain_words * sizeof(uint32_t)); // hand-off flags of the persistent CNN launches
         if (int e = z.launch(hs)) return e;
     }
     if (S == 1) {
@@ -811,15 +835,16 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
                                         iters ? iters + (size_t)i * B : nullptr)) return e;
         if (i % ROLLOUT_AMAX_SETS == 0) {
             MemList z;
+            z.zero(w.chain_flags, (size_t)ROLLOUT_AMAX_SETS * 2 * w.chain_words * sizeof(uint32_t));
             z.zero(w.amax_act, w.amax_words * sizeof(uint32_t));
             if (int e = z.launch(hs)) return e;
         }
         uint32_t* amax = w.amax_act + (size_t)(i % ROLLOUT_AMAX_SETS) * 11 * SOL_AMAX_SLOTS;
         if (sol_conv_correct_fusable(X)) {
             const Correct corr{tvy, tvx, nullptr, nullptr, nullptr};
-            if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, amax, &corr)) return e;
+            if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, amax, &corr, w.chain_flags + (size_t)(2 * (i % ROLLOUT_AMAX_SETS)) * w.chain_words)) return e;
         } else {
-            if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, amax)) return e;
+            if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, amax, nullptr, w.chain_flags + (size_t)(2 * (i % ROLLOUT_AMAX_SETS)) * w.chain_words)) return e;
             SOL_LAUNCH(k_correct_loss, dim3(egrid), dim3(256), 0, hs, tvy, tvx, w.O,
                                (const float*)nullptr, (const float*)nullptr, cfg->std_v0, cfg->std_v1, (float*)nullptr, B, Y, X);
             SOL_LAUNCH_CHECK();
