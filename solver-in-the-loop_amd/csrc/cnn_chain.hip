@@ -51,6 +51,45 @@ __device__ __forceinline__ unsigned ch_max4(const float4& v) {
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// Row maximum of staged items: the 64 consecutive items of a wave lie in at most TWO rows (544 items per row), so two
+// wave reductions and two LDS atomics per wave replace 64 same-address atomics (which the LDS serialises lane by lane:
+// 36 instructions x 64 lanes were 1.1 us per layer).  m = bits of this lane's max (0 for lanes without an item), k = its row.
+// wave maximum of non-negative float bit patterns with DPP row operations (__shfl_xor goes through the LDS crossbar: six
+// dependent ds_bpermute round trips per reduction cost more than the whole split of a halo row)
+template <int CTRL, int ROWMASK = 0xf>
+__device__ __forceinline__ unsigned ch_dpp(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, true);
+}
+__device__ __forceinline__ unsigned ch_wave_max(unsigned v) {
+    v = max(v, ch_dpp<0xB1>(v));          // quad_perm [1,0,3,2]
+    v = max(v, ch_dpp<0x4E>(v));          // quad_perm [2,3,0,1]
+    v = max(v, ch_dpp<0x141>(v));         // row_half_mirror
+    v = max(v, ch_dpp<0x140>(v));         // row_mirror: every lane holds its row-of-16 maximum
+    v = max(v, ch_dpp<0x142, 0xa>(v));    // row_bcast:15
+    v = max(v, ch_dpp<0x143, 0xc>(v));    // row_bcast:31: lane 63 holds the wave maximum
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ void ch_rowmax_publish(unsigned m, int k, unsigned* rowmax_words, const int* slot_of_k, int lane) {
+    const int k0 = __builtin_amdgcn_readfirstlane(k);
+    const unsigned a = ch_wave_max(k == k0 ? m : 0u), b = ch_wave_max(k == k0 ? 0u : m);
+    if (lane == 0) {
+        atomicMax(&rowmax_words[slot_of_k[k0]], a);
+        if (b) atomicMax(&rowmax_words[slot_of_k[k0 + 1]], b);
+    }
+}
+// Loop-invariant-code-motion fence: address arithmetic derived from the returned value is recomputed where it is used
+// instead of being hoisted out of the layer loop and kept (spilled) across the MFMA steps.
+__device__ __forceinline__ int ch_opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+
+// -DSOL_CHAIN_PROF (tools/chain_phase_probe.py builds such a library next to the product one): 100 MHz s_memrealtime stamps
+// of thread 0 of every workgroup, 8 per layer: layer start, after each of the five tap steps, stores issued, layer end.
+#ifdef SOL_CHAIN_PROF
+__device__ long long* g_chain_prof = nullptr;
+extern "C" int sol_chain_prof_set(long long* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_chain_prof), &buf, sizeof(buf)) == hipSuccess ? 0 : -1; }
+#define SOL_CHSTAMP(l, k) do { if (threadIdx.x == 0 && g_chain_prof) g_chain_prof[((size_t)blockIdx.x * SOL_CHAIN_MAXL + (l)) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SOL_CHSTAMP(l, k) do { } while (0)
+#endif
 
 __global__ void __launch_bounds__(768) k_cnn_chain(ChainArgs a) {
     extern __shared__ __align__(16) unsigned char smem_ch[];
@@ -89,15 +128,34 @@ __global__ void __launch_bounds__(768) k_cnn_chain(ChainArgs a) {
         *reinterpret_cast<uint2*>(q) = make_uint2(p0[0], p0[1]);
         *reinterpret_cast<uint2*>(q + CH_PLANE) = make_uint2(p1[0], p1[1]);
     };
+#ifndef SOL_CHAIN_NO_DMA
+    constexpr bool CH_DMA = true;                     // weight sets by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write
+#else
+    constexpr bool CH_DMA = false;
+#endif
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    typedef __attribute__((address_space(1))) const void glb_cvoid_t;
+    // set `dy` of `gw` -> weight slot `dy`: 20 chunks of 1 KB (64 lanes x 16 B, already in LDS image order), two per wave at most;
+    // completion is tracked by vmcnt: the step ends with s_waitcnt vmcnt(0) before its barrier
+    auto dma_wset = [&](int tidv, const uint4* gw, int dy) {
+        const int wv = tidv >> 6, ln = tidv & 63;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int c = wv + 12 * n;
+            if (c < 20)
+                __builtin_amdgcn_global_load_lds((glb_cvoid_t*)(gw + (size_t)dy * (CH_WBUF / 16) + c * 64 + ln),
+                                                 (lds_void_t*)(wts + dy * CH_WBUF + c * 1024), 16, 0, 0);
+        }
+    };
     constexpr int WV = CH_WBUF / 16;                  // 1280 uint4 per set
-    auto load_wset = [&](const uint4* gw, int dy, uint4 (&v)[2]) {
+    auto load_wset = [&](int tid, const uint4* gw, int dy, uint4 (&v)[2]) {
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int e = tid + n * 768;
             v[n] = e < WV ? gw[(size_t)dy * WV + e] : make_uint4(0, 0, 0, 0);
         }
     };
-    auto store_wset = [&](int dy, const uint4 (&v)[2]) {
+    auto store_wset = [&](int tid, int dy, const uint4 (&v)[2]) {
         uint4* dst = reinterpret_cast<uint4*>(wts + dy * CH_WBUF);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
@@ -169,17 +227,21 @@ __global__ void __launch_bounds__(768) k_cnn_chain(ChainArgs a) {
         }
         const uint4* gw0 = reinterpret_cast<const uint4*>(a.L[0].wsh) + 1;
         uint4 wv[2][2];
-        load_wset(gw0, 0, wv[0]);
-        load_wset(gw0, 1, wv[1]);
+        load_wset(tid, gw0, 0, wv[0]);
+        load_wset(tid, gw0, 1, wv[1]);
+        {
+            const int all_rr[8] = {0, 1, 2, 3, 4, 5, 6, 6};
 #pragma unroll
-        for (int n = 0; n < 5; ++n) {
-            const int e = tid + n * 768;
-            if (e < 7 * 544) atomicMax(&misc[e / 544], ch_max4(hv[n]));
+            for (int n = 0; n < 5; ++n) {
+                const int e = tid + n * 768;
+                const bool in = e < 7 * 544;
+                ch_rowmax_publish(in ? ch_max4(hv[n]) : 0u, in ? e / 544 : 6, misc, all_rr, lane);
+            }
         }
-        store_wset(0, wv[0]);
-        store_wset(1, wv[1]);
-        load_wset(gw0, 2, wv[0]);
-        load_wset(gw0, 3, wv[1]);
+        store_wset(tid, 0, wv[0]);
+        store_wset(tid, 1, wv[1]);
+        load_wset(tid, gw0, 2, wv[0]);
+        load_wset(tid, gw0, 3, wv[1]);
         __syncthreads();
 #pragma unroll
         for (int n = 0; n < 5; ++n) {
@@ -192,11 +254,16 @@ __global__ void __launch_bounds__(768) k_cnn_chain(ChainArgs a) {
                 if (e - rr * 544 == 0) rowinv[rr] = inv;
             }
         }
-        store_wset(2, wv[0]);
-        store_wset(3, wv[1]);
+        store_wset(tid, 2, wv[0]);
+        store_wset(tid, 3, wv[1]);
         __syncthreads();
     }
 
+    // Barriers inside the layer loop wait for LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() also
+    // waits for every global load / store in flight, which would serialise the prefetches (weights, flags, halo rows,
+    // epilogue operands) and the write-through output stores with the MFMA steps they are meant to hide behind.
+#define CH_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    uint4 stg[4];                                     // staging registers: a different load in every step (see the table below)
 #pragma unroll 1
     for (int l = 0; l < a.nl; ++l) {
         const ChainLayer L = a.L[l];
@@ -205,69 +272,72 @@ __global__ void __launch_bounds__(768) k_cnn_chain(ChainArgs a) {
         const uint4* gwn = more ? reinterpret_cast<const uint4*>(a.L[l + 1].wsh) + 1 : gw;
         const float winv = reinterpret_cast<const float*>(L.wsh)[1];
         unsigned* fl_prev = l > 0 ? a.flags + (size_t)(l - 1) * a.ntiles : nullptr;
+        unsigned* rm_prev = l > 0 ? a.rowmax + (size_t)(l - 1) * a.nrows : nullptr;     // row maxima the producers published with layer l-1
 #pragma unroll
         for (int n = 0; n < 2; ++n) total[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
+        SOL_CHSTAMP(l, 0);
         unsigned fu = 1u, fd = 1u;
+        bool halo_pending = l > 0;                    // the four halo rows still have to be fetched (uniform)
         float4 pres[2], pact[2];
 #pragma unroll
         for (int n = 0; n < 2; ++n) { pres[n] = make_float4(0.f, 0.f, 0.f, 0.f); pact[n] = make_float4(1.f, 1.f, 1.f, 1.f); }
+        // always TWO loads (an edge tile reads its one neighbour twice): the count the step-0 wait below relies on
+        auto flags_load = [&]() {
+            fu = __hip_atomic_load(&fl_prev[has_up ? tile - 1 : tile + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fd = __hip_atomic_load(&fl_prev[has_dn ? tile + 1 : tile - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto flags_ready = [&]() { return __builtin_amdgcn_readfirstlane(fu) != 0u && __builtin_amdgcn_readfirstlane(fd) != 0u; };
+        // the producer stored write-through (sc1) and drained before its flag: sc1 loads (L1 bypassed) read fresh data
+        unsigned hmax[3];                             // row maximum (bits) of this lane's three halo items
+        auto halo_issue = [&](int tidv) {
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const int e = tidv + n * 768, k = min(e / 544, 3), gr = G0 - 2 + (k < 2 ? k : k + 3);
+                hmax[n] = (gr >= 0 && gr < a.nrows) ? __hip_atomic_load(&rm_prev[gr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            }
+            const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.L[l - 1].y), 0, (int)tensor_bytes, 0x00020000);
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const int e = tidv + n * 768;
+                stg[n] = make_uint4(0u, 0u, 0u, 0u);
+                if (e < 4 * 544) {
+                    const int k = e / 544, rr = k < 2 ? k : k + 3, off = item_off(G0 - 2 + rr, e - k * 544);
+                    if (off >= 0) stg[n] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 16));
+                }
+            }
+        };
         // Five tap steps.  Steps 0..2: all three tiles read the own row G0+s (tap row dy = 2+s-t); steps 3, 4: the halo rows.
-        // One rolled loop (one copy of the MFMA body; the staging registers `stg` serve a different load in every step):
-        //   s   loads issued before the MFMAs                    stored / done after them
-        //   0   this layer's weight set 4                        set 4; drain; barrier; publish the PREVIOUS layer's flag
-        //   1   the neighbours' flags (relaxed)                  barrier
-        //   2   [flags checked] the four halo rows (sc1)         row maxima; barrier; split + stage the halo rows; barrier
-        //   3   next layer's set 2; residual / act reference     set 2; barrier
-        //   4   next layer's sets 1 and 3                        sets 1, 3; barrier
+        // One rolled loop (one copy of the MFMA body):
+        //   s   loads issued before the MFMAs                    after them
+        //   0   this layer's weight set 4; neighbours' flags     set 4 staged
+        //   1   --                                               flags ready -> the four halo rows are requested (sc1)
+        //   2   --                                               [late neighbour: wait, request] row maxima; barrier; split + stage them
+        //   3   next layer's set 2; residual / act reference     set 2 staged
+        //   4   next layer's sets 1 and 3                        sets 1, 3 staged
         // (next layer's set 0 follows in the epilogue: it is the last one this layer reads.)
 #pragma unroll 1
         for (int s = 0; s < 5; ++s) {
-            uint4 stg[4];
+            const int tids = ch_opaque(tid);          // staging addresses of this step: recomputed here, not carried across the MFMAs
             if (s == 0) {
-                load_wset(gw, 4, reinterpret_cast<uint4(&)[2]>(stg[0]));
-            } else if (s == 1) {
-                if (l > 0) {
-                    if (has_up) fu = __hip_atomic_load(&fl_prev[tile - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (has_dn) fd = __hip_atomic_load(&fl_prev[tile + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            } else if (s == 2) {
-                if (l > 0) {
-                    unsigned spins = 0;
-                    while (!(__builtin_amdgcn_readfirstlane(fu) && __builtin_amdgcn_readfirstlane(fd))) {
-                        __builtin_amdgcn_s_sleep(4);
-                        if (has_up) fu = __hip_atomic_load(&fl_prev[tile - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (has_dn) fd = __hip_atomic_load(&fl_prev[tile + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (++spins > CH_SPIN_LIMIT) {        // a neighbour never arrived (not resident?): flag the launch and go on
-                            if (lane == 0) atomicOr(a.err, 1u);
-                            break;
-                        }
-                    }
-                    // the producer stored write-through (sc1) and drained before the flag: sc1 loads read fresh data
-                    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.L[l - 1].y), 0, (int)tensor_bytes, 0x00020000);
-#pragma unroll
-                    for (int n = 0; n < 3; ++n) {
-                        const int e = tid + n * 768;
-                        stg[n] = make_uint4(0u, 0u, 0u, 0u);
-                        if (e < 4 * 544) {
-                            const int k = e / 544, rr = k < 2 ? k : k + 3, off = item_off(G0 - 2 + rr, e - k * 544);
-                            if (off >= 0) stg[n] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 16));
-                        }
-                    }
-                }
+                if (CH_DMA) dma_wset(tids, gw, 4);
+                else load_wset(tids, gw, 4, reinterpret_cast<uint4(&)[2]>(stg[0]));
+                if (l > 0) flags_load();
             } else if (s == 3) {
-                if (more) load_wset(gwn, 2, reinterpret_cast<uint4(&)[2]>(stg[0]));
+                if (more) { if (CH_DMA) dma_wset(tids, gwn, 2); else load_wset(tids, gwn, 2, reinterpret_cast<uint4(&)[2]>(stg[0])); }
                 if (tvalid) {
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
-                        const int e = lane + n * 64, px = e >> 3, c4 = e & 7;
-                        const size_t o4 = ((size_t)gy * W + wave * 16 + px) * 8 + c4;
+                        const int e = (tids & 63) + n * 64, px = e >> 3, c4 = e & 7;
+                        const size_t o4 = ((size_t)(G0 + (tids >> 8)) * W + ((tids >> 6) & 3) * 16 + px) * 8 + c4;
                         if (L.res) pres[n] = reinterpret_cast<const float4*>(L.res)[o4];
                         if (L.epi == SOL_EPI_DLRELU) pact[n] = reinterpret_cast<const float4*>(L.act)[o4];
                     }
                 }
-            } else {
-                if (more) { load_wset(gwn, 1, reinterpret_cast<uint4(&)[2]>(stg[0])); load_wset(gwn, 3, reinterpret_cast<uint4(&)[2]>(stg[2])); }
+            } else if (s == 4) {
+                if (more) {
+                    if (CH_DMA) { dma_wset(tids, gwn, 1); dma_wset(tids, gwn, 3); }
+                    else { load_wset(tids, gwn, 1, reinterpret_cast<uint4(&)[2]>(stg[0])); load_wset(tids, gwn, 3, reinterpret_cast<uint4(&)[2]>(stg[2])); }
+                }
             }
 
             int dy, rr;
@@ -276,47 +346,63 @@ __global__ void __launch_bounds__(768) k_cnn_chain(ChainArgs a) {
             else { dy = grp == 2 ? 4 : 0; rr = grp == 0 ? 0 : (grp == 1 ? 1 : 6); }
             do_step(dy, rr);
 
+            const int tidp = ch_opaque(tid);
+            // the step's LDS-DMA (issued before the MFMAs) has landed; waited BEFORE any halo request goes out.  In step 0 the
+            // two flag loads were issued AFTER the DMA and stay in flight (a flag comes from memory: ~2.5 us): vmcnt(2)
+            if (CH_DMA && s == 0) { if (l > 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            if (CH_DMA && s >= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (s == 0) {
-                store_wset(4, reinterpret_cast<uint4(&)[2]>(stg[0]));
+                if (!CH_DMA) store_wset(tidp, 4, reinterpret_cast<uint4(&)[2]>(stg[0]));
                 if (tid == 0) {      // bookkeeping words of this layer (last read before the previous layer's final barrier)
                     misc[0] = 0u; misc[1] = 0u; misc[5] = 0u; misc[6] = 0u;      // halo row maxima
                     misc[2] = 0u; misc[3] = 0u; misc[4] = 0u;                    // own (output) row maxima
-                    misc[8] = 0u; misc[9] = 0u;                                  // per-tensor absmax, wave ticket
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every wave: the previous layer's output stores have landed
-                __syncthreads();
-                if (l > 0 && tid == 0) __hip_atomic_store(&fl_prev[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (s == 1) {
+                if (halo_pending) {
+                    if (flags_ready()) { halo_issue(tidp); halo_pending = false; }
+                    else flags_load();                                            // try again after the next step
+                }
             } else if (s == 2) {
                 if (l > 0) {
-#pragma unroll
-                    for (int n = 0; n < 3; ++n) {
-                        const int e = tid + n * 768;
-                        if (e < 4 * 544) { const int k = e / 544; atomicMax(&misc[k < 2 ? k : k + 3], ch_max4(__builtin_bit_cast(float4, stg[n]))); }
+                    if (halo_pending) {                                           // a neighbour is late: wait here
+                        unsigned spins = 0;
+                        while (!flags_ready()) {
+                            __builtin_amdgcn_s_sleep(2);
+                            flags_load();
+                            if (++spins > CH_SPIN_LIMIT) {        // never arrived (not resident?): flag the launch and go on
+                                if (lane == 0) atomicOr(a.err, 1u);
+                                break;
+                            }
+                        }
+                        halo_issue(tidp);
+                        halo_pending = false;
                     }
-                    __syncthreads();
+                    const int tidq = ch_opaque(tid);
 #pragma unroll
                     for (int n = 0; n < 3; ++n) {
-                        const int e = tid + n * 768;
+                        const int e = tidq + n * 768;
                         if (e < 4 * 544) {
                             const int k = e / 544, r2 = k < 2 ? k : k + 3;
                             float sc, inv;
-                            ch_scale(misc[r2], sc, inv);
+                            ch_scale(hmax[n], sc, inv);
                             write_item(r2, e - k * 544, __builtin_bit_cast(float4, stg[n]), sc);
                             if (e - k * 544 == 0) rowinv[r2] = inv;
                         }
                     }
                 }
-                __syncthreads();
+            } else if (s == 3) {
+                if (more && !CH_DMA) store_wset(tidp, 2, reinterpret_cast<uint4(&)[2]>(stg[0]));
             } else {
-                if (s == 3 && more) store_wset(2, reinterpret_cast<uint4(&)[2]>(stg[0]));
-                if (s == 4 && more) { store_wset(1, reinterpret_cast<uint4(&)[2]>(stg[0])); store_wset(3, reinterpret_cast<uint4(&)[2]>(stg[2])); }
-                __syncthreads();
+                if (more && !CH_DMA) { store_wset(tidp, 1, reinterpret_cast<uint4(&)[2]>(stg[0])); store_wset(tidp, 3, reinterpret_cast<uint4(&)[2]>(stg[2])); }
             }
+            if (s != 0) CH_BARRIER();      // step 0 stages only weight set 4 (read from step 2 on): the barrier after step 1 covers it
+            SOL_CHSTAMP(l, 1 + s);
         }
         // ---------------- epilogue ----------------------------------------------------------------------
         {
-            uint4 wv[2];
-            if (more) load_wset(gwn, 0, wv);
+            const int tide = ch_opaque(tid);
+            const int lane = tide & 63, wave = (tide >> 6) & 3, grp = tide >> 8, g = lane >> 4, li = lane & 15, gy = G0 + grp;
+            if (more) { if (CH_DMA) dma_wset(tide, gwn, 0); else load_wset(tide, gwn, 0, reinterpret_cast<uint4(&)[2]>(stg[0])); }
             float* tb = reinterpret_cast<float*>(rows) + (grp * 4 + wave) * (16 * 32);      // aliases the (dead) halo slots
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
@@ -346,13 +432,15 @@ __global__ void __launch_bounds__(768) k_cnn_chain(ChainArgs a) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q), rout, off, 0, 16);       // write-through
                 }
             }
-            float rm = vmax;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) rm = fmaxf(rm, __shfl_xor(rm, off, 64));
-            if (lane == 0) atomicMax(&misc[2 + grp], __float_as_uint(rm));
-            if (L.ymax) amax_publish_last(tvalid ? vmax : 0.f, L.ymax, misc + 8);
-            if (more) store_wset(0, wv);
-            __syncthreads();
+            const unsigned rm = ch_wave_max(tvalid ? __float_as_uint(vmax) : 0u);
+            if (lane == 0) atomicMax(&misc[2 + grp], rm);
+            if (more && !CH_DMA) store_wset(tide, 0, reinterpret_cast<uint4(&)[2]>(stg[0]));
+            SOL_CHSTAMP(l, 6);
+            CH_BARRIER();
+            // per-tensor absmax (consumed by the weight-gradient kernels and the thin last layer): one atomic per workgroup
+            if (tid == 0 && L.ymax) atomicMax(&L.ymax[blockIdx.x & (SOL_AMAX_SLOTS - 1)], max(max(misc[2], misc[3]), misc[4]));
+            if (more && tvalid && (tide & 255) == 0)        // the row's maximum travels with the row (write-through, drained before the flag)
+                __hip_atomic_store(&a.rowmax[(size_t)l * a.nrows + gy], misc[2 + grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (more) {          // own rows of the next layer's input: split in place with the row's scale
                 float sc, inv;
                 ch_scale(misc[2 + grp], sc, inv);
@@ -361,11 +449,16 @@ __global__ void __launch_bounds__(768) k_cnn_chain(ChainArgs a) {
                     const int e = lane + n * 64, px = e >> 3, c4 = e & 7;
                     write_item(2 + grp, (wave * 16 + px + 2) * 8 + c4, tvalid ? v[n] : make_float4(0.f, 0.f, 0.f, 0.f), sc);
                 }
-                if ((tid & 255) == 0) rowinv[2 + grp] = inv;
-                __syncthreads();
+                if ((tide & 255) == 0) rowinv[2 + grp] = inv;
+                // publish: EVERY wave's write-through stores have landed, then ONE lane raises this layer's flag
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                CH_BARRIER();
+                if (tid == 0) __hip_atomic_store(&a.flags[(size_t)l * a.ntiles + tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            SOL_CHSTAMP(l, 7);
         }
     }
+#undef CH_BARRIER
 }
 
 int init_chain_kernel() {
@@ -393,9 +486,9 @@ bool sol_cnn_chain_usable(int B, int H, int W) {
     return ntiles >= 2 && ntiles <= chain_cus();
 }
 
-size_t sol_cnn_chain_flag_words(int B, int H, int nl) { return (size_t)nl * ((B * H + 2) / 3) + 64; }
+size_t sol_cnn_chain_flag_words(int B, int H, int nl) { return (size_t)nl * ((B * H + 2) / 3) + 64 + (size_t)nl * B * H; }
 
-// flags: sol_cnn_chain_flag_words() zeroed words (the last 64: error word); layers: nl descriptors
+// flags: sol_cnn_chain_flag_words() zeroed words = [nl][ntiles] flags, 64 words (error word), [nl][rows] published row maxima
 int sol_cnn_chain_launch(hipStream_t s, const ChainLayer* layers, int nl, const float* x0, unsigned* flags, int B, int H, int W, float slope) {
     SOL_REQUIRE(layers && nl >= 1 && nl <= SOL_CHAIN_MAXL && x0 && flags && sol_cnn_chain_usable(B, H, W), "sol_cnn_chain_launch: bad arguments");
     if (int e = init_chain_kernel()) return e;
@@ -403,6 +496,7 @@ int sol_cnn_chain_launch(hipStream_t s, const ChainLayer* layers, int nl, const 
     for (int l = 0; l < nl; ++l) a.L[l] = layers[l];
     a.nl = nl; a.x0 = x0; a.flags = flags; a.B = B; a.H = H; a.nrows = B * H; a.ntiles = (B * H + 2) / 3; a.slope = slope;
     a.err = flags + (size_t)nl * a.ntiles;
+    a.rowmax = a.err + 64;
     SOL_LAUNCH(k_cnn_chain, dim3(a.ntiles), dim3(768), (size_t)CH_LDS, s, a);
     SOL_LAUNCH_CHECK();
     return SOL_OK;

@@ -75,6 +75,7 @@ struct ChainArgs {
     const float* x0;        // input of the first layer
     unsigned* flags;        // [nl][ntiles], zero at launch
     unsigned* err;          // |= 1 when a neighbour's flag never arrived
+    unsigned* rowmax;       // [nl][rows]: max|y| of every output row (bits), published with the row
     int B, H, nrows, ntiles;
     float slope;
 };
@@ -129,7 +130,8 @@ struct SolOptions {
     int cpt;              // 0: automatic strip height of the CG kernels, 8 / 16: forced
     int dbg_skip;         // timing experiments only
     int step_prof;        // debugging: synchronous phase times of the solver step kernels on stderr
-    int cnn_persistent;   // 1: the 12 CNN layers of a pass as ONE cooperative launch where the shape allows it
+    int cnn_persistent;   // 1: the ten 32 -> 32 layers of a CNN pass as ONE persistent launch (cnn_chain.hip) where the shape allows it; default 0:
+                          //    measured equal to the per-layer launches end to end, kept as a verified experiment
     int graph_stream;     // 1: sol_train_graph_launch replays on an internal stream fenced by events against the caller's stream
 };
 SolOptions& sol_opt();

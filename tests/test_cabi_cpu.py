@@ -96,7 +96,7 @@ def test_options_table_and_abi_checks(lib):
     kc, bc, tc = C.c_int32(), C.c_int32(), C.c_int32()
     assert lib.sol_abi_sizes(C.byref(kc), C.byref(bc), C.byref(tc)) == 0
     assert (kc.value, bc.value, tc.value) == (C.sizeof(_lib.KarmanCfg), C.sizeof(_lib.BurgersCfg), C.sizeof(_lib.TrainCfg))
-    defaults = {"conv_precision": 0, "cnn_persistent": 1, "bww_fuse": 1, "correct_fuse": 1, "density_mode": 0, "streams": 1, "bww_chunk": 0}
+    defaults = {"conv_precision": 0, "cnn_persistent": 0, "bww_fuse": 1, "correct_fuse": 1, "density_mode": 0, "streams": 1, "bww_chunk": 0}
     for k, v in defaults.items():
         if not any(os.environ.get(e) for e, (o_, _) in _lib._ENV_OPTIONS.items() if o_ == k):
             assert _lib.get_option(k) == v, k

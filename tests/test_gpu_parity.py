@@ -638,6 +638,40 @@ def test_options_and_launch_profiler():
     assert lib.sol_version() == _lib.ABI_VERSION
 
 
+def test_persistent_cnn_chain_equals_per_layer_launches():
+    """Option cnn_persistent: the ten 32->32 layers of every CNN pass (forward and backward-data) as ONE persistent launch
+    with neighbour-flag halo exchange and per-row fp16 scales, against the per-layer launches and the float64 oracle:
+    training step (loss, gradient, final state) at 128x64 and the no-grad roll-out."""
+    from sol_amd import _lib
+    B, Y, X, ms = 2, 128, 64, 2
+    g, d, vy, vx, re, gts, params, std_v, loss = _oracle_problem(B, Y, X, ms)
+    gref = torch.cat([p.grad.reshape(-1) for p in params])
+    args = (f32(d), f32(vy), f32(vx), f32(re), f32(torch.stack([s[1] for s in gts])), f32(torch.stack([s[2] for s in gts])))
+    saved = _lib.get_option("cnn_persistent")
+    out = {}
+    try:
+        for mode in (0, 1):
+            _lib.set_option("cnn_persistent", mode)
+            net, tr = _trainer_from(params, g, B, Y, X, ms, std_v)
+            hl = tr.fwd_bwd(*args, want_final=True)
+            with _lib.profile() as p:
+                tr.fwd_bwd(*args, want_final=True, eager=True)
+            names = {k.strip("()") for k in p.kernels}
+            assert ("k_cnn_chain" in names) == (mode == 1) and ("k_conv5x5_sb<2, 2>" in names) == (mode == 0)
+            assert abs(float(hl) - float(loss)) < 1e-5 * abs(float(loss))
+            assert rel(tr.grads, gref) < TOL_GRAD
+            ro = sol_amd.SolRollout(net, tr.masks, B, Y, X, g.dx, std_v, o.STD_RE)
+            rd, ry, rx = (t.clone() for t in args[:3])
+            ro.run(rd, ry, rx, args[3], 5)
+            out[mode] = (tr.grads.clone(), [t.clone() for t in tr.final], ry, rx)
+    finally:
+        _lib.set_option("cnn_persistent", saved)
+    assert rel(out[1][0], out[0][0]) < 2e-6
+    for a, b in zip(out[1][1], out[0][1]):
+        assert rel(a, b) < 2e-6
+    assert rel(out[1][2], out[0][2]) < 2e-6 and rel(out[1][3], out[0][3]) < 2e-6
+
+
 # ---------------------------------------------------------------------------------------------
 # data parallel: two ranks, one device
 # ---------------------------------------------------------------------------------------------
