@@ -203,21 +203,46 @@ __device__ __forceinline__ float block_sum(float v, float* red, int slot) {
 
 // max over the SOL_AMAX_SLOTS slots of an absmax array (bits of non-negative floats) -> power-of-two scale 2^shift with
 // max * 2^shift in [2^14, 2^15), and its inverse
-__device__ __forceinline__ void amax_scale(const unsigned* slots, float& scale, float& inv) {
+// two halves so that a kernel can put other loads between the slot load and its first use
+__device__ __forceinline__ uint4 amax_load(const unsigned* slots) {
     static_assert(SOL_AMAX_SLOTS == 256, "one uint4 per lane");
-    const uint4 q = reinterpret_cast<const uint4*>(slots)[threadIdx.x & 63];
+    return reinterpret_cast<const uint4*>(slots)[threadIdx.x & 63];
+}
+template <int CTRL, int ROWMASK = 0xf>
+__device__ __forceinline__ unsigned amax_dpp(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, true);
+}
+__device__ __forceinline__ void amax_scale_of(const uint4& q, float& scale, float& inv) {
     unsigned m = max(max(q.x, q.y), max(q.z, q.w));
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+    // wave maximum with DPP row operations (six dependent ds_bpermute round trips of a __shfl_xor ladder cost ~0.3 us per launch)
+    m = max(m, amax_dpp<0xB1>(m));          // quad_perm [1,0,3,2]
+    m = max(m, amax_dpp<0x4E>(m));          // quad_perm [2,3,0,1]
+    m = max(m, amax_dpp<0x141>(m));         // row_half_mirror
+    m = max(m, amax_dpp<0x140>(m));         // row_mirror
+    m = max(m, amax_dpp<0x142, 0xa>(m));    // row_bcast:15
+    m = max(m, amax_dpp<0x143, 0xc>(m));    // row_bcast:31 -> lane 63 = wave maximum
+    m = (unsigned)__builtin_amdgcn_readlane((int)m, 63);
     int e = (int)(m >> 23) - 127;                     // max in [2^e, 2^(e+1))
     e = m == 0u ? 0 : min(max(e, -100), 100);
     scale = __uint_as_float((unsigned)(14 - e + 127) << 23);
     inv = __uint_as_float((unsigned)(e - 14 + 127) << 23);
 }
+__device__ __forceinline__ void amax_scale(const unsigned* slots, float& scale, float& inv) {
+    const uint4 q = amax_load(slots);
+    amax_scale_of(q, scale, inv);
+}
+__device__ __forceinline__ unsigned amax_wave_max(unsigned m) {       // lane 63 (and the return value) = wave maximum
+    m = max(m, amax_dpp<0xB1>(m));
+    m = max(m, amax_dpp<0x4E>(m));
+    m = max(m, amax_dpp<0x141>(m));
+    m = max(m, amax_dpp<0x140>(m));
+    m = max(m, amax_dpp<0x142, 0xa>(m));
+    m = max(m, amax_dpp<0x143, 0xc>(m));
+    return (unsigned)__builtin_amdgcn_readlane((int)m, 63);
+}
 // one atomic per workgroup: `v` = this thread's max|y|; `red` = 16 floats of LDS
 __device__ __forceinline__ void amax_publish(float v, unsigned* slots, float* red) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    v = __uint_as_float(amax_wave_max(__float_as_uint(fabsf(v))));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -232,10 +257,9 @@ __device__ __forceinline__ void amax_publish(float v, unsigned* slots, float* re
 // into lds2[0] (LDS integer atomics are cheap) and counts itself; the LDS unit executes these in arrival order, so the wave
 // that draws the last ticket reads the complete workgroup max and issues the single global atomic.  Nobody waits for anybody.
 __device__ __forceinline__ void amax_publish_last(float v, unsigned* slots, unsigned* lds2) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    const unsigned wm = amax_wave_max(__float_as_uint(fabsf(v)));
     if ((threadIdx.x & 63) == 0) {
-        atomicMax(&lds2[0], __float_as_uint(v));
+        atomicMax(&lds2[0], wm);
         const unsigned ticket = atomicAdd(&lds2[1], 1u);
         if (ticket == (blockDim.x >> 6) - 1) atomicMax(&slots[blockIdx.x & (SOL_AMAX_SLOTS - 1)], atomicMax(&lds2[0], 0u));
     }

@@ -136,11 +136,6 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     const float4* gx = reinterpret_cast<const float4*>(a.x);
     const uint4* gw = KIND == 2 ? reinterpret_cast<const uint4*>(a.wsh) + 1 : reinterpret_cast<const uint4*>(a.wsb);
     float sa = 1.f, out_scale = 1.f;                  // KIND 2: input scale 2^shift and 2^-(shift_x + shift_w)
-    if constexpr (KIND == 2) {
-        float sai;
-        amax_scale(a.xmax, sa, sai);
-        out_scale = sai * reinterpret_cast<const float*>(a.wsh)[1];
-    }
     SOL_CSTAMP(10);
     constexpr int WV = WBUF / 16;                     // uint4 per weight phase
     constexpr int WPT = (WV + 767) / 768;
@@ -189,9 +184,19 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     {   // prologue: input rows G0-2, G0-1, G0 (one per tile group, 3 float4 per thread) and the weights of tap row 0
         float4 hv[3];
         uint4 wv[WPT];
+        // every global load of the prologue goes out before anything is waited for: the absmax slots of x (KIND 2) travel
+        // together with the rows and the weights instead of costing a round trip of their own
+        uint4 am = make_uint4(0u, 0u, 0u, 0u);
+        float winv = 1.f;
+        if constexpr (KIND == 2) { am = amax_load(a.xmax); winv = reinterpret_cast<const float*>(a.wsh)[1]; }
 #pragma unroll
         for (int n = 0; n < 3; ++n) hv[n] = load_row(G0 - 2 + grp, t + n * 256);
         load_w(0, wv);
+        if constexpr (KIND == 2) {
+            float sai;
+            amax_scale_of(am, sa, sai);
+            out_scale = sai * winv;
+        }
 #pragma unroll
         for (int n = 0; n < 3; ++n) store_row(grp, hv[n], t + n * 256);
         store_w(0, wv);
