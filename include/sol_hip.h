@@ -238,6 +238,10 @@ typedef struct sol_train_cfg {
     float std_v0, std_v1;   /* dataStats['std'][1]  (karman_train.py:234-255,419,432) */
     float std_re;           /* dataStats['ext.std'][0]                                 */
     float lrelu_slope;      /* Keras LeakyReLU default 0.3                              */
+    /* --pretf (karman_train.py:351-355, 416-421): a pre-trained supervised model brings its OWN input / output
+     * normalisation ('in.std', 'out.std' of its stats.pickle) while the loss keeps dataStats['std'].  0 = use std_v*. */
+    float in_std_v0, in_std_v1;     /* feature scale of the velocity channels: feat = v / in_std       */
+    float out_std_v0, out_std_v1;   /* correction scale: velocity += out_std * CNN(feat)                */
 } sol_train_cfg;
 
 size_t sol_train_workspace_bytes(const sol_train_cfg* cfg);

@@ -428,14 +428,17 @@ def mars_moon(params, x, slope=0.3):
 # --------------------------------------------------------------------------------------
 # unrolled loop + loss  (karman_train.py:397-436)
 # --------------------------------------------------------------------------------------
-def correction(params, vy, vx, re, std_v, std_re):
-    feat = to_feature(vy, vx, re) / torch.tensor([std_v[0], std_v[1], std_re], dtype=vy.dtype)
-    out = mars_moon(params, feat) * torch.tensor([std_v[0], std_v[1]], dtype=vy.dtype)
+def correction(params, vy, vx, re, std_v, std_re, in_std_v=None, out_std_v=None):
+    """karman_train.py:413-424; in_std_v / out_std_v = dataStats['in.std'][1] / ['out.std'], present only with --pretf (:351-355)."""
+    si = std_v if in_std_v is None else in_std_v
+    so = std_v if out_std_v is None else out_std_v
+    feat = to_feature(vy, vx, re) / torch.tensor([si[0], si[1], std_re], dtype=vy.dtype)
+    out = mars_moon(params, feat) * torch.tensor([so[0], so[1]], dtype=vy.dtype)
     return to_staggered(out)
 
 
 def unrolled_loss(params, d0, vy0, vx0, re, gt_vy, gt_vx, geom, std_v, std_re, dt=1.0,
-                  return_states=False, **step_kw):
+                  return_states=False, in_std_v=None, out_std_v=None, **step_kw):
     """loss = sum_i l2_loss((gt_i - prd_i)/std_v)/msteps   karman_train.py:428-436.
     gt_vy/gt_vx: lists of msteps ground-truth frames."""
     msteps = len(gt_vy)
@@ -445,7 +448,7 @@ def unrolled_loss(params, d0, vy0, vx0, re, gt_vy, gt_vx, geom, std_v, std_re, d
     sv = torch.tensor([std_v[0], std_v[1]], dtype=vy0.dtype)
     for i in range(msteps):
         d, vy, vx = karman_step(d, vy, vx, re, geom, dt=dt, **step_kw)
-        cy, cx = correction(params, vy, vx, re, std_v, std_re)
+        cy, cx = correction(params, vy, vx, re, std_v, std_re, in_std_v, out_std_v)
         vy = vy + cy
         vx = vx + cx
         diff = (staggered_tensor(gt_vy[i], gt_vx[i]) - staggered_tensor(vy, vx)) / sv
@@ -515,6 +518,29 @@ def burgers_step(vy, vx, dt, nu=0.1, fy=None, fx=None, dx=1.0, diffusion="fft"):
         ay = ay + dt * fy
         ax = ax + dt * fx
     return ay, ax
+
+
+def burgers_unrolled_loss(params, vy0, vx0, fy, fx, gt_vy, gt_vx, std_v, std_f, dt, nu=0.1, noforce=False):
+    """The unrolled Burgers graph of burgers/burgers_train.py:379-437: msteps x [step_with_f (or step) -> CNN correction
+    on to_feature(velocity (, force)) / std -> velocity += to_staggered(out * std_v)], loss = sum_i l2_loss((gt_i - prd_i)
+    / std_v) / msteps.  fy/fx/gt_*: lists of msteps frames [B,Y+1,X] / [B,Y,X+1]; std_v, std_f: (std_y, std_x) pairs
+    (dataStats['std'][0], [1]).  params: mars_moon weights with 4 (2 with noforce) input channels."""
+    msteps = len(gt_vy)
+    vy, vx = vy0, vx0
+    losses = []
+    sv = torch.tensor([std_v[0], std_v[1]], dtype=vy0.dtype)
+    for i in range(msteps):
+        vy, vx = burgers_step(vy, vx, dt, nu, None if noforce else fy[i], None if noforce else fx[i])
+        feat = staggered_tensor(vy, vx)[:, :-1, :-1, :] / sv                      # to_feature_noforce: drop the duplicated edges
+        if not noforce:
+            ff = staggered_tensor(fy[i], fx[i])[:, :-1, :-1, :] / torch.tensor([std_f[0], std_f[1]], dtype=vy0.dtype)
+            feat = torch.cat([feat, ff], dim=-1)
+        cy, cx = to_staggered(mars_moon(params, feat) * sv)
+        vy = vy + cy
+        vx = vx + cx
+        diff = (staggered_tensor(gt_vy[i], gt_vx[i]) - staggered_tensor(vy, vx)) / sv
+        losses.append(0.5 * (diff * diff).sum())
+    return torch.stack(losses).sum() / msteps
 
 
 # --------------------------------------------------------------------------------------

@@ -39,7 +39,8 @@ class TrainCfg(C.Structure):
     """sol_train_cfg"""
     _fields_ = [("karman", KarmanCfg), ("msteps", C.c_int32),
                 ("std_v0", C.c_float), ("std_v1", C.c_float), ("std_re", C.c_float),
-                ("lrelu_slope", C.c_float)]
+                ("lrelu_slope", C.c_float),
+                ("in_std_v0", C.c_float), ("in_std_v1", C.c_float), ("out_std_v0", C.c_float), ("out_std_v1", C.c_float)]
 
 
 _P = C.c_void_p

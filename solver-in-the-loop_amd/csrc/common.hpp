@@ -18,7 +18,7 @@ int sol_density_chain(const sol_karman_cfg* c, void* stream, int ms, const float
 bool sol_conv_correct_fusable(int W);
 int sol_conv5x5_correct(void* stream, const float* x, const float* packed, const float* bias, int B, int H, int W,
                         const unsigned* x_absmax, float* vy, float* vx, const float* gt_vy, const float* gt_vx,
-                        float s0, float s1, float* loss);
+                        float s0, float s1, float l0, float l1, float* loss);
 size_t sol_bww_batched_ws_floats(int nseg, int B, int H, int cin, int cout);
 int sol_bww_batched(void* stream, const float* x, const float* dz, float* partial, int nseg, int nseg_layout, int overwrite,
                     long x_seg, long dz_seg, int B, int H, int W, int cin, int cout,
@@ -41,7 +41,8 @@ struct ConvArgs {
     // trainer only (sol_conv5x5_correct): the 32 -> 2 layer applies its output as the velocity correction instead of storing it
     float *cvy, *cvx;               // staggered velocity [B,H+1,W] / [B,H,W+1], updated in place (channel 0 -> v_y rows < H, 1 -> v_x columns < W)
     const float *gty, *gtx;         // ground-truth frames for the l2 loss, or NULL
-    float cs0, cs1;                 // std_v
+    float cs0, cs1;                 // correction scale (out.std, = std_v unless --pretf)
+    float ls0, ls1;                 // loss scale (std_v)
     float* closs;                   // += 0.5 * sum(((gt - v) / std)^2) over ALL faces, or NULL
 };
 constexpr int SOL_AMAX_SLOTS = 256;   // one per workgroup of a 256-WG launch: same-address atomics serialise in L2 (~0.3 us each)

@@ -1075,7 +1075,7 @@ bool sol_conv_correct_fusable(int W) {
 
 int sol_conv5x5_correct(void* stream, const float* x, const float* packed, const float* bias, int B, int H, int W,
                         const unsigned* x_absmax, float* vy, float* vx, const float* gt_vy, const float* gt_vx,
-                        float s0, float s1, float* loss) {
+                        float s0, float s1, float l0, float l1, float* loss) {
     if (int e = check_shape(B, H, W, 32, 2)) return e;
     SOL_REQUIRE(x && packed && x_absmax && vy && vx && sol_conv_correct_fusable(W), "sol_conv5x5_correct: bad arguments");
     if (int e = sol_init_conv_kernels()) return e;
@@ -1085,7 +1085,7 @@ int sol_conv5x5_correct(void* stream, const float* x, const float* packed, const
     a.wsb = packed + (size_t)25 * 32 * pad_out(2);
     a.wsh = packed + (size_t)25 * 32 * pad_out(2) + sol_conv_sb_packed_floats(pad_out(2));
     a.xmax = x_absmax;
-    a.cvy = vy; a.cvx = vx; a.gty = gt_vy; a.gtx = gt_vx; a.cs0 = s0; a.cs1 = s1; a.closs = loss;
+    a.cvy = vy; a.cvx = vx; a.gty = gt_vy; a.gtx = gt_vx; a.cs0 = s0; a.cs1 = s1; a.ls0 = l0; a.ls1 = l1; a.closs = loss;
     return sol_conv_sb_launch((hipStream_t)stream, a, 1, B * H * (W / 64));
 }
 

@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
         if (tvalid && li < 2) {
             const int jj = gy - b * H, nVy = (H + 1) * W, nVx = H * (W + 1);
             const float bias = a.bias ? a.bias[li] : 0.f;
-            const float s = li == 0 ? a.cs0 : a.cs1;
+            const float s = li == 0 ? a.cs0 : a.cs1, ls = li == 0 ? a.ls0 : a.ls1;
             float* vf = li == 0 ? a.cvy + (size_t)b * nVy + (size_t)jj * W : a.cvx + (size_t)b * nVx + (size_t)jj * (W + 1);
             const float* gt = li == 0 ? (a.gty ? a.gty + (size_t)b * nVy + (size_t)jj * W : nullptr)
                                       : (a.gtx ? a.gtx + (size_t)b * nVx + (size_t)jj * (W + 1) : nullptr);
@@ -354,9 +354,9 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
                 const int i = x0 + wave * 16 + 4 * g + r;
                 const float v = vf[i] + s * (acc[0][r] + bias);
                 vf[i] = v;
-                if (gt) { const float d = (gt[i] - v) / s; lsum += 0.5f * d * d; }
-                if (gt && li == 0 && jj == H - 1) { const float d = (gt[W + i] - vf[W + i]) / s; lsum += 0.5f * d * d; }   // v_y row H
-                if (gt && li == 1 && i == W - 1) { const float d = (gt[W] - vf[W]) / s; lsum += 0.5f * d * d; }            // v_x column W
+                if (gt) { const float d = (gt[i] - v) / ls; lsum += 0.5f * d * d; }
+                if (gt && li == 0 && jj == H - 1) { const float d = (gt[W + i] - vf[W + i]) / ls; lsum += 0.5f * d * d; }   // v_y row H
+                if (gt && li == 1 && i == W - 1) { const float d = (gt[W] - vf[W]) / ls; lsum += 0.5f * d * d; }            // v_x column W
             }
         }
         if (a.closs) {                                // workgroup uniform: wave sums -> LDS -> the last wave adds to the step's loss

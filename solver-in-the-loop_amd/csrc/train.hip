@@ -142,7 +142,7 @@ inline int64_t layer_koff(int l) {
 // ---- velocity += CNN correction (to_staggered pad, karman_train.py:88-90,413-426) + l2 loss ----
 __global__ void k_correct_loss(float* __restrict__ vy, float* __restrict__ vx, const float* __restrict__ O,
                                const float* __restrict__ gt_vy, const float* __restrict__ gt_vx,
-                               float s0, float s1, float* __restrict__ loss, int B, int Y, int X) {
+                               float s0, float s1, float l0, float l1, float* __restrict__ loss, int B, int Y, int X) {
     __shared__ float red[64];
     const int N = Y * X, nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
     const int total = B * (nVy + nVx);
@@ -153,7 +153,7 @@ __global__ void k_correct_loss(float* __restrict__ vy, float* __restrict__ vx, c
             float v = vy[e];
             if (k < N) v += s0 * O[((size_t)b * N + k) * 2];
             vy[e] = v;
-            if (gt_vy) { const float d = (gt_vy[e] - v) / s0; l += 0.5f * d * d; }
+            if (gt_vy) { const float d = (gt_vy[e] - v) / l0; l += 0.5f * d * d; }
         } else {
             const int e2 = e - B * nVy;
             const int b = e2 / nVx, k = e2 - b * nVx;
@@ -161,7 +161,7 @@ __global__ void k_correct_loss(float* __restrict__ vy, float* __restrict__ vx, c
             float v = vx[e2];
             if (i < X) v += s1 * O[((size_t)b * N + j * X + i) * 2 + 1];
             vx[e2] = v;
-            if (gt_vx) { const float d = (gt_vx[e2] - v) / s1; l += 0.5f * d * d; }
+            if (gt_vx) { const float d = (gt_vx[e2] - v) / l1; l += 0.5f * d * d; }
         }
     }
     if (loss) {
@@ -173,14 +173,14 @@ __global__ void k_correct_loss(float* __restrict__ vy, float* __restrict__ vx, c
 // ---- backward seed: g_prd = g_next + (prd - gt)/(std^2 msteps);  dO = std * g_prd on cells ----
 __global__ void k_seed(float* __restrict__ gvy, float* __restrict__ gvx, const float* __restrict__ vy,
                        const float* __restrict__ vx, const float* __restrict__ gt_vy, const float* __restrict__ gt_vx,
-                       float s0, float s1, float inv_m, float* __restrict__ dO4, float* __restrict__ dO2,
+                       float s0, float s1, float l0, float l1, float inv_m, float* __restrict__ dO4, float* __restrict__ dO2,
                        int first, int B, int Y, int X) {
     const int N = Y * X, nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
     const int total = B * (nVy + nVx);
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         if (e < B * nVy) {
             const int b = e / nVy, k = e - b * nVy;
-            float g = (vy[e] - gt_vy[e]) * inv_m / (s0 * s0);
+            float g = (vy[e] - gt_vy[e]) * inv_m / (l0 * l0);
             if (!first) g += gvy[e];
             gvy[e] = g;
             if (k < N) {
@@ -192,7 +192,7 @@ __global__ void k_seed(float* __restrict__ gvy, float* __restrict__ gvx, const f
             const int e2 = e - B * nVy;
             const int b = e2 / nVx, k = e2 - b * nVx;
             const int j = k / XP, i = k - j * XP;
-            float g = (vx[e2] - gt_vx[e2]) * inv_m / (s1 * s1);
+            float g = (vx[e2] - gt_vx[e2]) * inv_m / (l1 * l1);
             if (!first) g += gvx[e2];
             gvx[e2] = g;
             if (i < X) {
@@ -363,6 +363,11 @@ int pack_all(const sol_train_cfg* /*c*/, void* stream, const float* params, Ws& 
     return sol_pack_jobs((hipStream_t)stream, n, src, out, bo, bi, cin, cout, mode);
 }
 
+inline float in_s0(const sol_train_cfg* c) { return c->in_std_v0 > 0.f ? c->in_std_v0 : c->std_v0; }
+inline float in_s1(const sol_train_cfg* c) { return c->in_std_v1 > 0.f ? c->in_std_v1 : c->std_v1; }
+inline float out_s0(const sol_train_cfg* c) { return c->out_std_v0 > 0.f ? c->out_std_v0 : c->std_v0; }
+inline float out_s1(const sol_train_cfg* c) { return c->out_std_v1 > 0.f ? c->out_std_v1 : c->std_v1; }
+
 // CNN forward (model_mars_moon, karman_train.py:101-138).  acts: 11 buffers [cells][32].
 // amax: [11][SOL_AMAX_SLOTS] absmax slots of act[0..10] (zeroed by the caller): every producer publishes max|y| and every
 // 32-channel consumer derives its fp16 operand scale from it (sol_conv5x5_scaled).
@@ -392,7 +397,7 @@ int net_forward(const sol_train_cfg* c, void* s, const Ws& w, const float* feat,
     }
     if (corr)
         return sol_conv5x5_correct(s, act[10], w.wf[11], w.bias[11], B, Y, X, am(10), corr->vy, corr->vx, corr->gt_vy, corr->gt_vx,
-                                   c->std_v0, c->std_v1, corr->loss);
+                                   out_s0(c), out_s1(c), c->std_v0, c->std_v1, corr->loss);
     return sol_conv5x5_scaled(s, act[10], w.wf[11], w.bias[11], nullptr, nullptr, O, B, Y, X, 32, 2, SOL_EPI_NONE, sl, am(10), nullptr);
 }
 
@@ -489,7 +494,7 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
     void* stream = hs;
     const sol_karman_cfg* kc = &c->karman;
     const int B = kc->B, Y = kc->Y, X = kc->X, ms = c->msteps;
-    const float fscale[3] = {1.f / c->std_v0, 1.f / c->std_v1, 1.f / c->std_re};
+    const float fscale[3] = {1.f / in_s0(c), 1.f / in_s1(c), 1.f / c->std_re};
     const int egrid = (int)((w.st_vy + w.st_vx + 255) / 256);
     const size_t gVy = (size_t)Btot * w.nVy, gVx = (size_t)Btot * w.nVx;       // per-step stride of the gt frames
     const float* d0 = io.d0 + (size_t)b0 * w.N;
@@ -537,7 +542,7 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
             if (int e = net_forward(c, stream, wn, feat, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS, nullptr, w.chain_flags + (size_t)(2 * i) * w.chain_words)) return e;
             SOL_LAUNCH(k_correct_loss, dim3(egrid), dim3(256), 0, hs, vycur, vxcur, w.O,
                                gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx,
-                               c->std_v0, c->std_v1, io.loss_steps + i, B, Y, X);
+                               out_s0(c), out_s1(c), c->std_v0, c->std_v1, io.loss_steps + i, B, Y, X);
             SOL_LAUNCH_CHECK();
         }
     }
@@ -584,7 +589,7 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         float* dO2 = w.dO2 + (size_t)i * w.cells * 2;
         SOL_LAUNCH(k_seed, dim3(egrid), dim3(256), 0, hs, gvy, gvx, vycur, vxcur,
                            gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx,
-                           c->std_v0, c->std_v1, 1.f / (float)ms, w.dO4, dO2, i == ms - 1 ? 1 : 0, B, Y, X);
+                           out_s0(c), out_s1(c), c->std_v0, c->std_v1, 1.f / (float)ms, w.dO4, dO2, i == ms - 1 ? 1 : 0, B, Y, X);
         SOL_LAUNCH_CHECK();
         const float* act[11];
         float* D[11];
@@ -819,7 +824,7 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
     hipStream_t hs = (hipStream_t)stream;
     const sol_karman_cfg* kc = &cfg->karman;
     const int B = kc->B, Y = kc->Y, X = kc->X;
-    const float fscale[3] = {1.f / cfg->std_v0, 1.f / cfg->std_v1, 1.f / cfg->std_re};
+    const float fscale[3] = {1.f / in_s0(cfg), 1.f / in_s1(cfg), 1.f / cfg->std_re};
     const int egrid = (int)((w.st_vy + w.st_vx + 255) / 256);
     if (int e = pack_all(cfg, stream, params, w, false)) return e;
     float* act[11];
@@ -846,7 +851,7 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
         } else {
             if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, amax, nullptr, w.chain_flags + (size_t)(2 * (i % ROLLOUT_AMAX_SETS)) * w.chain_words)) return e;
             SOL_LAUNCH(k_correct_loss, dim3(egrid), dim3(256), 0, hs, tvy, tvx, w.O,
-                               (const float*)nullptr, (const float*)nullptr, cfg->std_v0, cfg->std_v1, (float*)nullptr, B, Y, X);
+                               (const float*)nullptr, (const float*)nullptr, out_s0(cfg), out_s1(cfg), cfg->std_v0, cfg->std_v1, (float*)nullptr, B, Y, X);
             SOL_LAUNCH_CHECK();
         }
     }

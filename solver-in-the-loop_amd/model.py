@@ -73,6 +73,17 @@ class ConvNet:
 
     @classmethod
     def load(cls, path, device="cuda"):
+        """`.pt` written by save(), or `.npz` holding the arrays of Keras `model.get_weights()` in order (arr_0, arr_1, ...:
+        the bridge from the reference's model.h5 -- h5py is not part of this image -- is `np.savez(path, *model.get_weights())`
+        on the TensorFlow side).  The architecture is recognised from the kernel shapes."""
+        if str(path).endswith(".npz"):
+            z = np.load(path)
+            ws = [z[k] for k in sorted(z.files, key=lambda k: int(k.split("_")[-1]))]
+            cin, cout = ws[0].shape[2], ws[-2].shape[3]
+            name = "mercury" if len(ws) == 6 else "mars_moon"
+            net = MODELS[name](cin, cout, device=device)
+            net.set_weights(ws)
+            return net
         blob = torch.load(path, map_location="cpu")
         net = MODELS[blob["name"]](blob["cin"], blob["cout"], device=device)
         net.set_weights([w.numpy() for w in blob["weights"]])

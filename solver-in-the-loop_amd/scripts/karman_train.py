@@ -42,6 +42,7 @@ def main(argv=None):
     p.add_argument("--clip-grad", action="store_true", help="turn on clip gradients")
     p.add_argument("--resume", default=-1, type=int, help="resume training epochs")
     p.add_argument("--inittf", default=None, help="load initial model weights (warm start)")
+    p.add_argument("--pretf", default=None, help="load pre-trained weights (only for testing pre-trained supervised model; do not use for a warm start!)")
     p.add_argument("--tf", default="/tmp/phiflow/tf", help="path to an output dir (model, logs, etc.)")
     params = vars(p.parse_args(argv))
     rank, world, local = sol_amd.dist.init_from_env()
@@ -63,6 +64,13 @@ def main(argv=None):
                                 skip_preprocessing=params["skip_ds"], scale=params["scale"])
     if params["only_ds"]:
         return None
+    if params["pretf"]:
+        # karman_train.py:351-355: the supervised model's own input / output normalisation travels in stats.pickle next to it
+        with open(os.path.dirname(params["pretf"]) + "/stats.pickle", "rb") as f:
+            ld_stats = pickle.load(f)
+        dataset.dataStats["in.std"] = (ld_stats["in.std"][0], (ld_stats["in.std"][1], ld_stats["in.std"][2]))
+        dataset.dataStats["out.std"] = ld_stats["out.std"]
+        log.info(dataset.dataStats)
     if params["resume"] > 0:
         with open(params["tf"] + "/dataStats.pickle", "rb") as f:
             dataset.dataStats = pickle.load(f)
@@ -80,6 +88,9 @@ def main(argv=None):
     assert params["model"] == "mars_moon", "the fused trainer implements model_mars_moon (the reference default)"
     model = sol_amd.model_mars_moon(cin=3, cout=2, seed=seed, device=dev)
     model.summary(print_fn=log.info)
+    if params["pretf"]:
+        log.info("load a pre-trained model: {}".format(params["pretf"]))
+        model.set_weights(sol_amd.ConvNet.load(params["pretf"], device="cpu").get_weights())
     if params["inittf"]:
         log.info("load an initial model (warm start): {}".format(params["inittf"]))
         model.set_weights(sol_amd.ConvNet.load(params["inittf"], device="cpu").get_weights())
@@ -91,8 +102,11 @@ def main(argv=None):
     else:
         model.set_weights(sol_amd.ConvNet.load(params["tf"] + "/model_epoch{:04d}.pt".format(params["resume"]), device="cpu").get_weights())
     std_v = dataset.dataStats["std"][1]
+    # karman_train.py:416-421: 'in.std' / 'out.std' (only present with --pretf) scale the network's input / output, the loss keeps 'std'
     trainer = sol_amd.SolTrainer(model, masks, Bl, Y, X, ms, dom.dx[1], std_v, dataset.dataStats["ext.std"][0],
-                                 clip_grad=params["clip_grad"])
+                                 clip_grad=params["clip_grad"],
+                                 in_std_v=dataset.dataStats["in.std"][1] if "in.std" in dataset.dataStats else None,
+                                 out_std_v=dataset.dataStats["out.std"] if "out.std" in dataset.dataStats else None)
     # persistent device buffers: the captured hipGraph keeps their addresses, new data is copied in
     f32 = lambda shape: torch.empty(shape, dtype=torch.float32, device=dev)
     d0, vy0, vx0, re = f32((Bl, Y, X)), f32((Bl, Y + 1, X)), f32((Bl, Y, X + 1)), f32((Bl,))

@@ -24,7 +24,7 @@ class SolTrainer:
     def __init__(self, net, masks, B, Y, X, msteps, dx, std_v, std_re, dt=1.0, res=None,
                  clip_grad=False, beta1=0.9, beta2=0.999, eps=1e-8, group=None, use_graph=True,
                  cg_rtol=1e-6, cg_atol=1e-9, cg_max_iter=2000, grad_pad="replicate", inflow_order="after",
-                 conv_precision="split", comm=None):
+                 conv_precision="split", comm=None, in_std_v=None, out_std_v=None):
         """conv_precision: arithmetic of the 32-channel convolutions (library option `conv_precision`):
         "split" (default) fp32-equivalent fp16x3 / bf16x6 operand splits on the 16-bit matrix pipe, "bf16x6",
         or "fp32" = strict fp32 MFMA.  The option is process wide in the library; every call of this trainer sets
@@ -38,7 +38,10 @@ class SolTrainer:
         self.B, self.Y, self.X, self.msteps = B, Y, X, msteps
         kc = ops.karman_cfg(B, Y, X, dx, dt=dt, res=res, cg_rtol=cg_rtol, cg_atol=cg_atol,
                             cg_max_iter=cg_max_iter, grad_pad=grad_pad, inflow_order=inflow_order, masks=masks)
-        self.cfg = TrainCfg(kc, msteps, float(std_v[0]), float(std_v[1]), float(std_re), float(net.slope))
+        # --pretf (karman_train.py:351-355,416-421): separate input / output normalisation of a pre-trained supervised model
+        i0, i1 = (float(in_std_v[0]), float(in_std_v[1])) if in_std_v is not None else (0.0, 0.0)
+        o0, o1 = (float(out_std_v[0]), float(out_std_v[1])) if out_std_v is not None else (0.0, 0.0)
+        self.cfg = TrainCfg(kc, msteps, float(std_v[0]), float(std_v[1]), float(std_re), float(net.slope), i0, i1, o0, o1)
         dev = net.params.device
         self.device = dev
         nbytes = self.lib.sol_train_workspace_bytes(C.byref(self.cfg))
@@ -166,12 +169,14 @@ class SolTrainer:
 class SolRollout:
     """No-grad roll-out of solver step + CNN correction (karman_apply.py:138-158)."""
 
-    def __init__(self, net, masks, B, Y, X, dx, std_v, std_re, dt=1.0, res=None, **solver):
+    def __init__(self, net, masks, B, Y, X, dx, std_v, std_re, dt=1.0, res=None, in_std_v=None, out_std_v=None, **solver):
         _lib.require_gpu()
         self.lib = _lib.load()
         self.net, self.masks, self.B = net, masks, B
         kc = ops.karman_cfg(B, Y, X, dx, dt=dt, res=res, masks=masks, **solver)
-        self.cfg = TrainCfg(kc, 1, float(std_v[0]), float(std_v[1]), float(std_re), float(net.slope))
+        i0, i1 = (float(in_std_v[0]), float(in_std_v[1])) if in_std_v is not None else (0.0, 0.0)
+        o0, o1 = (float(out_std_v[0]), float(out_std_v[1])) if out_std_v is not None else (0.0, 0.0)
+        self.cfg = TrainCfg(kc, 1, float(std_v[0]), float(std_v[1]), float(std_re), float(net.slope), i0, i1, o0, o1)
         nbytes = self.lib.sol_rollout_workspace_bytes(C.byref(self.cfg))
         self.workspace = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=net.params.device)
         self.workspace_bytes = nbytes

@@ -716,3 +716,114 @@ def test_library_rccl_communicator_single_rank():
     torch.cuda.synchronize()
     assert torch.equal(g, ref)
     comm.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# Burgers unrolled loss + gradient (BASELINE configs[0]); --pretf scales in the fused trainer
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("noforce,ms", [(False, 1), (False, 2), (True, 2)])
+def test_burgers_unrolled_loss_and_gradient_against_oracle(noforce, ms):
+    """burgers/ 32x32, batch 5, dt 0.1 (karman... burgers/Makefile:71 `-l 32 --dt 0.1 -b 5 -m 1`): the unrolled graph of
+    burgers_train.py:379-437 composed from the reference-shaped surface (BurgersTest.step_with_f, to_feature, model,
+    to_staggered) on the HIP ops with torch autograd, against the float64 oracle: loss and the full weight gradient."""
+    from sol_amd.burgers import to_feature, to_feature_noforce
+    B, Y, X, dt = 5, 32, 32, 0.1
+    gen = torch.Generator().manual_seed(7)
+    sm = lambda *shape: o._smooth(torch.randn(*shape, generator=gen, dtype=torch.float64))
+    vy, vx = 0.3 * sm(B, Y + 1, X), 0.3 * sm(B, Y, X + 1)
+    fy = [0.15 * sm(B, Y + 1, X) for _ in range(ms)]
+    fx = [0.15 * sm(B, Y, X + 1) for _ in range(ms)]
+    gy = [0.3 * sm(B, Y + 1, X) for _ in range(ms)]
+    gx = [0.3 * sm(B, Y, X + 1) for _ in range(ms)]
+    std_v, std_f = (0.21, 0.19), (0.09, 0.11)
+    cin = 2 if noforce else 4
+    params = [p.clone().requires_grad_(True) for p in o.init_params(0, cin=cin)]
+    loss = o.burgers_unrolled_loss(params, vy, vx, fy, fx, gy, gx, std_v, std_f, dt, noforce=noforce)
+    loss.backward()
+    gref = torch.cat([p.grad.reshape(-1) for p in params])
+
+    dom = sol_amd.Domain([Y, X], box=sol_amd.box([32, 32]), boundaries=sol_amd.PERIODIC)
+    sim = sol_amd.BurgersTest()
+    net = sol_amd.model_mars_moon(cin=cin, cout=2, seed=0)
+    net.set_weights([p.detach().numpy() for p in params])
+    st = sol_amd.BurgersVelocitySMAC(dom, velocity=f32(o.staggered_tensor(vy, vx)), batch_size=B)
+    sv = torch.tensor(std_v, device=DEV, dtype=torch.float32)
+    sin = sv if noforce else torch.cat([sv, torch.tensor(std_f, device=DEV, dtype=torch.float32)])
+    losses = []
+    for k in range(ms):
+        fr = sol_amd.BurgersVelocitySMAC(dom, velocity=f32(o.staggered_tensor(fy[k], fx[k])), batch_size=B)
+        st = sim.step(st, dt=dt) if noforce else sim.step_with_f(st, fr, dt=dt)
+        feat = to_feature_noforce([st]) if noforce else to_feature([st], [fr])
+        corr = sol_amd.to_staggered(net(feat / sin) * sv, dom.box)
+        st = st.copied_with(velocity=st.velocity + corr)
+        diff = (f32(o.staggered_tensor(gy[k], gx[k])) - st.velocity.staggered_tensor()) / sv
+        losses.append(0.5 * (diff * diff).sum())
+    total = torch.stack(losses).sum() / ms
+    total.backward()
+    assert abs(float(total) - float(loss)) < 1e-5 * abs(float(loss))
+    assert rel(net.params.grad, gref) < TOL_GRAD
+
+
+def test_fused_trainer_with_pretf_scales_against_oracle():
+    """--pretf (karman_train.py:351-355,416-421): input / output normalisation of a pre-trained model ('in.std', 'out.std')
+    differ from the loss scale ('std'): fused trainer vs oracle at 64x32, and the roll-out with the same scales."""
+    B, Y, X, ms = 2, 64, 32, 2
+    g = o.geometry(Y, X)
+    d, vy, vx = o.synthetic_state(B, Y, X, 1234)
+    re = torch.tensor(o.RE_TRAIN[:B], dtype=torch.float64)
+    gts = [o.synthetic_state(B, Y, X, 4321 + i, project_it=False) for i in range(ms)]
+    params = [p.clone().requires_grad_(True) for p in o.init_params(0)]
+    std_v, in_std, out_std = (0.2, 0.25), (0.31, 0.17), (0.05, 0.08)
+    loss = o.unrolled_loss(params, d, vy, vx, re, [s[1] for s in gts], [s[2] for s in gts], g, std_v, o.STD_RE,
+                           in_std_v=in_std, out_std_v=out_std)
+    loss.backward()
+    gref = torch.cat([p.grad.reshape(-1) for p in params])
+    net, tr = _trainer_from(params, g, B, Y, X, ms, std_v, in_std_v=in_std, out_std_v=out_std)
+    hl = tr.fwd_bwd(f32(d), f32(vy), f32(vx), f32(re), f32(torch.stack([s[1] for s in gts])), f32(torch.stack([s[2] for s in gts])))
+    assert abs(float(hl) - float(loss)) < 1e-5 * abs(float(loss))
+    assert rel(tr.grads, gref) < TOL_GRAD
+    ro = sol_amd.SolRollout(net, tr.masks, B, Y, X, g.dx, std_v, o.STD_RE, in_std_v=in_std, out_std_v=out_std)
+    hd, hy, hx = f32(d), f32(vy), f32(vx)
+    ro.run(hd, hy, hx, f32(re), 3)
+    with torch.no_grad():
+        rd, ry, rx = d, vy, vx
+        for _ in range(3):
+            rd, ry, rx = o.karman_step(rd, ry, rx, re, g)
+            cy, cx = o.correction([p.detach() for p in params], ry, rx, re, std_v, o.STD_RE, in_std, out_std)
+            ry, rx = ry + cy, rx + cx
+    assert rel(hy, ry) < TOL_FIELD and rel(hx, rx) < TOL_FIELD
+
+
+def test_torch_library_ops_are_registered_and_differentiable():
+    """torch.ops.sol.* (SURVEY 8b2 / north star "PyTorch-ROCm custom ops with a hand-written backward"): the registered
+    ops run the same C-ABI entry points as the ctypes path and carry the hand-written adjoints."""
+    import sol_amd.torch_ops  # noqa: F401  (registers the library)
+    B, Y, X = 2, 16, 8
+    g, mk = masks_for(Y, X)
+    d, vy, vx = (f32(t) for t in o.synthetic_state(B, Y, X, 5))
+    re = f32(torch.tensor(o.RE_TRAIN[:B]))
+    cfg = ops.karman_cfg(B, Y, X, g.dx, masks=mk)
+    h = sol_amd.torch_ops.register_scene(cfg, mk)
+    vy1 = vy.clone().requires_grad_(True)
+    vx1 = vx.clone().requires_grad_(True)
+    d2, py, px = torch.ops.sol.karman_step(d, vy1, vx1, re, h)
+    (py.sum() + 2 * px.sum()).backward()
+    vy2 = vy.clone().requires_grad_(True)
+    vx2 = vx.clone().requires_grad_(True)
+    e2, qy, qx = ops.karman_step(d, vy2, vx2, re, cfg, mk)
+    (qy.sum() + 2 * qx.sum()).backward()
+    assert torch.equal(py, qy) and torch.equal(px, qx) and torch.equal(d2, e2)
+    assert torch.equal(vy1.grad, vy2.grad) and torch.equal(vx1.grad, vx2.grad)
+    x = torch.randn(2, 16, 8, 32, device=DEV, dtype=torch.float32, requires_grad=True)
+    w = (torch.randn(5, 5, 32, 32, device=DEV, dtype=torch.float32) * 0.05).requires_grad_(True)
+    b = torch.zeros(32, device=DEV, dtype=torch.float32, requires_grad=True)
+    y1 = torch.ops.sol.conv5x5(x, w, b, None, True, 0.3)
+    y1.square().sum().backward()
+    gx1, gw1 = x.grad.clone(), w.grad.clone()
+    x.grad = w.grad = b.grad = None
+    y2 = ops.conv5x5(x, w, b, None, True, 0.3)
+    y2.square().sum().backward()
+    assert torch.equal(y1, y2) and torch.equal(gx1, x.grad) and torch.equal(gw1, w.grad)
+    assert torch.library  # the ops live in the dispatcher: torch.ops.sol.karman_step / conv5x5 / burgers_step / adam_tf_step
+    for name in ("karman_step", "conv5x5", "burgers_step", "adam_tf_step"):
+        assert hasattr(torch.ops.sol, name)
