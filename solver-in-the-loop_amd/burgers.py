@@ -2,6 +2,7 @@
 to_feature / to_feature_noforce (l.75-92), BurgersTest.step / step_with_f (l.178-187), and the TF1
 AdamOptimizer used at l.437 as a small optimizer object over the flat parameter buffer."""
 
+import numpy as np
 import torch
 
 from . import _lib, ops
@@ -67,3 +68,60 @@ class TFAdam:
         check(_lib.load().sol_adam_tf_step(stream(), ptr(self.net.params.detach()), ptr(g), ptr(self.m), ptr(self.v),
                                            self.net.n_params, self.t, float(lr), self.beta1, self.beta2, self.eps, 0.0,
                                            None, 0, None))
+
+
+# ---- data generation: forcing model and initial state (host side, numpy) --------------------------------------------
+# /root/reference/burgers/burgers.py:89-114 builds 20 travelling sine forces from PhiFlow's SinPotential / FieldEffect
+# and advances their phases with ForcingPhysics; :120 draws the initial velocity with math.randfreq.  PhiFlow 1.5.1 is
+# not installable here, so the field evaluation is RECALLED [EXT-RECALL]; every recalled choice is a named option.
+class SinForces:
+    """num_forces plane waves f_i(x) = amplitude_i * sin(k_i . x + phase_i) (per velocity component), k_i = (1 + u) 0.8
+    (sin a, cos a) with a = pi u, amplitude = (u - 0.5) 0.3 per component, phase = 2 pi u, omega = 0.8 u - 0.4
+    (burgers.py:99-108; u = independent uniform draws in that order).  step(dt): phase += dt * omega (ForcingPhysics.step,
+    :89-97).  variant "sin" (default): the field VALUE is data * sin(.) as recalled from SinPotential.sample_at;
+    variant "gradient": data * cos(.) * k (a potential's gradient), the alternative reading of the class name."""
+
+    def __init__(self, rng, num_forces=20, variant="sin"):
+        if variant not in ("sin", "gradient"):
+            raise ValueError("variant must be 'sin' or 'gradient'")
+        self.variant = variant
+        self.k, self.amp, self.phase, self.omega = [], [], [], []
+        for _ in range(num_forces):
+            angle = rng.uniform() * np.pi
+            direction = np.array([np.sin(angle), np.cos(angle)])
+            self.k.append((rng.uniform() + 1) * 0.8 * direction)
+            self.amp.append((rng.uniform(size=2) - 0.5) * 0.3)
+            self.phase.append(rng.uniform() * 2 * np.pi)
+            self.omega.append(rng.uniform() * 0.8 - 0.4)
+        self.k, self.amp = np.array(self.k), np.array(self.amp)
+        self.phase, self.omega = np.array(self.phase), np.array(self.omega)
+
+    def step(self, dt):
+        self.phase = self.phase + dt * self.omega
+
+    def _at(self, py, px, comp):
+        ph = self.k[:, 0, None, None] * py[None] + self.k[:, 1, None, None] * px[None] + self.phase[:, None, None]
+        if self.variant == "sin":
+            return (self.amp[:, comp, None, None] * np.sin(ph)).sum(0)
+        return (self.amp[:, comp, None, None] * np.cos(ph) * self.k[:, comp, None, None]).sum(0)
+
+    def staggered(self, Y, X, dx):
+        """sum of the force fields sampled on the staggered grid (`.at(dm.staggered_grid(0))`, :122): [1,Y+1,X+1,2], component 0
+        (y) at the y-faces (j dx, (i+0.5) dx), component 1 at the x-faces ((j+0.5) dx, i dx), physical coordinates."""
+        out = np.zeros((1, Y + 1, X + 1, 2))
+        jy, ix = np.meshgrid(np.arange(Y + 1) * dx, (np.arange(X) + 0.5) * dx, indexing="ij")
+        out[0, :, :X, 0] = self._at(jy, ix, 0)
+        jy, ix = np.meshgrid((np.arange(Y) + 0.5) * dx, np.arange(X + 1) * dx, indexing="ij")
+        out[0, :Y, :, 1] = self._at(jy, ix, 1)
+        return out
+
+
+def randfreq(shape, rng, power=8):
+    """math.randfreq (burgers.py:120, [EXT-RECALL]): complex white noise in Fourier space damped by (1 + |k|)^-power
+    (k = integer wave numbers), real part of the inverse FFT, normalised to unit standard deviation."""
+    Y, X = shape
+    noise = rng.standard_normal((Y, X)) + 1j * rng.standard_normal((Y, X))
+    ky, kx = np.meshgrid(np.fft.fftfreq(Y) * Y, np.fft.fftfreq(X) * X, indexing="ij")
+    k = np.sqrt(ky * ky + kx * kx)
+    f = np.fft.ifft2(noise * (1.0 / (1.0 + k)) ** power).real
+    return f / (f.std() + 1e-30)

@@ -50,9 +50,25 @@ class KarmanFlow:
         inflow = self.infl.geometry.value_at(yc, xc) * self.infl.rate
         return active, inflow
 
+    @staticmethod
+    def _digest(a):
+        """content key of a boundary-condition array (shape + bytes): object identity is not one -- ids are recycled after
+        garbage collection and a caller may pass a fresh but equal array every step"""
+        import hashlib
+        if isinstance(a, torch.Tensor):
+            a = a.detach().cpu().numpy()
+        a = np.ascontiguousarray(a)
+        return (a.shape, str(a.dtype), hashlib.sha1(a.view(np.uint8)).hexdigest())
+
     def _masks(self, domain, velBCy, velBCyMask, device):
-        key = (domain.resolution, domain.box.lower, domain.box.upper, id(velBCy), id(velBCyMask), str(device))
+        # fast path: the same objects as last time (the training loop passes the same two arrays every step)
+        last = getattr(self, "_last_masks", None)
+        if last is not None and last[0] is velBCy and last[1] is velBCyMask and last[2] == (domain.resolution, str(device)):
+            return last[3]
+        key = (domain.resolution, domain.box.lower, domain.box.upper, self._digest(velBCy), self._digest(velBCyMask), str(device))
         if key not in self._cache:
+            if len(self._cache) >= 8:                       # bounded: every entry holds device buffers and a solver blob
+                self._cache.pop(next(iter(self._cache)))
             active, inflow = self.scene_arrays(domain)
             Y, X = domain.resolution
             bcv = np.asarray(velBCy, dtype=np.float64).reshape(-1, Y + 1, X)
@@ -60,6 +76,8 @@ class KarmanFlow:
             if bcv.shape[0] > 1 and np.all(bcv == bcv[0:1]) and np.all(bcm == bcm[0:1]):
                 bcv, bcm = bcv[0:1], bcm[0:1]
             self._cache[key] = ops.SceneMasks(active, inflow, bcv, bcm, device, pressure_solver=self._pressure_solver)
+        # (holding the two objects keeps their ids from being recycled while they serve as the fast-path key)
+        self._last_masks = (velBCy, velBCyMask, (domain.resolution, str(device)), self._cache[key])
         return self._cache[key]
 
     def step(self, smoke, re, res, velBCy, velBCyMask, dt=1.0, gravity=None):

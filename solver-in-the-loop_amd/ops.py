@@ -173,9 +173,9 @@ AMAX_SLOTS = 256         # SOL_AMAX_SLOTS of csrc/common.hpp (include/sol_hip.h:
 
 
 def absmax_slots(x):
-    assert _lib.load().sol_absmax_slots() == AMAX_SLOTS
     """[AMAX_SLOTS] int32 slots holding the bit pattern of max|x| (the form sol_conv5x5_scaled consumes).  In the fused
     trainer the producing kernel publishes this; here it costs one reduction pass."""
+    assert _lib.load().sol_absmax_slots() == AMAX_SLOTS
     slots = torch.zeros(AMAX_SLOTS, dtype=torch.int32, device=x.device)
     slots[0] = x.detach().abs().max().to(torch.float32).view(torch.int32)
     return slots

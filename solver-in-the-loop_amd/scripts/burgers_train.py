@@ -13,7 +13,7 @@ import random
 import numpy as np
 import torch
 
-from _common import logger
+from _common import logger, select_gpu
 import sol_amd
 from sol_amd import ops, scene, _lib
 from sol_amd.burgers import BurgersTest, TFAdam, to_feature, to_feature_noforce
@@ -44,6 +44,7 @@ def main(argv=None):
     p.add_argument("--inittf", default=None)
     p.add_argument("--tf", default="/tmp/phiflow/tf")
     params = vars(p.parse_args(argv))
+    select_gpu(params["gpu"])
     log = logger(params["log"])
     log.info(params)
     random.seed(params["seed"]); np.random.seed(params["seed"]); torch.manual_seed(params["seed"])

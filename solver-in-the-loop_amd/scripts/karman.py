@@ -9,7 +9,7 @@ import pickle
 import numpy as np
 import torch
 
-from _common import logger
+from _common import logger, select_gpu
 import sol_amd
 from sol_amd import ops, scene
 
@@ -30,6 +30,7 @@ def main(argv=None):
     p.add_argument("-l", "--len", default=100, type=int, help="length of the reference axis")
     p.add_argument("--seed", default=0, type=int, help="seed for random number generator")
     params = vars(p.parse_args(argv))
+    select_gpu(params["gpu"])
     log = logger()
     res = params["res"]
     Y, X = 2 * res, res

@@ -8,7 +8,7 @@ import pickle
 import numpy as np
 import torch
 
-from _common import logger
+from _common import logger, select_gpu
 import sol_amd
 from sol_amd import ops, scene
 
@@ -27,6 +27,7 @@ def main(argv=None):
     p.add_argument("--stats", default="/tmp/phiflow/data/dataStats.pickle", help="path to datastats")
     p.add_argument("--model", default="/tmp/phiflow/tf/model.pt", help="path to a trained model")
     params = vars(p.parse_args(argv))
+    select_gpu(params["gpu"])
     log = logger()
     res = params["res"]
     Y, X = 2 * res, res

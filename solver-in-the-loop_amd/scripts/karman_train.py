@@ -14,7 +14,7 @@ import random
 import numpy as np
 import torch
 
-from _common import logger
+from _common import logger, select_gpu
 import sol_amd
 from sol_amd import ops, scene
 
@@ -45,6 +45,7 @@ def main(argv=None):
     p.add_argument("--pretf", default=None, help="load pre-trained weights (only for testing pre-trained supervised model; do not use for a warm start!)")
     p.add_argument("--tf", default="/tmp/phiflow/tf", help="path to an output dir (model, logs, etc.)")
     params = vars(p.parse_args(argv))
+    select_gpu(params["gpu"])
     rank, world, local = sol_amd.dist.init_from_env()
     if params["resume"] > 0 and params["log"]:
         root, ext = os.path.splitext(params["log"])

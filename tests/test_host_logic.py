@@ -153,3 +153,30 @@ def test_library_staleness_is_decided_by_source_content(tmp_path, monkeypatch):
     assert not _build._stale()
     stamp.write_text("0" * 40 + "\n")
     assert _build._stale()                              # sources changed since the build
+
+
+def test_burgers_forcing_model_and_randfreq():
+    """burgers.py:99-122 forcing model as restated in sol_amd.burgers (recalled PhiFlow semantics behind named variants):
+    closed-form value of a single wave at the staggered sample points, phase advance, both variants, randfreq statistics."""
+    import numpy as np
+    from sol_amd.burgers import SinForces, randfreq
+    rng = np.random.default_rng(3)
+    f = SinForces(rng, num_forces=1)
+    Y = X = 8
+    dx = 0.5
+    a = f.staggered(Y, X, dx)
+    assert a.shape == (1, Y + 1, X + 1, 2) and np.all(a[0, :, X, 0] == 0) and np.all(a[0, Y, :, 1] == 0)
+    k, amp, ph = f.k[0], f.amp[0], f.phase[0]
+    j, i = 3, 5
+    assert np.isclose(a[0, j, i, 0], amp[0] * np.sin(k[0] * j * dx + k[1] * (i + 0.5) * dx + ph))
+    assert np.isclose(a[0, j, i, 1], amp[1] * np.sin(k[0] * (j + 0.5) * dx + k[1] * i * dx + ph))
+    assert 0.8 <= np.linalg.norm(k) <= 1.6 and np.all(np.abs(amp) <= 0.15) and -0.4 <= f.omega[0] <= 0.4
+    f.step(0.1)
+    assert np.isclose(f.phase[0], ph + 0.1 * f.omega[0])
+    g = SinForces(np.random.default_rng(3), num_forces=1, variant="gradient")
+    b = g.staggered(Y, X, dx)
+    assert np.isclose(b[0, j, i, 0], amp[0] * np.cos(k[0] * j * dx + k[1] * (i + 0.5) * dx + ph) * k[0])
+    r = randfreq((33, 32), np.random.default_rng(0))
+    assert r.shape == (33, 32) and abs(r.std() - 1) < 1e-12
+    spec = np.abs(np.fft.fft2(r))
+    assert spec[0:3, 0:3].sum() > 0.9 * spec.sum()              # power 8: essentially the lowest wave numbers
