@@ -165,6 +165,28 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
             for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint2*>(q + pl * PLANE) = make_uint2(p[pl][0], p[pl][1]);
         }
     };
+    // -DSOL_CONV_DMA: tap-row weight sets by LDS-DMA (global_load_lds_dwordx4) instead of register staging.  Measured twice
+    // (round 1 and round 2): correct, but 13.14 -> 13.59 us per launch and 14.43 -> 15.11 ms per training step: off.
+#ifdef SOL_CONV_DMA
+    constexpr bool W_DMA = true;
+#else
+    constexpr bool W_DMA = false;
+#endif
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    typedef __attribute__((address_space(1))) const void glb_cvoid_t;
+    // the packed weights are already in LDS image order: a linear copy of WBUF bytes in 1 KB chunks (64 lanes x 16 B), waves
+    // taking chunks round robin; landed when the next __syncthreads() (which waits vmcnt(0)) has passed
+    auto dma_w = [&](int dy, int buf) {
+        constexpr int CHUNKS = WBUF / 1024;
+        const int wv = tid >> 6;
+#pragma unroll
+        for (int n = 0; n < (CHUNKS + 11) / 12; ++n) {
+            const int c = wv + 12 * n;
+            if (c < CHUNKS)
+                __builtin_amdgcn_global_load_lds((glb_cvoid_t*)(gw + (size_t)dy * WV + c * 64 + lane),
+                                                 (lds_void_t*)(Wt + buf * WBUF + c * 1024), 16, 0, 0);
+        }
+    };
     auto load_w = [&](int dy, uint4 (&v)[WPT]) {
 #pragma unroll
         for (int n = 0; n < WPT; ++n) {
@@ -191,7 +213,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
         if constexpr (KIND == 2) { am = amax_load(a.xmax); winv = reinterpret_cast<const float*>(a.wsh)[1]; }
 #pragma unroll
         for (int n = 0; n < 3; ++n) hv[n] = load_row(G0 - 2 + grp, t + n * 256);
-        load_w(0, wv);
+        if (W_DMA) dma_w(0, 0); else load_w(0, wv);
         if constexpr (KIND == 2) {
             float sai;
             amax_scale_of(am, sa, sai);
@@ -199,7 +221,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
         }
 #pragma unroll
         for (int n = 0; n < 3; ++n) store_row(grp, hv[n], t + n * 256);
-        store_w(0, wv);
+        if (!W_DMA) store_w(0, wv);
     }
     __syncthreads();
     SOL_CSTAMP(1);
@@ -241,7 +263,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
         }
         if (dy < 4) {
             hv = load_row(G0 + dy + 1, tid);          // the one new input row of the next tap row: G0-2 + (dy+1) + 2
-            load_w(dy + 1, wv);
+            if (W_DMA) dma_w(dy + 1, (dy + 1) & 1); else load_w(dy + 1, wv);
         }
         const int src = gy + dy - 2;                  // input row of this tile for this tap row
         if (tvalid && src >= row_lo && src < row_hi) {            // wave uniform
@@ -291,7 +313,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
         }
         if (dy < 4) {
             store_row((dy + 3) & 3, hv, tid);          // slot of row G0 + dy + 1; its previous tenant (row G0+dy-3) is dead
-            store_w((dy + 1) & 1, wv);
+            if (!W_DMA) store_w((dy + 1) & 1, wv);
         }
         __syncthreads();
         SOL_CSTAMP(2 + dy);
