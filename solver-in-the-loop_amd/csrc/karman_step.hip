@@ -267,14 +267,24 @@ __device__ __forceinline__ void cg_block_sum2(float& v0, float& v1, float* slot)
 }
 // workgroup max of a non-negative value (one barrier; `slot` = 16 floats, stale entries must be >= 0 and <= result)
 __device__ __forceinline__ float block_max(float v, float* slot) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    v = __uint_as_float(amax_wave_max(__float_as_uint(v)));      // DPP row operations (non-negative floats order like their bit patterns)
     if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
     __syncthreads();
     float m = 0.f;
     const int nw = (blockDim.x + 63) >> 6;
     for (int w = 0; w < nw; ++w) m = fmaxf(m, slot[w]);
     return m;
+}
+// two workgroup maxima with ONE barrier (`slot`: 32 floats)
+__device__ __forceinline__ void block_max2(float& a, float& b, float* slot) {
+    a = __uint_as_float(amax_wave_max(__float_as_uint(a)));
+    b = __uint_as_float(amax_wave_max(__float_as_uint(b)));
+    if ((threadIdx.x & 63) == 0) { slot[threadIdx.x >> 6] = a; slot[16 + (threadIdx.x >> 6)] = b; }
+    __syncthreads();
+    float ma = 0.f, mb = 0.f;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; ++w) { ma = fmaxf(ma, slot[w]); mb = fmaxf(mb, slot[16 + w]); }
+    a = ma; b = mb;
 }
 __device__ __forceinline__ float sum8lanes(float v) {   // all-reduce over aligned groups of 8 lanes
     v += dpp_mov<0xB1>(v);
@@ -1207,8 +1217,7 @@ __device__ __forceinline__ void karman_bwd_body(const StepArgs& a, float* smem) 
 #pragma unroll
         for (int n = 0; n < MAXT; ++n) gmax = fmaxf(gmax, fmaxf(fabsf(gy[n]), fabsf(gx[n])));
     }
-    smax = block_max(smax, L.red);          // barrier: S staged, accumulators cleared
-    gmax = block_max(gmax, L.red + 16);
+    block_max2(smax, gmax, L.red);          // barrier: S staged, accumulators cleared
     const float bound = 16.f * gmax * fmaxf(1.f, 2.f * a.dtdx * smax);
     const float qs = bound > 0.f ? 2147483648.f / bound : 0.f;      // fixed-point scale
     const float qi = bound > 0.f ? bound / 2147483648.f : 0.f;
