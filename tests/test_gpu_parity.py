@@ -422,6 +422,24 @@ def test_scripts_end_to_end(tmp_path):
         p = load("karman").main(["-o", data, "-r", "32", "-t", "14", "-s", "1", "--re", str(re_nr)])
         assert len([f for f in os.listdir(p) if f.startswith("velo_")]) == 12
     tf = str(tmp_path / "tf")
+    # (a) ONE training step (-t 3 -m 2: a single (batch, step) pair) against the oracle on the very batch the script drew:
+    #     same dataset object, same `random` seed -> same shuffled (sim, frame) pairs; weights = the seed-0 initialisation
+    import random
+    from sol_amd import scene as sc
+    tf1 = str(tmp_path / "tf1")
+    loss1 = load("karman_train").main(["--train", data, "-s", "1", "-n", "2", "-b", "2", "-t", "3", "-m", "2", "-e", "1",
+                                       "--lr", "1e-4", "--tf", tf1, "--seed", "0"])
+    random.seed(0)
+    ds = sc.PhifDataset(data, 3, 2, 2, print_fn=lambda *a: None, scale=1)
+    ds.newEpoch(exclude_tail=2)
+    dens, velo, ext = ds.getData(consecutive_frames=2, with_skip=1)
+    f64 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64)
+    vys, vxs = zip(*[sc.split_staggered(v) for v in velo])
+    ref = o.unrolled_loss(o.init_params(0), f64(dens[0][..., 0]), f64(vys[0]), f64(vxs[0]), f64(np.asarray(ext, dtype=np.float64)),
+                          [f64(v) for v in vys[1:]], [f64(v) for v in vxs[1:]], o.geometry(64, 32),
+                          tuple(float(v) for v in ds.dataStats["std"][1]), float(ds.dataStats["ext.std"][0]))
+    assert loss1 is not None and abs(loss1 - float(ref)) < 2e-5 * abs(float(ref)), (loss1, float(ref))
+    # (b) a longer run for the artefacts
     loss = load("karman_train").main(["--train", data, "-s", "1", "-n", "2", "-b", "2", "-t", "12", "-m", "2", "-e", "1",
                                       "--lr", "1e-4", "--tf", tf, "--seed", "0"])
     assert loss is not None and np.isfinite(loss)
