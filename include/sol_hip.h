@@ -48,8 +48,9 @@ int sol_abi_sizes(int32_t* karman_cfg, int32_t* burgers_cfg, int32_t* train_cfg)
  * new.  Unknown names / out-of-range values return SOL_ERR_ARG.
  *   conv_precision (0)  0: fp32-equivalent split arithmetic on the 16-bit matrix pipe (fp16 x3 where the operand's absmax
  *                          is known, bf16 x6 otherwise); 1: bf16 x6 always; 2: strict fp32 MFMA (v_mfma_f32_*_f32) everywhere
- *   cnn_persistent (0)  the ten 32->32 CNN layers of a pass as ONE persistent launch (neighbour-flag halo exchange) where the
- *                       shape allows it (W == 64, ceil(B*H/3) <= #CUs); measured on par with the per-layer launches
+ *   cnn_persistent (0)  the ten 32->32 CNN layers of a pass as ONE persistent launch (tagged-granule halo exchange between
+ *                       neighbouring workgroups) where the shape allows it (W == 64, ceil(B*H/3) <= #CUs); measured on par
+ *                       with the per-layer launches at B = 6
  *   bww_fuse (1), correct_fuse (1), density_mode (0), conv_thin (1), conv_r3 (1), conv_bww32 (1): fusion / kernel choices
  *   bww_chunk (0), bww_side (1), streams (1), cpt (0), conv_split3 (0), dbg_skip (0), step_prof (0): experiments, debugging */
 int sol_set_option(const char* name, int32_t value);

@@ -3,13 +3,21 @@
 // launch.  One workgroup per CU keeps its three image rows in LDS from layer to layer; only the two halo rows above and
 // below cross workgroups, through global memory with one flag per (layer, workgroup):
 //
-//   producer  epilogue stores its three output rows WRITE-THROUGH (16-byte sc1 buffer stores: the tensors are needed in HBM
-//             anyway -- saved activations / pre-activation gradients); every wave drains (s_waitcnt vmcnt(0)) behind the FIRST
-//             tap step of the next layer, then ONE lane stores the flag (relaxed, agent scope);
-//   consumer  loads both neighbours' flags relaxed at the start of tap step 1, checks them at tap step 2 (spins only if a
-//             neighbour is late), reads the four halo rows with sc1 loads (L2 served; the producer's sc1 stores left no stale
-//             line behind), splits them during tap step 2.
-//   (MI355X_MICROARCH.md, inter-workgroup visibility; cdna_hip_programming.md guideline 16, form R1.)
+//   The hand-off carries its own validity (form R2 of cdna_hip_programming.md guideline 16: "the data IS the flag"), because
+//   a flag costs a second ~2.5 us memory round trip behind the data's and a drain of the producer's stores before it:
+//   producer  after its epilogue knows the row's fp16 scale it writes every (pixel, 4 channels) item of its three rows as ONE
+//             16-byte granule {hi0 lo0 hi1 lo1 | hi2 lo2 hi3 lo3} -- the split planes the consumer needs anyway -- into an
+//             exchange buffer with write-through (sc1) stores.  The least significant bit of every lo half carries a tag bit:
+//             each naturally aligned 8-byte half holds a 2-bit tag (8-byte stores are single-copy atomic), tag = 1 + (write
+//             sequence number of the buffer mod 3); the buffer is double-buffered by layer parity, so the only stale content a
+//             reader can meet (the buffer's previous writer: two layers ago, or the region's previous use one training step ago)
+//             carries a different tag, and zero-filled memory carries 0.
+//             The row's max|y| travels as an 8-byte {bits, tag} word.  No drain, no flag, no fence.
+//   consumer  requests the granules of its four halo rows (sc1 loads, L1 bypassed) after tap step 0, checks the tags after
+//             tap step 2 (re-requests what was not there yet; bounded), strips the tag bits and writes the planes to LDS.
+//   Every reader of a row -- its owner and both neighbours -- uses the lo plane with the tag bit cleared (21 instead of 22
+//   significant bits of the split; the results of neighbouring workgroups stay consistent bit for bit).
+//   (MI355X_MICROARCH.md, inter-workgroup visibility and the hand-off price list.)
 //
 // A layer's 15 (output row, tap row) pairs run own-rows-first: steps 0..2 need only the workgroup's own input rows
 // (row G0+s for all three tiles with tap row dy = 2+s-t), steps 3..4 the halo rows -- 4 us of MFMA work cover the
@@ -119,14 +127,22 @@ __global__ void __launch_bounds__(768) k_cnn_chain(ChainArgs a) {
         if (gr < 0 || gr >= a.nrows || xx < 0 || xx >= W) return -1;
         return ((gr * W + xx) * 8 + c4) * 16;
     };
-    auto write_item = [&](int rr, int e, const float4& v, float sc) {
-        const int hc = e >> 3, c4 = e & 7;
-        unsigned p0[2], p1[2];
+    // planes of one item: hi pairs p0[2], lo pairs p1[2] with the tag bit (LSB of every lo half) cleared
+    auto split_item = [&](const float4& v, float sc, unsigned (&p0)[2], unsigned (&p1)[2]) {
         split2h(v.x, v.y, sc, p0[0], p1[0]);
         split2h(v.z, v.w, sc, p0[1], p1[1]);
+        p1[0] &= 0xfffefffeu; p1[1] &= 0xfffefffeu;
+    };
+    auto put_item = [&](int rr, int e, const unsigned (&p0)[2], const unsigned (&p1)[2]) {
+        const int hc = e >> 3, c4 = e & 7;
         unsigned char* q = rows + ch_slot(rr) * CH_SLOT + hc * 64 + ((((c4 >> 1) ^ swzb(hc)) << 4) | ((c4 & 1) << 3));
         *reinterpret_cast<uint2*>(q) = make_uint2(p0[0], p0[1]);
         *reinterpret_cast<uint2*>(q + CH_PLANE) = make_uint2(p1[0], p1[1]);
+    };
+    auto write_item = [&](int rr, int e, const float4& v, float sc) {
+        unsigned p0[2], p1[2];
+        split_item(v, sc, p0, p1);
+        put_item(rr, e, p0, p1);
     };
 #ifndef SOL_CHAIN_NO_DMA
     constexpr bool CH_DMA = true;                     // weight sets by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write
@@ -264,6 +280,28 @@ __global__ void __launch_bounds__(768) k_cnn_chain(ChainArgs a) {
     // epilogue operands) and the write-through output stores with the MFMA steps they are meant to hide behind.
 #define CH_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
     uint4 stg[4];                                     // staging registers: a different load in every step (see the table below)
+    // per-lane constants of the three halo items (item e = tid + n*768 of 4 rows x 544): kept in registers on purpose -- the
+    // index arithmetic (two divisions, clamps, swizzle) would otherwise run ~100 VALU instructions per layer on 12 waves
+    int h_goff[3], h_loff[3], h_row[3], h_flag[3];    // granule byte offset in a parity block, LDS byte offset, row index, flags
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        const int e = tid + n * 768, k = min(e / 544, 3), it = e - k * 544, rr = k < 2 ? k : k + 3, gr = G0 - 2 + rr;
+        const int hc = it >> 3, c4 = it & 7, xx = hc - 2;
+        const bool in = e < 4 * 544, rowreal = in && gr >= 0 && gr < a.nrows, real = rowreal && xx >= 0 && xx < W;
+        const int grc = min(max(gr, 0), a.nrows - 1), xc = min(max(xx, 0), W - 1);
+        h_goff[n] = ((grc * W + xc) * 8 + c4) * 16;
+        h_row[n] = grc;
+        h_loff[n] = ch_slot(rr) * CH_SLOT + hc * 64 + ((((c4 >> 1) ^ swzb(hc)) << 4) | ((c4 & 1) << 3));
+        h_flag[n] = (in ? 1 : 0) | (real ? 2 : 0) | (rowreal ? 4 : 0) | ((in && it == 0) ? 8 : 0) | (rr << 4);
+    }
+    const unsigned ep = *a.epoch;                     // training-step epoch (written by an earlier launch of the step)
+    // Tag of layer l's hand-off.  Each parity buffer sees the writers l = p, p+2, ... of one launch after those of the region's
+    // previous use (epoch - 1); a reader must reject exactly the writer BEFORE the one it waits for, so the tags follow the
+    // buffer's write sequence number modulo 3 (consecutive writers differ; 0 = never written).
+    const unsigned nw0 = (unsigned)(a.nl) / 2u, nw1 = (unsigned)(a.nl - 1) / 2u;      // writers per launch (layers 0 .. nl-2) with parity 0 / 1
+    auto chain_tag = [&](int l) -> unsigned { return 1u + (ep * ((l & 1) ? nw1 : nw0) + (unsigned)(l >> 1)) % 3u; };
+    const size_t xrow = (size_t)W * 8;                // granules per row
+    const int xbytes = (int)((size_t)2 * a.nrows * xrow * 16);
 #pragma unroll 1
     for (int l = 0; l < a.nl; ++l) {
         const ChainLayer L = a.L[l];
@@ -271,49 +309,40 @@ __global__ void __launch_bounds__(768) k_cnn_chain(ChainArgs a) {
         const uint4* gw = reinterpret_cast<const uint4*>(L.wsh) + 1;
         const uint4* gwn = more ? reinterpret_cast<const uint4*>(a.L[l + 1].wsh) + 1 : gw;
         const float winv = reinterpret_cast<const float*>(L.wsh)[1];
-        unsigned* fl_prev = l > 0 ? a.flags + (size_t)(l - 1) * a.ntiles : nullptr;
-        unsigned* rm_prev = l > 0 ? a.rowmax + (size_t)(l - 1) * a.nrows : nullptr;     // row maxima the producers published with layer l-1
 #pragma unroll
         for (int n = 0; n < 2; ++n) total[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         SOL_CHSTAMP(l, 0);
-        unsigned fu = 1u, fd = 1u;
-        bool halo_pending = l > 0;                    // the four halo rows still have to be fetched (uniform)
+#ifdef CH_EXP_NOHALO                                    // timing experiment only (wrong results): what the layer costs without the exchange
+        const bool exch = false;
+#else
+        const bool exch = l > 0;
+#endif
+        // hand-off of layer l-1's output: parity buffer (l-1)&1, tag 1 + (((l-1)/2 + epoch) mod 3)
+        const unsigned tag_in = chain_tag(l - 1);
+        const int par_in = (l - 1) & 1;
+        unsigned long long hrm[3];                    // {row max bits, tag} of this lane's three halo items' rows
         float4 pres[2], pact[2];
 #pragma unroll
         for (int n = 0; n < 2; ++n) { pres[n] = make_float4(0.f, 0.f, 0.f, 0.f); pact[n] = make_float4(1.f, 1.f, 1.f, 1.f); }
-        // always TWO loads (an edge tile reads its one neighbour twice): the count the step-0 wait below relies on
-        auto flags_load = [&]() {
-            fu = __hip_atomic_load(&fl_prev[has_up ? tile - 1 : tile + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            fd = __hip_atomic_load(&fl_prev[has_dn ? tile + 1 : tile - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        auto flags_ready = [&]() { return __builtin_amdgcn_readfirstlane(fu) != 0u && __builtin_amdgcn_readfirstlane(fd) != 0u; };
-        // the producer stored write-through (sc1) and drained before its flag: sc1 loads (L1 bypassed) read fresh data
-        unsigned hmax[3];                             // row maximum (bits) of this lane's three halo items
-        auto halo_issue = [&](int tidv) {
+        // request (again) the granules + row words of the halo rows: item e -> halo row k (0,1: above; 2,3: below), 544 items per row
+        auto halo_issue = [&]() {
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, xbytes, 0x00020000);
+            const int pbase = par_in * (xbytes >> 1);
 #pragma unroll
-            for (int n = 0; n < 3; ++n) {
-                const int e = tidv + n * 768, k = min(e / 544, 3), gr = G0 - 2 + (k < 2 ? k : k + 3);
-                hmax[n] = (gr >= 0 && gr < a.nrows) ? __hip_atomic_load(&rm_prev[gr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            }
-            const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.L[l - 1].y), 0, (int)tensor_bytes, 0x00020000);
-#pragma unroll
-            for (int n = 0; n < 3; ++n) {
-                const int e = tidv + n * 768;
-                stg[n] = make_uint4(0u, 0u, 0u, 0u);
-                if (e < 4 * 544) {
-                    const int k = e / 544, rr = k < 2 ? k : k + 3, off = item_off(G0 - 2 + rr, e - k * 544);
-                    if (off >= 0) stg[n] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 16));
-                }
+            for (int n = 0; n < 3; ++n) {      // unconditional loads (clamped addresses); items without data are zeroed
+                stg[n] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, pbase + h_goff[n], 0, 16));
+                hrm[n] = __hip_atomic_load(&a.rmx[(size_t)par_in * a.nrows + h_row[n]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(h_flag[n] & 2)) stg[n] = make_uint4(0u, 0u, 0u, 0u);
             }
         };
         // Five tap steps.  Steps 0..2: all three tiles read the own row G0+s (tap row dy = 2+s-t); steps 3, 4: the halo rows.
         // One rolled loop (one copy of the MFMA body):
         //   s   loads issued before the MFMAs                    after them
-        //   0   this layer's weight set 4; neighbours' flags     set 4 staged
-        //   1   --                                               flags ready -> the four halo rows are requested (sc1)
-        //   2   --                                               [late neighbour: wait, request] row maxima; barrier; split + stage them
-        //   3   next layer's set 2; residual / act reference     set 2 staged
-        //   4   next layer's sets 1 and 3                        sets 1, 3 staged
+        //   0   this layer's weight set 4 (LDS-DMA)              DMA landed; the halo granules + row words are requested
+        //   1   --                                               --
+        //   2   --                                               tags checked (re-request until valid), planes -> LDS
+        //   3   next layer's set 2; residual / act reference     --
+        //   4   next layer's sets 1 and 3                        --
         // (next layer's set 0 follows in the epilogue: it is the last one this layer reads.)
 #pragma unroll 1
         for (int s = 0; s < 5; ++s) {
@@ -321,7 +350,6 @@ __global__ void __launch_bounds__(768) k_cnn_chain(ChainArgs a) {
             if (s == 0) {
                 if (CH_DMA) dma_wset(tids, gw, 4);
                 else load_wset(tids, gw, 4, reinterpret_cast<uint4(&)[2]>(stg[0]));
-                if (l > 0) flags_load();
             } else if (s == 3) {
                 if (more) { if (CH_DMA) dma_wset(tids, gwn, 2); else load_wset(tids, gwn, 2, reinterpret_cast<uint4(&)[2]>(stg[0])); }
                 if (tvalid) {
@@ -347,52 +375,58 @@ __global__ void __launch_bounds__(768) k_cnn_chain(ChainArgs a) {
             do_step(dy, rr);
 
             const int tidp = ch_opaque(tid);
-            // the step's LDS-DMA (issued before the MFMAs) has landed; waited BEFORE any halo request goes out.  In step 0 the
-            // two flag loads were issued AFTER the DMA and stay in flight (a flag comes from memory: ~2.5 us): vmcnt(2)
-            if (CH_DMA && s == 0) { if (l > 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            if (CH_DMA && s >= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // the step's LDS-DMA (issued before the MFMAs) has landed; waited BEFORE the halo request goes out
+            // (step 3: the residual / activation-reference loads were issued AFTER the DMA and may stay in flight until the epilogue)
+            if (CH_DMA && (s == 0 || s == 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (CH_DMA && s == 3) {
+                const int nlate = tvalid ? ((L.res ? 2 : 0) + (L.epi == SOL_EPI_DLRELU ? 2 : 0)) : 0;
+                if (nlate == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (nlate == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            }
             if (s == 0) {
                 if (!CH_DMA) store_wset(tidp, 4, reinterpret_cast<uint4(&)[2]>(stg[0]));
-                if (tid == 0) {      // bookkeeping words of this layer (last read before the previous layer's final barrier)
-                    misc[0] = 0u; misc[1] = 0u; misc[5] = 0u; misc[6] = 0u;      // halo row maxima
-                    misc[2] = 0u; misc[3] = 0u; misc[4] = 0u;                    // own (output) row maxima
-                }
-            } else if (s == 1) {
-                if (halo_pending) {
-                    if (flags_ready()) { halo_issue(tidp); halo_pending = false; }
-                    else flags_load();                                            // try again after the next step
-                }
+                if (tid == 0) { misc[2] = 0u; misc[3] = 0u; misc[4] = 0u; }      // own (output) row maxima of this layer
+                if (exch) halo_issue();
             } else if (s == 2) {
-                if (l > 0) {
-                    if (halo_pending) {                                           // a neighbour is late: wait here
-                        unsigned spins = 0;
-                        while (!flags_ready()) {
-                            __builtin_amdgcn_s_sleep(2);
-                            flags_load();
-                            if (++spins > CH_SPIN_LIMIT) {        // never arrived (not resident?): flag the launch and go on
-                                if (lane == 0) atomicOr(a.err, 1u);
-                                break;
-                            }
+                if (exch) {
+                    unsigned spins = 0;
+                    for (;;) {
+                        bool ok = true;
+#pragma unroll
+                        for (int n = 0; n < 3; ++n) {
+                            const uint4 g4 = stg[n];
+                            const unsigned t0 = ((g4.x >> 16) & 1u) | ((g4.y >> 15) & 2u), t1 = ((g4.z >> 16) & 1u) | ((g4.w >> 15) & 2u);
+                            ok = ok && (!(h_flag[n] & 2) || (t0 == tag_in && t1 == tag_in)) && (!(h_flag[n] & 4) || (unsigned)(hrm[n] >> 32) == tag_in);
                         }
-                        halo_issue(tidp);
-                        halo_pending = false;
+                        if (__all(ok)) break;
+                        if (++spins > CH_SPIN_LIMIT) {            // a neighbour never delivered (not resident?): flag the launch and go on
+                            if (lane == 0) atomicOr(a.err, 1u);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(8);
+                        halo_issue();
                     }
-                    const int tidq = ch_opaque(tid);
 #pragma unroll
                     for (int n = 0; n < 3; ++n) {
-                        const int e = tidq + n * 768;
-                        if (e < 4 * 544) {
-                            const int k = e / 544, r2 = k < 2 ? k : k + 3;
-                            float sc, inv;
-                            ch_scale(hmax[n], sc, inv);
-                            write_item(r2, e - k * 544, __builtin_bit_cast(float4, stg[n]), sc);
-                            if (e - k * 544 == 0) rowinv[r2] = inv;
+                        if (h_flag[n] & 1) {
+                            const uint4 g4 = stg[n];
+                            // de-interleave {hi lo hi lo | hi lo hi lo} and strip the tag bits
+                            unsigned char* q = rows + h_loff[n];
+                            *reinterpret_cast<uint2*>(q) = make_uint2((g4.x & 0xffffu) | (g4.y << 16), (g4.z & 0xffffu) | (g4.w << 16));
+                            *reinterpret_cast<uint2*>(q + CH_PLANE) = make_uint2(((g4.x >> 16) | (g4.y & 0xffff0000u)) & 0xfffefffeu,
+                                                                                   ((g4.z >> 16) | (g4.w & 0xffff0000u)) & 0xfffefffeu);
+                            if (h_flag[n] & 8) {
+                                float sc, inv;
+                                ch_scale((h_flag[n] & 4) ? (unsigned)hrm[n] : 0u, sc, inv);
+                                rowinv[h_flag[n] >> 4] = inv;
+                            }
                         }
                     }
                 }
             } else if (s == 3) {
                 if (more && !CH_DMA) store_wset(tidp, 2, reinterpret_cast<uint4(&)[2]>(stg[0]));
-            } else {
+            } else if (s == 4) {
                 if (more && !CH_DMA) { store_wset(tidp, 1, reinterpret_cast<uint4(&)[2]>(stg[0])); store_wset(tidp, 3, reinterpret_cast<uint4(&)[2]>(stg[2])); }
             }
             if (s != 0) CH_BARRIER();      // step 0 stages only weight set 4 (read from step 2 on): the barrier after step 1 covers it
@@ -412,7 +446,6 @@ __global__ void __launch_bounds__(768) k_cnn_chain(ChainArgs a) {
             }
             float4 v[2];
             float vmax = 0.f;
-            const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(L.y, 0, (int)tensor_bytes, 0x00020000);
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int e = lane + n * 64, px = e >> 3, c4 = e & 7;
@@ -427,10 +460,7 @@ __global__ void __launch_bounds__(768) k_cnn_chain(ChainArgs a) {
                 }
                 v[n] = q;
                 vmax = fmaxf(vmax, __uint_as_float(ch_max4(q)));
-                if (tvalid) {
-                    const int off = (((gy * W) + wave * 16 + px) * 8 + c4) * 16;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q), rout, off, 0, 16);       // write-through
-                }
+                if (tvalid) reinterpret_cast<float4*>(L.y)[((size_t)gy * W + wave * 16 + px) * 8 + c4] = q;   // the tensor itself: plain store
             }
             const unsigned rm = ch_wave_max(tvalid ? __float_as_uint(vmax) : 0u);
             if (lane == 0) atomicMax(&misc[2 + grp], rm);
@@ -439,21 +469,34 @@ __global__ void __launch_bounds__(768) k_cnn_chain(ChainArgs a) {
             CH_BARRIER();
             // per-tensor absmax (consumed by the weight-gradient kernels and the thin last layer): one atomic per workgroup
             if (tid == 0 && L.ymax) atomicMax(&L.ymax[blockIdx.x & (SOL_AMAX_SLOTS - 1)], max(max(misc[2], misc[3]), misc[4]));
-            if (more && tvalid && (tide & 255) == 0)        // the row's maximum travels with the row (write-through, drained before the flag)
-                __hip_atomic_store(&a.rowmax[(size_t)l * a.nrows + gy], misc[2 + grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (more) {          // own rows of the next layer's input: split in place with the row's scale
+            if (more) {          // own rows of the next layer's input: split with the row's scale -> own LDS slots AND the hand-off buffer
                 float sc, inv;
-                ch_scale(misc[2 + grp], sc, inv);
+                const unsigned rmax = misc[2 + grp];
+                ch_scale(rmax, sc, inv);
+                const unsigned tag_out = chain_tag(l);
+                const unsigned tb0 = (tag_out & 1u) << 16, tb1 = (tag_out >> 1) << 16;
+                const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, xbytes, 0x00020000);
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     const int e = lane + n * 64, px = e >> 3, c4 = e & 7;
-                    write_item(2 + grp, (wave * 16 + px + 2) * 8 + c4, tvalid ? v[n] : make_float4(0.f, 0.f, 0.f, 0.f), sc);
+                    unsigned p0[2], p1[2];
+                    split_item(tvalid ? v[n] : make_float4(0.f, 0.f, 0.f, 0.f), sc, p0, p1);
+                    put_item(2 + grp, (wave * 16 + px + 2) * 8 + c4, p0, p1);
+                    if (tvalid) {    // granule {hi0 lo0 | hi1 lo1 || hi2 lo2 | hi3 lo3}, tag bits in the lo halves' LSBs
+                        u32x4 gq;
+                        gq.x = (p0[0] & 0xffffu) | (p1[0] << 16) | tb0;
+                        gq.y = (p0[0] >> 16) | (p1[0] & 0xffff0000u) | tb1;
+                        gq.z = (p0[1] & 0xffffu) | (p1[1] << 16) | tb0;
+                        gq.w = (p0[1] >> 16) | (p1[1] & 0xffff0000u) | tb1;
+                        __builtin_amdgcn_raw_buffer_store_b128(gq, rx, (int)((((size_t)(l & 1) * a.nrows + gy) * xrow + (wave * 16 + px) * 8 + c4) * 16), 0, 16);
+                    }
                 }
-                if ((tide & 255) == 0) rowinv[2 + grp] = inv;
-                // publish: EVERY wave's write-through stores have landed, then ONE lane raises this layer's flag
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if ((tide & 255) == 0) {
+                    rowinv[2 + grp] = inv;
+                    if (tvalid) __hip_atomic_store(&a.rmx[(size_t)(l & 1) * a.nrows + gy], ((unsigned long long)tag_out << 32) | rmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (CH_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // next layer's weight set 0 (LDS-DMA) has landed
                 CH_BARRIER();
-                if (tid == 0) __hip_atomic_store(&a.flags[(size_t)l * a.ntiles + tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             SOL_CHSTAMP(l, 7);
         }
@@ -486,17 +529,22 @@ bool sol_cnn_chain_usable(int B, int H, int W) {
     return ntiles >= 2 && ntiles <= chain_cus();
 }
 
-size_t sol_cnn_chain_flag_words(int B, int H, int nl) { return (size_t)nl * ((B * H + 2) / 3) + 64 + (size_t)nl * B * H; }
+// hand-off region of one chain launch, in 32-bit words: 64 (error word) + row words [2 parities][rows] x 8 B + granules
+// [2 parities][rows][64 px][8] x 16 B.  Must be ZERO before its first use (tag 0 = invalid); never needs zeroing again.
+size_t sol_cnn_chain_flag_words(int B, int H, int /*nl*/) { return 64 + (size_t)2 * B * H * 2 + (size_t)2 * B * H * 64 * 8 * 4; }
 
-// flags: sol_cnn_chain_flag_words() zeroed words = [nl][ntiles] flags, 64 words (error word), [nl][rows] published row maxima
-int sol_cnn_chain_launch(hipStream_t s, const ChainLayer* layers, int nl, const float* x0, unsigned* flags, int B, int H, int W, float slope) {
-    SOL_REQUIRE(layers && nl >= 1 && nl <= SOL_CHAIN_MAXL && x0 && flags && sol_cnn_chain_usable(B, H, W), "sol_cnn_chain_launch: bad arguments");
+// region: sol_cnn_chain_flag_words() words (zero before the first use); epoch: device word that changes by one between
+// consecutive uses of the same region (training step counter)
+int sol_cnn_chain_launch(hipStream_t s, const ChainLayer* layers, int nl, const float* x0, unsigned* flags, const unsigned* epoch, int B, int H, int W, float slope) {
+    SOL_REQUIRE(layers && nl >= 1 && nl <= SOL_CHAIN_MAXL && x0 && flags && epoch && sol_cnn_chain_usable(B, H, W), "sol_cnn_chain_launch: bad arguments");
     if (int e = init_chain_kernel()) return e;
     ChainArgs a{};
     for (int l = 0; l < nl; ++l) a.L[l] = layers[l];
     a.nl = nl; a.x0 = x0; a.flags = flags; a.B = B; a.H = H; a.nrows = B * H; a.ntiles = (B * H + 2) / 3; a.slope = slope;
-    a.err = flags + (size_t)nl * a.ntiles;
-    a.rowmax = a.err + 64;
+    a.err = flags;
+    a.epoch = epoch;
+    a.rmx = reinterpret_cast<unsigned long long*>(flags + 64);
+    a.xbuf = reinterpret_cast<uint4*>(flags + 64 + (size_t)2 * a.nrows * 2);
     SOL_LAUNCH(k_cnn_chain, dim3(a.ntiles), dim3(768), (size_t)CH_LDS, s, a);
     SOL_LAUNCH_CHECK();
     return SOL_OK;

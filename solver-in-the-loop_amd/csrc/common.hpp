@@ -74,15 +74,17 @@ struct ChainArgs {
     ChainLayer L[SOL_CHAIN_MAXL];
     int nl;
     const float* x0;        // input of the first layer
-    unsigned* flags;        // [nl][ntiles], zero at launch
-    unsigned* err;          // |= 1 when a neighbour's flag never arrived
-    unsigned* rowmax;       // [nl][rows]: max|y| of every output row (bits), published with the row
+    unsigned* flags;        // hand-off region (sol_cnn_chain_flag_words)
+    unsigned* err;          // |= 1 when a neighbour never delivered
+    const unsigned* epoch;  // training-step epoch (part of the hand-off tag)
+    unsigned long long* rmx;// [2 parities][rows]: {max|y| bits of the row, tag}
+    uint4* xbuf;            // [2 parities][rows][64 px][8]: 16-byte granules of the rows' fp16 planes, tagged
     int B, H, nrows, ntiles;
     float slope;
 };
 bool sol_cnn_chain_usable(int B, int H, int W);
 size_t sol_cnn_chain_flag_words(int B, int H, int nl);
-int sol_cnn_chain_launch(hipStream_t s, const ChainLayer* layers, int nl, const float* x0, unsigned* flags, int B, int H, int W, float slope);
+int sol_cnn_chain_launch(hipStream_t s, const ChainLayer* layers, int nl, const float* x0, unsigned* flags, const unsigned* epoch, int B, int H, int W, float slope);
 // fp16 section of a packed 32-input-channel weight buffer (sol_conv5x5_packed_floats layout)
 const void* sol_conv_packed_wsh(const float* packed, int cout);
 int sol_karman_step_bwd_fused(const sol_karman_cfg* cfg, void* stream,

@@ -213,10 +213,13 @@ struct MemJobs {
     uint32_t* dst[8];
     const uint32_t* src[8];     // nullptr: fill with zero
     size_t words[8];
+    const uint32_t* once[8];    // nullptr, or a control word: the job is skipped when it already holds `once_magic`
+    uint32_t once_magic;
     int n;
 };
 __global__ void k_mem_jobs(MemJobs j) {
     for (int k = 0; k < j.n; ++k) {
+        if (j.once[k] && *j.once[k] == j.once_magic) continue;       // uniform: written by k_chain_tick in an EARLIER launch
         uint32_t* d = j.dst[k];
         const uint32_t* s = j.src[k];
         const size_t n = j.words[k];
@@ -227,9 +230,17 @@ __global__ void k_mem_jobs(MemJobs j) {
             d[e] = s ? s[e] : 0u;
     }
 }
+// control words of the persistent CNN chain's hand-off regions: [0] epoch (one tick per use of the regions), [1] "zeroed" magic
+__global__ void k_chain_tick(uint32_t* ctl, uint32_t magic) {
+    if (threadIdx.x == 0) { ctl[0] = ctl[0] + 1u; ctl[1] = magic; }
+}
 struct MemList {
     MemJobs j{};
     void zero(void* p, size_t bytes) { copy(p, nullptr, bytes); }
+    void zero_once(void* p, size_t bytes, const uint32_t* ctl_magic, uint32_t magic) {      // zero unless *ctl_magic == magic
+        if (j.n < 8) { j.once[j.n] = ctl_magic; j.once_magic = magic; }
+        copy(p, nullptr, bytes);
+    }
     void copy(void* d, const void* s, size_t bytes) {
         if (!d || bytes == 0 || j.n >= 8) return;
         j.dst[j.n] = static_cast<uint32_t*>(d); j.src[j.n] = static_cast<const uint32_t*>(s); j.words[j.n] = bytes / 4; ++j.n;
@@ -301,6 +312,8 @@ struct Ws {
     size_t amax_words;             // (both arrays are contiguous: one memset per training step)
     uint32_t* chain_flags;         // [msteps (or ROLLOUT_AMAX_SETS)][2 passes][chain_words]: hand-off flags of the persistent CNN launches
     size_t chain_words;            // words per chain launch (0: chain not usable for this shape)
+    uint32_t* chain_ctl;           // [0] epoch, [1] magic ("the regions have been zeroed for THIS configuration")
+    uint32_t chain_magic;
     float *gvy[2], *gvx[2];
     float *wf[NL], *wb[NL], *bias[NL];
     float *part[NL];
@@ -334,6 +347,8 @@ size_t carve_ws(const sol_train_cfg* c, float* base, Ws& w, bool training) {
     w.amax_dz = reinterpret_cast<uint32_t*>(take(training ? w.amax_words : 0));
     w.chain_words = sol_cnn_chain_flag_words(B, Y, 10);      // carved whatever the options say: the workspace size must not depend on them
     w.chain_flags = reinterpret_cast<uint32_t*>(take((size_t)(training ? ms : ROLLOUT_AMAX_SETS) * 2 * w.chain_words));
+    w.chain_ctl = reinterpret_cast<uint32_t*>(take(64));
+    w.chain_magic = 0x5017C4A1u ^ ((uint32_t)B * 2654435761u + (uint32_t)Y * 40503u + (uint32_t)X * 97u + (uint32_t)ms * 7u + (training ? 1u : 0u));
     for (int k = 0; k < 2; ++k) { w.gvy[k] = take(w.st_vy); w.gvx[k] = take(w.st_vx); }
     for (int l = 0; l < NL; ++l) {
         const int cin = layer_cin(l), cout = layer_cout(l);
@@ -386,7 +401,7 @@ int net_forward(const sol_train_cfg* c, void* s, const Ws& w, const float* feat,
             L[2 * k] = ChainLayer{sol_conv_packed_wsh(w.wf[1 + 2 * k], 32), w.bias[1 + 2 * k], nullptr, nullptr, act[1 + 2 * k], am(1 + 2 * k), SOL_EPI_LRELU};
             L[2 * k + 1] = ChainLayer{sol_conv_packed_wsh(w.wf[2 + 2 * k], 32), w.bias[2 + 2 * k], act[2 * k], nullptr, act[2 + 2 * k], am(2 + 2 * k), SOL_EPI_LRELU};
         }
-        if (int e = sol_cnn_chain_launch((hipStream_t)s, L, 10, act[0], chain_flags, B, Y, X, sl)) return e;
+        if (int e = sol_cnn_chain_launch((hipStream_t)s, L, 10, act[0], chain_flags, w.chain_ctl, B, Y, X, sl)) return e;
     } else
     for (int k = 0; k < 5; ++k) {
         const float* h = act[2 * k];
@@ -607,7 +622,7 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
                 L[n++] = ChainLayer{sol_conv_packed_wsh(wn.wb[2 + 2 * k], 32), nullptr, nullptr, act[1 + 2 * k], D[1 + 2 * k], am(1 + 2 * k), SOL_EPI_DLRELU};
                 L[n++] = ChainLayer{sol_conv_packed_wsh(wn.wb[1 + 2 * k], 32), nullptr, D[2 + 2 * k], act[2 * k], D[2 * k], am(2 * k), SOL_EPI_DLRELU};
             }
-            if (int e = sol_cnn_chain_launch(hs, L, 10, D[10], w.chain_flags + (size_t)(2 * i + 1) * w.chain_words, B, Y, X, sl)) return e;
+            if (int e = sol_cnn_chain_launch(hs, L, 10, D[10], w.chain_flags + (size_t)(2 * i + 1) * w.chain_words, w.chain_ctl, B, Y, X, sl)) return e;
         } else
         for (int k = 4; k >= 0; --k) {
             const float* h = act[2 * k];
@@ -686,8 +701,14 @@ int train_fwd_bwd_impl(const sol_train_cfg* cfg, hipStream_t hs, const TrainIO& 
         }
         z.zero(w[k].dO4, w[k].cells * 4 * sizeof(float));
         z.zero(w[k].amax_act, 2 * w[k].amax_words * sizeof(uint32_t));                 // activation + gradient absmax slots
-        z.zero(w[k].chain_flags, (size_t)ms * 2 * w[k].chain_words * sizeof(uint32_t)); // hand-off flags of the persistent CNN launches
+        const bool chain = sol_cnn_chain_usable(sub.karman.B, Y, X);
+        // hand-off regions of the persistent CNN launches: zero ONCE (tag 0 = "never written"); afterwards the tags do the work
+        if (chain) z.zero_once(w[k].chain_flags, (size_t)ms * 2 * w[k].chain_words * sizeof(uint32_t), w[k].chain_ctl + 1, w[k].chain_magic);
         if (int e = z.launch(hs)) return e;
+        if (chain) {
+            SOL_LAUNCH(k_chain_tick, dim3(1), dim3(64), 0, hs, w[k].chain_ctl, w[k].chain_magic);
+            SOL_LAUNCH_CHECK();
+        }
     }
     if (S == 1) {
         if (int e = run_chain(&sub, w[0], w[0], B, 0, hs, io)) return e;
@@ -840,9 +861,14 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
                                         iters ? iters + (size_t)i * B : nullptr)) return e;
         if (i % ROLLOUT_AMAX_SETS == 0) {
             MemList z;
-            z.zero(w.chain_flags, (size_t)ROLLOUT_AMAX_SETS * 2 * w.chain_words * sizeof(uint32_t));
+            const bool chain = sol_cnn_chain_usable(B, Y, X);
+            if (chain) z.zero_once(w.chain_flags, (size_t)ROLLOUT_AMAX_SETS * 2 * w.chain_words * sizeof(uint32_t), w.chain_ctl + 1, w.chain_magic);
             z.zero(w.amax_act, w.amax_words * sizeof(uint32_t));
             if (int e = z.launch(hs)) return e;
+            if (chain) {
+                SOL_LAUNCH(k_chain_tick, dim3(1), dim3(64), 0, hs, w.chain_ctl, w.chain_magic);
+                SOL_LAUNCH_CHECK();
+            }
         }
         uint32_t* amax = w.amax_act + (size_t)(i % ROLLOUT_AMAX_SETS) * 11 * SOL_AMAX_SLOTS;
         if (sol_conv_correct_fusable(X)) {

@@ -35,6 +35,7 @@ import bench
 lib = _lib.load()
 lib.sol_chain_prof_set.argtypes = [C.c_void_p]
 dev = torch.device("cuda", 0)
+_lib.set_option("cnn_persistent", 1)
 wl = bench.Workload(sol_amd, dev, 6, 128, 64, 1, 0)
 tr = wl.trainer
 args = (wl.d0, wl.vy0, wl.vx0, wl.re, wl.gt_vy, wl.gt_vx)
