@@ -346,7 +346,7 @@ size_t carve_ws(const sol_train_cfg* c, float* base, Ws& w, bool training) {
     w.amax_act = reinterpret_cast<uint32_t*>(take(w.amax_words));
     w.amax_dz = reinterpret_cast<uint32_t*>(take(training ? w.amax_words : 0));
     w.chain_words = sol_cnn_chain_flag_words(B, Y, 10);      // carved whatever the options say: the workspace size must not depend on them
-    w.chain_flags = reinterpret_cast<uint32_t*>(take((size_t)(training ? ms : ROLLOUT_AMAX_SETS) * 2 * w.chain_words));
+    w.chain_flags = reinterpret_cast<uint32_t*>(take((training ? (size_t)ms * 2 : (size_t)ROLLOUT_AMAX_SETS) * w.chain_words));   // roll-out: forward pass only
     w.chain_ctl = reinterpret_cast<uint32_t*>(take(64));
     w.chain_magic = 0x5017C4A1u ^ ((uint32_t)B * 2654435761u + (uint32_t)Y * 40503u + (uint32_t)X * 97u + (uint32_t)ms * 7u + (training ? 1u : 0u));
     for (int k = 0; k < 2; ++k) { w.gvy[k] = take(w.st_vy); w.gvx[k] = take(w.st_vx); }
@@ -862,7 +862,7 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
         if (i % ROLLOUT_AMAX_SETS == 0) {
             MemList z;
             const bool chain = sol_cnn_chain_usable(B, Y, X);
-            if (chain) z.zero_once(w.chain_flags, (size_t)ROLLOUT_AMAX_SETS * 2 * w.chain_words * sizeof(uint32_t), w.chain_ctl + 1, w.chain_magic);
+            if (chain) z.zero_once(w.chain_flags, (size_t)ROLLOUT_AMAX_SETS * w.chain_words * sizeof(uint32_t), w.chain_ctl + 1, w.chain_magic);
             z.zero(w.amax_act, w.amax_words * sizeof(uint32_t));
             if (int e = z.launch(hs)) return e;
             if (chain) {
@@ -873,9 +873,9 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
         uint32_t* amax = w.amax_act + (size_t)(i % ROLLOUT_AMAX_SETS) * 11 * SOL_AMAX_SLOTS;
         if (sol_conv_correct_fusable(X)) {
             const Correct corr{tvy, tvx, nullptr, nullptr, nullptr};
-            if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, amax, &corr, w.chain_flags + (size_t)(2 * (i % ROLLOUT_AMAX_SETS)) * w.chain_words)) return e;
+            if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, amax, &corr, w.chain_flags + (size_t)(i % ROLLOUT_AMAX_SETS) * w.chain_words)) return e;
         } else {
-            if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, amax, nullptr, w.chain_flags + (size_t)(2 * (i % ROLLOUT_AMAX_SETS)) * w.chain_words)) return e;
+            if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, amax, nullptr, w.chain_flags + (size_t)(i % ROLLOUT_AMAX_SETS) * w.chain_words)) return e;
             SOL_LAUNCH(k_correct_loss, dim3(egrid), dim3(256), 0, hs, tvy, tvx, w.O,
                                (const float*)nullptr, (const float*)nullptr, out_s0(cfg), out_s1(cfg), cfg->std_v0, cfg->std_v1, (float*)nullptr, B, Y, X);
             SOL_LAUNCH_CHECK();
