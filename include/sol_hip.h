@@ -98,7 +98,8 @@ typedef struct sol_karman_cfg {
 
 /* 1 if the two-level CG preconditioner can be used for a Y x X grid, else 0 */
 int sol_karman_precond_supported(int32_t Y, int32_t X);
-/* 1 if the direct pressure solver is built for a Y x X grid (128 x 64), else 0 */
+/* 1 if the direct pressure solver is built for a Y x X grid (128 x 64, and grids of at most 2048 cells with
+ * Y % 16 == 0, X in {16, 32, 64}, e.g. the reference's 64 x 32 training recipe), else 0 */
 int sol_karman_direct_supported(int32_t Y, int32_t X);
 
 /* Forward step for grids beyond the one-workgroup kernels (the reference generates its data at 256 x 128:

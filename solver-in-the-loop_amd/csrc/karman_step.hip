@@ -46,13 +46,19 @@ __host__ __device__ inline int al4(int n) { return (n + 3) & ~3; }
 struct Lds {
     float *Avy, *Avx, *Bvy, *Bvx, *E, *red, *cs;
     unsigned char* act;
+    float* fdx;          // fd_small_floats(Y, X) floats behind the mask (16-byte aligned)
 };
 
 __host__ __device__ inline size_t lds_floats(int Y, int X, int cpt) {
     const int nVy = (Y + 1) * X, nVx = Y * (X + 1);
     return 2 * (size_t)(al4(nVy) + al4(nVx)) + 4 * (size_t)(Y / cpt + 2) * X + 64 + 4 * (size_t)al4(Y * X / 64);
 }
-__host__ inline size_t lds_bytes(int Y, int X, int cpt) { return lds_floats(Y, X, cpt) * 4 + (size_t)al4(Y * X); }
+// extra LDS of the direct pressure solver on SMALL grids (fd_solve_small: Y*X <= 2048): the transform matrices and two
+// field buffers live in LDS there (at 128x64 the register-tiled fd_solve streams them instead)
+__host__ __device__ inline size_t fd_small_floats(int Y, int X) {
+    return (Y * X <= 2048 && Y >= 16 && X >= 16) ? (size_t)Y * Y + (size_t)X * X + (size_t)X * Y + (size_t)X * 16 + 2 * (size_t)Y * X + (size_t)Y * 16 + 256 + 256 + 256 + 256 : 0;
+}
+__host__ inline size_t lds_bytes(int Y, int X, int cpt) { return lds_floats(Y, X, cpt) * 4 + (size_t)al4(Y * X) + fd_small_floats(Y, X) * 4 + 16; }
 
 __device__ inline Lds carve(float* smem, int Y, int X, int cpt) {
     const int nVy = (Y + 1) * X, nVx = Y * (X + 1);
@@ -65,6 +71,7 @@ __device__ inline Lds carve(float* smem, int Y, int X, int cpt) {
     l.red = l.E + 4 * (Y / cpt + 2) * X;
     l.cs = l.red + 64;                                    // coarse-space scratch: rc[2], rcM, zc
     l.act = reinterpret_cast<unsigned char*>(l.cs + 4 * al4(Y * X / 64));
+    l.fdx = reinterpret_cast<float*>(l.act + ((al4(Y * X) + 15) & ~15));
     return l;
 }
 
@@ -751,6 +758,127 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
     return B1;
 }
 
+// ---- the same direct solve for small grids (Y*X <= 2048, e.g. the reference's 64x32 training recipe,
+//      /root/reference/karman-2d/Makefile:78-80), any thread count ---------------------------------------------------------
+// Follows precond.direct_solve_reference line by line:  T2 = (Qy b Qx) / lam;  x0w = Qy[win,:] T2 Qx[:,win];
+// x_S = gather;  c = K' x_S;  W2 = -scatter(c);  T2 += (Qy[:,win] W2 Qx[win,:]) / lam;  x = Qy T2 Qx.
+// Everything is LDS resident (the matrices are copied in first: 30 KB at 64x32); each product runs as 4x4 register tiles
+// C[M][N] = sum_k At[k][M] B[k][N] with both operands read as 16-byte pieces (Qy, Qx are symmetric, so a transposed operand
+// is the matrix itself; intermediate results are stored in the orientation their consumer needs).
+__device__ __forceinline__ float* fd_solve_small(const float* __restrict__ blob, int Y, int X, const Own& o, float* ext, const float (&rf)[16]) {
+    const int* h = reinterpret_cast<const int*>(blob);
+    const int wy0 = h[3], wx0 = h[4], SP = h[6];
+    const float* gQy = blob + 16;
+    const float* gQx = gQy + (size_t)Y * Y;
+    const float* gIL = gQx + (size_t)X * X;            // [c][m]
+    const float* gKp = gIL + (size_t)X * Y;            // KpT [SP][SP]
+    const int* gsidx = reinterpret_cast<const int*>(gKp + (size_t)SP * SP);
+    const float* gQW = reinterpret_cast<const float*>(gsidx + SP);      // [c][16]
+    float* LQy = ext;
+    float* LQx = LQy + Y * Y;
+    float* LIL = LQx + X * X;
+    float* LQW = LIL + X * Y;
+    float* B0 = LQW + X * 16;          // [Y][X] / [X][Y]
+    float* B1 = B0 + Y * X;
+    float* U = B1 + Y * X;             // [Y][16] / [16][Y]
+    float* XW = U + Y * 16;            // [16][16]
+    float* W2 = XW + 256;
+    float* XS = W2 + 256;              // [SP] (SP <= 256)
+    float* CP = XS + 256;
+    const int tid = threadIdx.x, T = blockDim.x;
+    // matrices -> LDS (16-byte pieces; the blob sections are 16-byte aligned: header 16 words, Y, X multiples of 4)
+    {
+        const int n4 = (Y * Y + X * X + X * Y) / 4;
+        const float4* src = reinterpret_cast<const float4*>(gQy);
+        float4* dst = reinterpret_cast<float4*>(LQy);
+        for (int e = tid; e < n4; e += T) dst[e] = src[e];
+        for (int e = tid; e < X * 16; e += T) LQW[e] = gQW[e];
+        for (int e = tid; e < 256; e += T) W2[e] = 0.f;
+    }
+    if (o.owner) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) B0[(o.j0 + k) * X + o.i] = rf[k];
+    }
+    __syncthreads();
+    // C tile loop: MODE 0: C[m][n] = v;  1: Ct[n][m] = v;  2: Ct[n][m] = v * S[n][m];  3: Ct[n][m] += v * S[n][m]
+    auto mm = [&](const float* At, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K, int mode, const float* S) {
+        const int tn = N >> 2, tiles = (M >> 2) * tn;
+        for (int t = tid; t < tiles; t += T) {
+            const int m0 = (t / tn) << 2, n0 = (t % tn) << 2;
+            float acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+#pragma unroll 4
+            for (int k = 0; k < K; ++k) {
+                const float4 av = *reinterpret_cast<const float4*>(At + k * lda + m0);
+                const float4 bv = *reinterpret_cast<const float4*>(Bm + k * ldb + n0);
+                const float aa[4] = {av.x, av.y, av.z, av.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] += aa[i] * bb[j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (mode == 0) C[(m0 + i) * ldc + n0 + j] = acc[i][j];
+                    else if (mode == 1) C[(n0 + j) * ldc + m0 + i] = acc[i][j];
+                    else if (mode == 2) C[(n0 + j) * ldc + m0 + i] = acc[i][j] * S[(n0 + j) * ldc + m0 + i];
+                    else C[(n0 + j) * ldc + m0 + i] += acc[i][j] * S[(n0 + j) * ldc + m0 + i];
+                }
+        }
+    };
+    mm(LQy, Y, B0, X, B1, Y, Y, X, Y, 1, nullptr);          // P1t[c][j] = (Qy b)^T
+    __syncthreads();
+    mm(B1, Y, LQx, X, B0, Y, Y, X, X, 2, LIL);              // T2t[c][m] = (P1 Qx)[m][c] / lam
+    __syncthreads();
+    mm(B0, Y, LQW, 16, U, 16, Y, 16, X, 0, nullptr);        // u[m][i'] = sum_c T2[m][c] Qx[c][wx0+i']
+    __syncthreads();
+    for (int e = tid; e < 256; e += T) {                    // x0w[j'][i'] = sum_m Qy[wy0+j'][m] u[m][i']  (window offset: scalar reads)
+        const int jw = e >> 4, iw = e & 15;
+        const float* q = LQy + (wy0 + jw) * Y;
+        float sacc = 0.f;
+        for (int m = 0; m < Y; ++m) sacc += q[m] * U[m * 16 + iw];
+        XW[e] = sacc;
+    }
+    __syncthreads();
+    for (int e = tid; e < SP; e += T) { const int si = gsidx[e]; XS[e] = si >= 0 ? XW[si] : 0.f; }
+    __syncthreads();
+    for (int e = tid; e < SP; e += T) {                     // c = K' x_S
+        float sacc = 0.f;
+        for (int q = 0; q < SP; ++q) sacc += gKp[(size_t)q * SP + e] * XS[q];
+        CP[e] = sacc;
+    }
+    __syncthreads();
+    for (int e = tid; e < SP; e += T) { const int si = gsidx[e]; if (si >= 0) W2[si] = -CP[e]; }
+    __syncthreads();
+    for (int e = tid; e < Y * 16; e += T) {                 // t2wT[i'][m] = sum_j' Qy[m][wy0+j'] W2[j'][i']
+        const int iw = e / Y, m = e - iw * Y;
+        const float* q = LQy + m * Y + wy0;
+        float sacc = 0.f;
+#pragma unroll
+        for (int jw = 0; jw < 16; ++jw) sacc += q[jw] * W2[jw * 16 + iw];
+        U[iw * Y + m] = sacc;
+    }
+    __syncthreads();
+    for (int e = tid; e < X * Y; e += T) {                  // T2t[c][m] += (sum_i' t2w[m][i'] Qx[wx0+i'][c]) / lam
+        const int c = e / Y, m = e - c * Y;
+        float sacc = 0.f;
+#pragma unroll
+        for (int iw = 0; iw < 16; ++iw) sacc += U[iw * Y + m] * LQx[(wx0 + iw) * X + c];
+        B0[e] += sacc * LIL[e];
+    }
+    __syncthreads();
+    mm(B0, Y, LQx, X, B1, X, Y, X, X, 0, nullptr);          // P3[m][c] = T2 Qx
+    __syncthreads();
+    mm(LQy, Y, B1, X, B0, X, Y, X, Y, 0, nullptr);          // x[j][c] = Qy P3
+    __syncthreads();
+    return B0;
+}
+
 // per-cell matrix coefficients of the owned strip
 template <int CPT>
 __device__ __forceinline__ void cell_coeffs(const Own& o, const unsigned char* act, int Y, int X,
@@ -912,7 +1040,7 @@ __device__ __forceinline__ void karman_fwd_body(const StepArgs& a, float* smem) 
     float qys[FD_Y / 16];           // direct solver: this wave's slice of Qy (L2-warm: fd_prefetch), in flight behind the setup
 #pragma unroll
     for (int j = 0; j < FD_Y / 16; ++j) qys[j] = 0.f;
-    if constexpr (SOLVER == 2) fd_load_slice<FD_Y>(a.fd + 16, __builtin_amdgcn_readfirstlane(tid >> 6), qys);
+    if constexpr (SOLVER == 2) { if (Y == FD_Y) fd_load_slice<FD_Y>(a.fd + 16, __builtin_amdgcn_readfirstlane(tid >> 6), qys); }
     const Own o = ownership<CPT>(Y, X);
     float dg[CPT], ac[CPT], r[CPT], x[CPT];
     cell_coeffs<CPT>(o, L.act, Y, X, dg, ac);
@@ -928,8 +1056,8 @@ __device__ __forceinline__ void karman_fwd_body(const StepArgs& a, float* smem) 
     int it = 0;
     float* Pfd = nullptr;           // direct solver: the solution arrives as an LDS array
     SOL_STAMP(5);
-    if constexpr (SOLVER == 2) {            // host guarantees Y == 128, X == 64
-        Pfd = fd_solve(a.fd, qys, L.Bvy, r, a.prof);
+    if constexpr (SOLVER == 2) {            // host guarantees 128 x 64 (register-tiled) or a small grid (LDS resident)
+        if constexpr (CPT == 16) Pfd = Y == FD_Y ? fd_solve(a.fd, qys, L.Bvy, r, a.prof) : fd_solve_small(a.fd, Y, X, o, L.fdx, r);
     } else if constexpr (SOLVER == 1) {
         it = X == 64 ? pcg_solve<CPT, true, 32>(o, Y, X, L.act, dg, ac, r, x, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter)
                      : pcg_solve<CPT, false, 8>(o, Y, X, L.act, dg, ac, r, x, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter);
@@ -1121,7 +1249,7 @@ __device__ __forceinline__ void karman_bwd_body(const StepArgs& a, float* smem) 
     float qys[FD_Y / 16];
 #pragma unroll
     for (int j = 0; j < FD_Y / 16; ++j) qys[j] = 0.f;
-    if constexpr (SOLVER == 2) fd_load_slice<FD_Y>(a.fd + 16, __builtin_amdgcn_readfirstlane(tid >> 6), qys);
+    if constexpr (SOLVER == 2) { if (Y == FD_Y) fd_load_slice<FD_Y>(a.fd + 16, __builtin_amdgcn_readfirstlane(tid >> 6), qys); }
     const Own o = ownership<CPT>(Y, X);
     float dg[CPT], ac[CPT], r[CPT], z[CPT];
     cell_coeffs<CPT>(o, L.act, Y, X, dg, ac);
@@ -1141,8 +1269,8 @@ __device__ __forceinline__ void karman_bwd_body(const StepArgs& a, float* smem) 
     int it = 0;
     float* Pfd = nullptr;
     SOL_STAMP(2);
-    if constexpr (SOLVER == 2) {            // host guarantees Y == 128, X == 64
-        Pfd = fd_solve(a.fd, qys, L.Bvy, r, a.prof);
+    if constexpr (SOLVER == 2) {
+        if constexpr (CPT == 16) Pfd = Y == FD_Y ? fd_solve(a.fd, qys, L.Bvy, r, a.prof) : fd_solve_small(a.fd, Y, X, o, L.fdx, r);
     } else if constexpr (SOLVER == 1) {
         it = X == 64 ? pcg_solve<CPT, true, 32>(o, Y, X, L.act, dg, ac, r, z, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter)
                      : pcg_solve<CPT, false, 8>(o, Y, X, L.act, dg, ac, r, z, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter);
@@ -1473,8 +1601,9 @@ int check_cfg(const sol_karman_cfg* c) {
     SOL_REQUIRE(lds_bytes(c->Y, c->X, cpt) <= 160 * 1024, "grid %dx%d does not fit the 160 KiB LDS", c->Y, c->X);
     SOL_REQUIRE(c->dx > 0.f && c->cg_max_iter >= 0, "dx must be > 0 and cg_max_iter >= 0");
     if (c->direct) {
-        SOL_REQUIRE(c->Y == FD_Y && c->X == FD_X && cpt == 16, "the direct pressure solver is built for 128x64 grids only (got %dx%d)", c->Y, c->X);
-        SOL_REQUIRE(c->direct_n >= 16 + FD_Y * FD_Y + FD_X * FD_X + FD_X * FD_Y + 64 * 64 + 64 + FD_X * FD_WIN,
+        SOL_REQUIRE(((c->Y == FD_Y && c->X == FD_X) || fd_small_floats(c->Y, c->X) > 0) && cpt == 16,
+                    "the direct pressure solver is built for 128x64 and for grids of at most 2048 cells with Y %% 16 == 0, X >= 16 (got %dx%d)", c->Y, c->X);
+        SOL_REQUIRE(c->direct_n >= 16 + c->Y * c->Y + c->X * c->X + c->X * c->Y + 64 * 64 + 64 + c->X * FD_WIN,
                     "direct_n = %d is too small for a direct-solver blob", c->direct_n);
     }
     if (c->coarse_inv) {
@@ -1576,7 +1705,9 @@ int sol_density_chain(const sol_karman_cfg* c, void* stream, int ms, const float
 }
 
 extern "C" int sol_karman_precond_supported(int32_t Y, int32_t X) { return precond_ok(Y, X) ? 1 : 0; }
-extern "C" int sol_karman_direct_supported(int32_t Y, int32_t X) { return (Y == FD_Y && X == FD_X) ? 1 : 0; }
+extern "C" int sol_karman_direct_supported(int32_t Y, int32_t X) {
+    return ((Y == FD_Y && X == FD_X) || (fd_small_floats(Y, X) > 0 && Y % 16 == 0 && (X == 16 || X == 32 || X == 64))) ? 1 : 0;
+}
 
 static int step_fwd_impl(const sol_karman_cfg* cfg, void* stream,
                                    const float* d_in, const float* vy_in, const float* vx_in,

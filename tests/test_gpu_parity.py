@@ -52,9 +52,9 @@ def _loaded_native_library():
 def test_karman_step_against_golden(golden_dir, name, kw, precond):
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     B, Y, X = z["d"].shape
-    g, mk = masks_for(Y, X, precond)
+    g, mk = masks_for(Y, X, precond, "cg")                          # the iterative solvers (the direct one: next test)
     assert (mk.coarse_inv is not None) == (precond and Y >= 64)     # two-level CG only where the grid allows it
-    assert mk.direct is None                                        # the direct solver is built for 128x64
+    assert mk.direct is None
     cfg = ops.karman_cfg(B, Y, X, g.dx, masks=mk, **kw)
     vy = f32(z["vy"]).requires_grad_(True)
     vx = f32(z["vx"]).requires_grad_(True)
@@ -64,6 +64,30 @@ def test_karman_step_against_golden(golden_dir, name, kw, precond):
     assert rel(d2, z["d_out"]) < TOL_FIELD and rel(py, z["vy_out"]) < TOL_FIELD and rel(px, z["vx_out"]) < TOL_FIELD
     assert rel(vy.grad, z["g_vy"]) < TOL_GRAD and rel(vx.grad, z["g_vx"]) < TOL_GRAD
     assert int(info["iterations"].min()) > 5 and int(info["iterations"].max()) < 2000
+
+
+def test_direct_solver_at_the_reference_training_size(golden_dir):
+    """64x32 (the reference's own recipe, karman-2d/Makefile:78-80; BASELINE configs[1]): the direct pressure solver's
+    small-grid form (LDS-resident sine transforms + capacitance correction) -- no CG iteration at all -- against the golden
+    step (fields and input gradients) and against the preconditioned CG on the same inputs."""
+    z = np.load(os.path.join(golden_dir, "karman_step_64x32.npz"))
+    B, Y, X = z["d"].shape
+    g, mk = masks_for(Y, X)                                          # "auto": direct where it is built
+    assert mk.direct is not None and sol_amd.load().sol_karman_direct_supported(Y, X) == 1
+    assert sol_amd.load().sol_karman_direct_supported(16, 8) == 0
+    cfg = ops.karman_cfg(B, Y, X, g.dx, masks=mk)
+    vy = f32(z["vy"]).requires_grad_(True)
+    vx = f32(z["vx"]).requires_grad_(True)
+    info = {}
+    d2, py, px = ops.karman_step(f32(z["d"]), vy, vx, f32(z["re"]), cfg, mk, info)
+    ((py * f32(z["wy"])).sum() + (px * f32(z["wx"])).sum()).backward()
+    assert int(info["iterations"].max()) == 0 and int(info["iterations_bwd"].max()) == 0
+    assert rel(d2, z["d_out"]) < TOL_FIELD and rel(py, z["vy_out"]) < TOL_FIELD and rel(px, z["vx_out"]) < TOL_FIELD
+    assert rel(vy.grad, z["g_vy"]) < TOL_GRAD and rel(vx.grad, z["g_vx"]) < TOL_GRAD
+    g2, mk2 = masks_for(Y, X, True, "cg")
+    cfg2 = ops.karman_cfg(B, Y, X, g.dx, masks=mk2)
+    _, qy, qx = ops.karman_step(f32(z["d"]), f32(z["vy"]), f32(z["vx"]), f32(z["re"]), cfg2, mk2)
+    assert rel(py, qy) < TOL_FIELD and rel(px, qx) < TOL_FIELD
 
 
 @pytest.mark.parametrize("B,solver", [(1, "direct"), (2, "direct"), (1, "pcg"), (2, "pcg"), (2, "cg")])
