@@ -56,7 +56,7 @@ __host__ __device__ inline size_t lds_floats(int Y, int X, int cpt) {
 // extra LDS of the direct pressure solver on SMALL grids (fd_solve_small: Y*X <= 2048): the transform matrices and two
 // field buffers live in LDS there (at 128x64 the register-tiled fd_solve streams them instead)
 __host__ __device__ inline size_t fd_small_floats(int Y, int X) {
-    return (Y * X <= 2048 && Y >= 16 && X >= 16) ? (size_t)Y * Y + (size_t)X * X + (size_t)X * Y + (size_t)X * 16 + 2 * (size_t)Y * X + (size_t)Y * 16 + 256 + 256 + 256 + 256 : 0;
+    return (Y * X <= 2048 && Y >= 16 && X >= 16) ? (size_t)Y * Y + (size_t)X * X + (size_t)X * Y + (size_t)X * 16 + 2 * (size_t)Y * X + (size_t)Y * 16 + 256 + 256 + 256 + 256 + 4096 + (size_t)Y * 16 : 0;
 }
 __host__ inline size_t lds_bytes(int Y, int X, int cpt) { return lds_floats(Y, X, cpt) * 4 + (size_t)al4(Y * X) + fd_small_floats(Y, X) * 4 + 16; }
 
@@ -765,6 +765,36 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
 // Everything is LDS resident (the matrices are copied in first: 30 KB at 64x32); each product runs as 4x4 register tiles
 // C[M][N] = sum_k At[k][M] B[k][N] with both operands read as 16-byte pieces (Qy, Qx are symmetric, so a transposed operand
 // is the matrix itself; intermediate results are stored in the orientation their consumer needs).
+// stage the matrices of the blob into the solver's LDS region; called at kernel start so that the copies travel behind the
+// diffusion / advection phases (nothing else touches `ext`); the solve begins with a barrier
+__device__ __forceinline__ void fd_small_stage(const float* __restrict__ blob, int Y, int X, float* ext) {
+    const int* h = reinterpret_cast<const int*>(blob);
+    const int SP = h[6];
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int n4 = (Y * Y + X * X + X * Y) / 4;              // Qy, Qx, 1/lam: contiguous in the blob and in LDS
+    const float4* src = reinterpret_cast<const float4*>(blob + 16);
+    float4* dst = reinterpret_cast<float4*>(ext);
+#pragma unroll 8
+    for (int e = tid; e < n4; e += T) dst[e] = src[e];
+    const float* gKp = blob + 16 + (size_t)Y * Y + (size_t)X * X + (size_t)X * Y;
+    const float* gQW = gKp + (size_t)SP * SP + SP;
+    float* LQW = ext + Y * Y + X * X + X * Y;
+    float* W2 = LQW + X * 16 + 2 * Y * X + Y * 16 + 256;
+    float* KP = W2 + 256 + 256 + 256;
+#pragma unroll 4
+    for (int e = tid; e < X * 16; e += T) LQW[e] = gQW[e];
+    for (int e = tid; e < 256; e += T) W2[e] = 0.f;
+    if (SP <= 64) {
+#pragma unroll 8
+        for (int e = tid; e < SP * SP / 4; e += T) reinterpret_cast<float4*>(KP)[e] = reinterpret_cast<const float4*>(gKp)[e];
+    }
+    // QyW[m][j'] = Qy[m][wy0 + j'] (= Qy[wy0 + j'][m]: symmetric): the window rows as one compact, 16-byte aligned slab
+    float* QyW = KP + 4096;
+    const int wy0 = h[3];
+    const float* gQy = blob + 16;
+#pragma unroll 4
+    for (int e = tid; e < Y * 16; e += T) QyW[e] = gQy[(size_t)(wy0 + (e & 15)) * Y + (e >> 4)];
+}
 __device__ __forceinline__ float* fd_solve_small(const float* __restrict__ blob, int Y, int X, const Own& o, float* ext, const float (&rf)[16]) {
     const int* h = reinterpret_cast<const int*>(blob);
     const int wy0 = h[3], wx0 = h[4], SP = h[6];
@@ -785,16 +815,10 @@ __device__ __forceinline__ float* fd_solve_small(const float* __restrict__ blob,
     float* W2 = XW + 256;
     float* XS = W2 + 256;              // [SP] (SP <= 256)
     float* CP = XS + 256;
+    float* KP = CP + 256;              // K'^T [SP][SP] when SP <= 64 (fd_small_stage)
+    float* QyW = KP + 4096;            // [Y][16] window rows of Qy
     const int tid = threadIdx.x, T = blockDim.x;
-    // matrices -> LDS (16-byte pieces; the blob sections are 16-byte aligned: header 16 words, Y, X multiples of 4)
-    {
-        const int n4 = (Y * Y + X * X + X * Y) / 4;
-        const float4* src = reinterpret_cast<const float4*>(gQy);
-        float4* dst = reinterpret_cast<float4*>(LQy);
-        for (int e = tid; e < n4; e += T) dst[e] = src[e];
-        for (int e = tid; e < X * 16; e += T) LQW[e] = gQW[e];
-        for (int e = tid; e < 256; e += T) W2[e] = 0.f;
-    }
+    (void)gQy; (void)gQW;
     if (o.owner) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) B0[(o.j0 + k) * X + o.i] = rf[k];
@@ -827,7 +851,8 @@ __device__ __forceinline__ float* fd_solve_small(const float* __restrict__ blob,
                     if (mode == 0) C[(m0 + i) * ldc + n0 + j] = acc[i][j];
                     else if (mode == 1) C[(n0 + j) * ldc + m0 + i] = acc[i][j];
                     else if (mode == 2) C[(n0 + j) * ldc + m0 + i] = acc[i][j] * S[(n0 + j) * ldc + m0 + i];
-                    else C[(n0 + j) * ldc + m0 + i] += acc[i][j] * S[(n0 + j) * ldc + m0 + i];
+                    else if (mode == 3) C[(n0 + j) * ldc + m0 + i] += acc[i][j] * S[(n0 + j) * ldc + m0 + i];
+                    else C[(m0 + i) * ldc + n0 + j] += acc[i][j] * S[(m0 + i) * ldc + n0 + j];      // 4: in place, not transposed
                 }
         }
     };
@@ -837,40 +862,32 @@ __device__ __forceinline__ float* fd_solve_small(const float* __restrict__ blob,
     __syncthreads();
     mm(B0, Y, LQW, 16, U, 16, Y, 16, X, 0, nullptr);        // u[m][i'] = sum_c T2[m][c] Qx[c][wx0+i']
     __syncthreads();
-    for (int e = tid; e < 256; e += T) {                    // x0w[j'][i'] = sum_m Qy[wy0+j'][m] u[m][i']  (window offset: scalar reads)
-        const int jw = e >> 4, iw = e & 15;
-        const float* q = LQy + (wy0 + jw) * Y;
-        float sacc = 0.f;
-        for (int m = 0; m < Y; ++m) sacc += q[m] * U[m * 16 + iw];
-        XW[e] = sacc;
-    }
+    mm(QyW, 16, U, 16, XW, 16, 16, 16, Y, 0, nullptr);      // x0w[j'][i'] = sum_m Qy[wy0+j'][m] u[m][i']
     __syncthreads();
     for (int e = tid; e < SP; e += T) { const int si = gsidx[e]; XS[e] = si >= 0 ? XW[si] : 0.f; }
     __syncthreads();
     for (int e = tid; e < SP; e += T) {                     // c = K' x_S
         float sacc = 0.f;
-        for (int q = 0; q < SP; ++q) sacc += gKp[(size_t)q * SP + e] * XS[q];
+        if (SP <= 64) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
+            for (int q = 0; q < SP; q += 4) {
+                s0 += KP[q * SP + e] * XS[q]; s1 += KP[(q + 1) * SP + e] * XS[q + 1];
+                s2 += KP[(q + 2) * SP + e] * XS[q + 2]; s3 += KP[(q + 3) * SP + e] * XS[q + 3];
+            }
+            sacc = (s0 + s1) + (s2 + s3);
+        } else {
+#pragma unroll 16
+            for (int q = 0; q < SP; ++q) sacc += gKp[(size_t)q * SP + e] * XS[q];      // loads issued 16 deep
+        }
         CP[e] = sacc;
     }
     __syncthreads();
     for (int e = tid; e < SP; e += T) { const int si = gsidx[e]; if (si >= 0) W2[si] = -CP[e]; }
     __syncthreads();
-    for (int e = tid; e < Y * 16; e += T) {                 // t2wT[i'][m] = sum_j' Qy[m][wy0+j'] W2[j'][i']
-        const int iw = e / Y, m = e - iw * Y;
-        const float* q = LQy + m * Y + wy0;
-        float sacc = 0.f;
-#pragma unroll
-        for (int jw = 0; jw < 16; ++jw) sacc += q[jw] * W2[jw * 16 + iw];
-        U[iw * Y + m] = sacc;
-    }
+    mm(LQy + wy0 * Y, Y, W2, 16, U, Y, Y, 16, 16, 1, nullptr);      // t2wT[i'][m] = sum_j' Qy[wy0+j'][m] W2[j'][i']
     __syncthreads();
-    for (int e = tid; e < X * Y; e += T) {                  // T2t[c][m] += (sum_i' t2w[m][i'] Qx[wx0+i'][c]) / lam
-        const int c = e / Y, m = e - c * Y;
-        float sacc = 0.f;
-#pragma unroll
-        for (int iw = 0; iw < 16; ++iw) sacc += U[iw * Y + m] * LQx[(wx0 + iw) * X + c];
-        B0[e] += sacc * LIL[e];
-    }
+    mm(LQx + wx0 * X, X, U, Y, B0, Y, X, Y, 16, 4, LIL);            // T2t[c][m] += (sum_i' Qx[wx0+i'][c] t2w[m][i']) / lam
     __syncthreads();
     mm(B0, Y, LQx, X, B1, X, Y, X, X, 0, nullptr);          // P3[m][c] = T2 Qx
     __syncthreads();
@@ -912,7 +929,10 @@ __device__ __forceinline__ void karman_fwd_body(const StepArgs& a, float* smem) 
 
     SOL_STAMP(0);
     float fdp = 0.f;
-    if constexpr (SOLVER == 2) fdp = fd_prefetch(a.fd, a.fd_n);
+    if constexpr (SOLVER == 2) {
+        if (Y == FD_Y) fdp = fd_prefetch(a.fd, a.fd_n);
+        else if constexpr (CPT == 16) fd_small_stage(a.fd, Y, X, L.fdx);
+    }
     // ---- phase 1: load inputs (all global loads in flight before the first LDS store) ---
     // 16-byte loads: a dword load costs the texture path as much per wave as a dwordx4 one, and this phase is nothing else
     // (X, Y are multiples of 4, so every array and every batch offset is 16-byte aligned and a v_y quad stays in one row)
@@ -1194,7 +1214,10 @@ __device__ __forceinline__ void karman_bwd_body(const StepArgs& a, float* smem) 
 
     SOL_STAMP(0);
     float fdp = 0.f;
-    if constexpr (SOLVER == 2) fdp = fd_prefetch(a.fd, a.fd_n);
+    if constexpr (SOLVER == 2) {
+        if (Y == FD_Y) fdp = fd_prefetch(a.fd, a.fd_n);
+        else if constexpr (CPT == 16) fd_small_stage(a.fd, Y, X, L.fdx);
+    }
     // ---- 1: load incoming gradient (+ feature gradient): all global loads in flight first --------
     {
         const float* gy = a.g_vy_out + (size_t)b * nVy;
