@@ -24,7 +24,7 @@ int sol_bww_batched(void* stream, const float* x, const float* dz, float* partia
                     long x_seg, long dz_seg, int B, int H, int W, int cin, int cout,
                     const unsigned* xmax = nullptr, const unsigned* zmax = nullptr, long xmax_seg = 0, long zmax_seg = 0);
 int sol_bww_batched_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int nseg, int B, int H,
-                           int cin, int cout, int accumulate);
+                           int cin, int cout, int accumulate, int taps_transposed = 0);
 
 // forward / backward-data convolution arguments (conv5x5.hip, conv5x5_sb.hip)
 struct ConvArgs {
@@ -110,7 +110,7 @@ size_t sol_bww_step_ws_floats(int B, int H, int rb);
 size_t sol_conv_sb_packed_floats(int OP);
 size_t sol_conv_sh_packed_floats(int OP);
 int sol_pack_jobs(hipStream_t s, int n, const float* const* w, float* const* out, float* const* bias_out, const float* const* bias_in,
-                  const int* cin, const int* cout, const int* mode);
+                  const int* cin, const int* cout, const int* mode, int taps_transposed = 0);
 int sol_conv_sh_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int mode, void* out);
 int sol_conv_sb_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int mode, void* out);
 int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles);

@@ -933,7 +933,7 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww_thin(BwArgs a) {
 // stage 1 (to_dw = 0): grid.y chunks of `chunk` blocks are summed in parallel, the sum is written back into
 // the first block of the chunk; stage 2 (to_dw = 1): the chunk heads (stride `chunk`) are summed in order.
 __global__ void k_bww_reduce(float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
-                             int nblk, int cin, int cout, int IP, int OP, int chunk, int stride, int to_dw, int accumulate) {
+                             int nblk, int cin, int cout, int IP, int OP, int chunk, int stride, int to_dw, int accumulate, int tt) {
     const int nw = 25 * cin * cout;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int k0 = blockIdx.y * chunk * stride, k1 = min(k0 + chunk * stride, nblk);
@@ -942,7 +942,9 @@ __global__ void k_bww_reduce(float* __restrict__ partial, float* __restrict__ dw
         const size_t off = (size_t)(tap * IP + ci) * OP + co;
         float s = 0.f;
         for (int k = k0; k < k1; k += stride) s += partial[(size_t)k * (25 * IP * OP) + off];
-        if (to_dw) dw[e] = accumulate ? dw[e] + s : s;
+        // tt: the gradient was accumulated on transposed images: its tap (dy, dx) is the weight's tap (dx, dy)
+        const int eo = tt ? (((tap % 5) * 5 + tap / 5) * cin + ci) * cout + co : e;
+        if (to_dw) dw[eo] = accumulate ? dw[eo] + s : s;
         else partial[(size_t)k0 * (25 * IP * OP) + off] = s;
     } else if (e < nw + cout) {
         const int co = e - nw;
@@ -1185,7 +1187,7 @@ int sol_bww_batched(void* stream, const float* x, const float* dz, float* partia
     return bww_launch(stream, x, dz, partial, nseg, x_seg, dz_seg, rb, overwrite, B, H, W, cin, cout, nblk, xmax, zmax, xmax_seg, zmax_seg);
 }
 
-static int bww_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int rows, int rb, int cin, int cout, int accumulate) {
+static int bww_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int rows, int rb, int cin, int cout, int accumulate, int tt = 0) {
     SOL_REQUIRE(partial && dw_hwio && db, "sol_conv5x5_bwd_weight_reduce: NULL pointer");
     SOL_REQUIRE(cin >= 1 && cin <= 32 && cout >= 1 && cout <= 32, "sol_conv5x5_bwd_weight_reduce: channels out of range");
     int nblk, IP, OP;
@@ -1195,11 +1197,11 @@ static int bww_reduce(void* stream, const float* partial, float* dw_hwio, float*
     const int chunk = 16, ny = (nblk + chunk - 1) / chunk;
     hipStream_t hs = (hipStream_t)stream;
     if (ny > 1) {
-        SOL_LAUNCH(k_bww_reduce, dim3((total + 255) / 256, ny), dim3(256), 0, hs, pm, dw_hwio, db, nblk, cin, cout, IP, OP, chunk, 1, 0, 0);
+        SOL_LAUNCH(k_bww_reduce, dim3((total + 255) / 256, ny), dim3(256), 0, hs, pm, dw_hwio, db, nblk, cin, cout, IP, OP, chunk, 1, 0, 0, 0);
         SOL_LAUNCH_CHECK();
-        SOL_LAUNCH(k_bww_reduce, dim3((total + 255) / 256, 1), dim3(256), 0, hs, pm, dw_hwio, db, nblk, cin, cout, IP, OP, ny, chunk, 1, accumulate);
+        SOL_LAUNCH(k_bww_reduce, dim3((total + 255) / 256, 1), dim3(256), 0, hs, pm, dw_hwio, db, nblk, cin, cout, IP, OP, ny, chunk, 1, accumulate, tt);
     } else {
-        SOL_LAUNCH(k_bww_reduce, dim3((total + 255) / 256, 1), dim3(256), 0, hs, pm, dw_hwio, db, nblk, cin, cout, IP, OP, nblk, 1, 1, accumulate);
+        SOL_LAUNCH(k_bww_reduce, dim3((total + 255) / 256, 1), dim3(256), 0, hs, pm, dw_hwio, db, nblk, cin, cout, IP, OP, nblk, 1, 1, accumulate, tt);
     }
     SOL_LAUNCH_CHECK();
     return SOL_OK;
@@ -1233,7 +1235,7 @@ int sol_bww_step_reduce(void* stream, const float* partial, float* dw_hwio, floa
 }
 
 int sol_bww_batched_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int nseg, int B, int H,
-                           int cin, int cout, int accumulate) {
+                           int cin, int cout, int accumulate, int taps_transposed) {
     const int rows = nseg * B * H;
-    return bww_reduce(stream, partial, dw_hwio, db, rows, pick_rb(rows, cin <= 4 ? 4 : 32, cout), cin, cout, accumulate);
+    return bww_reduce(stream, partial, dw_hwio, db, rows, pick_rb(rows, cin <= 4 ? 4 : 32, cout), cin, cout, accumulate, taps_transposed);
 }

@@ -433,12 +433,13 @@ __global__ void __launch_bounds__(512) k_conv5x5_bww_sb(BwArgs a) {
 // Job = (layer, mode).  Every workgroup of a job first finds the layer's max|w| itself (<= 25,600 values), then packs
 // its share of the three sections of the job's buffer: fp32 [tap][o][i], bf16 planes, fp16 header + planes
 // (layouts as k_pack / k_pack_sb / k_pack_sh).  Replaces ~130 tiny launches per training step.
-struct PackJob { const float* w; float* out; float* bias_out; const float* bias_in; int cin, cout, mode; };   // cin/cout of the convolution being RUN
+struct PackJob { const float* w; float* out; float* bias_out; const float* bias_in; int cin, cout, mode; int tt; };   // cin/cout of the convolution being RUN; tt: taps transposed (dy <-> dx)
 struct PackJobs { PackJob j[24]; int n; };
 constexpr int PACK_WG = 8;        // workgroups per job
 
 __device__ __forceinline__ float pack_src(const PackJob& jb, int tap, int i, int o) {
     if (i >= jb.cin || o >= jb.cout) return 0.f;
+    if (jb.tt) tap = (tap % 5) * 5 + tap / 5;        // the convolution runs on TRANSPOSED images (train.hip): conv(x^T, w^T) = conv(x, w)^T
     return jb.mode == SOL_CONV_FWD ? jb.w[(tap * jb.cin + i) * jb.cout + o] : jb.w[((24 - tap) * jb.cout + o) * jb.cin + i];
 }
 
@@ -561,11 +562,11 @@ int sol_bww_sb_launch(hipStream_t s, const BwArgs& a, int nblk_run) {
 
 // internal (train.hip): pack `n` (layer, mode) jobs in one launch; out buffers sized by sol_conv5x5_packed_floats
 int sol_pack_jobs(hipStream_t s, int n, const float* const* w, float* const* out, float* const* bias_out, const float* const* bias_in,
-                  const int* cin, const int* cout, const int* mode) {
+                  const int* cin, const int* cout, const int* mode, int taps_transposed) {
     SOL_REQUIRE(n >= 1 && n <= 24, "sol_pack_jobs: 1..24 jobs (got %d)", n);
     PackJobs jobs{};
     jobs.n = n;
-    for (int k = 0; k < n; ++k) jobs.j[k] = PackJob{w[k], out[k], bias_out[k], bias_in[k], cin[k], cout[k], mode[k]};
+    for (int k = 0; k < n; ++k) jobs.j[k] = PackJob{w[k], out[k], bias_out[k], bias_in[k], cin[k], cout[k], mode[k], taps_transposed};
     SOL_LAUNCH(k_pack_jobs, dim3(n * PACK_WG), dim3(256), 0, s, jobs);
     SOL_LAUNCH_CHECK();
     return SOL_OK;

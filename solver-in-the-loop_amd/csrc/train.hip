@@ -142,16 +142,17 @@ inline int64_t layer_koff(int l) {
 // ---- velocity += CNN correction (to_staggered pad, karman_train.py:88-90,413-426) + l2 loss ----
 __global__ void k_correct_loss(float* __restrict__ vy, float* __restrict__ vx, const float* __restrict__ O,
                                const float* __restrict__ gt_vy, const float* __restrict__ gt_vx,
-                               float s0, float s1, float l0, float l1, float* __restrict__ loss, int B, int Y, int X) {
+                               float s0, float s1, float l0, float l1, float* __restrict__ loss, int B, int Y, int X, int tr) {
     __shared__ float red[64];
     const int N = Y * X, nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
+    auto cell = [&](int j, int i) { return tr ? i * Y + j : j * X + i; };      // O is [B][X][Y][2] in transposed CNN mode
     const int total = B * (nVy + nVx);
     float l = 0.f;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         if (e < B * nVy) {
             const int b = e / nVy, k = e - b * nVy;
             float v = vy[e];
-            if (k < N) v += s0 * O[((size_t)b * N + k) * 2];
+            if (k < N) v += s0 * O[((size_t)b * N + cell(k / X, k % X)) * 2];
             vy[e] = v;
             if (gt_vy) { const float d = (gt_vy[e] - v) / l0; l += 0.5f * d * d; }
         } else {
@@ -159,7 +160,7 @@ __global__ void k_correct_loss(float* __restrict__ vy, float* __restrict__ vx, c
             const int b = e2 / nVx, k = e2 - b * nVx;
             const int j = k / XP, i = k - j * XP;
             float v = vx[e2];
-            if (i < X) v += s1 * O[((size_t)b * N + j * X + i) * 2 + 1];
+            if (i < X) v += s1 * O[((size_t)b * N + cell(j, i)) * 2 + 1];
             vx[e2] = v;
             if (gt_vx) { const float d = (gt_vx[e2] - v) / l1; l += 0.5f * d * d; }
         }
@@ -174,8 +175,9 @@ __global__ void k_correct_loss(float* __restrict__ vy, float* __restrict__ vx, c
 __global__ void k_seed(float* __restrict__ gvy, float* __restrict__ gvx, const float* __restrict__ vy,
                        const float* __restrict__ vx, const float* __restrict__ gt_vy, const float* __restrict__ gt_vx,
                        float s0, float s1, float l0, float l1, float inv_m, float* __restrict__ dO4, float* __restrict__ dO2,
-                       int first, int B, int Y, int X) {
+                       int first, int B, int Y, int X, int tr) {
     const int N = Y * X, nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
+    auto cell = [&](int j, int i) { return tr ? i * Y + j : j * X + i; };
     const int total = B * (nVy + nVx);
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         if (e < B * nVy) {
@@ -184,7 +186,7 @@ __global__ void k_seed(float* __restrict__ gvy, float* __restrict__ gvx, const f
             if (!first) g += gvy[e];
             gvy[e] = g;
             if (k < N) {
-                const size_t c = (size_t)b * N + k;
+                const size_t c = (size_t)b * N + cell(k / X, k % X);
                 dO4[c * 4] = s0 * g;
                 dO2[c * 2] = s0 * g;
             }
@@ -196,7 +198,7 @@ __global__ void k_seed(float* __restrict__ gvy, float* __restrict__ gvx, const f
             if (!first) g += gvx[e2];
             gvx[e2] = g;
             if (i < X) {
-                const size_t c = (size_t)b * N + j * X + i;
+                const size_t c = (size_t)b * N + cell(j, i);
                 dO4[c * 4 + 1] = s1 * g;
                 dO2[c * 2 + 1] = s1 * g;
             }
@@ -256,6 +258,27 @@ struct MemList {
     }
 };
 
+// ---- transposed CNN mode ------------------------------------------------------------------------
+// The split-precision convolution / weight-gradient kernels want image rows of 64 pixels.  A 64 x 32 grid (the reference's own
+// training recipe, karman-2d/Makefile:78-80) has rows of 32 -- but columns of 64, and conv(x^T, w^T) = conv(x, w)^T: the
+// whole CNN runs on TRANSPOSED images [B][X][Y][C] with tap-transposed packed weights (sol_pack_jobs), the weight gradients
+// are transposed back in their reduction.  Only the two ends touch the solver's layout: the features are transposed after
+// the solver step, the feature gradient before its adjoint (two tiny launches per unrolled step), and the correction /
+// loss / seed kernels index the transposed cell order.
+__host__ __device__ inline bool cnn_transposed(int Y, int X) { return X % 64 != 0 && Y % 64 == 0; }
+// dst[b][i][j][c] = src[b][j][i][c]  (C floats per cell)
+template <int C>
+__global__ void k_transpose_cells(const float* __restrict__ src, float* __restrict__ dst, int B, int Y, int X) {
+    const int total = B * Y * X;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int b = e / (Y * X), r = e - b * (Y * X), i = r / Y, j = r - i * Y;       // e = destination cell (b, i, j)
+        const float* sp = src + ((size_t)(b * Y + j) * X + i) * C;
+        float* dp = dst + (size_t)e * C;
+        if (C == 4) *reinterpret_cast<float4*>(dp) = *reinterpret_cast<const float4*>(sp);
+        else *reinterpret_cast<float2*>(dp) = *reinterpret_cast<const float2*>(sp);
+    }
+}
+
 __global__ void k_pad_bias(const float* __restrict__ params, float* __restrict__ biasp, int64_t boff, int cout) {
     const int t = threadIdx.x;
     if (t < 32) biasp[t] = t < cout ? params[boff + t] : 0.f;
@@ -302,7 +325,8 @@ struct Ws {
     size_t nVy, nVx, N, cells, st_vy, st_vx, st_d;
     float *vy, *vx, *d;            // [msteps][B][...] states after step i (index i = state i+1)
     float *svy, *svx;              // [msteps] saved post-diffusion velocity
-    float *feat;                   // [msteps][cells][4]
+    float *feat;                   // [msteps][cells][4]  (cell order of the CNN: transposed in transposed CNN mode)
+    float *feat_raw, *dF_n;        // transposed CNN mode: the solver's feature output / the feature gradient in the solver's cell order
     float *acts;                   // [msteps][11][cells][32]
     float *O;                      // [cells][2]
     float *gA, *gB;                // [cells][32]
@@ -337,6 +361,8 @@ size_t carve_ws(const sol_train_cfg* c, float* base, Ws& w, bool training) {
     w.vy = take(ms * w.st_vy); w.vx = take(ms * w.st_vx); w.d = take(ms * w.st_d);
     w.svy = take(ms * w.st_vy); w.svx = take(ms * w.st_vx);
     w.feat = take(ms * w.cells * 4);
+    w.feat_raw = take(w.cells * 4);
+    w.dF_n = take(w.cells * 2);
     w.acts = take((size_t)ms * 11 * w.cells * 32);
     w.O = take(w.cells * 2);
     w.gA = take(w.cells * 32); w.gB = take(w.cells * 32);
@@ -355,7 +381,7 @@ size_t carve_ws(const sol_train_cfg* c, float* base, Ws& w, bool training) {
         w.wf[l] = take(sol_conv5x5_packed_floats(cin == 3 ? 4 : cin, cout, SOL_CONV_FWD));
         w.wb[l] = take(sol_conv5x5_packed_floats(cout == 2 ? 4 : cout, cin, SOL_CONV_BWD_DATA));
         w.bias[l] = take(32);
-        w.part_floats[l] = training ? sol_bww_batched_ws_floats(pick_bww_chunk(ms), B, Y, cin == 3 ? 4 : cin, cout) : 0;
+        w.part_floats[l] = training ? sol_bww_batched_ws_floats(pick_bww_chunk(ms), B, cnn_transposed(Y, X) ? X : Y, cin == 3 ? 4 : cin, cout) : 0;
         w.part[l] = take(w.part_floats[l]);
     }
     w.adam_scale = take(64);
@@ -363,7 +389,7 @@ size_t carve_ws(const sol_train_cfg* c, float* base, Ws& w, bool training) {
     return off * sizeof(float);
 }
 
-int pack_all(const sol_train_cfg* /*c*/, void* stream, const float* params, Ws& w, bool bwd) {
+int pack_all(const sol_train_cfg* c, void* stream, const float* params, Ws& w, bool bwd) {
     // every layer, forward and backward-data form, fp32 + split-bf16 + split-fp16 sections and the padded biases: ONE launch
     const float* src[24]; float* out[24]; float* bo[24]; const float* bi[24];
     int cin[24], cout[24], mode[24], n = 0;
@@ -375,7 +401,7 @@ int pack_all(const sol_train_cfg* /*c*/, void* stream, const float* params, Ws& 
             src[n] = params + koff; out[n] = w.wb[l]; bo[n] = nullptr; bi[n] = nullptr; cin[n] = co; cout[n] = ci; mode[n] = SOL_CONV_BWD_DATA; ++n;
         }
     }
-    return sol_pack_jobs((hipStream_t)stream, n, src, out, bo, bi, cin, cout, mode);
+    return sol_pack_jobs((hipStream_t)stream, n, src, out, bo, bi, cin, cout, mode, cnn_transposed(c->karman.Y, c->karman.X) ? 1 : 0);
 }
 
 inline float in_s0(const sol_train_cfg* c) { return c->in_std_v0 > 0.f ? c->in_std_v0 : c->std_v0; }
@@ -390,7 +416,8 @@ inline float out_s1(const sol_train_cfg* c) { return c->out_std_v1 > 0.f ? c->ou
 struct Correct { float *vy, *vx; const float *gt_vy, *gt_vx; float* loss; };
 int net_forward(const sol_train_cfg* c, void* s, const Ws& w, const float* feat, float* const* act, float* O, uint32_t* amax, const Correct* corr = nullptr,
                 uint32_t* chain_flags = nullptr) {
-    const int B = c->karman.B, Y = c->karman.Y, X = c->karman.X;
+    const bool tr = cnn_transposed(c->karman.Y, c->karman.X);      // then `feat` and every CNN tensor are [B][X][Y][C]
+    const int B = c->karman.B, Y = tr ? c->karman.X : c->karman.Y, X = tr ? c->karman.Y : c->karman.X;
     const float sl = c->lrelu_slope;
     auto am = [&](int k) { return amax ? amax + (size_t)k * SOL_AMAX_SLOTS : nullptr; };
     if (int e = sol_conv5x5_scaled(s, feat, w.wf[0], w.bias[0], nullptr, nullptr, act[0], B, Y, X, 4, 32, SOL_EPI_LRELU, sl, nullptr, am(0))) return e;
@@ -509,6 +536,9 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
     void* stream = hs;
     const sol_karman_cfg* kc = &c->karman;
     const int B = kc->B, Y = kc->Y, X = kc->X, ms = c->msteps;
+    const bool tr = cnn_transposed(Y, X);              // CNN tensors are [B][X][Y][C]; cY x cX = image shape the CNN kernels see
+    const int cY = tr ? X : Y, cX = tr ? Y : X;
+    const int tgrid = (int)((w.cells + 255) / 256);
     const float fscale[3] = {1.f / in_s0(c), 1.f / in_s1(c), 1.f / c->std_re};
     const int egrid = (int)((w.st_vy + w.st_vx + 255) / 256);
     const size_t gVy = (size_t)Btot * w.nVy, gVx = (size_t)Btot * w.nVx;       // per-step stride of the gt frames
@@ -534,7 +564,8 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         float* dcur = w.d + (size_t)i * w.st_d;
         float* vycur = w.vy + (size_t)i * w.st_vy;
         float* vxcur = w.vx + (size_t)i * w.st_vx;
-        float* feat = w.feat + (size_t)i * w.cells * 4;
+        float* feat_cnn = w.feat + (size_t)i * w.cells * 4;
+        float* feat = tr ? w.feat_raw : feat_cnn;       // what the solver step writes
         // The passive density leaves the critical path.  With the direct-solver kernels the density advection of step
         // i-1 (it only needs that step's saved velocity) rides in the solver launch of step i as B extra workgroups;
         // otherwise the whole chain is one launch after the unroll (sol_density_chain below).
@@ -548,16 +579,20 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
                                                  w.d + (size_t)(i - 1) * w.st_d)) return e;
         } else if (int e = sol_karman_step_fwd(kc, stream, din, vyin, vxin, re, io.active, io.inflow, bcv, bcm, io.bc_stride,
                                                dens_inline ? dcur : nullptr, vycur, vxcur, svy_i, svx_i, feat, fscale, it_i)) return e;
+        if (tr) {
+            SOL_LAUNCH(k_transpose_cells<4>, dim3(tgrid), dim3(256), 0, hs, (const float*)w.feat_raw, feat_cnn, B, Y, X);
+            SOL_LAUNCH_CHECK();
+        }
         float* act[11];
         for (int k = 0; k < 11; ++k) act[k] = w.acts + ((size_t)i * 11 + k) * w.cells * 32;
         if (sol_conv_correct_fusable(X)) {            // correction + loss ride in the epilogue of the last CNN layer
             const Correct corr{vycur, vxcur, gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx, io.loss_steps + i};
-            if (int e = net_forward(c, stream, wn, feat, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS, &corr, w.chain_flags + (size_t)(2 * i) * w.chain_words)) return e;
+            if (int e = net_forward(c, stream, wn, feat_cnn, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS, &corr, w.chain_flags + (size_t)(2 * i) * w.chain_words)) return e;
         } else {
-            if (int e = net_forward(c, stream, wn, feat, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS, nullptr, w.chain_flags + (size_t)(2 * i) * w.chain_words)) return e;
+            if (int e = net_forward(c, stream, wn, feat_cnn, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS, nullptr, w.chain_flags + (size_t)(2 * i) * w.chain_words)) return e;
             SOL_LAUNCH(k_correct_loss, dim3(egrid), dim3(256), 0, hs, vycur, vxcur, w.O,
                                gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx,
-                               out_s0(c), out_s1(c), c->std_v0, c->std_v1, io.loss_steps + i, B, Y, X);
+                               out_s0(c), out_s1(c), c->std_v0, c->std_v1, io.loss_steps + i, B, Y, X, tr ? 1 : 0);
             SOL_LAUNCH_CHECK();
         }
     }
@@ -604,7 +639,7 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         float* dO2 = w.dO2 + (size_t)i * w.cells * 2;
         SOL_LAUNCH(k_seed, dim3(egrid), dim3(256), 0, hs, gvy, gvx, vycur, vxcur,
                            gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx,
-                           out_s0(c), out_s1(c), c->std_v0, c->std_v1, 1.f / (float)ms, w.dO4, dO2, i == ms - 1 ? 1 : 0, B, Y, X);
+                           out_s0(c), out_s1(c), c->std_v0, c->std_v1, 1.f / (float)ms, w.dO4, dO2, i == ms - 1 ? 1 : 0, B, Y, X, tr ? 1 : 0);
         SOL_LAUNCH_CHECK();
         const float* act[11];
         float* D[11];
@@ -614,22 +649,22 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         }
         uint32_t* amd = w.amax_dz + (size_t)i * 11 * SOL_AMAX_SLOTS;
         auto am = [&](int k) { return amd + (size_t)k * SOL_AMAX_SLOTS; };
-        if (int e = sol_conv5x5_scaled(stream, w.dO4, wn.wb[11], nullptr, nullptr, act[10], D[10], B, Y, X, 4, 32, SOL_EPI_DLRELU, sl, nullptr, am(10))) return e;
-        if (sol_cnn_chain_usable(B, Y, X)) {
+        if (int e = sol_conv5x5_scaled(stream, w.dO4, wn.wb[11], nullptr, nullptr, act[10], D[10], B, cY, cX, 4, 32, SOL_EPI_DLRELU, sl, nullptr, am(10))) return e;
+        if (sol_cnn_chain_usable(B, cY, cX)) {
             // the ten backward-data convolutions as ONE persistent launch
             ChainLayer L[10];
             for (int k = 4, n = 0; k >= 0; --k) {
                 L[n++] = ChainLayer{sol_conv_packed_wsh(wn.wb[2 + 2 * k], 32), nullptr, nullptr, act[1 + 2 * k], D[1 + 2 * k], am(1 + 2 * k), SOL_EPI_DLRELU};
                 L[n++] = ChainLayer{sol_conv_packed_wsh(wn.wb[1 + 2 * k], 32), nullptr, D[2 + 2 * k], act[2 * k], D[2 * k], am(2 * k), SOL_EPI_DLRELU};
             }
-            if (int e = sol_cnn_chain_launch(hs, L, 10, D[10], w.chain_flags + (size_t)(2 * i + 1) * w.chain_words, w.chain_ctl, B, Y, X, sl)) return e;
+            if (int e = sol_cnn_chain_launch(hs, L, 10, D[10], w.chain_flags + (size_t)(2 * i + 1) * w.chain_words, w.chain_ctl, B, cY, cX, sl)) return e;
         } else
         for (int k = 4; k >= 0; --k) {
             const float* h = act[2 * k];
             const float* a = act[1 + 2 * k];
-            if (int e = sol_conv5x5_scaled(stream, D[2 + 2 * k], wn.wb[2 + 2 * k], nullptr, nullptr, a, D[1 + 2 * k], B, Y, X, 32, 32, SOL_EPI_DLRELU, sl,
+            if (int e = sol_conv5x5_scaled(stream, D[2 + 2 * k], wn.wb[2 + 2 * k], nullptr, nullptr, a, D[1 + 2 * k], B, cY, cX, 32, 32, SOL_EPI_DLRELU, sl,
                                            am(2 + 2 * k), am(1 + 2 * k))) return e;
-            if (int e = sol_conv5x5_scaled(stream, D[1 + 2 * k], wn.wb[1 + 2 * k], nullptr, D[2 + 2 * k], h, D[2 * k], B, Y, X, 32, 32, SOL_EPI_DLRELU, sl,
+            if (int e = sol_conv5x5_scaled(stream, D[1 + 2 * k], wn.wb[1 + 2 * k], nullptr, D[2 + 2 * k], h, D[2 * k], B, cY, cX, 32, 32, SOL_EPI_DLRELU, sl,
                                            am(1 + 2 * k), am(2 * k))) return e;
         }
         if (i % CH == 0) {
@@ -645,13 +680,13 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
             const float* feat_i = w.feat + (size_t)i * w.cells * 4;
             const float* acts_i = w.acts + (size_t)i * 11 * cl32;
             const float* dz_i = w.dzb + (size_t)i * 11 * cl32;
-            if (int e = sol_bww_batched(bs, feat_i, dz_i, w.part[0], n, CH, first, (long)(w.cells * 4), seg32, B, Y, X, 4, 32)) return e;
+            if (int e = sol_bww_batched(bs, feat_i, dz_i, w.part[0], n, CH, first, (long)(w.cells * 4), seg32, B, cY, cX, 4, 32)) return e;
             const long amseg = 11 * SOL_AMAX_SLOTS;      // absmax slots: [step][11][SOL_AMAX_SLOTS]
             for (int l = 1; l <= 10 && !fuse; ++l)
-                if (int e = sol_bww_batched(bs, acts_i + (size_t)(l - 1) * cl32, dz_i + (size_t)l * cl32, w.part[l], n, CH, first, seg32, seg32, B, Y, X, 32, 32,
+                if (int e = sol_bww_batched(bs, acts_i + (size_t)(l - 1) * cl32, dz_i + (size_t)l * cl32, w.part[l], n, CH, first, seg32, seg32, B, cY, cX, 32, 32,
                                             w.amax_act + ((size_t)i * 11 + (l - 1)) * SOL_AMAX_SLOTS, w.amax_dz + ((size_t)i * 11 + l) * SOL_AMAX_SLOTS,
                                             amseg, amseg)) return e;
-            if (int e = sol_bww_batched(bs, acts_i + (size_t)10 * cl32, w.dO2 + (size_t)i * w.cells * 2, w.part[11], n, CH, first, seg32, (long)(w.cells * 2), B, Y, X, 32, 2)) return e;
+            if (int e = sol_bww_batched(bs, acts_i + (size_t)10 * cl32, w.dO2 + (size_t)i * w.cells * 2, w.part[11], n, CH, first, seg32, (long)(w.cells * 2), B, cY, cX, 32, 2)) return e;
         }
         BwArgs jobs[10];
         if (fuse) {       // this step's dz tensors are complete: one job per 32 -> 32 layer
@@ -660,9 +695,15 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
                                              w.amax_act + ((size_t)i * 11 + (l - 1)) * SOL_AMAX_SLOTS, am(l))) return e;
         }
         if (i > 0) {
-            if (int e = sol_conv5x5_scaled(stream, D[0], wn.wb[0], nullptr, nullptr, nullptr, w.dF, B, Y, X, 32, 2, SOL_EPI_NONE, sl, am(0), nullptr)) return e;
+            if (int e = sol_conv5x5_scaled(stream, D[0], wn.wb[0], nullptr, nullptr, nullptr, w.dF, B, cY, cX, 32, 2, SOL_EPI_NONE, sl, am(0), nullptr)) return e;
+            const float* dF = w.dF;
+            if (tr) {       // feature gradient back into the solver's cell order ([B][X][Y][2] -> [B][Y][X][2]: the same kernel with the axes swapped)
+                SOL_LAUNCH(k_transpose_cells<2>, dim3(tgrid), dim3(256), 0, hs, (const float*)w.dF, w.dF_n, B, X, Y);
+                SOL_LAUNCH_CHECK();
+                dF = w.dF_n;
+            }
             if (int e = sol_karman_step_bwd_fused(kc, stream, w.svy + (size_t)i * w.st_vy, w.svx + (size_t)i * w.st_vx, re, io.active,
-                                                  bcm, io.bc_stride, gvy, gvx, w.dF, fscale, w.gvy[cur ^ 1], w.gvx[cur ^ 1],
+                                                  bcm, io.bc_stride, gvy, gvx, dF, fscale, w.gvy[cur ^ 1], w.gvx[cur ^ 1],
                                                   io.iters_bwd ? io.iters_bwd + (size_t)i * Btot + b0 : nullptr,
                                                   jobs, fuse ? 10 : 0, wg_per)) return e;
             cur ^= 1;
@@ -701,7 +742,7 @@ int train_fwd_bwd_impl(const sol_train_cfg* cfg, hipStream_t hs, const TrainIO& 
         }
         z.zero(w[k].dO4, w[k].cells * 4 * sizeof(float));
         z.zero(w[k].amax_act, 2 * w[k].amax_words * sizeof(uint32_t));                 // activation + gradient absmax slots
-        const bool chain = sol_cnn_chain_usable(sub.karman.B, Y, X);
+        const bool chain = sol_cnn_chain_usable(sub.karman.B, cnn_transposed(Y, X) ? X : Y, cnn_transposed(Y, X) ? Y : X);
         // hand-off regions of the persistent CNN launches: zero ONCE (tag 0 = "never written"); afterwards the tags do the work
         if (chain) z.zero_once(w[k].chain_flags, (size_t)ms * 2 * w[k].chain_words * sizeof(uint32_t), w[k].chain_ctl + 1, w[k].chain_magic);
         if (int e = z.launch(hs)) return e;
@@ -726,8 +767,9 @@ int train_fwd_bwd_impl(const sol_train_cfg* cfg, hipStream_t hs, const TrainIO& 
         const int64_t koff = layer_koff(l), boff = koff + 25 * cin * cout;
         const bool fused = l >= 1 && l <= 10 && train_fused(&sub, w[0], ms);
         for (int k = 0; k < S; ++k) {
+            const bool trn = cnn_transposed(Y, X);
             if (fused) { if (int e = sol_bww_step_reduce(hs, w[k].part[l], grads + koff, grads + boff, B / S, Y, 32, cin, cout, k > 0)) return e; }
-            else if (int e = sol_bww_batched_reduce(hs, w[k].part[l], grads + koff, grads + boff, pick_bww_chunk(ms), B / S, Y, cin, cout, k > 0)) return e;
+            else if (int e = sol_bww_batched_reduce(hs, w[k].part[l], grads + koff, grads + boff, pick_bww_chunk(ms), B / S, trn ? X : Y, cin, cout, k > 0, trn ? 1 : 0)) return e;
         }
     }
     return SOL_OK;
@@ -856,12 +898,17 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
     for (int i = 0; i < nsteps; ++i) {
         float* sd = (i & 1) ? w.d : d;   float* svy = (i & 1) ? w.vy : vy;   float* svx = (i & 1) ? w.vx : vx;
         float* td = (i & 1) ? d : w.d;   float* tvy = (i & 1) ? vy : w.vy;   float* tvx = (i & 1) ? vx : w.vx;
+        const bool tr = cnn_transposed(Y, X);
         if (int e = sol_karman_step_fwd(kc, stream, sd, svy, svx, re, active, inflow, velBCy, velBCyMask, bc_batch_stride,
-                                        td, tvy, tvx, nullptr, nullptr, w.feat, fscale,
+                                        td, tvy, tvx, nullptr, nullptr, tr ? w.feat_raw : w.feat, fscale,
                                         iters ? iters + (size_t)i * B : nullptr)) return e;
+        if (tr) {
+            SOL_LAUNCH(k_transpose_cells<4>, dim3((int)((w.cells + 255) / 256)), dim3(256), 0, hs, (const float*)w.feat_raw, w.feat, B, Y, X);
+            SOL_LAUNCH_CHECK();
+        }
         if (i % ROLLOUT_AMAX_SETS == 0) {
             MemList z;
-            const bool chain = sol_cnn_chain_usable(B, Y, X);
+            const bool chain = sol_cnn_chain_usable(B, tr ? X : Y, tr ? Y : X);
             if (chain) z.zero_once(w.chain_flags, (size_t)ROLLOUT_AMAX_SETS * w.chain_words * sizeof(uint32_t), w.chain_ctl + 1, w.chain_magic);
             z.zero(w.amax_act, w.amax_words * sizeof(uint32_t));
             if (int e = z.launch(hs)) return e;
@@ -877,7 +924,7 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
         } else {
             if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, amax, nullptr, w.chain_flags + (size_t)(i % ROLLOUT_AMAX_SETS) * w.chain_words)) return e;
             SOL_LAUNCH(k_correct_loss, dim3(egrid), dim3(256), 0, hs, tvy, tvx, w.O,
-                               (const float*)nullptr, (const float*)nullptr, out_s0(cfg), out_s1(cfg), cfg->std_v0, cfg->std_v1, (float*)nullptr, B, Y, X);
+                               (const float*)nullptr, (const float*)nullptr, out_s0(cfg), out_s1(cfg), cfg->std_v0, cfg->std_v1, (float*)nullptr, B, Y, X, tr ? 1 : 0);
             SOL_LAUNCH_CHECK();
         }
     }
