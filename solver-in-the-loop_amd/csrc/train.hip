@@ -152,7 +152,7 @@ __global__ void k_correct_loss(float* __restrict__ vy, float* __restrict__ vx, c
         if (e < B * nVy) {
             const int b = e / nVy, k = e - b * nVy;
             float v = vy[e];
-            if (k < N) v += s0 * O[((size_t)b * N + cell(k / X, k % X)) * 2];
+            if (k < N) v += s0 * O[((size_t)b * N + (tr ? cell(k / X, k % X) : k)) * 2];
             vy[e] = v;
             if (gt_vy) { const float d = (gt_vy[e] - v) / l0; l += 0.5f * d * d; }
         } else {
@@ -186,7 +186,7 @@ __global__ void k_seed(float* __restrict__ gvy, float* __restrict__ gvx, const f
             if (!first) g += gvy[e];
             gvy[e] = g;
             if (k < N) {
-                const size_t c = (size_t)b * N + cell(k / X, k % X);
+                const size_t c = (size_t)b * N + (tr ? cell(k / X, k % X) : k);
                 dO4[c * 4] = s0 * g;
                 dO2[c * 2] = s0 * g;
             }

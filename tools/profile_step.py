@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-kernel table of ONE eager training step (per-launch HIP events, sol_prof_*) + graph-replay ms/step.
-Usage: python tools/profile_step.py [B] [res] [msteps]"""
+Usage: python tools/profile_step.py [B] [res] [msteps] [cnn_persistent]"""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +10,8 @@ from sol_amd import _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 X = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 ms = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+if len(sys.argv) > 4:
+    _lib.set_option("cnn_persistent", int(sys.argv[4]))
 dev = torch.device("cuda", 0)
 wl = bench.Workload(sol_amd, dev, B, 2 * X, X, ms, 0)
 for _ in range(3):
