@@ -795,7 +795,8 @@ __device__ __forceinline__ void fd_small_stage(const float* __restrict__ blob, i
 #pragma unroll 4
     for (int e = tid; e < Y * 16; e += T) QyW[e] = gQy[(size_t)(wy0 + (e & 15)) * Y + (e >> 4)];
 }
-__device__ __forceinline__ float* fd_solve_small(const float* __restrict__ blob, int Y, int X, const Own& o, float* ext, const float (&rf)[16]) {
+template <int CPT>
+__device__ __forceinline__ float* fd_solve_small(const float* __restrict__ blob, int Y, int X, const Own& o, float* ext, const float (&rf)[CPT]) {
     const int* h = reinterpret_cast<const int*>(blob);
     const int wy0 = h[3], wx0 = h[4], SP = h[6];
     const float* gQy = blob + 16;
@@ -821,7 +822,7 @@ __device__ __forceinline__ float* fd_solve_small(const float* __restrict__ blob,
     (void)gQy; (void)gQW;
     if (o.owner) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) B0[(o.j0 + k) * X + o.i] = rf[k];
+        for (int k = 0; k < CPT; ++k) B0[(o.j0 + k) * X + o.i] = rf[k];
     }
     __syncthreads();
     // C tile loop: MODE 0: C[m][n] = v;  1: Ct[n][m] = v;  2: Ct[n][m] = v * S[n][m];  3: Ct[n][m] += v * S[n][m]
@@ -931,7 +932,7 @@ __device__ __forceinline__ void karman_fwd_body(const StepArgs& a, float* smem) 
     float fdp = 0.f;
     if constexpr (SOLVER == 2) {
         if (Y == FD_Y) fdp = fd_prefetch(a.fd, a.fd_n);
-        else if constexpr (CPT == 16) fd_small_stage(a.fd, Y, X, L.fdx);
+        else fd_small_stage(a.fd, Y, X, L.fdx);
     }
     // ---- phase 1: load inputs (all global loads in flight before the first LDS store) ---
     // 16-byte loads: a dword load costs the texture path as much per wave as a dwordx4 one, and this phase is nothing else
@@ -1060,7 +1061,7 @@ __device__ __forceinline__ void karman_fwd_body(const StepArgs& a, float* smem) 
     float qys[FD_Y / 16];           // direct solver: this wave's slice of Qy (L2-warm: fd_prefetch), in flight behind the setup
 #pragma unroll
     for (int j = 0; j < FD_Y / 16; ++j) qys[j] = 0.f;
-    if constexpr (SOLVER == 2) { if (Y == FD_Y) fd_load_slice<FD_Y>(a.fd + 16, __builtin_amdgcn_readfirstlane(tid >> 6), qys); }
+    if constexpr (SOLVER == 2 && CPT == 16) { if (Y == FD_Y) fd_load_slice<FD_Y>(a.fd + 16, __builtin_amdgcn_readfirstlane(tid >> 6), qys); }
     const Own o = ownership<CPT>(Y, X);
     float dg[CPT], ac[CPT], r[CPT], x[CPT];
     cell_coeffs<CPT>(o, L.act, Y, X, dg, ac);
@@ -1077,7 +1078,8 @@ __device__ __forceinline__ void karman_fwd_body(const StepArgs& a, float* smem) 
     float* Pfd = nullptr;           // direct solver: the solution arrives as an LDS array
     SOL_STAMP(5);
     if constexpr (SOLVER == 2) {            // host guarantees 128 x 64 (register-tiled) or a small grid (LDS resident)
-        if constexpr (CPT == 16) Pfd = Y == FD_Y ? fd_solve(a.fd, qys, L.Bvy, r, a.prof) : fd_solve_small(a.fd, Y, X, o, L.fdx, r);
+        if constexpr (CPT == 16) Pfd = Y == FD_Y ? fd_solve(a.fd, qys, L.Bvy, r, a.prof) : fd_solve_small<CPT>(a.fd, Y, X, o, L.fdx, r);
+        else Pfd = fd_solve_small<CPT>(a.fd, Y, X, o, L.fdx, r);
     } else if constexpr (SOLVER == 1) {
         it = X == 64 ? pcg_solve<CPT, true, 32>(o, Y, X, L.act, dg, ac, r, x, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter)
                      : pcg_solve<CPT, false, 8>(o, Y, X, L.act, dg, ac, r, x, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter);
@@ -1216,7 +1218,7 @@ __device__ __forceinline__ void karman_bwd_body(const StepArgs& a, float* smem) 
     float fdp = 0.f;
     if constexpr (SOLVER == 2) {
         if (Y == FD_Y) fdp = fd_prefetch(a.fd, a.fd_n);
-        else if constexpr (CPT == 16) fd_small_stage(a.fd, Y, X, L.fdx);
+        else fd_small_stage(a.fd, Y, X, L.fdx);
     }
     // ---- 1: load incoming gradient (+ feature gradient): all global loads in flight first --------
     {
@@ -1272,7 +1274,7 @@ __device__ __forceinline__ void karman_bwd_body(const StepArgs& a, float* smem) 
     float qys[FD_Y / 16];
 #pragma unroll
     for (int j = 0; j < FD_Y / 16; ++j) qys[j] = 0.f;
-    if constexpr (SOLVER == 2) { if (Y == FD_Y) fd_load_slice<FD_Y>(a.fd + 16, __builtin_amdgcn_readfirstlane(tid >> 6), qys); }
+    if constexpr (SOLVER == 2 && CPT == 16) { if (Y == FD_Y) fd_load_slice<FD_Y>(a.fd + 16, __builtin_amdgcn_readfirstlane(tid >> 6), qys); }
     const Own o = ownership<CPT>(Y, X);
     float dg[CPT], ac[CPT], r[CPT], z[CPT];
     cell_coeffs<CPT>(o, L.act, Y, X, dg, ac);
@@ -1293,7 +1295,8 @@ __device__ __forceinline__ void karman_bwd_body(const StepArgs& a, float* smem) 
     float* Pfd = nullptr;
     SOL_STAMP(2);
     if constexpr (SOLVER == 2) {
-        if constexpr (CPT == 16) Pfd = Y == FD_Y ? fd_solve(a.fd, qys, L.Bvy, r, a.prof) : fd_solve_small(a.fd, Y, X, o, L.fdx, r);
+        if constexpr (CPT == 16) Pfd = Y == FD_Y ? fd_solve(a.fd, qys, L.Bvy, r, a.prof) : fd_solve_small<CPT>(a.fd, Y, X, o, L.fdx, r);
+        else Pfd = fd_solve_small<CPT>(a.fd, Y, X, o, L.fdx, r);
     } else if constexpr (SOLVER == 1) {
         it = X == 64 ? pcg_solve<CPT, true, 32>(o, Y, X, L.act, dg, ac, r, z, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter)
                      : pcg_solve<CPT, false, 8>(o, Y, X, L.act, dg, ac, r, z, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter);
@@ -1600,6 +1603,7 @@ __global__ void __launch_bounds__(1024) k_density_chain(DensArgs a) {
 // reduction overhead in the issue-bound CG loop), 8 otherwise.  SOL_CPT=8|16 overrides.
 int pick_cpt(const sol_karman_cfg* c) {
     int cpt = (c->Y % 16 == 0 && c->X >= 16) ? 16 : 8;
+    if (c->direct && fd_small_floats(c->Y, c->X) > 0 && (c->Y / 8) * c->X <= 1024) cpt = 8;
     const int v = sol_opt().cpt;
     if (v == 8 || (v == 16 && c->Y % 16 == 0 && c->X >= 16)) cpt = v;
     return cpt;
@@ -1624,12 +1628,12 @@ int check_cfg(const sol_karman_cfg* c) {
     SOL_REQUIRE(lds_bytes(c->Y, c->X, cpt) <= 160 * 1024, "grid %dx%d does not fit the 160 KiB LDS", c->Y, c->X);
     SOL_REQUIRE(c->dx > 0.f && c->cg_max_iter >= 0, "dx must be > 0 and cg_max_iter >= 0");
     if (c->direct) {
-        SOL_REQUIRE(((c->Y == FD_Y && c->X == FD_X) || fd_small_floats(c->Y, c->X) > 0) && cpt == 16,
+        SOL_REQUIRE((c->Y == FD_Y && c->X == FD_X && cpt == 16) || fd_small_floats(c->Y, c->X) > 0,
                     "the direct pressure solver is built for 128x64 and for grids of at most 2048 cells with Y %% 16 == 0, X >= 16 (got %dx%d)", c->Y, c->X);
         SOL_REQUIRE(c->direct_n >= 16 + c->Y * c->Y + c->X * c->X + c->X * c->Y + 64 * 64 + 64 + c->X * FD_WIN,
                     "direct_n = %d is too small for a direct-solver blob", c->direct_n);
     }
-    if (c->coarse_inv) {
+    if (c->coarse_inv && !c->direct) {       // (the direct solver takes precedence: the preconditioner is then unused)
         SOL_REQUIRE(precond_ok(c->Y, c->X) && cpt == 16, "the two-level CG preconditioner is not available for a %dx%d grid", c->Y, c->X);
         SOL_REQUIRE(c->coarse_n == (c->Y / 8) * (c->X / 8), "coarse_n must be (Y/8)*(X/8) = %d (got %d)", (c->Y / 8) * (c->X / 8), c->coarse_n);
     }
@@ -1658,6 +1662,7 @@ void fill_common(StepArgs& a, const sol_karman_cfg* c) {
 int sol_init_karman_kernels() {
     static int rc = [] {
         const void* ks[] = {reinterpret_cast<const void*>(k_karman_fwd<8, 0>), reinterpret_cast<const void*>(k_karman_bwd<8, 0>),
+                            reinterpret_cast<const void*>(k_karman_fwd<8, 2>), reinterpret_cast<const void*>(k_karman_bwd<8, 2>),
                             reinterpret_cast<const void*>(k_karman_fwd<16, 0>), reinterpret_cast<const void*>(k_karman_bwd<16, 0>),
                             reinterpret_cast<const void*>(k_karman_fwd<16, 1>), reinterpret_cast<const void*>(k_karman_bwd<16, 1>),
                             reinterpret_cast<const void*>(k_karman_fwd<16, 2>), reinterpret_cast<const void*>(k_karman_bwd<16, 2>),
@@ -1762,7 +1767,7 @@ static int step_fwd_impl(const sol_karman_cfg* cfg, void* stream,
         SOL_LAUNCH_CHECK();
         return SOL_OK;
     }
-    if (cpt != 16) return launch_step(k_karman_fwd<8, 0>, 8, cfg, stream, a);
+    if (cpt != 16) return a.fd ? launch_step(k_karman_fwd<8, 2>, 8, cfg, stream, a) : launch_step(k_karman_fwd<8, 0>, 8, cfg, stream, a);
     if (a.fd) return launch_step(k_karman_fwd<16, 2>, 16, cfg, stream, a);
     if (a.cinv) return launch_step(k_karman_fwd<16, 1>, 16, cfg, stream, a);
     return launch_step(k_karman_fwd<16, 0>, 16, cfg, stream, a);
@@ -1830,7 +1835,7 @@ static int step_bwd_impl(const sol_karman_cfg* cfg, void* stream,
         SOL_LAUNCH_CHECK();
         return SOL_OK;
     }
-    if (cpt != 16) return launch_step(k_karman_bwd<8, 0>, 8, cfg, stream, a);
+    if (cpt != 16) return a.fd ? launch_step(k_karman_bwd<8, 2>, 8, cfg, stream, a) : launch_step(k_karman_bwd<8, 0>, 8, cfg, stream, a);
     if (a.fd) return launch_step(k_karman_bwd<16, 2>, 16, cfg, stream, a);
     if (a.cinv) return launch_step(k_karman_bwd<16, 1>, 16, cfg, stream, a);
     return launch_step(k_karman_bwd<16, 0>, 16, cfg, stream, a);

@@ -90,6 +90,31 @@ def test_direct_solver_at_the_reference_training_size(golden_dir):
     assert rel(py, qy) < TOL_FIELD and rel(px, qx) < TOL_FIELD
 
 
+@pytest.mark.parametrize("Y,X", [(32, 16), (64, 32)])
+def test_small_grid_direct_solver_shapes_against_oracle(Y, X):
+    """fd_solve_small on the small grids of the reference domain (Y = 2 X; it accepts Y % 16 == 0, X in {16, 32, 64}, at most
+    2048 cells): step and input gradients against the exactly solved float64 oracle, zero iterations."""
+    B = 2
+    g, mk = masks_for(Y, X)
+    assert mk.direct is not None
+    d, vy, vx = o.synthetic_state(B, Y, X, 77)
+    re = torch.tensor(o.RE_TRAIN[:B], dtype=torch.float64)
+    vy = vy.clone().requires_grad_(True)
+    vx = vx.clone().requires_grad_(True)
+    d2, py, px = o.karman_step(d, vy, vx, re, g)
+    gen = torch.Generator().manual_seed(3)
+    wy, wx = torch.randn(py.shape, generator=gen, dtype=torch.float64), torch.randn(px.shape, generator=gen, dtype=torch.float64)
+    ((py * wy).sum() + (px * wx).sum()).backward()
+    cfg = ops.karman_cfg(B, Y, X, g.dx, masks=mk)
+    hy, hx = f32(vy.detach()).requires_grad_(True), f32(vx.detach()).requires_grad_(True)
+    info = {}
+    e2, qy, qx = ops.karman_step(f32(d), hy, hx, f32(re), cfg, mk, info)
+    ((qy * f32(wy)).sum() + (qx * f32(wx)).sum()).backward()
+    assert int(info["iterations"].max()) == 0 and int(info["iterations_bwd"].max()) == 0
+    assert rel(e2, d2) < TOL_FIELD and rel(qy, py) < TOL_FIELD and rel(qx, px) < TOL_FIELD
+    assert rel(hy.grad, vy.grad) < TOL_GRAD and rel(hx.grad, vx.grad) < TOL_GRAD
+
+
 @pytest.mark.parametrize("B,solver", [(1, "direct"), (2, "direct"), (1, "pcg"), (2, "pcg"), (2, "cg")])
 def test_karman_step_full_size_against_oracle(B, solver):
     """The three PressureSolver implementations (direct = fast diagonalisation + capacitance correction,
