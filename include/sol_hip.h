@@ -93,7 +93,8 @@ typedef struct sol_karman_cfg {
                                of the rectangle Laplacian by sine transforms + a dense capacitance correction for
                                the obstacle cells, prepared by the host for the scene's `active` mask (layout:
                                precond.direct_solver_blob).  Takes precedence over the CG; no iteration, the
-                               solution equals the converged CG solution up to fp32 round-off.                */
+                               solution equals the converged CG solution up to fp32 round-off.  Built for
+                               128 x 64 and for small grids (sol_karman_direct_supported).                     */
 } sol_karman_cfg;
 
 /* 1 if the two-level CG preconditioner can be used for a Y x X grid, else 0 */
