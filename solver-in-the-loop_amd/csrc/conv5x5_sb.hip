@@ -141,15 +141,19 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     constexpr int WPT = (WV + 767) / 768;
 
     // one float4 (4 channels of one halo pixel) of global row `gr` per thread (threads 0..543)
-    auto load_row = [&](int gr, int e) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e < HWP * 8) {
-            const int hc = e >> 3, c4 = e & 7, xx = x0 + hc - 2;
-            if (gr >= 0 && gr < nrows && xx >= 0 && xx < W) v = gx[((size_t)gr * W + xx) * 8 + c4];
-        }
-        return v;
+    // The loads are UNCONDITIONAL (lanes without a pixel read the tensor's first 16 bytes and are zeroed when the row is
+    // written to LDS): a predicated load sits in its own basic block, and the register allocator's copies at the join made
+    // the compiler wait for it right there -- a full memory round trip in the prologue, four in a row in the unrolled loop.
+    auto row_ok = [&](int gr, int e) {
+        const int xx = x0 + (e >> 3) - 2;
+        return e < HWP * 8 && gr >= 0 && gr < nrows && xx >= 0 && xx < W;
     };
-    auto store_row = [&](int slot, const float4& v, int e) {
+    auto load_row = [&](int gr, int e) {
+        const int xx = x0 + (e >> 3) - 2;
+        return gx[row_ok(gr, e) ? ((size_t)gr * W + xx) * 8 + (e & 7) : (size_t)0];
+    };
+    auto store_row = [&](int slot, int gr, float4 v, int e) {
+        if (!row_ok(gr, e)) v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e < HWP * 8) {
             const int hc = e >> 3, c4 = e & 7;
             unsigned p[3][2];
@@ -165,47 +169,32 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
             for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint2*>(q + pl * PLANE) = make_uint2(p[pl][0], p[pl][1]);
         }
     };
-    // -DSOL_CONV_DMA: tap-row weight sets by LDS-DMA (global_load_lds_dwordx4) instead of register staging.  Measured twice
-    // (round 1 and round 2): correct, but 13.14 -> 13.59 us per launch and 14.43 -> 15.11 ms per training step: off.
-#ifdef SOL_CONV_DMA
-    constexpr bool W_DMA = true;
-#else
-    constexpr bool W_DMA = false;
-#endif
-    typedef __attribute__((address_space(3))) void lds_void_t;
-    typedef __attribute__((address_space(1))) const void glb_cvoid_t;
-    // the packed weights are already in LDS image order: a linear copy of WBUF bytes in 1 KB chunks (64 lanes x 16 B), waves
-    // taking chunks round robin; landed when the next __syncthreads() (which waits vmcnt(0)) has passed
-    auto dma_w = [&](int dy, int buf) {
-        constexpr int CHUNKS = WBUF / 1024;
-        const int wv = tid >> 6;
-#pragma unroll
-        for (int n = 0; n < (CHUNKS + 11) / 12; ++n) {
-            const int c = wv + 12 * n;
-            if (c < CHUNKS)
-                __builtin_amdgcn_global_load_lds((glb_cvoid_t*)(gw + (size_t)dy * WV + c * 64 + lane),
-                                                 (lds_void_t*)(Wt + buf * WBUF + c * 1024), 16, 0, 0);
-        }
+    static_assert(WPT <= 3, "weight phase: at most three 16-byte pieces per thread");
+    // one thread's share of a tap-row weight set travels as up to three NAMED uint4 (arrays and structs passed by reference
+    // through the lambdas ended up in scratch memory); clamped index instead of a predicate: see load_row
+    auto load_w = [&](int dy, uint4& p0, uint4& p1, uint4& p2) {
+        p0 = gw[(size_t)dy * WV + (tid < WV ? tid : WV - 1)];
+        if constexpr (WPT >= 2) p1 = gw[(size_t)dy * WV + (tid + 768 < WV ? tid + 768 : WV - 1)];
+        if constexpr (WPT >= 3) p2 = gw[(size_t)dy * WV + (tid + 1536 < WV ? tid + 1536 : WV - 1)];
     };
-    auto load_w = [&](int dy, uint4 (&v)[WPT]) {
-#pragma unroll
-        for (int n = 0; n < WPT; ++n) {
-            const int e = tid + n * 768;
-            v[n] = e < WV ? gw[(size_t)dy * WV + e] : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto store_w = [&](int buf, const uint4 (&v)[WPT]) {
+    auto store_w = [&](int buf, const uint4& p0, const uint4& p1, const uint4& p2) {
         uint4* dst = reinterpret_cast<uint4*>(Wt + buf * WBUF);
-#pragma unroll
-        for (int n = 0; n < WPT; ++n) {
-            const int e = tid + n * 768;
-            if (e < WV) dst[e] = v[n];
-        }
+        if (tid < WV) dst[tid] = p0;
+        if constexpr (WPT >= 2) { if (tid + 768 < WV) dst[tid + 768] = p1; }
+        if constexpr (WPT >= 3) { if (tid + 1536 < WV) dst[tid + 1536] = p2; }
     };
 
+    // Two tap rows of look-ahead: the input row and the weight set of tap row dy+2 are requested at the start of tap row dy
+    // (two named register sets in flight), the row/weights of tap row dy+1 are written to LDS BETWEEN the taps of row dy (their
+    // ring slot / weight buffer is free for the whole tap row), and the barriers of the loop wait for LDS traffic only
+    // (__syncthreads() would also wait for the loads in flight).
+#define SB_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    float4 hvA = make_float4(0.f, 0.f, 0.f, 0.f), hvB = hvA;   // the two register sets in flight (named, not an array: an
+    uint4 wA0, wA1, wA2, wB0, wB1, wB2;                         // indexed pair was left in scratch memory by the compiler)
+    wA0 = wA1 = wA2 = wB0 = wB1 = wB2 = make_uint4(0u, 0u, 0u, 0u);
     {   // prologue: input rows G0-2, G0-1, G0 (one per tile group, 3 float4 per thread) and the weights of tap row 0
         float4 hv[3];
-        uint4 wv[WPT];
+        uint4 w0 = make_uint4(0u, 0u, 0u, 0u), w1 = w0, w2 = w0;
         // every global load of the prologue goes out before anything is waited for: the absmax slots of x (KIND 2) travel
         // together with the rows and the weights instead of costing a round trip of their own
         uint4 am = make_uint4(0u, 0u, 0u, 0u);
@@ -213,17 +202,20 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
         if constexpr (KIND == 2) { am = amax_load(a.xmax); winv = reinterpret_cast<const float*>(a.wsh)[1]; }
 #pragma unroll
         for (int n = 0; n < 3; ++n) hv[n] = load_row(G0 - 2 + grp, t + n * 256);
-        if (W_DMA) dma_w(0, 0); else load_w(0, wv);
+        load_w(0, w0, w1, w2);
+        hvA = load_row(G0 + 1, tid);
+        load_w(1, wA0, wA1, wA2);
+        __builtin_amdgcn_sched_barrier(0);             // (the scheduler sank a weight load to its use otherwise)
         if constexpr (KIND == 2) {
             float sai;
             amax_scale_of(am, sa, sai);
             out_scale = sai * winv;
         }
 #pragma unroll
-        for (int n = 0; n < 3; ++n) store_row(grp, hv[n], t + n * 256);
-        if (!W_DMA) store_w(0, wv);
+        for (int n = 0; n < 3; ++n) store_row(grp, G0 - 2 + grp, hv[n], t + n * 256);
+        store_w(0, w0, w1, w2);
     }
-    __syncthreads();
+    SB_BARRIER();
     SOL_CSTAMP(1);
     if (SOL_CONV_TRUNC == 1) return;
 
@@ -248,23 +240,33 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     constexpr bool EPI_PREFETCH = false;
 #endif
 
-#pragma unroll 1
-    for (int dy = 0; dy < 5; ++dy) {
-        float4 hv;
-        uint4 wv[WPT];
+#ifndef SOL_CONV_STAGE_AT
+#define SOL_CONV_STAGE_AT 1, 3
+#endif
+    constexpr int STAGE_AT[2] = {SOL_CONV_STAGE_AT};
+    constexpr int STAGE_ROW_AT = STAGE_AT[0], STAGE_W_AT = STAGE_AT[1];   // after which tap (dx) the row / the weights are written
+    // one tap row: requests (row, weights) of tap row `nxt` into (hin, win) -- nxt < 0: nothing --, runs the five taps, writes
+    // (hout, wout) = row G0+dy+1 and the weights of tap row dy+1 to LDS
+    auto tap_row = [&](const int dy, const int nxt, float4& hin, uint4& wi0, uint4& wi1, uint4& wi2,
+                       const float4& hout, const uint4& wo0, const uint4& wo1, const uint4& wo2)
+                       __attribute__((always_inline)) {
         if (EPI_PREFETCH && dy == 3 && tvalid && a.CO == OP) {
 #pragma unroll
             for (int n = 0; n < EF4; ++n) {
                 const int e = lane + n * 64, px = e / (OP / 4), c4 = e % (OP / 4);
                 const size_t o4 = ((size_t)gy * W + x0 + wave * 16 + px) * (OP / 4) + c4;
-                if (a.res) pres[n] = reinterpret_cast<const float4*>(a.res)[o4];
-                if (a.epi == SOL_EPI_DLRELU) pact[n] = reinterpret_cast<const float4*>(a.act)[o4];
+                // unconditional as well (an absent operand reads the first 16 bytes of x; the epilogue ignores it)
+                const float4* rp = a.res ? reinterpret_cast<const float4*>(a.res) + o4 : gx;
+                const float4* ap = a.epi == SOL_EPI_DLRELU ? reinterpret_cast<const float4*>(a.act) + o4 : gx;
+                pres[n] = *rp;
+                pact[n] = *ap;
             }
         }
-        if (dy < 4) {
-            hv = load_row(G0 + dy + 1, tid);          // the one new input row of the next tap row: G0-2 + (dy+1) + 2
-            if (W_DMA) dma_w(dy + 1, (dy + 1) & 1); else load_w(dy + 1, wv);
+        if (nxt >= 0) {
+            hin = load_row(G0 + nxt, tid);            // the one new input row of tap row nxt: G0-2 + nxt + 2
+            load_w(nxt, wi0, wi1, wi2);
         }
+        __builtin_amdgcn_sched_barrier(0);
         const int src = gy + dy - 2;                  // input row of this tile for this tap row
         if (tvalid && src >= row_lo && src < row_hi) {            // wave uniform
             const unsigned char* hrow = ring + ((grp + dy) & 3) * SLOT;
@@ -273,6 +275,17 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
             auto load_ops = [&](int dx, uint4 (&ar)[NPL], uint4 (&br)[NT][NPL]) {
                 const int hc = pcc + dx;
                 const unsigned char* ap = hrow + hc * 64 + ((g ^ swzb(hc)) << 4);
+#ifdef SOL_CONV_EXP_NOLDS                             // experiment (tools/conv_variants.py): operands from registers, no ds_read
+                unsigned fake = 0x2c112e37u + (unsigned)(size_t)ap * 0x00010001u + dx;
+                asm volatile("" : "+v"(fake));
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) ar[pl] = make_uint4(fake, fake ^ 0x01000100u, fake + 0x00030002u, fake ^ 0x00100010u);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) br[n][pl] = make_uint4(fake ^ 0x02000200u, fake, fake ^ 0x00010100u, fake + 0x00010001u);
+                return;
+#endif
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) ar[pl] = *reinterpret_cast<const uint4*>(ap + pl * PLANE);
 #pragma unroll
@@ -288,6 +301,15 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
             for (int dx = 0; dx < 5; ++dx) {
                 if (dx < 4) load_ops(dx + 1, ao[(dx + 1) & 1], bo[(dx + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ds_reads above this tap's MFMAs
+#ifdef SOL_CONV_EXP_NOMFMA                            // experiment: the ds_reads are consumed, no MFMA issued
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    { const uint4 q = ao[dx & 1][pl]; asm volatile("" :: "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w)); }
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) { const uint4 q = bo[dx & 1][n][pl]; asm volatile("" :: "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w)); }
+                }
+                continue;
+#endif
                 if constexpr (KIND == 2) {
                     const f16x8 a1 = __builtin_bit_cast(f16x8, ao[dx & 1][0]), a2 = __builtin_bit_cast(f16x8, ao[dx & 1][NPL - 1]);
 #pragma unroll
@@ -309,14 +331,24 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                // staging of the next tap row in the shadow of this row's MFMAs (slot of row G0+dy+1: its previous tenant,
+                // row G0+dy-3, is dead; weight buffer (dy+1)&1: set dy-1 is dead)
+                if (dy < 4 && dx == STAGE_ROW_AT) { store_row((dy + 3) & 3, G0 + dy + 1, hout, tid); __builtin_amdgcn_sched_barrier(0); }
+                if (dy < 4 && dx == STAGE_W_AT) { store_w((dy + 1) & 1, wo0, wo1, wo2); __builtin_amdgcn_sched_barrier(0); }
             }
+        } else if (dy < 4) {                           // a wave without taps in this row (image border) only stages
+            store_row((dy + 3) & 3, G0 + dy + 1, hout, tid);
+            store_w((dy + 1) & 1, wo0, wo1, wo2);
         }
-        if (dy < 4) {
-            store_row((dy + 3) & 3, hv, tid);          // slot of row G0 + dy + 1; its previous tenant (row G0+dy-3) is dead
-            if (!W_DMA) store_w((dy + 1) & 1, wv);
-        }
-        __syncthreads();
+        SB_BARRIER();
         SOL_CSTAMP(2 + dy);
+    };
+    {
+        tap_row(0, 2, hvB, wB0, wB1, wB2, hvA, wA0, wA1, wA2);
+        tap_row(1, 3, hvA, wA0, wA1, wA2, hvB, wB0, wB1, wB2);
+        tap_row(2, 4, hvB, wB0, wB1, wB2, hvA, wA0, wA1, wA2);
+        tap_row(3, -1, hvA, wA0, wA1, wA2, hvB, wB0, wB1, wB2);
+        tap_row(4, -1, hvA, wA0, wA1, wA2, hvB, wB0, wB1, wB2);
     }
     if (SOL_CONV_TRUNC == 2) { if (acc[0][0] + acc[NT - 1][3] == 1.2345f) a.y[tid] = acl[0][1]; return; }
     if constexpr (KIND == 2) {

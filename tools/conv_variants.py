@@ -41,7 +41,8 @@ B, Y, X = 6, 128, 64
 dev = "cuda"
 x = torch.randn(B, Y, X, 32, device=dev)
 res = torch.randn(B, Y, X, 32, device=dev)
-packed = ops._pack(torch.randn(5, 5, 32, 32, device=dev) * 0.05, 32, 32, ops.CONV_FWD)
+w_raw = torch.randn(5, 5, 32, 32, device=dev) * 0.05
+packed = ops._pack(w_raw, 32, 32, ops.CONV_FWD)
 bias = torch.randn(32, device=dev)
 y = torch.empty_like(x)
 nslots = lib.sol_absmax_slots() if hasattr(lib, "sol_absmax_slots") else 64
@@ -78,3 +79,9 @@ t2 = timed(conv(ops.EPI_LRELU, None, None, None))
 t3 = timed(conv(ops.EPI_LRELU, ptr(res), None, ptr(yam)))
 t4 = timed(conv(ops.EPI_DLRELU, ptr(res), ptr(x), ptr(yam)))
 print("%-44s lrelu+ymax %.2f | lrelu %.2f | res+lrelu+ymax %.2f | res+dlrelu+ymax %.2f us" % (os.path.basename(lib_path), t1, t2, t3, t4))
+
+# correctness of the variant (residual + LeakyReLU) against float64 torch
+conv(ops.EPI_LRELU, ptr(res), None, ptr(yam))(); torch.cuda.synchronize()
+ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w_raw.double().permute(3, 2, 0, 1), bias.double(), padding=2).permute(0, 2, 3, 1) + res.double()
+ref = torch.where(ref > 0, ref, 0.3 * ref)
+print("    rel-L2 error vs float64: %.2e" % ((y.double() - ref).norm() / ref.norm()).item())
