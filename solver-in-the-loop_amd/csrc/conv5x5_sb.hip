@@ -119,7 +119,10 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     if (SOL_CONV_TRUNC == 0) return;
     SOL_CSTAMP(0);
     if (threadIdx.x == 0) *reinterpret_cast<uint2*>(smem_sb + AMAX_LDS) = make_uint2(0u, 0u);      // see amax_publish_last
-    const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = tid & 63, wave = (tid >> 6) & 3;
+    // the wave index is read into an SGPR: everything derived from it (tile row, image bounds, "does this wave have taps in
+    // this tap row") is then provably wave uniform -- scalar branches instead of exec-masked regions that the compiler
+    // executes back to back with conservative waits at the joins
+    const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wid >> 2, t = tid & 255, lane = tid & 63, wave = wid & 3;
     const int g = lane >> 4, li = lane & 15;
     const int H = a.H, W = a.W;
     // workgroup = three CONSECUTIVE global image rows G0 .. G0+2 (row = b*H + y) of one 64-pixel column block:
@@ -231,9 +234,19 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     // training pipeline they come from HBM (the forward activations are hundreds of launches old), a 2 us round trip that
     // otherwise sits between the last MFMA and the first store
     constexpr int EF4 = 16 * OP / 4 / 64;             // float4 per lane of the wave's [16 px][OP] tile
-    float4 pres[EF4], pact[EF4];
-#pragma unroll
-    for (int n = 0; n < EF4; ++n) { pres[n] = make_float4(0.f, 0.f, 0.f, 0.f); pact[n] = make_float4(1.f, 1.f, 1.f, 1.f); }
+    // They travel by LDS-DMA into a per-wave 2 x EF4 KB region ([res | act][n][lane] float4: every lane reads back exactly what
+    // it requested), not into registers: with register destinations the register allocator copied a freshly requested value
+    // (`global_load; s_waitcnt vmcnt(0); v_mov`) -- a memory round trip in the open, once per launch.  The request is inline
+    // assembly: after the BUILTIN the compiler makes the next ds_read wait for the request (it cannot tell that the operand
+    // reads do not alias the DMA target), i.e. the first operand read of tap row 4 waited for the round trip.  Requests the
+    // compiler does not know about only make its own vmcnt waits longer, never shorter (the counter retires in order); the
+    // read-back in the epilogue is ordered by an explicit s_waitcnt vmcnt(0).
+    __shared__ __align__(16) unsigned char pf_lds[12 * 2 * EF4 * 1024];
+    unsigned char* pf = pf_lds + wid * (2 * EF4 * 1024);
+    auto lds_dma16 = [&](const void* src, unsigned char* dst_wave_uniform) __attribute__((always_inline)) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst_wave_uniform);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(lo) : "m0");
+    };
 #ifndef SOL_CONV_LATE_EPI                             // (A/B switch: 14.85 -> 14.77 ms per training step)
     constexpr bool EPI_PREFETCH = true;
 #else
@@ -250,28 +263,33 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     auto tap_row = [&](const int dy, const int nxt, float4& hin, uint4& wi0, uint4& wi1, uint4& wi2,
                        const float4& hout, const uint4& wo0, const uint4& wo1, const uint4& wo2)
                        __attribute__((always_inline)) {
-        if (EPI_PREFETCH && dy == 3 && tvalid && a.CO == OP) {
+        // requested AFTER the last staging store of tap row 3: the compiler's wait counts are conservative across the
+        // staging branches, and a request before them was waited for (a round trip in the open) when the weights were written
+        auto epi_prefetch = [&]() __attribute__((always_inline)) {
+            if (EPI_PREFETCH && tvalid && a.CO == OP) {
 #pragma unroll
-            for (int n = 0; n < EF4; ++n) {
-                const int e = lane + n * 64, px = e / (OP / 4), c4 = e % (OP / 4);
-                const size_t o4 = ((size_t)gy * W + x0 + wave * 16 + px) * (OP / 4) + c4;
-                // unconditional as well (an absent operand reads the first 16 bytes of x; the epilogue ignores it)
-                const float4* rp = a.res ? reinterpret_cast<const float4*>(a.res) + o4 : gx;
-                const float4* ap = a.epi == SOL_EPI_DLRELU ? reinterpret_cast<const float4*>(a.act) + o4 : gx;
-                pres[n] = *rp;
-                pact[n] = *ap;
+                for (int n = 0; n < EF4; ++n) {
+                    const int e = lane + n * 64, px = e / (OP / 4), c4 = e % (OP / 4);
+                    const size_t o4 = ((size_t)gy * W + x0 + wave * 16 + px) * (OP / 4) + c4;
+                    if (a.res) lds_dma16(reinterpret_cast<const float4*>(a.res) + o4, pf + n * 1024);
+                    if (a.epi == SOL_EPI_DLRELU) lds_dma16(reinterpret_cast<const float4*>(a.act) + o4, pf + (EF4 + n) * 1024);
+                }
             }
-        }
+        };
         if (nxt >= 0) {
             hin = load_row(G0 + nxt, tid);            // the one new input row of tap row nxt: G0-2 + nxt + 2
             load_w(nxt, wi0, wi1, wi2);
         }
         __builtin_amdgcn_sched_barrier(0);
         const int src = gy + dy - 2;                  // input row of this tile for this tap row
-        if (tvalid && src >= row_lo && src < row_hi) {            // wave uniform
-            const unsigned char* hrow = ring + ((grp + dy) & 3) * SLOT;
-            const unsigned char* wbuf = Wt + (dy & 1) * WBUF;
-            uint4 ao[2][NPL], bo[2][NT][NPL];
+        // The staging / prefetch code stands ONCE, outside the "has taps" conditionals (a wave of a border tile skips the taps
+        // of tap rows that lie in another image): with a second copy in an else branch the compiler merged the two paths'
+        // outstanding-load state conservatively and waited (vmcnt(0)) at the start of the next tap row.
+        const bool has_taps = tvalid && src >= row_lo && src < row_hi;   // wave uniform (SGPR)
+        const unsigned char* hrow = ring + ((grp + dy) & 3) * SLOT;
+        const unsigned char* wbuf = Wt + (dy & 1) * WBUF;
+        uint4 ao[2][NPL], bo[2][NT][NPL];
+        {
             auto load_ops = [&](int dx, uint4 (&ar)[NPL], uint4 (&br)[NT][NPL]) {
                 const int hc = pcc + dx;
                 const unsigned char* ap = hrow + hc * 64 + ((g ^ swzb(hc)) << 4);
@@ -296,9 +314,10 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
                     for (int pl = 0; pl < NPL; ++pl) br[n][pl] = *reinterpret_cast<const uint4*>(bp + pl * WPL);
                 }
             };
-            load_ops(0, ao[0], bo[0]);
+            auto taps = [&](const int dx0, const int dx1) __attribute__((always_inline)) {
+            if (dx0 == 0) load_ops(0, ao[0], bo[0]);
 #pragma unroll
-            for (int dx = 0; dx < 5; ++dx) {
+            for (int dx = dx0; dx < dx1; ++dx) {
                 if (dx < 4) load_ops(dx + 1, ao[(dx + 1) & 1], bo[(dx + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ds_reads above this tap's MFMAs
 #ifdef SOL_CONV_EXP_NOMFMA                            // experiment: the ds_reads are consumed, no MFMA issued
@@ -331,14 +350,17 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                // staging of the next tap row in the shadow of this row's MFMAs (slot of row G0+dy+1: its previous tenant,
-                // row G0+dy-3, is dead; weight buffer (dy+1)&1: set dy-1 is dead)
-                if (dy < 4 && dx == STAGE_ROW_AT) { store_row((dy + 3) & 3, G0 + dy + 1, hout, tid); __builtin_amdgcn_sched_barrier(0); }
-                if (dy < 4 && dx == STAGE_W_AT) { store_w((dy + 1) & 1, wo0, wo1, wo2); __builtin_amdgcn_sched_barrier(0); }
             }
-        } else if (dy < 4) {                           // a wave without taps in this row (image border) only stages
-            store_row((dy + 3) & 3, G0 + dy + 1, hout, tid);
-            store_w((dy + 1) & 1, wo0, wo1, wo2);
+            };
+            // staging of the next tap row in the shadow of this row's MFMAs (slot of row G0+dy+1: its previous tenant,
+            // row G0+dy-3, is dead; weight buffer (dy+1)&1: set dy-1 is dead)
+            static_assert(STAGE_ROW_AT <= STAGE_W_AT && STAGE_W_AT <= 4, "staging positions");
+            if (has_taps) taps(0, STAGE_ROW_AT + 1);
+            if (dy < 4) { store_row((dy + 3) & 3, G0 + dy + 1, hout, tid); __builtin_amdgcn_sched_barrier(0); }
+            if (has_taps) taps(STAGE_ROW_AT + 1, STAGE_W_AT + 1);
+            if (dy < 4) { store_w((dy + 1) & 1, wo0, wo1, wo2); __builtin_amdgcn_sched_barrier(0); }
+            if (dy == 3) { epi_prefetch(); __builtin_amdgcn_sched_barrier(0); }
+            if (has_taps) taps(STAGE_W_AT + 1, 5);
         }
         SB_BARRIER();
         SOL_CSTAMP(2 + dy);
@@ -370,6 +392,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
             for (int r = 0; r < 4; ++r) tb[(4 * g + r) * OP + n * 16 + li] = acc[n][r] + bias;
         }
         // same-wave LDS round trip: the compiler's s_waitcnt lgkmcnt orders write -> read
+        if (EPI_PREFETCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of res / act has landed
         if (tvalid) {
             constexpr int F4 = 16 * OP / 4 / 64;          // float4 per lane
 #pragma unroll
@@ -378,12 +401,12 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
                 const int px = e / (OP / 4), c4 = e % (OP / 4);
                 float4 v = *reinterpret_cast<const float4*>(&tb[px * OP + c4 * 4]);
                 const size_t o4 = ((size_t)gy * W + x0 + wave * 16 + px) * (OP / 4) + c4;
-                if (a.res) { const float4 q = EPI_PREFETCH ? pres[n] : reinterpret_cast<const float4*>(a.res)[o4]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+                if (a.res) { const float4 q = EPI_PREFETCH ? *reinterpret_cast<const float4*>(pf + n * 1024 + lane * 16) : reinterpret_cast<const float4*>(a.res)[o4]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
                 if (a.epi == SOL_EPI_LRELU) {
                     v.x = v.x > 0.f ? v.x : a.slope * v.x; v.y = v.y > 0.f ? v.y : a.slope * v.y;
                     v.z = v.z > 0.f ? v.z : a.slope * v.z; v.w = v.w > 0.f ? v.w : a.slope * v.w;
                 } else if (a.epi == SOL_EPI_DLRELU) {
-                    const float4 q = EPI_PREFETCH ? pact[n] : reinterpret_cast<const float4*>(a.act)[o4];
+                    const float4 q = EPI_PREFETCH ? *reinterpret_cast<const float4*>(pf + (EF4 + n) * 1024 + lane * 16) : reinterpret_cast<const float4*>(a.act)[o4];
                     v.x *= q.x > 0.f ? 1.f : a.slope; v.y *= q.y > 0.f ? 1.f : a.slope;
                     v.z *= q.z > 0.f ? 1.f : a.slope; v.w *= q.w > 0.f ? 1.f : a.slope;
                 }
@@ -519,6 +542,7 @@ __global__ void __launch_bounds__(256) k_pack_jobs(PackJobs jobs) {
     }
 }
 
+// dynamic part: ring + two weight buffers (three planes: the bf16 kinds) + absmax words (the kernels add 24 x OP/16 KB static)
 constexpr size_t sb_lds(int OP) { return (size_t)4 * 3 * 68 * 64 + 2 * (size_t)5 * 3 * OP * 64 + 16; }
 
 int init_sb_kernels() {
@@ -526,9 +550,13 @@ int init_sb_kernels() {
         const void* ks[] = {reinterpret_cast<const void*>(k_conv5x5_bww_sb<0>), reinterpret_cast<const void*>(k_conv5x5_bww_sb<2>), reinterpret_cast<const void*>(k_conv5x5_sb<1, 0>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 0>),
                             reinterpret_cast<const void*>(k_conv5x5_sb<1, 1>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 1>),
                             reinterpret_cast<const void*>(k_conv5x5_sb<1, 2>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 2>)};
-        for (const void* k : ks)
-            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        for (const void* k : ks) {
+            // static LDS (the conv kernels' epilogue-prefetch regions) counts against the same 160 KB
+            hipFuncAttributes fa;
+            if (hipFuncGetAttributes(&fa, k) != hipSuccess) return sol_set_error(SOL_ERR_HIP, "hipFuncGetAttributes(split conv kernels) failed");
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes) != hipSuccess)
                 return sol_set_error(SOL_ERR_HIP, "hipFuncSetAttribute(split-bf16 conv kernels) failed");
+        }
         return SOL_OK;
     }();
     return rc;
