@@ -192,6 +192,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     // ring slot / weight buffer is free for the whole tap row), and the barriers of the loop wait for LDS traffic only
     // (__syncthreads() would also wait for the loads in flight).
 #define SB_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    float biasv[NT];                                  // bias of output channel n*16 + li (0 without a bias / beyond CO)
     float4 hvA = make_float4(0.f, 0.f, 0.f, 0.f), hvB = hvA;   // the two register sets in flight (named, not an array: an
     uint4 wA0, wA1, wA2, wB0, wB1, wB2;                         // indexed pair was left in scratch memory by the compiler)
     wA0 = wA1 = wA2 = wB0 = wB1 = wB2 = make_uint4(0u, 0u, 0u, 0u);
@@ -203,6 +204,12 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
         uint4 am = make_uint4(0u, 0u, 0u, 0u);
         float winv = 1.f;
         if constexpr (KIND == 2) { am = amax_load(a.xmax); winv = reinterpret_cast<const float*>(a.wsh)[1]; }
+        {   // the biases travel with the prologue's requests too (they were two serial round trips in the epilogue); without a
+            // bias the lanes read x[0] and the value is dropped
+            const float* bp = a.bias ? a.bias : a.x;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) biasv[n] = bp[a.bias ? (n * 16 + li < a.CO ? n * 16 + li : 0) : 0];
+        }
 #pragma unroll
         for (int n = 0; n < 3; ++n) hv[n] = load_row(G0 - 2 + grp, t + n * 256);
         load_w(0, w0, w1, w2);
@@ -387,7 +394,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
         float* tb = reinterpret_cast<float*>(halo) + wave * (16 * OP);   // 16 px x OP floats per wave
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const float bias = a.bias ? a.bias[n * 16 + li] : 0.f;
+            const float bias = a.bias ? biasv[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) tb[(4 * g + r) * OP + n * 16 + li] = acc[n][r] + bias;
         }
@@ -421,7 +428,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
         float lsum = 0.f;
         if (tvalid && li < 2) {
             const int jj = gy - b * H, nVy = (H + 1) * W, nVx = H * (W + 1);
-            const float bias = a.bias ? a.bias[li] : 0.f;
+            const float bias = a.bias ? biasv[0] : 0.f;
             const float s = li == 0 ? a.cs0 : a.cs1, ls = li == 0 ? a.ls0 : a.ls1;
             float* vf = li == 0 ? a.cvy + (size_t)b * nVy + (size_t)jj * W : a.cvx + (size_t)b * nVx + (size_t)jj * (W + 1);
             const float* gt = li == 0 ? (a.gty ? a.gty + (size_t)b * nVy + (size_t)jj * W : nullptr)
@@ -450,7 +457,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
         for (int n = 0; n < NT; ++n) {
             const int co = n * 16 + li;
             if (co >= a.CO) continue;
-            const float bias = a.bias ? a.bias[co] : 0.f;
+            const float bias = a.bias ? biasv[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int cc = wave * 16 + 4 * g + r;

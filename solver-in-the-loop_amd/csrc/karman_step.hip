@@ -694,9 +694,13 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
     // ---- spectral coefficients of the correction: t2w = Qy[:, win] W2 ; T2 += (t2w Qx[win, :]) / lam
     {
         f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+        float qw[FD_WIN];
+#pragma unroll
+        for (int jw = 0; jw < FD_WIN; ++jw) qw[jw] = F.Qy[(size_t)(F.wy0 + jw) * FD_Y + m];
+        __builtin_amdgcn_sched_barrier(0);              // all 16 requests in flight before the first use (1.6 -> 0.7 us)
 #pragma unroll
         for (int jw = 0; jw < FD_WIN; ++jw) {
-            const float qv = F.Qy[(size_t)(F.wy0 + jw) * FD_Y + m];
+            const float qv = qw[jw];
             const float4 wv = *reinterpret_cast<const float4*>(W2 + jw * FD_WIN + 4 * cb);
             const f2 qq = {qv, qv};
             a0 += qq * (f2){wv.x, wv.y};
