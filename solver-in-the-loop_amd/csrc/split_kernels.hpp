@@ -84,19 +84,21 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
     constexpr int BW_XST = NPL * BW_XPL, BW_ZST = NPL * BW_ZPL;
     unsigned char* const XS = smem_sb;
     unsigned char* const ZS = smem_sb + 2 * BW_XST;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wave index is read into an SGPR: staging role, tile coordinates and every row-range test below are then scalar
+    // branches (an exec-masked region per role made the compiler wait for a load inside the region it was issued in)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
     const int mt = wave & 1, nt = (wave >> 1) & 1, kb = wave >> 2;
     const int H = a.H;
     const int R = a.nseg * a.B * H, RPS = a.B * H;
     const int r0 = blk * a.rb, r1 = min(r0 + a.rb, R);
 
-    // staging roles, one item = 2 pixels x 4 channels: threads 0..255 move the x items of halo pixels 0..63 (and threads
-    // 0..15 a second one for halo pixels 64..67), threads 256..511 the dz items -- every wave carries an equal share
-    const bool xrole = tid < 256, zrole = !xrole, xrole2 = tid < 16;
-    const int it = xrole ? tid : tid - 256;
+    // Staging roles: waves 0..3 move the x row, waves 4..7 the dz row.  One item = 2 pixels x 4 channels (two float4 requests);
+    // both roles have exactly 256 items per row: x items are the image pixel pairs (2i, 2i+1) -> halo positions (2i+2, 2i+3);
+    // the halo positions 0, 1, 66, 67 of every x stage are zero for good (written once below).  No request is predicated.
+    const bool xrole = wave < 4;
+    const int it = tid & 255;
     const int pxg = it >> 3, c4 = it & 7;          // 2-pixel group, channel quad
-    float4 sv[2], sv2[2];
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
     float sx = 1.f, sz = 1.f, out_scale = 1.f;
     if constexpr (KIND == 2) {
@@ -111,29 +113,28 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
         const int seg = gr / RPS, grs = gr - seg * RPS;
         return reinterpret_cast<const float4*>(base + (size_t)seg * seg_stride) + (size_t)grs * W * 8;
     };
-    auto load_x = [&](int gr) {
-        const float4* gx = row_ptr(a.x, a.x_seg, gr);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int xx = 2 * pxg - 2 + j;
-            sv[j] = (xx >= 0 && xx < W) ? gx[xx * 8 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (xrole2) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int xx = 2 * (32 + pxg) - 2 + j;       // halo pixels 64..67 -> image pixels 62..65
-                sv2[j] = xx < W ? gx[xx * 8 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    };
-    auto load_z = [&](int gz) {
-        const float4* gzp = row_ptr(a.dz, a.dz_seg, gz);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) sv[j] = gzp[(2 * pxg + j) * 8 + c4];
+    // this thread's item of x row gx_row (x role) or dz row gz_row (dz role); rows outside [0, R) are replaced by row r0 (their
+    // item is requested and dropped)
+    // the role's tensor and segment stride, selected ONCE and made opaque (left as `xrole ? a.x : a.dz` at the point of use the
+    // compiler built a two-entry table in scratch memory and read it back in every row)
+    unsigned long long role_base = (unsigned long long)(xrole ? a.x : a.dz);
+    long role_seg = xrole ? a.x_seg : a.dz_seg;
+    asm volatile("" : "+s"(role_base), "+s"(role_seg));
+    auto request = [&](int gx_row, int gz_row, float4& v0, float4& v1) __attribute__((always_inline)) {
+        const int gr = xrole ? gx_row : gz_row;
+        // (global address space spelled out: a pointer made from the opaque integer is generic, and flat loads also count in
+        // lgkmcnt -- the LDS-only barriers below would wait for them)
+        typedef const f32x4 __attribute__((address_space(1)))* gf4p;
+        const int rr = gr >= 0 && gr < R ? gr : r0, seg = rr / RPS, grs = rr - seg * RPS;
+        gf4p rp = (gf4p)(role_base + ((unsigned long long)seg * role_seg + (unsigned long long)grs * W * 32) * sizeof(float));
+        const f32x4 q0 = rp[(2 * pxg) * 8 + c4], q1 = rp[(2 * pxg + 1) * 8 + c4];
+        v0 = make_float4(q0[0], q0[1], q0[2], q0[3]);
+        v1 = make_float4(q1[0], q1[1], q1[2], q1[3]);
     };
     // split the 2 px x 4 ch item and write it transposed: per channel one 4-byte piece (2 pixels) per plane
-    auto store_item = [&](const float4 (&v)[2], int pg, unsigned char* base, int plane_bytes, int row_bytes, bool is_x) {
-        const float e[4][2] = {{v[0].x, v[1].x}, {v[0].y, v[1].y}, {v[0].z, v[1].z}, {v[0].w, v[1].w}};
+    auto store_item = [&](const float4& v0, const float4& v1, int pg, unsigned char* base, int plane_bytes, int row_bytes, bool is_x)
+                          __attribute__((always_inline)) {
+        const float e[4][2] = {{v0.x, v1.x}, {v0.y, v1.y}, {v0.z, v1.z}, {v0.w, v1.w}};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int ch = 4 * c4 + c;
@@ -146,36 +147,52 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
             for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<unsigned*>(q + pl * plane_bytes) = p[pl];
         }
     };
-    auto store_x = [&](int gr) {
-        store_item(sv, pxg, XS + (gr & 1) * BW_XST, BW_XPL, 256, true);
-        if (xrole2) store_item(sv2, 32 + pxg, XS + (gr & 1) * BW_XST, BW_XPL, 256, true);
-    };
-    auto store_z = [&](int gz) {
-        store_item(sv, pxg, ZS + ((gz + 6) % 6) * BW_ZST, BW_ZPL, 128, false);
-        if (gz >= r0 && gz < r1) {   // bias gradient: every owned dz row is staged exactly once
-            bs[0] += sv[0].x + sv[1].x;
-            bs[1] += sv[0].y + sv[1].y;
-            bs[2] += sv[0].z + sv[1].z;
-            bs[3] += sv[0].w + sv[1].w;
+    // write the item as x row gx_row / dz row gz_row (callers pass rows that are in range for the thread's role)
+    auto stage = [&](int gx_row, int gz_row, const float4& v0, const float4& v1) __attribute__((always_inline)) {
+        if (xrole) store_item(v0, v1, pxg + 1, XS + (gx_row & 1) * BW_XST, BW_XPL, 256, true);
+        else {
+            store_item(v0, v1, pxg, ZS + ((gz_row + 6) % 6) * BW_ZST, BW_ZPL, 128, false);
+            if (gz_row >= r0 && gz_row < r1) {   // bias gradient: every owned dz row is staged exactly once
+                bs[0] += v0.x + v1.x;
+                bs[1] += v0.y + v1.y;
+                bs[2] += v0.z + v1.z;
+                bs[3] += v0.w + v1.w;
+            }
         }
     };
+    auto z_in_range = [&](int gz) { return gz >= 0 && gz < R && gz <= r1 + 1; };
 
-    // ---- prologue: dz rows r0-2 .. r0+2 and x row r0 ------------------------------------------
-    if (xrole) { load_x(r0); store_x(r0); }
-    if (zrole) {   // all five loads in flight before the first split (the accumulators are not live yet)
+    // ---- prologue: dz rows r0-2 .. r0+2 and x row r0 go to LDS; the items of x rows r0+1, r0+2 / dz rows r0+3, r0+4 are
+    //      requested into the register sets B and C (three rows of look-ahead: the operands come from HBM -- forward activations
+    //      and gradients written hundreds of launches ago -- and a row of MFMA work covers about half of that round trip) ----
+    float4 sA0, sA1, sB0, sB1, sC0, sC1;
+    sA0 = sA1 = sB0 = sB1 = sC0 = sC1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
         float4 pv[5][2];
+        if (xrole) request(r0, 0, pv[0][0], pv[0][1]);
+        else {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int gz = r0 - 2 + k;
-            if (gz >= 0 && gz < R) { load_z(gz); for (int j = 0; j < 2; ++j) pv[k][j] = sv[j]; }
+            for (int k = 0; k < 5; ++k) request(0, r0 - 2 + k, pv[k][0], pv[k][1]);
         }
+        request(r0 + 1 < r1 ? r0 + 1 : r0, r0 + 3, sB0, sB1);
+        request(r0 + 2 < r1 ? r0 + 2 : r0, r0 + 4, sC0, sC1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (xrole) {
+            stage(r0, 0, pv[0][0], pv[0][1]);
+            // the zero halo positions (0, 1) and (66, 67) of both stages, all planes: 2 x NPL x 32 channels x 2 pieces
+            for (int e = tid; e < 2 * NPL * 32 * 2; e += 256) {
+                const int side = e & 1, ch = (e >> 1) & 31, pl = (e >> 6) % NPL, st = e / (64 * NPL);
+                const int pg = side ? 33 : 0;
+                *reinterpret_cast<unsigned*>(XS + st * BW_XST + pl * BW_XPL + ch * 256 + ((((pg >> 2) ^ (ch & 15)) << 4) | ((pg & 3) << 2))) = 0u;
+            }
+        } else {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int gz = r0 - 2 + k;
-            if (gz >= 0 && gz < R) { for (int j = 0; j < 2; ++j) sv[j] = pv[k][j]; store_z(gz); }
+            for (int k = 0; k < 5; ++k)
+                if (z_in_range(r0 - 2 + k)) stage(0, r0 - 2 + k, pv[k][0], pv[k][1]);
         }
     }
-    __syncthreads();
+#define BW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")   /* LDS only: requests stay in flight */
+    BW_BARRIER();
 
     f32x4 acc[25];
 #pragma unroll
@@ -184,12 +201,12 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
     constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
     const int c0 = 4 * kb + g;
 
-#pragma unroll 1
-    for (int gr = r0; gr < r1; ++gr) {
+    // one image row: request the items of x row gr+3 / dz row gr+5 into (i0, i1), run the 25 taps of row gr, write the items
+    // held in (o0, o1) -- x row gr+1 / dz row gr+3, requested two iterations ago -- to LDS
+    auto do_row = [&](const int gr, float4& i0, float4& i1, const float4& o0, const float4& o1) __attribute__((always_inline)) {
         const int y = gr % H;
-        const bool nx = gr + 1 < r1, nz = gr + 3 < R && gr + 3 <= r1 + 1;
-        if (xrole && nx) load_x(gr + 1);
-        if (zrole && nz) load_z(gr + 3);
+        request(gr + 3 < r1 ? gr + 3 : r0, gr + 5, i0, i1);
+        __builtin_amdgcn_sched_barrier(0);
 
         // x operand of this lane: pixels 8*c0 .. 8*c0+11 (halo coordinates) of channel 16*mt + li, three planes
         uint4 A[NPL][5];
@@ -234,10 +251,22 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
                                                                                    acc[dy * 5 + dx], 0, 0, 0);
             }
         }
-        if (xrole && nx) store_x(gr + 1);
-        if (zrole && nz) store_z(gr + 3);
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if (xrole ? gr + 1 < r1 : z_in_range(gr + 3)) stage(gr + 1, gr + 3, o0, o1);
+        BW_BARRIER();
+    };
+    // (six rows per trip: at the loop's back edge the compiler's wait-count pass gives up on the requests in flight and waits
+    // for all of them -- once per six rows instead of once per three)
+#pragma unroll 1
+    for (int gr = r0; gr < r1; gr += 6) {
+        do_row(gr, sA0, sA1, sB0, sB1);
+        if (gr + 1 < r1) do_row(gr + 1, sB0, sB1, sC0, sC1);
+        if (gr + 2 < r1) do_row(gr + 2, sC0, sC1, sA0, sA1);
+        if (gr + 3 < r1) do_row(gr + 3, sA0, sA1, sB0, sB1);
+        if (gr + 4 < r1) do_row(gr + 4, sB0, sB1, sC0, sC1);
+        if (gr + 5 < r1) do_row(gr + 5, sC0, sC1, sA0, sA1);
     }
+    __syncthreads();                                     // (also retires the requests of rows beyond r1)
 
     // ---- fold the two pixel halves through LDS and add into this block's partial slice --------
     float* red = reinterpret_cast<float*>(smem_sb);      // [4 waves][25 taps][256]
@@ -270,7 +299,7 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
     }
     __syncthreads();
     float* redb = reinterpret_cast<float*>(smem_sb);     // [256 dz items][4]
-    if (zrole) {
+    if (!xrole) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) redb[it * 4 + c] = bs[c];
     }
