@@ -584,10 +584,15 @@ __device__ __forceinline__ void fd_trans_rl(const float (&sl)[NK / 16], const fl
 // Touch every 128-byte line of the blob once at kernel start (one dword per line, summed into a value the caller
 // keeps alive): the solver kernels run between convolution launches that stream hundreds of MB through the L2,
 // so the 263 KB of coefficients would otherwise come from HBM inside the latency-bound scalar-load loops.
+// All requests go out before the first is summed (clamped index, no predicate): as a loop `s += blob[i]` the five requests of a
+// thread were issued one round trip after the other -- in the training pipeline, where the convolution launches have flushed
+// the blob out of the L2, that made the load phase of the adjoint kernel 15 us instead of 3.4 (tools/step_phases.py ... train).
+// The blob has at most 8 x 512 lines of 128 bytes (checked by the host: fd_n <= 131072 words).
 __device__ __forceinline__ float fd_prefetch(const float* __restrict__ blob, int words) {
-    float s = 0.f;
-    for (int i = threadIdx.x * 32; i < words; i += blockDim.x * 32) s += blob[i];
-    return s;
+    float v[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) v[n] = blob[min((int)(threadIdx.x + n * blockDim.x) * 32, words - 1)];
+    return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
 }
 
 // rhs in rf[] (strip layout: rows 16*wave + k, column lane); returns the solution as a [128][64] LDS array (inside buf,
@@ -1236,31 +1241,45 @@ __device__ __forceinline__ void karman_bwd_body(const StepArgs& a, float* smem) 
         const float4* gy4 = reinterpret_cast<const float4*>(gy);
         const float4* df4 = reinterpret_cast<const float4*>(df);
         const float4* gact = reinterpret_cast<const float4*>(a.active);
-        float4 ty[NV], ta[CPT / 4];
-        float tx[MAXT];
+        float4 ty[NV], ta[CPT / 4], f0[NV], f1[NV];
+        float tx[MAXT], fxv[MAXT];
+        // EVERY request of the phase goes out before the first value is used (clamped indices; without a feature gradient the
+        // feature requests read the velocity gradient and get weight 0).  With the feature loads inside `if (df)` next to their
+        // use, the compiler produced one memory round trip per loop iteration: 3.4 us warm, but 15 us in the training pipeline
+        // where every operand comes from HBM (tools/step_phases.py 6 64 train).
+        const float4* dq4 = df ? df4 : gy4;
+        const float* dq = df ? df : gy;
+        const float w0 = df ? a.fs0 : 0.f, w1 = df ? a.fs1 : 0.f;
 #pragma unroll
         for (int n = 0; n < NV; ++n) {
-            const int q = min(tid + n * nthr, nQy - 1);                                               // branch-free: clamped indices
+            const int q = min(tid + n * nthr, nQy - 1);
+            const int qd = df ? min(q, (N >> 2) - 1) : 0;
             ty[n] = gy4[q];
-            if (df) {                                                                                 // workgroup uniform
-                const int qd = min(q, (N >> 2) - 1);
-                const float4 f0 = df4[2 * qd], f1 = df4[2 * qd + 1];
-                const float w = (q << 2) < N ? a.fs0 : 0.f;                                           // rows j < Y
-                ty[n].x += w * f0.x; ty[n].y += w * f0.z; ty[n].z += w * f1.x; ty[n].w += w * f1.z;
-            }
+            f0[n] = dq4[2 * qd];
+            f1[n] = dq4[2 * qd + 1];
         }
 #pragma unroll
         for (int n = 0; n < MAXT; ++n) {
             const int kx = min(tid + n * nthr, nVx - 1);
             const int j = (int)(((float)kx + 0.5f) * invXP), i = kx - j * XP;
             tx[n] = gx[kx];
-            if (df) {
-                const float fxv = df[2 * (j * X + min(i, X - 1)) + 1];
-                tx[n] += i < X ? a.fs1 * fxv : 0.f;
-            }
+            fxv[n] = dq[df ? 2 * (j * X + min(i, X - 1)) + 1 : 0];
         }
 #pragma unroll
         for (int n = 0; n < CPT / 4; ++n) ta[n] = gact[min(tid + n * nthr, (N >> 2) - 1)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int q = min(tid + n * nthr, nQy - 1);
+            const float w = (q << 2) < N ? w0 : 0.f;                                                  // rows j < Y
+            ty[n].x += w * f0[n].x; ty[n].y += w * f0[n].z; ty[n].z += w * f1[n].x; ty[n].w += w * f1[n].z;
+        }
+#pragma unroll
+        for (int n = 0; n < MAXT; ++n) {
+            const int kx = min(tid + n * nthr, nVx - 1);
+            const int j = (int)(((float)kx + 0.5f) * invXP), i = kx - j * XP;
+            tx[n] += i < X ? w1 * fxv[n] : 0.f;
+        }
 #pragma unroll
         for (int n = 0; n < NV; ++n) { const int q = tid + n * nthr; if (q < nQy) reinterpret_cast<float4*>(L.Avy)[q] = ty[n]; }
 #pragma unroll
@@ -1516,7 +1535,10 @@ __global__ void __launch_bounds__(512) k_karman_bwd_bww(StepArgs a, BwPack bw) {
             sub = x * per + s % per;
         }
 #endif
+        const bool stamp = a.prof && threadIdx.x == 0 && (idx == 0 || (int)blockIdx.x == (int)gridDim.x - 1);   // step_prof only
+        if (stamp) a.prof[idx == 0 ? 16 : 18] = wall_clock64();
         sbk::bww_sb_body<2>(bw.a[job], sub, reinterpret_cast<unsigned char*>(smem));
+        if (stamp) a.prof[idx == 0 ? 17 : 19] = wall_clock64();
     }
 }
 
@@ -1636,6 +1658,7 @@ int check_cfg(const sol_karman_cfg* c) {
                     "the direct pressure solver is built for 128x64 and for grids of at most 2048 cells with Y %% 16 == 0, X >= 16 (got %dx%d)", c->Y, c->X);
         SOL_REQUIRE(c->direct_n >= 16 + c->Y * c->Y + c->X * c->X + c->X * c->Y + 64 * 64 + 64 + c->X * FD_WIN,
                     "direct_n = %d is too small for a direct-solver blob", c->direct_n);
+        SOL_REQUIRE(c->direct_n <= 8 * 512 * 32, "direct_n = %d: the blob is larger than the kernels' prefetch covers (131072 words)", c->direct_n);
     }
     if (c->coarse_inv && !c->direct) {       // (the direct solver takes precedence: the preconditioner is then unused)
         SOL_REQUIRE(precond_ok(c->Y, c->X) && cpt == 16, "the two-level CG preconditioner is not available for a %dx%d grid", c->Y, c->X);
@@ -1681,6 +1704,32 @@ int sol_init_karman_kernels() {
 
 namespace {
 
+// step_prof (debugging, synchronous): the kernels' phase stamps (100 MHz wall clock) of workgroup 0, printed per launch
+static long long* prof_buffer() {
+    static long long* pbuf = nullptr;
+    if (!pbuf && hipMalloc(&pbuf, 32 * sizeof(long long)) != hipSuccess) pbuf = nullptr;
+    return pbuf;
+}
+static int prof_print(hipStream_t stream, const StepArgs& a, bool fused) {
+    long long h[32];
+    SOL_HIP_CHECK(hipStreamSynchronize(stream));
+    SOL_HIP_CHECK(hipMemcpy(h, a.prof, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[SOL_STEP_PROF %s] us per phase:", a.g_vy_in ? "bwd" : "fwd");
+    for (int i = 1; i <= 8; ++i) fprintf(stderr, " %.2f", (double)(h[i] - h[i - 1]) * 0.01);
+    fprintf(stderr, "  total %.2f\n", (double)(h[8] - h[0]) * 0.01);
+    if (a.fd) {
+        const int s0 = a.g_vy_in ? 2 : 5;      // stamp taken just before the solve
+        fprintf(stderr, "[SOL_STEP_PROF direct] fwd-transform %.2f  u %.2f  x0w %.2f  K' %.2f  scatter+t2w %.2f  spectral add %.2f  x-inverse %.2f\n",
+                (double)(h[9] - h[s0]) * 0.01, (double)(h[10] - h[9]) * 0.01, (double)(h[11] - h[10]) * 0.01, (double)(h[12] - h[11]) * 0.01,
+                (double)(h[13] - h[12]) * 0.01, (double)(h[14] - h[13]) * 0.01, (double)(h[15] - h[14]) * 0.01);
+    }
+    if (fused)      // relative to the adjoint workgroup's first stamp: first / last weight-gradient workgroup
+        fprintf(stderr, "[SOL_STEP_PROF fused] adjoint 0.00 .. %.2f | first gradient workgroup %.2f .. %.2f | last %.2f .. %.2f\n",
+                (double)(h[8] - h[0]) * 0.01, (double)(h[16] - h[0]) * 0.01, (double)(h[17] - h[0]) * 0.01,
+                (double)(h[18] - h[0]) * 0.01, (double)(h[19] - h[0]) * 0.01);
+    return SOL_OK;
+}
+
 template <typename K>
 int launch_step(K kernel, int cpt, const sol_karman_cfg* c, void* stream, const StepArgs& a0) {
     const int threads = (int)align_up((size_t)(c->Y / cpt) * c->X, 64);
@@ -1688,27 +1737,10 @@ int launch_step(K kernel, int cpt, const sol_karman_cfg* c, void* stream, const 
     if (int e = sol_init_karman_kernels()) return e;
     StepArgs a = a0;
     const bool prof = sol_opt().step_prof != 0;     // debugging: synchronous, prints phase times
-    static long long* pbuf = nullptr;
-    if (prof) {
-        if (!pbuf) SOL_HIP_CHECK(hipMalloc(&pbuf, 16 * sizeof(long long)));
-        a.prof = pbuf;
-    }
+    if (prof) a.prof = prof_buffer();
     SOL_LAUNCH_NAMED(a.g_vy_in ? "k_karman_bwd" : "k_karman_fwd", kernel, dim3(c->B), dim3(threads), lds, (hipStream_t)stream, a);
     SOL_LAUNCH_CHECK();
-    if (prof) {
-        long long h[16];
-        SOL_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-        SOL_HIP_CHECK(hipMemcpy(h, pbuf, sizeof(h), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[SOL_STEP_PROF %s] us per phase:", a.g_vy_in ? "bwd" : "fwd");
-        for (int i = 1; i <= 8; ++i) fprintf(stderr, " %.2f", (double)(h[i] - h[i - 1]) * 0.01);
-        fprintf(stderr, "  total %.2f\n", (double)(h[8] - h[0]) * 0.01);
-        if (a.fd) {
-            const int s0 = a.g_vy_in ? 2 : 5;      // stamp taken just before the solve
-            fprintf(stderr, "[SOL_STEP_PROF direct] fwd-transform %.2f  u %.2f  x0w %.2f  K' %.2f  scatter+t2w %.2f  spectral add %.2f  x-inverse %.2f\n",
-                    (double)(h[9] - h[s0]) * 0.01, (double)(h[10] - h[9]) * 0.01, (double)(h[11] - h[10]) * 0.01, (double)(h[12] - h[11]) * 0.01,
-                    (double)(h[13] - h[12]) * 0.01, (double)(h[14] - h[13]) * 0.01, (double)(h[15] - h[14]) * 0.01);
-        }
-    }
+    if (prof && a.prof) return prof_print((hipStream_t)stream, a, false);
     return SOL_OK;
 }
 
@@ -1767,8 +1799,10 @@ static int step_fwd_impl(const sol_karman_cfg* cfg, void* stream,
         SOL_REQUIRE(cpt == 16 && a.fd && dens_d_in && dens_svy && dens_svx && inflow, "fused solver + density launch: unsupported configuration");
         if (int e = sol_init_karman_kernels()) return e;
         DensStep q{cfg->B, cfg->Y, cfg->X, cfg->inflow_before, cfg->dt / cfg->dx, cfg->dt, dens_d_in, dens_svy, dens_svx, inflow, dens_d_out};
+        if (sol_opt().step_prof) a.prof = prof_buffer();
         SOL_LAUNCH(k_karman_fwd_dens, dim3(2 * cfg->B), dim3(512), lds_bytes(cfg->Y, cfg->X, 16), (hipStream_t)stream, a, q);
         SOL_LAUNCH_CHECK();
+        if (a.prof) return prof_print((hipStream_t)stream, a, false);
         return SOL_OK;
     }
     if (cpt != 16) return a.fd ? launch_step(k_karman_fwd<8, 2>, 8, cfg, stream, a) : launch_step(k_karman_fwd<8, 0>, 8, cfg, stream, a);
@@ -1835,8 +1869,10 @@ static int step_bwd_impl(const sol_karman_cfg* cfg, void* stream,
         pk.n = nbw; pk.wg_per = wg_per;
         size_t lds = lds_bytes(cfg->Y, cfg->X, 16);
         if (lds < (size_t)sbk::BW_LDS) lds = sbk::BW_LDS;
+        if (sol_opt().step_prof) a.prof = prof_buffer();
         SOL_LAUNCH(k_karman_bwd_bww, dim3(cfg->B + nbw * wg_per), dim3(512), lds, (hipStream_t)stream, a, pk);
         SOL_LAUNCH_CHECK();
+        if (a.prof) return prof_print((hipStream_t)stream, a, true);
         return SOL_OK;
     }
     if (cpt != 16) return a.fd ? launch_step(k_karman_bwd<8, 2>, 8, cfg, stream, a) : launch_step(k_karman_bwd<8, 0>, 8, cfg, stream, a);

@@ -27,3 +27,18 @@ for it in range(3):
     _, py, px = ops.karman_step(d0, vy, vx, re, cfg, masks)
     (py.sum() + px.sum()).backward()
 torch.cuda.synchronize()
+
+# ---- the same stamps inside ONE eager training step (cold operands, the weight-gradient workgroups riding in the adjoint
+#      launches): `python tools/step_phases.py B X train` prints the fused launches of the reverse sweep (last three shown by tail)
+if len(sys.argv) > 3 and sys.argv[3] == "train":
+    import bench
+    _lib.set_option("step_prof", 0)
+    wl = bench.Workload(sol_amd, dev, B, Y, X, 32, 0)
+    for _ in range(2):
+        wl.step(1e-6)
+    torch.cuda.synchronize()
+    _lib.set_option("step_prof", 1)
+    sys.stderr.write("--- eager training step\n")
+    wl.trainer.fwd_bwd(wl.d0, wl.vy0, wl.vx0, wl.re, wl.gt_vy, wl.gt_vx, want_final=True, eager=True)
+    torch.cuda.synchronize()
+    _lib.set_option("step_prof", 0)
