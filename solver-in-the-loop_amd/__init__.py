@@ -13,7 +13,7 @@ from .karman import KarmanFlow, to_feature, to_staggered, lr_schedule, velocity_
 from .model import model_mars_moon, model_mercury, MarsMoon, Mercury, ConvNet  # noqa: F401
 from .trainer import SolTrainer, SolRollout  # noqa: F401
 from . import synthetic, scene, burgers  # noqa: F401
-from .burgers import BurgersTest, TFAdam  # noqa: F401
+from .burgers import BurgersTest, BurgersTrainer, TFAdam  # noqa: F401
 
 __version__ = "0.1.0"
 

@@ -125,3 +125,91 @@ def randfreq(shape, rng, power=8):
     k = np.sqrt(ky * ky + kx * kx)
     f = np.fft.ifft2(noise * (1.0 / (1.0 + k)) ** power).real
     return f / (f.std() + 1e-30)
+
+
+# ---- fused trainer: the whole unrolled step (burgers_train.py:379-437) as ONE hipGraph ----------------------------------
+class BurgersTrainer:
+    """Unrolled solver-in-the-loop training step of the Burgers path (/root/reference/burgers/burgers_train.py:379-437):
+    msteps x [BurgersTest.step(_with_f) -> to_feature -> model -> to_staggered correction -> l2 loss], loss = sum / msteps,
+    its gradient with respect to the flat parameter buffer, TF1-Adam.  The graph is COMPOSED from the differentiable HIP ops
+    of this package by torch autograd (the same composition scripts/burgers_train.py steps eagerly) and captured ONCE into a
+    hipGraph over static input buffers; every further step copies the batch into those buffers and replays
+    (forward + backward ~ 60 launches per unrolled step: the path is launch bound at 32x32, which is what the capture removes).
+    Adam runs outside the graph (its bias correction takes the host-side step counter).
+
+    velo: [msteps+1, B, Y+1, X+1, 2] staggered frames (frame 0 = start state, frames 1.. = targets), forc: [msteps, B, Y+1, X+1, 2]
+    (ignored with noforce) -- what BurgersDataset.getData(consecutive_frames=msteps) returns, stacked."""
+
+    def __init__(self, net, domain, batch_size, msteps, dt, std_v, std_f=None, noforce=False, use_graph=True, viscosity=0.1):
+        from . import fluid
+        self.net, self.dom, self.B, self.ms, self.dt, self.noforce = net, domain, int(batch_size), int(msteps), float(dt), bool(noforce)
+        dev = net.params.device
+        Y, X = domain.resolution
+        self.sim = BurgersTest(default_viscosity=viscosity)
+        self.std_v = torch.as_tensor(std_v, dtype=torch.float32, device=dev).reshape(2)
+        if noforce:
+            self.std_in = self.std_v
+        else:
+            self.std_in = torch.cat([self.std_v, torch.as_tensor(std_f, dtype=torch.float32, device=dev).reshape(2)])
+        self.velo = torch.zeros(self.ms + 1, self.B, Y + 1, X + 1, 2, dtype=torch.float32, device=dev)
+        self.forc = torch.zeros(self.ms, self.B, Y + 1, X + 1, 2, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self.opt = TFAdam(net)
+        self.use_graph, self._graph, self._fluid = bool(use_graph), None, fluid
+
+    # the unrolled loss on the static buffers (reference-shaped surface; scripts/burgers_train.py holds the same lines)
+    def _unrolled_loss(self):
+        from .karman import to_staggered
+        F = self._fluid
+        st = F.BurgersVelocitySMAC(self.dom, velocity=self.velo[0], batch_size=self.B)
+        losses = []
+        for k in range(self.ms):
+            fr = None if self.noforce else F.BurgersVelocitySMAC(self.dom, velocity=self.forc[k], batch_size=self.B)
+            st = self.sim.step(st, dt=self.dt) if self.noforce else self.sim.step_with_f(st, fr, dt=self.dt)
+            feat = to_feature_noforce([st]) if self.noforce else to_feature([st], [fr])
+            corr = to_staggered(self.net(feat / self.std_in) * self.std_v, self.dom.box)
+            st = st.copied_with(velocity=st.velocity + corr)
+            diff = (self.velo[k + 1] - st.velocity.staggered_tensor()) / self.std_v
+            losses.append(0.5 * (diff * diff).sum())
+        return torch.stack(losses).sum() / self.ms
+
+    def _eager(self):
+        self.net.params.grad = None
+        loss = self._unrolled_loss()
+        loss.backward()
+        self.loss.copy_(loss.detach())
+
+    def _capture(self):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):           # warm-up off the capture: library initialisation, allocator pools
+            for _ in range(2):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.net.params.grad = None             # the captured backward allocates .grad from the graph's pool and rewrites it per replay
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = self._unrolled_loss()
+            loss.backward()
+            self.loss.copy_(loss.detach())
+        self._graph = g
+
+    def fwd_bwd(self, velo, forc=None, eager=False):
+        """Copies the batch into the static buffers, runs forward + backward; returns the loss tensor (device scalar); the
+        gradient is net.params.grad."""
+        self.velo.copy_(torch.as_tensor(velo, dtype=torch.float32).reshape(self.velo.shape), non_blocking=True)
+        if not self.noforce:
+            self.forc.copy_(torch.as_tensor(forc, dtype=torch.float32).reshape(self.forc.shape), non_blocking=True)
+        if eager or not self.use_graph:
+            self._eager()
+        else:
+            if self._graph is None:
+                self._capture()
+            self._graph.replay()
+        return self.loss
+
+    def train_step(self, velo, forc=None, lr=1e-3, eager=False):
+        loss = self.fwd_bwd(velo, forc, eager)
+        self.opt.step(lr)
+        return loss

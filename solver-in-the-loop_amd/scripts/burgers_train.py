@@ -1,10 +1,9 @@
 #!/usr/bin/env python
 """Solver-in-the-loop training for forced Burgers -- flags / loop / outputs of
 /root/reference/burgers/burgers_train.py (flags :22-44, unroll :379-417, loss :419-437, loop :465-500).
-The unrolled graph is composed from the differentiable HIP ops (BurgersTest.step_with_f = fused
-periodic advection + spectral diffusion kernel, 5x5 convs on fp32 MFMA) with torch autograd; the
-optimizer is the TF1-Adam kernel.  BASELINE configs[0] (32x32, msteps 1) is a plumbing/correctness
-config, so this path is not graph-captured."""
+The unrolled graph is composed from the differentiable HIP ops (BurgersTest.step_with_f = fused periodic advection + spectral
+diffusion kernel, 5x5 convs on the matrix cores) by torch autograd and captured ONCE into a hipGraph over static buffers
+(sol_amd.BurgersTrainer); --no-graph steps the same composition eagerly.  The optimizer is the TF1-Adam kernel."""
 import argparse
 import os
 import pickle
@@ -16,7 +15,6 @@ import torch
 from _common import logger, select_gpu
 import sol_amd
 from sol_amd import ops, scene, _lib
-from sol_amd.burgers import BurgersTest, TFAdam, to_feature, to_feature_noforce
 
 
 def main(argv=None):
@@ -43,6 +41,7 @@ def main(argv=None):
     p.add_argument("--resume", default=-1, type=int)
     p.add_argument("--inittf", default=None)
     p.add_argument("--tf", default="/tmp/phiflow/tf")
+    p.add_argument("--no-graph", action="store_true", help="step the unrolled graph eagerly instead of replaying a captured hipGraph")
     params = vars(p.parse_args(argv))
     select_gpu(params["gpu"])
     log = logger(params["log"])
@@ -61,7 +60,6 @@ def main(argv=None):
     Y, X = dataset.resolution
     B, ms, dt = params["sbatch"], params["msteps"], params["dt"]
     dom = sol_amd.Domain([Y, X], box=sol_amd.box([params["len"]] * 2), boundaries=sol_amd.PERIODIC)
-    simulator_lo = BurgersTest()
     cin = 2 if params["noforce"] else 4
     model = sol_amd.model_mars_moon(cin=cin, cout=2, seed=params["seed"])
     model.summary(print_fn=log.info)
@@ -73,11 +71,8 @@ def main(argv=None):
             pickle.dump(dataset.dataStats, f)
     else:
         model.set_weights(sol_amd.ConvNet.load(params["tf"] + "/model_epoch{:04d}.pt".format(params["resume"]), device="cpu").get_weights())
-    opt = TFAdam(model)
-    std_v = torch.tensor(dataset.dataStats["std"][0], dtype=torch.float32, device="cuda")
-    std_f = torch.tensor(dataset.dataStats["std"][1], dtype=torch.float32, device="cuda")
-    std_in = std_v if params["noforce"] else torch.cat([std_v, std_f])
-    f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda")
+    trainer = sol_amd.BurgersTrainer(model, dom, B, ms, dt, dataset.dataStats["std"][0], dataset.dataStats["std"][1],
+                                     noforce=params["noforce"], use_graph=not params["no_graph"])
     current_lr = params["lr"]
     l2 = None
     for j in range(params["epochs"]):
@@ -89,21 +84,7 @@ def main(argv=None):
         for ib in range(dataset.numOfBatchs):
             for i in range(dataset.numOfSteps):
                 velo, forc = dataset.getData(consecutive_frames=ms, with_skip=1)
-                st = sol_amd.BurgersVelocitySMAC(dom, velocity=f32(velo[0]), batch_size=B)
-                losses = []
-                for k in range(ms):
-                    fr = sol_amd.BurgersVelocitySMAC(dom, velocity=f32(forc[k]), batch_size=B)
-                    st = simulator_lo.step(st, dt=dt) if params["noforce"] else simulator_lo.step_with_f(st, fr, dt=dt)
-                    feat = to_feature_noforce([st]) if params["noforce"] else to_feature([st], [fr])
-                    corr = sol_amd.to_staggered(model(feat / std_in) * std_v, dom.box)
-                    st = st.copied_with(velocity=st.velocity + corr)
-                    diff = (f32(velo[k + 1]) - st.velocity.staggered_tensor()) / std_v
-                    losses.append(0.5 * (diff * diff).sum())
-                loss = torch.stack(losses).sum() / ms
-                model.params.grad = None
-                loss.backward()
-                opt.step(current_lr)
-                l2 = float(loss)
+                l2 = float(trainer.train_step(np.stack(velo[:ms + 1]), np.stack(forc[:ms]), current_lr))
                 log.info("epoch {:03d}/{:03d}, batch {:03d}/{:03d}, step {:04d}/{:04d}: loss={}".format(
                     j + 1, params["epochs"], ib + 1, dataset.numOfBatchs, i + 1, dataset.numOfSteps, l2))
                 dataset.nextStep()

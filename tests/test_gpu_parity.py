@@ -929,4 +929,53 @@ def test_torch_library_ops_are_registered_and_differentiable():
     assert torch.equal(y1, y2) and torch.equal(gx1, x.grad) and torch.equal(gw1, w.grad)
     assert torch.library  # the ops live in the dispatcher: torch.ops.sol.karman_step / conv5x5 / burgers_step / adam_tf_step
     for name in ("karman_step", "conv5x5", "burgers_step", "adam_tf_step"):
-        assert hasattr(torch.ops.sol, name)
+        assert hasattr(torch.ops.sol, name)@pytest.mark.gpu
+@pytest.mark.parametrize("noforce,ms", [(False, 2), (True, 3)])
+def test_burgers_fused_trainer_graph_equals_eager_and_oracle(noforce, ms):
+    """BurgersTrainer: the unrolled Burgers training step (burgers_train.py:379-437) captured into ONE hipGraph over static
+    buffers.  Replays must reproduce the eager composition (same kernels: loss and gradient to 1e-6), follow NEW batch data
+    copied into the static buffers, agree with the float64 oracle, and a TF-Adam step through the trainer must equal the
+    eager one bit for bit in the weights."""
+    B, Y, X, dt = 5, 32, 32, 0.1
+    gen = torch.Generator().manual_seed(11)
+    sm = lambda *shape: o._smooth(torch.randn(*shape, generator=gen, dtype=torch.float64))
+    std_v, std_f = (0.21, 0.19), (0.09, 0.11)
+    cin = 2 if noforce else 4
+    dom = sol_amd.Domain([Y, X], box=sol_amd.box([32, 32]), boundaries=sol_amd.PERIODIC)
+
+    def batch():
+        vy = [0.3 * sm(B, Y + 1, X) for _ in range(ms + 1)]
+        vx = [0.3 * sm(B, Y, X + 1) for _ in range(ms + 1)]
+        fy = [0.15 * sm(B, Y + 1, X) for _ in range(ms)]
+        fx = [0.15 * sm(B, Y, X + 1) for _ in range(ms)]
+        velo = torch.stack([o.staggered_tensor(a, b) for a, b in zip(vy, vx)])
+        forc = torch.stack([o.staggered_tensor(a, b) for a, b in zip(fy, fx)])
+        return vy, vx, fy, fx, velo, forc
+
+    params = [p.clone().requires_grad_(True) for p in o.init_params(3, cin=cin)]
+    net_g = sol_amd.model_mars_moon(cin=cin, cout=2, seed=0)
+    net_g.set_weights([p.detach().numpy() for p in params])
+    net_e = net_g.clone()
+    tg = sol_amd.BurgersTrainer(net_g, dom, B, ms, dt, std_v, std_f, noforce=noforce, use_graph=True)
+    te = sol_amd.BurgersTrainer(net_e, dom, B, ms, dt, std_v, std_f, noforce=noforce, use_graph=False)
+    for it in range(3):                       # three different batches through the SAME captured graph
+        vy, vx, fy, fx, velo, forc = batch()
+        lg = float(tg.fwd_bwd(velo, forc))
+        le = float(te.fwd_bwd(velo, forc))
+        assert tg._graph is not None and te._graph is None
+        assert abs(lg - le) <= 1e-6 * abs(le)
+        assert rel(net_g.params.grad, net_e.params.grad) < 1e-6
+        if it == 2:                           # float64 oracle on the last batch
+            loss = o.burgers_unrolled_loss(params, vy[0], vx[0], fy, fx, vy[1:], vx[1:], std_v, std_f, dt, noforce=noforce)
+            loss.backward()
+            gref = torch.cat([p.grad.reshape(-1) for p in params])
+            assert abs(lg - float(loss)) < 1e-5 * abs(float(loss))
+            assert rel(net_g.params.grad, gref) < TOL_GRAD
+    vy, vx, fy, fx, velo, forc = batch()
+    tg.train_step(velo, forc, lr=1e-3)
+    te.train_step(velo, forc, lr=1e-3)
+    assert tg.opt.t == 1 and rel(net_g.params.detach(), net_e.params.detach()) < 1e-7
+    assert float((net_g.params.detach() - f32(torch.cat([p.detach().reshape(-1) for p in params]))).abs().max()) > 0
+
+
+
