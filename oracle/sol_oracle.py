@@ -425,15 +425,47 @@ def mars_moon(params, x, slope=0.3):
     return _conv(h, params[22], params[23])
 
 
+def mercury_param_shapes(cin=3, cout=2):
+    """model_mercury, karman_train.py:92-99: Conv2D(32, 5, same, relu), Conv2D(64, 5, same, relu), Conv2D(2, 5, same)."""
+    chans = [cin, 32, 64, cout]
+    shapes = []
+    for l in range(3):
+        shapes.append((5, 5, chans[l], chans[l + 1]))
+        shapes.append((chans[l + 1],))
+    return shapes
+
+
+def init_params_mercury(seed=0, cin=3, cout=2, dtype=torch.float64):
+    g = torch.Generator().manual_seed(seed)
+    ps = []
+    for shp in mercury_param_shapes(cin, cout):
+        if len(shp) == 4:
+            lim = math.sqrt(6.0 / (shp[0] * shp[1] * (shp[2] + shp[3])))
+            ps.append(((torch.rand(shp, generator=g, dtype=torch.float64) * 2 - 1) * lim).to(dtype))
+        else:
+            ps.append(torch.zeros(shp, dtype=dtype))
+    return ps
+
+
+def mercury(params, x):
+    """karman_train.py:92-99."""
+    h = F.relu(_conv(x, params[0], params[1]))
+    h = F.relu(_conv(h, params[2], params[3]))
+    return _conv(h, params[4], params[5])
+
+
 # --------------------------------------------------------------------------------------
 # unrolled loop + loss  (karman_train.py:397-436)
 # --------------------------------------------------------------------------------------
 def correction(params, vy, vx, re, std_v, std_re, in_std_v=None, out_std_v=None):
-    """karman_train.py:413-424; in_std_v / out_std_v = dataStats['in.std'][1] / ['out.std'], present only with --pretf (:351-355)."""
+    """karman_train.py:413-424; in_std_v / out_std_v = dataStats['in.std'][1] / ['out.std'], present only with --pretf (:351-355).
+    The network is the one the parameter list belongs to (`eval('model_'+params['model'])`, :394): 24 tensors = mars_moon,
+    6 = mercury."""
     si = std_v if in_std_v is None else in_std_v
     so = std_v if out_std_v is None else out_std_v
     feat = to_feature(vy, vx, re) / torch.tensor([si[0], si[1], std_re], dtype=vy.dtype)
-    out = mars_moon(params, feat) * torch.tensor([so[0], so[1]], dtype=vy.dtype)
+    net = mercury if len(params) == 6 else mars_moon
+    out = net(params, feat) * torch.tensor([so[0], so[1]], dtype=vy.dtype)
     return to_staggered(out)
 
 

@@ -11,7 +11,7 @@ from .fluid import (box, Box, Sphere, Inflow, Obstacle, Gravity, Domain, OPEN, P
 from . import ops, dist  # noqa: F401
 from .karman import KarmanFlow, to_feature, to_staggered, lr_schedule, velocity_bc_masks  # noqa: F401
 from .model import model_mars_moon, model_mercury, MarsMoon, Mercury, ConvNet  # noqa: F401
-from .trainer import SolTrainer, SolRollout  # noqa: F401
+from .trainer import SolTrainer, SolRollout, GraphTrainer, make_trainer  # noqa: F401
 from . import synthetic, scene, burgers  # noqa: F401
 from .burgers import BurgersTest, BurgersTrainer, TFAdam  # noqa: F401
 

@@ -86,8 +86,10 @@ def main(argv=None):
     active, inflow = simulator_lo.scene_arrays(dom)
     velBCy, velBCyMask = sol_amd.velocity_bc_masks(Y, X)
     masks = ops.SceneMasks(active, inflow, velBCy.reshape(Y + 1, X), velBCyMask.reshape(Y + 1, X), dev)
-    assert params["model"] == "mars_moon", "the fused trainer implements model_mars_moon (the reference default)"
-    model = sol_amd.model_mars_moon(cin=3, cout=2, seed=seed, device=dev)
+    # eval('model_'+params['model']) (karman_train.py:394): mars_moon runs the C++ schedule (SolTrainer), mercury the
+    # autograd composition of the same ops captured into a hipGraph (GraphTrainer)
+    assert params["model"] in sol_amd.model.MODELS, "unknown model %r (have: %s)" % (params["model"], ", ".join(sol_amd.model.MODELS))
+    model = sol_amd.model.MODELS[params["model"]](3, 2, seed, dev)
     model.summary(print_fn=log.info)
     if params["pretf"]:
         log.info("load a pre-trained model: {}".format(params["pretf"]))
@@ -104,7 +106,7 @@ def main(argv=None):
         model.set_weights(sol_amd.ConvNet.load(params["tf"] + "/model_epoch{:04d}.pt".format(params["resume"]), device="cpu").get_weights())
     std_v = dataset.dataStats["std"][1]
     # karman_train.py:416-421: 'in.std' / 'out.std' (only present with --pretf) scale the network's input / output, the loss keeps 'std'
-    trainer = sol_amd.SolTrainer(model, masks, Bl, Y, X, ms, dom.dx[1], std_v, dataset.dataStats["ext.std"][0],
+    trainer = sol_amd.make_trainer(model, masks, Bl, Y, X, ms, dom.dx[1], std_v, dataset.dataStats["ext.std"][0],
                                  clip_grad=params["clip_grad"],
                                  in_std_v=dataset.dataStats["in.std"][1] if "in.std" in dataset.dataStats else None,
                                  out_std_v=dataset.dataStats["out.std"] if "out.std" in dataset.dataStats else None)

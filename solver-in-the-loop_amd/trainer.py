@@ -189,3 +189,103 @@ class SolRollout:
                                    ptr(re), ptr(mk.active), ptr(mk.inflow), ptr(mk.velBCy), ptr(mk.velBCyMask),
                                    mk.bc_stride, nsteps, ptr(self.workspace), self.workspace_bytes, ptr(iters)))
         return iters.reshape(nsteps, self.B)
+
+
+class GraphTrainer:
+    """The SolTrainer call surface for networks the C++ trainer has no fused schedule for (`model_mercury`,
+    karman_train.py:92-99 / `eval('model_'+...)` at :394).  The unrolled step of karman_train.py:397-457 is COMPOSED from
+    the differentiable HIP ops (KarmanFlow.step, to_feature, the network, to_staggered) by torch autograd and captured once
+    into a hipGraph over static buffers; a step copies the batch in and replays.  Same outputs as SolTrainer: the loss,
+    `grads` (flat, Keras get_weights() order), `loss_steps`, `final` = [density, vy, vx] after the last step; TF-Adam with
+    optional per-tensor clip; data parallel through the same DPStep (one SUM all-reduce of `grads`)."""
+
+    def __init__(self, net, B, Y, X, msteps, std_v, std_re, res=None, clip_grad=False, beta1=0.9, beta2=0.999, eps=1e-8,
+                 group=None, use_graph=True, comm=None, in_std_v=None, out_std_v=None, pressure_solver=None):
+        from . import fluid, karman
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.net, self.B, self.Y, self.X, self.msteps = net, B, Y, X, msteps
+        dev = self.device = net.params.device
+        self.dom = fluid.Domain([Y, X], box=fluid.box[0:200, 0:100])
+        self.sim = karman.KarmanFlow(pressure_solver=pressure_solver)
+        self.res = X if res is None else res
+        self.bcv, self.bcm = karman.velocity_bc_masks(Y, X, batch_size=B)
+        t = lambda v: torch.tensor([float(a) for a in v], dtype=torch.float32, device=dev)
+        self.scale_loss = t(std_v)
+        self.scale_in = t(list(in_std_v if in_std_v is not None else std_v) + [std_re])
+        self.scale_out = t(out_std_v if out_std_v is not None else std_v)
+        f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        self._in = [f32(B, Y, X), f32(B, Y + 1, X), f32(B, Y, X + 1), f32(B), f32(msteps, B, Y + 1, X), f32(msteps, B, Y, X + 1)]
+        n = net.n_params
+        self.grads, self.m, self.v = f32(n), f32(n), f32(n)
+        self.loss_steps = f32(msteps)
+        self._fin = [f32(B, Y, X), f32(B, Y + 1, X), f32(B, Y, X + 1)]
+        self.final = None
+        self.scratch = f32(64)
+        self.t = 0
+        self.clip_norm = 1e-3 if clip_grad else 0.0
+        self.beta1, self.beta2, self.eps = beta1, beta2, eps
+        self._offsets = (C.c_int64 * len(net.offsets))(*[int(o) for o in net.offsets])
+        self.use_graph, self._graph = use_graph, None
+        self._want_final, self._eager = False, False
+        self._dp = DPStep(self._fwd_bwd_flat, self._apply_flat, group=group, comm=comm)
+
+    def _unrolled(self):
+        from . import fluid, karman
+        d0, vy0, vx0, re, gt_vy, gt_vx = self._in
+        B, Y, X = self.B, self.Y, self.X
+        pad = torch.nn.functional.pad
+        stag = lambda vy, vx: torch.stack([pad(vy, (0, 1)), pad(vx, (0, 0, 0, 1))], dim=-1)     # [B,Y+1,X+1,2]
+        st = fluid.Fluid(self.dom, density=d0.reshape(B, Y, X, 1), velocity=stag(vy0, vx0), batch_size=B)
+        losses = []
+        for i in range(self.msteps):
+            st = self.sim.step(st, re=re, res=self.res, velBCy=self.bcv, velBCyMask=self.bcm)
+            corr = karman.to_staggered(self.net(karman.to_feature(st, re) / self.scale_in) * self.scale_out, self.dom.box)
+            st = st.copied_with(velocity=st.velocity + corr)
+            diff = (stag(gt_vy[i], gt_vx[i]) - st.velocity.staggered_tensor()) / self.scale_loss
+            losses.append(0.5 * (diff * diff).sum())
+        losses = torch.stack(losses)
+        self.net.params.grad = None
+        (losses.sum() / self.msteps).backward()
+        self.loss_steps.copy_(losses.detach())
+        self.grads.copy_(self.net.params.grad)
+        vt = st.velocity.staggered_tensor().detach()
+        self._fin[0].copy_(st.density.data.detach().reshape(B, Y, X))
+        self._fin[1].copy_(vt[:, :, :X, 0])
+        self._fin[2].copy_(vt[:, :Y, :, 1])
+
+    def fwd_bwd(self, d0, vy0, vx0, re, gt_vy, gt_vx, want_final=False, eager=False):
+        for dst, src in zip(self._in, (d0, vy0, vx0, re, gt_vy, gt_vx)):
+            dst.copy_(src, non_blocking=True)
+        if eager or not self.use_graph:
+            self._unrolled()
+        else:
+            if self._graph is None:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        self._unrolled()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                self.net.params.grad = None
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._unrolled()
+                self._graph = g
+            self._graph.replay()
+        self.final = self._fin if want_final else None
+        return self.loss_steps.sum() / self.msteps
+
+    apply_gradients = SolTrainer.apply_gradients
+    _fwd_bwd_flat = SolTrainer._fwd_bwd_flat
+    _apply_flat = SolTrainer._apply_flat
+    train_step = SolTrainer.train_step
+
+
+def make_trainer(net, masks, B, Y, X, msteps, dx, std_v, std_re, **kw):
+    """SolTrainer (the C++ schedule: model_mars_moon) or GraphTrainer (autograd composition in a hipGraph: everything else)."""
+    if net.name == "mars_moon":
+        return SolTrainer(net, masks, B, Y, X, msteps, dx, std_v, std_re, **kw)
+    keep = ("res", "clip_grad", "beta1", "beta2", "eps", "group", "use_graph", "comm", "in_std_v", "out_std_v")
+    return GraphTrainer(net, B, Y, X, msteps, std_v, std_re, **{k: v for k, v in kw.items() if k in keep})
