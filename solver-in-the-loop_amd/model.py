@@ -120,7 +120,7 @@ class MarsMoon(ConvNet):
 class Mercury(ConvNet):
     """model_mercury, karman_train.py:92-99: Conv5x5(cin->32)+ReLU, Conv5x5(32->64)+ReLU, Conv5x5(64->2).
     The conv kernels are built for <= 32 channels per side, so the 64-channel layer runs as two 32-channel
-    halves (output split for 32->64, input split + residual accumulation for 64->2).  Per-op path only."""
+    halves (output split for 32->64, input split + residual accumulation for 64->2).  Training: trainer.GraphTrainer."""
     name = "mercury"
     slope = 0.0                                      # ReLU = LeakyReLU with slope 0
 
