@@ -991,7 +991,9 @@ def test_torch_library_ops_are_registered_and_differentiable():
     assert torch.equal(y1, y2) and torch.equal(gx1, x.grad) and torch.equal(gw1, w.grad)
     assert torch.library  # the ops live in the dispatcher: torch.ops.sol.karman_step / conv5x5 / burgers_step / adam_tf_step
     for name in ("karman_step", "conv5x5", "burgers_step", "adam_tf_step"):
-        assert hasattr(torch.ops.sol, name)@pytest.mark.gpu
+        assert hasattr(torch.ops.sol, name)
+
+
 @pytest.mark.parametrize("noforce,ms", [(False, 2), (True, 3)])
 def test_burgers_fused_trainer_graph_equals_eager_and_oracle(noforce, ms):
     """BurgersTrainer: the unrolled Burgers training step (burgers_train.py:379-437) captured into ONE hipGraph over static
