@@ -252,7 +252,9 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     unsigned char* pf = pf_lds + wid * (2 * EF4 * 1024);
     auto lds_dma16 = [&](const void* src, unsigned char* dst_wave_uniform) __attribute__((always_inline)) {
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst_wave_uniform);
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(lo) : "m0");
+        unsigned keep;                                    // M0 is saved and restored inside the block (it may not be clobbered)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(lo));
     };
 #ifndef SOL_CONV_LATE_EPI                             // (A/B switch: 14.85 -> 14.77 ms per training step)
     constexpr bool EPI_PREFETCH = true;
