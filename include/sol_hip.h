@@ -177,6 +177,15 @@ int sol_burgers_step_bwd(const sol_burgers_cfg* cfg, void* stream,
                          const float* g_vy_out, const float* g_vx_out,
                          float* g_vy_in, float* g_vx_in);
 
+/* Forward-only Burgers step for grids beyond the one-workgroup kernels (up to 1024 x 1024): the reference generates its
+ * training data at 128 x 128 (burgers/Makefile:19-29, `burgers.py -r 128`; PhiFlow Burgers.step on the CPU there).  Same
+ * arguments as sol_burgers_step_fwd plus a workspace of sol_burgers_step_large_workspace_bytes(cfg).  Not differentiable. */
+size_t sol_burgers_step_large_workspace_bytes(const sol_burgers_cfg* cfg);
+int sol_burgers_step_fwd_large(const sol_burgers_cfg* cfg, void* stream, const float* vy_in, const float* vx_in,
+                               const float* f_y, const float* f_x, const float* circ_yp1, const float* circ_x,
+                               const float* circ_y, const float* circ_xp1, float* vy_out, float* vx_out,
+                               void* workspace, size_t workspace_bytes);
+
 /* ------------------------------------------------------------------------------------
  * 5x5 SAME convolution, NHWC fp32 tensors.  32-input-channel layers with W % 64 == 0 evaluate their fp32 products as
  * exact 16-bit MFMA products of operand splits with fp32 accumulation (option conv_precision; 2 = fp32 MFMA

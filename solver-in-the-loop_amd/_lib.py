@@ -60,6 +60,8 @@ _SIGS = {
     "sol_karman_step_bwd": (C.c_int, [C.POINTER(KarmanCfg), _P] + [_P] * 5 + [C.c_int64] + [_P] * 3 + [C.POINTER(C.c_float)] + [_P] * 3),
     "sol_burgers_step_fwd": (C.c_int, [C.POINTER(BurgersCfg), _P] + [_P] * 10),
     "sol_burgers_step_bwd": (C.c_int, [C.POINTER(BurgersCfg), _P] + [_P] * 10),
+    "sol_burgers_step_large_workspace_bytes": (C.c_size_t, [C.POINTER(BurgersCfg)]),
+    "sol_burgers_step_fwd_large": (C.c_int, [C.POINTER(BurgersCfg), _P] + [_P] * 10 + [_P, C.c_size_t]),
     "sol_conv5x5_packed_floats": (C.c_size_t, [C.c_int32] * 3),
     "sol_conv5x5_pack": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "sol_conv5x5": (C.c_int, [_P] * 7 + [C.c_int32] * 6 + [C.c_float]),

@@ -42,7 +42,13 @@ class BurgersTest:
         if f is not None:
             fy = f.velocity.data[0].data.reshape(B, Y + 1, X)
             fx = f.velocity.data[1].data.reshape(B, Y, X + 1)
-        oy, ox = ops.burgers_step(vy, vx, fy, fx, cfg, self._circ[key])
+        if max(Y, X) > ops.BURGERS_LDS_MAX:
+            # beyond the one-workgroup kernels (data generation at the reference's 128 x 128): forward-only multi-workgroup path
+            if torch.is_grad_enabled() and (vy.requires_grad or vx.requires_grad):
+                raise NotImplementedError("the large-grid Burgers step (%dx%d) is forward only" % (Y, X))
+            oy, ox = ops.burgers_step_large(vy, vx, fy, fx, cfg, self._circ[key])
+        else:
+            oy, ox = ops.burgers_step(vy, vx, fy, fx, cfg, self._circ[key])
         return v.copied_with(velocity=StaggeredGrid([oy.reshape(B, Y + 1, X, 1), ox.reshape(B, Y, X + 1, 1)], v.velocity.box))
 
     def step(self, v, dt=1.0, effects=()):

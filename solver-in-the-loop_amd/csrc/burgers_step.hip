@@ -231,6 +231,73 @@ __global__ void __launch_bounds__(NT) k_burgers_bwd(BArgs a) {
     for (int k = tid; k < nVx; k += NT) a.g_vx_in[(size_t)b * nVx + k] = L.Bvx[k];
 }
 
+// ------------------------------------------------------------------------------------
+// Large grids (forward only): the reference generates its Burgers training data at 128 x 128 (burgers/Makefile:19-29,
+// `burgers.py -r 128`), beyond the one-workgroup-in-LDS kernels above.  Same arithmetic on global memory with the whole chip:
+// one launch for the advection, two tiled products for the separable circulant diffusion per component, force added by the
+// second.  Not differentiable (the reference does not train through its hi-res data either).
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_burgers_adv_large(int B, int Y, int X, float dtdx, const float* __restrict__ vy_in,
+                                                           const float* __restrict__ vx_in, float* __restrict__ ay, float* __restrict__ ax) {
+    const int nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
+    const int total = B * (nVy + nVx);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int b = e / (nVy + nVx), r = e - b * (nVy + nVx);
+        const float* Vy = vy_in + (size_t)b * nVy;
+        const float* Vx = vx_in + (size_t)b * nVx;
+        if (r < nVy) {
+            const int j = r / X, i = r - j * X;
+            const float uy = Vy[r];
+            const int ja = wrap(j - 1, Y), jb = wrap(j, Y);
+            const float ux = 0.25f * (Vx[ja * XP + i] + Vx[ja * XP + i + 1] + Vx[jb * XP + i] + Vx[jb * XP + i + 1]);
+            const BilP s = bil_wrap(Y + 1, X, j, -uy * dtdx, i, -ux * dtdx);
+            ay[(size_t)b * nVy + r] = (1.f - s.wy) * ((1.f - s.wx) * Vy[s.j0 * X + s.i0] + s.wx * Vy[s.j0 * X + s.i1]) +
+                                      s.wy * ((1.f - s.wx) * Vy[s.j1 * X + s.i0] + s.wx * Vy[s.j1 * X + s.i1]);
+        } else {
+            const int k = r - nVy, j = k / XP, i = k - j * XP;
+            const float ux = Vx[k];
+            const int ia = wrap(i - 1, X), ib = wrap(i, X);
+            const float uy = 0.25f * (Vy[j * X + ia] + Vy[j * X + ib] + Vy[(j + 1) * X + ia] + Vy[(j + 1) * X + ib]);
+            const BilP s = bil_wrap(Y, XP, j, -uy * dtdx, i, -ux * dtdx);
+            ax[(size_t)b * nVx + k] = (1.f - s.wy) * ((1.f - s.wx) * Vx[s.j0 * XP + s.i0] + s.wx * Vx[s.j0 * XP + s.i1]) +
+                                      s.wy * ((1.f - s.wx) * Vx[s.j1 * XP + s.i0] + s.wx * Vx[s.j1 * XP + s.i1]);
+        }
+    }
+}
+
+// One 16 x 16 output tile per workgroup of C[b] = L * In[b] * R^T restricted to one side per launch:
+//   SIDE 0:  out[j][i] = sum_k in[j][k] * R[i][k]          (in [H][W], R [W][W])
+//   SIDE 1:  out[j][i] = sum_k Lm[j][k] * in[k][i] (+ dt f) (Lm [H][H], in [H][W])
+// summed over k in ascending order like diffuse2 above (same rounding as the one-workgroup kernel).
+template <int SIDE>
+__global__ void __launch_bounds__(256) k_burgers_circ_large(int H, int W, const float* __restrict__ in, const float* __restrict__ M,
+                                                            float* __restrict__ out, const float* __restrict__ f, float dt) {
+    __shared__ float ta[16][17], tb[16][17];
+    const int b = blockIdx.z, tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + tx, j = blockIdx.y * 16 + ty;
+    const float* src = in + (size_t)b * H * W;
+    const int K = SIDE == 0 ? W : H;
+    float s = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        if (SIDE == 0) {
+            ta[ty][tx] = (j < H && k0 + tx < K) ? src[(size_t)j * W + k0 + tx] : 0.f;              // in[j][k]
+            const int ir = blockIdx.x * 16 + ty;
+            tb[ty][tx] = (ir < W && k0 + tx < K) ? M[(size_t)ir * W + k0 + tx] : 0.f;              // R[i][k], row i = tile column ty
+        } else {
+            ta[ty][tx] = (j < H && k0 + tx < K) ? M[(size_t)j * H + k0 + tx] : 0.f;                // Lm[j][k]
+            tb[ty][tx] = (k0 + ty < K && i < W) ? src[(size_t)(k0 + ty) * W + i] : 0.f;            // in[k][i]
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += SIDE == 0 ? ta[ty][k] * tb[tx][k] : ta[ty][k] * tb[k][tx];
+        __syncthreads();
+    }
+    if (i < W && j < H) {
+        const size_t o = (size_t)b * H * W + (size_t)j * W + i;
+        out[o] = (SIDE == 1 && f) ? s + dt * f[o] : s;
+    }
+}
+
 int bcheck(const sol_burgers_cfg* c) {
     SOL_REQUIRE(c != nullptr, "cfg is NULL");
     SOL_REQUIRE(c->B >= 1 && c->Y >= 2 && c->X >= 2 && c->Y <= 64 && c->X <= 64, "burgers: need 2 <= Y,X <= 64 (got %d,%d)", c->Y, c->X);
@@ -281,4 +348,45 @@ extern "C" int sol_burgers_step_bwd(const sol_burgers_cfg* cfg, void* stream, co
     a.cyp1 = circ_yp1; a.cx = circ_x; a.cy = circ_y; a.cxp1 = circ_xp1;
     a.g_vy_out = g_vy_out; a.g_vx_out = g_vx_out; a.g_vy_in = g_vy_in; a.g_vx_in = g_vx_in;
     return blaunch(k_burgers_bwd, cfg, stream, a);
+}
+
+// ---- large-grid forward step (data generation at the reference's 128 x 128 hi-res setting, burgers/Makefile:19-29) ----
+extern "C" size_t sol_burgers_step_large_workspace_bytes(const sol_burgers_cfg* cfg) {
+    if (!cfg || cfg->B < 1 || cfg->Y < 2 || cfg->X < 2) return 0;
+    const size_t nVy = (size_t)(cfg->Y + 1) * cfg->X, nVx = (size_t)cfg->Y * (cfg->X + 1);
+    return (size_t)cfg->B * 2 * (nVy + nVx) * sizeof(float);      // advected field + one product, both components
+}
+
+extern "C" int sol_burgers_step_fwd_large(const sol_burgers_cfg* cfg, void* stream, const float* vy_in, const float* vx_in,
+                                          const float* f_y, const float* f_x, const float* circ_yp1, const float* circ_x,
+                                          const float* circ_y, const float* circ_xp1, float* vy_out, float* vx_out,
+                                          void* workspace, size_t workspace_bytes) {
+    SOL_REQUIRE(cfg != nullptr, "cfg is NULL");
+    SOL_REQUIRE(cfg->B >= 1 && cfg->Y >= 2 && cfg->X >= 2 && cfg->Y <= 1024 && cfg->X <= 1024, "burgers (large): need 2 <= Y,X <= 1024 (got %d,%d)", cfg->Y, cfg->X);
+    SOL_REQUIRE(cfg->dx > 0.f, "dx must be > 0");
+    SOL_REQUIRE(vy_in && vx_in && circ_yp1 && circ_x && circ_y && circ_xp1 && vy_out && vx_out && workspace, "sol_burgers_step_fwd_large: NULL pointer");
+    SOL_REQUIRE((f_y == nullptr) == (f_x == nullptr), "f_y and f_x must both be given or both be NULL");
+    SOL_REQUIRE(workspace_bytes >= sol_burgers_step_large_workspace_bytes(cfg), "sol_burgers_step_fwd_large: workspace too small");
+    const int B = cfg->B, Y = cfg->Y, X = cfg->X;
+    const size_t nVy = (size_t)(Y + 1) * X, nVx = (size_t)Y * (X + 1);
+    float* ay = reinterpret_cast<float*>(workspace);
+    float* ax = ay + B * nVy;
+    float* ty = ax + B * nVx;
+    float* tx = ty + B * nVy;
+    hipStream_t hs = (hipStream_t)stream;
+    const int total = (int)(B * (nVy + nVx));
+    SOL_LAUNCH(k_burgers_adv_large, dim3((total + 255) / 256), dim3(256), 0, hs, B, Y, X, cfg->dt / cfg->dx, vy_in, vx_in, ay, ax);
+    SOL_LAUNCH_CHECK();
+    auto tiles = [](int H, int W, int B_) { return dim3((W + 15) / 16, (H + 15) / 16, B_); };
+    // v_y: [Y+1][X]:  T = A * Cx^T, out = Cyp1 * T (+ dt f_y)
+    SOL_LAUNCH(k_burgers_circ_large<0>, tiles(Y + 1, X, B), dim3(256), 0, hs, Y + 1, X, (const float*)ay, circ_x, ty, (const float*)nullptr, 0.f);
+    SOL_LAUNCH_CHECK();
+    SOL_LAUNCH(k_burgers_circ_large<1>, tiles(Y + 1, X, B), dim3(256), 0, hs, Y + 1, X, (const float*)ty, circ_yp1, vy_out, f_y, cfg->dt);
+    SOL_LAUNCH_CHECK();
+    // v_x: [Y][X+1]:  T = A * Cxp1^T, out = Cy * T (+ dt f_x)
+    SOL_LAUNCH(k_burgers_circ_large<0>, tiles(Y, X + 1, B), dim3(256), 0, hs, Y, X + 1, (const float*)ax, circ_xp1, tx, (const float*)nullptr, 0.f);
+    SOL_LAUNCH_CHECK();
+    SOL_LAUNCH(k_burgers_circ_large<1>, tiles(Y, X + 1, B), dim3(256), 0, hs, Y, X + 1, (const float*)tx, circ_y, vx_out, f_x, cfg->dt);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
 }

@@ -289,3 +289,24 @@ def burgers_circ(Y, X, amount, device="cuda"):
 
 def burgers_step(vy, vx, fy, fx, cfg, circ):
     return BurgersStepFn.apply(vy, vx, fy, fx, cfg, circ)
+
+
+BURGERS_LDS_MAX = 64      # largest grid edge of the one-workgroup (differentiable) Burgers kernels
+
+
+def burgers_step_large(vy, vx, fy, fx, cfg, circ, workspace=None):
+    """Forward-only Burgers step for grids beyond the one-workgroup kernels (the reference's 128 x 128 data generation,
+    /root/reference/burgers/Makefile:19-29): sol_burgers_step_fwd_large.  Returns (vy, vx) after the step."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    vy, vx = _lib.f32(vy), _lib.f32(vx)
+    fy = None if fy is None else _lib.f32(fy)
+    fx = None if fx is None else _lib.f32(fx)
+    nbytes = lib.sol_burgers_step_large_workspace_bytes(C.byref(cfg))
+    if workspace is None or workspace.numel() * 4 < nbytes:
+        workspace = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=vy.device)
+    oy, ox = torch.empty_like(vy), torch.empty_like(vx)
+    check(lib.sol_burgers_step_fwd_large(C.byref(cfg), stream(), ptr(vy), ptr(vx), ptr(fy), ptr(fx),
+                                         ptr(circ[0]), ptr(circ[1]), ptr(circ[2]), ptr(circ[3]), ptr(oy), ptr(ox),
+                                         ptr(workspace), workspace.numel() * 4))
+    return oy, ox

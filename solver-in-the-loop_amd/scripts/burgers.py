@@ -3,7 +3,8 @@
 HIP Burgers step (state on the GPU, one launch per frame).  Forcing: sol_amd.burgers.SinForces (the reference's 20
 SinPotential forces + ForcingPhysics, recalled semantics behind --force-variant), or hi-res force / velocity files
 down-sampled by -d (--initvH / --loadfH, the reference's hires -> lores chain, Makefile:35-49).
-Grids up to 64 x 64 (one workgroup per simulation in LDS); the reference's 128 x 128 hi-res set is beyond this kernel."""
+Grids up to 64 x 64 run the one-workgroup (differentiable) kernel, larger ones -- the reference's 128 x 128 hi-res set,
+burgers/Makefile:19-29 -- the forward-only multi-workgroup step."""
 import argparse
 import glob
 import pickle
@@ -38,8 +39,8 @@ def main(argv=None):
     select_gpu(params["gpu"])
     log = logger()
     res = params["res"]
-    if res > 64:
-        raise SystemExit("burgers.py: -r %d exceeds the 64 x 64 limit of the one-workgroup Burgers kernel" % res)
+    if res > 1024:
+        raise SystemExit("burgers.py: -r %d exceeds the 1024 x 1024 limit of the large-grid Burgers step" % res)
     rng = np.random.default_rng(params["seed"])
     dx = params["len"] / res
     dom = sol_amd.Domain([res, res], box=sol_amd.box([params["len"]] * 2), boundaries=sol_amd.PERIODIC)

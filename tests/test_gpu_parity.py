@@ -503,6 +503,42 @@ def test_burgers_step_against_golden(golden_dir):
     assert torch.equal(ny, zy) and torch.equal(nx, zx)
 
 
+@pytest.mark.parametrize("Y,X", [(128, 128), (96, 160)])
+def test_burgers_large_grid_forward_step_against_oracle(Y, X):
+    """The reference generates its Burgers training data at 128 x 128 (burgers/Makefile:19-29, `-r 128 --dt 0.1`): beyond the
+    one-workgroup LDS kernels.  The forward-only multi-workgroup step (sol_burgers_step_fwd_large) against the float64 oracle
+    (FFT diffusion), with and without force, through ops and through the reference-shaped BurgersTest surface; at 64 x 64 it
+    must agree with the LDS kernel."""
+    B, dt, nu = 2, 0.1, 0.1
+    gen = torch.Generator().manual_seed(3)
+    sm = lambda *shape: o._smooth(torch.randn(*shape, generator=gen, dtype=torch.float64))
+    vy, vx = 0.8 * sm(B, Y + 1, X), 0.8 * sm(B, Y, X + 1)
+    fy, fx = 0.2 * sm(B, Y + 1, X), 0.2 * sm(B, Y, X + 1)
+    dx = 32.0 / Y                                                  # -l 32
+    cfg = sol_amd._lib.BurgersCfg(B, Y, X, dx, dt)
+    circ = ops.burgers_circ(Y, X, dt * nu)
+    for force in (True, False):
+        ry, rx = o.burgers_step(vy, vx, dt, nu, fy if force else None, fx if force else None, dx=dx)
+        hy, hx = ops.burgers_step_large(f32(vy), f32(vx), f32(fy) if force else None, f32(fx) if force else None, cfg, circ)
+        assert rel(hy, ry) < TOL_FIELD and rel(hx, rx) < TOL_FIELD
+    dom = sol_amd.Domain([Y, X], box=sol_amd.box([32.0, 32.0 * X / Y]), boundaries=sol_amd.PERIODIC)
+    st = sol_amd.BurgersVelocitySMAC(dom, velocity=f32(o.staggered_tensor(vy, vx)), batch_size=B)
+    fr = sol_amd.BurgersVelocitySMAC(dom, velocity=f32(o.staggered_tensor(fy, fx)), batch_size=B)
+    out = sol_amd.BurgersTest().step_with_f(st, fr, dt=dt).velocity.staggered_tensor()
+    ry, rx = o.burgers_step(vy, vx, dt, nu, fy, fx, dx=dx)
+    assert rel(out, o.staggered_tensor(ry, rx)) < TOL_FIELD
+    with pytest.raises(NotImplementedError):
+        st2 = sol_amd.BurgersVelocitySMAC(dom, velocity=f32(o.staggered_tensor(vy, vx)).requires_grad_(True), batch_size=B)
+        sol_amd.BurgersTest().step(st2, dt=dt)
+    # same operator as the one-workgroup kernel where both apply
+    c64 = sol_amd._lib.BurgersCfg(B, 64, 64, 0.5, dt)
+    k64 = ops.burgers_circ(64, 64, dt * nu)
+    a, b = f32(0.8 * sm(B, 65, 64)), f32(0.8 * sm(B, 64, 65))
+    ly, lx = ops.burgers_step(a, b, None, None, c64, k64)
+    gy, gx = ops.burgers_step_large(a, b, None, None, c64, k64)
+    assert rel(gy, ly) < 1e-6 and rel(gx, lx) < 1e-6
+
+
 # ---------------------------------------------------------------------------------------------
 # scripts: data generation -> training -> roll-out on a tiny scene (flags of the reference scripts)
 # ---------------------------------------------------------------------------------------------
@@ -908,6 +944,10 @@ def test_burgers_data_generation_scripts(tmp_path):
         spec.loader.exec_module(m)
         return m
 
+    # the reference's own hi-res setting (burgers/Makefile:19-23: -r 128 -l 32 --dt 0.1): forward-only large-grid step
+    h128 = load("burgers").main(["-o", str(tmp_path / "hires128"), "-r", "128", "-l", "32", "--dt", "0.1", "--skipsteps", "2", "-t", "3", "--seed", "0"])
+    v128 = scene.read_zipped_array(h128 + "/velo_000002.npz")
+    assert v128.shape == (1, 129, 129, 2) and np.isfinite(v128).all() and np.abs(v128).max() > 0
     hi = load("burgers").main(["-o", str(tmp_path / "hires"), "-r", "64", "-l", "32", "--dt", "0.1", "--skipsteps", "3", "-t", "10", "--seed", "1"])
     v0 = scene.read_zipped_array(hi + "/velo_000000.npz")
     f5 = scene.read_zipped_array(hi + "/forc_000005.npz")
@@ -919,7 +959,7 @@ def test_burgers_data_generation_scripts(tmp_path):
     vl = scene.read_zipped_array(lo + "/velo_000009.npz")
     assert vl.shape == (1, 33, 33, 2) and np.isfinite(vl).all()
     with pytest.raises(SystemExit):
-        load("burgers").main(["-r", "128"])
+        load("burgers").main(["-r", "2048"])
     loss = load("burgers_train").main(["--train", str(tmp_path / "lores"), "-s", "1", "-n", "2", "-b", "2", "-t", "8", "-m", "2", "-e", "1", "--dt", "0.1",
                                        "--lr", "1e-4", "--tf", str(tmp_path / "tf"), "--seed", "0"])
     assert loss is not None and np.isfinite(loss)
