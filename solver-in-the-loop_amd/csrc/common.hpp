@@ -105,6 +105,8 @@ int sol_bww_jobs_launch(void* stream, const BwArgs* bw, int nbw, int wg_per);
 int sol_bww_step_job(BwArgs* out, const float* x, const float* dz, float* partial, int overwrite, int B, int H, int W, int rb,
                      const unsigned* xmax, const unsigned* zmax);
 int sol_bww_step_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int B, int H, int rb, int cin, int cout, int accumulate);
+int sol_bww_reduce_layers(void* stream, int n, float* const* partial, float* const* dw_hwio, float* const* db, const int* rows, const int* rb,
+                          const int* cin, const int* cout, int accumulate, int taps_transposed);
 size_t sol_bww_step_ws_floats(int B, int H, int rb);
 // split-bf16 section of the packed weights and the kernels that consume it (conv5x5_sb.hip)
 size_t sol_conv_sb_packed_floats(int OP);

@@ -956,6 +956,41 @@ __global__ void k_bww_reduce(float* __restrict__ partial, float* __restrict__ dw
     }
 }
 
+// the same two stages for SEVERAL layers in one launch each (blockIdx.z = layer): a training step reduces twelve layers, 24
+// launches of a few microseconds of work each
+struct ReduceJob { float *partial, *dw, *db; int nblk, cin, cout, IP, OP, ny, accumulate, tt; };
+struct ReduceJobs { ReduceJob j[12]; };
+__global__ void k_bww_reduce_jobs(ReduceJobs J, int stage2) {
+    const ReduceJob& r = J.j[blockIdx.z];
+    constexpr int CHUNK = 16;
+    const int nw = 25 * r.cin * r.cout;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    int k0, k1, stride, to_dw;
+    if (!stage2) {                      // chunk sums, folded into the first block of every chunk (layers with one chunk: nothing)
+        if (r.ny <= 1 || (int)blockIdx.y >= r.ny) return;
+        k0 = blockIdx.y * CHUNK; k1 = min(k0 + CHUNK, r.nblk); stride = 1; to_dw = 0;
+    } else {                            // chunk heads (or, with one chunk, the blocks themselves) in order -> dw, db
+        if (blockIdx.y > 0) return;
+        k0 = 0; k1 = r.nblk; stride = r.ny > 1 ? CHUNK : 1; to_dw = 1;
+    }
+    if (e < nw) {
+        const int co = e % r.cout, ci = (e / r.cout) % r.cin, tap = e / (r.cout * r.cin);
+        const size_t off = (size_t)(tap * r.IP + ci) * r.OP + co;
+        float s = 0.f;
+        for (int k = k0; k < k1; k += stride) s += r.partial[(size_t)k * (25 * r.IP * r.OP) + off];
+        const int eo = r.tt ? (((tap % 5) * 5 + tap / 5) * r.cin + ci) * r.cout + co : e;
+        if (to_dw) r.dw[eo] = r.accumulate ? r.dw[eo] + s : s;
+        else r.partial[(size_t)k0 * (25 * r.IP * r.OP) + off] = s;
+    } else if (e < nw + r.cout) {
+        const int co = e - nw;
+        float* pb = r.partial + (size_t)r.nblk * (25 * r.IP * r.OP);
+        float s = 0.f;
+        for (int k = k0; k < k1; k += stride) s += pb[(size_t)k * r.OP + co];
+        if (to_dw) r.db[co] = r.accumulate ? r.db[co] + s : s;
+        else pb[(size_t)k0 * r.OP + co] = s;
+    }
+}
+
 int check_shape(int B, int H, int W, int cin, int cout) {
     SOL_REQUIRE(B >= 1 && H >= 1 && W >= 4, "conv5x5: bad image shape B=%d H=%d W=%d", B, H, W);
     SOL_REQUIRE((W <= 64 && 64 % W == 0 && H % (64 / W) == 0) || W % 64 == 0,
@@ -1227,6 +1262,32 @@ int sol_bww_step_job(BwArgs* out, const float* x, const float* dz, float* partia
     a.nblk = (B * H) / rb; a.nseg = 1; a.rb = rb; a.x_seg = 0; a.dz_seg = 0; a.overwrite = overwrite;
     a.xmax = xmax; a.zmax = zmax; a.xmax_seg = 0; a.zmax_seg = 0;
     *out = a;
+    return SOL_OK;
+}
+
+// n <= 12 layers at once: rows[i] / rb[i] as in bww_reduce (rb <= 0: pick_rb), same summation order as the per-layer launches
+int sol_bww_reduce_layers(void* stream, int n, float* const* partial, float* const* dw_hwio, float* const* db, const int* rows, const int* rb,
+                          const int* cin, const int* cout, int accumulate, int taps_transposed) {
+    SOL_REQUIRE(n >= 1 && n <= 12, "sol_bww_reduce_layers: 1 <= n <= 12");
+    ReduceJobs J{};
+    int max_total = 0, max_ny = 1;
+    for (int i = 0; i < n; ++i) {
+        SOL_REQUIRE(partial[i] && dw_hwio[i] && db[i] && cin[i] >= 1 && cin[i] <= 32 && cout[i] >= 1 && cout[i] <= 32, "sol_bww_reduce_layers: bad layer %d", i);
+        ReduceJob& r = J.j[i];
+        const int rbi = rb[i] > 0 ? rb[i] : pick_rb(rows[i], cin[i] <= 4 ? 4 : 32, cout[i]);
+        bww_dims(rows[i], rbi, cin[i] <= 4 ? 4 : 32, cout[i], &r.nblk, &r.IP, &r.OP);
+        r.partial = partial[i]; r.dw = dw_hwio[i]; r.db = db[i]; r.cin = cin[i]; r.cout = cout[i];
+        r.ny = (r.nblk + 15) / 16; r.accumulate = accumulate; r.tt = taps_transposed;
+        max_total = max_total > 25 * cin[i] * cout[i] + cout[i] ? max_total : 25 * cin[i] * cout[i] + cout[i];
+        max_ny = max_ny > r.ny ? max_ny : r.ny;
+    }
+    hipStream_t hs = (hipStream_t)stream;
+    if (max_ny > 1) {
+        SOL_LAUNCH(k_bww_reduce_jobs, dim3((max_total + 255) / 256, max_ny, n), dim3(256), 0, hs, J, 0);
+        SOL_LAUNCH_CHECK();
+    }
+    SOL_LAUNCH(k_bww_reduce_jobs, dim3((max_total + 255) / 256, 1, n), dim3(256), 0, hs, J, 1);
+    SOL_LAUNCH_CHECK();
     return SOL_OK;
 }
 

@@ -762,15 +762,21 @@ int train_fwd_bwd_impl(const sol_train_cfg* cfg, hipStream_t hs, const TrainIO& 
             SOL_HIP_CHECK(hipStreamWaitEvent(hs, sp->join[k], 0));
         }
     }
-    for (int l = 0; l < NL; ++l) {
-        const int cin = layer_cin(l), cout = layer_cout(l);
-        const int64_t koff = layer_koff(l), boff = koff + 25 * cin * cout;
-        const bool fused = l >= 1 && l <= 10 && train_fused(&sub, w[0], ms);
-        for (int k = 0; k < S; ++k) {
-            const bool trn = cnn_transposed(Y, X);
-            if (fused) { if (int e = sol_bww_step_reduce(hs, w[k].part[l], grads + koff, grads + boff, B / S, Y, 32, cin, cout, k > 0)) return e; }
-            else if (int e = sol_bww_batched_reduce(hs, w[k].part[l], grads + koff, grads + boff, pick_bww_chunk(ms), B / S, trn ? X : Y, cin, cout, k > 0, trn ? 1 : 0)) return e;
+    // all twelve layers of a chain in two launches (chain k > 0 accumulates onto chain k-1: one pair of launches per chain)
+    const bool trn = cnn_transposed(Y, X);
+    const bool fused_all = train_fused(&sub, w[0], ms);
+    for (int k = 0; k < S; ++k) {
+        float *part[NL], *dw[NL], *db[NL];
+        int rows[NL], rbs[NL], cins[NL], couts[NL];
+        for (int l = 0; l < NL; ++l) {
+            const int cin = layer_cin(l), cout = layer_cout(l);
+            const int64_t koff = layer_koff(l), boff = koff + 25 * cin * cout;
+            const bool fused = l >= 1 && l <= 10 && fused_all;
+            part[l] = w[k].part[l]; dw[l] = grads + koff; db[l] = grads + boff; cins[l] = cin; couts[l] = cout;
+            rows[l] = fused ? (B / S) * Y : pick_bww_chunk(ms) * (B / S) * (trn ? X : Y);
+            rbs[l] = fused ? 32 : 0;
         }
+        if (int e = sol_bww_reduce_layers(hs, NL, part, dw, db, rows, rbs, cins, couts, k > 0 ? 1 : 0, trn ? 1 : 0)) return e;
     }
     return SOL_OK;
 }
