@@ -7,8 +7,25 @@
 // by soname), so libsol_hip.so itself has no link-time dependency on it and single-GPU users never load it.
 #include "common.hpp"
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 #include <string.h>
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+// ROCm install without the RCCL development headers: the five entry points this file binds by dlsym, declared as RCCL 2.x does
+extern "C" {
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclFloat32 = 7 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId*);
+ncclResult_t ncclCommInitRank(ncclComm_t*, int, ncclUniqueId, int);
+ncclResult_t ncclAllReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+ncclResult_t ncclCommDestroy(ncclComm_t);
+const char* ncclGetErrorString(ncclResult_t);
+}
+#endif
 
 namespace {
 
@@ -69,6 +86,10 @@ extern "C" int sol_comm_init(const char* id, int32_t nranks, int32_t rank, sol_c
     if (rccl().err) return sol_set_error(SOL_ERR_HIP, "RCCL unavailable: %s", rccl().err);
     ncclUniqueId u;
     memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    int dev = -1, ndev = 0;
+    SOL_HIP_CHECK(hipGetDeviceCount(&ndev));
+    SOL_HIP_CHECK(hipGetDevice(&dev));
+    SOL_REQUIRE(ndev >= 1 && dev >= 0 && dev < ndev, "sol_comm_init: no usable HIP device is current (device %d of %d)", dev, ndev);
     ncclComm_t c = nullptr;
     SOL_RCCL_CHECK(rccl().CommInitRank(&c, nranks, u, rank));      // binds to the calling thread's current HIP device
     *out = new sol_comm{c, nranks, rank};

@@ -371,7 +371,10 @@ size_t carve_ws(const sol_train_cfg* c, float* base, Ws& w, bool training) {
     w.amax_words = (size_t)(training ? ms : ROLLOUT_AMAX_SETS) * 11 * SOL_AMAX_SLOTS;
     w.amax_act = reinterpret_cast<uint32_t*>(take(w.amax_words));
     w.amax_dz = reinterpret_cast<uint32_t*>(take(training ? w.amax_words : 0));
-    w.chain_words = sol_cnn_chain_flag_words(B, Y, 10);      // carved whatever the options say: the workspace size must not depend on them
+    // hand-off regions of the persistent CNN chain: sized by the image height the CNN kernels see (X in transposed-CNN mode) and
+    // carved only while the option is on (like bww_chunk, the option then enters the workspace size: a workspace sized with
+    // the option off is refused, not overrun, when it is switched on later)
+    w.chain_words = sol_opt().cnn_persistent ? sol_cnn_chain_flag_words(B, cnn_transposed(Y, X) ? X : Y, 10) : 0;
     w.chain_flags = reinterpret_cast<uint32_t*>(take((training ? (size_t)ms * 2 : (size_t)ROLLOUT_AMAX_SETS) * w.chain_words));   // roll-out: forward pass only
     w.chain_ctl = reinterpret_cast<uint32_t*>(take(64));
     w.chain_magic = 0x5017C4A1u ^ ((uint32_t)B * 2654435761u + (uint32_t)Y * 40503u + (uint32_t)X * 97u + (uint32_t)ms * 7u + (training ? 1u : 0u));

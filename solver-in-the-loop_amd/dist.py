@@ -92,22 +92,45 @@ class SolComm:
 
 
 class DPStep:
-    """train step = local fwd_bwd -> all-reduce(SUM) grads (+ loss) -> identical optimizer
-    update on every rank.  `fwd_bwd(*batch) -> (loss_tensor, flat_grads)`, `apply(grads, lr)`."""
+    """train step = local fwd_bwd -> ONE all-reduce(SUM) of [grads | loss] -> identical optimizer update on every rank
+    (one exchange per training step).  `fwd_bwd(*batch) -> (loss_tensor, flat_grads)`,
+    `apply(grads, lr)`.
 
-    def __init__(self, fwd_bwd, apply, group=None, comm=None):
-        """comm: optional SolComm -- the gradient all-reduce then goes through sol_allreduce_grads (the library's own
-        RCCL communicator) instead of torch.distributed.all_reduce; both are RCCL on the GPU."""
-        self.fwd_bwd, self.apply, self.group, self.comm = fwd_bwd, apply, group, comm
+    The scalar loss travels in the slot behind the gradient (count n + 1) instead of a collective of its own.  `flat`:
+    optional persistent buffer of n + 1 elements whose first n elements ARE the gradient tensor fwd_bwd returns (the
+    trainers allocate their gradient that way: no copy at all); without it the step packs grads and loss into an internal
+    buffer (one copy of the gradient each way).  `collectives` counts the all-reduces issued so far."""
+
+    def __init__(self, fwd_bwd, apply, group=None, comm=None, flat=None):
+        """comm: optional SolComm -- the all-reduce then goes through sol_allreduce_grads (the library's own RCCL
+        communicator) instead of torch.distributed.all_reduce; both are RCCL on the GPU."""
+        self.fwd_bwd, self.apply, self.group, self.comm, self.flat = fwd_bwd, apply, group, comm, flat
+        self.collectives = 0
+        self._pack = None
+
+    def _exchange(self, loss, grads):
+        n = grads.numel()
+        own = self.flat is not None and self.flat.numel() == n + 1 and self.flat.data_ptr() == grads.data_ptr()
+        if own:
+            buf = self.flat
+        else:
+            if self._pack is None or self._pack.numel() != n + 1 or self._pack.dtype != grads.dtype or self._pack.device != grads.device:
+                self._pack = torch.empty(n + 1, dtype=grads.dtype, device=grads.device)
+            buf = self._pack
+            buf[:n].copy_(grads.reshape(-1))
+        buf[n:].copy_(loss.detach().reshape(1).to(buf.dtype))
+        if self.comm is not None:
+            self.comm.allreduce_sum_(buf)
+        else:
+            allreduce_sum_(buf, self.group)
+        self.collectives += 1
+        if not own:
+            grads.reshape(-1).copy_(buf[:n])
+        return buf[n].clone()
 
     def __call__(self, *batch, lr):
         loss, grads = self.fwd_bwd(*batch)
         if world_size(self.group) > 1:
-            if self.comm is not None:
-                self.comm.allreduce_sum_(grads)
-            else:
-                allreduce_sum_(grads, self.group)
-            loss = loss.clone()
-            allreduce_sum_(loss, self.group)
+            loss = self._exchange(loss, grads)
         self.apply(grads, lr)
         return loss

@@ -63,7 +63,8 @@ class KarmanFlow:
     def _masks(self, domain, velBCy, velBCyMask, device):
         # fast path: the same objects as last time (the training loop passes the same two arrays every step)
         last = getattr(self, "_last_masks", None)
-        if last is not None and last[0] is velBCy and last[1] is velBCyMask and last[2] == (domain.resolution, str(device)):
+        fast = (domain.resolution, domain.box.lower, domain.box.upper, str(device))
+        if last is not None and last[0] is velBCy and last[1] is velBCyMask and last[2] == fast:
             return last[3]
         key = (domain.resolution, domain.box.lower, domain.box.upper, self._digest(velBCy), self._digest(velBCyMask), str(device))
         if key not in self._cache:
@@ -77,7 +78,7 @@ class KarmanFlow:
                 bcv, bcm = bcv[0:1], bcm[0:1]
             self._cache[key] = ops.SceneMasks(active, inflow, bcv, bcm, device, pressure_solver=self._pressure_solver)
         # (holding the two objects keeps their ids from being recycled while they serve as the fast-path key)
-        self._last_masks = (velBCy, velBCyMask, (domain.resolution, str(device)), self._cache[key])
+        self._last_masks = (velBCy, velBCyMask, fast, self._cache[key])
         return self._cache[key]
 
     def step(self, smoke, re, res, velBCy, velBCyMask, dt=1.0, gravity=None):

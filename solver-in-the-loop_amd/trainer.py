@@ -20,6 +20,22 @@ from ._lib import TrainCfg, check, ptr, stream
 from .dist import DPStep
 
 
+_CONV_PRECISION = {"split": 0, "bf16x6": 1, "fp32": 2}
+
+
+def _conv_precision_code(name):
+    if name is None:
+        return None
+    if name not in _CONV_PRECISION:
+        raise ValueError("conv_precision must be one of %s or None (got %r)" % (sorted(_CONV_PRECISION), name))
+    return _CONV_PRECISION[name]
+
+
+def _apply_conv_precision(code):
+    if code is not None:
+        _lib.set_option("conv_precision", code)
+
+
 class SolTrainer:
     def __init__(self, net, masks, B, Y, X, msteps, dx, std_v, std_re, dt=1.0, res=None,
                  clip_grad=False, beta1=0.9, beta2=0.999, eps=1e-8, group=None, use_graph=True,
@@ -28,11 +44,12 @@ class SolTrainer:
         """conv_precision: arithmetic of the 32-channel convolutions (library option `conv_precision`):
         "split" (default) fp32-equivalent fp16x3 / bf16x6 operand splits on the 16-bit matrix pipe, "bf16x6",
         or "fp32" = strict fp32 MFMA.  The option is process wide in the library; every call of this trainer sets
-        it, so trainers of different precision can alternate in one process."""
+        it, so trainers of different precision can alternate in one process.  None keeps whatever the option table holds
+        (e.g. a SOL_CONV_NO_SB / SOL_CONV_NO_FP16 debugging override applied when the library was loaded)."""
         _lib.require_gpu()
         self.lib = _lib.load()
-        self.conv_precision = {"split": 0, "bf16x6": 1, "fp32": 2}[conv_precision]
-        _lib.set_option("conv_precision", self.conv_precision)
+        self.conv_precision = _conv_precision_code(conv_precision)
+        _apply_conv_precision(self.conv_precision)
         assert net.name == "mars_moon", "the fused trainer implements model_mars_moon (the reference default)"
         self.net, self.masks = net, masks
         self.B, self.Y, self.X, self.msteps = B, Y, X, msteps
@@ -48,7 +65,9 @@ class SolTrainer:
         self.workspace = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
         self.workspace_bytes = nbytes
         n = net.n_params
-        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        # gradient + one slot for the loss: the data-parallel exchange is ONE all-reduce of this buffer (dist.DPStep)
+        self._flat = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        self.grads = self._flat[:n]
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.loss_steps = torch.zeros(msteps, dtype=torch.float32, device=dev)
@@ -61,18 +80,18 @@ class SolTrainer:
         self._offsets = (C.c_int64 * len(net.offsets))(*[int(o) for o in net.offsets])
         self.final = None
         self.use_graph = use_graph
-        self._graph = None          # (key, handle): replayable hipGraph of the whole fwd+bwd
-        self._captures = 0          # graph (re)captures so far
+        self._graphs = {}           # want_final -> (key, handle): replayable hipGraphs of the whole fwd+bwd
+        self._captures = 0          # re-captures caused by MOVED input buffers so far
         self._stage = None          # internal input buffers, used once the caller's buffers turn out not to be persistent
         self._fin = None
         self._want_final = False
         self._eager = False
-        self._dp = DPStep(self._fwd_bwd_flat, self._apply_flat, group=group, comm=comm)
+        self._dp = DPStep(self._fwd_bwd_flat, self._apply_flat, group=group, comm=comm, flat=self._flat)
 
     def __del__(self):
         try:
-            if self._graph is not None:
-                self.lib.sol_train_graph_destroy(self._graph[1])
+            for _, h in self._graphs.values():
+                self.lib.sol_train_graph_destroy(h)
         except Exception:
             pass
 
@@ -88,7 +107,7 @@ class SolTrainer:
         B, Y, X, ms = self.B, self.Y, self.X, self.msteps
         assert vy0.shape == (B, Y + 1, X) and vx0.shape == (B, Y, X + 1) and d0.shape == (B, Y, X)
         assert gt_vy.shape == (ms, B, Y + 1, X) and gt_vx.shape == (ms, B, Y, X + 1) and re.shape == (B,)
-        _lib.set_option("conv_precision", self.conv_precision)
+        _apply_conv_precision(self.conv_precision)
         if self._stage is not None and not eager:
             for dst, src in zip(self._stage, (d0, vy0, vx0, re, gt_vy, gt_vx)):
                 dst.copy_(src)
@@ -106,21 +125,23 @@ class SolTrainer:
         if self.use_graph and not eager:
             # all pointers are baked into the graph: re-capture only when a buffer moved
             key = tuple(a.value if isinstance(a, C.c_void_p) else a for a in args)
-            if self._graph is None or self._graph[0] != key:
-                self._captures += 1
-                if self._captures == 4 and self._stage is None:
-                    # the caller passes fresh tensors every step: stop re-capturing (each capture is a device-wide
-                    # synchronisation + ~1000 node instantiations), stage the inputs instead
-                    self._stage = [t.clone() for t in (d0, vy0, vx0, re, gt_vy, gt_vx)]
-                    return self.fwd_bwd(d0, vy0, vx0, re, gt_vy, gt_vx, want_final=want_final)
-                if self._graph is not None:
-                    check(self.lib.sol_train_graph_destroy(self._graph[1]))
-                    self._graph = None
+            slot = bool(want_final)                      # one graph per output set: toggling want_final re-captures nothing
+            cur = self._graphs.get(slot)
+            if cur is None or cur[0] != key:
+                if cur is not None:
+                    # the caller's buffers moved (fresh tensors every step): after three such re-captures (each one is a
+                    # device-wide synchronisation + ~1000 node instantiations) stage the inputs instead
+                    self._captures += 1
+                    if self._captures >= 3 and self._stage is None:
+                        self._stage = [t.clone() for t in (d0, vy0, vx0, re, gt_vy, gt_vx)]
+                        return self.fwd_bwd(d0, vy0, vx0, re, gt_vy, gt_vx, want_final=want_final)
+                    check(self.lib.sol_train_graph_destroy(cur[1]))
+                    del self._graphs[slot]
                 h = C.c_void_p()
                 torch.cuda.synchronize()
                 check(self.lib.sol_train_graph_create(C.byref(self.cfg), *args, C.byref(h)))
-                self._graph = (key, h)
-            check(self.lib.sol_train_graph_launch(self._graph[1], stream()))
+                self._graphs[slot] = (key, h)
+            check(self.lib.sol_train_graph_launch(self._graphs[slot][1], stream()))
         else:
             check(self.lib.sol_train_fwd_bwd(C.byref(self.cfg), stream(), *args))
         self.final = fin if want_final else None
@@ -169,9 +190,11 @@ class SolTrainer:
 class SolRollout:
     """No-grad roll-out of solver step + CNN correction (karman_apply.py:138-158)."""
 
-    def __init__(self, net, masks, B, Y, X, dx, std_v, std_re, dt=1.0, res=None, in_std_v=None, out_std_v=None, **solver):
+    def __init__(self, net, masks, B, Y, X, dx, std_v, std_re, dt=1.0, res=None, in_std_v=None, out_std_v=None,
+                 conv_precision="split", **solver):
         _lib.require_gpu()
         self.lib = _lib.load()
+        self.conv_precision = _conv_precision_code(conv_precision)
         self.net, self.masks, self.B = net, masks, B
         kc = ops.karman_cfg(B, Y, X, dx, dt=dt, res=res, masks=masks, **solver)
         i0, i1 = (float(in_std_v[0]), float(in_std_v[1])) if in_std_v is not None else (0.0, 0.0)
@@ -185,6 +208,7 @@ class SolRollout:
         """Advances (d, vy, vx) in place by nsteps; returns CG iterations [nsteps,B]."""
         iters = torch.zeros(nsteps * self.B, dtype=torch.int32, device=d.device)
         mk = self.masks
+        _apply_conv_precision(self.conv_precision)
         check(self.lib.sol_rollout(C.byref(self.cfg), stream(), ptr(self.net.params.detach()), ptr(d), ptr(vy), ptr(vx),
                                    ptr(re), ptr(mk.active), ptr(mk.inflow), ptr(mk.velBCy), ptr(mk.velBCyMask),
                                    mk.bc_stride, nsteps, ptr(self.workspace), self.workspace_bytes, ptr(iters)))
@@ -200,16 +224,36 @@ class GraphTrainer:
     optional per-tensor clip; data parallel through the same DPStep (one SUM all-reduce of `grads`)."""
 
     def __init__(self, net, B, Y, X, msteps, std_v, std_re, res=None, clip_grad=False, beta1=0.9, beta2=0.999, eps=1e-8,
-                 group=None, use_graph=True, comm=None, in_std_v=None, out_std_v=None, pressure_solver=None):
+                 group=None, use_graph=True, comm=None, in_std_v=None, out_std_v=None, pressure_solver=None,
+                 dx=None, dt=1.0, masks=None, cg_rtol=1e-6, cg_atol=1e-9, cg_max_iter=2000, grad_pad="replicate",
+                 inflow_order="after", conv_precision="split"):
+        """dx: cell size (default 100 / X, the reference's `--len 100`); the domain is box[0:Y*dx, 0:X*dx] as the scripts
+        build it (karman_train.py:363: box[0:len*2, 0:len]).  masks: optional SceneMasks of the caller -- its boundary
+        arrays are used; its scene must be the one KarmanFlow derives from the domain (checked).  The solver options are
+        those of SolTrainer and are forwarded to KarmanFlow."""
         from . import fluid, karman
         _lib.require_gpu()
         self.lib = _lib.load()
+        self.conv_precision = _conv_precision_code(conv_precision)
         self.net, self.B, self.Y, self.X, self.msteps = net, B, Y, X, msteps
         dev = self.device = net.params.device
-        self.dom = fluid.Domain([Y, X], box=fluid.box[0:200, 0:100])
-        self.sim = karman.KarmanFlow(pressure_solver=pressure_solver)
+        dx = 100.0 / X if dx is None else float(dx)
+        self.dt = float(dt)
+        self.dom = fluid.Domain([Y, X], box=fluid.box[0:Y * dx, 0:X * dx])
+        self.sim = karman.KarmanFlow(pressure_solver=pressure_solver, cg_rtol=cg_rtol, cg_atol=cg_atol, cg_max_iter=cg_max_iter,
+                                     grad_pad=grad_pad, inflow_order=inflow_order)
         self.res = X if res is None else res
-        self.bcv, self.bcm = karman.velocity_bc_masks(Y, X, batch_size=B)
+        if masks is not None:
+            import numpy as np
+            active, inflow = self.sim.scene_arrays(self.dom)
+            if not (np.array_equal(masks.active.reshape(Y, X).cpu().numpy(), active.astype(np.float32)) and
+                    np.array_equal(masks.inflow.reshape(Y, X).cpu().numpy(), inflow.astype(np.float32))):
+                raise ValueError("GraphTrainer composes KarmanFlow.step, whose scene (inflow box, sphere) follows from the domain; "
+                                 "the given masks describe a different scene")
+            self.bcv = masks.velBCy.reshape(-1, Y + 1, X, 1).cpu().numpy()
+            self.bcm = masks.velBCyMask.reshape(-1, Y + 1, X, 1).cpu().numpy()
+        else:
+            self.bcv, self.bcm = karman.velocity_bc_masks(Y, X, batch_size=B)
         t = lambda v: torch.tensor([float(a) for a in v], dtype=torch.float32, device=dev)
         self.scale_loss = t(std_v)
         self.scale_in = t(list(in_std_v if in_std_v is not None else std_v) + [std_re])
@@ -217,7 +261,8 @@ class GraphTrainer:
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         self._in = [f32(B, Y, X), f32(B, Y + 1, X), f32(B, Y, X + 1), f32(B), f32(msteps, B, Y + 1, X), f32(msteps, B, Y, X + 1)]
         n = net.n_params
-        self.grads, self.m, self.v = f32(n), f32(n), f32(n)
+        self._flat = f32(n + 1)                   # gradient + loss slot: one all-reduce per step (dist.DPStep)
+        self.grads, self.m, self.v = self._flat[:n], f32(n), f32(n)
         self.loss_steps = f32(msteps)
         self._fin = [f32(B, Y, X), f32(B, Y + 1, X), f32(B, Y, X + 1)]
         self.final = None
@@ -228,7 +273,7 @@ class GraphTrainer:
         self._offsets = (C.c_int64 * len(net.offsets))(*[int(o) for o in net.offsets])
         self.use_graph, self._graph = use_graph, None
         self._want_final, self._eager = False, False
-        self._dp = DPStep(self._fwd_bwd_flat, self._apply_flat, group=group, comm=comm)
+        self._dp = DPStep(self._fwd_bwd_flat, self._apply_flat, group=group, comm=comm, flat=self._flat)
 
     def _unrolled(self):
         from . import fluid, karman
@@ -239,7 +284,7 @@ class GraphTrainer:
         st = fluid.Fluid(self.dom, density=d0.reshape(B, Y, X, 1), velocity=stag(vy0, vx0), batch_size=B)
         losses = []
         for i in range(self.msteps):
-            st = self.sim.step(st, re=re, res=self.res, velBCy=self.bcv, velBCyMask=self.bcm)
+            st = self.sim.step(st, re=re, res=self.res, velBCy=self.bcv, velBCyMask=self.bcm, dt=self.dt)
             corr = karman.to_staggered(self.net(karman.to_feature(st, re) / self.scale_in) * self.scale_out, self.dom.box)
             st = st.copied_with(velocity=st.velocity + corr)
             diff = (stag(gt_vy[i], gt_vx[i]) - st.velocity.staggered_tensor()) / self.scale_loss
@@ -255,6 +300,7 @@ class GraphTrainer:
         self._fin[2].copy_(vt[:, :Y, :, 1])
 
     def fwd_bwd(self, d0, vy0, vx0, re, gt_vy, gt_vx, want_final=False, eager=False):
+        _apply_conv_precision(self.conv_precision)
         for dst, src in zip(self._in, (d0, vy0, vx0, re, gt_vy, gt_vx)):
             dst.copy_(src, non_blocking=True)
         if eager or not self.use_graph:
@@ -287,5 +333,4 @@ def make_trainer(net, masks, B, Y, X, msteps, dx, std_v, std_re, **kw):
     """SolTrainer (the C++ schedule: model_mars_moon) or GraphTrainer (autograd composition in a hipGraph: everything else)."""
     if net.name == "mars_moon":
         return SolTrainer(net, masks, B, Y, X, msteps, dx, std_v, std_re, **kw)
-    keep = ("res", "clip_grad", "beta1", "beta2", "eps", "group", "use_graph", "comm", "in_std_v", "out_std_v")
-    return GraphTrainer(net, B, Y, X, msteps, std_v, std_re, **{k: v for k, v in kw.items() if k in keep})
+    return GraphTrainer(net, B, Y, X, msteps, std_v, std_re, dx=dx, masks=masks, **kw)     # unknown keywords raise TypeError
