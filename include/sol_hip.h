@@ -52,6 +52,7 @@ int sol_abi_sizes(int32_t* karman_cfg, int32_t* burgers_cfg, int32_t* train_cfg)
  *                       neighbouring workgroups) where the shape allows it (W == 64, ceil(B*H/3) <= #CUs); measured on par
  *                       with the per-layer launches at B = 6
  *   bww_fuse (1), correct_fuse (1), density_mode (0), conv_thin (1), conv_r3 (1), conv_bww32 (1): fusion / kernel choices
+ *   k3d_tile (1)        karman-3d advection from LDS tiles that hold the full z column + halo (0: straight from global memory)
  *   bww_chunk (0), bww_side (1), streams (1), cpt (0), conv_split3 (0), dbg_skip (0), step_prof (0): experiments, debugging */
 int sol_set_option(const char* name, int32_t value);
 int sol_get_option(const char* name, int32_t* value);
@@ -324,6 +325,57 @@ int sol_comm_init(const char* id, int32_t nranks, int32_t rank, sol_comm** out);
 /* in-place SUM over all ranks of flat_grad[count] (device fp32), asynchronous on `stream` */
 int sol_allreduce_grads(sol_comm* comm, void* stream, float* flat_grad, int64_t count);
 int sol_comm_destroy(sol_comm* comm);
+
+/* ------------------------------------------------------------------------------------
+ * karman-3d (BASELINE.json configs[4]: 128 x 64 x 64).  The reference has NO 3-D code (/root/reference/README.md:37-38);
+ * these entry points are the dimension-generic twins of the 2-D ones: the same KarmanFlow.step
+ * (karman-2d/karman_train.py:173-185) with a third axis, and model_mars_moon (karman_train.py:101-138) with Conv3D(5)
+ * layers.  Layout: density [B,Y,X,Z], v_y [B,Y+1,X,Z], v_x [B,Y,X+1,Z], v_z [B,Y,X,Z+1] (y = flow direction, z
+ * contiguous); CNN tensors NDHWC = [B,Y,X,Z,C].  FORWARD ONLY in this version (roll-out / data generation; the adjoint is
+ * the next row of DESIGN.md section 7).
+ * ---------------------------------------------------------------------------------- */
+typedef struct sol_karman3d_cfg {
+    int32_t B, Y, X, Z;     /* batch, cells per axis                                                   */
+    float dx;               /* cell size = len / X                                                      */
+    float dt;               /* time step                                                                */
+    float res;              /* `res` of step(): alpha = dt*res*res/Re (karman_train.py:175)             */
+    int32_t grad_pad;       /* 0: replicate (PhiFlow 1.x), 1: dirichlet0                                */
+    int32_t inflow_before;  /* 0: density += inflow*dt after advection, 1: before                       */
+    int32_t direct_n;       /* number of 32-bit words of `direct`                                        */
+    const float* direct;    /* DEVICE blob of the direct pressure solver for the scene's `active` mask
+                               (three sine-transform matrices, 1/eigenvalues, capacitance matrix of the
+                               obstacle cells; layout: precond3d.direct_solver_blob3d).  Required.       */
+} sol_karman3d_cfg;
+int32_t sol_abi_size_karman3d(void);      /* sizeof(sol_karman3d_cfg) of the library (checked by the ctypes mirror) */
+
+/* Arguments as sol_karman_step_fwd_large with the third component; active / inflow [Y,X,Z]; velBCy / velBCyMask
+ * [Y+1,X,Z] (bc_batch_stride 0) or [B,Y+1,X,Z]; feat_out [B,Y,X,Z,4] (or NULL): fused to_feature = the three components
+ * at the low faces of every cell and Re, each times feat_scale[c] (HOST array of 4 = 1/std).  direct_header_host: HOST
+ * copy of the first 16 words of the blob.  workspace: sol_karman3d_step_workspace_bytes(cfg) bytes of DEVICE scratch.
+ * Outputs must not alias inputs. */
+size_t sol_karman3d_step_workspace_bytes(const sol_karman3d_cfg* cfg);
+int sol_karman3d_step_fwd(const sol_karman3d_cfg* cfg, void* stream,
+                          const float* d_in, const float* vy_in, const float* vx_in, const float* vz_in,
+                          const float* re, const float* active, const float* inflow,
+                          const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
+                          float* d_out, float* vy_out, float* vx_out, float* vz_out,
+                          float* feat_out, const float* feat_scale, const int32_t* direct_header_host,
+                          void* workspace, size_t workspace_bytes);
+/* velocity += s_c * out[..., c] for the three components (to_staggered + add, karman_train.py:88-90, 424-426):
+ * out [B,Y,X,Z,cout], cout >= 3; the last face of each component's own axis receives no correction. */
+int sol_karman3d_correct(void* stream, const float* out, int32_t cout, float s0, float s1, float s2,
+                         float* vy, float* vx, float* vz, int32_t B, int32_t Y, int32_t X, int32_t Z);
+
+/* 5 x 5 x 5 SAME convolution, NDHWC fp32 (keras.layers.Conv3D(filters, 5, padding='same') + bias / LeakyReLU / add).
+ * w_dhwio [5,5,5,cin,cout] (Keras layout, D = y).  Runs as five passes of the 2-D kernels over the (H, W) planes with the
+ * running sum in y, the centre slice last (bias, activation, absmax publish): same per-product arithmetic as sol_conv5x5.
+ * x [B,D,H,W,cin] with cin in {4 (zero padded), 32}; residual [B,D,H,W,cout] or NULL is added before the activation;
+ * epilogue SOL_EPI_NONE / SOL_EPI_LRELU; x_absmax / y_absmax as in sol_conv5x5_scaled (may be NULL).  x != y, D >= 3. */
+size_t sol_conv3d_packed_floats(int32_t cin, int32_t cout);
+int sol_conv3d_pack(void* stream, const float* w_dhwio, int32_t cin, int32_t cout, float* packed);
+int sol_conv3d(void* stream, const float* x, const float* packed, const float* bias, const float* residual, float* y,
+               int32_t B, int32_t D, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t epilogue, float slope,
+               const uint32_t* x_absmax, uint32_t* y_absmax);
 
 /* offsets (in floats) of layer l's kernel / bias inside the flat mars_moon parameter
  * vector; l in [0,12).  cin/cout may be NULL.                                            */

@@ -35,6 +35,14 @@ class BurgersCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("Y", C.c_int32), ("X", C.c_int32), ("dx", C.c_float), ("dt", C.c_float)]
 
 
+class Karman3DCfg(C.Structure):
+    """sol_karman3d_cfg"""
+    _fields_ = [("B", C.c_int32), ("Y", C.c_int32), ("X", C.c_int32), ("Z", C.c_int32),
+                ("dx", C.c_float), ("dt", C.c_float), ("res", C.c_float),
+                ("grad_pad", C.c_int32), ("inflow_before", C.c_int32),
+                ("direct_n", C.c_int32), ("direct", C.c_void_p)]
+
+
 class TrainCfg(C.Structure):
     """sol_train_cfg"""
     _fields_ = [("karman", KarmanCfg), ("msteps", C.c_int32),
@@ -82,6 +90,13 @@ _SIGS = {
     "sol_comm_init": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "sol_allreduce_grads": (C.c_int, [_P, _P, _P, C.c_int64]),
     "sol_comm_destroy": (C.c_int, [_P]),
+    "sol_abi_size_karman3d": (C.c_int32, []),
+    "sol_karman3d_step_workspace_bytes": (C.c_size_t, [C.POINTER(Karman3DCfg)]),
+    "sol_karman3d_step_fwd": (C.c_int, [C.POINTER(Karman3DCfg), _P] + [_P] * 9 + [C.c_int64] + [_P] * 5 + [C.POINTER(C.c_float), _P, _P, C.c_size_t]),
+    "sol_karman3d_correct": (C.c_int, [_P, _P, C.c_int32] + [C.c_float] * 3 + [_P] * 3 + [C.c_int32] * 4),
+    "sol_conv3d_packed_floats": (C.c_size_t, [C.c_int32] * 2),
+    "sol_conv3d_pack": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    "sol_conv3d": (C.c_int, [_P] * 6 + [C.c_int32] * 7 + [C.c_float] + [_P] * 2),
     "sol_mars_moon_layer": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 
@@ -100,7 +115,7 @@ def lib_path():
     return _build.LIB
 
 
-ABI_VERSION = 200     # sol_version() of the library these bindings were written against
+ABI_VERSION = 210     # sol_version() of the library these bindings were written against
 
 # Debugging overrides: environment variable -> (option, value).  Read ONCE here, in Python, when the library is loaded;
 # the library itself never reads the environment (options are set through sol_set_option, include/sol_hip.h).
@@ -144,6 +159,9 @@ def load():
     if (kc.value, bc.value, tc.value) != (C.sizeof(KarmanCfg), C.sizeof(BurgersCfg), C.sizeof(TrainCfg)):
         raise SolError("struct layout mismatch between libsol_hip.so %r and the ctypes mirror %r"
                        % ((kc.value, bc.value, tc.value), (C.sizeof(KarmanCfg), C.sizeof(BurgersCfg), C.sizeof(TrainCfg))))
+    if lib.sol_abi_size_karman3d() != C.sizeof(Karman3DCfg):
+        raise SolError("struct layout mismatch: sol_karman3d_cfg is %d bytes in libsol_hip.so, %d in the ctypes mirror"
+                       % (lib.sol_abi_size_karman3d(), C.sizeof(Karman3DCfg)))
     _lib = lib
     for env, (opt, val) in _ENV_OPTIONS.items():
         if os.environ.get(env):

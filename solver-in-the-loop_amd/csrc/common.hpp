@@ -26,6 +26,10 @@ int sol_bww_batched(void* stream, const float* x, const float* dz, float* partia
 int sol_bww_batched_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int nseg, int B, int H,
                            int cin, int cout, int accumulate, int taps_transposed = 0);
 
+// C[b] (M x N) = (accumulate ? C[b] : 0) + A[b] (M x K) * B[b] (K x N), row major, fp32, batch strides may be 0 (karman_large.hip)
+int sol_gemm_f32(hipStream_t s, int batch, const float* A, int lda, long sA, const float* Bm, int ldb, long sB, float* C, int ldc, long sC,
+                 int M, int N, int K, int accumulate);
+
 // forward / backward-data convolution arguments (conv5x5.hip, conv5x5_sb.hip)
 struct ConvArgs {
     const float *x, *wp, *bias, *res, *act;
@@ -138,6 +142,7 @@ struct SolOptions {
     int cnn_persistent;   // 1: the ten 32 -> 32 layers of a CNN pass as ONE persistent launch (cnn_chain.hip) where the shape allows it; default 0:
                           //    measured equal to the per-layer launches end to end, kept as a verified experiment
     int graph_stream;     // 1: sol_train_graph_launch replays on an internal stream fenced by events against the caller's stream
+    int k3d_tile;         // 1 (default): karman-3d advection from LDS tiles holding the full z column + halo; 0: straight from global memory
 };
 SolOptions& sol_opt();
 

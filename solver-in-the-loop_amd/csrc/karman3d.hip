@@ -1,0 +1,514 @@
+// karman-3d forward solver step (BASELINE.json configs[4]: 128 x 64 x 64, SOL-16) for gfx950.
+//
+// The reference has no 3-D code (/root/reference/README.md:37-38); the algorithm is the dimension-generic restatement of
+// KarmanFlow.step (/root/reference/karman-2d/karman_train.py:173-185) + PhiFlow's IncompressibleFlow.step, exactly as
+// oracle/sol_oracle3d.py states it.  Layout: density [B,Y,X,Z], v_y [B,Y+1,X,Z], v_x [B,Y,X+1,Z], v_z [B,Y,X,Z+1]; y = flow
+// direction, z contiguous.
+//
+// A 128 x 64 x 64 component is 2 MB: the state cannot live in one CU's LDS like the 2-D step (karman_step.hip), so the step is
+// a sequence of chip-wide launches (the structure of karman_large.hip) over L2 / MALL resident fields:
+//   k3_diffuse      explicit 7-point diffusion (replicate padding, dx = 1) + velocity BC on the flow component  -> sv_*
+//   k3_advect_tile  semi-Lagrangian advection of the three components (clamped) and the density (zero ghost ring) + inflow +
+//                   hard-BC face masks.  One workgroup = an 8 x 8 (y, x) tile holding the FULL z column of the three diffused
+//                   components with a 2-cell halo in LDS (13 x 12 x 64 floats per component, 117 KB at Z = 64): every
+//                   trilinear gather and every cross-component average of the tile is served from LDS, lanes run along z
+//                   (conflict free, coalesced stores); samples that leave the halo (CFL > 1) fall back to global reads.
+//                   (k3_advect: the same arithmetic straight from global memory -- option k3d_tile = 0, and any Z > 64.)
+//   k3_div          rhs = -div
+//   pressure        DIRECT solve x = G (b - U_S E_SS x_S), x_S = (I + G_SS E_SS)^-1 (G b)_S with G = the empty-box Dirichlet
+//                   Laplacian diagonalised by three sine transforms (batched fp32 GEMMs along z, x, y) and the capacitance
+//                   correction of the obstacle cells (precond3d.direct_solver_blob3d): 12 transform passes + k3_capacitance
+//   k3_project      v -= mask * grad p, fused to_feature (4 channels: three components + Re)
+// Forward only: the adjoint of the 3-D step is the next row.
+#include "common.hpp"
+
+namespace {
+
+constexpr int FD3_HEADER = 16;
+constexpr int FD3_MAGIC = 0x46443333;     // "FD33"
+
+struct K3Args {
+    int B, Y, X, Z;
+    float dtdx, dt, adt;
+    int grad_pad, inflow_before;
+    const float *d_in, *vy_in, *vx_in, *vz_in, *re, *active, *inflow, *bcv, *bcm;
+    long bc_stride;
+    float *d_out, *vy_out, *vx_out, *vz_out, *svy, *svx, *svz, *rhs, *feat;
+    const float* p;
+    float fs0, fs1, fs2, fs3;
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// 7-point replicate-padded Laplacian of one component array [n0][n1][n2] at (j, i, k)
+__device__ __forceinline__ float lap7(const float* f, int n0, int n1, int n2, int j, int i, int k) {
+    const size_t s0 = (size_t)n1 * n2, s1 = n2;
+    const size_t c = (size_t)j * s0 + (size_t)i * s1 + k;
+    const float v = f[c];
+    return f[j + 1 < n0 ? c + s0 : c] + f[j > 0 ? c - s0 : c] + f[i + 1 < n1 ? c + s1 : c] + f[i > 0 ? c - s1 : c] +
+           f[k + 1 < n2 ? c + 1 : c] + f[k > 0 ? c - 1 : c] - 6.f * v;
+}
+
+__global__ void __launch_bounds__(256) k3_diffuse(K3Args a) {
+    const int Y = a.Y, X = a.X, Z = a.Z;
+    const int nVy = (Y + 1) * X * Z, nVx = Y * (X + 1) * Z, nVz = Y * X * (Z + 1);
+    const int b = blockIdx.y;
+    const float alpha = a.adt / a.re[b];
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nVy + nVx + nVz; e += gridDim.x * blockDim.x) {
+        if (e < nVy) {
+            const int k = e % Z, i = (e / Z) % X, j = e / (Z * X);
+            const float* f = a.vy_in + (size_t)b * nVy;
+            float v = f[e] + alpha * lap7(f, Y + 1, X, Z, j, i, k);
+            const size_t m = (size_t)b * a.bc_stride + e;
+            v = v * (1.f - a.bcm[m]) + a.bcv[m];
+            a.svy[(size_t)b * nVy + e] = v;
+        } else if (e < nVy + nVx) {
+            const int q = e - nVy, k = q % Z, i = (q / Z) % (X + 1), j = q / (Z * (X + 1));
+            const float* f = a.vx_in + (size_t)b * nVx;
+            a.svx[(size_t)b * nVx + q] = f[q] + alpha * lap7(f, Y, X + 1, Z, j, i, k);
+        } else {
+            const int q = e - nVy - nVx, k = q % (Z + 1), i = (q / (Z + 1)) % X, j = q / ((Z + 1) * X);
+            const float* f = a.vz_in + (size_t)b * nVz;
+            a.svz[(size_t)b * nVz + q] = f[q] + alpha * lap7(f, Y, X, Z + 1, j, i, k);
+        }
+    }
+}
+
+// ---- hard-BC face masks from the `active` cell mask ('boundary' extrapolation: outside the OPEN domain = edge value) ----
+__device__ __forceinline__ float acc_at(const float* act, int Y, int X, int Z, int j, int i, int k) {
+    return act[((size_t)clampi(j, 0, Y - 1) * X + clampi(i, 0, X - 1)) * Z + clampi(k, 0, Z - 1)] != 0.f ? 1.f : 0.f;
+}
+template <int AX>
+__device__ __forceinline__ float face_mask(const float* act, int Y, int X, int Z, int j, int i, int k) {
+    return acc_at(act, Y, X, Z, j - (AX == 0), i - (AX == 1), k - (AX == 2)) * acc_at(act, Y, X, Z, j, i, k);
+}
+
+// ---- readers of the diffused components: straight from global memory, or from the workgroup's LDS tile ----------------
+struct GlobalReader {
+    const float *sy, *sx, *sz;
+    int Y, X, Z;
+    __device__ __forceinline__ float y(int j, int i, int k) const { return sy[((size_t)j * X + i) * Z + k]; }
+    __device__ __forceinline__ float x(int j, int i, int k) const { return sx[((size_t)j * (X + 1) + i) * Z + k]; }
+    __device__ __forceinline__ float z(int j, int i, int k) const { return sz[((size_t)j * X + i) * (Z + 1) + k]; }
+};
+constexpr int T3 = 8;          // tile edge (cells) in y and x
+constexpr int HL3 = 2;         // halo cells
+constexpr int TR = T3 + 2 * HL3;      // cell rows / columns of the tile region (12); face arrays have one more along their axis
+struct TileReader {
+    GlobalReader g;
+    const float *ly, *lx, *lz;        // LDS: [TR+1][TR][Z], [TR][TR+1][Z], [TR][TR][Z+1]
+    int j0, i0;                       // first cell row / column of the region (may be negative: clipped rows are never read)
+    __device__ __forceinline__ float y(int j, int i, int k) const {
+        const int rj = j - j0, ri = i - i0;
+        return ((unsigned)rj <= (unsigned)TR && (unsigned)ri < (unsigned)TR) ? ly[(rj * TR + ri) * g.Z + k] : g.y(j, i, k);
+    }
+    __device__ __forceinline__ float x(int j, int i, int k) const {
+        const int rj = j - j0, ri = i - i0;
+        return ((unsigned)rj < (unsigned)TR && (unsigned)ri <= (unsigned)TR) ? lx[(rj * (TR + 1) + ri) * g.Z + k] : g.x(j, i, k);
+    }
+    __device__ __forceinline__ float z(int j, int i, int k) const {
+        const int rj = j - j0, ri = i - i0;
+        return ((unsigned)rj < (unsigned)TR && (unsigned)ri < (unsigned)TR) ? lz[(rj * TR + ri) * (g.Z + 1) + k] : g.z(j, i, k);
+    }
+};
+
+// trilinear sample of component C (0: y faces [Y+1][X][Z], 1: x faces, 2: z faces) at index-space position
+// (j + oy, i + ox, k + oz) of its own lattice, indices clamped ('boundary' extrapolation).  floor() acts on the OFFSET only:
+// the interpolation weights keep their full fp32 precision whatever the base index.
+template <int C, class R>
+__device__ __forceinline__ float tri_clamp(const R& r, int j, float oy, int i, float ox, int k, float oz) {
+    const int n0 = r.g_Y() + (C == 0), n1 = r.g_X() + (C == 1), n2 = r.g_Z() + (C == 2);
+    const float fy = floorf(oy), fx = floorf(ox), fz = floorf(oz);
+    const float wy = oy - fy, wx = ox - fx, wz = oz - fz;
+    const int ja = j + (int)fy, ia = i + (int)fx, ka = k + (int)fz;
+    const int j0 = clampi(ja, 0, n0 - 1), j1 = clampi(ja + 1, 0, n0 - 1);
+    const int i0 = clampi(ia, 0, n1 - 1), i1 = clampi(ia + 1, 0, n1 - 1);
+    const int k0 = clampi(ka, 0, n2 - 1), k1 = clampi(ka + 1, 0, n2 - 1);
+    auto rd = [&](int jj, int ii, int kk) { return C == 0 ? r.y(jj, ii, kk) : (C == 1 ? r.x(jj, ii, kk) : r.z(jj, ii, kk)); };
+    const float c00 = (1.f - wz) * rd(j0, i0, k0) + wz * rd(j0, i0, k1);
+    const float c01 = (1.f - wz) * rd(j0, i1, k0) + wz * rd(j0, i1, k1);
+    const float c10 = (1.f - wz) * rd(j1, i0, k0) + wz * rd(j1, i0, k1);
+    const float c11 = (1.f - wz) * rd(j1, i1, k0) + wz * rd(j1, i1, k1);
+    return (1.f - wy) * ((1.f - wx) * c00 + wx * c01) + wy * ((1.f - wx) * c10 + wx * c11);
+}
+struct GR : GlobalReader {
+    __device__ __forceinline__ int g_Y() const { return Y; }
+    __device__ __forceinline__ int g_X() const { return X; }
+    __device__ __forceinline__ int g_Z() const { return Z; }
+};
+struct TRd : TileReader {
+    __device__ __forceinline__ int g_Y() const { return g.Y; }
+    __device__ __forceinline__ int g_X() const { return g.X; }
+    __device__ __forceinline__ int g_Z() const { return g.Z; }
+};
+
+// one advected value per call.  kind 0/1/2: face of that component at (j, i, k); kind 3: cell (j, i, k).
+// Velocity at the sample point: the own component is the stored value, the others are the bilinear averages of their four
+// surrounding faces (index clamped: 'boundary' extrapolation of the component grids)  [oracle: advect_mac]
+template <class R>
+__device__ __forceinline__ void advect_point(const K3Args& a, const R& r, int b, int kind, int j, int i, int k) {
+    const int Y = a.Y, X = a.X, Z = a.Z;
+    if (kind == 0) {
+        const float uy = r.y(j, i, k);
+        const int ja = max(j - 1, 0), jb = min(j, Y - 1);
+        const float ux = 0.25f * (r.x(ja, i, k) + r.x(ja, i + 1, k) + r.x(jb, i, k) + r.x(jb, i + 1, k));
+        const float uz = 0.25f * (r.z(ja, i, k) + r.z(ja, i, k + 1) + r.z(jb, i, k) + r.z(jb, i, k + 1));
+        const float v = tri_clamp<0>(r, j, -uy * a.dtdx, i, -ux * a.dtdx, k, -uz * a.dtdx);
+        a.vy_out[(size_t)b * (Y + 1) * X * Z + ((size_t)j * X + i) * Z + k] = v * face_mask<0>(a.active, Y, X, Z, j, i, k);
+    } else if (kind == 1) {
+        const float ux = r.x(j, i, k);
+        const int ia = max(i - 1, 0), ib = min(i, X - 1);
+        const float uy = 0.25f * (r.y(j, ia, k) + r.y(j, ib, k) + r.y(j + 1, ia, k) + r.y(j + 1, ib, k));
+        const float uz = 0.25f * (r.z(j, ia, k) + r.z(j, ia, k + 1) + r.z(j, ib, k) + r.z(j, ib, k + 1));
+        const float v = tri_clamp<1>(r, j, -uy * a.dtdx, i, -ux * a.dtdx, k, -uz * a.dtdx);
+        a.vx_out[(size_t)b * Y * (X + 1) * Z + ((size_t)j * (X + 1) + i) * Z + k] = v * face_mask<1>(a.active, Y, X, Z, j, i, k);
+    } else if (kind == 2) {
+        const float uz = r.z(j, i, k);
+        const int ka = max(k - 1, 0), kb = min(k, Z - 1);
+        const float uy = 0.25f * (r.y(j, i, ka) + r.y(j, i, kb) + r.y(j + 1, i, ka) + r.y(j + 1, i, kb));
+        const float ux = 0.25f * (r.x(j, i, ka) + r.x(j, i, kb) + r.x(j, i + 1, ka) + r.x(j, i + 1, kb));
+        const float v = tri_clamp<2>(r, j, -uy * a.dtdx, i, -ux * a.dtdx, k, -uz * a.dtdx);
+        a.vz_out[(size_t)b * Y * X * (Z + 1) + ((size_t)j * X + i) * (Z + 1) + k] = v * face_mask<2>(a.active, Y, X, Z, j, i, k);
+    } else {
+        const size_t N = (size_t)Y * X * Z, c = ((size_t)j * X + i) * Z + k;
+        const float uy = 0.5f * (r.y(j, i, k) + r.y(j + 1, i, k));
+        const float ux = 0.5f * (r.x(j, i, k) + r.x(j, i + 1, k));
+        const float uz = 0.5f * (r.z(j, i, k) + r.z(j, i, k + 1));
+        const float oy = -uy * a.dtdx, ox = -ux * a.dtdx, oz = -uz * a.dtdx;
+        const float fy = floorf(oy), fx = floorf(ox), fz = floorf(oz);
+        const float wy = oy - fy, wx = ox - fx, wz = oz - fz;
+        const int j0 = j + (int)fy, i0 = i + (int)fx, k0 = k + (int)fz;
+        const float* gd = a.d_in + (size_t)b * N;
+        float acc = 0.f;
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+            for (int di = 0; di < 2; ++di)
+#pragma unroll
+                for (int dk = 0; dk < 2; ++dk) {
+                    const int jj = j0 + dj, ii = i0 + di, kk = k0 + dk;
+                    float v = 0.f;                    // extrapolation 'constant': one ring of zero ghost cells
+                    if ((unsigned)jj < (unsigned)Y && (unsigned)ii < (unsigned)X && (unsigned)kk < (unsigned)Z) {
+                        const size_t q = ((size_t)jj * X + ii) * Z + kk;
+                        v = gd[q];
+                        if (a.inflow_before) v += a.inflow[q];
+                    }
+                    acc += (dj ? wy : 1.f - wy) * (di ? wx : 1.f - wx) * (dk ? wz : 1.f - wz) * v;
+                }
+        if (!a.inflow_before) acc += a.inflow[c] * a.dt;
+        a.d_out[(size_t)b * N + c] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) k3_advect(K3Args a) {
+    const int Y = a.Y, X = a.X, Z = a.Z;
+    const int nVy = (Y + 1) * X * Z, nVx = Y * (X + 1) * Z, nVz = Y * X * (Z + 1), N = Y * X * Z;
+    const int b = blockIdx.y;
+    GR r;
+    r.sy = a.svy + (size_t)b * nVy; r.sx = a.svx + (size_t)b * nVx; r.sz = a.svz + (size_t)b * nVz; r.Y = Y; r.X = X; r.Z = Z;
+    const int total = nVy + nVx + nVz + (a.d_out ? N : 0);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        if (e < nVy) advect_point(a, r, b, 0, e / (Z * X), (e / Z) % X, e % Z);
+        else if (e < nVy + nVx) { const int q = e - nVy; advect_point(a, r, b, 1, q / (Z * (X + 1)), (q / Z) % (X + 1), q % Z); }
+        else if (e < nVy + nVx + nVz) { const int q = e - nVy - nVx; advect_point(a, r, b, 2, q / ((Z + 1) * X), (q / (Z + 1)) % X, q % (Z + 1)); }
+        else { const int q = e - nVy - nVx - nVz; advect_point(a, r, b, 3, q / (Z * X), (q / Z) % X, q % Z); }
+    }
+}
+
+// One workgroup = tile (ty, tx) of 8 x 8 cells x the full z column of simulation b.  It owns the y faces j0..j0+7 (the last
+// tile row also face Y), the x faces i0..i0+7 (the last tile column also face X), all z faces and cells of its columns.
+__global__ void __launch_bounds__(256) k3_advect_tile(K3Args a, int tiles_x) {
+    extern __shared__ __align__(16) float lds3[];
+    const int Y = a.Y, X = a.X, Z = a.Z;
+    const int nVy = (Y + 1) * X * Z, nVx = Y * (X + 1) * Z, nVz = Y * X * (Z + 1);
+    const int b = blockIdx.y, ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+    const int jt = ty * T3, it = tx * T3;             // first owned cell
+    TRd r;
+    r.g.sy = a.svy + (size_t)b * nVy; r.g.sx = a.svx + (size_t)b * nVx; r.g.sz = a.svz + (size_t)b * nVz;
+    r.g.Y = Y; r.g.X = X; r.g.Z = Z;
+    r.j0 = jt - HL3; r.i0 = it - HL3;
+    float* ly = lds3;
+    float* lx = ly + (TR + 1) * TR * Z;
+    float* lz = lx + TR * (TR + 1) * Z;
+    r.ly = ly; r.lx = lx; r.lz = lz;
+    // stage the region (rows / columns outside the arrays are skipped: clamped indices never address them)
+    for (int e = threadIdx.x; e < (TR + 1) * TR * Z; e += 256) {
+        const int k = e % Z, ri = (e / Z) % TR, rj = e / (Z * TR), j = r.j0 + rj, i = r.i0 + ri;
+        if ((unsigned)j <= (unsigned)Y && (unsigned)i < (unsigned)X) ly[e] = r.g.y(j, i, k);
+    }
+    for (int e = threadIdx.x; e < TR * (TR + 1) * Z; e += 256) {
+        const int k = e % Z, ri = (e / Z) % (TR + 1), rj = e / (Z * (TR + 1)), j = r.j0 + rj, i = r.i0 + ri;
+        if ((unsigned)j < (unsigned)Y && (unsigned)i <= (unsigned)X) lx[e] = r.g.x(j, i, k);
+    }
+    for (int e = threadIdx.x; e < TR * TR * (Z + 1); e += 256) {
+        const int k = e % (Z + 1), ri = (e / (Z + 1)) % TR, rj = e / ((Z + 1) * TR), j = r.j0 + rj, i = r.i0 + ri;
+        if ((unsigned)j < (unsigned)Y && (unsigned)i < (unsigned)X) lz[e] = r.g.z(j, i, k);
+    }
+    __syncthreads();
+    const int ny = min(T3, Y - jt) + (jt + T3 >= Y ? 1 : 0);      // y-face rows owned
+    const int nx = min(T3, X - it) + (it + T3 >= X ? 1 : 0);      // x-face columns owned
+    const int cy = min(T3, Y - jt), cx = min(T3, X - it);         // cells owned
+    for (int e = threadIdx.x; e < ny * cx * Z; e += 256) advect_point(a, r, b, 0, jt + e / (Z * cx), it + (e / Z) % cx, e % Z);
+    for (int e = threadIdx.x; e < cy * nx * Z; e += 256) advect_point(a, r, b, 1, jt + e / (Z * nx), it + (e / Z) % nx, e % Z);
+    for (int e = threadIdx.x; e < cy * cx * (Z + 1); e += 256) advect_point(a, r, b, 2, jt + e / ((Z + 1) * cx), it + (e / (Z + 1)) % cx, e % (Z + 1));
+    if (a.d_out)
+        for (int e = threadIdx.x; e < cy * cx * Z; e += 256) advect_point(a, r, b, 3, jt + e / (Z * cx), it + (e / Z) % cx, e % Z);
+}
+
+__global__ void __launch_bounds__(256) k3_div(K3Args a) {
+    const int Y = a.Y, X = a.X, Z = a.Z, N = Y * X * Z;
+    const int b = blockIdx.y;
+    const float* vy = a.vy_out + (size_t)b * (Y + 1) * X * Z;
+    const float* vx = a.vx_out + (size_t)b * Y * (X + 1) * Z;
+    const float* vz = a.vz_out + (size_t)b * Y * X * (Z + 1);
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < N; c += gridDim.x * blockDim.x) {
+        const int k = c % Z, i = (c / Z) % X, j = c / (Z * X);
+        const float div = (vy[((size_t)(j + 1) * X + i) * Z + k] - vy[((size_t)j * X + i) * Z + k]) +
+                          (vx[((size_t)j * (X + 1) + i + 1) * Z + k] - vx[((size_t)j * (X + 1) + i) * Z + k]) +
+                          (vz[((size_t)j * X + i) * (Z + 1) + k + 1] - vz[((size_t)j * X + i) * (Z + 1) + k]);
+        a.rhs[(size_t)b * N + c] = -div;           // M p = -div  <=>  A p = div
+    }
+}
+
+__global__ void __launch_bounds__(256) k3_project(K3Args a) {
+    const int Y = a.Y, X = a.X, Z = a.Z, N = Y * X * Z;
+    const int nVy = (Y + 1) * X * Z, nVx = Y * (X + 1) * Z, nVz = Y * X * (Z + 1);
+    const int b = blockIdx.y;
+    const float* P = a.p + (size_t)b * N;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nVy + nVx + nVz; e += gridDim.x * blockDim.x) {
+        if (e < nVy) {
+            const int k = e % Z, i = (e / Z) % X, j = e / (Z * X);
+            float g = 0.f;
+            if (j >= 1 && j <= Y - 1) g = P[((size_t)j * X + i) * Z + k] - P[((size_t)(j - 1) * X + i) * Z + k];
+            else if (a.grad_pad == 1) g = j == 0 ? P[((size_t)i) * Z + k] : -P[((size_t)(Y - 1) * X + i) * Z + k];
+            float* dst = a.vy_out + (size_t)b * nVy + e;
+            const float v = *dst - face_mask<0>(a.active, Y, X, Z, j, i, k) * g;
+            *dst = v;
+            if (a.feat && j < Y) a.feat[((size_t)b * N + e) * 4 + 0] = v * a.fs0;
+        } else if (e < nVy + nVx) {
+            const int q = e - nVy, k = q % Z, i = (q / Z) % (X + 1), j = q / (Z * (X + 1));
+            float g = 0.f;
+            if (i >= 1 && i <= X - 1) g = P[((size_t)j * X + i) * Z + k] - P[((size_t)j * X + i - 1) * Z + k];
+            else if (a.grad_pad == 1) g = i == 0 ? P[((size_t)j * X) * Z + k] : -P[((size_t)j * X + X - 1) * Z + k];
+            float* dst = a.vx_out + (size_t)b * nVx + q;
+            const float v = *dst - face_mask<1>(a.active, Y, X, Z, j, i, k) * g;
+            *dst = v;
+            if (a.feat && i < X) a.feat[((size_t)b * N + ((size_t)j * X + i) * Z + k) * 4 + 1] = v * a.fs1;
+        } else {
+            const int q = e - nVy - nVx, k = q % (Z + 1), i = (q / (Z + 1)) % X, j = q / ((Z + 1) * X);
+            float g = 0.f;
+            if (k >= 1 && k <= Z - 1) g = P[((size_t)j * X + i) * Z + k] - P[((size_t)j * X + i) * Z + k - 1];
+            else if (a.grad_pad == 1) g = k == 0 ? P[((size_t)j * X + i) * Z] : -P[((size_t)j * X + i) * Z + Z - 1];
+            float* dst = a.vz_out + (size_t)b * nVz + q;
+            const float v = *dst - face_mask<2>(a.active, Y, X, Z, j, i, k) * g;
+            *dst = v;
+            if (a.feat && k < Z) {
+                float* f = a.feat + ((size_t)b * N + ((size_t)j * X + i) * Z + k) * 4;
+                f[2] = v * a.fs2;
+                f[3] = a.re[b] * a.fs3;
+            }
+        }
+    }
+}
+
+// T[e] *= il[e]  (1 / eigenvalue of the empty-box Laplacian, natural [m][c][e] order)
+__global__ void __launch_bounds__(256) k3_scale(float* __restrict__ T, const float* __restrict__ il, int N) {
+    const int b = blockIdx.y;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < N; e += gridDim.x * blockDim.x) T[(size_t)b * N + e] *= il[e];
+}
+
+// capacitance correction: xs = g[sidx], c = K' xs (KpT = K' transposed, [SP][SP], zero padded), rhs[sidx] -= c.
+// grid (SP / 64, B), 256 threads: 64 outputs x 4 slices of the sum.
+__global__ void __launch_bounds__(256) k3_capacitance(const float* __restrict__ g, const float* __restrict__ KpT, const int* __restrict__ sidx,
+                                                       float* __restrict__ rhs, int SP, int N) {
+    extern __shared__ float xs[];             // [SP] + [4][64]
+    float* part = xs + SP;
+    const int b = blockIdx.y;
+    const float* gb = g + (size_t)b * N;
+    for (int t = threadIdx.x; t < SP; t += 256) { const int si = sidx[t]; xs[t] = si >= 0 ? gb[si] : 0.f; }
+    __syncthreads();
+    const int s = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    float c = 0.f;
+    for (int q = sl; q < SP; q += 4) c += KpT[(size_t)q * SP + s] * xs[q];
+    part[sl * 64 + (threadIdx.x & 63)] = c;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int si = sidx[s];
+        if (si >= 0) rhs[(size_t)b * N + si] -= part[threadIdx.x] + part[64 + threadIdx.x] + part[128 + threadIdx.x] + part[192 + threadIdx.x];
+    }
+}
+
+// velocity += scale_c * correction[..., c]  (to_staggered + add, karman_train.py:88-90, 424-426, three components): the
+// correction has no value on the last face of each component's own axis
+__global__ void __launch_bounds__(256) k3_correct(const float* __restrict__ out, int CO, float s0, float s1, float s2, float* __restrict__ vy,
+                                                   float* __restrict__ vx, float* __restrict__ vz, int B, int Y, int X, int Z) {
+    const size_t N = (size_t)Y * X * Z, total = (size_t)B * N;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = e / N, c = e - b * N;
+        const int k = (int)(c % Z), i = (int)((c / Z) % X), j = (int)(c / ((size_t)Z * X));
+        const float* o = out + e * CO;
+        vy[b * (size_t)(Y + 1) * X * Z + ((size_t)j * X + i) * Z + k] += s0 * o[0];
+        vx[b * (size_t)Y * (X + 1) * Z + ((size_t)j * (X + 1) + i) * Z + k] += s1 * o[1];
+        vz[b * (size_t)Y * X * (Z + 1) + ((size_t)j * X + i) * (Z + 1) + k] += s2 * o[2];
+    }
+}
+
+// y = src (or 0): small fill / copy without memset / memcpy graph nodes (ROCm 7.2 graph memset defect)
+__global__ void __launch_bounds__(256) k3_fill(float* __restrict__ y, const float* __restrict__ src, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) y[e] = src ? src[e] : 0.f;
+}
+
+int grid_for(size_t n) { const size_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
+
+}  // namespace
+
+extern "C" int32_t sol_abi_size_karman3d(void) { return (int32_t)sizeof(sol_karman3d_cfg); }
+
+extern "C" size_t sol_karman3d_step_workspace_bytes(const sol_karman3d_cfg* c) {
+    if (!c) return 0;
+    const size_t B = c->B, Y = c->Y, X = c->X, Z = c->Z;
+    // three diffused components + rhs + two transform buffers
+    const size_t floats = B * ((Y + 1) * X * Z + Y * (X + 1) * Z + Y * X * (Z + 1) + 3 * Y * X * Z) + 256;
+    return floats * sizeof(float);
+}
+
+extern "C" int sol_karman3d_step_fwd(const sol_karman3d_cfg* c, void* stream,
+                                     const float* d_in, const float* vy_in, const float* vx_in, const float* vz_in,
+                                     const float* re, const float* active, const float* inflow,
+                                     const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
+                                     float* d_out, float* vy_out, float* vx_out, float* vz_out,
+                                     float* feat_out, const float* feat_scale, const int32_t* direct_header_host,
+                                     void* workspace, size_t workspace_bytes) {
+    SOL_REQUIRE(c != nullptr, "cfg is NULL");
+    SOL_REQUIRE(c->B >= 1 && c->Y >= 8 && c->X >= 8 && c->Z >= 8 && c->B <= 65535, "sol_karman3d_step_fwd: B >= 1, Y, X, Z >= 8 (got %d, %d, %d, %d)", c->B, c->Y, c->X, c->Z);
+    SOL_REQUIRE((size_t)(c->Y + 1) * (c->X + 1) * (c->Z + 1) * 3 < ((size_t)1 << 31), "sol_karman3d_step_fwd: grid too large for 32-bit face indices");
+    SOL_REQUIRE(vy_in && vx_in && vz_in && re && active && velBCy && velBCyMask && vy_out && vx_out && vz_out && workspace, "sol_karman3d_step_fwd: NULL pointer argument");
+    SOL_REQUIRE((d_in && inflow) || !d_out, "density output requested without d_in / inflow");
+    SOL_REQUIRE(!feat_out || feat_scale, "feat_out requires feat_scale");
+    SOL_REQUIRE(c->direct && c->direct_n > 0, "sol_karman3d_step_fwd needs the direct-solver blob (cfg.direct, precond3d.direct_solver_blob3d)");
+    SOL_REQUIRE(workspace_bytes >= sol_karman3d_step_workspace_bytes(c), "workspace too small");
+    SOL_REQUIRE(vy_in != vy_out && vx_in != vx_out && vz_in != vz_out && (d_in != d_out || !d_out), "sol_karman3d_step_fwd: outputs must not alias the inputs");
+    SOL_REQUIRE(direct_header_host && direct_header_host[0] == FD3_MAGIC, "sol_karman3d_step_fwd: direct_header_host must be the first 16 words of the blob (host copy)");
+    const int B = c->B, Y = c->Y, X = c->X, Z = c->Z, N = Y * X * Z;
+    const int nS = direct_header_host[4], SP = direct_header_host[5];
+    SOL_REQUIRE(direct_header_host[1] == Y && direct_header_host[2] == X && direct_header_host[3] == Z, "direct-solver blob is for a %dx%dx%d grid, cfg is %dx%dx%d",
+                direct_header_host[1], direct_header_host[2], direct_header_host[3], Y, X, Z);
+    SOL_REQUIRE(nS >= 0 && SP >= nS && SP % 64 == 0 && SP <= 8192, "direct-solver blob header is inconsistent (nS %d, SP %d)", nS, SP);
+    SOL_REQUIRE((size_t)c->direct_n == (size_t)FD3_HEADER + (size_t)Y * Y + (size_t)X * X + (size_t)Z * Z + (size_t)N + (size_t)SP * SP + SP,
+                "direct-solver blob has %d words, expected %zu", c->direct_n,
+                (size_t)FD3_HEADER + (size_t)Y * Y + (size_t)X * X + (size_t)Z * Z + (size_t)N + (size_t)SP * SP + SP);
+    hipStream_t s = (hipStream_t)stream;
+    const float* Qy = c->direct + FD3_HEADER;
+    const float* Qx = Qy + (size_t)Y * Y;
+    const float* Qz = Qx + (size_t)X * X;
+    const float* il = Qz + (size_t)Z * Z;
+    const float* KpT = il + (size_t)N;
+    const int* sidx = reinterpret_cast<const int*>(KpT + (size_t)SP * SP);
+    float* w = static_cast<float*>(workspace);
+    const size_t nVy = (size_t)(Y + 1) * X * Z, nVx = (size_t)Y * (X + 1) * Z, nVz = (size_t)Y * X * (Z + 1);
+    float* svy = w; w += B * nVy;
+    float* svx = w; w += B * nVx;
+    float* svz = w; w += B * nVz;
+    float* R = w; w += (size_t)B * N;
+    float* T1 = w; w += (size_t)B * N;
+    float* T2 = w; w += (size_t)B * N;
+
+    K3Args a{};
+    a.B = B; a.Y = Y; a.X = X; a.Z = Z; a.dtdx = c->dt / c->dx; a.dt = c->dt; a.adt = c->dt * c->res * c->res;
+    a.grad_pad = c->grad_pad; a.inflow_before = c->inflow_before;
+    a.d_in = d_in; a.vy_in = vy_in; a.vx_in = vx_in; a.vz_in = vz_in; a.re = re; a.active = active; a.inflow = inflow;
+    a.bcv = velBCy; a.bcm = velBCyMask; a.bc_stride = bc_batch_stride;
+    a.d_out = d_out; a.vy_out = vy_out; a.vx_out = vx_out; a.vz_out = vz_out; a.svy = svy; a.svx = svx; a.svz = svz; a.rhs = R; a.feat = feat_out; a.p = T2;
+    if (feat_scale) { a.fs0 = feat_scale[0]; a.fs1 = feat_scale[1]; a.fs2 = feat_scale[2]; a.fs3 = feat_scale[3]; }
+    const size_t faces = nVy + nVx + nVz;
+    SOL_LAUNCH(k3_diffuse, dim3(grid_for(faces), B), dim3(256), 0, s, a);
+    const size_t tile_lds = ((size_t)(TR + 1) * TR * Z + (size_t)TR * (TR + 1) * Z + (size_t)TR * TR * (Z + 1)) * sizeof(float);
+    if (sol_opt().k3d_tile && tile_lds <= 160 * 1024) {
+        static int rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k3_advect_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
+        SOL_REQUIRE(rc == 0, "hipFuncSetAttribute(k3_advect_tile) failed");
+        const int tiles_y = (Y + T3 - 1) / T3, tiles_x = (X + T3 - 1) / T3;
+        SOL_LAUNCH(k3_advect_tile, dim3(tiles_y * tiles_x, B), dim3(256), tile_lds, s, a, tiles_x);
+    } else {
+        SOL_LAUNCH(k3_advect, dim3(grid_for(faces + N), B), dim3(256), 0, s, a);
+    }
+    SOL_LAUNCH(k3_div, dim3(grid_for(N), B), dim3(256), 0, s, a);
+    SOL_LAUNCH_CHECK();
+
+    // ---- direct pressure solve.  One sine transform of the whole batch along each axis = one batched GEMM:
+    //   z: [(b,j,i)] x Z times Qz;   x: per (b, j): Qx times [X x Z];   y: per b: Qy times [Y x (X Z)]
+    auto tz = [&](const float* in, float* out) { return sol_gemm_f32(s, 1, in, Z, 0, Qz, Z, 0, out, Z, 0, B * Y * X, Z, Z, 0); };
+    auto tx = [&](const float* in, float* out) { return sol_gemm_f32(s, B * Y, Qx, X, 0, in, Z, (long)X * Z, out, Z, (long)X * Z, X, Z, X, 0); };
+    auto ty = [&](const float* in, float* out) { return sol_gemm_f32(s, B, Qy, Y, 0, in, X * Z, (long)N, out, X * Z, (long)N, Y, X * Z, Y, 0); };
+    auto G = [&](float* src, float* t1, float* t2) -> int {     // t2 = G src  (src is preserved)
+        if (int e = tz(src, t1)) return e;
+        if (int e = tx(t1, t2)) return e;
+        if (int e = ty(t2, t1)) return e;
+        SOL_LAUNCH(k3_scale, dim3(grid_for(N), B), dim3(256), 0, s, t1, il, N);
+        if (int e = ty(t1, t2)) return e;
+        if (int e = tx(t2, t1)) return e;
+        return tz(t1, t2);
+    };
+    if (int e = G(R, T1, T2)) return e;
+    if (nS > 0) {
+        SOL_LAUNCH(k3_capacitance, dim3(SP / 64, B), dim3(256), (size_t)(SP + 256) * sizeof(float), s, T2, KpT, sidx, R, SP, N);
+        if (int e = G(R, T1, T2)) return e;
+    }
+    SOL_LAUNCH(k3_project, dim3(grid_for(faces), B), dim3(256), 0, s, a);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
+extern "C" int sol_karman3d_correct(void* stream, const float* out, int32_t cout, float s0, float s1, float s2,
+                                    float* vy, float* vx, float* vz, int32_t B, int32_t Y, int32_t X, int32_t Z) {
+    SOL_REQUIRE(out && vy && vx && vz && cout >= 3 && B >= 1 && Y >= 1 && X >= 1 && Z >= 1, "sol_karman3d_correct: bad arguments");
+    SOL_LAUNCH(k3_correct, dim3(grid_for((size_t)B * Y * X * Z)), dim3(256), 0, (hipStream_t)stream, out, cout, s0, s1, s2, vy, vx, vz, B, Y, X, Z);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// 5 x 5 x 5 SAME convolution, NDHWC (D = y, H = x, W = z), as FIVE passes of the 2-D kernels of conv5x5(_sb).hip over the
+// (x, z) planes: y[d] = sum_kd conv2d(x[d + kd - 2], w[kd]).  The running sum lives in y (fp32, read back as the 2-D
+// kernels' residual operand); the centre slice runs LAST over all B*D planes and carries bias, activation and the absmax
+// publish.  Same arithmetic per product as the 2-D layers (split fp16 / bf16 MFMA or fp32 MFMA, option conv_precision).
+// ------------------------------------------------------------------------------------------------------------------------
+extern "C" size_t sol_conv3d_packed_floats(int32_t cin, int32_t cout) { return 5 * align_up(sol_conv5x5_packed_floats(cin, cout, SOL_CONV_FWD), 64); }
+
+extern "C" int sol_conv3d_pack(void* stream, const float* w_dhwio, int32_t cin, int32_t cout, float* packed) {
+    SOL_REQUIRE(w_dhwio && packed, "sol_conv3d_pack: NULL pointer");
+    const size_t per = align_up(sol_conv5x5_packed_floats(cin, cout, SOL_CONV_FWD), 64);
+    for (int kd = 0; kd < 5; ++kd)
+        if (int e = sol_conv5x5_pack(stream, w_dhwio + (size_t)kd * 25 * cin * cout, cin, cout, SOL_CONV_FWD, packed + kd * per)) return e;
+    return SOL_OK;
+}
+
+extern "C" int sol_conv3d(void* stream, const float* x, const float* packed, const float* bias, const float* residual, float* y,
+                          int32_t B, int32_t D, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t epilogue, float slope,
+                          const uint32_t* x_absmax, uint32_t* y_absmax) {
+    SOL_REQUIRE(x && packed && y && x != y, "sol_conv3d: NULL pointer / in-place call");
+    SOL_REQUIRE(B >= 1 && D >= 3, "sol_conv3d: B >= 1, D >= 3 (got %d, %d)", B, D);
+    SOL_REQUIRE(epilogue == SOL_EPI_NONE || epilogue == SOL_EPI_LRELU, "sol_conv3d: epilogue must be SOL_EPI_NONE or SOL_EPI_LRELU");
+    hipStream_t s = (hipStream_t)stream;
+    const int cin_k = cin <= 4 ? 4 : 32;
+    SOL_REQUIRE(cin == cin_k, "sol_conv3d: input channels must be 4 (zero padded) or 32 (got %d)", cin);
+    const size_t per = align_up(sol_conv5x5_packed_floats(cin, cout, SOL_CONV_FWD), 64);
+    const size_t pin = (size_t)H * W * cin, pout = (size_t)H * W * cout;      // floats per plane
+    for (int b = 0; b < B; ++b) {
+        const float* xb = x + (size_t)b * D * pin;
+        float* yb = y + (size_t)b * D * pout;
+        const float* rb = residual ? residual + (size_t)b * D * pout : nullptr;
+        // planes 0, 1 receive nothing from slice kd = 0: they start from the residual (or zero)
+        SOL_LAUNCH(k3_fill, dim3(grid_for(2 * pout)), dim3(256), 0, s, yb, rb, 2 * pout);
+        SOL_LAUNCH_CHECK();
+        // kd = 0: y[2:D] = conv(x[0:D-2], w0) (+ residual[2:D])
+        if (int e = sol_conv5x5_scaled(stream, xb, packed, nullptr, rb ? rb + 2 * pout : nullptr, nullptr, yb + 2 * pout, D - 2, H, W, cin, cout, SOL_EPI_NONE, slope, x_absmax, nullptr)) return e;
+        // kd = 1: y[1:D] += conv(x[0:D-1], w1)
+        if (int e = sol_conv5x5_scaled(stream, xb, packed + per, nullptr, yb + pout, nullptr, yb + pout, D - 1, H, W, cin, cout, SOL_EPI_NONE, slope, x_absmax, nullptr)) return e;
+        // kd = 3: y[0:D-1] += conv(x[1:D], w3)
+        if (int e = sol_conv5x5_scaled(stream, xb + pin, packed + 3 * per, nullptr, yb, nullptr, yb, D - 1, H, W, cin, cout, SOL_EPI_NONE, slope, x_absmax, nullptr)) return e;
+        // kd = 4: y[0:D-2] += conv(x[2:D], w4)
+        if (int e = sol_conv5x5_scaled(stream, xb + 2 * pin, packed + 4 * per, nullptr, yb, nullptr, yb, D - 2, H, W, cin, cout, SOL_EPI_NONE, slope, x_absmax, nullptr)) return e;
+    }
+    // kd = 2 (centre): every plane of the batch, with bias / activation / absmax publish
+    return sol_conv5x5_scaled(stream, x, packed + 2 * per, bias, y, nullptr, y, B * D, H, W, cin, cout, epilogue, slope, x_absmax, y_absmax);
+}

@@ -262,6 +262,12 @@ int gemm(hipStream_t s, int batch, const float* A, int lda, long sA, const float
 
 }  // namespace
 
+// shared with karman3d.hip (the sine transforms of the 3-D direct solve are batched products of this kind)
+int sol_gemm_f32(hipStream_t s, int batch, const float* A, int lda, long sA, const float* Bm, int ldb, long sB, float* C, int ldc, long sC,
+                 int M, int N, int K, int accumulate) {
+    return gemm(s, batch, A, lda, sA, Bm, ldb, sB, C, ldc, sC, M, N, K, accumulate);
+}
+
 extern "C" size_t sol_karman_step_large_workspace_bytes(const sol_karman_cfg* c) {
     if (!c) return 0;
     const size_t B = c->B, Y = c->Y, X = c->X;

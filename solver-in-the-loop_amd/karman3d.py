@@ -1,0 +1,237 @@
+"""karman-3d (BASELINE.json configs[4]): host surface of the 3-D forward path.
+
+The reference has no 3-D code (/root/reference/README.md:37-38).  This module is the dimension-generic twin of karman.py /
+model.py / trainer.SolRollout: the same scene (karman-2d/karman_train.py:166-171, 363-373) with a third axis, the same step
+(`KarmanFlow.step`, :173-185), `model_mars_moon` (:101-138) with Conv3D(5) layers over 4 input channels (three velocity
+components + Re) and 3 output channels, and the roll-out loop of karman_apply.py:138-158.  Forward only in this version.
+
+Layout: density [B,Y,X,Z], v_y [B,Y+1,X,Z], v_x [B,Y,X+1,Z], v_z [B,Y,X,Z+1] (y = flow direction, z contiguous); CNN
+tensors [B,Y,X,Z,C].  Everything calls libsol_hip.so (csrc/karman3d.hip); there is no CPU implementation.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Karman3DCfg, check, ptr, stream
+
+EPI_NONE, EPI_LRELU = 0, 1
+
+
+def scene_arrays3d(Y, X, Z, length=100.0, obstacle="sphere"):
+    """(active, inflow) [Y,X,Z] float64: Inflow(box[5:10, 25:75, 25:75]) and Obstacle(Sphere([50, 50, 50], 10)) -- the
+    dimension-generic form of karman_train.py:169-170 -- on the domain box[0:2*len, 0:len, 0:len] (:363).  Cell centres
+    inside count (inclusive box bounds, dist^2 <= r^2), as in the 2-D scene."""
+    if obstacle != "sphere":
+        raise NotImplementedError("the HIP path takes window-sized obstacles (sphere); obstacle=%r is an oracle-only option" % (obstacle,))
+    if not (Y == 2 * X and Z == X):
+        raise ValueError("karman-3d domain is box[0:2*len, 0:len, 0:len]: resolution must be (2*res, res, res)")
+    dx = length / X
+    c = [(np.arange(n) + 0.5) * dx for n in (Y, X, Z)]
+    YC, XC, ZC = np.meshgrid(*c, indexing="ij")
+    s = length / 100.0
+    inflow = ((YC >= 5 * s) & (YC <= 10 * s) & (XC >= 25 * s) & (XC <= 75 * s) & (ZC >= 25 * s) & (ZC <= 75 * s)).astype(np.float64)
+    obst = (((YC - 50 * s) ** 2 + (XC - 50 * s) ** 2 + (ZC - 50 * s) ** 2) <= (10 * s) ** 2).astype(np.float64)
+    return 1.0 - obst, inflow
+
+
+def velocity_bc_masks3d(Y, X, Z):
+    """velBCy / velBCyMask of karman_train.py:366-373 with the third axis: the two inflow-side planes and the four lateral
+    walls of the flow component, [Y+1,X,Z], values 1."""
+    vn = np.zeros((Y + 1, X, Z))
+    vn[0:2, :, :] = 1.0
+    vn[:, 0, :] = 1.0
+    vn[:, -1, :] = 1.0
+    vn[:, :, 0] = 1.0
+    vn[:, :, -1] = 1.0
+    return vn, np.copy(vn)
+
+
+class Scene3D:
+    """Device-resident constants of a karman-3d scene: masks + the direct pressure-solver blob (precond3d)."""
+
+    def __init__(self, Y, X, Z, length=100.0, device="cuda", velBCy=None, velBCyMask=None):
+        from .precond3d import direct_solver_blob3d
+        self.Y, self.X, self.Z = Y, X, Z
+        self.dx = length / X
+        active, inflow = scene_arrays3d(Y, X, Z, length)
+        bcv, bcm = velocity_bc_masks3d(Y, X, Z)
+        if velBCy is not None:
+            bcv, bcm = np.asarray(velBCy, dtype=np.float64), np.asarray(velBCyMask, dtype=np.float64)
+        n = (Y + 1) * X * Z
+        if bcv.size % n or bcv.size != bcm.size:
+            raise ValueError("velBCy / velBCyMask must be [Y+1,X,Z] or [B,Y+1,X,Z]")
+        self.bc_stride = 0 if bcv.size == n else n
+        self.active_np = active
+        self.active = _lib.f32(active, device)
+        self.inflow = _lib.f32(inflow, device)
+        self.velBCy = _lib.f32(bcv, device)
+        self.velBCyMask = _lib.f32(bcm, device)
+        blob = direct_solver_blob3d(active)
+        if blob is None:
+            raise ValueError("the direct pressure solver does not support this scene (%dx%dx%d)" % (Y, X, Z))
+        self.direct = torch.from_numpy(blob).to(device)
+        self.direct_header = np.ascontiguousarray(blob[:16].view(np.int32))
+
+
+class Karman3DFlow:
+    """`simulator.step(...)` of the 3-D scene: one sol_karman3d_step_fwd."""
+
+    def __init__(self, scene, batch_size, dt=1.0, res=None, grad_pad="replicate", inflow_order="after"):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.scene, self.B = scene, batch_size
+        s = scene
+        self.cfg = Karman3DCfg(batch_size, s.Y, s.X, s.Z, float(s.dx), float(dt), float(s.X if res is None else res),
+                               {"replicate": 0, "dirichlet0": 1}[grad_pad], {"after": 0, "before": 1}[inflow_order],
+                               s.direct.numel(), s.direct.data_ptr())
+        nbytes = self.lib.sol_karman3d_step_workspace_bytes(C.byref(self.cfg))
+        self.workspace = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=s.active.device)
+        self.workspace_bytes = nbytes
+
+    def step(self, d, vy, vx, vz, re, feat_out=None, feat_scale=None):
+        """(d, vy, vx, vz) -> new tensors after one solver step; feat_out [B,Y,X,Z,4] (optional) receives the scaled features."""
+        s, B = self.scene, self.B
+        Y, X, Z = s.Y, s.X, s.Z
+        d, vy, vx, vz, re = (_lib.f32(t) for t in (d, vy, vx, vz, re))
+        assert d.shape == (B, Y, X, Z) and vy.shape == (B, Y + 1, X, Z) and vx.shape == (B, Y, X + 1, Z) and vz.shape == (B, Y, X, Z + 1)
+        assert re.shape == (B,)
+        out = [torch.empty_like(t) for t in (d, vy, vx, vz)]
+        fs = None
+        if feat_out is not None:
+            assert feat_out.shape == (B, Y, X, Z, 4) and feat_out.is_contiguous()
+            fs = (C.c_float * 4)(*[float(v) for v in feat_scale])
+        check(self.lib.sol_karman3d_step_fwd(C.byref(self.cfg), stream(), ptr(d), ptr(vy), ptr(vx), ptr(vz), ptr(re),
+                                             ptr(s.active), ptr(s.inflow), ptr(s.velBCy), ptr(s.velBCyMask), s.bc_stride,
+                                             ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(feat_out), fs,
+                                             s.direct_header.ctypes.data_as(C.c_void_p), ptr(self.workspace), self.workspace_bytes))
+        return tuple(out)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# model_mars_moon with Conv3D(5) layers
+# ---------------------------------------------------------------------------------------------------------------------
+class MarsMoon3D:
+    """12 Conv3D(5, padding='same') layers, 32 features, five residual blocks (karman_train.py:101-138 in 3-D): 4 -> 32,
+    10 x 32 -> 32, 32 -> 3; 1 048 675 parameters in ONE flat fp32 buffer in Keras get_weights() order (kernels DHWIO).
+    Keras defaults: glorot_uniform kernels, zero biases, LeakyReLU(alpha=0.3)."""
+    name = "mars_moon3d"
+    slope = 0.3
+
+    def __init__(self, cin=4, cout=3, seed=0, device="cuda"):
+        self.cin, self.cout = cin, cout
+        chans = [cin] + [32] * 11 + [cout]
+        self.chans = chans
+        self.shapes = []
+        for l in range(12):
+            self.shapes += [(5, 5, 5, chans[l], chans[l + 1]), (chans[l + 1],)]
+        self.offsets = np.concatenate([[0], np.cumsum([int(np.prod(s)) for s in self.shapes])]).astype(np.int64)
+        gen = torch.Generator().manual_seed(seed)
+        parts = []
+        for s in self.shapes:
+            if len(s) == 5:
+                lim = math.sqrt(6.0 / (125 * (s[3] + s[4])))
+                parts.append(((torch.rand(s, generator=gen, dtype=torch.float64) * 2 - 1) * lim).reshape(-1))
+            else:
+                parts.append(torch.zeros(s, dtype=torch.float64))
+        self.params = torch.cat(parts).to(device=device, dtype=torch.float32).contiguous()
+        self._packed = None
+
+    @property
+    def n_params(self):
+        return int(self.offsets[-1])
+
+    def tensors(self):
+        return [self.params[self.offsets[k]:self.offsets[k + 1]].reshape(self.shapes[k]) for k in range(len(self.shapes))]
+
+    def get_weights(self):
+        return [t.detach().cpu().numpy() for t in self.tensors()]
+
+    def set_weights(self, weights):
+        flat = np.concatenate([np.asarray(w, dtype=np.float32).reshape(-1) for w in weights])
+        assert flat.size == self.n_params, "weight list does not match %s" % self.name
+        self.params.copy_(torch.as_tensor(flat, device=self.params.device))
+        self._packed = None
+
+    def pack(self):
+        """(packed weights, padded biases) per layer in the layout the conv kernels consume; cached until set_weights."""
+        if self._packed is None:
+            lib = _lib.load()
+            t = self.tensors()
+            self._packed = []
+            for l in range(12):
+                cin, cout = self.chans[l], self.chans[l + 1]
+                cin_k = 4 if cin <= 4 else 32
+                w = t[2 * l]
+                if cin_k != cin:
+                    w = torch.nn.functional.pad(w, (0, 0, 0, cin_k - cin))
+                w = w.contiguous()
+                buf = torch.empty(lib.sol_conv3d_packed_floats(cin_k, cout), dtype=torch.float32, device=w.device)
+                check(lib.sol_conv3d_pack(stream(), ptr(w), cin_k, cout, ptr(buf)))
+                self._packed.append((buf, t[2 * l + 1].contiguous(), cin_k, cout))
+        return self._packed
+
+
+def conv3d(x, packed, bias, residual, cout, lrelu, slope, x_absmax=None, y_absmax=None, out=None):
+    """sol_conv3d: x [B,Y,X,Z,cin] -> [B,Y,X,Z,cout]."""
+    lib = _lib.load()
+    B, D, H, W, cin = x.shape
+    y = out if out is not None else torch.empty(B, D, H, W, cout, dtype=torch.float32, device=x.device)
+    check(lib.sol_conv3d(stream(), ptr(x), ptr(packed), ptr(bias), ptr(residual), ptr(y), B, D, H, W, cin, cout,
+                         EPI_LRELU if lrelu else EPI_NONE, float(slope), ptr(x_absmax), ptr(y_absmax)))
+    return y
+
+
+class Karman3DRollout:
+    """No-grad roll-out: nsteps x [solver step -> features / std -> CNN -> velocity += std * correction]
+    (karman_apply.py:138-158 / the forward half of karman_train.py:397-426, three components)."""
+
+    def __init__(self, net, scene, B, std_v, std_re, dt=1.0, res=None, conv_precision="split", **solver):
+        from .trainer import _conv_precision_code
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.net, self.scene, self.B = net, scene, B
+        self.sim = Karman3DFlow(scene, B, dt=dt, res=res, **solver)
+        self.std_v = tuple(float(v) for v in std_v)
+        self.feat_scale = [1.0 / self.std_v[0], 1.0 / self.std_v[1], 1.0 / self.std_v[2], 1.0 / float(std_re)]
+        self.conv_precision = _conv_precision_code(conv_precision)
+        dev = scene.active.device
+        Y, X, Z = scene.Y, scene.X, scene.Z
+        f = lambda c: torch.empty(B, Y, X, Z, c, dtype=torch.float32, device=dev)
+        self.feat = f(4)
+        self.h = [f(32), f(32), f(32)]          # block input / intermediate / block output, rotated
+        self.out = f(net.cout)
+        self.amax = torch.zeros(12, 256, dtype=torch.int32, device=dev)      # absmax slots of the 32-channel activations
+
+    def correction(self):
+        """self.feat -> self.out (the network), publishing / consuming the per-tensor absmax of every 32-channel tensor."""
+        from .trainer import _apply_conv_precision
+        _apply_conv_precision(self.conv_precision)
+        pk = self.net.pack()
+        sl = self.net.slope
+        self.amax.zero_()
+        am = lambda k: self.amax[k]
+        h, a, n = self.h
+        conv3d(self.feat, pk[0][0], pk[0][1], None, 32, True, sl, None, am(0), out=h)
+        for k in range(5):
+            conv3d(h, pk[1 + 2 * k][0], pk[1 + 2 * k][1], None, 32, True, sl, am(2 * k), am(2 * k + 1), out=a)
+            conv3d(a, pk[2 + 2 * k][0], pk[2 + 2 * k][1], h, 32, True, sl, am(2 * k + 1), am(2 * k + 2), out=n)
+            h, n = n, h
+        conv3d(h, pk[11][0], pk[11][1], None, self.net.cout, False, sl, am(10), None, out=self.out)
+        return self.out
+
+    def step(self, d, vy, vx, vz, re):
+        d, vy, vx, vz = self.sim.step(d, vy, vx, vz, re, feat_out=self.feat, feat_scale=self.feat_scale)
+        out = self.correction()
+        s = self.scene
+        check(self.lib.sol_karman3d_correct(stream(), ptr(out), self.net.cout, self.std_v[0], self.std_v[1], self.std_v[2],
+                                            ptr(vy), ptr(vx), ptr(vz), self.B, s.Y, s.X, s.Z))
+        return d, vy, vx, vz
+
+    def run(self, d, vy, vx, vz, re, nsteps):
+        re = _lib.f32(re)
+        for _ in range(nsteps):
+            d, vy, vx, vz = self.step(d, vy, vx, vz, re)
+        return d, vy, vx, vz

@@ -14,6 +14,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
 import sol_oracle as o  # noqa: E402
+import sol_oracle3d as o3  # noqa: E402
 
 torch.set_default_dtype(torch.float64)
 
@@ -116,7 +117,46 @@ def sol32_case(B=6, Y=128, X=64, ms=32, adam_steps=3, lr=1e-4):
     return out
 
 
+def k3d_case(B=2, Y=32, X=16, Z=16, nroll=2):
+    """karman-3d (BASELINE configs[4]) at 32 x 16 x 16: one solver step, the network on that step's features, and a
+    2-step roll-out (solver + correction), all from oracle/sol_oracle3d.py.  Weights = init_params(0) with seeded biases
+    and the output layer scaled by 0.05 (an untrained Glorot corrector fed back blows the roll-out up); they are NOT
+    stored (4 MB): the tests regenerate them with `k3d_params()` below.  The roll-out state is stored subsampled."""
+    g = o3.geometry(Y, X, Z)
+    d, v = o3.synthetic_state(B, Y, X, Z, 77)
+    d, v = r32(d), tuple(r32(c) for c in v)
+    re = torch.tensor(o3.RE_TRAIN[:B])
+    params = k3d_params()
+    std_v = (0.2, 0.25, 0.3)
+    with torch.no_grad():
+        d1, v1 = o3.karman3d_step(d, v, re, g)
+        feat = o3.to_feature(v1, re) / torch.tensor(list(std_v) + [o3.STD_RE])
+        net_out = o3.mars_moon3d(params, feat)
+        states = o3.rollout(params, d, v, re, g, std_v, o3.STD_RE, nroll)
+    n = lambda t: t.detach().numpy().astype(np.float32)
+    dr, vr = states[-1]
+    sub = lambda t: n(t).ravel()[::4]
+    return dict(d=n(d), vy=n(v[0]), vx=n(v[1]), vz=n(v[2]), re=n(re), std_v=np.array(std_v), std_re=o3.STD_RE,
+                d_out=n(d1), vy_out=n(v1[0]), vx_out=n(v1[1]), vz_out=n(v1[2]), net_out=n(net_out), nroll=nroll,
+                roll_norms=np.array([float(t.norm()) for t in (dr,) + tuple(vr)]),
+                roll_d_sub4=sub(dr), roll_vy_sub4=sub(vr[0]), roll_vx_sub4=sub(vr[1]), roll_vz_sub4=sub(vr[2]))
+
+
+def k3d_params(last_layer_scale=0.05):
+    ps = [r32(p) for p in o3.init_params(0)]
+    gen = torch.Generator().manual_seed(99)
+    for k, p in enumerate(ps):
+        if p.dim() == 1:
+            ps[k] = r32(0.01 * torch.randn(p.shape, generator=gen))
+    ps[22] = r32(ps[22] * last_layer_scale)
+    return ps
+
+
 if __name__ == "__main__":
+    if "--k3d" in sys.argv:
+        np.savez_compressed(os.path.join(HERE, "karman3d_32x16x16.npz"), **k3d_case())
+        print("karman3d_32x16x16.npz", os.path.getsize(os.path.join(HERE, "karman3d_32x16x16.npz")) // 1024, "KB")
+        sys.exit(0)
     if "--sol32" in sys.argv:          # the 6-minute fixture is generated on request only
         np.savez_compressed(os.path.join(HERE, "train_128x64_sol32.npz"), **sol32_case())
         sys.exit(0)

@@ -1,0 +1,180 @@
+"""GPU parity tests of the karman-3d forward path (pytest -m gpu): csrc/karman3d.hip through the C ABI against
+oracle/sol_oracle3d.py (float64) and the committed fixture tests/golden/karman3d_32x16x16.npz.
+Tolerance: <= 1e-5 relative L2 on velocity / density fields (north star), fp32 kernels vs the float64 oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import sol_amd
+import sol_oracle3d as o
+from sol_amd import karman3d as k3
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL_FIELD = 1e-5
+
+
+def rel(a, b):
+    a = torch.as_tensor(np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a), dtype=torch.float64)
+    b = torch.as_tensor(np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b), dtype=torch.float64)
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def f32(t):
+    return torch.as_tensor(np.asarray(t), dtype=torch.float32).to(DEV).contiguous()
+
+
+@pytest.fixture(scope="module")
+def fixture3d(golden_dir):
+    return np.load(os.path.join(golden_dir, "karman3d_32x16x16.npz"))
+
+
+@pytest.fixture(scope="module")
+def scene_small():
+    return k3.Scene3D(32, 16, 16, device=DEV)
+
+
+@pytest.mark.parametrize("tile", [1, 0])
+def test_karman3d_step_against_golden(fixture3d, scene_small, tile):
+    z = fixture3d
+    B = z["d"].shape[0]
+    sol_amd._lib.set_option("k3d_tile", tile)
+    try:
+        sim = k3.Karman3DFlow(scene_small, B)
+        feat = torch.zeros(B, 32, 16, 16, 4, device=DEV)
+        fs = [1 / 0.2, 1 / 0.25, 1 / 0.3, 1 / float(z["std_re"])]
+        d, vy, vx, vz = sim.step(f32(z["d"]), f32(z["vy"]), f32(z["vx"]), f32(z["vz"]), f32(z["re"]), feat_out=feat, feat_scale=fs)
+        torch.cuda.synchronize()
+    finally:
+        sol_amd._lib.set_option("k3d_tile", 1)
+    errs = [rel(a, z[k]) for a, k in ((d, "d_out"), (vy, "vy_out"), (vx, "vx_out"), (vz, "vz_out"))]
+    assert max(errs) < TOL_FIELD, errs
+    # fused to_feature: the three components at the low faces + Re, scaled
+    ref = torch.stack([torch.as_tensor(z["vy_out"])[:, :32] * fs[0], torch.as_tensor(z["vx_out"])[:, :, :16] * fs[1],
+                       torch.as_tensor(z["vz_out"])[..., :16] * fs[2],
+                       torch.as_tensor(z["re"]).reshape(B, 1, 1, 1).expand(B, 32, 16, 16) * fs[3]], dim=-1)
+    assert rel(feat, ref) < TOL_FIELD
+
+
+def test_karman3d_tile_and_global_advection_agree_bitwise(fixture3d, scene_small):
+    z = fixture3d
+    outs = []
+    for tile in (1, 0):
+        sol_amd._lib.set_option("k3d_tile", tile)
+        sim = k3.Karman3DFlow(scene_small, 2)
+        outs.append(sim.step(f32(z["d"]), f32(z["vy"]), f32(z["vx"]), f32(z["vz"]), f32(z["re"])))
+    sol_amd._lib.set_option("k3d_tile", 1)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)          # same arithmetic, LDS vs global operands
+
+
+def test_karman3d_step_variants_and_large_cfl_against_oracle():
+    """dirichlet0 pressure-gradient padding, inflow before advection, dt = 2 with |v| ~ 1.3 cells per step (samples leave
+    the LDS halo and take the global fallback)."""
+    B, Y, X, Z = 2, 16, 8, 8
+    g = o.geometry(Y, X, Z)
+    d, v = o.synthetic_state(B, Y, X, Z, 5)
+    v = (v[0] * 4.0, v[1] * 6.0, v[2] * 6.0)            # dx = 12.5: ~0.4 cells per unit time along y, up to ~1 across
+    re = torch.tensor(o.RE_TRAIN[:B])
+    sc = k3.Scene3D(Y, X, Z, device=DEV)
+    for kw in (dict(grad_pad="dirichlet0", inflow_order="before"), dict()):
+        with torch.no_grad():
+            dr, vr = o.karman3d_step(d, v, re, g, dt=2.0, **kw)
+        sim = k3.Karman3DFlow(sc, B, dt=2.0, **kw)
+        out = sim.step(f32(d), f32(v[0]), f32(v[1]), f32(v[2]), f32(re))
+        errs = [rel(a, b) for a, b in zip(out, (dr,) + tuple(vr))]
+        assert max(errs) < TOL_FIELD, (kw, errs)
+
+
+def _oracle_conv(x, w, b, res, lrelu, slope=0.3):
+    y = o.conv3d_same(x, w, b)
+    if res is not None:
+        y = y + res
+    return torch.nn.functional.leaky_relu(y, slope) if lrelu else y
+
+
+@pytest.mark.parametrize("shape,cin,cout,res,lrelu", [
+    ((1, 6, 16, 16), 4, 32, False, True),          # first layer (fp32 MFMA thin kernel), W | 64
+    ((2, 5, 16, 16), 32, 32, True, True),          # residual block tail, two simulations
+    ((1, 4, 16, 16), 32, 3, False, False),         # output layer
+    ((1, 4, 64, 64), 32, 32, True, True),          # W = 64: the split fp16 / bf16 MFMA kernels
+    ((1, 3, 64, 64), 4, 32, False, True),
+    ((1, 3, 64, 64), 32, 3, False, False),
+])
+def test_conv3d_against_oracle(shape, cin, cout, res, lrelu):
+    B, D, H, W = shape
+    gen = torch.Generator().manual_seed(B * 1000 + D * 100 + cin)
+    x = torch.randn(B, D, H, W, cin, generator=gen, dtype=torch.float64).float().double()
+    w = (torch.randn(5, 5, 5, cin, cout, generator=gen, dtype=torch.float64) / np.sqrt(125 * cin)).float().double()
+    b = torch.randn(cout, generator=gen, dtype=torch.float64).float().double()
+    r = torch.randn(B, D, H, W, cout, generator=gen, dtype=torch.float64).float().double() if res else None
+    ref = _oracle_conv(x, w, b, r, lrelu)
+    lib = sol_amd.load()
+    wd = f32(w)
+    packed = torch.empty(lib.sol_conv3d_packed_floats(cin, cout), dtype=torch.float32, device=DEV)
+    sol_amd._lib.check(lib.sol_conv3d_pack(sol_amd._lib.stream(), sol_amd._lib.ptr(wd), cin, cout, sol_amd._lib.ptr(packed)))
+    xd = f32(x)
+    for use_amax in ((False, True) if cin == 32 else (False,)):
+        amax = sol_amd.ops.absmax_slots(xd) if use_amax else None
+        ymax = torch.zeros(256, dtype=torch.int32, device=DEV)
+        y = k3.conv3d(xd, packed, f32(b), f32(r) if res else None, cout, lrelu, 0.3, amax, ymax)
+        torch.cuda.synchronize()
+        assert rel(y, ref) < 2e-6, (use_amax, rel(y, ref))
+        pub = float(ymax.max().view(torch.float32))
+        assert abs(pub - float(y.abs().max())) <= 1e-6 * pub            # the centre pass publishes max|y| of the finished tensor
+
+
+def test_network_and_rollout_against_golden(fixture3d, scene_small):
+    import make_golden as mg
+    z = fixture3d
+    B = z["d"].shape[0]
+    net = k3.MarsMoon3D(device=DEV)
+    assert net.n_params == 1048675
+    net.set_weights([p.numpy() for p in mg.k3d_params()])
+    std_v = tuple(float(s) for s in z["std_v"])
+    ro = k3.Karman3DRollout(net, scene_small, B, std_v, float(z["std_re"]))
+    # the network alone, on the features of the fixture's solver step
+    fs = ro.feat_scale
+    ref_feat = torch.stack([torch.as_tensor(z["vy_out"])[:, :32] * fs[0], torch.as_tensor(z["vx_out"])[:, :, :16] * fs[1],
+                            torch.as_tensor(z["vz_out"])[..., :16] * fs[2],
+                            torch.as_tensor(z["re"]).reshape(B, 1, 1, 1).expand(B, 32, 16, 16) * fs[3]], dim=-1)
+    ro.feat.copy_(ref_feat.to(DEV))
+    out = ro.correction()
+    assert rel(out, z["net_out"]) < 5e-6, rel(out, z["net_out"])
+    # two roll-out steps (solver + correction)
+    d, vy, vx, vz = ro.run(f32(z["d"]), f32(z["vy"]), f32(z["vx"]), f32(z["vz"]), f32(z["re"]), int(z["nroll"]))
+    torch.cuda.synchronize()
+    for a, k in ((d, "roll_d_sub4"), (vy, "roll_vy_sub4"), (vx, "roll_vx_sub4"), (vz, "roll_vz_sub4")):
+        assert rel(a.reshape(-1)[::4], z[k]) < TOL_FIELD, (k, rel(a.reshape(-1)[::4], z[k]))
+    assert np.allclose([float(a.double().norm()) for a in (d, vy, vx, vz)], z["roll_norms"], rtol=1e-5)
+
+
+@pytest.mark.timeout(900)
+def test_karman3d_full_size_step_against_oracle():
+    """BASELINE configs[4] grid: one step at 128 x 64 x 64 against the float64 oracle (DST-preconditioned CG pressure solve),
+    plus the size-independent property: the projected field is divergence free on interior active cells."""
+    B, Y, X, Z = 1, 128, 64, 64
+    g = o.geometry(Y, X, Z)
+    d, v = o.synthetic_state(B, Y, X, Z, 1234)
+    re = torch.tensor([o.RE_TRAIN[2]])
+    with torch.no_grad():
+        d1, v1 = o.karman3d_step(d, v, re, g)                     # spin-up: divergence free, consistent with the BCs
+        d1, v1 = d1.float().double(), tuple(c.float().double() for c in v1)
+        dr, vr = o.karman3d_step(d1, v1, re, g)
+    sc = k3.Scene3D(Y, X, Z, device=DEV)
+    sim = k3.Karman3DFlow(sc, B)
+    out = sim.step(f32(d1), f32(v1[0]), f32(v1[1]), f32(v1[2]), f32(re))
+    torch.cuda.synchronize()
+    errs = [rel(a, b) for a, b in zip(out, (dr,) + tuple(vr))]
+    assert max(errs) < TOL_FIELD, errs
+    vy, vx, vz = (t.double().cpu() for t in out[1:])
+    div = o.divergence((vy, vx, vz))
+    inner = torch.zeros(Y, X, Z, dtype=torch.float64)
+    inner[1:-1, 1:-1, 1:-1] = 1.0
+    resid = float((div * inner * torch.as_tensor(g.active)).abs().max())
+    assert resid < 2e-5, resid                                    # |v| ~ 1: fp32 round-off of the direct solve
