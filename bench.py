@@ -26,7 +26,8 @@ import torch
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_MFMA16_TF = 2500.0        # dense 16-bit MFMA peak
 PEAK_MFMA32_TF = 157.3         # fp32 matrix peak
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # written by tools/pmc_summary.py --json
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")   # written by tools/pmc_summary.py --json (with the library's source hash)
+RANK_SKEW_LIMIT = 0.25         # N > 1: fail when the slowest rank's timed region is this much longer than the fastest one's
 
 
 def parse():
@@ -161,13 +162,73 @@ def profile_kernels(wl, lr, trainer=None):
     return {k.strip("()"): {"calls": c, "avg_us": t / max(c, 1), "total_us": t} for k, (c, t) in p.kernels.items()}
 
 
+def karman3d_leg(sol_amd, dev, B=1, steps=8):
+    """BASELINE configs[4] grid, forward path (the 3-D adjoint is not built yet): 128 x 64 x 64, SOL-16-style roll-out of
+    solver step + Conv3D correction.  Reports ms per simulation step, the per-kernel table of one step (per-launch HIP events)
+    and, for the stencil kernels, their ALGORITHMIC bytes per launch against the 8 TB/s HBM peak:
+      k3_diffuse      reads the 3 components + the 2 BC arrays of the flow component, writes 3 components
+      k3_advect_*     reads 3 diffused components + density, writes 3 components + density
+      k3_div          reads 3 components, writes the right-hand side
+      k3_project      reads pressure + 3 components, writes 3 components + the 4-channel feature tensor"""
+    from sol_amd import karman3d as k3, synthetic, _lib
+    Y, X, Z = 128, 64, 64
+    sc = k3.Scene3D(Y, X, Z, device=dev)
+    net = k3.MarsMoon3D(device=dev)
+    w = net.get_weights()
+    w[22] = w[22] * 0.01
+    net.set_weights(w)
+    ro = k3.Karman3DRollout(net, sc, B, (0.2, 0.2, 0.2), synthetic.STD_RE)
+    gen = torch.Generator().manual_seed(4)
+    r = lambda *s: torch.randn(*s, generator=gen)
+    st = (torch.rand(B, Y, X, Z, generator=gen).to(dev), (1.0 + 0.1 * r(B, Y + 1, X, Z)).to(dev), (0.1 * r(B, Y, X + 1, Z)).to(dev),
+          (0.1 * r(B, Y, X, Z + 1)).to(dev))
+    re = synthetic.reynolds(B).float().to(dev)
+    st = ro.step(*st, re)                   # warm-up + spin-up
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    s2 = st
+    for _ in range(steps):
+        s2 = ro.step(*s2, re)
+    b.record()
+    torch.cuda.synchronize()
+    ms_step = a.elapsed_time(b) / steps
+    with _lib.profile() as p:
+        ro.step(*st, re)
+    N = Y * X * Z
+    nV = [(Y + 1) * X * Z, Y * (X + 1) * Z, Y * X * (Z + 1)]
+    alg = {"k3_diffuse": 4.0 * B * (2 * sum(nV) + 2 * nV[0]), "k3_advect_tile": 4.0 * B * (2 * sum(nV) + 2 * N), "k3_advect": 4.0 * B * (2 * sum(nV) + 2 * N),
+           "k3_div": 4.0 * B * (sum(nV) + N), "k3_project": 4.0 * B * (N + 2 * sum(nV) + 4 * N)}
+    kern = {}
+    tot = sum(t for _, t in p.kernels.values())
+    for k, (c, t) in sorted(p.kernels.items(), key=lambda kv: -kv[1][1]):
+        nm = k.strip("()")
+        e = {"calls": c, "avg_us": round(t / max(c, 1), 2), "share": round(t / tot, 4)}
+        if nm in alg:
+            e["algorithmic_GBps"] = alg[nm] / (t / c * 1e-6) / 1e9
+            e["frac_of_hbm_peak"] = e["algorithmic_GBps"] / PEAK_HBM_GBS
+        kern[nm] = e
+    flop = 2.0 * 125 * (4 * 32 + 10 * 32 * 32 + 32 * 3) * B * N
+    t_cnn = sum(t for k, (c, t) in p.kernels.items() if "conv" in k or k == "k3_fill")
+    return {"workload": "karman-3d %dx%dx%d, batch %d, forward roll-out (solver step + Conv3D(5) mars_moon correction; BASELINE configs[4] grid)" % (Y, X, Z, B),
+            "ms_per_sim_step": ms_step, "sim_steps_per_s": B * 1e3 / ms_step, "finite": bool(torch.isfinite(s2[1]).all()),
+            "cnn_fp32_equiv_TFLOPs": flop / (t_cnn * 1e-6) / 1e12, "solver_us": sum(t for k, (c, t) in p.kernels.items() if "conv" not in k and k not in ("k3_fill", "k3_correct")),
+            "kernels": kern, "note": "forward only: the adjoint of the 3-D step / Conv3D weight gradients are not built (DESIGN.md section 7)"}
+
+
 def load_traffic():
-    """{'kernel|grid': {'FETCH_SIZE': KB, 'WRITE_SIZE': KB}} from the committed rocprofv3 --pmc summary, or {}."""
+    """{'kernel|grid': {'FETCH_SIZE': KB, 'WRITE_SIZE': KB}} from the committed rocprofv3 --pmc summary -- but only when it was
+    collected for THIS build: the file carries the content hash of the library sources it was taken at
+    (sol_amd._build._source_hash()); counters of other kernels are not this run's traffic, the fields stay null then."""
     try:
         with open(TRAFFIC_FILE) as f:
-            return json.load(f)
+            tab = json.load(f)
     except (OSError, ValueError):
         return {}
+    from sol_amd import _build
+    if tab.get("source_hash") != _build._source_hash():
+        return {"stale": True, "collected_at_source_hash": tab.get("source_hash")}
+    return tab
 
 
 def traffic_bytes(tab, kernel, grid):
@@ -208,8 +269,17 @@ def main():
 
     sec, loss, trace = timed_steps(wl, args.lr, args.steps, args.warmup, barrier)
     tsec = torch.tensor([sec], dtype=torch.float64, device=dev)
+    rank_ms = [sec / args.steps * 1e3]
     if world > 1:
+        allsec = [torch.zeros_like(tsec) for _ in range(world)]
+        torch.distributed.all_gather(allsec, tsec)
+        rank_ms = [float(t.item()) / args.steps * 1e3 for t in allsec]
         torch.distributed.all_reduce(tsec, op=torch.distributed.ReduceOp.MAX)
+        if rank == 0:
+            print("bench.py: per-rank ms/step " + " ".join("%.3f" % v for v in rank_ms), file=sys.stderr, flush=True)
+        if max(rank_ms) > (1.0 + RANK_SKEW_LIMIT) * min(rank_ms):
+            raise SystemExit("bench.py: rank skew -- per-rank ms/step %s differ by more than %d %%: a rank is throttled, shares its device or "
+                             "lost its binding; the weak-scaling number would be that rank's, not the job's" % (rank_ms, int(RANK_SKEW_LIMIT * 100)))
     sec = float(tsec.item())
     if not math.isfinite(loss) or not all(math.isfinite(v) for v in trace):
         raise SystemExit("bench.py: non-finite loss in the timed run (warm-up trace %s, final %s): the measurement is invalid" % (trace, loss))
@@ -221,7 +291,10 @@ def main():
     if world > 1:
         ev = lambda: torch.cuda.Event(enable_timing=True)
         a, b = ev(), ev()
-        g = tr.grads.clone()
+        g = tr._flat.clone()                  # what a training step exchanges: [gradient | loss], ONE collective
+        c0 = tr._dp.collectives
+        wl.step(args.lr)
+        collectives_per_step = tr._dp.collectives - c0
         for _ in range(3):
             sol_amd.dist.allreduce_sum_(g)
         torch.cuda.synchronize()
@@ -235,6 +308,7 @@ def main():
         sigs = [torch.zeros_like(sig) for _ in range(world)]
         torch.distributed.all_gather(sigs, sig)
         dp = {"backend": torch.distributed.get_backend(), "allreduce_us": a.elapsed_time(b) / 20 * 1e3, "allreduce_bytes": g.numel() * 4,
+              "collectives_per_step": collectives_per_step, "rank_ms_per_step": rank_ms,
               "weights_bit_identical_across_ranks": bool(all(bool((s == sigs[0]).all()) for s in sigs))}
         if not dp["weights_bit_identical_across_ranks"]:
             raise SystemExit("bench.py: the replicas' weights diverged")
@@ -277,16 +351,18 @@ def main():
         if cst:
             t_conv = cst["avg_us"] * 1e-6
             peak = PEAK_MFMA16_TF if nprod > 1 else PEAK_MFMA32_TF
-            executed = nprod * flop_conv / t_conv / 1e12
-            roof_conv = {"kernel": cname, "bound": "mfma", "achieved": executed, "peak": peak, "unit": "TFLOP/s", "frac": executed / peak,
+            alg = flop_conv / t_conv / 1e12              # ALGORITHMIC fp32 FLOP of the convolution per launch / launch duration
+            roof_conv = {"kernel": cname, "bound": "mfma", "achieved": alg, "peak": peak, "unit": "TFLOP/s", "frac": alg / peak,
+                         "mfma_pipe_busy": nprod * alg / peak,
                          "traffic": traffic_bytes(traffic, cname, ((B * Y + 2) // 3) * max(1, X // 64) * 768),
                          "launch_us": cst["avg_us"], "launches_per_train_step": cst["calls"], "share_of_step_kernel_time": cst["total_us"] / tot_prof,
                          "algorithmic_fp32_flop_per_launch": flop_conv, "executed_mfma_flop_per_launch": nprod * flop_conv,
-                         "algorithmic_fp32_TFLOPs": flop_conv / t_conv / 1e12,
-                         "note": ("achieved = EXECUTED 16-bit MFMA FLOPs (%d exact 16-bit products per fp32 product, fp32 accumulation) / the kernel's "
-                                  "average duration inside an eager training step (per-launch HIP events); peak = dense 16-bit MFMA peak.  "
-                                  "fp32-equivalent rate = achieved / %d." % (nprod, nprod)) if nprod > 1 else
-                                 "fp32 MFMA (v_mfma_f32_16x16x4_f32); achieved = algorithmic fp32 FLOPs / average in-pipeline duration"}
+                         "frac_of_fp32_matrix_peak": alg / PEAK_MFMA32_TF,
+                         "note": ("achieved = algorithmic fp32 FLOPs of the convolution (2*25*32*32 per output pixel) / the kernel's average duration "
+                                  "inside an eager training step (per-launch HIP events on the launch stream); peak = dense peak of the pipe the kernel "
+                                  "runs on (16-bit MFMA).  Each fp32 product is evaluated as %d exact 16-bit MFMA products with fp32 accumulation: "
+                                  "mfma_pipe_busy = %d x frac is the occupancy of that pipe, frac_of_fp32_matrix_peak compares with v_mfma_f32_*_f32." % (nprod, nprod))
+                                 if nprod > 1 else "fp32 MFMA (v_mfma_f32_16x16x4_f32); achieved = algorithmic fp32 FLOPs / average in-pipeline duration"}
         # (2) the fused advect+pressure step the north star names, as launched in the training graph at this batch size
         sname, sst = pick("k_karman_fwd_dens", "k_karman_fwd")
         roof_solver = None
@@ -297,6 +373,13 @@ def main():
                            "frac": bytes_step / t_s / (PEAK_HBM_GBS * 1e9), "traffic": traffic_bytes(traffic, sname, (2 if sname.endswith("dens") else 1) * B * 512),
                            "launch_us": sst["avg_us"], "launches_per_train_step": sst["calls"], "share_of_step_kernel_time": sst["total_us"] / tot_prof,
                            "cg_iters": kf_tr, "algorithmic_bytes_per_launch": bytes_step,
+                           "accounting": "SURVEY 8d formula 4*(10*Nf + 9*N + 11*N*k) per sample-step with the MEASURED k of this solver (k = 0 for the direct solve)",
+                           "reference_cg_equivalent": {
+                               "k_planning": 180, "algorithmic_bytes_per_launch": 4.0 * (10 * Nf + 9 * N + 11.0 * N * 180) * B,
+                               "achieved": 4.0 * (10 * Nf + 9 * N + 11.0 * N * 180) * B / t_s / 1e9,
+                               "frac": 4.0 * (10 * Nf + 9 * N + 11.0 * N * 180) * B / t_s / (PEAK_HBM_GBS * 1e9),
+                               "note": "the traffic the reference's unpreconditioned CG (k ~ 180 at 128x64, SURVEY 8d worked example) would move for the "
+                                       "same result: what this launch REPLACES, not what it moves"},
                            "pressure_solver": "direct (sine-transform diagonalisation + capacitance correction, no iteration)" if direct
                                               else "two-level preconditioned CG",
                            "note": "LDS-resident, one workgroup (CU) per simulation: B = %d simulations occupy %d of 256 CUs, so the fraction of "
@@ -328,6 +411,9 @@ def main():
             "roofline": roof_conv if roof_conv and (not roof_solver or cst["total_us"] >= sst["total_us"]) else roof_solver,
             "roofline_solver_step": roof_solver,
             "roofline_conv": roof_conv,
+            "traffic_source": {"file": os.path.relpath(TRAFFIC_FILE, ROOT), "matches_this_build": bool(traffic.get("kernels")),
+                               "note": "HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc passes, gfx950 correction); null when the "
+                                       "counters were collected for another build of the library"},
             "kernels_in_step": kern_tab,
             "profiled_step_kernel_time_ms": tot_prof * 1e-3,
             "train_step_breakdown": {"solver_alg_bytes_fwd": fwd_b, "solver_alg_bytes_bwd": bwd_b,
@@ -355,23 +441,28 @@ def main():
                 del df, vyf, vxf
             except Exception as e:
                 out["roofline_solver_step_full_chip_256_sims"] = {"error": str(e)}
-            # strict fp32 MFMA leg: the same training step with every convolution on v_mfma_f32_*_f32
-            if args.precision != "fp32":
+            # the same training step in the two other convolution arithmetics: strict fp32 MFMA (every convolution on
+            # v_mfma_f32_*_f32) and bf16x6 (true 24-bit operand splits, six exact bf16 products per fp32 product)
+            for leg, prec, kname, npr in (("strict_fp32", "fp32", "k_conv5x5_r3<2>", 1), ("bf16x6", "bf16x6", "k_conv5x5_sb<2, 0>", 6)):
+                if args.precision == prec:
+                    continue
                 try:
-                    tr32 = sol_amd.SolTrainer(wl.net.clone(), wl.masks, B, Y, X, ms, wl.dx, wl.std_v,
-                                              synthetic.STD_RE, conv_precision="fp32")
-                    s32, l32, _ = timed_steps(wl, args.lr, max(3, min(5, args.steps)), 2, lambda: torch.cuda.synchronize(), trainer=tr32)
-                    n32 = max(3, min(5, args.steps))
-                    p32 = profile_kernels(wl, args.lr, trainer=tr32)
-                    c32 = p32.get("k_conv5x5_r3<2>")
-                    out["strict_fp32"] = {"ms_per_step": s32 / n32 * 1e3, "sim_steps_per_s": B * ms * n32 / s32, "loss": l32,
-                                          "roofline": None if not c32 else {
-                                              "kernel": "k_conv5x5_r3<2>", "bound": "mfma", "achieved": flop_conv / (c32["avg_us"] * 1e-6) / 1e12,
-                                              "peak": PEAK_MFMA32_TF, "unit": "TFLOP/s", "frac": flop_conv / (c32["avg_us"] * 1e-6) / (PEAK_MFMA32_TF * 1e12),
-                                              "launch_us": c32["avg_us"], "traffic": traffic_bytes(traffic, "k_conv5x5_r3<2>", ((B * Y + 2) // 3) * max(1, X // 64) * 768)}}
-                    del tr32
+                    trp = sol_amd.SolTrainer(wl.net.clone(), wl.masks, B, Y, X, ms, wl.dx, wl.std_v,
+                                             synthetic.STD_RE, conv_precision=prec)
+                    np_ = max(3, min(5, args.steps))
+                    sp, lp, _ = timed_steps(wl, args.lr, np_, 2, lambda: torch.cuda.synchronize(), trainer=trp)
+                    pp = profile_kernels(wl, args.lr, trainer=trp)
+                    cp = pp.get(kname)
+                    pk = PEAK_MFMA32_TF if npr == 1 else PEAK_MFMA16_TF
+                    out[leg] = {"ms_per_step": sp / np_ * 1e3, "sim_steps_per_s": B * ms * np_ / sp, "loss": lp,
+                                "roofline": None if not cp else {
+                                    "kernel": kname, "bound": "mfma", "achieved": flop_conv / (cp["avg_us"] * 1e-6) / 1e12,
+                                    "peak": pk, "unit": "TFLOP/s", "frac": flop_conv / (cp["avg_us"] * 1e-6) / (pk * 1e12),
+                                    "mfma_pipe_busy": npr * flop_conv / (cp["avg_us"] * 1e-6) / (pk * 1e12),
+                                    "launch_us": cp["avg_us"], "traffic": traffic_bytes(traffic, kname, ((B * Y + 2) // 3) * max(1, X // 64) * 768)}}
+                    del trp
                 except Exception as e:
-                    out["strict_fp32"] = {"error": str(e)}
+                    out[leg] = {"error": str(e)}
             # the reference's own training recipe (karman-2d/Makefile:78-80): 64x32, batch 3, SOL-32
             if (Y, X, B) == (128, 64, 6) and world == 1:
                 try:
@@ -393,6 +484,11 @@ def main():
                 out["rollout"] = {"sim_steps_per_s": 50.0 / t_ro, "batch": 1, "steps": 50, "us_per_step": t_ro / 50 * 1e6}
             except Exception as e:          # never let the extra line break the contract line
                 out["rollout"] = {"error": str(e)}
+        if not args.no_extras and world == 1:
+            try:
+                out["karman3d"] = karman3d_leg(sol_amd, dev)
+            except Exception as e:
+                out["karman3d"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, Y, X, B)
         else:

@@ -142,6 +142,7 @@ struct SolOptions {
     int cnn_persistent;   // 1: the ten 32 -> 32 layers of a CNN pass as ONE persistent launch (cnn_chain.hip) where the shape allows it; default 0:
                           //    measured equal to the per-layer launches end to end, kept as a verified experiment
     int graph_stream;     // 1: sol_train_graph_launch replays on an internal stream fenced by events against the caller's stream
+    int k3d_fused_tf;     // 1 (default): the sine transforms of the karman-3d pressure solve as LDS-resident plane / column-slab kernels; 0: batched GEMMs
     int k3d_tile;         // 1 (default): karman-3d advection from LDS tiles holding the full z column + halo; 0: straight from global memory
 };
 SolOptions& sol_opt();

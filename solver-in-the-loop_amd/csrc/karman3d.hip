@@ -217,7 +217,8 @@ __global__ void __launch_bounds__(256) k3_advect(K3Args a) {
 
 // One workgroup = tile (ty, tx) of 8 x 8 cells x the full z column of simulation b.  It owns the y faces j0..j0+7 (the last
 // tile row also face Y), the x faces i0..i0+7 (the last tile column also face X), all z faces and cells of its columns.
-__global__ void __launch_bounds__(256) k3_advect_tile(K3Args a, int tiles_x) {
+constexpr int ADV_T = 1024;      // 16 waves per workgroup: the tile kernel owns a CU (117 KB of LDS), its gathers are latency bound
+__global__ void __launch_bounds__(ADV_T) k3_advect_tile(K3Args a, int tiles_x) {
     extern __shared__ __align__(16) float lds3[];
     const int Y = a.Y, X = a.X, Z = a.Z;
     const int nVy = (Y + 1) * X * Z, nVx = Y * (X + 1) * Z, nVz = Y * X * (Z + 1);
@@ -232,15 +233,15 @@ __global__ void __launch_bounds__(256) k3_advect_tile(K3Args a, int tiles_x) {
     float* lz = lx + TR * (TR + 1) * Z;
     r.ly = ly; r.lx = lx; r.lz = lz;
     // stage the region (rows / columns outside the arrays are skipped: clamped indices never address them)
-    for (int e = threadIdx.x; e < (TR + 1) * TR * Z; e += 256) {
+    for (int e = threadIdx.x; e < (TR + 1) * TR * Z; e += ADV_T) {
         const int k = e % Z, ri = (e / Z) % TR, rj = e / (Z * TR), j = r.j0 + rj, i = r.i0 + ri;
         if ((unsigned)j <= (unsigned)Y && (unsigned)i < (unsigned)X) ly[e] = r.g.y(j, i, k);
     }
-    for (int e = threadIdx.x; e < TR * (TR + 1) * Z; e += 256) {
+    for (int e = threadIdx.x; e < TR * (TR + 1) * Z; e += ADV_T) {
         const int k = e % Z, ri = (e / Z) % (TR + 1), rj = e / (Z * (TR + 1)), j = r.j0 + rj, i = r.i0 + ri;
         if ((unsigned)j < (unsigned)Y && (unsigned)i <= (unsigned)X) lx[e] = r.g.x(j, i, k);
     }
-    for (int e = threadIdx.x; e < TR * TR * (Z + 1); e += 256) {
+    for (int e = threadIdx.x; e < TR * TR * (Z + 1); e += ADV_T) {
         const int k = e % (Z + 1), ri = (e / (Z + 1)) % TR, rj = e / ((Z + 1) * TR), j = r.j0 + rj, i = r.i0 + ri;
         if ((unsigned)j < (unsigned)Y && (unsigned)i < (unsigned)X) lz[e] = r.g.z(j, i, k);
     }
@@ -248,11 +249,11 @@ __global__ void __launch_bounds__(256) k3_advect_tile(K3Args a, int tiles_x) {
     const int ny = min(T3, Y - jt) + (jt + T3 >= Y ? 1 : 0);      // y-face rows owned
     const int nx = min(T3, X - it) + (it + T3 >= X ? 1 : 0);      // x-face columns owned
     const int cy = min(T3, Y - jt), cx = min(T3, X - it);         // cells owned
-    for (int e = threadIdx.x; e < ny * cx * Z; e += 256) advect_point(a, r, b, 0, jt + e / (Z * cx), it + (e / Z) % cx, e % Z);
-    for (int e = threadIdx.x; e < cy * nx * Z; e += 256) advect_point(a, r, b, 1, jt + e / (Z * nx), it + (e / Z) % nx, e % Z);
-    for (int e = threadIdx.x; e < cy * cx * (Z + 1); e += 256) advect_point(a, r, b, 2, jt + e / ((Z + 1) * cx), it + (e / (Z + 1)) % cx, e % (Z + 1));
+    for (int e = threadIdx.x; e < ny * cx * Z; e += ADV_T) advect_point(a, r, b, 0, jt + e / (Z * cx), it + (e / Z) % cx, e % Z);
+    for (int e = threadIdx.x; e < cy * nx * Z; e += ADV_T) advect_point(a, r, b, 1, jt + e / (Z * nx), it + (e / Z) % nx, e % Z);
+    for (int e = threadIdx.x; e < cy * cx * (Z + 1); e += ADV_T) advect_point(a, r, b, 2, jt + e / ((Z + 1) * cx), it + (e / (Z + 1)) % cx, e % (Z + 1));
     if (a.d_out)
-        for (int e = threadIdx.x; e < cy * cx * Z; e += 256) advect_point(a, r, b, 3, jt + e / (Z * cx), it + (e / Z) % cx, e % Z);
+        for (int e = threadIdx.x; e < cy * cx * Z; e += ADV_T) advect_point(a, r, b, 3, jt + e / (Z * cx), it + (e / Z) % cx, e % Z);
 }
 
 __global__ void __launch_bounds__(256) k3_div(K3Args a) {
@@ -318,23 +319,129 @@ __global__ void __launch_bounds__(256) k3_scale(float* __restrict__ T, const flo
 }
 
 // capacitance correction: xs = g[sidx], c = K' xs (KpT = K' transposed, [SP][SP], zero padded), rhs[sidx] -= c.
-// grid (SP / 64, B), 256 threads: 64 outputs x 4 slices of the sum.
+// Stage 1, grid (SP / 32, CAPQ, B): 32 outputs x 8 slices of this workgroup's chunk of the sum -> part[b][chunk][s]
+// (the dense product is a 10 MB stream at 128 x 64 x 64: it wants the whole chip, not SP / 64 workgroups);
+// stage 2 folds the CAPQ chunks in a fixed order (deterministic) and applies the correction.
+constexpr int CAPQ = 8;
 __global__ void __launch_bounds__(256) k3_capacitance(const float* __restrict__ g, const float* __restrict__ KpT, const int* __restrict__ sidx,
-                                                       float* __restrict__ rhs, int SP, int N) {
-    extern __shared__ float xs[];             // [SP] + [4][64]
-    float* part = xs + SP;
-    const int b = blockIdx.y;
+                                                       float* __restrict__ part, int SP, int N) {
+    __shared__ float xs[1024];                // this chunk of xs (SP / CAPQ <= 1024)
+    __shared__ float red[8][32];
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const int qn = SP / CAPQ, q0 = ch * qn;
     const float* gb = g + (size_t)b * N;
-    for (int t = threadIdx.x; t < SP; t += 256) { const int si = sidx[t]; xs[t] = si >= 0 ? gb[si] : 0.f; }
+    for (int t = threadIdx.x; t < qn; t += 256) { const int si = sidx[q0 + t]; xs[t] = si >= 0 ? gb[si] : 0.f; }
     __syncthreads();
-    const int s = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    const int sl = threadIdx.x >> 5, s = blockIdx.x * 32 + (threadIdx.x & 31);
     float c = 0.f;
-    for (int q = sl; q < SP; q += 4) c += KpT[(size_t)q * SP + s] * xs[q];
-    part[sl * 64 + (threadIdx.x & 63)] = c;
+    for (int q = sl; q < qn; q += 8) c += KpT[(size_t)(q0 + q) * SP + s] * xs[q];
+    red[sl][threadIdx.x & 31] = c;
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int si = sidx[s];
-        if (si >= 0) rhs[(size_t)b * N + si] -= part[threadIdx.x] + part[64 + threadIdx.x] + part[128 + threadIdx.x] + part[192 + threadIdx.x];
+    if (threadIdx.x < 32) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += red[k][threadIdx.x];
+        part[((size_t)b * CAPQ + ch) * SP + s] = v;
+    }
+}
+__global__ void __launch_bounds__(256) k3_cap_apply(const float* __restrict__ part, const int* __restrict__ sidx, float* __restrict__ rhs, int SP, int N) {
+    const int b = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= SP) return;
+    const int si = sidx[s];
+    if (si < 0) return;
+    float c = 0.f;
+#pragma unroll
+    for (int k = 0; k < CAPQ; ++k) c += part[((size_t)b * CAPQ + k) * SP + s];
+    rhs[(size_t)b * N + si] -= c;
+}
+
+// ---- sine transforms with LDS-resident planes / column slabs (X, Z <= 64, Y <= 128) -----------------------------------
+// k3_tzx: one workgroup = one (x, z) plane of one simulation: out = Qx (F Qz), both products from LDS (the two transforms
+// of a plane cost ONE read and ONE write of the plane instead of two each).  Q symmetric, so the same kernel serves the
+// forward and the inverse direction.
+__global__ void __launch_bounds__(256) k3_tzx(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ Qx,
+                                               const float* __restrict__ Qz, int X, int Z) {
+    __shared__ float A[64][65], Q[64][65];
+    const size_t plane = (size_t)blockIdx.x * X * Z;
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    for (int e = t; e < X * Z; e += 256) A[e / Z][e % Z] = in[plane + e];
+    for (int e = t; e < Z * Z; e += 256) Q[e / Z][e % Z] = Qz[e];
+    __syncthreads();
+    float acc[4][4];
+    auto mm = [&](int K, bool left) {        // left: acc = Q[rows ty*4..][k] * A[k][cols tx*4..]; else acc = A[rows][k] * Q[k][cols]
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
+        for (int k = 0; k < K; ++k) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { av[r] = left ? Q[k][ty * 4 + r] : A[ty * 4 + r][k]; bv[r] = left ? A[k][tx * 4 + r] : Q[k][tx * 4 + r]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] += av[r] * bv[c];
+        }
+    };
+    mm(Z, false);                            // T = F Qz   (rows: x, cols: z)
+    __syncthreads();
+    if (ty * 4 < X && tx * 4 < Z)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) A[ty * 4 + r][tx * 4 + c] = acc[r][c];
+    for (int e = t; e < X * X; e += 256) Q[e / X][e % X] = Qx[e];
+    __syncthreads();
+    mm(X, true);                             // out = Qx T  (Qx symmetric: Q[k][m] = Qx[m][k])
+    if (ty * 4 < X && tx * 4 < Z)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out[plane + (size_t)(ty * 4 + r) * Z + tx * 4 + c] = acc[r][c];
+}
+
+// k3_ty: one workgroup = a slab of 32 columns (flattened (x, z) index) x all Y rows of one simulation:
+// out = Qy diag(il) Qy f  -- forward transform along y, division by the eigenvalues, inverse transform, one read / write.
+__global__ void __launch_bounds__(256) k3_ty(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ Qy,
+                                              const float* __restrict__ il, int Y, int XZ) {
+    extern __shared__ __align__(16) float lty[];          // Qy [Y][Y+4] + F [Y][36]
+    const int QS = Y + 4;
+    float* Q = lty;
+    float* Fm = lty + (size_t)Y * QS;
+    const int b = blockIdx.y, c0 = blockIdx.x * 32;
+    const size_t base = (size_t)b * Y * XZ + c0;
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;       // outputs: rows ty*8 .. +7 (two passes of 64 rows at Y = 128), cols tx*2, +1
+    for (int e = t; e < Y * Y; e += 256) Q[(e / Y) * QS + e % Y] = Qy[e];
+    for (int e = t; e < Y * 32; e += 256) Fm[(e >> 5) * 36 + (e & 31)] = in[base + (size_t)(e >> 5) * XZ + (e & 31)];
+    __syncthreads();
+    const int RP = (Y + 127) / 128 * 8;      // rows per thread: 8 for Y <= 128
+    float acc[8][2];
+    for (int pass = 0; pass < 2; ++pass) {
+        // pass 0: T = Qy F, scaled by il;  pass 1: out = Qy T
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { acc[r][0] = 0.f; acc[r][1] = 0.f; }
+        const int m0 = ty * RP;
+        if (m0 < Y)
+            for (int k = 0; k < Y; ++k) {
+                const float f0 = Fm[k * 36 + tx * 2], f1 = Fm[k * 36 + tx * 2 + 1];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { const float q = Q[k * QS + m0 + r]; acc[r][0] += q * f0; acc[r][1] += q * f1; }   // Qy symmetric
+            }
+        __syncthreads();
+        if (m0 < Y) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int m = m0 + r;
+                if (pass == 0) {
+                    const float2 s2 = *reinterpret_cast<const float2*>(&il[(size_t)m * XZ + c0 + tx * 2]);
+                    Fm[m * 36 + tx * 2] = acc[r][0] * s2.x;
+                    Fm[m * 36 + tx * 2 + 1] = acc[r][1] * s2.y;
+                } else {
+                    *reinterpret_cast<float2*>(&out[base + (size_t)m * XZ + tx * 2]) = make_float2(acc[r][0], acc[r][1]);
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -393,7 +500,7 @@ extern "C" int sol_karman3d_step_fwd(const sol_karman3d_cfg* c, void* stream,
     const int nS = direct_header_host[4], SP = direct_header_host[5];
     SOL_REQUIRE(direct_header_host[1] == Y && direct_header_host[2] == X && direct_header_host[3] == Z, "direct-solver blob is for a %dx%dx%d grid, cfg is %dx%dx%d",
                 direct_header_host[1], direct_header_host[2], direct_header_host[3], Y, X, Z);
-    SOL_REQUIRE(nS >= 0 && SP >= nS && SP % 64 == 0 && SP <= 8192, "direct-solver blob header is inconsistent (nS %d, SP %d)", nS, SP);
+    SOL_REQUIRE(nS >= 0 && SP >= nS && SP % 64 == 0 && SP <= 8192 && (size_t)8 * SP <= (size_t)N, "direct-solver blob header is inconsistent (nS %d, SP %d)", nS, SP);
     SOL_REQUIRE((size_t)c->direct_n == (size_t)FD3_HEADER + (size_t)Y * Y + (size_t)X * X + (size_t)Z * Z + (size_t)N + (size_t)SP * SP + SP,
                 "direct-solver blob has %d words, expected %zu", c->direct_n,
                 (size_t)FD3_HEADER + (size_t)Y * Y + (size_t)X * X + (size_t)Z * Z + (size_t)N + (size_t)SP * SP + SP);
@@ -427,7 +534,7 @@ extern "C" int sol_karman3d_step_fwd(const sol_karman3d_cfg* c, void* stream,
         static int rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k3_advect_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
         SOL_REQUIRE(rc == 0, "hipFuncSetAttribute(k3_advect_tile) failed");
         const int tiles_y = (Y + T3 - 1) / T3, tiles_x = (X + T3 - 1) / T3;
-        SOL_LAUNCH(k3_advect_tile, dim3(tiles_y * tiles_x, B), dim3(256), tile_lds, s, a, tiles_x);
+        SOL_LAUNCH(k3_advect_tile, dim3(tiles_y * tiles_x, B), dim3(ADV_T), tile_lds, s, a, tiles_x);
     } else {
         SOL_LAUNCH(k3_advect, dim3(grid_for(faces + N), B), dim3(256), 0, s, a);
     }
@@ -448,10 +555,29 @@ extern "C" int sol_karman3d_step_fwd(const sol_karman3d_cfg* c, void* stream,
         if (int e = tx(t2, t1)) return e;
         return tz(t1, t2);
     };
-    if (int e = G(R, T1, T2)) return e;
+    // LDS-resident form: three launches per application of G (plane-wise z+x transforms, column-slab y transform + scaling +
+    // inverse y transform, plane-wise inverse) instead of six batched GEMMs + a scaling pass
+    const bool fused_tf = sol_opt().k3d_fused_tf && X <= 64 && Z <= 64 && Y <= 128 && X % 4 == 0 && Z % 4 == 0 && Y % 16 == 0 && (X * Z) % 32 == 0;
+    const size_t ty_lds = ((size_t)Y * (Y + 4) + (size_t)Y * 36) * sizeof(float);
+    auto Gf = [&](float* src, float* t1, float* t2) -> int {
+        static int rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k3_ty), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
+        SOL_REQUIRE(rc == 0, "hipFuncSetAttribute(k3_ty) failed");
+        SOL_LAUNCH(k3_tzx, dim3(B * Y), dim3(256), 0, s, src, t1, Qx, Qz, X, Z);
+        SOL_LAUNCH(k3_ty, dim3(X * Z / 32, B), dim3(256), ty_lds, s, t1, t2, Qy, il, Y, X * Z);
+        SOL_LAUNCH(k3_tzx, dim3(B * Y), dim3(256), 0, s, t2, t1, Qx, Qz, X, Z);
+        SOL_LAUNCH_CHECK();
+        return SOL_OK;
+    };
+    // result in `res`: T2 for the GEMM path, T1 for the fused path
+    float* res = fused_tf ? T1 : T2;
+    a.p = res;
+    if (int e = fused_tf ? Gf(R, T1, T2) : G(R, T1, T2)) return e;
     if (nS > 0) {
-        SOL_LAUNCH(k3_capacitance, dim3(SP / 64, B), dim3(256), (size_t)(SP + 256) * sizeof(float), s, T2, KpT, sidx, R, SP, N);
-        if (int e = G(R, T1, T2)) return e;
+        SOL_REQUIRE(SP / CAPQ <= 1024 && SP % (32 * CAPQ / 4) == 0, "direct-solver blob: SP = %d does not fit the capacitance kernel", SP);
+        float* cpart = fused_tf ? T2 : T1;          // scratch: the buffer G does not return its result in (B * CAPQ * SP <= B * N floats)
+        SOL_LAUNCH(k3_capacitance, dim3(SP / 32, CAPQ, B), dim3(256), 0, s, res, KpT, sidx, cpart, SP, N);
+        SOL_LAUNCH(k3_cap_apply, dim3((SP + 255) / 256, B), dim3(256), 0, s, cpart, sidx, R, SP, N);
+        if (int e = fused_tf ? Gf(R, T1, T2) : G(R, T1, T2)) return e;
     }
     SOL_LAUNCH(k3_project, dim3(grid_for(faces), B), dim3(256), 0, s, a);
     SOL_LAUNCH_CHECK();

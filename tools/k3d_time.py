@@ -34,8 +34,9 @@ re = synthetic.reynolds(B).float().to(dev)
 st = ro.step(d, vy, vx, vz, re)          # warm-up (packs the weights)
 torch.cuda.synchronize()
 out = {"B": B}
-for tile in (1, 0):
+for tile, ftf in ((1, 1), (0, 1), (0, 0)):
     sol_amd._lib.set_option("k3d_tile", tile)
+    sol_amd._lib.set_option("k3d_fused_tf", ftf)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s2 = st
     e0.record()
@@ -43,8 +44,9 @@ for tile in (1, 0):
         s2 = ro.sim.step(*s2, re)
     e1.record()
     torch.cuda.synchronize()
-    out["solver_ms_tile%d" % tile] = e0.elapsed_time(e1) / steps
+    out["solver_ms_tile%d_fusedtf%d" % (tile, ftf)] = e0.elapsed_time(e1) / steps
 sol_amd._lib.set_option("k3d_tile", 1)
+sol_amd._lib.set_option("k3d_fused_tf", 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(steps):

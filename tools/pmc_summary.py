@@ -2,7 +2,9 @@
 """Mean counter value per (kernel, grid size) from a rocprofv3 --pmc run written with --output-format csv.
 Usage: python tools/pmc_summary.py <dir with *counter_collection.csv> [substring filter] [--json out.json]
 --json writes {"kernels": {"<kernel>|<grid>": {"<counter>": mean, "dispatches": n}}} -- the file bench.py reads its
-roofline `traffic` from (profiles/r02_pmc_traffic.json); several runs (one counter each) merge into one file."""
+roofline `traffic` from (profiles/r03_pmc_traffic.json); several runs (one counter each) merge into one file.  The file
+records the content hash of the library sources it was collected at (sol_amd._build._source_hash()): bench.py reports the
+traffic only while the build it runs matches."""
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 
@@ -37,6 +39,16 @@ if jout:
         e = tab["kernels"].setdefault("%s|%s" % (name, grid), {})
         e[ctr] = s / n
         e["dispatches"] = n
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import sol_amd
+    h = sol_amd._build._source_hash()
+    if tab.get("source_hash") not in (None, h):
+        tab["kernels"] = {k: v for k, v in tab["kernels"].items() if False}      # other build: start over
+        for (name, grid, ctr), (s, n) in sorted(acc.items()):
+            e = tab["kernels"].setdefault("%s|%s" % (name, grid), {})
+            e[ctr] = s / n
+            e["dispatches"] = n
+    tab["source_hash"] = h
     tab["unit"] = "as reported by rocprofv3 (FETCH_SIZE / WRITE_SIZE: KB per dispatch; gfx950: FETCH_SIZE under-counts wide reads 2x)"
     with open(jout, "w") as f:
         json.dump(tab, f, indent=1, sort_keys=True)
