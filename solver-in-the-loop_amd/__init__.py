@@ -13,7 +13,8 @@ from .karman import KarmanFlow, to_feature, to_staggered, lr_schedule, velocity_
 from .model import model_mars_moon, model_mercury, MarsMoon, Mercury, ConvNet  # noqa: F401
 from .trainer import SolTrainer, SolRollout, GraphTrainer, make_trainer  # noqa: F401
 from . import synthetic, scene, burgers  # noqa: F401
-from .burgers import BurgersTest, BurgersTrainer, TFAdam  # noqa: F401
+from .burgers import BurgersTest, BurgersTrainer, BurgersRollout, TFAdam  # noqa: F401
+from . import karman3d, precond3d  # noqa: F401
 
 __version__ = "0.1.0"
 

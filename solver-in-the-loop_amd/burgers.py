@@ -219,3 +219,73 @@ class BurgersTrainer:
         loss = self.fwd_bwd(velo, forc, eager)
         self.opt.step(lr)
         return loss
+
+
+# ---- no-grad roll-out (burgers_apply.py:129-151) ------------------------------------------------------------------------
+class BurgersRollout:
+    """Inference loop of /root/reference/burgers/burgers_apply.py:129-151 without autograd state:
+        v = step_with_f(v, f_prev, dt)  (or step(v, dt))  ->  features = to_feature([v], [f_next]) / std  ->
+        correction = to_staggered(model(features) * std_v)  ->  v += correction
+    (the reference advances with the force frame it loaded on the PREVIOUS iteration and feeds the network the frame it
+    loads on THIS iteration, :131-134).  One step = the HIP solver step + twelve conv launches + the pad/add, captured ONCE
+    into a hipGraph over static buffers (the path is launch bound at 32 x 32); step() copies the two force frames in and
+    replays.  `vel` / `corr` are the static staggered tensors [B,Y+1,X+1,2] holding the state after the step and its
+    correction (what the script writes as velTf / corTf)."""
+
+    def __init__(self, net, domain, batch_size, dt, std_v, std_f=None, noforce=False, use_graph=True, viscosity=0.1):
+        from . import fluid
+        _lib.require_gpu()
+        self.net, self.dom, self.B, self.dt, self.noforce = net, domain, int(batch_size), float(dt), bool(noforce)
+        dev = net.params.device
+        Y, X = domain.resolution
+        self.sim = BurgersTest(default_viscosity=viscosity)
+        self.std_v = torch.as_tensor(std_v, dtype=torch.float32, device=dev).reshape(2)
+        self.std_in = self.std_v if noforce else torch.cat([self.std_v, torch.as_tensor(std_f, dtype=torch.float32, device=dev).reshape(2)])
+        z = lambda: torch.zeros(self.B, Y + 1, X + 1, 2, dtype=torch.float32, device=dev)
+        self.vel, self.corr, self.f_step, self.f_feat = z(), z(), z(), z()
+        self.use_graph, self._graph, self._fluid = bool(use_graph), None, fluid
+
+    def _one(self):
+        from .karman import to_staggered
+        F = self._fluid
+        with torch.no_grad():
+            st = F.BurgersVelocitySMAC(self.dom, velocity=self.vel, batch_size=self.B)
+            if self.noforce:
+                st = self.sim.step(st, dt=self.dt)
+                feat = to_feature_noforce([st])
+            else:
+                st = self.sim.step_with_f(st, F.BurgersVelocitySMAC(self.dom, velocity=self.f_step, batch_size=self.B), dt=self.dt)
+                feat = to_feature([st], [F.BurgersVelocitySMAC(self.dom, velocity=self.f_feat, batch_size=self.B)])
+            cv = to_staggered(self.net.predict(feat / self.std_in) * self.std_v, self.dom.box)
+            self.corr.copy_(cv.staggered_tensor())
+            self.vel.copy_((st.velocity + cv).staggered_tensor())
+
+    def reset(self, velocity):
+        self.vel.copy_(torch.as_tensor(velocity, dtype=torch.float32).reshape(self.vel.shape))
+        self.corr.zero_()
+
+    def step(self, f_step=None, f_feat=None):
+        """Advances self.vel by one corrected step.  f_step: force frame of the solver step, f_feat: force frame of the
+        network's input ([B,Y+1,X+1,2] staggered; ignored with noforce)."""
+        if not self.noforce:
+            self.f_step.copy_(torch.as_tensor(f_step, dtype=torch.float32).reshape(self.f_step.shape), non_blocking=True)
+            self.f_feat.copy_(torch.as_tensor(f_feat, dtype=torch.float32).reshape(self.f_feat.shape), non_blocking=True)
+        if not self.use_graph:
+            self._one()
+            return self.vel
+        if self._graph is None:
+            keep = self.vel.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):           # warm-up off the capture (library initialisation, allocator pools)
+                self._one()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.vel.copy_(keep)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._one()
+            self._graph = g
+            self.vel.copy_(keep)
+        self._graph.replay()
+        return self.vel

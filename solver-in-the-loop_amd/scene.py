@@ -188,12 +188,52 @@ class PhifDataset:
     def nextStep(self):
         self.stepIdx += 1
 
+    def selection(self):
+        """[(sim index, first frame)] of the current batch / step (what getData assembles)."""
+        return [self.epoch[self.batchIdx + i][self.stepIdx] for i in range(self.batchSize)]
+
     def getData(self, consecutive_frames, with_skip=1):
-        sel = [self.epoch[self.batchIdx + i][self.stepIdx] for i in range(self.batchSize)]
+        sel = self.selection()
         frames = lambda k: [np.concatenate([self.dataPreloaded[self.dataSims[s]][f + j * with_skip][k] for (s, f) in sel], axis=0)
                             for j in range(consecutive_frames + 1)]
         ext = [self.extConstChannelPerSim[self.dataSims[s]][0] for (s, _) in sel]
         return [frames(0), frames(1), ext]
+
+
+class ResidentFrames:
+    """The pre-loaded (down-sampled) frames of a PhifDataset resident in device memory (the whole
+    6 x 500-frame set of the reference's recipe is ~300 MB), split into the solver's layouts once:
+    dens [S,F,Y,X], vy [S,F,Y+1,X], vx [S,F,Y,X+1].  A training batch is then a device-side gather of (sim, frame) windows
+    into the trainer's persistent buffers -- no per-step host concatenation, no pageable 20 MB host-to-device copy."""
+
+    def __init__(self, dataset, device):
+        import torch
+        sims = dataset.dataSims
+        pre = dataset.dataPreloaded
+        F = len(pre[sims[0]])
+        dens = np.stack([np.stack([pre[s][i][0][0, ..., 0] for i in range(F)]) for s in sims])
+        velo = [[split_staggered(pre[s][i][1]) for i in range(F)] for s in sims]
+        vy = np.stack([np.stack([velo[j][i][0][0] for i in range(F)]) for j in range(len(sims))])
+        vx = np.stack([np.stack([velo[j][i][1][0] for i in range(F)]) for j in range(len(sims))])
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+        self.dens, self.vy, self.vx = up(dens), up(vy), up(vx)
+        self.re = torch.tensor([float(dataset.extConstChannelPerSim[s][0]) for s in sims], dtype=torch.float32, device=device)
+        self.device = device
+        self.bytes = sum(t.numel() * 4 for t in (self.dens, self.vy, self.vx))
+
+    def gather(self, sel, msteps, d0, vy0, vx0, re, gt_vy, gt_vx, with_skip=1):
+        """sel: [(sim index, first frame)] of this rank's simulations (what PhifDataset.getData selects).  Fills the start
+        state (frame f), the msteps ground-truth frames (f+1 .. f+msteps) and Re, all on the device."""
+        import torch
+        s = torch.tensor([a for a, _ in sel], dtype=torch.long, device=self.device)
+        f = torch.tensor([b for _, b in sel], dtype=torch.long, device=self.device)
+        fr = f[None, :] + (torch.arange(1, msteps + 1, device=self.device) * with_skip)[:, None]      # [msteps, B]
+        torch.index_select(self.re, 0, s, out=re)
+        d0.copy_(self.dens[s, f])
+        vy0.copy_(self.vy[s, f])
+        vx0.copy_(self.vx[s, f])
+        gt_vy.copy_(self.vy[s[None, :], fr])
+        gt_vx.copy_(self.vx[s[None, :], fr])
 
 
 class BurgersDataset(PhifDataset):

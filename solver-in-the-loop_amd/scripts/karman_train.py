@@ -5,11 +5,14 @@ output files as /root/reference/karman-2d/karman_train.py (flags :20-47, dataset
 (SolTrainer.train_step).  Differences, all at the edges: eager PyTorch buffers instead of TF
 placeholders; model files are `model_epochNNNN.pt` / `model.pt` (Keras get_weights() order, torch.save)
 instead of .h5; TensorBoard summaries are replaced by the log lines; one process per GPU under
-torch.distributed.run shards the `-b` simulations of a batch over the ranks (new capability)."""
+torch.distributed.run shards the `-b` simulations of a batch over the ranks (new capability); the down-sampled set stays
+resident in device memory and a batch is a device-side gather (--host-feed restores the reference's per-step host
+assembly + copy); the loss of step i is read back after step i+1 has been enqueued, so logging never idles the GPU."""
 import argparse
 import os
 import pickle
 import random
+import time
 
 import numpy as np
 import torch
@@ -44,6 +47,8 @@ def main(argv=None):
     p.add_argument("--inittf", default=None, help="load initial model weights (warm start)")
     p.add_argument("--pretf", default=None, help="load pre-trained weights (only for testing pre-trained supervised model; do not use for a warm start!)")
     p.add_argument("--tf", default="/tmp/phiflow/tf", help="path to an output dir (model, logs, etc.)")
+    p.add_argument("--host-feed", action="store_true", help="assemble every batch on the host and copy it (the reference's feed_dict path) "
+                                                            "instead of gathering from the device-resident set")
     params = vars(p.parse_args(argv))
     select_gpu(params["gpu"])
     rank, world, local = sol_amd.dist.init_from_env()
@@ -115,8 +120,23 @@ def main(argv=None):
     d0, vy0, vx0, re = f32((Bl, Y, X)), f32((Bl, Y + 1, X)), f32((Bl, Y, X + 1)), f32((Bl,))
     gt_vy, gt_vx = f32((ms, Bl, Y + 1, X)), f32((ms, Bl, Y, X + 1))
 
+    resident = None if params["host_feed"] else scene.ResidentFrames(dataset, dev)
+    if resident is not None:
+        log.info("training set resident on {}: {:.1f} MB".format(dev, resident.bytes / 2 ** 20))
+    # loss read-back: step i's scalar goes to pinned host memory asynchronously and is logged once step i+1 is enqueued
+    host_loss = [torch.zeros(1, dtype=torch.float32).pin_memory() for _ in range(2)]
+    copied = [torch.cuda.Event() for _ in range(2)]
+    pending = None                      # (slot, log prefix)
+    stats = {"steps": 0, "t0": None}
+
+    def flush(p):
+        copied[p[0]].synchronize()
+        log.info(p[1].format(float(host_loss[p[0]][0])))
+        return float(host_loss[p[0]][0])
+
     current_lr = params["lr"]
     loss = None
+    nstep = 0
     for j in range(params["epochs"]):
         dataset.newEpoch(exclude_tail=ms)
         if j < params["resume"]:
@@ -125,19 +145,37 @@ def main(argv=None):
         current_lr = sol_amd.lr_schedule(j, current_lr) if params["adplr"] else params["lr"]
         for ib in range(dataset.numOfBatchs):
             for i in range(dataset.numOfSteps):
-                dens, velo, ext = dataset.getData(consecutive_frames=ms, with_skip=1)
-                vy, vx = zip(*[scene.split_staggered(v[lo:hi]) for v in velo])
-                d0.copy_(torch.from_numpy(dens[0][lo:hi, ..., 0]))
-                vy0.copy_(torch.from_numpy(vy[0])); vx0.copy_(torch.from_numpy(vx[0]))
-                gt_vy.copy_(torch.from_numpy(np.stack(vy[1:]))); gt_vx.copy_(torch.from_numpy(np.stack(vx[1:])))
-                re.copy_(torch.as_tensor(ext[lo:hi], dtype=torch.float32))
-                loss = trainer.train_step(d0, vy0, vx0, re, gt_vy, gt_vx, current_lr)
-                log.info("epoch {:03d}/{:03d}, batch {:03d}/{:03d}, step {:04d}/{:04d}: loss={}".format(
-                    j + 1, params["epochs"], ib + 1, dataset.numOfBatchs, i + 1, dataset.numOfSteps, float(loss)))
+                if resident is not None:
+                    resident.gather(dataset.selection()[lo:hi], ms, d0, vy0, vx0, re, gt_vy, gt_vx)
+                else:
+                    dens, velo, ext = dataset.getData(consecutive_frames=ms, with_skip=1)
+                    vy, vx = zip(*[scene.split_staggered(v[lo:hi]) for v in velo])
+                    d0.copy_(torch.from_numpy(dens[0][lo:hi, ..., 0]))
+                    vy0.copy_(torch.from_numpy(vy[0])); vx0.copy_(torch.from_numpy(vx[0]))
+                    gt_vy.copy_(torch.from_numpy(np.stack(vy[1:]))); gt_vx.copy_(torch.from_numpy(np.stack(vx[1:])))
+                    re.copy_(torch.as_tensor(ext[lo:hi], dtype=torch.float32))
+                loss_t = trainer.train_step(d0, vy0, vx0, re, gt_vy, gt_vx, current_lr)
+                slot = nstep & 1
+                host_loss[slot].copy_(loss_t.detach().reshape(1), non_blocking=True)
+                copied[slot].record()
+                if pending is not None:
+                    loss = flush(pending)
+                pending = (slot, "epoch {:03d}/{:03d}, batch {:03d}/{:03d}, step {:04d}/{:04d}: loss={{}}".format(
+                    j + 1, params["epochs"], ib + 1, dataset.numOfBatchs, i + 1, dataset.numOfSteps))
+                nstep += 1
+                if nstep == 4:                      # steady state: graph captured, allocator warm
+                    torch.cuda.synchronize()
+                    stats["t0"] = time.perf_counter()
                 dataset.nextStep()
             dataset.nextBatch()
         if j % 10 == 9 and rank == 0:
             model.save(params["tf"] + "/model_epoch{:04d}.pt".format(j + 1))
+    if pending is not None:
+        loss = flush(pending)
+    if stats["t0"] is not None and nstep > 4:
+        torch.cuda.synchronize()
+        main.last_ms_per_step = (time.perf_counter() - stats["t0"]) / (nstep - 4) * 1e3
+        log.info("steady state: {:.3f} ms per training step over {} steps".format(main.last_ms_per_step, nstep - 4))
     if rank == 0:
         model.save(params["tf"] + "/model.pt")
     return None if loss is None else float(loss)

@@ -1095,3 +1095,77 @@ def test_burgers_fused_trainer_graph_equals_eager_and_oracle(noforce, ms):
 
 
 
+
+
+# ---------------------------------------------------------------------------------------------
+# Burgers roll-out (burgers_apply.py:129-151)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("noforce,use_graph", [(False, True), (False, False), (True, True)])
+def test_burgers_rollout_against_oracle(noforce, use_graph):
+    """BurgersRollout: 10 corrected steps (solver step with the PREVIOUS force frame, network input with the CURRENT one, as
+    burgers_apply.py:131-134 does) against the float64 oracle; the replayed hipGraph equals the eager composition."""
+    B, Y, X, dt, nsteps = 2, 32, 32, 0.1, 10
+    gen = torch.Generator().manual_seed(21)
+    sm = lambda *shape: o._smooth(torch.randn(*shape, generator=gen, dtype=torch.float64))
+    std_v, std_f = (0.21, 0.19), (0.09, 0.11)
+    cin = 2 if noforce else 4
+    dom = sol_amd.Domain([Y, X], box=sol_amd.box([32, 32]), boundaries=sol_amd.PERIODIC)
+    vy, vx = 0.3 * sm(B, Y + 1, X), 0.3 * sm(B, Y, X + 1)
+    fy = [0.15 * sm(B, Y + 1, X) for _ in range(nsteps + 1)]
+    fx = [0.15 * sm(B, Y, X + 1) for _ in range(nsteps + 1)]
+    params = [p.clone() for p in o.init_params(3, cin=cin)]
+    params[22] = params[22] * 0.1
+    net = sol_amd.model_mars_moon(cin=cin, cout=2, seed=0)
+    net.set_weights([p.numpy() for p in params])
+    ro = sol_amd.BurgersRollout(net, dom, B, dt, std_v, std_f, noforce=noforce, use_graph=use_graph)
+    ro.reset(o.staggered_tensor(vy, vx))
+    sv = torch.tensor(std_v)
+    ry, rx = vy, vx
+    for i in range(1, nsteps + 1):
+        ro.step(None if noforce else o.staggered_tensor(fy[i - 1], fx[i - 1]), None if noforce else o.staggered_tensor(fy[i], fx[i]))
+        with torch.no_grad():
+            ry, rx = o.burgers_step(ry, rx, dt, 0.1, None if noforce else fy[i - 1], None if noforce else fx[i - 1])
+            feat = o.staggered_tensor(ry, rx)[:, :-1, :-1, :] / sv
+            if not noforce:
+                feat = torch.cat([feat, o.staggered_tensor(fy[i], fx[i])[:, :-1, :-1, :] / torch.tensor(std_f)], dim=-1)
+            cy, cx = o.to_staggered(o.mars_moon(params, feat) * sv)
+            ry, rx = ry + cy, rx + cx
+    torch.cuda.synchronize()
+    assert (ro._graph is not None) == use_graph
+    assert rel(ro.vel, o.staggered_tensor(ry, rx)) < TOL_FIELD, rel(ro.vel, o.staggered_tensor(ry, rx))
+    assert rel(ro.corr, o.staggered_tensor(cy, cx)) < 1e-4 and float(ro.corr.abs().max()) > 0
+
+
+def test_burgers_apply_script(tmp_path):
+    """scripts/burgers_apply.py (flags of burgers_apply.py:22-33): velTf / corTf frames of a forced roll-out from force files."""
+    import importlib.util
+    import pickle
+    import sys
+    from sol_amd import scene
+    sdir = os.path.join(os.path.dirname(os.path.abspath(sol_amd.__file__)), "scripts")
+    sys.path.insert(0, sdir)
+    spec = importlib.util.spec_from_file_location("sol_script_burgers_apply", os.path.join(sdir, "burgers_apply.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res, steps = 32, 6
+    gen = torch.Generator().manual_seed(5)
+    fdir = scene.scene_create(str(tmp_path / "forces"))
+    for i in range(steps):
+        fr = 0.15 * sol_amd.synthetic._smooth(torch.randn(1, res + 1, res + 1, generator=gen, dtype=torch.float64)).unsqueeze(-1).repeat(1, 1, 1, 2)
+        scene.scene_write(fdir, [fr.numpy().astype(np.float32)], ["forc"], i)
+    net = sol_amd.model_mars_moon(cin=4, cout=2, seed=1)
+    with torch.no_grad():
+        net.tensors()[22].mul_(0.1)
+    net.save(str(tmp_path / "model.pt"))
+    with open(tmp_path / "dataStats.pickle", "wb") as f:
+        pickle.dump({"std": [(0.3, 0.3), (0.1, 0.1)]}, f)
+    out = mod.main(["-r", str(res), "-l", "32", "-t", str(steps), "--dt", "0.1", "-s", "1", "--loadfH", fdir + "/forc_0*.npz",
+                    "-o", str(tmp_path / "run"), "--stats", str(tmp_path / "dataStats.pickle"), "--model", str(tmp_path / "model.pt")])
+    v = scene.read_zipped_array(out + "/velTf_%06d.npz" % (steps - 1))
+    c = scene.read_zipped_array(out + "/corTf_%06d.npz" % (steps - 1))
+    assert v.shape == (1, res + 1, res + 1, 2) and c.shape == v.shape and np.isfinite(v).all() and np.abs(c).max() > 0
+    v0 = scene.read_zipped_array(out + "/velTf_000000.npz")
+    assert np.abs(v - v0).max() > 0
+    with pytest.raises(SystemExit):
+        mod.main(["-r", str(res), "-t", "3", "-o", str(tmp_path / "run2"), "--stats", str(tmp_path / "dataStats.pickle"),
+                  "--model", str(tmp_path / "model.pt")])          # forces required unless --noforce

@@ -70,3 +70,27 @@ def test_phif_dataset_stats_and_batches(tmp_path):
     # skip_preprocessing reuses the cached ds_ files
     ds2 = scene.PhifDataset(str(tmp_path), 5, 2, 2, print_fn=logs.append, skip_preprocessing=True, scale=4)
     assert np.array_equal(ds2.dataPreloaded[ds2.dataSims[0]][0][1], ds.dataPreloaded[ds.dataSims[0]][0][1])
+
+
+def test_resident_frames_gather_equals_host_assembly(tmp_path):
+    """ResidentFrames (the set kept in device memory): the device-side gather of (sim, frame) windows fills the
+    trainer's buffers exactly as the reference-shaped host path (getData + split + stack) does.  (device = cpu here.)"""
+    import torch
+    _fake_set(tmp_path, nsims=3, frames=7)
+    ds = scene.PhifDataset(str(tmp_path), 7, 3, 3, print_fn=lambda *a: None, scale=1)
+    ms = 3
+    ds.newEpoch(exclude_tail=ms)
+    ds.nextStep()
+    res = scene.ResidentFrames(ds, "cpu")
+    Y, X = ds.resolution
+    B = 2                                         # this "rank" owns simulations 1..2 of the batch of 3
+    f32 = lambda *s: torch.zeros(*s, dtype=torch.float32)
+    d0, vy0, vx0, re = f32(B, Y, X), f32(B, Y + 1, X), f32(B, Y, X + 1), f32(B)
+    gvy, gvx = f32(ms, B, Y + 1, X), f32(ms, B, Y, X + 1)
+    res.gather(ds.selection()[1:3], ms, d0, vy0, vx0, re, gvy, gvx)
+    dens, velo, ext = ds.getData(consecutive_frames=ms)
+    vy, vx = zip(*[scene.split_staggered(v[1:3]) for v in velo])
+    assert np.array_equal(d0.numpy(), dens[0][1:3, ..., 0]) and np.array_equal(vy0.numpy(), vy[0]) and np.array_equal(vx0.numpy(), vx[0])
+    assert np.array_equal(gvy.numpy(), np.stack(vy[1:])) and np.array_equal(gvx.numpy(), np.stack(vx[1:]))
+    assert np.allclose(re.numpy(), np.asarray(ext[1:3], dtype=np.float32))
+    assert res.bytes == 3 * 7 * 4 * (Y * X + (Y + 1) * X + Y * (X + 1))
