@@ -51,6 +51,7 @@ class KarmanGeometry:
     Y: int
     X: int
     length: float = 100.0
+    inflow_antialias: bool = False       # Q3: GeometryMask anti-aliasing of the Inflow box; recalled default off
     dx: float = field(init=False)
     inflow: np.ndarray = field(init=False)      # [Y,X]   1 where cell centre in box[5:10,25:75]
     obstacle: np.ndarray = field(init=False)    # [Y,X]   1 where cell centre inside the sphere
@@ -69,6 +70,13 @@ class KarmanGeometry:
         YC, XC = np.meshgrid(yc, xc, indexing="ij")
         # Box.value_at: inclusive on both sides  [EXT-RECALL A.4]
         self.inflow = ((YC >= 5.0) & (YC <= 10.0) & (XC >= 25.0) & (XC <= 75.0)).astype(np.float64)
+        if self.inflow_antialias:
+            # anti-aliased variant: linear ramp of one cell width across the box surface, clip(0.5 - sdf/dx, 0, 1) with the
+            # signed distance of the cell centre to the box [EXT-RECALL: later PhiFlow 1.x GeometryMask(antialias=True)]
+            qy = np.abs(YC - 7.5) - 2.5
+            qx = np.abs(XC - 50.0) - 25.0
+            sdf = np.sqrt(np.maximum(qy, 0) ** 2 + np.maximum(qx, 0) ** 2) + np.minimum(np.maximum(qy, qx), 0)
+            self.inflow = np.clip(0.5 - sdf / self.dx, 0.0, 1.0)
         # Sphere.value_at: dist^2 <= r^2  [EXT-RECALL A.6]
         self.obstacle = (((YC - 50.0) ** 2 + (XC - 50.0) ** 2) <= 10.0 ** 2).astype(np.float64)
         self.active = 1.0 - self.obstacle
@@ -112,10 +120,10 @@ class KarmanGeometry:
 _GEOM_CACHE = {}
 
 
-def geometry(Y, X, length=100.0):
-    key = (Y, X, float(length))
+def geometry(Y, X, length=100.0, inflow_antialias=False):
+    key = (Y, X, float(length), bool(inflow_antialias))
     if key not in _GEOM_CACHE:
-        _GEOM_CACHE[key] = KarmanGeometry(Y, X, length)
+        _GEOM_CACHE[key] = KarmanGeometry(Y, X, length, inflow_antialias)
     return _GEOM_CACHE[key]
 
 
@@ -152,8 +160,13 @@ def _sample(fld, ly, lx, mode):
     mode 'replicate': clamp indices (extrapolation 'boundary');
     mode 'zero': one ring of zero ghost cells, coords clamped onto it (extrapolation
                  'constant', PhiFlow pad_constant_boundaries)  [EXT-RECALL A.5];
+    mode 'zero_box': Q4 alternative -- zero strictly outside the field's box (local coordinate beyond the outer cell FACES),
+                 edge-clamped bilinear inside it (no half-cell blend towards a ghost ring);
     mode 'circular': indices modulo the array length (extrapolation 'periodic')."""
     B, H, W = fld.shape
+    if mode == "zero_box":
+        inside = ((ly >= -0.5) & (ly <= H - 0.5) & (lx >= -0.5) & (lx <= W - 0.5)).to(fld.dtype)
+        return inside * _sample(fld, ly, lx, "replicate")
     if mode == "zero":
         fld = F.pad(fld, (1, 1, 1, 1))
         ly = ly + 1.0
@@ -335,17 +348,21 @@ def project(vy, vx, geom, grad_pad="replicate", solver="direct", return_info=Fal
 # full solver step  (KarmanFlow.step, karman_train.py:173-185)
 # --------------------------------------------------------------------------------------
 def karman_step(d, vy, vx, re, geom, dt=1.0, res=None, grad_pad="replicate", solver="direct",
-                inflow_order="after"):
+                inflow_order="after", den_mode="zero"):
     """One `simulator_lo.step(...)`:
        diffuse + BC (karman_train.py:175-183)  ->  IncompressibleFlow.step [EXT-RECALL A.4]:
        density = SL(density, v); v = SL(v, v); density += inflow*dt; v = divergence_free(v).
-       inflow_order 'before' reproduces the phi2 variant (karman-2d-phi2/karman_train.py:182)."""
+       inflow_order 'before' reproduces the phi2 variant (karman-2d-phi2/karman_train.py:182).
+       Switchable recalled choices: Q2 inflow_order, Q3 geometry(..., inflow_antialias=), Q4 den_mode
+       ('zero' ghost ring | 'zero_box'), Q5 grad_pad, Q6 solver ('direct' = converged solve | 'cg' = SparseCG restatement with
+       accuracy 1e-5 and the batch-global stop); Q7 is burgers_step(periodic_faces=).  The HIP path implements the defaults
+       plus Q2, Q3 (the inflow mask is an input array), Q5 and any converged solve for Q6."""
     res = geom.X if res is None else res
     cy, cx = diffuse_bc(vy, vx, re, res, dt, geom)
     infl = _t(geom.inflow, vy)
     if inflow_order == "before":
         d = d + infl            # phi2: advect(density + inflow)
-    d2, ay, ax = advect_mac(d, cy, cx, dt, geom.dx)
+    d2, ay, ax = advect_mac(d, cy, cx, dt, geom.dx, den_mode=den_mode)
     if inflow_order == "after":
         d2 = d2 + infl * dt
     py, px = project(ay, ax, geom, grad_pad=grad_pad, solver=solver)
@@ -535,17 +552,37 @@ def burgers_diffusion_matrices(H, W, amount, dtype=torch.float64):
     return circ(H), circ(W)
 
 
-def burgers_step(vy, vx, dt, nu=0.1, fy=None, fx=None, dx=1.0, diffusion="fft"):
+def burgers_step(vy, vx, dt, nu=0.1, fy=None, fx=None, dx=1.0, diffusion="fft", periodic_faces="array"):
     """BurgersTest.step / step_with_f (burgers_train.py:182-187) -> PhiFlow Burgers.step:
     v = SL(v, v, dt); v = diffuse(v, dt*nu) (periodic -> FFT) [EXT-RECALL A.9]; v += dt*f.
-    Periodic staggered components keep the duplicated +1 face; sampling wraps modulo the
-    array length (Q7)."""
-    _, ay, ax = advect_mac(None, vy, vx, dt, dx, vel_mode="circular")
-    if diffusion == "fft":
-        ay = diffuse_periodic_fft(ay, dt * nu)
-        ax = diffuse_periodic_fft(ax, dt * nu)
+    Q7, handling of the duplicated +1 face of a periodic staggered component:
+      periodic_faces 'array' (default, recalled): the component arrays keep Y+1 / X+1 faces and sampling / the FFT wrap
+        modulo the ARRAY length;
+      periodic_faces 'domain': the duplicated face is a copy of face 0 -- advection and diffusion act on the Y (X) distinct
+        faces, wrapping modulo the domain resolution, and the copy is re-attached afterwards."""
+    if periodic_faces == "domain":
+        cy, cx = vy[:, :-1, :], vx[:, :, :-1]
+        B, Y, X = cy.shape
+        out = []
+        for kind, fld in (("y", cy), ("x", cx)):
+            py, px = _points(kind, Y, X, dx, vy)
+            py = py[:Y, :X].unsqueeze(0).expand(B, -1, -1)
+            px = px[:Y, :X].unsqueeze(0).expand(B, -1, -1)
+            uy = _sample(cy, *_local("y", py, px, dx), "circular")
+            ux = _sample(cx, *_local("x", py, px, dx), "circular")
+            a = _sample(fld, *_local(kind, py - uy * dt, px - ux * dt, dx), "circular")
+            out.append(diffuse_periodic_fft(a, dt * nu))
+        ay = torch.cat([out[0], out[0][:, :1, :]], dim=1)
+        ax = torch.cat([out[1], out[1][:, :, :1]], dim=2)
+    elif periodic_faces == "array":
+        _, ay, ax = advect_mac(None, vy, vx, dt, dx, vel_mode="circular")
+        if diffusion == "fft":
+            ay = diffuse_periodic_fft(ay, dt * nu)
+            ax = diffuse_periodic_fft(ax, dt * nu)
+        else:
+            raise ValueError(diffusion)
     else:
-        raise ValueError(diffusion)
+        raise ValueError(periodic_faces)
     if fy is not None:
         ay = ay + dt * fy
         ax = ax + dt * fx

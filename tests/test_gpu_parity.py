@@ -1169,3 +1169,70 @@ def test_burgers_apply_script(tmp_path):
     with pytest.raises(SystemExit):
         mod.main(["-r", str(res), "-t", "3", "-o", str(tmp_path / "run2"), "--stats", str(tmp_path / "dataStats.pickle"),
                   "--model", str(tmp_path / "model.pt")])          # forces required unless --noforce
+
+
+# ---------------------------------------------------------------------------------------------
+# real-data training loop at graph speed
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.timeout(900)
+def test_real_data_training_loop_runs_at_graph_speed(tmp_path):
+    """scripts/karman_train.py on a generated 128 x 64 set (6 simulations, SOL-32, the BASELINE configs[2] shape): with the
+    set resident on the device and the loss read back one step late, a training step of the script costs what a replay of
+    the captured graph on persistent synthetic buffers costs (bench.py's number).  --host-feed (the reference's per-step
+    host assembly + pageable copy + float(loss)) is timed next to it."""
+    import importlib.util
+    import sys
+    sdir = os.path.join(os.path.dirname(os.path.abspath(sol_amd.__file__)), "scripts")
+    sys.path.insert(0, sdir)
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location("sol_script_" + name, os.path.join(sdir, name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    B, Y, X, ms, frames = 6, 128, 64, 32, 47
+    data = str(tmp_path / "set")
+    for k in range(B):
+        load("karman").main(["-o", data, "-r", str(X), "-t", str(frames + 2), "-s", "1", "--re", str(o.RE_TRAIN[k])])
+    kt = load("karman_train")
+    args = ["--train", data, "-s", "1", "-n", str(B), "-b", str(B), "-t", str(frames), "-m", str(ms), "-e", "1", "--lr", "1e-6", "--seed", "0"]
+    loss = kt.main(args + ["--tf", str(tmp_path / "tf")])
+    t_res = kt.main.last_ms_per_step
+    assert loss is not None and np.isfinite(loss)
+    loss_h = kt.main(args + ["--tf", str(tmp_path / "tf_h"), "--host-feed"])
+    t_host = kt.main.last_ms_per_step
+    assert abs(loss_h - loss) <= 1e-5 * abs(loss)               # same batches, same arithmetic: the feed path changes nothing
+    # the synthetic replay of the same shape
+    g, mk = masks_for(Y, X)
+    net = sol_amd.model_mars_moon(cin=3, cout=2, seed=0)
+    tr = sol_amd.SolTrainer(net, mk, B, Y, X, ms, g.dx, (0.2, 0.2), o.STD_RE)
+    d, vy, vx = (f32(t) for t in sol_amd.synthetic.state(B, Y, X, 3))
+    gy, gx = (f32(t) for t in sol_amd.synthetic.frames(ms, B, Y, X, 9))
+    re = f32(sol_amd.synthetic.reynolds(B))
+    for _ in range(4):
+        tr.train_step(d, vy, vx, re, gy, gx, lr=1e-9)
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    n = frames - ms - 4
+    for _ in range(n):
+        tr.train_step(d, vy, vx, re, gy, gx, lr=1e-9)
+    torch.cuda.synchronize()
+    t_syn = (time.perf_counter() - t0) / n * 1e3
+    print("real-data loop: resident %.3f ms/step, host-feed %.3f ms/step, synthetic replay %.3f ms/step" % (t_res, t_host, t_syn))
+    assert t_res <= 1.10 * t_syn, (t_res, t_syn)
+
+
+def test_q3_antialiased_inflow_mask_through_the_hip_step():
+    """the inflow rate mask is an INPUT array of the HIP step, so the anti-aliased variant of the
+    recalled GeometryMask semantics runs unchanged (fractional rates)."""
+    B, Y, X = 2, 64, 32
+    g = o.geometry(Y, X, inflow_antialias=True)
+    mk = ops.SceneMasks(g.active, g.inflow, g.bc_mask, g.bc_mask)
+    d, vy, vx = o.synthetic_state(B, Y, X, 8)
+    re = torch.tensor(o.RE_TRAIN[:B], dtype=torch.float64)
+    rd, ry, rx = o.karman_step(d, vy, vx, re, g)
+    hd, hy, hx = ops.karman_step(f32(d), f32(vy), f32(vx), f32(re), ops.karman_cfg(B, Y, X, g.dx, masks=mk), mk)
+    assert rel(hd, rd) < TOL_FIELD and rel(hy, ry) < TOL_FIELD and rel(hx, rx) < TOL_FIELD
+    assert float((rd - o.karman_step(d, vy, vx, re, o.geometry(Y, X))[0]).abs().max()) > 1e-3        # the option does change the density

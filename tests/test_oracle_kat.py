@@ -203,3 +203,63 @@ def test_step_autograd_matches_finite_differences():
             b = (tm, vx.detach()) if t is vy else (vy.detach(), tm)
             fd = (fn(*a) - fn(*b)) / (2 * eps)
             assert abs(fd - gr[idx]) < 1e-5 * max(1.0, abs(fd)), (idx, fd, gr[idx])
+
+
+# ---------------------------------------------------------------------------------------------
+# the recalled PhiFlow choices are switchable
+# ---------------------------------------------------------------------------------------------
+def test_q3_inflow_antialias_option():
+    g0, g1 = o.geometry(64, 32), o.geometry(64, 32, inflow_antialias=True)
+    assert g0.inflow.sum() == 16 and set(np.unique(g0.inflow)) == {0.0, 1.0}
+    # anti-aliased: a one-cell linear ramp -- fractional values appear, cells well inside stay 1, the integral is the box area
+    assert 0.0 < g1.inflow[g1.inflow > 0].min() < 1.0 and g1.inflow.max() == 1.0
+    assert abs(g1.inflow.sum() * g1.dx ** 2 - 5.0 * 50.0) < 0.25 * 5.0 * 50.0
+    assert np.array_equal(g0.active, g1.active) and np.array_equal(g0.my, g1.my)        # the obstacle / pressure matrix are untouched
+
+
+def test_q4_density_extrapolation_variants():
+    f = torch.ones(1, 4, 4)
+    ly = torch.tensor([[[-0.5, -0.25, -0.75, 1.5]]])
+    lx = torch.full_like(ly, 1.0)
+    ring = o._sample(f, ly, lx, "zero")          # blends to the zero ghost cell centre at -1
+    box = o._sample(f, ly, lx, "zero_box")       # 1 inside the box (edge at -0.5), 0 outside
+    assert torch.allclose(ring, torch.tensor([[[0.5, 0.75, 0.25, 1.0]]]))
+    assert torch.allclose(box, torch.tensor([[[1.0, 1.0, 0.0, 1.0]]]))
+    # in a step the two differ only next to the open boundary
+    g = o.geometry(16, 8)
+    d, vy, vx = o.synthetic_state(1, 16, 8, 3)
+    re = torch.tensor([1e5])
+    a = o.karman_step(d, vy, vx, re, g)[0]
+    b = o.karman_step(d, vy, vx, re, g, den_mode="zero_box")[0]
+    assert torch.allclose(a[:, 2:-2, 2:-2], b[:, 2:-2, 2:-2]) and not torch.allclose(a, b)
+
+
+def test_q6_sparse_cg_restatement_vs_converged_solve():
+    g = o.geometry(32, 16)
+    d, vy, vx = o.synthetic_state(2, 32, 16, 9, project_it=False)
+    re = torch.tensor([1e5, 2e5])
+    a = o.karman_step(d, vy, vx, re, g, solver="direct")
+    b = o.karman_step(d, vy, vx, re, g, solver="cg")            # accuracy 1e-5 on max|r|, batch-global stop
+    err = float((a[1] - b[1]).abs().max())
+    assert 0.0 < err < 1e-4
+
+
+def test_q7_periodic_duplicated_face_variants():
+    B, Y, X = 1, 8, 8
+    gen = torch.Generator().manual_seed(0)
+    # a field that IS periodic with a consistent duplicated face
+    cy = torch.randn(B, Y, X, generator=gen) * 0.3
+    cx = torch.randn(B, Y, X, generator=gen) * 0.3
+    vy = torch.cat([cy, cy[:, :1]], dim=1)
+    vx = torch.cat([cx, cx[:, :, :1]], dim=2)
+    ay, ax = o.burgers_step(vy, vx, 0.1, periodic_faces="domain")
+    assert torch.equal(ay[:, -1], ay[:, 0]) and torch.equal(ax[:, :, -1], ax[:, :, 0])      # the copy stays a copy
+    by, bx = o.burgers_step(vy, vx, 0.1, periodic_faces="array")
+    assert by.shape == ay.shape and not torch.allclose(ay, by)                              # the recalled default wraps modulo Y+1
+    # zero velocity, zero viscosity: both are the identity
+    z = torch.zeros_like(vy), torch.zeros_like(vx)
+    for mode in ("array", "domain"):
+        ry, rx = o.burgers_step(*z, 0.1, nu=0.0, fy=vy, fx=vx, periodic_faces=mode)
+        assert torch.allclose(ry, 0.1 * vy) and torch.allclose(rx, 0.1 * vx)
+    with pytest.raises(ValueError):
+        o.burgers_step(vy, vx, 0.1, periodic_faces="nope")
