@@ -463,27 +463,46 @@ def main():
                     del trp
                 except Exception as e:
                     out[leg] = {"error": str(e)}
-            # the reference's own training recipe (karman-2d/Makefile:78-80): 64x32, batch 3, SOL-32
+            # the reference's own training recipe (karman-2d/Makefile:78-80): 64x32, batch 3, SOL-32 -- with the per-layer
+            # conv launches (default) and with the ten 32->32 layers of a CNN pass as ONE persistent launch (option
+            # cnn_persistent: 32 workgroups at this size, where a launch is pure latency)
             if (Y, X, B) == (128, 64, 6) and world == 1:
+                for leg, persistent in (("reference_recipe_64x32_b3", 0), ("reference_recipe_64x32_b3_persistent_cnn", 1)):
+                    if persistent and args.precision != "split":
+                        continue
+                    try:
+                        sol_amd._lib.set_option("cnn_persistent", persistent)          # enters the workspace size: set before the trainer exists
+                        wl2 = Workload(sol_amd, dev, 3, 64, 32, ms, rank, args.precision)
+                        s2, l2, _ = timed_steps(wl2, args.lr, 10, 3, lambda: torch.cuda.synchronize())
+                        out[leg] = {"workload": "karman-2d 64x32 SOL-%d, batch 3 (karman-2d/Makefile:78-80)" % ms, "cnn_persistent": persistent,
+                                    "ms_per_step": s2 / 10 * 1e3, "sim_steps_per_s": 3 * ms * 10 / s2, "loss": l2,
+                                    "cg_iters_fwd_mean": wl2.trainer.solver_algorithmic_bytes()[2]}
+                        del wl2
+                    except Exception as e:
+                        out[leg] = {"error": str(e)}
+                    finally:
+                        sol_amd._lib.set_option("cnn_persistent", 0)
+            # second half of BASELINE.json's metric: no-grad roll-out (karman_apply.py:138-158).  B = 1 is the reference's
+            # script shape (one latency-bound launch after the other on 43 workgroups); B = 6 is the same engine on the
+            # bench batch; "persistent_cnn" = the ten 32->32 layers of a step as one launch (option cnn_persistent)
+            out["rollout"] = {}
+            for leg, rb, persistent in (("b1", 1, 0), ("b1_persistent_cnn", 1, 1), ("b6", B, 0)):
                 try:
-                    wl2 = Workload(sol_amd, dev, 3, 64, 32, ms, rank, args.precision)
-                    s2, l2, _ = timed_steps(wl2, args.lr, 10, 3, lambda: torch.cuda.synchronize())
-                    out["reference_recipe_64x32_b3"] = {"workload": "karman-2d 64x32 SOL-%d, batch 3 (karman-2d/Makefile:78-80)" % ms,
-                                                        "ms_per_step": s2 / 10 * 1e3, "sim_steps_per_s": 3 * ms * 10 / s2, "loss": l2,
-                                                        "cg_iters_fwd_mean": wl2.trainer.solver_algorithmic_bytes()[2]}
-                    del wl2
-                except Exception as e:
-                    out["reference_recipe_64x32_b3"] = {"error": str(e)}
-            # second half of BASELINE.json's metric: no-grad roll-out (karman_apply.py:138-158), B = 1
-            try:
-                ro = sol_amd.SolRollout(wl.net, wl.masks, 1, Y, X, wl.dx, wl.std_v, synthetic.STD_RE)
-                rd, ry, rx = wl.d0[:1].clone(), wl.vy0[:1].clone(), wl.vx0[:1].clone()
-                re1 = wl.re[:1].contiguous()
-                ro.run(rd, ry, rx, re1, 5)
-                t_ro = time_call(lambda: ro.run(rd, ry, rx, re1, 50), 2)
-                out["rollout"] = {"sim_steps_per_s": 50.0 / t_ro, "batch": 1, "steps": 50, "us_per_step": t_ro / 50 * 1e6}
-            except Exception as e:          # never let the extra line break the contract line
-                out["rollout"] = {"error": str(e)}
+                    sol_amd._lib.set_option("cnn_persistent", persistent)
+                    ro = sol_amd.SolRollout(wl.net, wl.masks, rb, Y, X, wl.dx, wl.std_v, synthetic.STD_RE)
+                    rd, ry, rx = wl.d0[:rb].clone(), wl.vy0[:rb].clone(), wl.vx0[:rb].clone()
+                    re1 = wl.re[:rb].contiguous()
+                    ro.run(rd, ry, rx, re1, 6)
+                    t_ro = time_call(lambda: ro.run(rd, ry, rx, re1, 50), 2)
+                    out["rollout"][leg] = {"sim_steps_per_s": 50.0 * rb / t_ro, "batch": rb, "steps": 50, "us_per_step": t_ro / 50 * 1e6,
+                                           "finite": bool(torch.isfinite(ry).all())}
+                    del ro
+                except Exception as e:          # never let the extra line break the contract line
+                    out["rollout"][leg] = {"error": str(e)}
+                finally:
+                    sol_amd._lib.set_option("cnn_persistent", 0)
+            if "b1" in out["rollout"] and "us_per_step" in out["rollout"]["b1"]:
+                out["rollout"].update({k: out["rollout"]["b1"][k] for k in ("sim_steps_per_s", "batch", "steps", "us_per_step")})
         if not args.no_extras and world == 1:
             try:
                 out["karman3d"] = karman3d_leg(sol_amd, dev)
