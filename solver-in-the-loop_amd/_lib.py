@@ -224,6 +224,8 @@ def ptr(t):
         raise SolError("expected a CUDA tensor")
     if not t.is_contiguous():
         raise SolError("expected a contiguous tensor")
+    if t.dtype not in (torch.float32, torch.int32):
+        raise SolError("expected a float32 / int32 tensor (got %s): the C ABI takes 32-bit buffers only" % t.dtype)
     return C.c_void_p(t.data_ptr())
 
 

@@ -200,18 +200,31 @@ __device__ __forceinline__ void advect_point(const K3Args& a, const R& r, int b,
     }
 }
 
+// Work unit of both advection kernels: one z COLUMN (fixed kind, j, i) per wave, lanes along z.  j, i and everything derived
+// from them (array bounds, neighbour rows, "is this row in the LDS region") are wave uniform -- scalar registers and scalar
+// branches; no per-point index decoding (three integer divisions per point cost more than the interpolation itself).
+template <class R>
+__device__ __forceinline__ void advect_column(const K3Args& a, const R& r, int b, int kind, int j, int i, int lane) {
+    const int nk = a.Z + (kind == 2 ? 1 : 0);
+    for (int k = lane; k < nk; k += 64) advect_point(a, r, b, kind, j, i, k);
+}
+
 __global__ void __launch_bounds__(256) k3_advect(K3Args a) {
     const int Y = a.Y, X = a.X, Z = a.Z;
-    const int nVy = (Y + 1) * X * Z, nVx = Y * (X + 1) * Z, nVz = Y * X * (Z + 1), N = Y * X * Z;
+    const int nVy = (Y + 1) * X * Z, nVx = Y * (X + 1) * Z, nVz = Y * X * (Z + 1);
     const int b = blockIdx.y;
     GR r;
     r.sy = a.svy + (size_t)b * nVy; r.sx = a.svx + (size_t)b * nVx; r.sz = a.svz + (size_t)b * nVz; r.Y = Y; r.X = X; r.Z = Z;
-    const int total = nVy + nVx + nVz + (a.d_out ? N : 0);
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        if (e < nVy) advect_point(a, r, b, 0, e / (Z * X), (e / Z) % X, e % Z);
-        else if (e < nVy + nVx) { const int q = e - nVy; advect_point(a, r, b, 1, q / (Z * (X + 1)), (q / Z) % (X + 1), q % Z); }
-        else if (e < nVy + nVx + nVz) { const int q = e - nVy - nVx; advect_point(a, r, b, 2, q / ((Z + 1) * X), (q / (Z + 1)) % X, q % (Z + 1)); }
-        else { const int q = e - nVy - nVx - nVz; advect_point(a, r, b, 3, q / (Z * X), (q / Z) % X, q % Z); }
+    const int cY = (Y + 1) * X, cX = Y * (X + 1), cC = Y * X;        // columns per kind: y faces, x faces, z faces (= cells), cells
+    const int total = cY + cX + cC + (a.d_out ? cC : 0);
+    const int lane = threadIdx.x & 63;
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    for (int c = wave0; c < total; c += nwaves) {
+        if (c < cY) advect_column(a, r, b, 0, c / X, c % X, lane);
+        else if (c < cY + cX) { const int q = c - cY; advect_column(a, r, b, 1, q / (X + 1), q % (X + 1), lane); }
+        else if (c < cY + cX + cC) { const int q = c - cY - cX; advect_column(a, r, b, 2, q / X, q % X, lane); }
+        else { const int q = c - cY - cX - cC; advect_column(a, r, b, 3, q / X, q % X, lane); }
     }
 }
 
@@ -232,28 +245,36 @@ __global__ void __launch_bounds__(ADV_T) k3_advect_tile(K3Args a, int tiles_x) {
     float* lx = ly + (TR + 1) * TR * Z;
     float* lz = lx + TR * (TR + 1) * Z;
     r.ly = ly; r.lx = lx; r.lz = lz;
-    // stage the region (rows / columns outside the arrays are skipped: clamped indices never address them)
-    for (int e = threadIdx.x; e < (TR + 1) * TR * Z; e += ADV_T) {
-        const int k = e % Z, ri = (e / Z) % TR, rj = e / (Z * TR), j = r.j0 + rj, i = r.i0 + ri;
-        if ((unsigned)j <= (unsigned)Y && (unsigned)i < (unsigned)X) ly[e] = r.g.y(j, i, k);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr int NW = ADV_T / 64;
+    // stage the region column by column (rows / columns outside the arrays are skipped: clamped indices never address them)
+    for (int c = wave; c < (TR + 1) * TR; c += NW) {
+        const int rj = c / TR, ri = c % TR, j = r.j0 + rj, i = r.i0 + ri;
+        if ((unsigned)j <= (unsigned)Y && (unsigned)i < (unsigned)X)
+            for (int k = lane; k < Z; k += 64) ly[c * Z + k] = r.g.y(j, i, k);
     }
-    for (int e = threadIdx.x; e < TR * (TR + 1) * Z; e += ADV_T) {
-        const int k = e % Z, ri = (e / Z) % (TR + 1), rj = e / (Z * (TR + 1)), j = r.j0 + rj, i = r.i0 + ri;
-        if ((unsigned)j < (unsigned)Y && (unsigned)i <= (unsigned)X) lx[e] = r.g.x(j, i, k);
+    for (int c = wave; c < TR * (TR + 1); c += NW) {
+        const int rj = c / (TR + 1), ri = c % (TR + 1), j = r.j0 + rj, i = r.i0 + ri;
+        if ((unsigned)j < (unsigned)Y && (unsigned)i <= (unsigned)X)
+            for (int k = lane; k < Z; k += 64) lx[c * Z + k] = r.g.x(j, i, k);
     }
-    for (int e = threadIdx.x; e < TR * TR * (Z + 1); e += ADV_T) {
-        const int k = e % (Z + 1), ri = (e / (Z + 1)) % TR, rj = e / ((Z + 1) * TR), j = r.j0 + rj, i = r.i0 + ri;
-        if ((unsigned)j < (unsigned)Y && (unsigned)i < (unsigned)X) lz[e] = r.g.z(j, i, k);
+    for (int c = wave; c < TR * TR; c += NW) {
+        const int rj = c / TR, ri = c % TR, j = r.j0 + rj, i = r.i0 + ri;
+        if ((unsigned)j < (unsigned)Y && (unsigned)i < (unsigned)X)
+            for (int k = lane; k <= Z; k += 64) lz[c * (Z + 1) + k] = r.g.z(j, i, k);
     }
     __syncthreads();
     const int ny = min(T3, Y - jt) + (jt + T3 >= Y ? 1 : 0);      // y-face rows owned
     const int nx = min(T3, X - it) + (it + T3 >= X ? 1 : 0);      // x-face columns owned
     const int cy = min(T3, Y - jt), cx = min(T3, X - it);         // cells owned
-    for (int e = threadIdx.x; e < ny * cx * Z; e += ADV_T) advect_point(a, r, b, 0, jt + e / (Z * cx), it + (e / Z) % cx, e % Z);
-    for (int e = threadIdx.x; e < cy * nx * Z; e += ADV_T) advect_point(a, r, b, 1, jt + e / (Z * nx), it + (e / Z) % nx, e % Z);
-    for (int e = threadIdx.x; e < cy * cx * (Z + 1); e += ADV_T) advect_point(a, r, b, 2, jt + e / ((Z + 1) * cx), it + (e / (Z + 1)) % cx, e % (Z + 1));
-    if (a.d_out)
-        for (int e = threadIdx.x; e < cy * cx * Z; e += ADV_T) advect_point(a, r, b, 3, jt + e / (Z * cx), it + (e / Z) % cx, e % Z);
+    const int cY = ny * cx, cX = cy * nx, cC = cy * cx;
+    const int total = cY + cX + cC + (a.d_out ? cC : 0);
+    for (int c = wave; c < total; c += NW) {
+        if (c < cY) advect_column(a, r, b, 0, jt + c / cx, it + c % cx, lane);
+        else if (c < cY + cX) { const int q = c - cY; advect_column(a, r, b, 1, jt + q / nx, it + q % nx, lane); }
+        else if (c < cY + cX + cC) { const int q = c - cY - cX; advect_column(a, r, b, 2, jt + q / cx, it + q % cx, lane); }
+        else { const int q = c - cY - cX - cC; advect_column(a, r, b, 3, jt + q / cx, it + q % cx, lane); }
+    }
 }
 
 __global__ void __launch_bounds__(256) k3_div(K3Args a) {
@@ -411,8 +432,9 @@ __global__ void __launch_bounds__(256) k3_ty(const float* __restrict__ in, float
     const int b = blockIdx.y, c0 = blockIdx.x * 32;
     const size_t base = (size_t)b * Y * XZ + c0;
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4;       // outputs: rows ty*8 .. +7 (two passes of 64 rows at Y = 128), cols tx*2, +1
-    for (int e = t; e < Y * Y; e += 256) Q[(e / Y) * QS + e % Y] = Qy[e];
-    for (int e = t; e < Y * 32; e += 256) Fm[(e >> 5) * 36 + (e & 31)] = in[base + (size_t)(e >> 5) * XZ + (e & 31)];
+    const int Y4 = Y >> 2;                   // 16-byte pieces (Y % 16 == 0; rows of Q / Fm are 16-byte aligned: QS, 36 are multiples of 4)
+    for (int e = t; e < Y * Y4; e += 256) *reinterpret_cast<float4*>(&Q[(e / Y4) * QS + (e % Y4) * 4]) = reinterpret_cast<const float4*>(Qy)[e];
+    for (int e = t; e < Y * 8; e += 256) *reinterpret_cast<float4*>(&Fm[(e >> 3) * 36 + (e & 7) * 4]) = *reinterpret_cast<const float4*>(&in[base + (size_t)(e >> 3) * XZ + (e & 7) * 4]);
     __syncthreads();
     const int RP = (Y + 127) / 128 * 8;      // rows per thread: 8 for Y <= 128
     float acc[8][2];
@@ -536,7 +558,7 @@ extern "C" int sol_karman3d_step_fwd(const sol_karman3d_cfg* c, void* stream,
         const int tiles_y = (Y + T3 - 1) / T3, tiles_x = (X + T3 - 1) / T3;
         SOL_LAUNCH(k3_advect_tile, dim3(tiles_y * tiles_x, B), dim3(ADV_T), tile_lds, s, a, tiles_x);
     } else {
-        SOL_LAUNCH(k3_advect, dim3(grid_for(faces + N), B), dim3(256), 0, s, a);
+        SOL_LAUNCH(k3_advect, dim3(grid_for((size_t)((Y + 1) * X + Y * (X + 1) + 2 * Y * X) * 64), B), dim3(256), 0, s, a);
     }
     SOL_LAUNCH(k3_div, dim3(grid_for(N), B), dim3(256), 0, s, a);
     SOL_LAUNCH_CHECK();

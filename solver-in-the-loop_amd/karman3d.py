@@ -115,7 +115,7 @@ class Karman3DFlow:
 # ---------------------------------------------------------------------------------------------------------------------
 class MarsMoon3D:
     """12 Conv3D(5, padding='same') layers, 32 features, five residual blocks (karman_train.py:101-138 in 3-D): 4 -> 32,
-    10 x 32 -> 32, 32 -> 3; 1 048 675 parameters in ONE flat fp32 buffer in Keras get_weights() order (kernels DHWIO).
+    10 x 32 -> 32, 32 -> 3; 1 308 355 parameters in ONE flat fp32 buffer in Keras get_weights() order (kernels DHWIO).
     Keras defaults: glorot_uniform kernels, zero biases, LeakyReLU(alpha=0.3)."""
     name = "mars_moon3d"
     slope = 0.3
@@ -207,8 +207,11 @@ class Karman3DRollout:
 
     def correction(self):
         """self.feat -> self.out (the network), publishing / consuming the per-tensor absmax of every 32-channel tensor."""
-        from .trainer import _apply_conv_precision
-        _apply_conv_precision(self.conv_precision)
+        from .trainer import _conv_precision_scope
+        with _conv_precision_scope(self.conv_precision):
+            return self._correction()
+
+    def _correction(self):
         pk = self.net.pack()
         sl = self.net.slope
         self.amax.zero_()

@@ -36,6 +36,25 @@ def _apply_conv_precision(code):
         _lib.set_option("conv_precision", code)
 
 
+class _conv_precision_scope:
+    """The library's `conv_precision` option is process wide; a trainer / roll-out sets ITS value for the duration of a call
+    and puts the previous one back, so objects of different precision can alternate and nothing leaks into later calls of
+    the per-op API (None: leave the option alone)."""
+
+    def __init__(self, code):
+        self.code = code
+
+    def __enter__(self):
+        if self.code is not None:
+            self.prev = _lib.get_option("conv_precision")
+            _lib.set_option("conv_precision", self.code)
+
+    def __exit__(self, *exc):
+        if self.code is not None:
+            _lib.set_option("conv_precision", self.prev)
+        return False
+
+
 class SolTrainer:
     def __init__(self, net, masks, B, Y, X, msteps, dx, std_v, std_re, dt=1.0, res=None,
                  clip_grad=False, beta1=0.9, beta2=0.999, eps=1e-8, group=None, use_graph=True,
@@ -44,12 +63,12 @@ class SolTrainer:
         """conv_precision: arithmetic of the 32-channel convolutions (library option `conv_precision`):
         "split" (default) fp32-equivalent fp16x3 / bf16x6 operand splits on the 16-bit matrix pipe, "bf16x6",
         or "fp32" = strict fp32 MFMA.  The option is process wide in the library; every call of this trainer sets
-        it, so trainers of different precision can alternate in one process.  None keeps whatever the option table holds
+        it for the duration of the call (and restores the previous value), so trainers of different precision can alternate in
+        one process.  None keeps whatever the option table holds
         (e.g. a SOL_CONV_NO_SB / SOL_CONV_NO_FP16 debugging override applied when the library was loaded)."""
         _lib.require_gpu()
         self.lib = _lib.load()
         self.conv_precision = _conv_precision_code(conv_precision)
-        _apply_conv_precision(self.conv_precision)
         assert net.name == "mars_moon", "the fused trainer implements model_mars_moon (the reference default)"
         self.net, self.masks = net, masks
         self.B, self.Y, self.X, self.msteps = B, Y, X, msteps
@@ -107,7 +126,11 @@ class SolTrainer:
         B, Y, X, ms = self.B, self.Y, self.X, self.msteps
         assert vy0.shape == (B, Y + 1, X) and vx0.shape == (B, Y, X + 1) and d0.shape == (B, Y, X)
         assert gt_vy.shape == (ms, B, Y + 1, X) and gt_vx.shape == (ms, B, Y, X + 1) and re.shape == (B,)
-        _apply_conv_precision(self.conv_precision)
+        with _conv_precision_scope(self.conv_precision):
+            return self._fwd_bwd(d0, vy0, vx0, re, gt_vy, gt_vx, want_final, eager)
+
+    def _fwd_bwd(self, d0, vy0, vx0, re, gt_vy, gt_vx, want_final, eager):
+        B, Y, X, ms = self.B, self.Y, self.X, self.msteps
         if self._stage is not None and not eager:
             for dst, src in zip(self._stage, (d0, vy0, vx0, re, gt_vy, gt_vx)):
                 dst.copy_(src)
@@ -134,7 +157,7 @@ class SolTrainer:
                     self._captures += 1
                     if self._captures >= 3 and self._stage is None:
                         self._stage = [t.clone() for t in (d0, vy0, vx0, re, gt_vy, gt_vx)]
-                        return self.fwd_bwd(d0, vy0, vx0, re, gt_vy, gt_vx, want_final=want_final)
+                        return self._fwd_bwd(d0, vy0, vx0, re, gt_vy, gt_vx, want_final, eager)
                     check(self.lib.sol_train_graph_destroy(cur[1]))
                     del self._graphs[slot]
                 h = C.c_void_p()
@@ -208,10 +231,10 @@ class SolRollout:
         """Advances (d, vy, vx) in place by nsteps; returns CG iterations [nsteps,B]."""
         iters = torch.zeros(nsteps * self.B, dtype=torch.int32, device=d.device)
         mk = self.masks
-        _apply_conv_precision(self.conv_precision)
-        check(self.lib.sol_rollout(C.byref(self.cfg), stream(), ptr(self.net.params.detach()), ptr(d), ptr(vy), ptr(vx),
-                                   ptr(re), ptr(mk.active), ptr(mk.inflow), ptr(mk.velBCy), ptr(mk.velBCyMask),
-                                   mk.bc_stride, nsteps, ptr(self.workspace), self.workspace_bytes, ptr(iters)))
+        with _conv_precision_scope(self.conv_precision):
+            check(self.lib.sol_rollout(C.byref(self.cfg), stream(), ptr(self.net.params.detach()), ptr(d), ptr(vy), ptr(vx),
+                                       ptr(re), ptr(mk.active), ptr(mk.inflow), ptr(mk.velBCy), ptr(mk.velBCyMask),
+                                       mk.bc_stride, nsteps, ptr(self.workspace), self.workspace_bytes, ptr(iters)))
         return iters.reshape(nsteps, self.B)
 
 
@@ -300,7 +323,10 @@ class GraphTrainer:
         self._fin[2].copy_(vt[:, :Y, :, 1])
 
     def fwd_bwd(self, d0, vy0, vx0, re, gt_vy, gt_vx, want_final=False, eager=False):
-        _apply_conv_precision(self.conv_precision)
+        with _conv_precision_scope(self.conv_precision):
+            return self._fwd_bwd(d0, vy0, vx0, re, gt_vy, gt_vx, want_final, eager)
+
+    def _fwd_bwd(self, d0, vy0, vx0, re, gt_vy, gt_vx, want_final, eager):
         for dst, src in zip(self._in, (d0, vy0, vx0, re, gt_vy, gt_vx)):
             dst.copy_(src, non_blocking=True)
         if eager or not self.use_graph:

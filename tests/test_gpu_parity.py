@@ -749,19 +749,40 @@ def test_sol32_bench_workload_against_golden(golden_dir, precision):
 # ---------------------------------------------------------------------------------------------
 # precision equivalence of the split-operand convolution
 # ---------------------------------------------------------------------------------------------
+# worst ratio over the ten |reference| deciles of (rms error of the split kernel) / (rms error of the strict fp32-MFMA kernel), and
+# of the max errors, MEASURED on MI355X with tools/split_precision_ranges.py (profiles/r03_split_precision_ranges.json); the
+# test allows these + 10 %.  Columns: rms fp16x3, rms bf16x6, max fp16x3, max bf16x6.  "mixed_r": the left half of every
+# image row scaled by r -- the within-tensor dynamic range; 2^-19 of the tensor maximum is where the fp16 lo plane starts to
+# underflow: no cliff shows in the forward convolution, the worst case of both split kernels is the
+# 1e-5 range (1.4x / 1.6x the fp32-MFMA kernel's error in ONE decile, relative L2 still 0.4x / 0.8x).
+SPLIT_RATIOS = {
+    "normal":      (0.45, 0.86, 0.47, 1.02),
+    "heavy":       (0.46, 0.82, 0.83, 1.08),
+    "mixed_1e-3":  (0.69, 1.00, 0.65, 1.47),
+    "mixed_1e-5":  (1.38, 1.59, 1.39, 1.38),
+    "mixed_2^-18": (0.44, 0.84, 0.40, 1.22),
+    "mixed_2^-19": (0.44, 0.85, 0.44, 1.21),
+    "mixed_2^-20": (0.46, 0.86, 0.49, 1.14),
+    "mixed_2^-22": (0.45, 0.85, 0.43, 1.03),
+}
+
+
 def test_split_conv_error_not_worse_than_fp32_mfma():
-    """On the same inputs the fp16x3 split kernel (and the bf16x6 one) must not be less accurate than the strict fp32-MFMA
-    kernel, measured against a float64 convolution per CLASS of output elements (deciles of |reference|), not only in
-    relative L2 -- including an input whose left half is 1e-3 of its right half (small outputs next to large ones) and a
-    heavy-tailed one."""
+    """On the same inputs the fp16x3 split kernel and the bf16x6 one against the strict fp32-MFMA kernel, measured against a
+    float64 convolution per CLASS of output elements (deciles of |reference|), not only in relative L2 -- for a normal and a
+    heavy-tailed input and for within-tensor dynamic ranges from 1e-3 down to 2^-22 (around the fp16 lo plane's underflow
+    point, 2^-19 of the tensor maximum).  Bounds: the measured ratios + 10 % (SPLIT_RATIOS); in relative L2 both split
+    kernels must be at least as accurate as the fp32-MFMA kernel in every case."""
     from sol_amd import _lib
     gen = torch.Generator().manual_seed(5)
     B, Y, X = 2, 64, 64
     cases = {"normal": torch.randn(B, Y, X, 32, generator=gen),
              "heavy": torch.randn(B, Y, X, 32, generator=gen) * torch.exp(2.0 * torch.randn(B, Y, X, 32, generator=gen))}
-    mixed = torch.randn(B, Y, X, 32, generator=gen)
-    mixed[:, :, :32] *= 1e-3
-    cases["mixed_1e-3"] = mixed
+    for name, ratio in (("mixed_1e-3", 1e-3), ("mixed_1e-5", 1e-5), ("mixed_2^-18", 2.0 ** -18), ("mixed_2^-19", 2.0 ** -19),
+                        ("mixed_2^-20", 2.0 ** -20), ("mixed_2^-22", 2.0 ** -22)):
+        m = torch.randn(B, Y, X, 32, generator=gen)
+        m[:, :, :32] *= ratio
+        cases[name] = m
     w = (torch.randn(5, 5, 32, 32, generator=gen) * 0.05).float().to(DEV)
     bias = torch.zeros(32, dtype=torch.float32, device=DEV)
     packed = ops._pack(w, 32, 32, ops.CONV_FWD)
@@ -778,6 +799,7 @@ def test_split_conv_error_not_worse_than_fp32_mfma():
             assert not torch.equal(y_f, y_h) and not torch.equal(y_f, y_b)          # three different kernels did run
             order = ref.abs().reshape(-1).argsort()
             n = order.numel()
+            worst = {"rms_fp16x3": 0.0, "rms_bf16x6": 0.0, "max_fp16x3": 0.0, "max_bf16x6": 0.0}
             for q in range(10):
                 idx = order[q * n // 10:(q + 1) * n // 10]
                 r = ref.reshape(-1)[idx]
@@ -785,9 +807,15 @@ def test_split_conv_error_not_worse_than_fp32_mfma():
                 rms = {k: float(v.pow(2).mean().sqrt()) for k, v in e.items()}
                 mx = {k: float(v.abs().max()) for k, v in e.items()}
                 for k in ("fp16x3", "bf16x6"):
-                    assert rms[k] <= 1.5 * rms["fp32"], (name, q, k, rms)
-                    assert mx[k] <= 2.0 * mx["fp32"], (name, q, k, mx)
-            assert rel(y_h, ref) <= 1.5 * rel(y_f, ref) and rel(y_b, ref) <= 1.5 * rel(y_f, ref)
+                    worst["rms_" + k] = max(worst["rms_" + k], rms[k] / rms["fp32"])
+                    worst["max_" + k] = max(worst["max_" + k], mx[k] / mx["fp32"])
+            bound = SPLIT_RATIOS[name]
+            got = (worst["rms_fp16x3"], worst["rms_bf16x6"], worst["max_fp16x3"], worst["max_bf16x6"])
+            assert all(g <= 1.10 * b + 0.005 for g, b in zip(got, bound)), (name, got, bound)
+            # the small half alone (pixels 2..29 of a row see only scaled inputs): still fp32 quality in relative L2
+            small = (slice(None), slice(None), slice(2, 30))
+            assert rel(y_h[small], ref[small]) <= rel(y_f[small], ref[small]) and rel(y_b[small], ref[small]) <= rel(y_f[small], ref[small])
+            assert rel(y_h, ref) <= rel(y_f, ref) and rel(y_b, ref) <= rel(y_f, ref)
     finally:
         _lib.set_option("conv_precision", saved)
 
