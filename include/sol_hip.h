@@ -352,6 +352,7 @@ int32_t sol_abi_size_karman3d(void);      /* sizeof(sol_karman3d_cfg) of the lib
  * [Y+1,X,Z] (bc_batch_stride 0) or [B,Y+1,X,Z]; feat_out [B,Y,X,Z,4] (or NULL): fused to_feature = the three components
  * at the low faces of every cell and Re, each times feat_scale[c] (HOST array of 4 = 1/std).  direct_header_host: HOST
  * copy of the first 16 words of the blob.  workspace: sol_karman3d_step_workspace_bytes(cfg) bytes of DEVICE scratch.
+ * saved_vy/vx/vz (all three, or all NULL): receive the post-diffusion + BC velocity, the only state the adjoint needs.
  * Outputs must not alias inputs. */
 size_t sol_karman3d_step_workspace_bytes(const sol_karman3d_cfg* cfg);
 int sol_karman3d_step_fwd(const sol_karman3d_cfg* cfg, void* stream,
@@ -359,8 +360,21 @@ int sol_karman3d_step_fwd(const sol_karman3d_cfg* cfg, void* stream,
                           const float* re, const float* active, const float* inflow,
                           const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
                           float* d_out, float* vy_out, float* vx_out, float* vz_out,
+                          float* saved_vy, float* saved_vx, float* saved_vz,
                           float* feat_out, const float* feat_scale, const int32_t* direct_header_host,
                           void* workspace, size_t workspace_bytes);
+/* Adjoint of the step w.r.t. its input velocity (the density is a passive tracer: buoyancy_factor = 0, karman_train.py:363).
+ * saved_v*: the post-diffusion + BC velocity the forward call stored (saved_vy/vx/vz, all three or NULL there).  The
+ * pressure adjoint is a second direct solve with the same symmetric matrix (PhiFlow's custom gradient of the CG solve).
+ * The advection adjoint scatters with fp32 global atomics: reproducible to round-off, not bit for bit.
+ * workspace: sol_karman3d_step_bwd_workspace_bytes(cfg). */
+size_t sol_karman3d_step_bwd_workspace_bytes(const sol_karman3d_cfg* cfg);
+int sol_karman3d_step_bwd(const sol_karman3d_cfg* cfg, void* stream,
+                          const float* saved_vy, const float* saved_vx, const float* saved_vz,
+                          const float* re, const float* active, const float* velBCyMask, int64_t bc_batch_stride,
+                          const float* g_vy_out, const float* g_vx_out, const float* g_vz_out,
+                          float* g_vy_in, float* g_vx_in, float* g_vz_in,
+                          const int32_t* direct_header_host, void* workspace, size_t workspace_bytes);
 /* velocity += s_c * out[..., c] for the three components (to_staggered + add, karman_train.py:88-90, 424-426):
  * out [B,Y,X,Z,cout], cout >= 3; the last face of each component's own axis receives no correction. */
 int sol_karman3d_correct(void* stream, const float* out, int32_t cout, float s0, float s1, float s2,
@@ -370,9 +384,12 @@ int sol_karman3d_correct(void* stream, const float* out, int32_t cout, float s0,
  * w_dhwio [5,5,5,cin,cout] (Keras layout, D = y).  Runs as five passes of the 2-D kernels over the (H, W) planes with the
  * running sum in y, the centre slice last (bias, activation, absmax publish): same per-product arithmetic as sol_conv5x5.
  * x [B,D,H,W,cin] with cin in {4 (zero padded), 32}; residual [B,D,H,W,cout] or NULL is added before the activation;
- * epilogue SOL_EPI_NONE / SOL_EPI_LRELU; x_absmax / y_absmax as in sol_conv5x5_scaled (may be NULL).  x != y, D >= 3. */
+ * epilogue SOL_EPI_NONE / SOL_EPI_LRELU; x_absmax / y_absmax as in sol_conv5x5_scaled (may be NULL).  x != y, D >= 3.
+ * Backward-data is the same entry point on weights packed with mode SOL_CONV_BWD_DATA (cin = channels of dy = the forward
+ * layer's cout, cout = channels of dx = the forward layer's cin; w_dhwio is the FORWARD kernel): dx = conv3d(dy, flip(w)^T).
+ * The weight gradient is five calls of sol_conv5x5_bwd_weight on the shifted plane ranges (ops composed on the host). */
 size_t sol_conv3d_packed_floats(int32_t cin, int32_t cout);
-int sol_conv3d_pack(void* stream, const float* w_dhwio, int32_t cin, int32_t cout, float* packed);
+int sol_conv3d_pack(void* stream, const float* w_dhwio, int32_t cin, int32_t cout, int32_t mode, float* packed);
 int sol_conv3d(void* stream, const float* x, const float* packed, const float* bias, const float* residual, float* y,
                int32_t B, int32_t D, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t epilogue, float slope,
                const uint32_t* x_absmax, uint32_t* y_absmax);

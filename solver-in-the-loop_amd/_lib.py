@@ -92,10 +92,12 @@ _SIGS = {
     "sol_comm_destroy": (C.c_int, [_P]),
     "sol_abi_size_karman3d": (C.c_int32, []),
     "sol_karman3d_step_workspace_bytes": (C.c_size_t, [C.POINTER(Karman3DCfg)]),
-    "sol_karman3d_step_fwd": (C.c_int, [C.POINTER(Karman3DCfg), _P] + [_P] * 9 + [C.c_int64] + [_P] * 5 + [C.POINTER(C.c_float), _P, _P, C.c_size_t]),
+    "sol_karman3d_step_fwd": (C.c_int, [C.POINTER(Karman3DCfg), _P] + [_P] * 9 + [C.c_int64] + [_P] * 8 + [C.POINTER(C.c_float), _P, _P, C.c_size_t]),
+    "sol_karman3d_step_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Karman3DCfg)]),
+    "sol_karman3d_step_bwd": (C.c_int, [C.POINTER(Karman3DCfg), _P] + [_P] * 6 + [C.c_int64] + [_P] * 6 + [_P, _P, C.c_size_t]),
     "sol_karman3d_correct": (C.c_int, [_P, _P, C.c_int32] + [C.c_float] * 3 + [_P] * 3 + [C.c_int32] * 4),
     "sol_conv3d_packed_floats": (C.c_size_t, [C.c_int32] * 2),
-    "sol_conv3d_pack": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    "sol_conv3d_pack": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "sol_conv3d": (C.c_int, [_P] * 6 + [C.c_int32] * 7 + [C.c_float] + [_P] * 2),
     "sol_mars_moon_layer": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }

@@ -487,83 +487,21 @@ __global__ void __launch_bounds__(256) k3_fill(float* __restrict__ y, const floa
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) y[e] = src ? src[e] : 0.f;
 }
 
+
 int grid_for(size_t n) { const size_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
 
-}  // namespace
-
-extern "C" int32_t sol_abi_size_karman3d(void) { return (int32_t)sizeof(sol_karman3d_cfg); }
-
-extern "C" size_t sol_karman3d_step_workspace_bytes(const sol_karman3d_cfg* c) {
-    if (!c) return 0;
-    const size_t B = c->B, Y = c->Y, X = c->X, Z = c->Z;
-    // three diffused components + rhs + two transform buffers
-    const size_t floats = B * ((Y + 1) * X * Z + Y * (X + 1) * Z + Y * X * (Z + 1) + 3 * Y * X * Z) + 256;
-    return floats * sizeof(float);
-}
-
-extern "C" int sol_karman3d_step_fwd(const sol_karman3d_cfg* c, void* stream,
-                                     const float* d_in, const float* vy_in, const float* vx_in, const float* vz_in,
-                                     const float* re, const float* active, const float* inflow,
-                                     const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
-                                     float* d_out, float* vy_out, float* vx_out, float* vz_out,
-                                     float* feat_out, const float* feat_scale, const int32_t* direct_header_host,
-                                     void* workspace, size_t workspace_bytes) {
-    SOL_REQUIRE(c != nullptr, "cfg is NULL");
-    SOL_REQUIRE(c->B >= 1 && c->Y >= 8 && c->X >= 8 && c->Z >= 8 && c->B <= 65535, "sol_karman3d_step_fwd: B >= 1, Y, X, Z >= 8 (got %d, %d, %d, %d)", c->B, c->Y, c->X, c->Z);
-    SOL_REQUIRE((size_t)(c->Y + 1) * (c->X + 1) * (c->Z + 1) * 3 < ((size_t)1 << 31), "sol_karman3d_step_fwd: grid too large for 32-bit face indices");
-    SOL_REQUIRE(vy_in && vx_in && vz_in && re && active && velBCy && velBCyMask && vy_out && vx_out && vz_out && workspace, "sol_karman3d_step_fwd: NULL pointer argument");
-    SOL_REQUIRE((d_in && inflow) || !d_out, "density output requested without d_in / inflow");
-    SOL_REQUIRE(!feat_out || feat_scale, "feat_out requires feat_scale");
-    SOL_REQUIRE(c->direct && c->direct_n > 0, "sol_karman3d_step_fwd needs the direct-solver blob (cfg.direct, precond3d.direct_solver_blob3d)");
-    SOL_REQUIRE(workspace_bytes >= sol_karman3d_step_workspace_bytes(c), "workspace too small");
-    SOL_REQUIRE(vy_in != vy_out && vx_in != vx_out && vz_in != vz_out && (d_in != d_out || !d_out), "sol_karman3d_step_fwd: outputs must not alias the inputs");
-    SOL_REQUIRE(direct_header_host && direct_header_host[0] == FD3_MAGIC, "sol_karman3d_step_fwd: direct_header_host must be the first 16 words of the blob (host copy)");
+// ---- direct pressure solve: M x = R (M = -A), in place helpers shared by the forward step and its adjoint.  R is modified
+// (the capacitance correction is subtracted from it); *res = the buffer (T1 or T2) that holds x.
+int pressure_solve3d(hipStream_t s, const sol_karman3d_cfg* c, const int32_t* hdr, float* R, float* T1, float* T2, float** res_out) {
     const int B = c->B, Y = c->Y, X = c->X, Z = c->Z, N = Y * X * Z;
-    const int nS = direct_header_host[4], SP = direct_header_host[5];
-    SOL_REQUIRE(direct_header_host[1] == Y && direct_header_host[2] == X && direct_header_host[3] == Z, "direct-solver blob is for a %dx%dx%d grid, cfg is %dx%dx%d",
-                direct_header_host[1], direct_header_host[2], direct_header_host[3], Y, X, Z);
-    SOL_REQUIRE(nS >= 0 && SP >= nS && SP % 64 == 0 && SP <= 8192 && (size_t)8 * SP <= (size_t)N, "direct-solver blob header is inconsistent (nS %d, SP %d)", nS, SP);
-    SOL_REQUIRE((size_t)c->direct_n == (size_t)FD3_HEADER + (size_t)Y * Y + (size_t)X * X + (size_t)Z * Z + (size_t)N + (size_t)SP * SP + SP,
-                "direct-solver blob has %d words, expected %zu", c->direct_n,
-                (size_t)FD3_HEADER + (size_t)Y * Y + (size_t)X * X + (size_t)Z * Z + (size_t)N + (size_t)SP * SP + SP);
-    hipStream_t s = (hipStream_t)stream;
+    const int nS = hdr[4], SP = hdr[5];
     const float* Qy = c->direct + FD3_HEADER;
     const float* Qx = Qy + (size_t)Y * Y;
     const float* Qz = Qx + (size_t)X * X;
     const float* il = Qz + (size_t)Z * Z;
     const float* KpT = il + (size_t)N;
     const int* sidx = reinterpret_cast<const int*>(KpT + (size_t)SP * SP);
-    float* w = static_cast<float*>(workspace);
-    const size_t nVy = (size_t)(Y + 1) * X * Z, nVx = (size_t)Y * (X + 1) * Z, nVz = (size_t)Y * X * (Z + 1);
-    float* svy = w; w += B * nVy;
-    float* svx = w; w += B * nVx;
-    float* svz = w; w += B * nVz;
-    float* R = w; w += (size_t)B * N;
-    float* T1 = w; w += (size_t)B * N;
-    float* T2 = w; w += (size_t)B * N;
-
-    K3Args a{};
-    a.B = B; a.Y = Y; a.X = X; a.Z = Z; a.dtdx = c->dt / c->dx; a.dt = c->dt; a.adt = c->dt * c->res * c->res;
-    a.grad_pad = c->grad_pad; a.inflow_before = c->inflow_before;
-    a.d_in = d_in; a.vy_in = vy_in; a.vx_in = vx_in; a.vz_in = vz_in; a.re = re; a.active = active; a.inflow = inflow;
-    a.bcv = velBCy; a.bcm = velBCyMask; a.bc_stride = bc_batch_stride;
-    a.d_out = d_out; a.vy_out = vy_out; a.vx_out = vx_out; a.vz_out = vz_out; a.svy = svy; a.svx = svx; a.svz = svz; a.rhs = R; a.feat = feat_out; a.p = T2;
-    if (feat_scale) { a.fs0 = feat_scale[0]; a.fs1 = feat_scale[1]; a.fs2 = feat_scale[2]; a.fs3 = feat_scale[3]; }
-    const size_t faces = nVy + nVx + nVz;
-    SOL_LAUNCH(k3_diffuse, dim3(grid_for(faces), B), dim3(256), 0, s, a);
-    const size_t tile_lds = ((size_t)(TR + 1) * TR * Z + (size_t)TR * (TR + 1) * Z + (size_t)TR * TR * (Z + 1)) * sizeof(float);
-    if (sol_opt().k3d_tile && tile_lds <= 160 * 1024) {
-        static int rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k3_advect_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
-        SOL_REQUIRE(rc == 0, "hipFuncSetAttribute(k3_advect_tile) failed");
-        const int tiles_y = (Y + T3 - 1) / T3, tiles_x = (X + T3 - 1) / T3;
-        SOL_LAUNCH(k3_advect_tile, dim3(tiles_y * tiles_x, B), dim3(ADV_T), tile_lds, s, a, tiles_x);
-    } else {
-        SOL_LAUNCH(k3_advect, dim3(grid_for((size_t)((Y + 1) * X + Y * (X + 1) + 2 * Y * X) * 64), B), dim3(256), 0, s, a);
-    }
-    SOL_LAUNCH(k3_div, dim3(grid_for(N), B), dim3(256), 0, s, a);
-    SOL_LAUNCH_CHECK();
-
-    // ---- direct pressure solve.  One sine transform of the whole batch along each axis = one batched GEMM:
+    // One sine transform of the whole batch along each axis = one batched GEMM:
     //   z: [(b,j,i)] x Z times Qz;   x: per (b, j): Qx times [X x Z];   y: per b: Qy times [Y x (X Z)]
     auto tz = [&](const float* in, float* out) { return sol_gemm_f32(s, 1, in, Z, 0, Qz, Z, 0, out, Z, 0, B * Y * X, Z, Z, 0); };
     auto tx = [&](const float* in, float* out) { return sol_gemm_f32(s, B * Y, Qx, X, 0, in, Z, (long)X * Z, out, Z, (long)X * Z, X, Z, X, 0); };
@@ -592,16 +530,352 @@ extern "C" int sol_karman3d_step_fwd(const sol_karman3d_cfg* c, void* stream,
     };
     // result in `res`: T2 for the GEMM path, T1 for the fused path
     float* res = fused_tf ? T1 : T2;
-    a.p = res;
+    *res_out = res;
     if (int e = fused_tf ? Gf(R, T1, T2) : G(R, T1, T2)) return e;
     if (nS > 0) {
-        SOL_REQUIRE(SP / CAPQ <= 1024 && SP % (32 * CAPQ / 4) == 0, "direct-solver blob: SP = %d does not fit the capacitance kernel", SP);
+        SOL_REQUIRE(SP / CAPQ <= 1024 && SP % 64 == 0, "direct-solver blob: SP = %d does not fit the capacitance kernel", SP);
         float* cpart = fused_tf ? T2 : T1;          // scratch: the buffer G does not return its result in (B * CAPQ * SP <= B * N floats)
         SOL_LAUNCH(k3_capacitance, dim3(SP / 32, CAPQ, B), dim3(256), 0, s, res, KpT, sidx, cpart, SP, N);
         SOL_LAUNCH(k3_cap_apply, dim3((SP + 255) / 256, B), dim3(256), 0, s, cpart, sidx, R, SP, N);
         if (int e = fused_tf ? Gf(R, T1, T2) : G(R, T1, T2)) return e;
     }
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
+// validates the blob header against the configuration (shared by the forward and the adjoint entry points)
+int check_blob3d(const sol_karman3d_cfg* c, const int32_t* hdr) {
+    SOL_REQUIRE(c->direct && c->direct_n > 0, "the karman-3d step needs the direct-solver blob (cfg.direct, precond3d.direct_solver_blob3d)");
+    SOL_REQUIRE(hdr && hdr[0] == FD3_MAGIC, "direct_header_host must be the first 16 words of the blob (host copy)");
+    const int Y = c->Y, X = c->X, Z = c->Z;
+    const size_t N = (size_t)Y * X * Z;
+    const int nS = hdr[4], SP = hdr[5];
+    SOL_REQUIRE(hdr[1] == Y && hdr[2] == X && hdr[3] == Z, "direct-solver blob is for a %dx%dx%d grid, cfg is %dx%dx%d", hdr[1], hdr[2], hdr[3], Y, X, Z);
+    SOL_REQUIRE(nS >= 0 && SP >= nS && SP % 64 == 0 && SP <= 8192 && (size_t)8 * SP <= N, "direct-solver blob header is inconsistent (nS %d, SP %d)", nS, SP);
+    const size_t want = (size_t)FD3_HEADER + (size_t)Y * Y + (size_t)X * X + (size_t)Z * Z + N + (size_t)SP * SP + SP;
+    SOL_REQUIRE((size_t)c->direct_n == want, "direct-solver blob has %d words, expected %zu", c->direct_n, want);
+    return SOL_OK;
+}
+
+// ========================================================================================================================
+// Adjoint of the 3-D step with respect to its input velocity (density is a passive tracer: no adjoint).  Stages in reverse:
+//   k3b_rhs        q = G^T (mask . g_out)                  (adjoint of  out = v~ - mask . G p)
+//   pressure       g_div = M^-1 q                           (second solve with the same symmetric matrix: PhiFlow's custom gradient)
+//   k3b_gva        g_a = mask . (g_out + D^T g_div)          (adjoint of the divergence and of the hard-BC face masks)
+//   k3b_advect_adj scatter of g_a through the trilinear gathers of the semi-Lagrangian step, for the field term AND the
+//                  back-trace (velocity) term, into g_c (fp32 global atomics: the summation order is not fixed, the result is
+//                  reproducible to round-off only -- the 2-D kernels scatter in int32 fixed point into LDS)
+//   k3b_diffuse_adj g_in = (I + alpha L^T)(g_c . (1 - bcm))  (gather form of the transposed replicate-padded Laplacian)
+// ========================================================================================================================
+struct K3BArgs {
+    int B, Y, X, Z;
+    float dtdx, adt;
+    int grad_pad;
+    const float *re, *active, *bcm;
+    long bc_stride;
+    const float *svy, *svx, *svz;           // saved post-diffusion velocity
+    const float *goy, *gox, *goz;           // gradient w.r.t. the step's output velocity
+    float *gay, *gax, *gaz;                 // g_a
+    float *gcy, *gcx, *gcz;                 // g_c (zeroed before the scatter)
+    float *giy, *gix, *giz;                 // result: gradient w.r.t. the step's input velocity
+    float* rhs;
+    const float* gdiv;
+};
+
+template <int AX>
+__device__ __forceinline__ bool boundary_face(int Y, int X, int Z, int j, int i, int k) {
+    return AX == 0 ? (j == 0 || j == Y) : (AX == 1 ? (i == 0 || i == X) : (k == 0 || k == Z));
+}
+
+__global__ void __launch_bounds__(256) k3b_rhs(K3BArgs a) {
+    const int Y = a.Y, X = a.X, Z = a.Z, N = Y * X * Z;
+    const int b = blockIdx.y;
+    const float* gy = a.goy + (size_t)b * (Y + 1) * X * Z;
+    const float* gx = a.gox + (size_t)b * Y * (X + 1) * Z;
+    const float* gz = a.goz + (size_t)b * Y * X * (Z + 1);
+    const bool keep = a.grad_pad == 1;           // dirichlet0: the boundary faces' gradient depends on p; replicate: it is zero
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < N; c += gridDim.x * blockDim.x) {
+        const int k = c % Z, i = (c / Z) % X, j = c / (Z * X);
+        auto wy = [&](int jj) { return (keep || (jj != 0 && jj != Y)) ? face_mask<0>(a.active, Y, X, Z, jj, i, k) * gy[((size_t)jj * X + i) * Z + k] : 0.f; };
+        auto wx = [&](int ii) { return (keep || (ii != 0 && ii != X)) ? face_mask<1>(a.active, Y, X, Z, j, ii, k) * gx[((size_t)j * (X + 1) + ii) * Z + k] : 0.f; };
+        auto wz = [&](int kk) { return (keep || (kk != 0 && kk != Z)) ? face_mask<2>(a.active, Y, X, Z, j, i, kk) * gz[((size_t)j * X + i) * (Z + 1) + kk] : 0.f; };
+        a.rhs[(size_t)b * N + c] = (wy(j) - wy(j + 1)) + (wx(i) - wx(i + 1)) + (wz(k) - wz(k + 1));
+    }
+}
+
+__global__ void __launch_bounds__(256) k3b_gva(K3BArgs a) {
+    const int Y = a.Y, X = a.X, Z = a.Z, N = Y * X * Z;
+    const int nVy = (Y + 1) * X * Z, nVx = Y * (X + 1) * Z, nVz = Y * X * (Z + 1);
+    const int b = blockIdx.y;
+    const float* P = a.gdiv + (size_t)b * N;
+    auto cell = [&](int j, int i, int k) { return ((unsigned)j < (unsigned)Y && (unsigned)i < (unsigned)X && (unsigned)k < (unsigned)Z) ? P[((size_t)j * X + i) * Z + k] : 0.f; };
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nVy + nVx + nVz; e += gridDim.x * blockDim.x) {
+        if (e < nVy) {
+            const int k = e % Z, i = (e / Z) % X, j = e / (Z * X);
+            a.gay[(size_t)b * nVy + e] = face_mask<0>(a.active, Y, X, Z, j, i, k) * (a.goy[(size_t)b * nVy + e] + cell(j - 1, i, k) - cell(j, i, k));
+        } else if (e < nVy + nVx) {
+            const int q = e - nVy, k = q % Z, i = (q / Z) % (X + 1), j = q / (Z * (X + 1));
+            a.gax[(size_t)b * nVx + q] = face_mask<1>(a.active, Y, X, Z, j, i, k) * (a.gox[(size_t)b * nVx + q] + cell(j, i - 1, k) - cell(j, i, k));
+        } else {
+            const int q = e - nVy - nVx, k = q % (Z + 1), i = (q / (Z + 1)) % X, j = q / ((Z + 1) * X);
+            a.gaz[(size_t)b * nVz + q] = face_mask<2>(a.active, Y, X, Z, j, i, k) * (a.goz[(size_t)b * nVz + q] + cell(j, i, k - 1) - cell(j, i, k));
+        }
+    }
+}
+
+// adjoint of one advected face value of component C at (j, i, k): gs = g_a there
+template <int C>
+__device__ __forceinline__ void advect_adj_point(const K3BArgs& a, const GR& r, float* gy, float* gx, float* gz, int j, int i, int k, float gs) {
+    const int Y = a.Y, X = a.X, Z = a.Z;
+    auto iy = [&](int jj, int ii, int kk) { return ((size_t)jj * X + ii) * Z + kk; };
+    auto ix = [&](int jj, int ii, int kk) { return ((size_t)jj * (X + 1) + ii) * Z + kk; };
+    auto iz = [&](int jj, int ii, int kk) { return ((size_t)jj * X + ii) * (Z + 1) + kk; };
+    // velocity at the sample point, exactly as the forward pass forms it
+    float uy, ux, uz;
+    int ja, jb, ia, ib, ka, kb;
+    if (C == 0) {
+        ja = max(j - 1, 0); jb = min(j, Y - 1);
+        uy = r.y(j, i, k);
+        ux = 0.25f * (r.x(ja, i, k) + r.x(ja, i + 1, k) + r.x(jb, i, k) + r.x(jb, i + 1, k));
+        uz = 0.25f * (r.z(ja, i, k) + r.z(ja, i, k + 1) + r.z(jb, i, k) + r.z(jb, i, k + 1));
+    } else if (C == 1) {
+        ia = max(i - 1, 0); ib = min(i, X - 1);
+        ux = r.x(j, i, k);
+        uy = 0.25f * (r.y(j, ia, k) + r.y(j, ib, k) + r.y(j + 1, ia, k) + r.y(j + 1, ib, k));
+        uz = 0.25f * (r.z(j, ia, k) + r.z(j, ia, k + 1) + r.z(j, ib, k) + r.z(j, ib, k + 1));
+    } else {
+        ka = max(k - 1, 0); kb = min(k, Z - 1);
+        uz = r.z(j, i, k);
+        uy = 0.25f * (r.y(j, i, ka) + r.y(j, i, kb) + r.y(j + 1, i, ka) + r.y(j + 1, i, kb));
+        ux = 0.25f * (r.x(j, i, ka) + r.x(j, i, kb) + r.x(j, i + 1, ka) + r.x(j, i + 1, kb));
+    }
+    const float oy = -uy * a.dtdx, ox = -ux * a.dtdx, oz = -uz * a.dtdx;
+    const int n0 = Y + (C == 0), n1 = X + (C == 1), n2 = Z + (C == 2);
+    const float fy = floorf(oy), fx = floorf(ox), fz = floorf(oz);
+    const float wy = oy - fy, wx = ox - fx, wz = oz - fz;
+    const int j0 = clampi(j + (int)fy, 0, n0 - 1), j1 = clampi(j + (int)fy + 1, 0, n0 - 1);
+    const int i0 = clampi(i + (int)fx, 0, n1 - 1), i1 = clampi(i + (int)fx + 1, 0, n1 - 1);
+    const int k0 = clampi(k + (int)fz, 0, n2 - 1), k1 = clampi(k + (int)fz + 1, 0, n2 - 1);
+    float* gT = C == 0 ? gy : (C == 1 ? gx : gz);
+    auto idx = [&](int jj, int ii, int kk) { return C == 0 ? iy(jj, ii, kk) : (C == 1 ? ix(jj, ii, kk) : iz(jj, ii, kk)); };
+    auto val = [&](int jj, int ii, int kk) { return C == 0 ? r.y(jj, ii, kk) : (C == 1 ? r.x(jj, ii, kk) : r.z(jj, ii, kk)); };
+    float dy = 0.f, dx = 0.f, dz = 0.f;          // d(sample) / d(offset) along each axis
+#pragma unroll
+    for (int cj = 0; cj < 2; ++cj)
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int ck = 0; ck < 2; ++ck) {
+                const int jj = cj ? j1 : j0, ii = ci ? i1 : i0, kk = ck ? k1 : k0;
+                const float by = cj ? wy : 1.f - wy, bx = ci ? wx : 1.f - wx, bz = ck ? wz : 1.f - wz;
+                const float v = val(jj, ii, kk);
+                atomicAdd(&gT[idx(jj, ii, kk)], by * bx * bz * gs);          // field term
+                dy += (cj ? 1.f : -1.f) * bx * bz * v;
+                dx += by * (ci ? 1.f : -1.f) * bz * v;
+                dz += by * bx * (ck ? 1.f : -1.f) * v;
+            }
+    // back-trace term: offset_a = -dtdx * u_a(x0)
+    const float guy = -a.dtdx * gs * dy, gux = -a.dtdx * gs * dx, guz = -a.dtdx * gs * dz;
+    if (C == 0) {
+        atomicAdd(&gy[iy(j, i, k)], guy);
+        const float qx = 0.25f * gux, qz = 0.25f * guz;
+        atomicAdd(&gx[ix(ja, i, k)], qx); atomicAdd(&gx[ix(ja, i + 1, k)], qx); atomicAdd(&gx[ix(jb, i, k)], qx); atomicAdd(&gx[ix(jb, i + 1, k)], qx);
+        atomicAdd(&gz[iz(ja, i, k)], qz); atomicAdd(&gz[iz(ja, i, k + 1)], qz); atomicAdd(&gz[iz(jb, i, k)], qz); atomicAdd(&gz[iz(jb, i, k + 1)], qz);
+    } else if (C == 1) {
+        atomicAdd(&gx[ix(j, i, k)], gux);
+        const float qy = 0.25f * guy, qz = 0.25f * guz;
+        atomicAdd(&gy[iy(j, ia, k)], qy); atomicAdd(&gy[iy(j, ib, k)], qy); atomicAdd(&gy[iy(j + 1, ia, k)], qy); atomicAdd(&gy[iy(j + 1, ib, k)], qy);
+        atomicAdd(&gz[iz(j, ia, k)], qz); atomicAdd(&gz[iz(j, ia, k + 1)], qz); atomicAdd(&gz[iz(j, ib, k)], qz); atomicAdd(&gz[iz(j, ib, k + 1)], qz);
+    } else {
+        atomicAdd(&gz[iz(j, i, k)], guz);
+        const float qy = 0.25f * guy, qx = 0.25f * gux;
+        atomicAdd(&gy[iy(j, i, ka)], qy); atomicAdd(&gy[iy(j, i, kb)], qy); atomicAdd(&gy[iy(j + 1, i, ka)], qy); atomicAdd(&gy[iy(j + 1, i, kb)], qy);
+        atomicAdd(&gx[ix(j, i, ka)], qx); atomicAdd(&gx[ix(j, i, kb)], qx); atomicAdd(&gx[ix(j, i + 1, ka)], qx); atomicAdd(&gx[ix(j, i + 1, kb)], qx);
+    }
+}
+
+__global__ void __launch_bounds__(256) k3b_advect_adj(K3BArgs a) {
+    const int Y = a.Y, X = a.X, Z = a.Z;
+    const int nVy = (Y + 1) * X * Z, nVx = Y * (X + 1) * Z, nVz = Y * X * (Z + 1);
+    const int b = blockIdx.y;
+    GR r;
+    r.sy = a.svy + (size_t)b * nVy; r.sx = a.svx + (size_t)b * nVx; r.sz = a.svz + (size_t)b * nVz; r.Y = Y; r.X = X; r.Z = Z;
+    float* gy = a.gcy + (size_t)b * nVy;
+    float* gx = a.gcx + (size_t)b * nVx;
+    float* gz = a.gcz + (size_t)b * nVz;
+    const int cY = (Y + 1) * X, cX = Y * (X + 1), cC = Y * X;
+    const int lane = threadIdx.x & 63;
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    for (int c = wave0; c < cY + cX + cC; c += nwaves) {
+        if (c < cY) {
+            const int j = c / X, i = c % X;
+            for (int k = lane; k < Z; k += 64) { const float g = a.gay[(size_t)b * nVy + ((size_t)j * X + i) * Z + k]; if (g != 0.f) advect_adj_point<0>(a, r, gy, gx, gz, j, i, k, g); }
+        } else if (c < cY + cX) {
+            const int q = c - cY, j = q / (X + 1), i = q % (X + 1);
+            for (int k = lane; k < Z; k += 64) { const float g = a.gax[(size_t)b * nVx + ((size_t)j * (X + 1) + i) * Z + k]; if (g != 0.f) advect_adj_point<1>(a, r, gy, gx, gz, j, i, k, g); }
+        } else {
+            const int q = c - cY - cX, j = q / X, i = q % X;
+            for (int k = lane; k <= Z; k += 64) { const float g = a.gaz[(size_t)b * nVz + ((size_t)j * X + i) * (Z + 1) + k]; if (g != 0.f) advect_adj_point<2>(a, r, gy, gx, gz, j, i, k, g); }
+        }
+    }
+}
+
+// (I + alpha L^T) g at (j, i, k) of a component array [n0][n1][n2]: the transposed replicate-padded 7-point Laplacian in gather
+// form -- a neighbour q - delta inside the array contributes g there, a direction that leaves the array contributes g[q] itself
+__device__ __forceinline__ float lapT7(const float* g, float sc_here, const float* scm, int n0, int n1, int n2, int j, int i, int k) {
+    const size_t s0 = (size_t)n1 * n2, s1 = n2;
+    const size_t c = (size_t)j * s0 + (size_t)i * s1 + k;
+    auto at = [&](size_t q) { return scm ? g[q] * (1.f - scm[q]) : g[q]; };
+    const float v = g[c] * sc_here;
+    float acc = -6.f * v;
+    acc += j + 1 < n0 ? at(c + s0) : v;
+    acc += j > 0 ? at(c - s0) : v;
+    acc += i + 1 < n1 ? at(c + s1) : v;
+    acc += i > 0 ? at(c - s1) : v;
+    acc += k + 1 < n2 ? at(c + 1) : v;
+    acc += k > 0 ? at(c - 1) : v;
+    return acc;
+}
+
+__global__ void __launch_bounds__(256) k3b_diffuse_adj(K3BArgs a) {
+    const int Y = a.Y, X = a.X, Z = a.Z;
+    const int nVy = (Y + 1) * X * Z, nVx = Y * (X + 1) * Z, nVz = Y * X * (Z + 1);
+    const int b = blockIdx.y;
+    const float alpha = a.adt / a.re[b];
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nVy + nVx + nVz; e += gridDim.x * blockDim.x) {
+        if (e < nVy) {
+            const int k = e % Z, i = (e / Z) % X, j = e / (Z * X);
+            const float* g = a.gcy + (size_t)b * nVy;
+            const float* m = a.bcm + (size_t)b * a.bc_stride;          // g' = g . (1 - bcm): the BC blend's adjoint
+            const float sc = 1.f - m[e];
+            a.giy[(size_t)b * nVy + e] = g[e] * sc + alpha * lapT7(g, sc, m, Y + 1, X, Z, j, i, k);
+        } else if (e < nVy + nVx) {
+            const int q = e - nVy, k = q % Z, i = (q / Z) % (X + 1), j = q / (Z * (X + 1));
+            const float* g = a.gcx + (size_t)b * nVx;
+            a.gix[(size_t)b * nVx + q] = g[q] + alpha * lapT7(g, 1.f, nullptr, Y, X + 1, Z, j, i, k);
+        } else {
+            const int q = e - nVy - nVx, k = q % (Z + 1), i = (q / (Z + 1)) % X, j = q / ((Z + 1) * X);
+            const float* g = a.gcz + (size_t)b * nVz;
+            a.giz[(size_t)b * nVz + q] = g[q] + alpha * lapT7(g, 1.f, nullptr, Y, X, Z + 1, j, i, k);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int32_t sol_abi_size_karman3d(void) { return (int32_t)sizeof(sol_karman3d_cfg); }
+
+extern "C" size_t sol_karman3d_step_workspace_bytes(const sol_karman3d_cfg* c) {
+    if (!c) return 0;
+    const size_t B = c->B, Y = c->Y, X = c->X, Z = c->Z;
+    // three diffused components + rhs + two transform buffers
+    const size_t floats = B * ((Y + 1) * X * Z + Y * (X + 1) * Z + Y * X * (Z + 1) + 3 * Y * X * Z) + 256;
+    return floats * sizeof(float);
+}
+
+extern "C" int sol_karman3d_step_fwd(const sol_karman3d_cfg* c, void* stream,
+                                     const float* d_in, const float* vy_in, const float* vx_in, const float* vz_in,
+                                     const float* re, const float* active, const float* inflow,
+                                     const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
+                                     float* d_out, float* vy_out, float* vx_out, float* vz_out,
+                                     float* saved_vy, float* saved_vx, float* saved_vz,
+                                     float* feat_out, const float* feat_scale, const int32_t* direct_header_host,
+                                     void* workspace, size_t workspace_bytes) {
+    SOL_REQUIRE(c != nullptr, "cfg is NULL");
+    SOL_REQUIRE((saved_vy && saved_vx && saved_vz) || (!saved_vy && !saved_vx && !saved_vz), "saved_vy / saved_vx / saved_vz: all three or none");
+    SOL_REQUIRE(c->B >= 1 && c->Y >= 8 && c->X >= 8 && c->Z >= 8 && c->B <= 65535, "sol_karman3d_step_fwd: B >= 1, Y, X, Z >= 8 (got %d, %d, %d, %d)", c->B, c->Y, c->X, c->Z);
+    SOL_REQUIRE((size_t)(c->Y + 1) * (c->X + 1) * (c->Z + 1) * 3 < ((size_t)1 << 31), "sol_karman3d_step_fwd: grid too large for 32-bit face indices");
+    SOL_REQUIRE(vy_in && vx_in && vz_in && re && active && velBCy && velBCyMask && vy_out && vx_out && vz_out && workspace, "sol_karman3d_step_fwd: NULL pointer argument");
+    SOL_REQUIRE((d_in && inflow) || !d_out, "density output requested without d_in / inflow");
+    SOL_REQUIRE(!feat_out || feat_scale, "feat_out requires feat_scale");
+    if (int e = check_blob3d(c, direct_header_host)) return e;
+    SOL_REQUIRE(workspace_bytes >= sol_karman3d_step_workspace_bytes(c), "workspace too small");
+    SOL_REQUIRE(vy_in != vy_out && vx_in != vx_out && vz_in != vz_out && (d_in != d_out || !d_out), "sol_karman3d_step_fwd: outputs must not alias the inputs");
+    const int B = c->B, Y = c->Y, X = c->X, Z = c->Z, N = Y * X * Z;
+    hipStream_t s = (hipStream_t)stream;
+    float* w = static_cast<float*>(workspace);
+    const size_t nVy = (size_t)(Y + 1) * X * Z, nVx = (size_t)Y * (X + 1) * Z, nVz = (size_t)Y * X * (Z + 1);
+    float* svy = w; w += B * nVy;
+    float* svx = w; w += B * nVx;
+    float* svz = w; w += B * nVz;
+    float* R = w; w += (size_t)B * N;
+    float* T1 = w; w += (size_t)B * N;
+    float* T2 = w; w += (size_t)B * N;
+    if (saved_vy) { svy = saved_vy; svx = saved_vx; svz = saved_vz; }     // training: the post-diffusion velocity is the only state the adjoint needs
+
+    K3Args a{};
+    a.B = B; a.Y = Y; a.X = X; a.Z = Z; a.dtdx = c->dt / c->dx; a.dt = c->dt; a.adt = c->dt * c->res * c->res;
+    a.grad_pad = c->grad_pad; a.inflow_before = c->inflow_before;
+    a.d_in = d_in; a.vy_in = vy_in; a.vx_in = vx_in; a.vz_in = vz_in; a.re = re; a.active = active; a.inflow = inflow;
+    a.bcv = velBCy; a.bcm = velBCyMask; a.bc_stride = bc_batch_stride;
+    a.d_out = d_out; a.vy_out = vy_out; a.vx_out = vx_out; a.vz_out = vz_out; a.svy = svy; a.svx = svx; a.svz = svz; a.rhs = R; a.feat = feat_out; a.p = T2;
+    if (feat_scale) { a.fs0 = feat_scale[0]; a.fs1 = feat_scale[1]; a.fs2 = feat_scale[2]; a.fs3 = feat_scale[3]; }
+    const size_t faces = nVy + nVx + nVz;
+    SOL_LAUNCH(k3_diffuse, dim3(grid_for(faces), B), dim3(256), 0, s, a);
+    const size_t tile_lds = ((size_t)(TR + 1) * TR * Z + (size_t)TR * (TR + 1) * Z + (size_t)TR * TR * (Z + 1)) * sizeof(float);
+    if (sol_opt().k3d_tile && tile_lds <= 160 * 1024) {
+        static int rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k3_advect_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
+        SOL_REQUIRE(rc == 0, "hipFuncSetAttribute(k3_advect_tile) failed");
+        const int tiles_y = (Y + T3 - 1) / T3, tiles_x = (X + T3 - 1) / T3;
+        SOL_LAUNCH(k3_advect_tile, dim3(tiles_y * tiles_x, B), dim3(ADV_T), tile_lds, s, a, tiles_x);
+    } else {
+        SOL_LAUNCH(k3_advect, dim3(grid_for((size_t)((Y + 1) * X + Y * (X + 1) + 2 * Y * X) * 64), B), dim3(256), 0, s, a);
+    }
+    SOL_LAUNCH(k3_div, dim3(grid_for(N), B), dim3(256), 0, s, a);
+    SOL_LAUNCH_CHECK();
+
+    float* res = nullptr;
+    if (int e = pressure_solve3d(s, c, direct_header_host, R, T1, T2, &res)) return e;
+    a.p = res;
     SOL_LAUNCH(k3_project, dim3(grid_for(faces), B), dim3(256), 0, s, a);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
+extern "C" size_t sol_karman3d_step_bwd_workspace_bytes(const sol_karman3d_cfg* c) {
+    if (!c) return 0;
+    const size_t B = c->B, Y = c->Y, X = c->X, Z = c->Z;
+    // g_a and g_c (three components each) + rhs + two transform buffers
+    const size_t floats = B * (2 * ((Y + 1) * X * Z + Y * (X + 1) * Z + Y * X * (Z + 1)) + 3 * Y * X * Z) + 256;
+    return floats * sizeof(float);
+}
+
+extern "C" int sol_karman3d_step_bwd(const sol_karman3d_cfg* c, void* stream,
+                                     const float* saved_vy, const float* saved_vx, const float* saved_vz,
+                                     const float* re, const float* active, const float* velBCyMask, int64_t bc_batch_stride,
+                                     const float* g_vy_out, const float* g_vx_out, const float* g_vz_out,
+                                     float* g_vy_in, float* g_vx_in, float* g_vz_in,
+                                     const int32_t* direct_header_host, void* workspace, size_t workspace_bytes) {
+    SOL_REQUIRE(c != nullptr, "cfg is NULL");
+    SOL_REQUIRE(c->B >= 1 && c->Y >= 8 && c->X >= 8 && c->Z >= 8 && c->B <= 65535, "sol_karman3d_step_bwd: B >= 1, Y, X, Z >= 8");
+    SOL_REQUIRE(saved_vy && saved_vx && saved_vz && re && active && velBCyMask && g_vy_out && g_vx_out && g_vz_out && g_vy_in && g_vx_in && g_vz_in && workspace,
+                "sol_karman3d_step_bwd: NULL pointer argument");
+    if (int e = check_blob3d(c, direct_header_host)) return e;
+    SOL_REQUIRE(workspace_bytes >= sol_karman3d_step_bwd_workspace_bytes(c), "workspace too small");
+    const int B = c->B, Y = c->Y, X = c->X, Z = c->Z, N = Y * X * Z;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nVy = (size_t)(Y + 1) * X * Z, nVx = (size_t)Y * (X + 1) * Z, nVz = (size_t)Y * X * (Z + 1), faces = nVy + nVx + nVz;
+    float* w = static_cast<float*>(workspace);
+    K3BArgs a{};
+    a.B = B; a.Y = Y; a.X = X; a.Z = Z; a.dtdx = c->dt / c->dx; a.adt = c->dt * c->res * c->res; a.grad_pad = c->grad_pad;
+    a.re = re; a.active = active; a.bcm = velBCyMask; a.bc_stride = bc_batch_stride;
+    a.svy = saved_vy; a.svx = saved_vx; a.svz = saved_vz; a.goy = g_vy_out; a.gox = g_vx_out; a.goz = g_vz_out;
+    a.gay = w; w += B * nVy; a.gax = w; w += B * nVx; a.gaz = w; w += B * nVz;
+    a.gcy = w; w += B * nVy; a.gcx = w; w += B * nVx; a.gcz = w; w += B * nVz;
+    float* R = w; w += (size_t)B * N;
+    float* T1 = w; w += (size_t)B * N;
+    float* T2 = w; w += (size_t)B * N;
+    a.rhs = R; a.giy = g_vy_in; a.gix = g_vx_in; a.giz = g_vz_in;
+    SOL_LAUNCH(k3b_rhs, dim3(grid_for(N), B), dim3(256), 0, s, a);
+    SOL_LAUNCH_CHECK();
+    float* res = nullptr;
+    if (int e = pressure_solve3d(s, c, direct_header_host, R, T1, T2, &res)) return e;
+    a.gdiv = res;
+    SOL_LAUNCH(k3b_gva, dim3(grid_for(faces), B), dim3(256), 0, s, a);
+    SOL_LAUNCH(k3_fill, dim3(grid_for(B * faces)), dim3(256), 0, s, a.gcy, (const float*)nullptr, B * faces);     // g_c: three contiguous components
+    SOL_LAUNCH(k3b_advect_adj, dim3(grid_for((size_t)((Y + 1) * X + Y * (X + 1) + Y * X) * 64), B), dim3(256), 0, s, a);
+    SOL_LAUNCH(k3b_diffuse_adj, dim3(grid_for(faces), B), dim3(256), 0, s, a);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }
@@ -622,11 +896,16 @@ extern "C" int sol_karman3d_correct(void* stream, const float* out, int32_t cout
 // ------------------------------------------------------------------------------------------------------------------------
 extern "C" size_t sol_conv3d_packed_floats(int32_t cin, int32_t cout) { return 5 * align_up(sol_conv5x5_packed_floats(cin, cout, SOL_CONV_FWD), 64); }
 
-extern "C" int sol_conv3d_pack(void* stream, const float* w_dhwio, int32_t cin, int32_t cout, float* packed) {
+extern "C" int sol_conv3d_pack(void* stream, const float* w_dhwio, int32_t cin, int32_t cout, int32_t mode, float* packed) {
     SOL_REQUIRE(w_dhwio && packed, "sol_conv3d_pack: NULL pointer");
+    SOL_REQUIRE(mode == SOL_CONV_FWD || mode == SOL_CONV_BWD_DATA, "sol_conv3d_pack: bad mode %d", mode);
     const size_t per = align_up(sol_conv5x5_packed_floats(cin, cout, SOL_CONV_FWD), 64);
-    for (int kd = 0; kd < 5; ++kd)
-        if (int e = sol_conv5x5_pack(stream, w_dhwio + (size_t)kd * 25 * cin * cout, cin, cout, SOL_CONV_FWD, packed + kd * per)) return e;
+    for (int kd = 0; kd < 5; ++kd) {
+        // backward-data: the flipped kernel -- slice kd of the run convolution is the forward slice 4 - kd, its 2-D taps flipped
+        // and its channel axes swapped by the 2-D packer's SOL_CONV_BWD_DATA mode
+        const int src = mode == SOL_CONV_FWD ? kd : 4 - kd;
+        if (int e = sol_conv5x5_pack(stream, w_dhwio + (size_t)src * 25 * cin * cout, cin, cout, mode, packed + kd * per)) return e;
+    }
     return SOL_OK;
 }
 

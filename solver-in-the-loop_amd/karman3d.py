@@ -7,6 +7,10 @@ components + Re) and 3 output channels, and the roll-out loop of karman_apply.py
 
 Layout: density [B,Y,X,Z], v_y [B,Y+1,X,Z], v_x [B,Y,X+1,Z], v_z [B,Y,X,Z+1] (y = flow direction, z contiguous); CNN
 tensors [B,Y,X,Z,C].  Everything calls libsol_hip.so (csrc/karman3d.hip); there is no CPU implementation.
+
+Training (SOL-n, the reverse sweep of karman_train.py:397-457 in 3-D): `Karman3DFlow.step` and `conv3d` are torch.autograd
+Functions over the HIP adjoints (sol_karman3d_step_bwd; Conv3D backward-data = sol_conv3d on flipped weights, weight gradient
+= five passes of the 2-D weight-gradient kernels), composed by `Karman3DTrainer` exactly as the reference composes its graph.
 """
 import ctypes as C
 import math
@@ -87,15 +91,13 @@ class Karman3DFlow:
         self.cfg = Karman3DCfg(batch_size, s.Y, s.X, s.Z, float(s.dx), float(dt), float(s.X if res is None else res),
                                {"replicate": 0, "dirichlet0": 1}[grad_pad], {"after": 0, "before": 1}[inflow_order],
                                s.direct.numel(), s.direct.data_ptr())
-        nbytes = self.lib.sol_karman3d_step_workspace_bytes(C.byref(self.cfg))
+        nbytes = max(self.lib.sol_karman3d_step_workspace_bytes(C.byref(self.cfg)), self.lib.sol_karman3d_step_bwd_workspace_bytes(C.byref(self.cfg)))
         self.workspace = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=s.active.device)
         self.workspace_bytes = nbytes
 
-    def step(self, d, vy, vx, vz, re, feat_out=None, feat_scale=None):
-        """(d, vy, vx, vz) -> new tensors after one solver step; feat_out [B,Y,X,Z,4] (optional) receives the scaled features."""
+    def _fwd(self, d, vy, vx, vz, re, saved=None, feat_out=None, feat_scale=None):
         s, B = self.scene, self.B
         Y, X, Z = s.Y, s.X, s.Z
-        d, vy, vx, vz, re = (_lib.f32(t) for t in (d, vy, vx, vz, re))
         assert d.shape == (B, Y, X, Z) and vy.shape == (B, Y + 1, X, Z) and vx.shape == (B, Y, X + 1, Z) and vz.shape == (B, Y, X, Z + 1)
         assert re.shape == (B,)
         out = [torch.empty_like(t) for t in (d, vy, vx, vz)]
@@ -103,11 +105,64 @@ class Karman3DFlow:
         if feat_out is not None:
             assert feat_out.shape == (B, Y, X, Z, 4) and feat_out.is_contiguous()
             fs = (C.c_float * 4)(*[float(v) for v in feat_scale])
+        sv = saved if saved is not None else (None, None, None)
         check(self.lib.sol_karman3d_step_fwd(C.byref(self.cfg), stream(), ptr(d), ptr(vy), ptr(vx), ptr(vz), ptr(re),
                                              ptr(s.active), ptr(s.inflow), ptr(s.velBCy), ptr(s.velBCyMask), s.bc_stride,
-                                             ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(feat_out), fs,
+                                             ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(sv[0]), ptr(sv[1]), ptr(sv[2]),
+                                             ptr(feat_out), fs,
                                              s.direct_header.ctypes.data_as(C.c_void_p), ptr(self.workspace), self.workspace_bytes))
         return tuple(out)
+
+    def _bwd(self, saved, re, gvy, gvx, gvz):
+        s = self.scene
+        gi = [torch.empty_like(t) for t in saved]
+        check(self.lib.sol_karman3d_step_bwd(C.byref(self.cfg), stream(), ptr(saved[0]), ptr(saved[1]), ptr(saved[2]), ptr(re),
+                                             ptr(s.active), ptr(s.velBCyMask), s.bc_stride, ptr(gvy), ptr(gvx), ptr(gvz),
+                                             ptr(gi[0]), ptr(gi[1]), ptr(gi[2]),
+                                             s.direct_header.ctypes.data_as(C.c_void_p), ptr(self.workspace), self.workspace_bytes))
+        return gi
+
+    def step(self, d, vy, vx, vz, re, feat_out=None, feat_scale=None):
+        """(d, vy, vx, vz) -> new tensors after one solver step.  Differentiable with respect to the velocity (the density is
+        a passive tracer) when a velocity input requires grad; feat_out [B,Y,X,Z,4] (optional, no-grad use) receives the
+        scaled features."""
+        d, vy, vx, vz, re = (_lib.f32(t) for t in (d, vy, vx, vz, re))
+        if torch.is_grad_enabled() and (vy.requires_grad or vx.requires_grad or vz.requires_grad):
+            if feat_out is not None:
+                raise ValueError("feat_out is the fused no-grad feature output: build the features with to_feature3d() when training")
+            return _Karman3DStepFn.apply(self, d, vy, vx, vz, re)
+        return self._fwd(d, vy, vx, vz, re, None, feat_out, feat_scale)
+
+
+class _Karman3DStepFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sim, d, vy, vx, vz, re):
+        saved = [torch.empty_like(t) for t in (vy, vx, vz)]
+        out = sim._fwd(d, vy.contiguous(), vx.contiguous(), vz.contiguous(), re, saved)
+        ctx.sim = sim
+        ctx.save_for_backward(re, *saved)
+        ctx.mark_non_differentiable(out[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, _gd, gvy, gvx, gvz):
+        re, sy, sx, sz = ctx.saved_tensors
+        z = lambda g, t: torch.zeros_like(t) if g is None else g.contiguous()
+        gi = ctx.sim._bwd((sy, sx, sz), re, z(gvy, sy), z(gvx, sx), z(gvz, sz))
+        return None, None, gi[0], gi[1], gi[2], None
+
+
+def to_feature3d(vy, vx, vz, re):
+    """karman_train.py:77-86 with three components: [B,Y,X,Z,4] = the components at the low faces of every cell + Re."""
+    Y, X, Z = vx.shape[1], vy.shape[2], vy.shape[3]
+    st = torch.stack([vy[:, :Y], vx[:, :, :X], vz[..., :Z]], dim=-1)
+    return torch.cat([st, re.reshape(-1, 1, 1, 1, 1).expand(-1, Y, X, Z, 1).to(st.dtype)], dim=-1)
+
+
+def to_staggered3d(t):
+    """karman_train.py:88-90 with three components: zero padding at the high end of each component's own axis."""
+    pad = torch.nn.functional.pad
+    return pad(t[..., 0], (0, 0, 0, 0, 0, 1)), pad(t[..., 1], (0, 0, 0, 1)), pad(t[..., 2], (0, 1))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -139,6 +194,17 @@ class MarsMoon3D:
         self.params = torch.cat(parts).to(device=device, dtype=torch.float32).contiguous()
         self._packed = None
 
+    def __call__(self, x):
+        """Differentiable forward (training): x [B,Y,X,Z,4] -> [B,Y,X,Z,cout]; gradients flow to self.params (set
+        `net.params.requires_grad_(True)`) and to x."""
+        p = self.tensors()
+        sl = self.slope
+        h = conv3d_fn(x, p[0], p[1], None, True, sl)
+        for k in range(5):
+            a = conv3d_fn(h, p[2 + 4 * k], p[3 + 4 * k], None, True, sl)
+            h = conv3d_fn(a, p[4 + 4 * k], p[5 + 4 * k], h, True, sl)
+        return conv3d_fn(h, p[22], p[23], None, False, sl)
+
     @property
     def n_params(self):
         return int(self.offsets[-1])
@@ -169,7 +235,7 @@ class MarsMoon3D:
                     w = torch.nn.functional.pad(w, (0, 0, 0, cin_k - cin))
                 w = w.contiguous()
                 buf = torch.empty(lib.sol_conv3d_packed_floats(cin_k, cout), dtype=torch.float32, device=w.device)
-                check(lib.sol_conv3d_pack(stream(), ptr(w), cin_k, cout, ptr(buf)))
+                check(lib.sol_conv3d_pack(stream(), ptr(w), cin_k, cout, 0, ptr(buf)))
                 self._packed.append((buf, t[2 * l + 1].contiguous(), cin_k, cout))
         return self._packed
 
@@ -182,6 +248,142 @@ def conv3d(x, packed, bias, residual, cout, lrelu, slope, x_absmax=None, y_absma
     check(lib.sol_conv3d(stream(), ptr(x), ptr(packed), ptr(bias), ptr(residual), ptr(y), B, D, H, W, cin, cout,
                          EPI_LRELU if lrelu else EPI_NONE, float(slope), ptr(x_absmax), ptr(y_absmax)))
     return y
+
+
+def _pack3d(w, cin_run, cout_run, mode):
+    lib = _lib.load()
+    buf = torch.empty(lib.sol_conv3d_packed_floats(cin_run, cout_run), dtype=torch.float32, device=w.device)
+    check(lib.sol_conv3d_pack(stream(), ptr(w.contiguous()), cin_run, cout_run, mode, ptr(buf)))
+    return buf
+
+
+def _pad_ch(x, c):
+    return x.contiguous() if x.shape[-1] == c else torch.nn.functional.pad(x, (0, c - x.shape[-1])).contiguous()
+
+
+def conv3d_bwd_weight(xk, dz, cin, cout):
+    """dW [5,5,5,cin,cout], db [cout] of y = conv3d(x, W) + b from xk [B,D,H,W,cin_k] (channels padded to 4 / 32) and dz
+    [B,D,H,W,cout]:  dW[kd] = sum over planes d of the 2-D weight gradient of (x[d + kd - 2], dz[d]) -- five passes of
+    sol_conv5x5_bwd_weight over the shifted plane ranges, each accumulated in its own partial buffer and reduced once."""
+    lib = _lib.load()
+    B, D, H, W, cin_k = xk.shape
+    co_k = cout if cout in (2, 32) else 32                 # the 2-D weight-gradient kernels take 2 or 32 output channels
+    dzk = _pad_ch(dz, co_k)
+    nws = lib.sol_conv5x5_bwd_weight_ws_floats(B * D, H, W, cin_k, co_k)
+    dW = torch.empty(5, 5, 5, cin, cout, dtype=torch.float32, device=xk.device)
+    db = torch.empty(co_k, dtype=torch.float32, device=xk.device)
+    dwk = torch.empty(5, 5, cin, co_k, dtype=torch.float32, device=xk.device)
+    dbk = torch.empty(co_k, dtype=torch.float32, device=xk.device)
+    for kd in range(5):
+        part = torch.zeros(nws, dtype=torch.float32, device=xk.device)
+        lo, hi = max(0, 2 - kd), min(D, D + 2 - kd)          # output planes that see input plane d + kd - 2
+        if kd == 2:
+            check(lib.sol_conv5x5_bwd_weight(stream(), ptr(xk), ptr(dzk), ptr(part), B * D, H, W, cin_k, co_k))
+        else:
+            for b in range(B):
+                check(lib.sol_conv5x5_bwd_weight(stream(), ptr(xk[b, lo + kd - 2:hi + kd - 2]), ptr(dzk[b, lo:hi]), ptr(part), hi - lo, H, W, cin_k, co_k))
+        check(lib.sol_conv5x5_bwd_weight_reduce(stream(), ptr(part), ptr(dwk), ptr(dbk if kd != 2 else db), B * D, H, W, cin, co_k, 0))
+        dW[kd].copy_(dwk[..., :cout])
+    return dW, db[:cout].clone()
+
+
+class _Conv3DFn(torch.autograd.Function):
+    """y = act(conv3d_same(x, w) + b (+ residual)), NDHWC, w in Keras DHWIO layout."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, residual, lrelu, slope):
+        _lib.require_gpu()
+        cin, cout = w.shape[3], w.shape[4]
+        assert cin in (1, 2, 3, 4, 32), "conv3d supports <= 4 or 32 input channels"
+        cin_k = 4 if cin <= 4 else 32
+        xk = _pad_ch(_lib.f32(x), cin_k)
+        wk = _pad_ch(_lib.f32(w).permute(0, 1, 2, 4, 3), cin_k).permute(0, 1, 2, 4, 3).contiguous() if cin_k != cin else _lib.f32(w)
+        packed = _pack3d(wk, cin_k, cout, 0)
+        res = None if residual is None else _lib.f32(residual)
+        y = conv3d(xk, packed, _lib.f32(b), res, cout, lrelu, slope)
+        ctx.save_for_backward(xk, w, y)
+        ctx.meta = (cin, cout, cin_k, lrelu, slope, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xk, w, y = ctx.saved_tensors
+        cin, cout, cin_k, lrelu, slope, has_res = ctx.meta
+        dz = gy.contiguous()
+        if lrelu:
+            dz = dz * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, slope))
+        dW, db = conv3d_bwd_weight(xk, dz, cin, cout)
+        # data gradient: the flipped kernel, run channels (cout -> cin)
+        co_k = 4 if cout <= 4 else 32
+        packed = _pack3d(_lib.f32(w), cout, cin, 1)
+        dx = conv3d(_pad_ch(dz, co_k), packed, None, None, cin, False, slope)
+        return dx, dW, db, (dz if has_res else None), None, None
+
+
+def conv3d_fn(x, w, b, residual=None, lrelu=False, slope=0.3):
+    return _Conv3DFn.apply(x, w, b, residual, lrelu, slope)
+
+
+class Karman3DTrainer:
+    """SOL-n training step of the 3-D scene: msteps x [solver step -> features / std -> mars_moon3d -> velocity += std *
+    to_staggered(correction)], loss = sum_i l2_loss((gt_i - prd_i) / std_v) / msteps (karman_train.py:397-447 with three
+    components), reverse sweep through the HIP adjoints by torch autograd, TF-Adam on the flat parameter buffer
+    (sol_adam_tf_step).  gts: [msteps] of (vy, vx, vz) ground-truth frames."""
+
+    def __init__(self, net, scene, B, msteps, std_v, std_re, dt=1.0, res=None, beta1=0.9, beta2=0.999, eps=1e-8, conv_precision="split", **solver):
+        from .trainer import _conv_precision_code
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.net, self.scene, self.B, self.ms = net, scene, B, msteps
+        self.sim = Karman3DFlow(scene, B, dt=dt, res=res, **solver)
+        dev = scene.active.device
+        self.std_v = torch.tensor([float(v) for v in std_v], dtype=torch.float32, device=dev)
+        self.std_in = torch.tensor([float(v) for v in std_v] + [float(std_re)], dtype=torch.float32, device=dev)
+        self.conv_precision = _conv_precision_code(conv_precision)
+        net.params.requires_grad_(True)
+        self.m = torch.zeros_like(net.params.detach())
+        self.v = torch.zeros_like(net.params.detach())
+        self.t = 0
+        self.beta1, self.beta2, self.eps = beta1, beta2, eps
+        self.loss_steps = None
+        self.final = None
+
+    def fwd_bwd(self, d, vy, vx, vz, re, gts):
+        from .trainer import _conv_precision_scope
+        f = _lib.f32
+        d, vy, vx, vz, re = f(d), f(vy), f(vx), f(vz), f(re)
+        self.net.params.grad = None
+        self.net._packed = None
+        with _conv_precision_scope(self.conv_precision):
+            v = (vy.requires_grad_(True), vx, vz)             # the state enters the graph (the step's autograd Function needs a grad-requiring input)
+            losses = []
+            for i in range(self.ms):
+                d, *v = self.sim.step(d, v[0], v[1], v[2], re)
+                out = self.net(to_feature3d(v[0], v[1], v[2], re) / self.std_in) * self.std_v
+                v = tuple(a + c for a, c in zip(v, to_staggered3d(out)))
+                losses.append(sum(0.5 * (((f(g) - a) / s) ** 2).sum() for g, a, s in zip(gts[i], v, self.std_v)))
+            losses = torch.stack(losses)
+            loss = losses.sum() / self.ms
+            loss.backward()
+        self.loss_steps = losses.detach()
+        self.final = (d.detach(),) + tuple(a.detach() for a in v)
+        return loss.detach()
+
+    @property
+    def grads(self):
+        return self.net.params.grad
+
+    def apply_gradients(self, lr):
+        self.t += 1
+        p = self.net.params.detach()
+        check(self.lib.sol_adam_tf_step(stream(), ptr(p), ptr(self.net.params.grad.contiguous()), ptr(self.m), ptr(self.v),
+                                        self.net.n_params, self.t, float(lr), self.beta1, self.beta2, self.eps, 0.0, None, 0, None))
+        self.net._packed = None
+
+    def train_step(self, d, vy, vx, vz, re, gts, lr):
+        loss = self.fwd_bwd(d, vy, vx, vz, re, gts)
+        self.apply_gradients(lr)
+        return loss
 
 
 class Karman3DRollout:

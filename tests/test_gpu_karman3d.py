@@ -191,3 +191,88 @@ def test_karman3d_full_size_step_against_oracle():
     inner[1:-1, 1:-1, 1:-1] = 1.0
     resid = float((div * inner * torch.as_tensor(g.active)).abs().max())
     assert resid < 2e-5, resid                                    # |v| ~ 1: fp32 round-off of the direct solve
+
+
+# ---------------------------------------------------------------------------------------------
+# training path: adjoint of the 3-D step, Conv3D gradients, SOL-n trainer
+# ---------------------------------------------------------------------------------------------
+TOL_GRAD = 1e-4          # as in 2-D: gradients pass through two fp32 direct solves per step
+
+
+@pytest.mark.parametrize("shape,kw", [((2, 16, 8, 8), {}), ((2, 16, 8, 8), dict(grad_pad="dirichlet0")), ((1, 32, 16, 16), {})])
+def test_karman3d_step_adjoint_against_oracle_autograd(shape, kw):
+    B, Y, X, Z = shape
+    g = o.geometry(Y, X, Z)
+    d, v = o.synthetic_state(B, Y, X, Z, 13)
+    v = tuple(c.float().double() for c in v)
+    re = torch.tensor(o.RE_TRAIN[:B])
+    gen = torch.Generator().manual_seed(3)
+    w = [torch.randn(c.shape, generator=gen, dtype=torch.float64).float().double() for c in v]
+    vr = tuple(c.clone().requires_grad_(True) for c in v)
+    _, out = o.karman3d_step(d, vr, re, g, **kw)
+    sum((a * b).sum() for a, b in zip(out, w)).backward()
+    sc = k3.Scene3D(Y, X, Z, device=DEV)
+    sim = k3.Karman3DFlow(sc, B, **kw)
+    hv = [f32(c).requires_grad_(True) for c in v]
+    hout = sim.step(f32(d), hv[0], hv[1], hv[2], f32(re))
+    assert max(rel(a, b) for a, b in zip(hout[1:], out)) < TOL_FIELD
+    sum((a * f32(b)).sum() for a, b in zip(hout[1:], w)).backward()
+    errs = [rel(a.grad, b.grad) for a, b in zip(hv, vr)]
+    assert max(errs) < TOL_GRAD, errs
+    assert not hout[0].requires_grad                      # the density is a passive tracer
+
+
+@pytest.mark.parametrize("shape,cin,cout,res,lrelu", [
+    ((1, 5, 16, 16), 4, 32, False, True), ((2, 4, 16, 16), 32, 32, True, True), ((1, 4, 16, 16), 32, 3, False, False),
+    ((1, 3, 64, 64), 32, 32, True, True), ((1, 3, 64, 64), 32, 3, False, False), ((1, 3, 64, 64), 4, 32, False, True)])
+def test_conv3d_gradients_against_oracle(shape, cin, cout, res, lrelu):
+    B, D, H, W = shape
+    gen = torch.Generator().manual_seed(7 + cin + cout)
+    r64 = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64).float().double()
+    x, w, b = r64(B, D, H, W, cin).requires_grad_(True), (r64(5, 5, 5, cin, cout) / np.sqrt(125 * cin)).float().double().requires_grad_(True), r64(cout).requires_grad_(True)
+    r = r64(B, D, H, W, cout).requires_grad_(True) if res else None
+    gy = r64(B, D, H, W, cout)
+    (_oracle_conv(x, w, b, r, lrelu) * gy).sum().backward()
+    hx, hw, hb = (f32(t.detach()).requires_grad_(True) for t in (x, w, b))
+    hr = f32(r.detach()).requires_grad_(True) if res else None
+    y = k3.conv3d_fn(hx, hw, hb, hr, lrelu, 0.3)
+    (y * f32(gy)).sum().backward()
+    assert rel(hx.grad, x.grad) < 5e-6 and rel(hw.grad, w.grad) < 5e-6 and rel(hb.grad, b.grad) < 5e-6, (rel(hx.grad, x.grad), rel(hw.grad, w.grad), rel(hb.grad, b.grad))
+    if res:
+        assert rel(hr.grad, r.grad) < 5e-6
+
+
+def test_karman3d_trainer_sol2_against_oracle():
+    """SOL-2 at 32 x 16 x 16, B = 2: loss, per-step losses, the full 1.3 M-element gradient, the final state and one TF-Adam
+    update against the float64 oracle (autograd through the unrolled 3-D graph)."""
+    import make_golden as mg
+    import sol_oracle as o2
+    B, Y, X, Z, ms = 2, 32, 16, 16, 2
+    g = o.geometry(Y, X, Z)
+    d, v = o.synthetic_state(B, Y, X, Z, 77)
+    d, v = d.float().double(), tuple(c.float().double() for c in v)
+    re = torch.tensor(o.RE_TRAIN[:B])
+    gts = []
+    for i in range(ms):
+        _, gv = o.synthetic_state(B, Y, X, Z, 500 + i)
+        gts.append(tuple(c.float().double() for c in gv))
+    std_v = (0.2, 0.25, 0.3)
+    params = [p.clone().requires_grad_(True) for p in mg.k3d_params()]
+    loss = o.unrolled_loss(params, d, v, re, gts, g, std_v, o.STD_RE)
+    loss.backward()
+    gref = torch.cat([p.grad.reshape(-1) for p in params])
+    sc = k3.Scene3D(Y, X, Z, device=DEV)
+    net = k3.MarsMoon3D(device=DEV)
+    net.set_weights([p.detach().numpy() for p in params])
+    tr = k3.Karman3DTrainer(net, sc, B, ms, std_v, o.STD_RE)
+    hl = tr.fwd_bwd(d, v[0], v[1], v[2], re, gts)
+    assert abs(float(hl) - float(loss)) < 1e-5 * abs(float(loss)), (float(hl), float(loss))
+    assert rel(tr.grads, gref) < TOL_GRAD, rel(tr.grads, gref)
+    off = net.offsets
+    per = [rel(tr.grads[off[k]:off[k + 1]], params[k].grad.reshape(-1)) for k in range(len(params))]
+    assert max(per) < 3 * TOL_GRAD, per
+    # one TF-Adam update (epsilon-hat form) against the oracle's
+    p2, _, _ = o2.adam_tf([p.detach() for p in params], [p.grad for p in params], [torch.zeros_like(p) for p in params],
+                          [torch.zeros_like(p) for p in params], 1, 1e-4)
+    tr.apply_gradients(1e-4)
+    assert rel(net.params.detach(), torch.cat([p.reshape(-1) for p in p2])) < 1e-6
