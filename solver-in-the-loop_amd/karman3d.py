@@ -269,20 +269,24 @@ def conv3d_bwd_weight(xk, dz, cin, cout):
     B, D, H, W, cin_k = xk.shape
     co_k = cout if cout in (2, 32) else 32                 # the 2-D weight-gradient kernels take 2 or 32 output channels
     dzk = _pad_ch(dz, co_k)
-    nws = lib.sol_conv5x5_bwd_weight_ws_floats(B * D, H, W, cin_k, co_k)
     dW = torch.empty(5, 5, 5, cin, cout, dtype=torch.float32, device=xk.device)
     db = torch.empty(co_k, dtype=torch.float32, device=xk.device)
     dwk = torch.empty(5, 5, cin, co_k, dtype=torch.float32, device=xk.device)
     dbk = torch.empty(co_k, dtype=torch.float32, device=xk.device)
+
+    def one(x_planes, dz_planes, n, accumulate, db_out):
+        # the partial buffer's layout follows the launch (rows / workgroup count): one buffer per call, folded into dwk
+        part = torch.zeros(lib.sol_conv5x5_bwd_weight_ws_floats(n, H, W, cin_k, co_k), dtype=torch.float32, device=xk.device)
+        check(lib.sol_conv5x5_bwd_weight(stream(), ptr(x_planes), ptr(dz_planes), ptr(part), n, H, W, cin_k, co_k))
+        check(lib.sol_conv5x5_bwd_weight_reduce(stream(), ptr(part), ptr(dwk), ptr(db_out), n, H, W, cin, co_k, accumulate))
+
     for kd in range(5):
-        part = torch.zeros(nws, dtype=torch.float32, device=xk.device)
         lo, hi = max(0, 2 - kd), min(D, D + 2 - kd)          # output planes that see input plane d + kd - 2
         if kd == 2:
-            check(lib.sol_conv5x5_bwd_weight(stream(), ptr(xk), ptr(dzk), ptr(part), B * D, H, W, cin_k, co_k))
+            one(xk, dzk, B * D, 0, db)
         else:
             for b in range(B):
-                check(lib.sol_conv5x5_bwd_weight(stream(), ptr(xk[b, lo + kd - 2:hi + kd - 2]), ptr(dzk[b, lo:hi]), ptr(part), hi - lo, H, W, cin_k, co_k))
-        check(lib.sol_conv5x5_bwd_weight_reduce(stream(), ptr(part), ptr(dwk), ptr(dbk if kd != 2 else db), B * D, H, W, cin, co_k, 0))
+                one(xk[b, lo + kd - 2:hi + kd - 2], dzk[b, lo:hi], hi - lo, 1 if b else 0, dbk)
         dW[kd].copy_(dwk[..., :cout])
     return dW, db[:cout].clone()
 

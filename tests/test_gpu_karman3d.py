@@ -130,7 +130,7 @@ def test_conv3d_against_oracle(shape, cin, cout, res, lrelu):
     lib = sol_amd.load()
     wd = f32(w)
     packed = torch.empty(lib.sol_conv3d_packed_floats(cin, cout), dtype=torch.float32, device=DEV)
-    sol_amd._lib.check(lib.sol_conv3d_pack(sol_amd._lib.stream(), sol_amd._lib.ptr(wd), cin, cout, sol_amd._lib.ptr(packed)))
+    sol_amd._lib.check(lib.sol_conv3d_pack(sol_amd._lib.stream(), sol_amd._lib.ptr(wd), cin, cout, 0, sol_amd._lib.ptr(packed)))
     xd = f32(x)
     for use_amax in ((False, True) if cin == 32 else (False,)):
         amax = sol_amd.ops.absmax_slots(xd) if use_amax else None
@@ -237,7 +237,10 @@ def test_conv3d_gradients_against_oracle(shape, cin, cout, res, lrelu):
     hr = f32(r.detach()).requires_grad_(True) if res else None
     y = k3.conv3d_fn(hx, hw, hb, hr, lrelu, 0.3)
     (y * f32(gy)).sum().backward()
-    assert rel(hx.grad, x.grad) < 5e-6 and rel(hw.grad, w.grad) < 5e-6 and rel(hb.grad, b.grad) < 5e-6, (rel(hx.grad, x.grad), rel(hw.grad, w.grad), rel(hb.grad, b.grad))
+    errs = (rel(hx.grad, x.grad), rel(hw.grad, w.grad), rel(hb.grad, b.grad))
+    per_plane = [rel(hx.grad[:, dd], x.grad[:, dd]) for dd in range(D)]
+    per_slice = [rel(hw.grad[kd], w.grad[kd]) for kd in range(5)]
+    assert max(errs) < 5e-6, (errs, per_plane, per_slice)
     if res:
         assert rel(hr.grad, r.grad) < 5e-6
 
@@ -271,8 +274,13 @@ def test_karman3d_trainer_sol2_against_oracle():
     off = net.offsets
     per = [rel(tr.grads[off[k]:off[k + 1]], params[k].grad.reshape(-1)) for k in range(len(params))]
     assert max(per) < 3 * TOL_GRAD, per
-    # one TF-Adam update (epsilon-hat form) against the oracle's
+    # one TF-Adam update in closed form from the gradient the trainer holds (epsilon-hat form: m = 0.1 g, v = 0.001 g^2,
+    # lr_t = lr sqrt(1 - 0.999) / (1 - 0.9)); the float64 oracle's update differs where fp32 round-off flips the sign of a
+    # near-zero gradient element, so the comparison is made on the same gradient
+    g64, p64 = tr.grads.double(), net.params.detach().double()
+    expect = p64 - 1e-4 * (1 - 0.999) ** 0.5 / (1 - 0.9) * 0.1 * g64 / ((0.001 * g64 * g64).sqrt() + 1e-8)
+    tr.apply_gradients(1e-4)
+    assert rel(net.params.detach(), expect) < 1e-6
     p2, _, _ = o2.adam_tf([p.detach() for p in params], [p.grad for p in params], [torch.zeros_like(p) for p in params],
                           [torch.zeros_like(p) for p in params], 1, 1e-4)
-    tr.apply_gradients(1e-4)
-    assert rel(net.params.detach(), torch.cat([p.reshape(-1) for p in p2])) < 1e-6
+    assert rel(net.params.detach(), torch.cat([p.reshape(-1) for p in p2])) < 1e-4
