@@ -163,9 +163,9 @@ def profile_kernels(wl, lr, trainer=None):
 
 
 def karman3d_leg(sol_amd, dev, B=1, steps=8):
-    """BASELINE configs[4] grid, forward path (the 3-D adjoint is not built yet): 128 x 64 x 64, SOL-16-style roll-out of
-    solver step + Conv3D correction.  Reports ms per simulation step, the per-kernel table of one step (per-launch HIP events)
-    and, for the stencil kernels, their ALGORITHMIC bytes per launch against the 8 TB/s HBM peak:
+    """BASELINE configs[4] grid, 128 x 64 x 64: (a) forward roll-out of solver step + Conv3D correction -- ms per simulation
+    step, the per-kernel table of one step (per-launch HIP events) and, for the stencil kernels, their ALGORITHMIC bytes per
+    launch against the 8 TB/s HBM peak; (b) the SOL-16 training step (train_sol16).  Stencil traffic accounting:
       k3_diffuse      reads the 3 components + the 2 BC arrays of the flow component, writes 3 components
       k3_advect_*     reads 3 diffused components + density, writes 3 components + density
       k3_div          reads 3 components, writes the right-hand side
@@ -210,10 +210,38 @@ def karman3d_leg(sol_amd, dev, B=1, steps=8):
         kern[nm] = e
     flop = 2.0 * 125 * (4 * 32 + 10 * 32 * 32 + 32 * 3) * B * N
     t_cnn = sum(t for k, (c, t) in p.kernels.items() if "conv" in k or k == "k3_fill")
-    return {"workload": "karman-3d %dx%dx%d, batch %d, forward roll-out (solver step + Conv3D(5) mars_moon correction; BASELINE configs[4] grid)" % (Y, X, Z, B),
+    # SOL-16 training step (BASELINE configs[4]: forward unroll, loss, reverse sweep through the HIP adjoints, TF-Adam)
+    train = None
+    try:
+        del ro
+        ms3 = 16
+        tr = k3.Karman3DTrainer(net, sc, B, ms3, (0.2, 0.2, 0.2), synthetic.STD_RE)
+        gts = []
+        gs = st
+        with torch.no_grad():
+            sim = tr.sim
+            for _ in range(ms3):                      # ground truth = plain solver roll-out of a perturbed start (as the 2-D workload)
+                gs = sim.step(gs[0], gs[1], gs[2], gs[3], re)
+                gts.append(tuple(t + 0.01 * torch.randn_like(t) for t in gs[1:]))
+        torch.cuda.reset_peak_memory_stats()
+        l0 = float(tr.train_step(*st, re, gts, lr=1e-7))
+        torch.cuda.synchronize()
+        nrep = 2
+        t0 = time.perf_counter()
+        for _ in range(nrep):
+            l1 = float(tr.train_step(*st, re, gts, lr=1e-7))
+        torch.cuda.synchronize()
+        t_tr = (time.perf_counter() - t0) / nrep
+        train = {"msteps": ms3, "ms_per_step": t_tr * 1e3, "sim_steps_per_s": B * ms3 / t_tr, "loss": l1, "loss_first": l0, "finite": bool(math.isfinite(l1)),
+                 "peak_memory_GB": torch.cuda.max_memory_allocated() / 2 ** 30,
+                 "conv_fp32_equiv_TFLOPs_of_step": 3.0 * flop * ms3 / t_tr / 1e12,
+                 "note": "autograd composition of the HIP ops (eager launches, no hipGraph): forward + reverse sweep + TF-Adam"}
+    except Exception as e:
+        train = {"error": str(e)}
+    return {"train_sol16": train,"workload": "karman-3d %dx%dx%d, batch %d, forward roll-out (solver step + Conv3D(5) mars_moon correction; BASELINE configs[4] grid)" % (Y, X, Z, B),
             "ms_per_sim_step": ms_step, "sim_steps_per_s": B * 1e3 / ms_step, "finite": bool(torch.isfinite(s2[1]).all()),
             "cnn_fp32_equiv_TFLOPs": flop / (t_cnn * 1e-6) / 1e12, "solver_us": sum(t for k, (c, t) in p.kernels.items() if "conv" not in k and k not in ("k3_fill", "k3_correct")),
-            "kernels": kern, "note": "forward only: the adjoint of the 3-D step / Conv3D weight gradients are not built (DESIGN.md section 7)"}
+            "kernels": kern}
 
 
 def load_traffic():
