@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsol_hip.so")
-SOURCES = ["karman_step.hip", "karman_large.hip", "karman3d.hip", "burgers_step.hip", "conv5x5.hip", "conv5x5_sb.hip", "train.hip", "comm.hip", "cnn_chain.hip"]
+SOURCES = ["karman_step.hip", "karman_large.hip", "karman3d.hip", "conv3d_sb.hip", "burgers_step.hip", "conv5x5.hip", "conv5x5_sb.hip", "train.hip", "comm.hip", "cnn_chain.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 # the CG loop packs its vector updates by hand (float2); the SLP vectoriser only adds v_mov traffic there
 EXTRA = {"karman_step.hip": ["-fno-slp-vectorize"]}

@@ -121,6 +121,12 @@ int sol_conv_sh_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int 
 int sol_conv_sb_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int mode, void* out);
 int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles);
 
+// fused 5x5x5 convolution, 32 -> 32 channels, W == 64 (conv3d_sb.hip)
+size_t sol_conv3d_sh_packed_floats();
+int sol_conv3d_sh_pack(hipStream_t s, const float* w_dhwio, int mode, float* out);
+int sol_conv3d_sb_launch(hipStream_t s, const float* x, const float* wsh, const float* bias, const float* residual, float* y,
+                         int B, int D, int H, int epilogue, float slope, const unsigned* x_absmax, unsigned* y_absmax);
+
 // ---- process-wide options (sol_set_option / sol_get_option, include/sol_hip.h) ----------------------------------
 // Read at every call (plain ints, no caching in function-local statics), so a host may switch e.g. the convolution
 // precision between two trainers of one process.  The library itself never reads the environment.
@@ -143,6 +149,7 @@ struct SolOptions {
                           //    measured equal to the per-layer launches end to end, kept as a verified experiment
     int graph_stream;     // 1: sol_train_graph_launch replays on an internal stream fenced by events against the caller's stream
     int k3d_fused_tf;     // 1 (default): the sine transforms of the karman-3d pressure solve as LDS-resident plane / column-slab kernels; 0: batched GEMMs
+    int k3d_conv_fused;   // 1 (default): 32 -> 32 Conv3D layers with W == 64 and a known operand absmax as ONE launch (conv3d_sb.hip); 0: five passes of the 2-D kernel
     int k3d_tile;         // 1 (default): karman-3d advection from LDS tiles holding the full z column + halo; 0: straight from global memory
 };
 SolOptions& sol_opt();

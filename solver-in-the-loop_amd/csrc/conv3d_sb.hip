@@ -1,0 +1,323 @@
+// 5 x 5 x 5 SAME convolution, 32 -> 32 channels, NDHWC with W == 64, as ONE launch on the gfx950 16-bit matrix cores with
+// fp32-equivalent arithmetic (fp16 three-product operand splits, per-tensor power-of-two scale: KIND 2 of conv5x5_sb.hip).
+//
+// Replaces keras.layers.Conv3D(32, 5, padding='same') (+ bias, LeakyReLU, residual add) of the 3-D model_mars_moon -- the
+// dimension-generic form of /root/reference/karman-2d/karman_train.py:101-138 (the reference has no 3-D code, README.md:37-38).
+//
+// Why a kernel of its own: the five-pass form (sol_conv3d in karman3d.hip: one launch of the 2-D kernel per depth slice,
+// running sum in HBM) pays the 2-D kernel's per-workgroup skeleton (prologue round trip, epilogue, write drain) and a
+// read-modify-write of the 64 MB output per slice.  Here a workgroup keeps its three (x, z)-plane rows' accumulators in
+// registers across ALL 125 taps: for each depth slice kd it runs the 2-D kernel's five tap rows on plane d + kd - 2 (shared
+// 4-slot LDS ring of split input rows, double-buffered tap-row weight sets, one barrier per five taps), and the first rows /
+// weight sets of slice kd + 1 are REQUESTED during tap rows 3 and 4 of slice kd, so that the only exposed cost of a slice
+// boundary is one LDS write round + barrier.  One prologue round trip and one epilogue per 125 taps instead of per 25.
+//
+// Work decomposition, operand layout (ds_read_b128 fragments, XOR swizzle), epilogue: as k_conv5x5_sb<2, 2>.
+#include "split_kernels.hpp"
+
+namespace {
+
+using namespace sbk;
+
+#define C3_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+__global__ void __launch_bounds__(768) k_conv3d_sb(ConvArgs a, int nrows, int D) {
+    constexpr int NT = 2, OP = 32, HWP = 68;
+    constexpr int PLANE = HWP * 64;               // bytes per fp16 plane of one halo row
+    constexpr int SLOT = 2 * PLANE;               // hi + lo plane
+    constexpr int WPL = OP * 64;                  // bytes per (dx, plane) weight block
+    constexpr int WBUF = 5 * 2 * WPL;             // bytes per tap-row weight set (20 480)
+    constexpr int AMAX_LDS = 4 * SLOT + 2 * WBUF;
+    extern __shared__ __align__(16) unsigned char smem_c3[];
+    if (threadIdx.x == 0) *reinterpret_cast<uint2*>(smem_c3 + AMAX_LDS) = make_uint2(0u, 0u);      // see amax_publish_last
+    const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wid >> 2, t = tid & 255, lane = tid & 63, wave = wid & 3;
+    const int g = lane >> 4, li = lane & 15;
+    const int H = a.H;
+    constexpr int W = 64;
+    // workgroup = three consecutive global rows G0 .. G0+2 (row = plane * H + x-row, plane = b * D + d) of the [B*D*H][64][32] tensor
+    const int bx = xcd_tile(blockIdx.x, gridDim.x);
+    const int G0 = bx * 3;
+    const int gy = G0 + grp;
+    const bool tvalid = gy < nrows;
+    const int plane = (tvalid ? gy : 0) / H, dpl = plane % D;
+    const int row_lo = plane * H, row_hi = row_lo + H;
+    unsigned char* ring = smem_c3;                    // [4][2 planes][68][64 B]
+    unsigned char* Wt = smem_c3 + 4 * SLOT;           // [2][5][2 planes][32][64 B]
+    const float4* gx = reinterpret_cast<const float4*>(a.x);
+    const uint4* gw = reinterpret_cast<const uint4*>(a.wsh) + 1;      // header {2^shift_w, 2^-shift_w, 0, 0} then 25 tap-row sets
+    float sa = 1.f, out_scale = 1.f;
+    constexpr int WV = WBUF / 16;                     // 1280 uint4 per tap-row set
+    static_assert((WV + 767) / 768 == 2, "two 16-byte pieces per thread and weight set");
+
+    // unconditional loads (clamped index, zeroed when written to LDS): see conv5x5_sb.hip
+    auto row_ok = [&](int gr, int e) {
+        const int xx = (e >> 3) - 2;
+        return e < HWP * 8 && gr >= 0 && gr < nrows && xx >= 0 && xx < W;
+    };
+    auto load_row = [&](int gr, int e) {
+        const int xx = (e >> 3) - 2;
+        return gx[row_ok(gr, e) ? ((size_t)gr * W + xx) * 8 + (e & 7) : (size_t)0];
+    };
+    auto store_row = [&](int slot, int gr, float4 v, int e) {
+        if (!row_ok(gr, e)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < HWP * 8) {
+            const int hc = e >> 3, c4 = e & 7;
+            unsigned p0[2], p1[2];
+            split2h(v.x, v.y, sa, p0[0], p1[0]);
+            split2h(v.z, v.w, sa, p0[1], p1[1]);
+            unsigned char* q = ring + slot * SLOT + hc * 64 + ((((c4 >> 1) ^ swzb(hc)) << 4) | ((c4 & 1) << 3));
+            *reinterpret_cast<uint2*>(q) = make_uint2(p0[0], p0[1]);
+            *reinterpret_cast<uint2*>(q + PLANE) = make_uint2(p1[0], p1[1]);
+        }
+    };
+    auto load_w = [&](int set, uint4& p0, uint4& p1) {
+        p0 = gw[(size_t)set * WV + tid];
+        p1 = gw[(size_t)set * WV + (tid + 768 < WV ? tid + 768 : WV - 1)];
+    };
+    auto store_w = [&](int buf, const uint4& p0, const uint4& p1) {
+        uint4* dst = reinterpret_cast<uint4*>(Wt + buf * WBUF);
+        dst[tid] = p0;
+        if (tid + 768 < WV) dst[tid + 768] = p1;
+    };
+
+    float biasv[NT];
+    float4 hvA = make_float4(0.f, 0.f, 0.f, 0.f), hvB = hvA;      // the two register sets of the tap-row pipeline
+    float4 hvP0 = hvA, hvP1 = hvA, hvP2 = hvA;                     // first three rows of the NEXT depth slice
+    uint4 wA0, wA1, wB0, wB1, wP0, wP1;
+    wA0 = wA1 = wB0 = wB1 = wP0 = wP1 = make_uint4(0u, 0u, 0u, 0u);
+    {   // prologue of slice kd = 0: rows G0-2 .. G0 of plane d - 2 (one per tile group) and tap-row weight set 0
+        const int sh = -2 * H;
+        uint4 am = amax_load(a.xmax);
+        const float winv = reinterpret_cast<const float*>(a.wsh)[1];
+        {
+            const float* bp = a.bias ? a.bias : a.x;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) biasv[n] = bp[a.bias ? n * 16 + li : 0];
+        }
+        hvP0 = load_row(G0 - 2 + grp + sh, t);
+        hvP1 = load_row(G0 - 2 + grp + sh, t + 256);
+        hvP2 = load_row(G0 - 2 + grp + sh, t + 512);
+        load_w(0, wP0, wP1);
+        hvA = load_row(G0 + 1 + sh, tid);
+        load_w(1, wA0, wA1);
+        __builtin_amdgcn_sched_barrier(0);
+        float sai;
+        amax_scale_of(am, sa, sai);
+        out_scale = sai * winv;
+        store_row(grp, G0 - 2 + grp + sh, hvP0, t);
+        store_row(grp, G0 - 2 + grp + sh, hvP1, t + 256);
+        store_row(grp, G0 - 2 + grp + sh, hvP2, t + 512);
+        store_w(0, wP0, wP1);
+    }
+    C3_BARRIER();
+
+    f32x4 acc[NT], acl[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; acl[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const int pcc = wave * 16 + li;
+
+    // residual of the epilogue: fetched by LDS-DMA during the last tap rows (conv5x5_sb.hip explains the form)
+    constexpr int EF4 = 16 * OP / 4 / 64;             // 2 float4 per lane of the wave's [16 px][32] tile
+    __shared__ __align__(16) unsigned char pf_lds[12 * EF4 * 1024];
+    unsigned char* pf = pf_lds + wid * (EF4 * 1024);
+    auto lds_dma16 = [&](const void* src, unsigned char* dst_wave_uniform) __attribute__((always_inline)) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst_wave_uniform);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(lo));
+    };
+
+    // one tap row of depth slice kd.  MODE 0: request row / weights of tap row dy + 2 of this slice into (hin, wi);
+    // MODE 1 (dy == 3): request the next slice's first three rows + weight set 0 into (hvP, wP);
+    // MODE 2 (dy == 4): request the next slice's row G0+1 + weight set 1 into (hin, wi).  last: no next slice.
+    // Between the taps: (hout, wo) = row G0+dy+1 / weight set dy+1 of this slice go to LDS (dy < 4).
+    auto tap_row = [&](const int kd, const int dy, const int mode, const bool last, float4& hin, uint4& wi0, uint4& wi1,
+                       const float4& hout, const uint4& wo0, const uint4& wo1) __attribute__((always_inline)) {
+        const int sh = (kd - 2) * H, shn = (kd - 1) * H;
+        if (mode == 0) {
+            hin = load_row(G0 + dy + 2 + sh, tid);
+            load_w(kd * 5 + dy + 2, wi0, wi1);
+        } else if (!last) {
+            if (mode == 1) {
+                hvP0 = load_row(G0 - 2 + grp + shn, t);
+                hvP1 = load_row(G0 - 2 + grp + shn, t + 256);
+                hvP2 = load_row(G0 - 2 + grp + shn, t + 512);
+                load_w((kd + 1) * 5, wP0, wP1);
+            } else {
+                hin = load_row(G0 + 1 + shn, tid);
+                load_w((kd + 1) * 5 + 1, wi0, wi1);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int src = gy + sh + dy - 2;             // input row of this tile for this tap row
+        const bool plane_ok = dpl + kd - 2 >= 0 && dpl + kd - 2 < D;
+        const bool has_taps = tvalid && plane_ok && src >= row_lo + sh && src < row_hi + sh;      // wave uniform
+        const unsigned char* hrow = ring + ((grp + dy) & 3) * SLOT;
+        const unsigned char* wbuf = Wt + (dy & 1) * WBUF;
+        uint4 ao[2][2], bo[2][NT][2];
+        auto load_ops = [&](int dx, uint4 (&ar)[2], uint4 (&br)[NT][2]) {
+            const int hc = pcc + dx;
+            const unsigned char* ap = hrow + hc * 64 + ((g ^ swzb(hc)) << 4);
+            ar[0] = *reinterpret_cast<const uint4*>(ap);
+            ar[1] = *reinterpret_cast<const uint4*>(ap + PLANE);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int co = n * 16 + li;
+                const unsigned char* bp = wbuf + dx * 2 * WPL + co * 64 + ((g ^ swzb(co)) << 4);
+                br[n][0] = *reinterpret_cast<const uint4*>(bp);
+                br[n][1] = *reinterpret_cast<const uint4*>(bp + WPL);
+            }
+        };
+        auto taps = [&](const int dx0, const int dx1) __attribute__((always_inline)) {
+            if (dx0 == 0) load_ops(0, ao[0], bo[0]);
+#pragma unroll
+            for (int dx = dx0; dx < dx1; ++dx) {
+                if (dx < 4) load_ops(dx + 1, ao[(dx + 1) & 1], bo[(dx + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const f16x8 a1 = __builtin_bit_cast(f16x8, ao[dx & 1][0]), a2 = __builtin_bit_cast(f16x8, ao[dx & 1][1]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const f16x8 b1 = __builtin_bit_cast(f16x8, bo[dx & 1][n][0]), b2 = __builtin_bit_cast(f16x8, bo[dx & 1][n][1]);
+                    acl[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, acl[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, acc[n], 0, 0, 0);
+                    acl[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, acl[n], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (has_taps) taps(0, 2);
+        if (dy < 4) { store_row((dy + 3) & 3, G0 + dy + 1 + sh, hout, tid); __builtin_amdgcn_sched_barrier(0); }
+        if (has_taps) taps(2, 4);
+        if (dy < 4) { store_w((dy + 1) & 1, wo0, wo1); __builtin_amdgcn_sched_barrier(0); }
+        if (dy == 3 && last && tvalid && a.res) {     // residual prefetch, after the last staging store of the launch
+#pragma unroll
+            for (int n = 0; n < EF4; ++n) {
+                const int e = lane + n * 64, px = e / (OP / 4), c4 = e % (OP / 4);
+                const size_t o4 = ((size_t)gy * W + wave * 16 + px) * (OP / 4) + c4;
+                lds_dma16(reinterpret_cast<const float4*>(a.res) + o4, pf + n * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (has_taps) taps(4, 5);
+        C3_BARRIER();
+    };
+
+    for (int kd = 0; kd < 5; ++kd) {
+        const bool last = kd == 4;
+        tap_row(kd, 0, 0, last, hvB, wB0, wB1, hvA, wA0, wA1);
+        tap_row(kd, 1, 0, last, hvA, wA0, wA1, hvB, wB0, wB1);
+        tap_row(kd, 2, 0, last, hvB, wB0, wB1, hvA, wA0, wA1);
+        tap_row(kd, 3, 1, last, hvA, wA0, wA1, hvB, wB0, wB1);
+        tap_row(kd, 4, 2, last, hvA, wA0, wA1, hvB, wB0, wB1);
+        if (!last) {
+            // slice boundary: every wave is past the barrier of tap row 4, so the ring slots 0..2 and weight buffer 0 are free;
+            // the rows / weights were requested two tap rows ago
+            const int shn = (kd - 1) * H;
+            store_row(grp, G0 - 2 + grp + shn, hvP0, t);
+            store_row(grp, G0 - 2 + grp + shn, hvP1, t + 256);
+            store_row(grp, G0 - 2 + grp + shn, hvP2, t + 512);
+            store_w(0, wP0, wP1);
+            C3_BARRIER();
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[n][r] = (acc[n][r] + acl[n][r] * (1.f / 2048.f)) * out_scale;
+
+    // ---- epilogue: transpose the wave's [16 px][32] tile through LDS (the ring is free after the last barrier) ----
+    unsigned char* halo = ring + (size_t)grp * 4 * 16 * OP * sizeof(float);
+    float vmax = 0.f;
+    float* tb = reinterpret_cast<float*>(halo) + wave * (16 * OP);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const float bias = a.bias ? biasv[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tb[(4 * g + r) * OP + n * 16 + li] = acc[n][r] + bias;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's LDS-DMA of the residual has landed
+    if (tvalid) {
+#pragma unroll
+        for (int n = 0; n < EF4; ++n) {
+            const int e = lane + n * 64;
+            const int px = e / (OP / 4), c4 = e % (OP / 4);
+            float4 v = *reinterpret_cast<const float4*>(&tb[px * OP + c4 * 4]);
+            const size_t o4 = ((size_t)gy * W + wave * 16 + px) * (OP / 4) + c4;
+            if (a.res) { const float4 q = *reinterpret_cast<const float4*>(pf + n * 1024 + lane * 16); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+            if (a.epi == SOL_EPI_LRELU) {
+                v.x = v.x > 0.f ? v.x : a.slope * v.x; v.y = v.y > 0.f ? v.y : a.slope * v.y;
+                v.z = v.z > 0.f ? v.z : a.slope * v.z; v.w = v.w > 0.f ? v.w : a.slope * v.w;
+            }
+            vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            reinterpret_cast<float4*>(a.y)[o4] = v;
+        }
+    }
+    if (a.ymax) amax_publish_last(vmax, a.ymax, reinterpret_cast<unsigned*>(smem_c3 + AMAX_LDS));
+}
+
+// fp16 weight planes of all 125 taps with ONE power-of-two scale: header {2^shift_w, 2^-shift_w, 0, 0}, then
+// out[tap = (kd*5 + dy)*5 + dx][plane 2][o 32][chunk s][j] in the LDS image order of the 2-D kernels (k_pack_sh).
+// mode SOL_CONV_BWD_DATA: the flipped kernel with swapped channel axes (w is the FORWARD kernel [125][cout_run][cin_run]).
+__global__ void __launch_bounds__(256) k_pack3_sh(const float* __restrict__ w, float* __restrict__ hdr, unsigned short* __restrict__ out, int mode) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int e = threadIdx.x; e < 125 * 32 * 32; e += 256) m = fmaxf(m, fabsf(w[e]));       // every workgroup finds the same maximum
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const unsigned mb = __float_as_uint(m);
+    int ex = (int)(mb >> 23) - 127;
+    ex = mb == 0u ? 0 : min(max(ex, -100), 100);
+    const float sc = __uint_as_float((unsigned)(14 - ex + 127) << 23), inv = __uint_as_float((unsigned)(ex - 14 + 127) << 23);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[0] = sc; hdr[1] = inv; hdr[2] = 0.f; hdr[3] = 0.f; }
+    const int total = 125 * 32 * 16;                 // pairs of input channels
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int jp = e & 3, s = (e >> 2) & 3, o = (e >> 4) & 31, tap = e >> 9;
+        const int i0 = 8 * (s ^ swzb(o)) + 2 * jp;
+        float v[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = i0 + q;
+            v[q] = mode == SOL_CONV_FWD ? w[((size_t)tap * 32 + i) * 32 + o] : w[((size_t)(124 - tap) * 32 + o) * 32 + i];
+        }
+        unsigned p[2];
+        split2h(v[0], v[1], sc, p[0], p[1]);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+            *reinterpret_cast<unsigned*>(out + ((((size_t)tap * 2 + pl) * 32 + o) * 4 + s) * 8 + 2 * jp) = p[pl];
+    }
+}
+
+constexpr size_t c3_lds() { return (size_t)4 * 2 * 68 * 64 + 2 * (size_t)5 * 2 * 32 * 64 + 16; }
+
+}  // namespace
+
+// floats of the fused kernel's weight section: header (4) + 125 taps x 2 planes x 32 x 32 fp16
+size_t sol_conv3d_sh_packed_floats() { return 4 + (size_t)125 * 2 * 32 * 16; }
+
+int sol_conv3d_sh_pack(hipStream_t s, const float* w_dhwio, int mode, float* out) {
+    SOL_LAUNCH(k_pack3_sh, dim3(64), dim3(256), 0, s, w_dhwio, out, reinterpret_cast<unsigned short*>(out + 4), mode);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
+// y = epi(conv3d(x, w) + bias (+ residual)), x / y [nplanes = B*D][H][64][32]; wsh from sol_conv3d_sh_pack; x_absmax required
+int sol_conv3d_sb_launch(hipStream_t s, const float* x, const float* wsh, const float* bias, const float* residual, float* y,
+                         int B, int D, int H, int epilogue, float slope, const unsigned* x_absmax, unsigned* y_absmax) {
+    static int rc = [] {
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_conv3d_sb)) != hipSuccess) return -1;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024 - (int)fa.sharedSizeBytes) == hipSuccess ? 0 : -1;
+    }();
+    SOL_REQUIRE(rc == 0, "hipFuncSetAttribute(k_conv3d_sb) failed");
+    ConvArgs a{};
+    a.x = x; a.bias = bias; a.res = residual; a.y = y; a.B = B * D; a.H = H; a.W = 64; a.CO = 32; a.epi = epilogue; a.slope = slope;
+    a.wsh = wsh; a.xmax = x_absmax; a.ymax = y_absmax; a.tiles_x = 1;
+    const int nrows = B * D * H;
+    SOL_LAUNCH(k_conv3d_sb, dim3((nrows + 2) / 3), dim3(768), c3_lds(), s, a, nrows, D);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}

@@ -257,6 +257,11 @@ def _pack3d(w, cin_run, cout_run, mode):
     return buf
 
 
+def _absmax(x):
+    from . import ops
+    return ops.absmax_slots(x)
+
+
 def _pad_ch(x, c):
     return x.contiguous() if x.shape[-1] == c else torch.nn.functional.pad(x, (0, c - x.shape[-1])).contiguous()
 
@@ -304,7 +309,8 @@ class _Conv3DFn(torch.autograd.Function):
         wk = _pad_ch(_lib.f32(w).permute(0, 1, 2, 4, 3), cin_k).permute(0, 1, 2, 4, 3).contiguous() if cin_k != cin else _lib.f32(w)
         packed = _pack3d(wk, cin_k, cout, 0)
         res = None if residual is None else _lib.f32(residual)
-        y = conv3d(xk, packed, _lib.f32(b), res, cout, lrelu, slope)
+        # the operand's absmax selects the fp16 three-product kernels (and, for 32 -> 32 layers, the one-launch 5x5x5 kernel)
+        y = conv3d(xk, packed, _lib.f32(b), res, cout, lrelu, slope, _absmax(xk) if cin_k == 32 else None)
         ctx.save_for_backward(xk, w, y)
         ctx.meta = (cin, cout, cin_k, lrelu, slope, residual is not None)
         return y
@@ -320,7 +326,8 @@ class _Conv3DFn(torch.autograd.Function):
         # data gradient: the flipped kernel, run channels (cout -> cin)
         co_k = 4 if cout <= 4 else 32
         packed = _pack3d(_lib.f32(w), cout, cin, 1)
-        dx = conv3d(_pad_ch(dz, co_k), packed, None, None, cin, False, slope)
+        dzk = _pad_ch(dz, co_k)
+        dx = conv3d(dzk, packed, None, None, cin, False, slope, _absmax(dzk) if co_k == 32 else None)
         return dx, dW, db, (dz if has_res else None), None, None
 
 

@@ -115,7 +115,8 @@ def _oracle_conv(x, w, b, res, lrelu, slope=0.3):
     ((1, 6, 16, 16), 4, 32, False, True),          # first layer (fp32 MFMA thin kernel), W | 64
     ((2, 5, 16, 16), 32, 32, True, True),          # residual block tail, two simulations
     ((1, 4, 16, 16), 32, 3, False, False),         # output layer
-    ((1, 4, 64, 64), 32, 32, True, True),          # W = 64: the split fp16 / bf16 MFMA kernels
+    ((1, 4, 64, 64), 32, 32, True, True),          # W = 64: the split fp16 / bf16 MFMA kernels (with absmax: the one-launch kernel)
+    ((2, 6, 64, 64), 32, 32, False, True),         # two simulations, six planes: slice validity at both ends and across samples
     ((1, 3, 64, 64), 4, 32, False, True),
     ((1, 3, 64, 64), 32, 3, False, False),
 ])
@@ -140,6 +141,14 @@ def test_conv3d_against_oracle(shape, cin, cout, res, lrelu):
         assert rel(y, ref) < 2e-6, (use_amax, rel(y, ref))
         pub = float(ymax.max().view(torch.float32))
         assert abs(pub - float(y.abs().max())) <= 1e-6 * pub            # the centre pass publishes max|y| of the finished tensor
+        if use_amax and cin == 32 and cout == 32 and W == 64:
+            # this call ran the one-launch 5x5x5 kernel (conv3d_sb.hip); the five-pass composition must agree with it
+            sol_amd._lib.set_option("k3d_conv_fused", 0)
+            try:
+                y5 = k3.conv3d(xd, packed, f32(b), f32(r) if res else None, cout, lrelu, 0.3, amax, None)
+            finally:
+                sol_amd._lib.set_option("k3d_conv_fused", 1)
+            assert not torch.equal(y, y5) and rel(y, y5) < 1e-6
 
 
 def test_network_and_rollout_against_golden(fixture3d, scene_small):

@@ -776,14 +776,14 @@ def test_split_conv_error_not_worse_than_fp32_mfma():
     from sol_amd import _lib
     gen = torch.Generator().manual_seed(5)
     B, Y, X = 2, 64, 64
-    cases = {"normal": torch.randn(B, Y, X, 32, generator=gen),
-             "heavy": torch.randn(B, Y, X, 32, generator=gen) * torch.exp(2.0 * torch.randn(B, Y, X, 32, generator=gen))}
+    cases = {"normal": torch.randn(B, Y, X, 32, generator=gen, dtype=torch.float32),
+             "heavy": torch.randn(B, Y, X, 32, generator=gen, dtype=torch.float32) * torch.exp(2.0 * torch.randn(B, Y, X, 32, generator=gen, dtype=torch.float32))}
     for name, ratio in (("mixed_1e-3", 1e-3), ("mixed_1e-5", 1e-5), ("mixed_2^-18", 2.0 ** -18), ("mixed_2^-19", 2.0 ** -19),
                         ("mixed_2^-20", 2.0 ** -20), ("mixed_2^-22", 2.0 ** -22)):
-        m = torch.randn(B, Y, X, 32, generator=gen)
+        m = torch.randn(B, Y, X, 32, generator=gen, dtype=torch.float32)
         m[:, :, :32] *= ratio
         cases[name] = m
-    w = (torch.randn(5, 5, 32, 32, generator=gen) * 0.05).float().to(DEV)
+    w = (torch.randn(5, 5, 32, 32, generator=gen, dtype=torch.float32) * 0.05).to(DEV)
     bias = torch.zeros(32, dtype=torch.float32, device=DEV)
     packed = ops._pack(w, 32, 32, ops.CONV_FWD)
     saved = _lib.get_option("conv_precision")
