@@ -86,7 +86,10 @@ __device__ __forceinline__ float face_mask(const float* act, int Y, int X, int Z
 // ---- readers of the diffused components: straight from global memory, or from the workgroup's LDS tile ----------------
 struct GlobalReader {
     const float *sy, *sx, *sz;
+    const float* act;                 // the scene's `active` cell mask [Y][X][Z]
     int Y, X, Z;
+    // accessible mask at a cell index that may lie one cell outside the domain ('boundary' extrapolation: edge value)
+    __device__ __forceinline__ float acc(int j, int i, int k) const { return acc_at(act, Y, X, Z, j, i, k); }
     __device__ __forceinline__ float y(int j, int i, int k) const { return sy[((size_t)j * X + i) * Z + k]; }
     __device__ __forceinline__ float x(int j, int i, int k) const { return sx[((size_t)j * (X + 1) + i) * Z + k]; }
     __device__ __forceinline__ float z(int j, int i, int k) const { return sz[((size_t)j * X + i) * (Z + 1) + k]; }
@@ -97,7 +100,12 @@ constexpr int TR = T3 + 2 * HL3;      // cell rows / columns of the tile region 
 struct TileReader {
     GlobalReader g;
     const float *ly, *lx, *lz;        // LDS: [TR+1][TR][Z], [TR][TR+1][Z], [TR][TR][Z+1]
+    const unsigned char* la;          // LDS: accessible mask of the region's cells [TR][TR][Z] (bytes; rows / columns beyond the domain hold the edge value)
     int j0, i0;                       // first cell row / column of the region (may be negative: clipped rows are never read)
+    __device__ __forceinline__ float acc(int j, int i, int k) const {
+        const int rj = j - j0, ri = i - i0, kk = clampi(k, 0, g.Z - 1);
+        return ((unsigned)rj < (unsigned)TR && (unsigned)ri < (unsigned)TR) ? (float)la[(rj * TR + ri) * g.Z + kk] : g.acc(j, i, k);
+    }
     __device__ __forceinline__ float y(int j, int i, int k) const {
         const int rj = j - j0, ri = i - i0;
         return ((unsigned)rj <= (unsigned)TR && (unsigned)ri < (unsigned)TR) ? ly[(rj * TR + ri) * g.Z + k] : g.y(j, i, k);
@@ -154,21 +162,21 @@ __device__ __forceinline__ void advect_point(const K3Args& a, const R& r, int b,
         const float ux = 0.25f * (r.x(ja, i, k) + r.x(ja, i + 1, k) + r.x(jb, i, k) + r.x(jb, i + 1, k));
         const float uz = 0.25f * (r.z(ja, i, k) + r.z(ja, i, k + 1) + r.z(jb, i, k) + r.z(jb, i, k + 1));
         const float v = tri_clamp<0>(r, j, -uy * a.dtdx, i, -ux * a.dtdx, k, -uz * a.dtdx);
-        a.vy_out[(size_t)b * (Y + 1) * X * Z + ((size_t)j * X + i) * Z + k] = v * face_mask<0>(a.active, Y, X, Z, j, i, k);
+        a.vy_out[(size_t)b * (Y + 1) * X * Z + ((size_t)j * X + i) * Z + k] = v * (r.acc(j - 1, i, k) * r.acc(j, i, k));
     } else if (kind == 1) {
         const float ux = r.x(j, i, k);
         const int ia = max(i - 1, 0), ib = min(i, X - 1);
         const float uy = 0.25f * (r.y(j, ia, k) + r.y(j, ib, k) + r.y(j + 1, ia, k) + r.y(j + 1, ib, k));
         const float uz = 0.25f * (r.z(j, ia, k) + r.z(j, ia, k + 1) + r.z(j, ib, k) + r.z(j, ib, k + 1));
         const float v = tri_clamp<1>(r, j, -uy * a.dtdx, i, -ux * a.dtdx, k, -uz * a.dtdx);
-        a.vx_out[(size_t)b * Y * (X + 1) * Z + ((size_t)j * (X + 1) + i) * Z + k] = v * face_mask<1>(a.active, Y, X, Z, j, i, k);
+        a.vx_out[(size_t)b * Y * (X + 1) * Z + ((size_t)j * (X + 1) + i) * Z + k] = v * (r.acc(j, i - 1, k) * r.acc(j, i, k));
     } else if (kind == 2) {
         const float uz = r.z(j, i, k);
         const int ka = max(k - 1, 0), kb = min(k, Z - 1);
         const float uy = 0.25f * (r.y(j, i, ka) + r.y(j, i, kb) + r.y(j + 1, i, ka) + r.y(j + 1, i, kb));
         const float ux = 0.25f * (r.x(j, i, ka) + r.x(j, i, kb) + r.x(j, i + 1, ka) + r.x(j, i + 1, kb));
         const float v = tri_clamp<2>(r, j, -uy * a.dtdx, i, -ux * a.dtdx, k, -uz * a.dtdx);
-        a.vz_out[(size_t)b * Y * X * (Z + 1) + ((size_t)j * X + i) * (Z + 1) + k] = v * face_mask<2>(a.active, Y, X, Z, j, i, k);
+        a.vz_out[(size_t)b * Y * X * (Z + 1) + ((size_t)j * X + i) * (Z + 1) + k] = v * (r.acc(j, i, k - 1) * r.acc(j, i, k));
     } else {
         const size_t N = (size_t)Y * X * Z, c = ((size_t)j * X + i) * Z + k;
         const float uy = 0.5f * (r.y(j, i, k) + r.y(j + 1, i, k));
@@ -214,7 +222,7 @@ __global__ void __launch_bounds__(256) k3_advect(K3Args a) {
     const int nVy = (Y + 1) * X * Z, nVx = Y * (X + 1) * Z, nVz = Y * X * (Z + 1);
     const int b = blockIdx.y;
     GR r;
-    r.sy = a.svy + (size_t)b * nVy; r.sx = a.svx + (size_t)b * nVx; r.sz = a.svz + (size_t)b * nVz; r.Y = Y; r.X = X; r.Z = Z;
+    r.sy = a.svy + (size_t)b * nVy; r.sx = a.svx + (size_t)b * nVx; r.sz = a.svz + (size_t)b * nVz; r.act = a.active; r.Y = Y; r.X = X; r.Z = Z;
     const int cY = (Y + 1) * X, cX = Y * (X + 1), cC = Y * X;        // columns per kind: y faces, x faces, z faces (= cells), cells
     const int total = cY + cX + cC + (a.d_out ? cC : 0);
     const int lane = threadIdx.x & 63;
@@ -244,24 +252,39 @@ __global__ void __launch_bounds__(ADV_T) k3_advect_tile(K3Args a, int tiles_x) {
     float* ly = lds3;
     float* lx = ly + (TR + 1) * TR * Z;
     float* lz = lx + TR * (TR + 1) * Z;
-    r.ly = ly; r.lx = lx; r.lz = lz;
+    unsigned char* la = reinterpret_cast<unsigned char*>(lz + TR * TR * (Z + 1));
+    r.ly = ly; r.lx = lx; r.lz = lz; r.la = la; r.g.act = a.active;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     constexpr int NW = ADV_T / 64;
-    // stage the region column by column (rows / columns outside the arrays are skipped: clamped indices never address them)
-    for (int c = wave; c < (TR + 1) * TR; c += NW) {
-        const int rj = c / TR, ri = c % TR, j = r.j0 + rj, i = r.i0 + ri;
-        if ((unsigned)j <= (unsigned)Y && (unsigned)i < (unsigned)X)
-            for (int k = lane; k < Z; k += 64) ly[c * Z + k] = r.g.y(j, i, k);
-    }
-    for (int c = wave; c < TR * (TR + 1); c += NW) {
-        const int rj = c / (TR + 1), ri = c % (TR + 1), j = r.j0 + rj, i = r.i0 + ri;
-        if ((unsigned)j < (unsigned)Y && (unsigned)i <= (unsigned)X)
-            for (int k = lane; k < Z; k += 64) lx[c * Z + k] = r.g.x(j, i, k);
-    }
-    for (int c = wave; c < TR * TR; c += NW) {
-        const int rj = c / TR, ri = c % TR, j = r.j0 + rj, i = r.i0 + ri;
-        if ((unsigned)j < (unsigned)Y && (unsigned)i < (unsigned)X)
-            for (int k = lane; k <= Z; k += 64) lz[c * (Z + 1) + k] = r.g.z(j, i, k);
+    // stage the region column by column (lanes along z).  The loads are unconditional with clamped indices (a predicated load
+    // waits inside its own block: one exposed round trip per column, 28 columns per wave), four columns in flight per wave;
+    // positions outside the arrays then hold edge values that no clamped index ever addresses.
+    auto stage = [&](float* dst, int ncol_r, int ncol_i, int nj, int ni, int nz, auto&& rd) {
+        const int ncol = ncol_r * ncol_i;
+        for (int c0 = wave; c0 < ncol; c0 += 4 * NW) {
+            float v[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = min(c0 + u * NW, ncol - 1), j = clampi(r.j0 + c / ncol_i, 0, nj - 1), i = clampi(r.i0 + c % ncol_i, 0, ni - 1);
+                v[u][0] = rd(j, i, min(lane, nz - 1));
+                v[u][1] = rd(j, i, min(lane + 64, nz - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * NW;
+                if (c < ncol) {
+                    if (lane < nz) dst[c * nz + lane] = v[u][0];
+                    if (lane + 64 < nz) dst[c * nz + lane + 64] = v[u][1];
+                }
+            }
+        }
+    };
+    stage(ly, TR + 1, TR, Y + 1, X, Z, [&](int j, int i, int k) { return r.g.y(j, i, k); });
+    stage(lx, TR, TR + 1, Y, X + 1, Z, [&](int j, int i, int k) { return r.g.x(j, i, k); });
+    stage(lz, TR, TR, Y, X, Z + 1, [&](int j, int i, int k) { return r.g.z(j, i, k); });
+    for (int c = wave; c < TR * TR; c += NW) {            // accessible mask of the region's cells: clamped = 'boundary' extrapolation
+        const int j = r.j0 + c / TR, i = r.i0 + c % TR;
+        for (int k = lane; k < Z; k += 64) la[c * Z + k] = acc_at(a.active, Y, X, Z, j, i, k) != 0.f ? 1 : 0;
     }
     __syncthreads();
     const int ny = min(T3, Y - jt) + (jt + T3 >= Y ? 1 : 0);      // y-face rows owned
@@ -813,7 +836,7 @@ extern "C" int sol_karman3d_step_fwd(const sol_karman3d_cfg* c, void* stream,
     if (feat_scale) { a.fs0 = feat_scale[0]; a.fs1 = feat_scale[1]; a.fs2 = feat_scale[2]; a.fs3 = feat_scale[3]; }
     const size_t faces = nVy + nVx + nVz;
     SOL_LAUNCH(k3_diffuse, dim3(grid_for(faces), B), dim3(256), 0, s, a);
-    const size_t tile_lds = ((size_t)(TR + 1) * TR * Z + (size_t)TR * (TR + 1) * Z + (size_t)TR * TR * (Z + 1)) * sizeof(float);
+    const size_t tile_lds = ((size_t)(TR + 1) * TR * Z + (size_t)TR * (TR + 1) * Z + (size_t)TR * TR * (Z + 1)) * sizeof(float) + (size_t)TR * TR * Z;
     if (sol_opt().k3d_tile && tile_lds <= 160 * 1024) {
         static int rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k3_advect_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
         SOL_REQUIRE(rc == 0, "hipFuncSetAttribute(k3_advect_tile) failed");
