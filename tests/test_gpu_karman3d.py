@@ -54,7 +54,7 @@ def test_karman3d_step_against_golden(fixture3d, scene_small, tile, fused_tf):
         d, vy, vx, vz = sim.step(f32(z["d"]), f32(z["vy"]), f32(z["vx"]), f32(z["vz"]), f32(z["re"]), feat_out=feat, feat_scale=fs)
         torch.cuda.synchronize()
     finally:
-        sol_amd._lib.set_option("k3d_tile", 1)
+        sol_amd._lib.set_option("k3d_tile", 0)
         sol_amd._lib.set_option("k3d_fused_tf", 1)
     errs = [rel(a, z[k]) for a, k in ((d, "d_out"), (vy, "vy_out"), (vx, "vx_out"), (vz, "vz_out"))]
     assert max(errs) < TOL_FIELD, errs
@@ -81,7 +81,7 @@ def test_karman3d_tile_and_global_advection_agree(fixture3d, scene_small):
         sol_amd._lib.set_option("k3d_tile", tile)
         sim = k3.Karman3DFlow(scene_small, 2)
         outs.append(sim.step(f32(z["d"]), f32(z["vy"]), f32(z["vx"]), f32(z["vz"]), f32(z["re"])))
-    sol_amd._lib.set_option("k3d_tile", 1)
+    sol_amd._lib.set_option("k3d_tile", 0)
     for a, b in zip(*outs):
         assert rel(a, b) < 1e-6           # same arithmetic, LDS vs global operands (the compiler contracts the two kernels differently)
 

@@ -99,4 +99,4 @@ def test_cabi_exports_the_3d_entry_points():
     nb = lib.sol_karman3d_step_workspace_bytes(C.byref(cfg))
     assert 6 * 2 * 128 * 64 * 64 * 4 < nb < 6.3 * 2 * 128 * 64 * 64 * 4          # three components + three cell buffers
     assert lib.sol_conv3d_packed_floats(32, 32) >= 5 * lib.sol_conv5x5_packed_floats(32, 32, 0)
-    assert sol_amd._lib.get_option("k3d_tile") == 1
+    assert sol_amd._lib.get_option("k3d_tile") == 0

@@ -45,7 +45,7 @@ for tile, ftf in ((1, 1), (0, 1), (0, 0)):
     e1.record()
     torch.cuda.synchronize()
     out["solver_ms_tile%d_fusedtf%d" % (tile, ftf)] = e0.elapsed_time(e1) / steps
-sol_amd._lib.set_option("k3d_tile", 1)
+sol_amd._lib.set_option("k3d_tile", 0)
 sol_amd._lib.set_option("k3d_fused_tf", 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
