@@ -341,7 +341,11 @@ class Karman3DTrainer:
     components), reverse sweep through the HIP adjoints by torch autograd, TF-Adam on the flat parameter buffer
     (sol_adam_tf_step).  gts: [msteps] of (vy, vx, vz) ground-truth frames."""
 
-    def __init__(self, net, scene, B, msteps, std_v, std_re, dt=1.0, res=None, beta1=0.9, beta2=0.999, eps=1e-8, conv_precision="split", **solver):
+    def __init__(self, net, scene, B, msteps, std_v, std_re, dt=1.0, res=None, beta1=0.9, beta2=0.999, eps=1e-8, conv_precision="split",
+                 use_graph=False, **solver):
+        """use_graph: capture the whole forward unroll + reverse sweep ONCE into a hipGraph over static input buffers (the
+        TF1 "build the graph, sess.run many" shape, as trainer.GraphTrainer does for the 2-D mercury model): a step then
+        copies the batch in and replays ~3000 launches with one host call."""
         from .trainer import _conv_precision_code
         _lib.require_gpu()
         self.lib = _lib.load()
@@ -356,38 +360,77 @@ class Karman3DTrainer:
         self.v = torch.zeros_like(net.params.detach())
         self.t = 0
         self.beta1, self.beta2, self.eps = beta1, beta2, eps
-        self.loss_steps = None
+        Y, X, Z = scene.Y, scene.X, scene.Z
+        f = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        # static buffers: inputs, ground-truth frames, outputs (the graph bakes their addresses in)
+        self._in = [f(B, Y, X, Z), f(B, Y + 1, X, Z), f(B, Y, X + 1, Z), f(B, Y, X, Z + 1), f(B)]
+        self._gt = [f(msteps, B, Y + 1, X, Z), f(msteps, B, Y, X + 1, Z), f(msteps, B, Y, X, Z + 1)]
+        self.loss_steps = f(msteps)
+        self._loss = f(())
+        self._grads = f(net.n_params)
+        self._fin = [f(B, Y, X, Z), f(B, Y + 1, X, Z), f(B, Y, X + 1, Z), f(B, Y, X, Z + 1)]
         self.final = None
+        self.use_graph, self._graph = bool(use_graph), None
+
+    def _unrolled(self):
+        d, vy, vx, vz, re = self._in
+        self.net.params.grad = None
+        v = (vy.detach().clone().requires_grad_(True), vx, vz)     # the state enters the graph (the step's autograd Function needs a grad-requiring input)
+        losses = []
+        for i in range(self.ms):
+            d, *v = self.sim.step(d, v[0], v[1], v[2], re)
+            out = self.net(to_feature3d(v[0], v[1], v[2], re) / self.std_in) * self.std_v
+            v = tuple(a + c for a, c in zip(v, to_staggered3d(out)))
+            losses.append(sum(0.5 * (((g[i] - a) / s) ** 2).sum() for g, a, s in zip(self._gt, v, self.std_v)))
+        losses = torch.stack(losses)
+        loss = losses.sum() / self.ms
+        loss.backward()
+        self.loss_steps.copy_(losses.detach())
+        self._loss.copy_(loss.detach())
+        self._grads.copy_(self.net.params.grad)
+        for dst, src in zip(self._fin, (d,) + tuple(v)):
+            dst.copy_(src.detach())
 
     def fwd_bwd(self, d, vy, vx, vz, re, gts):
+        """gts: [msteps] of (vy, vx, vz) frames, or the three stacked tensors [msteps, B, ...]."""
         from .trainer import _conv_precision_scope
-        f = _lib.f32
-        d, vy, vx, vz, re = f(d), f(vy), f(vx), f(vz), f(re)
-        self.net.params.grad = None
-        self.net._packed = None
+        for dst, src in zip(self._in, (d, vy, vx, vz, re)):
+            dst.copy_(_lib.f32(src), non_blocking=True)
+        if isinstance(gts, (list, tuple)) and len(gts) == self.ms and isinstance(gts[0], (list, tuple)):
+            for i, fr in enumerate(gts):
+                for c in range(3):
+                    self._gt[c][i].copy_(_lib.f32(fr[c]), non_blocking=True)
+        else:
+            for c in range(3):
+                self._gt[c].copy_(_lib.f32(gts[c]), non_blocking=True)
         with _conv_precision_scope(self.conv_precision):
-            v = (vy.requires_grad_(True), vx, vz)             # the state enters the graph (the step's autograd Function needs a grad-requiring input)
-            losses = []
-            for i in range(self.ms):
-                d, *v = self.sim.step(d, v[0], v[1], v[2], re)
-                out = self.net(to_feature3d(v[0], v[1], v[2], re) / self.std_in) * self.std_v
-                v = tuple(a + c for a, c in zip(v, to_staggered3d(out)))
-                losses.append(sum(0.5 * (((f(g) - a) / s) ** 2).sum() for g, a, s in zip(gts[i], v, self.std_v)))
-            losses = torch.stack(losses)
-            loss = losses.sum() / self.ms
-            loss.backward()
-        self.loss_steps = losses.detach()
-        self.final = (d.detach(),) + tuple(a.detach() for a in v)
-        return loss.detach()
+            if not self.use_graph:
+                self._unrolled()
+            else:
+                if self._graph is None:
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):          # warm-up off the capture: library initialisation, allocator pools
+                        self._unrolled()
+                    torch.cuda.current_stream().wait_stream(side)
+                    torch.cuda.synchronize()
+                    self.net.params.grad = None
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._unrolled()
+                    self._graph = g
+                self._graph.replay()
+        self.final = tuple(self._fin)
+        return self._loss
 
     @property
     def grads(self):
-        return self.net.params.grad
+        return self._grads
 
     def apply_gradients(self, lr):
         self.t += 1
         p = self.net.params.detach()
-        check(self.lib.sol_adam_tf_step(stream(), ptr(p), ptr(self.net.params.grad.contiguous()), ptr(self.m), ptr(self.v),
+        check(self.lib.sol_adam_tf_step(stream(), ptr(p), ptr(self._grads), ptr(self.m), ptr(self.v),
                                         self.net.n_params, self.t, float(lr), self.beta1, self.beta2, self.eps, 0.0, None, 0, None))
         self.net._packed = None
 

@@ -254,9 +254,10 @@ def test_conv3d_gradients_against_oracle(shape, cin, cout, res, lrelu):
         assert rel(hr.grad, r.grad) < 5e-6
 
 
-def test_karman3d_trainer_sol2_against_oracle():
-    """SOL-2 at 32 x 16 x 16, B = 2: loss, per-step losses, the full 1.3 M-element gradient, the final state and one TF-Adam
-    update against the float64 oracle (autograd through the unrolled 3-D graph)."""
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_karman3d_trainer_sol2_against_oracle(use_graph):
+    """SOL-2 at 32 x 16 x 16, B = 2: loss, the full 1.3 M-element gradient and one TF-Adam update against the float64 oracle
+    (autograd through the unrolled 3-D graph); eager composition and the replayed hipGraph (second replay checked)."""
     import make_golden as mg
     import sol_oracle as o2
     B, Y, X, Z, ms = 2, 32, 16, 16, 2
@@ -276,8 +277,12 @@ def test_karman3d_trainer_sol2_against_oracle():
     sc = k3.Scene3D(Y, X, Z, device=DEV)
     net = k3.MarsMoon3D(device=DEV)
     net.set_weights([p.detach().numpy() for p in params])
-    tr = k3.Karman3DTrainer(net, sc, B, ms, std_v, o.STD_RE)
+    tr = k3.Karman3DTrainer(net, sc, B, ms, std_v, o.STD_RE, use_graph=use_graph)
     hl = tr.fwd_bwd(d, v[0], v[1], v[2], re, gts)
+    if use_graph:
+        assert tr._graph is not None
+        tr._grads.zero_()
+        hl = tr.fwd_bwd(d, v[0], v[1], v[2], re, gts)          # a pure replay
     assert abs(float(hl) - float(loss)) < 1e-5 * abs(float(loss)), (float(hl), float(loss))
     assert rel(tr.grads, gref) < TOL_GRAD, rel(tr.grads, gref)
     off = net.offsets
