@@ -969,3 +969,39 @@ extern "C" int sol_conv3d(void* stream, const float* x, const float* packed, con
     // kd = 2 (centre): every plane of the batch, with bias / activation / absmax publish
     return sol_conv5x5_scaled(stream, x, packed + 2 * per, bias, y, nullptr, y, B * D, H, W, cin, cout, epilogue, slope, x_absmax, y_absmax);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Conv3D weight gradient: dW[kd][dy][dx][ci][co] = sum over planes d of the 2-D weight gradient of (x[d + kd - 2], dz[d]) --
+// five passes of the batched 2-D weight-gradient kernels (conv5x5_sb.hip: one workgroup per CU owning many rows, fp16
+// three-product operands when the absmax of both tensors is given) over the shifted plane ranges, each into `partial` and
+// reduced into its depth slice of dw; db from the centre pass (all planes).
+// ------------------------------------------------------------------------------------------------------------------------
+extern "C" size_t sol_conv3d_bwd_weight_ws_floats(int32_t B, int32_t D, int32_t H, int32_t /*W*/, int32_t cin, int32_t cout) {
+    return sol_bww_batched_ws_floats(1, B * D, H, cin, cout);
+}
+
+extern "C" int sol_conv3d_bwd_weight(void* stream, const float* x, const float* dz, const uint32_t* x_absmax, const uint32_t* dz_absmax,
+                                     float* partial, float* dw_dhwio, float* db, float* db_scratch,
+                                     int32_t B, int32_t D, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t cin_real, int32_t cout_real) {
+    SOL_REQUIRE(x && dz && partial && dw_dhwio && db && db_scratch, "sol_conv3d_bwd_weight: NULL pointer");
+    SOL_REQUIRE(B >= 1 && D >= 3 && (cin == 4 || cin == 32) && (cout == 2 || cout == 32) && cin_real >= 1 && cin_real <= cin && cout_real >= 1 && cout_real <= cout,
+                "sol_conv3d_bwd_weight: bad shape (B %d, D %d, channels %d -> %d)", B, D, cin, cout);
+    SOL_REQUIRE(cout_real == cout, "sol_conv3d_bwd_weight: the reduce writes dw with the kernel's output-channel count (pad dz and slice the result)");
+    const size_t pin = (size_t)H * W * cin, pout = (size_t)H * W * cout;
+    const size_t slice = (size_t)25 * cin_real * cout_real;
+    for (int kd = 0; kd < 5; ++kd) {
+        const int lo = kd < 2 ? 2 - kd : 0, hi = kd > 2 ? D + 2 - kd : D;       // output planes that see input plane d + kd - 2
+        if (kd == 2) {
+            if (int e = sol_bww_batched(stream, x, dz, partial, 1, 1, 1, 0, 0, B * D, H, W, cin, cout, x_absmax, dz_absmax, 0, 0)) return e;
+            if (int e = sol_bww_batched_reduce(stream, partial, dw_dhwio + kd * slice, db, 1, B * D, H, cin_real, cout_real, 0)) return e;
+            continue;
+        }
+        for (int b = 0; b < B; ++b) {
+            const float* xb = x + ((size_t)b * D + lo + kd - 2) * pin;
+            const float* zb = dz + ((size_t)b * D + lo) * pout;
+            if (int e = sol_bww_batched(stream, xb, zb, partial, 1, 1, 1, 0, 0, hi - lo, H, W, cin, cout, x_absmax, dz_absmax, 0, 0)) return e;
+            if (int e = sol_bww_batched_reduce(stream, partial, dw_dhwio + kd * slice, db_scratch, 1, hi - lo, H, cin_real, cout_real, b ? 1 : 0)) return e;
+        }
+    }
+    return SOL_OK;
+}

@@ -268,32 +268,21 @@ def _pad_ch(x, c):
 
 def conv3d_bwd_weight(xk, dz, cin, cout):
     """dW [5,5,5,cin,cout], db [cout] of y = conv3d(x, W) + b from xk [B,D,H,W,cin_k] (channels padded to 4 / 32) and dz
-    [B,D,H,W,cout]:  dW[kd] = sum over planes d of the 2-D weight gradient of (x[d + kd - 2], dz[d]) -- five passes of
-    sol_conv5x5_bwd_weight over the shifted plane ranges, each accumulated in its own partial buffer and reduced once."""
+    [B,D,H,W,cout]: sol_conv3d_bwd_weight (five passes of the batched 2-D weight-gradient kernels over the shifted plane
+    ranges; fp16 three-product operands for the 32 -> 32 case, scaled by the absmax of x and dz)."""
     lib = _lib.load()
     B, D, H, W, cin_k = xk.shape
     co_k = cout if cout in (2, 32) else 32                 # the 2-D weight-gradient kernels take 2 or 32 output channels
     dzk = _pad_ch(dz, co_k)
-    dW = torch.empty(5, 5, 5, cin, cout, dtype=torch.float32, device=xk.device)
-    db = torch.empty(co_k, dtype=torch.float32, device=xk.device)
-    dwk = torch.empty(5, 5, cin, co_k, dtype=torch.float32, device=xk.device)
-    dbk = torch.empty(co_k, dtype=torch.float32, device=xk.device)
-
-    def one(x_planes, dz_planes, n, accumulate, db_out):
-        # the partial buffer's layout follows the launch (rows / workgroup count): one buffer per call, folded into dwk
-        part = torch.zeros(lib.sol_conv5x5_bwd_weight_ws_floats(n, H, W, cin_k, co_k), dtype=torch.float32, device=xk.device)
-        check(lib.sol_conv5x5_bwd_weight(stream(), ptr(x_planes), ptr(dz_planes), ptr(part), n, H, W, cin_k, co_k))
-        check(lib.sol_conv5x5_bwd_weight_reduce(stream(), ptr(part), ptr(dwk), ptr(db_out), n, H, W, cin, co_k, accumulate))
-
-    for kd in range(5):
-        lo, hi = max(0, 2 - kd), min(D, D + 2 - kd)          # output planes that see input plane d + kd - 2
-        if kd == 2:
-            one(xk, dzk, B * D, 0, db)
-        else:
-            for b in range(B):
-                one(xk[b, lo + kd - 2:hi + kd - 2], dzk[b, lo:hi], hi - lo, 1 if b else 0, dbk)
-        dW[kd].copy_(dwk[..., :cout])
-    return dW, db[:cout].clone()
+    dev = xk.device
+    part = torch.empty(lib.sol_conv3d_bwd_weight_ws_floats(B, D, H, W, cin_k, co_k), dtype=torch.float32, device=dev)
+    dW = torch.empty(5, 5, 5, cin, co_k, dtype=torch.float32, device=dev)
+    db = torch.empty(co_k, dtype=torch.float32, device=dev)
+    scratch = torch.empty(co_k, dtype=torch.float32, device=dev)
+    both32 = cin_k == 32 and co_k == 32
+    check(lib.sol_conv3d_bwd_weight(stream(), ptr(xk), ptr(dzk), ptr(_absmax(xk)) if both32 else None, ptr(_absmax(dzk)) if both32 else None,
+                                    ptr(part), ptr(dW), ptr(db), ptr(scratch), B, D, H, W, cin_k, co_k, cin, co_k))
+    return dW[..., :cout].contiguous(), db[:cout].clone()
 
 
 class _Conv3DFn(torch.autograd.Function):
