@@ -280,7 +280,11 @@ def conv3d_bwd_weight(xk, dz, cin, cout):
     db = torch.empty(co_k, dtype=torch.float32, device=dev)
     scratch = torch.empty(co_k, dtype=torch.float32, device=dev)
     both32 = cin_k == 32 and co_k == 32
-    check(lib.sol_conv3d_bwd_weight(stream(), ptr(xk), ptr(dzk), ptr(_absmax(xk)) if both32 else None, ptr(_absmax(dzk)) if both32 else None,
+    # (the slot tensors must outlive the call: a temporary inside ptr(...) is freed -- and its block handed to the next
+    # allocation -- before the launch is even enqueued)
+    xmax = _absmax(xk) if both32 else None
+    zmax = _absmax(dzk) if both32 else None
+    check(lib.sol_conv3d_bwd_weight(stream(), ptr(xk), ptr(dzk), ptr(xmax), ptr(zmax),
                                     ptr(part), ptr(dW), ptr(db), ptr(scratch), B, D, H, W, cin_k, co_k, cin, co_k))
     return dW[..., :cout].contiguous(), db[:cout].clone()
 

@@ -240,7 +240,7 @@ def test_conv3d_gradients_against_oracle(shape, cin, cout, res, lrelu):
     r64 = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64).float().double()
     x, w, b = r64(B, D, H, W, cin).requires_grad_(True), (r64(5, 5, 5, cin, cout) / np.sqrt(125 * cin)).float().double().requires_grad_(True), r64(cout).requires_grad_(True)
     r = r64(B, D, H, W, cout).requires_grad_(True) if res else None
-    gy = r64(B, D, H, W, cout)
+    gy = r64(B, D, H, W, cout) * 1e-3             # the upstream gradient lives on another scale than the activations (operand scales must not mix)
     (_oracle_conv(x, w, b, r, lrelu) * gy).sum().backward()
     hx, hw, hb = (f32(t.detach()).requires_grad_(True) for t in (x, w, b))
     hr = f32(r.detach()).requires_grad_(True) if res else None
