@@ -298,3 +298,24 @@ def test_karman3d_trainer_sol2_against_oracle(use_graph):
     p2, _, _ = o2.adam_tf([p.detach() for p in params], [p.grad for p in params], [torch.zeros_like(p) for p in params],
                           [torch.zeros_like(p) for p in params], 1, 1e-4)
     assert rel(net.params.detach(), torch.cat([p.reshape(-1) for p in p2])) < 1e-4
+
+
+def test_karman3d_script(tmp_path):
+    """scripts/karman3d.py: data generation at 16 x 8 x 8, a SOL-2 training demo on those frames, and a corrected roll-out
+    with the model it wrote."""
+    import importlib.util
+    from sol_amd import scene
+    sdir = os.path.join(os.path.dirname(os.path.abspath(sol_amd.__file__)), "scripts")
+    sys.path.insert(0, sdir)
+    spec = importlib.util.spec_from_file_location("sol_script_karman3d", os.path.join(sdir, "karman3d.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(["-r", "8", "-t", "8", "--re", "1.6e5", "-o", str(tmp_path / "run"), "--train-sol", "2", "--train-steps", "2"])
+    v = scene.read_zipped_array(out + "/velo_000007.npz")
+    d = scene.read_zipped_array(out + "/dens_000007.npz")
+    assert v.shape == (1, 17, 9, 9, 3) and d.shape == (1, 16, 8, 8, 1) and np.isfinite(v).all() and d.max() > 0
+    assert abs(float(v[0, 0, 0, 0, 0]) - 1.0) < 1e-6 and float(v[0, :, :, 8, 0].max()) == 0.0      # component 0 = flow component, zero padded beyond Z
+    assert os.path.isfile(out + "/model3d.pt")
+    out2 = mod.main(["-r", "8", "-t", "4", "--re", "1.6e5", "-o", str(tmp_path / "run2"), "--model", out + "/model3d.pt"])
+    v2 = scene.read_zipped_array(out2 + "/velo_000003.npz")
+    assert np.isfinite(v2).all() and np.abs(v2 - scene.read_zipped_array(out + "/velo_000003.npz")).max() > 0       # the corrector acts
