@@ -1,0 +1,40 @@
+#!/bin/bash
+# Round-3 measurement artefacts, run ON THE GPU BOX (gpurun -- 'bash tools/collect_profiles.sh'):
+#   1. bench.py line (unprofiled)                                   -> gpurun_out/r3prof/bench.json
+#   2. rocprofv3 --kernel-trace --stats of the SAME bench command   -> kernel_stats.txt (tools/rocpd_stats.py)
+#   3. PMC passes, one counter set each (FETCH_SIZE / WRITE_SIZE cannot share a pass; --pmc never combined with other
+#      trace domains): HBM traffic per launch -> r03_pmc_traffic.json (with the library's source hash), and the SQ
+#      counters of the conv / solver kernels -> pmc_sq.txt
+# Copy what is to be judged from gpurun_out/r3prof/ into profiles/ afterwards.
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out/r3prof
+rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp; export TMPDIR=/tmp
+ARGS="--steps 20 --warmup 5"
+python $R/bench.py $ARGS 2>$OUT/bench.err | tail -1 > $OUT/bench.json
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $R/bench.py $ARGS > $OUT/bench_under_rocprof.json 2>$OUT/rocprof.err
+DB=$(find $OUT/trace -name "*.db" | head -1)
+if [ -n "$DB" ]; then python $R/tools/rocpd_stats.py "$DB" > $OUT/kernel_stats.txt; else ls -R $OUT/trace > $OUT/kernel_stats.txt; fi
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline > /dev/null 2>>$OUT/rocprof.err
+  python $R/tools/pmc_summary.py $OUT/pmc_$C "" --json $OUT/r03_pmc_traffic.json > $OUT/pmc_$C.txt
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F16 \
+  --output-format csv -d $OUT/pmc_sq -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline > /dev/null 2>>$OUT/rocprof.err
+python $R/tools/pmc_summary.py $OUT/pmc_sq "k_" > $OUT/pmc_sq.txt
+# karman-3d: kernel trace + HBM counters of the forward roll-out and one training step
+cat > /tmp/k3d_prof.py <<PY
+import sys, json, torch
+sys.path.insert(0, "$R")
+import sol_amd, bench
+print(json.dumps(bench.karman3d_leg(sol_amd, torch.device("cuda", 0))))
+PY
+rocprofv3 --kernel-trace --stats -d $OUT/trace3d -o trace -- python /tmp/k3d_prof.py > $OUT/k3d_under_rocprof.json 2>>$OUT/rocprof.err
+DB=$(find $OUT/trace3d -name "*.db" | head -1)
+[ -n "$DB" ] && python $R/tools/rocpd_stats.py "$DB" > $OUT/k3d_kernel_stats.txt
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc3d_$C -o pmc -- python $R/tools/k3d_time.py 1 2 > /dev/null 2>>$OUT/rocprof.err
+  python $R/tools/pmc_summary.py $OUT/pmc3d_$C "k" > $OUT/pmc3d_$C.txt
+done
+rm -rf $OUT/trace $OUT/trace3d $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq $OUT/pmc3d_FETCH_SIZE $OUT/pmc3d_WRITE_SIZE
+ls -la $OUT
