@@ -210,6 +210,26 @@ class profile:
         return False
 
 
+class no_gc_during_capture:
+    """A stream capture must not be interrupted by Python's cyclic garbage collector: a collected object whose finaliser
+    calls the HIP runtime (a trainer destroying its hipGraph, a torch CUDAGraph, a freed allocator segment) makes the runtime
+    refuse the call -- or abort -- while ANY stream of the process is capturing in global mode.  Collect what is collectable
+    first, then keep the collector off for the duration of the capture."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self._was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+        return False
+
+
 def check(code):
     if code != 0:
         raise SolError("libsol_hip error %d: %s" % (code, load().sol_last_error().decode()))

@@ -195,7 +195,7 @@ class BurgersTrainer:
         torch.cuda.synchronize()
         self.net.params.grad = None             # the captured backward allocates .grad from the graph's pool and rewrites it per replay
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with _lib.no_gc_during_capture(), torch.cuda.graph(g):
             loss = self._unrolled_loss()
             loss.backward()
             self.loss.copy_(loss.detach())
@@ -283,7 +283,7 @@ class BurgersRollout:
             torch.cuda.synchronize()
             self.vel.copy_(keep)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with _lib.no_gc_during_capture(), torch.cuda.graph(g):
                 self._one()
             self._graph = g
             self.vel.copy_(keep)

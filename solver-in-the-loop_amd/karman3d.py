@@ -194,16 +194,29 @@ class MarsMoon3D:
         self.params = torch.cat(parts).to(device=device, dtype=torch.float32).contiguous()
         self._packed = None
 
+    def train_packs(self):
+        """Per layer (forward-packed, backward-data-packed) weights, built once and reused by every unrolled step of a
+        training step (the weights only change between steps: whoever updates them resets `_tpacks`)."""
+        if getattr(self, "_tpacks", None) is None:
+            t = self.tensors()
+            self._tpacks = []
+            for l in range(12):
+                cin, cout = self.chans[l], self.chans[l + 1]
+                w = t[2 * l].detach()
+                self._tpacks.append((_pack3d(w, 4 if cin <= 4 else 32, cout, 0), _pack3d(w, cout, cin, 1)))
+        return self._tpacks
+
     def __call__(self, x):
         """Differentiable forward (training): x [B,Y,X,Z,4] -> [B,Y,X,Z,cout]; gradients flow to self.params (set
         `net.params.requires_grad_(True)`) and to x."""
         p = self.tensors()
+        pk = self.train_packs()
         sl = self.slope
-        h = conv3d_fn(x, p[0], p[1], None, True, sl)
+        h = conv3d_fn(x, p[0], p[1], None, True, sl, pk[0])
         for k in range(5):
-            a = conv3d_fn(h, p[2 + 4 * k], p[3 + 4 * k], None, True, sl)
-            h = conv3d_fn(a, p[4 + 4 * k], p[5 + 4 * k], h, True, sl)
-        return conv3d_fn(h, p[22], p[23], None, False, sl)
+            a = conv3d_fn(h, p[2 + 4 * k], p[3 + 4 * k], None, True, sl, pk[1 + 2 * k])
+            h = conv3d_fn(a, p[4 + 4 * k], p[5 + 4 * k], h, True, sl, pk[2 + 2 * k])
+        return conv3d_fn(h, p[22], p[23], None, False, sl, pk[11])
 
     @property
     def n_params(self):
@@ -218,8 +231,10 @@ class MarsMoon3D:
     def set_weights(self, weights):
         flat = np.concatenate([np.asarray(w, dtype=np.float32).reshape(-1) for w in weights])
         assert flat.size == self.n_params, "weight list does not match %s" % self.name
-        self.params.copy_(torch.as_tensor(flat, device=self.params.device))
+        with torch.no_grad():
+            self.params.copy_(torch.as_tensor(flat, device=self.params.device))
         self._packed = None
+        self._tpacks = None
 
     def pack(self):
         """(packed weights, padded biases) per layer in the layout the conv kernels consume; cached until set_weights."""
@@ -293,14 +308,18 @@ class _Conv3DFn(torch.autograd.Function):
     """y = act(conv3d_same(x, w) + b (+ residual)), NDHWC, w in Keras DHWIO layout."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, lrelu, slope):
+    def forward(ctx, x, w, b, residual, lrelu, slope, packs):
         _lib.require_gpu()
         cin, cout = w.shape[3], w.shape[4]
         assert cin in (1, 2, 3, 4, 32), "conv3d supports <= 4 or 32 input channels"
         cin_k = 4 if cin <= 4 else 32
         xk = _pad_ch(_lib.f32(x), cin_k)
-        wk = _pad_ch(_lib.f32(w).permute(0, 1, 2, 4, 3), cin_k).permute(0, 1, 2, 4, 3).contiguous() if cin_k != cin else _lib.f32(w)
-        packed = _pack3d(wk, cin_k, cout, 0)
+        if packs is not None and cin_k == cin:
+            packed = packs[0]
+        else:
+            wk = _pad_ch(_lib.f32(w).permute(0, 1, 2, 4, 3), cin_k).permute(0, 1, 2, 4, 3).contiguous() if cin_k != cin else _lib.f32(w)
+            packed = _pack3d(wk, cin_k, cout, 0)
+        ctx.packed_bwd = packs[1] if packs is not None else None
         res = None if residual is None else _lib.f32(residual)
         # the operand's absmax selects the fp16 three-product kernels (and, for 32 -> 32 layers, the one-launch 5x5x5 kernel)
         y = conv3d(xk, packed, _lib.f32(b), res, cout, lrelu, slope, _absmax(xk) if cin_k == 32 else None)
@@ -318,14 +337,15 @@ class _Conv3DFn(torch.autograd.Function):
         dW, db = conv3d_bwd_weight(xk, dz, cin, cout)
         # data gradient: the flipped kernel, run channels (cout -> cin)
         co_k = 4 if cout <= 4 else 32
-        packed = _pack3d(_lib.f32(w), cout, cin, 1)
+        packed = ctx.packed_bwd if ctx.packed_bwd is not None else _pack3d(_lib.f32(w), cout, cin, 1)
         dzk = _pad_ch(dz, co_k)
         dx = conv3d(dzk, packed, None, None, cin, False, slope, _absmax(dzk) if co_k == 32 else None)
-        return dx, dW, db, (dz if has_res else None), None, None
+        return dx, dW, db, (dz if has_res else None), None, None, None
 
 
-def conv3d_fn(x, w, b, residual=None, lrelu=False, slope=0.3):
-    return _Conv3DFn.apply(x, w, b, residual, lrelu, slope)
+def conv3d_fn(x, w, b, residual=None, lrelu=False, slope=0.3, packs=None):
+    """packs: optional (forward-packed, backward-data-packed) weight buffers of this layer (MarsMoon3D.train_packs)."""
+    return _Conv3DFn.apply(x, w, b, residual, lrelu, slope, packs)
 
 
 class Karman3DTrainer:
@@ -368,6 +388,7 @@ class Karman3DTrainer:
     def _unrolled(self):
         d, vy, vx, vz, re = self._in
         self.net.params.grad = None
+        self.net._tpacks = None                     # the weights moved since the last step: re-pack once (inside the graph when captured)
         v = (vy.detach().clone().requires_grad_(True), vx, vz)     # the state enters the graph (the step's autograd Function needs a grad-requiring input)
         losses = []
         for i in range(self.ms):
@@ -409,7 +430,7 @@ class Karman3DTrainer:
                     torch.cuda.synchronize()
                     self.net.params.grad = None
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    with _lib.no_gc_during_capture(), torch.cuda.graph(g):
                         self._unrolled()
                     self._graph = g
                 self._graph.replay()

@@ -162,7 +162,8 @@ class SolTrainer:
                     del self._graphs[slot]
                 h = C.c_void_p()
                 torch.cuda.synchronize()
-                check(self.lib.sol_train_graph_create(C.byref(self.cfg), *args, C.byref(h)))
+                with _lib.no_gc_during_capture():
+                    check(self.lib.sol_train_graph_create(C.byref(self.cfg), *args, C.byref(h)))
                 self._graphs[slot] = (key, h)
             check(self.lib.sol_train_graph_launch(self._graphs[slot][1], stream()))
         else:
@@ -342,7 +343,7 @@ class GraphTrainer:
                 torch.cuda.synchronize()
                 self.net.params.grad = None
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with _lib.no_gc_during_capture(), torch.cuda.graph(g):
                     self._unrolled()
                 self._graph = g
             self._graph.replay()
