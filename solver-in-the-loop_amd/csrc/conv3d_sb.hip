@@ -317,7 +317,11 @@ int sol_conv3d_sb_launch(hipStream_t s, const float* x, const float* wsh, const 
     a.x = x; a.bias = bias; a.res = residual; a.y = y; a.B = B * D; a.H = H; a.W = 64; a.CO = 32; a.epi = epilogue; a.slope = slope;
     a.wsh = wsh; a.xmax = x_absmax; a.ymax = y_absmax; a.tiles_x = 1;
     const int nrows = B * D * H;
-    SOL_LAUNCH(k_conv3d_sb, dim3((nrows + 2) / 3), dim3(768), c3_lds(), s, a, nrows, D);
+    // a multiple of 8 workgroups, so that the XCD-aware tile order applies (xcd_tile): every XCD then owns a contiguous block of
+    // planes and the five depth slices of a row come from ITS L2 (2.5 MB of reuse distance) instead of being fetched by all
+    // eight L2s (measured without it: 745 MB of fabric reads per launch for 64 MB of input).  Padding tiles own no rows.
+    const int ntiles = (nrows + 2) / 3, grid = (ntiles + 7) / 8 * 8;
+    SOL_LAUNCH(k_conv3d_sb, dim3(grid), dim3(768), c3_lds(), s, a, nrows, D);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }

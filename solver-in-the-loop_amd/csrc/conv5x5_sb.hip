@@ -605,7 +605,8 @@ int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles) {
     if (int e = init_sb_kernels()) return e;
     const int nprod = sol_opt().conv_split3 ? 3 : 6;
     const int nrows = ntiles / a.tiles_x;             // global image rows B*H
-    const int grid3 = ((nrows + 2) / 3) * a.tiles_x;  // three consecutive rows of one column block per workgroup
+    int grid3 = ((nrows + 2) / 3) * a.tiles_x;        // three consecutive rows of one column block per workgroup
+    if (grid3 > 64) grid3 = (grid3 + 7) / 8 * 8;      // XCD-aware tile order needs a multiple of 8 (xcd_tile); padding tiles own no rows
     const size_t lds = sb_lds(NT * 16);
     if (a.xmax) {                                     // per-tensor absmax known: fp16 three-product kernels
         if (NT == 2) SOL_LAUNCH((k_conv5x5_sb<2, 2>), dim3(grid3), dim3(768), lds, s, a, nrows);
