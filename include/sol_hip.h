@@ -228,6 +228,8 @@ int sol_conv5x5(void* stream, const float* x, const float* packed, const float* 
  * publishes its absmax in the unrolled training graph, so no extra pass over the data exists. */
 #define SOL_ABSMAX_SLOTS 256
 int32_t sol_absmax_slots(void);   /* == SOL_ABSMAX_SLOTS of the library that was loaded */
+/* slots[0..SOL_ABSMAX_SLOTS) = bit patterns whose maximum is max|x| over x[0..n): for tensors whose producer did not publish it */
+int sol_absmax(void* stream, const float* x, int64_t n, uint32_t* slots);
 int sol_conv5x5_scaled(void* stream, const float* x, const float* packed, const float* bias,
                        const float* residual, const float* act_ref, float* y,
                        int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,

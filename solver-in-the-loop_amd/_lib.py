@@ -74,6 +74,7 @@ _SIGS = {
     "sol_conv5x5_pack": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "sol_conv5x5": (C.c_int, [_P] * 7 + [C.c_int32] * 6 + [C.c_float]),
     "sol_absmax_slots": (C.c_int32, []),
+    "sol_absmax": (C.c_int, [_P, _P, C.c_int64, _P]),
     "sol_conv5x5_scaled": (C.c_int, [_P] * 7 + [C.c_int32] * 6 + [C.c_float] + [_P] * 2),
     "sol_conv5x5_bwd_weight_ws_floats": (C.c_size_t, [C.c_int32] * 5),
     "sol_conv5x5_bwd_weight": (C.c_int, [_P] * 4 + [C.c_int32] * 5),

@@ -573,6 +573,21 @@ int init_sb_kernels() {
 
 }  // namespace
 
+// max|x| of a tensor into the SOL_ABSMAX_SLOTS-slot form the scaled kernels consume (sol_conv5x5_scaled, sol_conv3d, the weight
+// gradients): for callers whose producer did not publish it.  One pass over x at HBM speed.
+namespace {
+__global__ void k_zero_slots(unsigned* slots) { slots[threadIdx.x] = 0u; }
+}
+extern "C" int sol_absmax(void* stream, const float* x, int64_t n, uint32_t* slots) {
+    SOL_REQUIRE(x && slots && n > 0, "sol_absmax: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    SOL_LAUNCH(k_zero_slots, dim3(1), dim3(SOL_AMAX_SLOTS), 0, s, slots);
+    const size_t blocks = ((size_t)n + 4095) / 4096;
+    SOL_LAUNCH(k_absmax, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks))), dim3(256), 0, s, x, (size_t)n, slots);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
 size_t sol_conv_sb_packed_floats(int OP) { return (size_t)25 * 3 * OP * 16; }   // 25 taps x 3 planes x OP x 32 bf16
 
 int sol_conv_sb_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int mode, void* out) {
