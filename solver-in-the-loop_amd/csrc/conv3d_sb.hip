@@ -255,6 +255,243 @@ __global__ void __launch_bounds__(768) k_conv3d_sb(ConvArgs a, int nrows, int D)
     if (a.ymax) amax_publish_last(vmax, a.ymax, reinterpret_cast<unsigned*>(smem_c3 + AMAX_LDS));
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// k_conv3d_sb6: the same convolution with SIX rows per workgroup and a 32-pixel x 32-channel tile per wave.
+// The 3-row kernel above is bound by its LDS operand stream: per tap a wave issues 6 ds_read_b128 (2 A + 4 B) for 6 MFMAs, and
+// all twelve waves re-read the SAME weight fragments.  A wave that owns two 16-pixel tiles reads the weight fragments once for
+// both: 8 reads (4 A + 4 B) per 12 MFMAs -- one third less LDS traffic per matrix instruction.  With three rows per workgroup that
+// would leave six waves for four SIMDs (why the 2-D kernel cannot do it at 768 rows); the 3-D launches have 8 192 rows per
+// simulation, so six rows per workgroup still fill the chip five times over.  12 waves: wave = (row r = wid / 2, pixel half).
+// Input rows live in an 8-slot ring (row G0-2+rr in slot rr & 7: six live rows + the incoming one); everything else -- split
+// staging, double-buffered tap-row weight sets, next-slice prefetch during tap rows 3 / 4, one LDS-only barrier per five taps,
+// epilogue through LDS -- as above.  The residual is read straight from global memory in the epilogue (no LDS-DMA region: the
+// ring takes 70 KB).
+// ------------------------------------------------------------------------------------------------------------------------
+// Loop-invariant-code-motion fence (as in cnn_chain.hip): operand addresses derived from the returned value are recomputed in the
+// tap row that uses them instead of being hoisted out of the slice loop and spilled (scratch reloads share vmcnt with the
+// prefetched rows: every reload would wait for the loads in flight).
+__device__ __forceinline__ int c6_opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+#ifndef C6_ABUF
+#define C6_ABUF 1      // 2: prefetch the next tap's A fragments behind this tap's MFMAs (spills: 168 VGPRs + scratch); 1: read per tap
+#endif
+__global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D) {
+    constexpr int OP = 32, HWP = 68;
+    constexpr int PLANE = HWP * 64, SLOT = 2 * PLANE, WPL = OP * 64, WBUF = 5 * 2 * WPL;
+    constexpr int NSLOT = 8, ROWS = 6;
+    constexpr int AMAX_LDS = NSLOT * SLOT + 2 * WBUF;
+    extern __shared__ __align__(16) unsigned char smem_c6[];
+    if (threadIdx.x == 0) *reinterpret_cast<uint2*>(smem_c6 + AMAX_LDS) = make_uint2(0u, 0u);
+    const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = wid >> 1, half = wid & 1;           // this wave's row of the workgroup and its 32-pixel half
+    const int g = lane >> 4, li = lane & 15;
+    const int H = a.H;
+    constexpr int W = 64;
+    const int bx = xcd_tile(blockIdx.x, gridDim.x);
+    const int G0 = bx * ROWS;
+    const int gy = G0 + r;
+    const bool tvalid = gy < nrows;
+    const int plane = (tvalid ? gy : 0) / H, dpl = plane % D;
+    const int row_lo = plane * H, row_hi = row_lo + H;
+    unsigned char* ring = smem_c6;
+    unsigned char* Wt = smem_c6 + NSLOT * SLOT;
+    const float4* gx = reinterpret_cast<const float4*>(a.x);
+    const uint4* gw = reinterpret_cast<const uint4*>(a.wsh) + 1;
+    float sa = 1.f, out_scale = 1.f;
+    constexpr int WV = WBUF / 16;
+
+    auto row_ok = [&](int gr, int e) {
+        const int xx = (e >> 3) - 2;
+        return e < HWP * 8 && gr >= 0 && gr < nrows && xx >= 0 && xx < W;
+    };
+    auto load_row = [&](int gr, int e) {
+        const int xx = (e >> 3) - 2;
+        return gx[row_ok(gr, e) ? ((size_t)gr * W + xx) * 8 + (e & 7) : (size_t)0];
+    };
+    auto store_row = [&](int slot, int gr, float4 v, int e) {
+        if (!row_ok(gr, e)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < HWP * 8) {
+            const int hc = e >> 3, c4 = e & 7;
+            unsigned p0[2], p1[2];
+            split2h(v.x, v.y, sa, p0[0], p1[0]);
+            split2h(v.z, v.w, sa, p0[1], p1[1]);
+            unsigned char* q = ring + slot * SLOT + hc * 64 + ((((c4 >> 1) ^ swzb(hc)) << 4) | ((c4 & 1) << 3));
+            *reinterpret_cast<uint2*>(q) = make_uint2(p0[0], p0[1]);
+            *reinterpret_cast<uint2*>(q + PLANE) = make_uint2(p1[0], p1[1]);
+        }
+    };
+    auto load_w = [&](int set, uint4& p0, uint4& p1) {
+        p0 = gw[(size_t)set * WV + tid];
+        p1 = gw[(size_t)set * WV + (tid + 768 < WV ? tid + 768 : WV - 1)];
+    };
+    auto store_w = [&](int buf, const uint4& p0, const uint4& p1) {
+        uint4* dst = reinterpret_cast<uint4*>(Wt + buf * WBUF);
+        dst[tid] = p0;
+        if (tid + 768 < WV) dst[tid + 768] = p1;
+    };
+    // the six rows rr = 0..5 of a depth slice as ONE item list: item e = tid + n*768 (n < 5) -> row e / 544, position e % 544
+    constexpr int ROW_ITEMS = HWP * 8;                // 544 float4 per row
+    auto pro_row = [&](int e) { return e / ROW_ITEMS; };
+    auto pro_load = [&](int sh, int n) {
+        const int e = tid + n * 768, rr = pro_row(e);
+        return rr < ROWS ? load_row(G0 - 2 + rr + sh, e - rr * ROW_ITEMS) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto pro_store = [&](int sh, int n, const float4& v) {
+        const int e = tid + n * 768, rr = pro_row(e);
+        if (rr < ROWS) store_row(rr, G0 - 2 + rr + sh, v, e - rr * ROW_ITEMS);
+    };
+
+    float biasv[2];
+    float4 hvA = make_float4(0.f, 0.f, 0.f, 0.f), hvB = hvA, hvP0 = hvA, hvP1 = hvA, hvP2 = hvA, hvP3 = hvA, hvP4 = hvA;
+    uint4 wA0, wA1, wB0, wB1, wP0, wP1;
+    wA0 = wA1 = wB0 = wB1 = wP0 = wP1 = make_uint4(0u, 0u, 0u, 0u);
+    {
+        const int sh = -2 * H;
+        uint4 am = amax_load(a.xmax);
+        const float winv = reinterpret_cast<const float*>(a.wsh)[1];
+        {
+            const float* bp = a.bias ? a.bias : a.x;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) biasv[n] = bp[a.bias ? n * 16 + li : 0];
+        }
+        hvP0 = pro_load(sh, 0); hvP1 = pro_load(sh, 1); hvP2 = pro_load(sh, 2); hvP3 = pro_load(sh, 3); hvP4 = pro_load(sh, 4);
+        load_w(0, wP0, wP1);
+        hvA = load_row(G0 + 4 + sh, tid);             // rr = 6: the new row of tap row 1
+        load_w(1, wA0, wA1);
+        __builtin_amdgcn_sched_barrier(0);
+        float sai;
+        amax_scale_of(am, sa, sai);
+        out_scale = sai * winv;
+        pro_store(sh, 0, hvP0); pro_store(sh, 1, hvP1); pro_store(sh, 2, hvP2); pro_store(sh, 3, hvP3); pro_store(sh, 4, hvP4);
+        store_w(0, wP0, wP1);
+    }
+    C3_BARRIER();
+
+    f32x4 acc[2][2], acl[2][2];                       // [pixel tile][channel tile]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) { acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; acl[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const int pcc = half * 32 + li;                   // A-row pixel of pixel tile 0 (tile 1: + 16)
+
+    auto tap_row = [&](const int kd, const int dy, const int mode, const bool last, float4& hin, uint4& wi0, uint4& wi1,
+                       const float4& hout, const uint4& wo0, const uint4& wo1) __attribute__((always_inline)) {
+        const int sh = (kd - 2) * H, shn = (kd - 1) * H;
+        if (mode == 0) {
+            hin = load_row(G0 + dy + 5 + sh, tid);    // rr = dy + 7: the new row of tap row dy + 2
+            load_w(kd * 5 + dy + 2, wi0, wi1);
+        } else if (!last) {
+            if (mode == 1) {
+                hvP0 = pro_load(shn, 0); hvP1 = pro_load(shn, 1); hvP2 = pro_load(shn, 2); hvP3 = pro_load(shn, 3); hvP4 = pro_load(shn, 4);
+                load_w((kd + 1) * 5, wP0, wP1);
+            } else {
+                hin = load_row(G0 + 4 + shn, tid);
+                load_w((kd + 1) * 5 + 1, wi0, wi1);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int src = gy + sh + dy - 2;
+        const bool plane_ok = dpl + kd - 2 >= 0 && dpl + kd - 2 < D;
+        const bool has_taps = tvalid && plane_ok && src >= row_lo + sh && src < row_hi + sh;
+        const unsigned char* hrow = ring + ((r + dy) & 7) * SLOT;
+        const unsigned char* wbuf = Wt + (dy & 1) * WBUF;
+        // operands are NOT double buffered across taps here (64 more VGPRs would spill): the A fragments of the next tap are
+        // prefetched behind this tap's MFMAs, the shared B fragments are read at the head of the tap; three waves per SIMD cover the rest
+        uint4 ao[C6_ABUF][2][2], bo[2][2];            // A: [buffer][tile][plane]; B: [tile][plane]
+        const int pcc_ = c6_opaque(pcc), li_ = c6_opaque(li), g_ = c6_opaque(g);
+        auto load_a = [&](int dx, uint4 (&ar)[2][2]) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int hc = pcc_ + 16 * m + dx;
+                const unsigned char* ap = hrow + hc * 64 + ((g_ ^ swzb(hc)) << 4);
+                ar[m][0] = *reinterpret_cast<const uint4*>(ap);
+                ar[m][1] = *reinterpret_cast<const uint4*>(ap + PLANE);
+            }
+        };
+        auto load_b = [&](int dx) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int co = n * 16 + li_;
+                const unsigned char* bp = wbuf + dx * 2 * WPL + co * 64 + ((g_ ^ swzb(co)) << 4);
+                bo[n][0] = *reinterpret_cast<const uint4*>(bp);
+                bo[n][1] = *reinterpret_cast<const uint4*>(bp + WPL);
+            }
+        };
+        auto taps = [&](const int dx0, const int dx1) __attribute__((always_inline)) {
+            if (C6_ABUF == 2 && dx0 == 0) load_a(0, ao[0]);
+#pragma unroll
+            for (int dx = dx0; dx < dx1; ++dx) {
+                load_b(dx);
+                if (C6_ABUF == 2) { if (dx < 4) load_a(dx + 1, ao[(dx + 1) & (C6_ABUF - 1)]); }
+                else load_a(dx, ao[0]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const f16x8 a1 = __builtin_bit_cast(f16x8, ao[dx & (C6_ABUF - 1)][m][0]), a2 = __builtin_bit_cast(f16x8, ao[dx & (C6_ABUF - 1)][m][1]);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const f16x8 b1 = __builtin_bit_cast(f16x8, bo[n][0]), b2 = __builtin_bit_cast(f16x8, bo[n][1]);
+                        acl[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, acl[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, acc[m][n], 0, 0, 0);
+                        acl[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, acl[m][n], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (has_taps) taps(0, 2);
+        if (dy < 4) { store_row((dy + 6) & 7, G0 + dy + 4 + sh, hout, tid); __builtin_amdgcn_sched_barrier(0); }
+        if (has_taps) taps(2, 4);
+        if (dy < 4) { store_w((dy + 1) & 1, wo0, wo1); __builtin_amdgcn_sched_barrier(0); }
+        if (has_taps) taps(4, 5);
+        C3_BARRIER();
+    };
+
+    for (int kd = 0; kd < 5; ++kd) {
+        const bool last = kd == 4;
+        tap_row(kd, 0, 0, last, hvB, wB0, wB1, hvA, wA0, wA1);
+        tap_row(kd, 1, 0, last, hvA, wA0, wA1, hvB, wB0, wB1);
+        tap_row(kd, 2, 0, last, hvB, wB0, wB1, hvA, wA0, wA1);
+        tap_row(kd, 3, 1, last, hvA, wA0, wA1, hvB, wB0, wB1);
+        tap_row(kd, 4, 2, last, hvA, wA0, wA1, hvB, wB0, wB1);
+        if (!last) {
+            const int shn = (kd - 1) * H;
+            pro_store(shn, 0, hvP0); pro_store(shn, 1, hvP1); pro_store(shn, 2, hvP2); pro_store(shn, 3, hvP3); pro_store(shn, 4, hvP4);
+            store_w(0, wP0, wP1);
+            C3_BARRIER();
+        }
+    }
+    // ---- epilogue: the wave's [32 px][32 co] tile through LDS (the ring is free after the last barrier), 16-byte stores ----
+    float* tb = reinterpret_cast<float*>(ring) + wid * (32 * OP);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const float bias = a.bias ? biasv[n] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                tb[(16 * m + 4 * g + q) * OP + n * 16 + li] = (acc[m][n][q] + acl[m][n][q] * (1.f / 2048.f)) * out_scale + bias;
+        }
+    float vmax = 0.f;
+    if (tvalid) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {                 // 256 float4 per wave
+            const int e = lane + n * 64, px = e >> 3, c4 = e & 7;
+            float4 v = *reinterpret_cast<const float4*>(&tb[px * OP + c4 * 4]);
+            const size_t o4 = ((size_t)gy * W + half * 32 + px) * (OP / 4) + c4;
+            if (a.res) { const float4 q = reinterpret_cast<const float4*>(a.res)[o4]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+            if (a.epi == SOL_EPI_LRELU) {
+                v.x = v.x > 0.f ? v.x : a.slope * v.x; v.y = v.y > 0.f ? v.y : a.slope * v.y;
+                v.z = v.z > 0.f ? v.z : a.slope * v.z; v.w = v.w > 0.f ? v.w : a.slope * v.w;
+            }
+            vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            reinterpret_cast<float4*>(a.y)[o4] = v;
+        }
+    }
+    if (a.ymax) amax_publish_last(vmax, a.ymax, reinterpret_cast<unsigned*>(smem_c6 + AMAX_LDS));
+}
+
+constexpr size_t c6_lds() { return (size_t)8 * 2 * 68 * 64 + 2 * (size_t)5 * 2 * 32 * 64 + 16; }
+
 // fp16 weight planes of all 125 taps with ONE power-of-two scale: header {2^shift_w, 2^-shift_w, 0, 0}, then
 // out[tap = (kd*5 + dy)*5 + dx][plane 2][o 32][chunk s][j] in the LDS image order of the 2-D kernels (k_pack_sh).
 // mode SOL_CONV_BWD_DATA: the flipped kernel with swapped channel axes (w is the FORWARD kernel [125][cout_run][cin_run]).
@@ -317,6 +554,14 @@ int sol_conv3d_sb_launch(hipStream_t s, const float* x, const float* wsh, const 
     a.x = x; a.bias = bias; a.res = residual; a.y = y; a.B = B * D; a.H = H; a.W = 64; a.CO = 32; a.epi = epilogue; a.slope = slope;
     a.wsh = wsh; a.xmax = x_absmax; a.ymax = y_absmax; a.tiles_x = 1;
     const int nrows = B * D * H;
+    if (sol_opt().k3d_conv_rows6) {                   // six rows per workgroup, 32 x 32 tile per wave
+        static int rc6 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
+        SOL_REQUIRE(rc6 == 0, "hipFuncSetAttribute(k_conv3d_sb6) failed");
+        const int nt6 = (nrows + 5) / 6, grid6 = (nt6 + 7) / 8 * 8;
+        SOL_LAUNCH(k_conv3d_sb6, dim3(grid6), dim3(768), c6_lds(), s, a, nrows, D);
+        SOL_LAUNCH_CHECK();
+        return SOL_OK;
+    }
     // a multiple of 8 workgroups, so that the XCD-aware tile order applies (xcd_tile): every XCD then owns a contiguous block of
     // planes and the five depth slices of a row come from ITS L2 (2.5 MB of reuse distance) instead of being fetched by all
     // eight L2s (measured without it: 745 MB of fabric reads per launch for 64 MB of input).  Padding tiles own no rows.

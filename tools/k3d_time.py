@@ -48,12 +48,16 @@ for tile, ftf in ((1, 1), (0, 1), (0, 0)):
 sol_amd._lib.set_option("k3d_tile", 0)
 sol_amd._lib.set_option("k3d_fused_tf", 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(steps):
+for rows6 in (0, 1):                       # three-row / six-row Conv3D kernel; the default (1) is timed last and stays on
+    sol_amd._lib.set_option("k3d_conv_rows6", rows6)
     ro.correction()
-e1.record()
-torch.cuda.synchronize()
-out["cnn_ms"] = e0.elapsed_time(e1) / steps
+    e0.record()
+    for _ in range(steps):
+        ro.correction()
+    e1.record()
+    torch.cuda.synchronize()
+    out["cnn_ms_rows6_%d" % rows6] = e0.elapsed_time(e1) / steps
+out["cnn_ms"] = out["cnn_ms_rows6_1"]
 e0.record()
 s2 = st
 for _ in range(steps):
