@@ -267,16 +267,17 @@ __global__ void __launch_bounds__(768) k_conv3d_sb(ConvArgs a, int nrows, int D)
 // epilogue through LDS -- as above.  The residual is read straight from global memory in the epilogue (no LDS-DMA region: the
 // ring takes 70 KB).
 // ------------------------------------------------------------------------------------------------------------------------
-// Loop-invariant-code-motion fence (as in cnn_chain.hip): operand addresses derived from the returned value are recomputed in the
-// tap row that uses them instead of being hoisted out of the slice loop and spilled (scratch reloads share vmcnt with the
-// prefetched rows: every reload would wait for the loads in flight).
-__device__ __forceinline__ int c6_opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 #ifndef C6_ABUF
 #define C6_ABUF 1      // 2: prefetch the next tap's A fragments behind this tap's MFMAs (spills: 168 VGPRs + scratch); 1: read per tap
 #endif
 __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D) {
     constexpr int OP = 32, HWP = 68;
-    constexpr int PLANE = HWP * 64, SLOT = 2 * PLANE, WPL = OP * 64, WBUF = 5 * 2 * WPL;
+    // LDS images with PADDED strides instead of the XOR swizzle of the kernels above: a pixel (an output channel) is 160 bytes =
+    // 64 B hi plane (four 16-byte channel chunks) + 64 B lo plane + 32 B pad.  160-byte strides are conflict free for the
+    // ds_read_b128 lane groups of gfx950, and -- the point -- every operand address of a tap row is ONE lane-dependent VGPR plus
+    // an instruction immediate ((16 m + dx) * 160 + 64 * plane), where the XOR form needs address arithmetic (or 20 live
+    // address registers) per tap: 29 -> 13 VALU instructions per 12 MFMAs.
+    constexpr int PS = 160, SLOT = HWP * PS, WDX = OP * PS, WBUF = 5 * WDX, WGL = 5 * 2 * OP * 64;
     constexpr int NSLOT = 8, ROWS = 6;
     constexpr int AMAX_LDS = NSLOT * SLOT + 2 * WBUF;
     extern __shared__ __align__(16) unsigned char smem_c6[];
@@ -297,7 +298,13 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
     const float4* gx = reinterpret_cast<const float4*>(a.x);
     const uint4* gw = reinterpret_cast<const uint4*>(a.wsh) + 1;
     float sa = 1.f, out_scale = 1.f;
-    constexpr int WV = WBUF / 16;
+    constexpr int WV = WGL / 16;                      // 16-byte chunks of a tap-row weight set in global memory (1280)
+    // global chunk q = ((dx*2 + plane)*32 + o)*4 + s holds logical chunk s ^ swzb(o) (k_pack3_sh): its place in the padded image
+    auto w_dst = [&](int q) {
+        const int s4 = q & 3, o = (q >> 2) & 31, pl = (q >> 7) & 1, dx = q >> 8;
+        return dx * WDX + o * PS + pl * 64 + ((s4 ^ swzb(o)) << 4);
+    };
+    const int wd0 = w_dst(tid), wd1 = w_dst(tid + 768 < WV ? tid + 768 : WV - 1);
 
     auto row_ok = [&](int gr, int e) {
         const int xx = (e >> 3) - 2;
@@ -314,9 +321,9 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
             unsigned p0[2], p1[2];
             split2h(v.x, v.y, sa, p0[0], p1[0]);
             split2h(v.z, v.w, sa, p0[1], p1[1]);
-            unsigned char* q = ring + slot * SLOT + hc * 64 + ((((c4 >> 1) ^ swzb(hc)) << 4) | ((c4 & 1) << 3));
+            unsigned char* q = ring + slot * SLOT + hc * PS + c4 * 8;
             *reinterpret_cast<uint2*>(q) = make_uint2(p0[0], p0[1]);
-            *reinterpret_cast<uint2*>(q + PLANE) = make_uint2(p1[0], p1[1]);
+            *reinterpret_cast<uint2*>(q + 64) = make_uint2(p1[0], p1[1]);
         }
     };
     auto load_w = [&](int set, uint4& p0, uint4& p1) {
@@ -324,9 +331,9 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
         p1 = gw[(size_t)set * WV + (tid + 768 < WV ? tid + 768 : WV - 1)];
     };
     auto store_w = [&](int buf, const uint4& p0, const uint4& p1) {
-        uint4* dst = reinterpret_cast<uint4*>(Wt + buf * WBUF);
-        dst[tid] = p0;
-        if (tid + 768 < WV) dst[tid + 768] = p1;
+        unsigned char* dst = Wt + buf * WBUF;
+        *reinterpret_cast<uint4*>(dst + wd0) = p0;
+        if (tid + 768 < WV) *reinterpret_cast<uint4*>(dst + wd1) = p1;
     };
     // the six rows rr = 0..5 of a depth slice as ONE item list: item e = tid + n*768 (n < 5) -> row e / 544, position e % 544
     constexpr int ROW_ITEMS = HWP * 8;                // 544 float4 per row
@@ -371,7 +378,8 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) { acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; acl[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    const int pcc = half * 32 + li;                   // A-row pixel of pixel tile 0 (tile 1: + 16)
+    const int a_lane = (half * 32 + li) * PS + g * 16;     // A operand: pixel tile 0, tap 0 (tile m, tap dx: + (16 m + dx) * PS)
+    const unsigned char* b_lane = Wt + li * PS + g * 16;   // B operand: channel tile 0 (tile n: + 16 n * PS; tap dx: + dx * WDX)
 
     auto tap_row = [&](const int kd, const int dy, const int mode, const bool last, float4& hin, uint4& wi0, uint4& wi1,
                        const float4& hout, const uint4& wo0, const uint4& wo1) __attribute__((always_inline)) {
@@ -392,28 +400,23 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
         const int src = gy + sh + dy - 2;
         const bool plane_ok = dpl + kd - 2 >= 0 && dpl + kd - 2 < D;
         const bool has_taps = tvalid && plane_ok && src >= row_lo + sh && src < row_hi + sh;
-        const unsigned char* hrow = ring + ((r + dy) & 7) * SLOT;
-        const unsigned char* wbuf = Wt + (dy & 1) * WBUF;
+        const unsigned char* hrow = ring + ((r + dy) & 7) * SLOT + a_lane;
+        const unsigned char* wbuf = b_lane + (dy & 1) * WBUF;
         // operands are NOT double buffered across taps here (64 more VGPRs would spill): the A fragments of the next tap are
         // prefetched behind this tap's MFMAs, the shared B fragments are read at the head of the tap; three waves per SIMD cover the rest
         uint4 ao[C6_ABUF][2][2], bo[2][2];            // A: [buffer][tile][plane]; B: [tile][plane]
-        const int pcc_ = c6_opaque(pcc), li_ = c6_opaque(li), g_ = c6_opaque(g);
         auto load_a = [&](int dx, uint4 (&ar)[2][2]) {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                const int hc = pcc_ + 16 * m + dx;
-                const unsigned char* ap = hrow + hc * 64 + ((g_ ^ swzb(hc)) << 4);
-                ar[m][0] = *reinterpret_cast<const uint4*>(ap);
-                ar[m][1] = *reinterpret_cast<const uint4*>(ap + PLANE);
+                ar[m][0] = *reinterpret_cast<const uint4*>(hrow + (16 * m + dx) * PS);
+                ar[m][1] = *reinterpret_cast<const uint4*>(hrow + (16 * m + dx) * PS + 64);
             }
         };
         auto load_b = [&](int dx) {
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const int co = n * 16 + li_;
-                const unsigned char* bp = wbuf + dx * 2 * WPL + co * 64 + ((g_ ^ swzb(co)) << 4);
-                bo[n][0] = *reinterpret_cast<const uint4*>(bp);
-                bo[n][1] = *reinterpret_cast<const uint4*>(bp + WPL);
+                bo[n][0] = *reinterpret_cast<const uint4*>(wbuf + dx * WDX + 16 * n * PS);
+                bo[n][1] = *reinterpret_cast<const uint4*>(wbuf + dx * WDX + 16 * n * PS + 64);
             }
         };
         auto taps = [&](const int dx0, const int dx1) __attribute__((always_inline)) {
@@ -490,7 +493,7 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
     if (a.ymax) amax_publish_last(vmax, a.ymax, reinterpret_cast<unsigned*>(smem_c6 + AMAX_LDS));
 }
 
-constexpr size_t c6_lds() { return (size_t)8 * 2 * 68 * 64 + 2 * (size_t)5 * 2 * 32 * 64 + 16; }
+constexpr size_t c6_lds() { return (size_t)8 * 68 * 160 + 2 * (size_t)5 * 32 * 160 + 16; }
 
 // fp16 weight planes of all 125 taps with ONE power-of-two scale: header {2^shift_w, 2^-shift_w, 0, 0}, then
 // out[tap = (kd*5 + dy)*5 + dx][plane 2][o 32][chunk s][j] in the LDS image order of the 2-D kernels (k_pack_sh).
