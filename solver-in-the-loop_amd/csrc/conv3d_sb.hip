@@ -267,19 +267,32 @@ __global__ void __launch_bounds__(768) k_conv3d_sb(ConvArgs a, int nrows, int D)
 // epilogue through LDS -- as above.  The residual is read straight from global memory in the epilogue (no LDS-DMA region: the
 // ring takes 70 KB).
 // ------------------------------------------------------------------------------------------------------------------------
-#ifndef C6_ABUF
-#define C6_ABUF 1      // 2: prefetch the next tap's A fragments behind this tap's MFMAs (spills: 168 VGPRs + scratch); 1: read per tap
+// -DSOL_C6_PROF (tools/c6_phase_probe.py builds such a library next to the product one): per-wave s_memtime stamps (low 32 bits,
+// kept in LDS, dumped at the end) -- 8 per tap row -- into the buffer set with sol_c6_prof_set().
+#ifdef SOL_C6_PROF
+__device__ unsigned* g_c6_prof = nullptr;
+extern "C" int sol_c6_prof_set(unsigned* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_c6_prof), &buf, sizeof(buf)) == hipSuccess ? 0 : -1; }
+#define C6_NSTAMP 216
+#define C6_STAMP(i) do { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (lane == 0) c6_st[(i)] = t_; } while (0)
+#else
+#define C6_STAMP(i) do { } while (0)
 #endif
+#ifndef C6_PREFETCH
+#define C6_PREFETCH 0
+#endif
+template <int DBG>
 __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D) {
     constexpr int OP = 32, HWP = 68;
-    // LDS images with PADDED strides instead of the XOR swizzle of the kernels above: a pixel (an output channel) is 160 bytes =
-    // 64 B hi plane (four 16-byte channel chunks) + 64 B lo plane + 32 B pad.  160-byte strides are conflict free for the
-    // ds_read_b128 lane groups of gfx950, and -- the point -- every operand address of a tap row is ONE lane-dependent VGPR plus
-    // an instruction immediate ((16 m + dx) * 160 + 64 * plane), where the XOR form needs address arithmetic (or 20 live
-    // address registers) per tap: 29 -> 13 VALU instructions per 12 MFMAs.
-    constexpr int PS = 160, SLOT = HWP * PS, WDX = OP * PS, WBUF = 5 * WDX, WGL = 5 * 2 * OP * 64;
-    constexpr int NSLOT = 8, ROWS = 6;
-    constexpr int AMAX_LDS = NSLOT * SLOT + 2 * WBUF;
+    // Input rows in LDS with a PADDED pixel stride instead of the XOR swizzle of the kernels above: a pixel is 160 bytes = 64 B hi
+    // plane (four 16-byte channel chunks) + 64 B lo plane + 32 B pad.  160-byte strides are conflict free for the ds_read_b128
+    // lane groups of gfx950, and -- the point -- every A address of a tap row is ONE lane-dependent VGPR plus an instruction
+    // immediate ((16 m + dx) * 160 + 64 * plane), where the XOR form needs address arithmetic (or 10 live address registers)
+    // per tap: 29 -> 13 VALU instructions per 12 MFMAs.  The weight sets keep the XOR image of k_pack3_sh (its swizzle depends
+    // on the lane only, so the B addresses are base + immediate as well) and travel global -> LDS by LDS-DMA: no staging
+    // registers, no ds_write, three rotating 20 KB buffers (set t + 2 is requested during tap row t).
+    constexpr int PS = 160, SLOT = HWP * PS, WPL = OP * 64, WSET = 5 * 2 * WPL;
+    constexpr int NSLOT = 8, ROWS = 6, NWB = 3;
+    constexpr int AMAX_LDS = NSLOT * SLOT + NWB * WSET;
     extern __shared__ __align__(16) unsigned char smem_c6[];
     if (threadIdx.x == 0) *reinterpret_cast<uint2*>(smem_c6 + AMAX_LDS) = make_uint2(0u, 0u);
     const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -293,28 +306,28 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
     const bool tvalid = gy < nrows;
     const int plane = (tvalid ? gy : 0) / H, dpl = plane % D;
     const int row_lo = plane * H, row_hi = row_lo + H;
-    unsigned char* ring = smem_c6;
-    unsigned char* Wt = smem_c6 + NSLOT * SLOT;
+    unsigned char* Wt = smem_c6;                      // weight buffers first: LDS-DMA destinations (M0) below 64 KB
+    unsigned char* ring = smem_c6 + NWB * WSET;
     const float4* gx = reinterpret_cast<const float4*>(a.x);
-    const uint4* gw = reinterpret_cast<const uint4*>(a.wsh) + 1;
+    const unsigned char* gw = reinterpret_cast<const unsigned char*>(a.wsh) + 16;
     float sa = 1.f, out_scale = 1.f;
-    constexpr int WV = WGL / 16;                      // 16-byte chunks of a tap-row weight set in global memory (1280)
-    // global chunk q = ((dx*2 + plane)*32 + o)*4 + s holds logical chunk s ^ swzb(o) (k_pack3_sh): its place in the padded image
-    auto w_dst = [&](int q) {
-        const int s4 = q & 3, o = (q >> 2) & 31, pl = (q >> 7) & 1, dx = q >> 8;
-        return dx * WDX + o * PS + pl * 64 + ((s4 ^ swzb(o)) << 4);
-    };
-    const int wd0 = w_dst(tid), wd1 = w_dst(tid + 768 < WV ? tid + 768 : WV - 1);
+#ifdef SOL_C6_PROF
+    unsigned* c6_st = reinterpret_cast<unsigned*>(smem_c6 + AMAX_LDS + 16) + wid * C6_NSTAMP;
+    C6_STAMP(200);
+    if (lane == 0) c6_st[204] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
 
     auto row_ok = [&](int gr, int e) {
         const int xx = (e >> 3) - 2;
         return e < HWP * 8 && gr >= 0 && gr < nrows && xx >= 0 && xx < W;
     };
     auto load_row = [&](int gr, int e) {
+        if (DBG & 64) return make_float4(0.f, 0.f, 0.f, 0.f);
         const int xx = (e >> 3) - 2;
         return gx[row_ok(gr, e) ? ((size_t)gr * W + xx) * 8 + (e & 7) : (size_t)0];
     };
     auto store_row = [&](int slot, int gr, float4 v, int e) {
+        if (DBG & 64) return;
         if (!row_ok(gr, e)) v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e < HWP * 8) {
             const int hc = e >> 3, c4 = e & 7;
@@ -326,14 +339,20 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
             *reinterpret_cast<uint2*>(q + 64) = make_uint2(p1[0], p1[1]);
         }
     };
-    auto load_w = [&](int set, uint4& p0, uint4& p1) {
-        p0 = gw[(size_t)set * WV + tid];
-        p1 = gw[(size_t)set * WV + (tid + 768 < WV ? tid + 768 : WV - 1)];
+    // LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to dst + 16 * lane (conv5x5_sb.hip explains the form)
+    auto lds_dma16 = [&](const void* src, unsigned char* dst_wave_uniform) __attribute__((always_inline)) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst_wave_uniform);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(lo));
     };
-    auto store_w = [&](int buf, const uint4& p0, const uint4& p1) {
-        unsigned char* dst = Wt + buf * WBUF;
-        *reinterpret_cast<uint4*>(dst + wd0) = p0;
-        if (tid + 768 < WV) *reinterpret_cast<uint4*>(dst + wd1) = p1;
+    // weight set t (one tap row: 20 one-KB pieces) into buffer buf: piece wid by every wave, piece wid + 12 by waves 0..7
+    auto dma_w = [&](int t, int buf) __attribute__((always_inline)) {
+        if (DBG & 32) return;
+        const unsigned char* src = gw + (size_t)t * WSET + lane * 16;
+        unsigned char* dst = Wt + buf * WSET;
+        lds_dma16(src + wid * 1024, dst + wid * 1024);
+        if (wid < 8) lds_dma16(src + (wid + 12) * 1024, dst + (wid + 12) * 1024);
     };
     // the six rows rr = 0..5 of a depth slice as ONE item list: item e = tid + n*768 (n < 5) -> row e / 544, position e % 544
     constexpr int ROW_ITEMS = HWP * 8;                // 544 float4 per row
@@ -349,8 +368,6 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
 
     float biasv[2];
     float4 hvA = make_float4(0.f, 0.f, 0.f, 0.f), hvB = hvA, hvP0 = hvA, hvP1 = hvA, hvP2 = hvA, hvP3 = hvA, hvP4 = hvA;
-    uint4 wA0, wA1, wB0, wB1, wP0, wP1;
-    wA0 = wA1 = wB0 = wB1 = wP0 = wP1 = make_uint4(0u, 0u, 0u, 0u);
     {
         const int sh = -2 * H;
         uint4 am = amax_load(a.xmax);
@@ -361,16 +378,18 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
             for (int n = 0; n < 2; ++n) biasv[n] = bp[a.bias ? n * 16 + li : 0];
         }
         hvP0 = pro_load(sh, 0); hvP1 = pro_load(sh, 1); hvP2 = pro_load(sh, 2); hvP3 = pro_load(sh, 3); hvP4 = pro_load(sh, 4);
-        load_w(0, wP0, wP1);
         hvA = load_row(G0 + 4 + sh, tid);             // rr = 6: the new row of tap row 1
-        load_w(1, wA0, wA1);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_w(0, 0);
+        dma_w(1, 1);
         __builtin_amdgcn_sched_barrier(0);
         float sai;
         amax_scale_of(am, sa, sai);
         out_scale = sai * winv;
         pro_store(sh, 0, hvP0); pro_store(sh, 1, hvP1); pro_store(sh, 2, hvP2); pro_store(sh, 3, hvP3); pro_store(sh, 4, hvP4);
-        store_w(0, wP0, wP1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    C6_STAMP(201);
     C3_BARRIER();
 
     f32x4 acc[2][2], acl[2][2];                       // [pixel tile][channel tile]
@@ -378,61 +397,64 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) { acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; acl[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    const int a_lane = (half * 32 + li) * PS + g * 16;     // A operand: pixel tile 0, tap 0 (tile m, tap dx: + (16 m + dx) * PS)
-    const unsigned char* b_lane = Wt + li * PS + g * 16;   // B operand: channel tile 0 (tile n: + 16 n * PS; tap dx: + dx * WDX)
+    const int a_lane = (half * 32 + li) * PS + g * 16;                     // A: pixel tile 0, tap 0 (tile m, tap dx: + (16 m + dx) * PS)
+    const unsigned char* b_lane = Wt + li * 64 + ((g ^ swzb(li)) << 4);   // B: channel tile 0 (tile n: + 16 n * 64; tap dx: + dx * 2 * WPL)
 
-    auto tap_row = [&](const int kd, const int dy, const int mode, const bool last, float4& hin, uint4& wi0, uint4& wi1,
-                       const float4& hout, const uint4& wo0, const uint4& wo1) __attribute__((always_inline)) {
+    // one tap row of depth slice kd (weight set t = 5 kd + dy in buffer wb).  MODE 0: request the row of tap row dy + 2 of this
+    // slice into hin; MODE 1 (dy == 3): request the next slice's first six rows into hvP; MODE 2 (dy == 4): request the next
+    // slice's row G0+4 into hin.  last: no next slice.  Between the taps: hout = row G0+dy+4 of this slice goes to LDS (dy < 4)
+    // and weight set t + 2 is requested into buffer wb2 (free since the barrier of tap row t - 1).
+    auto tap_row = [&](const int kd, const int dy, const int mode, const bool last, const int wb, const int wb2, float4& hin,
+                       const float4& hout) __attribute__((always_inline)) {
         const int sh = (kd - 2) * H, shn = (kd - 1) * H;
-        if (mode == 0) {
+        C6_STAMP((kd * 5 + dy) * 8 + 0);
+        if (DBG & 4) {
+        } else if (mode == 0) {
             hin = load_row(G0 + dy + 5 + sh, tid);    // rr = dy + 7: the new row of tap row dy + 2
-            load_w(kd * 5 + dy + 2, wi0, wi1);
         } else if (!last) {
             if (mode == 1) {
                 hvP0 = pro_load(shn, 0); hvP1 = pro_load(shn, 1); hvP2 = pro_load(shn, 2); hvP3 = pro_load(shn, 3); hvP4 = pro_load(shn, 4);
-                load_w((kd + 1) * 5, wP0, wP1);
             } else {
                 hin = load_row(G0 + 4 + shn, tid);
-                load_w((kd + 1) * 5 + 1, wi0, wi1);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         const int src = gy + sh + dy - 2;
         const bool plane_ok = dpl + kd - 2 >= 0 && dpl + kd - 2 < D;
-        const bool has_taps = tvalid && plane_ok && src >= row_lo + sh && src < row_hi + sh;
+        const bool has_taps = !(DBG & 1) && tvalid && plane_ok && src >= row_lo + sh && src < row_hi + sh;
         const unsigned char* hrow = ring + ((r + dy) & 7) * SLOT + a_lane;
-        const unsigned char* wbuf = b_lane + (dy & 1) * WBUF;
-        // operands are NOT double buffered across taps here (64 more VGPRs would spill): the A fragments of the next tap are
-        // prefetched behind this tap's MFMAs, the shared B fragments are read at the head of the tap; three waves per SIMD cover the rest
-        uint4 ao[C6_ABUF][2][2], bo[2][2];            // A: [buffer][tile][plane]; B: [tile][plane]
-        auto load_a = [&](int dx, uint4 (&ar)[2][2]) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                ar[m][0] = *reinterpret_cast<const uint4*>(hrow + (16 * m + dx) * PS);
-                ar[m][1] = *reinterpret_cast<const uint4*>(hrow + (16 * m + dx) * PS + 64);
-            }
-        };
-        auto load_b = [&](int dx) {
+        const unsigned char* wbuf = b_lane + wb * WSET;
+        // operands are NOT double buffered across taps (the registers are not there at three waves per SIMD); three waves per
+        // SIMD cover the LDS latency
+        constexpr int PF = (DBG & 512) ? 1 : C6_PREFETCH;   // 1: operands of tap dx + 1 are read before the MFMAs of tap dx
+        uint4 ao[PF + 1][2][2], bo[PF + 1][2][2];     // [buffer][tile][plane]
+        auto load_ab = [&](int dx, int q) {
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                bo[n][0] = *reinterpret_cast<const uint4*>(wbuf + dx * WDX + 16 * n * PS);
-                bo[n][1] = *reinterpret_cast<const uint4*>(wbuf + dx * WDX + 16 * n * PS + 64);
+                bo[q][n][0] = *reinterpret_cast<const uint4*>(wbuf + dx * 2 * WPL + 16 * n * 64);
+                bo[q][n][1] = *reinterpret_cast<const uint4*>(wbuf + dx * 2 * WPL + 16 * n * 64 + WPL);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                ao[q][m][0] = *reinterpret_cast<const uint4*>(hrow + (16 * m + dx) * PS);
+                ao[q][m][1] = *reinterpret_cast<const uint4*>(hrow + (16 * m + dx) * PS + 64);
             }
         };
         auto taps = [&](const int dx0, const int dx1) __attribute__((always_inline)) {
-            if (C6_ABUF == 2 && dx0 == 0) load_a(0, ao[0]);
+            if (PF && dx0 == 0) load_ab(0, 0);
 #pragma unroll
             for (int dx = dx0; dx < dx1; ++dx) {
-                load_b(dx);
-                if (C6_ABUF == 2) { if (dx < 4) load_a(dx + 1, ao[(dx + 1) & (C6_ABUF - 1)]); }
-                else load_a(dx, ao[0]);
+                const int q = PF ? (dx & 1) : 0;
+                if (PF) { if (dx < 4) load_ab(dx + 1, q ^ 1); }
+                else if (!(DBG & 2) || dx == 0) load_ab(dx, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (PF) { if (dx < 4) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const f16x8 a1 = __builtin_bit_cast(f16x8, ao[dx & (C6_ABUF - 1)][m][0]), a2 = __builtin_bit_cast(f16x8, ao[dx & (C6_ABUF - 1)][m][1]);
+                    const f16x8 a1 = __builtin_bit_cast(f16x8, ao[q][m][0]), a2 = __builtin_bit_cast(f16x8, ao[q][m][1]);
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
-                        const f16x8 b1 = __builtin_bit_cast(f16x8, bo[n][0]), b2 = __builtin_bit_cast(f16x8, bo[n][1]);
+                        const f16x8 b1 = __builtin_bit_cast(f16x8, bo[q][n][0]), b2 = __builtin_bit_cast(f16x8, bo[q][n][1]);
                         acl[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, acl[m][n], 0, 0, 0);
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, acc[m][n], 0, 0, 0);
                         acl[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, acl[m][n], 0, 0, 0);
@@ -442,27 +464,45 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
             }
         };
         if (has_taps) taps(0, 2);
-        if (dy < 4) { store_row((dy + 6) & 7, G0 + dy + 4 + sh, hout, tid); __builtin_amdgcn_sched_barrier(0); }
+        C6_STAMP((kd * 5 + dy) * 8 + 1);
+        if (dy < 4 && !(DBG & 4)) { store_row((dy + 6) & 7, G0 + dy + 4 + sh, hout, tid); __builtin_amdgcn_sched_barrier(0); }
+        C6_STAMP((kd * 5 + dy) * 8 + 2);
         if (has_taps) taps(2, 4);
-        if (dy < 4) { store_w((dy + 1) & 1, wo0, wo1); __builtin_amdgcn_sched_barrier(0); }
+        C6_STAMP((kd * 5 + dy) * 8 + 3);
+        const bool more_w = !last || dy < 3;          // set t + 2 exists (t + 2 <= 124)
+        if (more_w && !(DBG & 4)) { dma_w(kd * 5 + dy + 2, wb2); __builtin_amdgcn_sched_barrier(0); }
+        C6_STAMP((kd * 5 + dy) * 8 + 4);
         if (has_taps) taps(4, 5);
-        C3_BARRIER();
+        C6_STAMP((kd * 5 + dy) * 8 + 5);
+        // weight set t + 1 (requested during tap row t - 1) must have landed before the barrier publishes it: every vector-memory
+        // operation of THIS tap row is younger -- the row request(s) at its head and this wave's one or two DMA pieces
+        if (!(DBG & 4) && !(DBG & 128)) {
+            if (mode == 1 && !last) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (mode != 0 && last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
+        C6_STAMP((kd * 5 + dy) * 8 + 6);
+        if (!(DBG & 8)) C3_BARRIER();
+        C6_STAMP((kd * 5 + dy) * 8 + 7);
     };
 
+    int wb0 = 0;                                      // buffer of weight set 5 kd
     for (int kd = 0; kd < 5; ++kd) {
         const bool last = kd == 4;
-        tap_row(kd, 0, 0, last, hvB, wB0, wB1, hvA, wA0, wA1);
-        tap_row(kd, 1, 0, last, hvA, wA0, wA1, hvB, wB0, wB1);
-        tap_row(kd, 2, 0, last, hvB, wB0, wB1, hvA, wA0, wA1);
-        tap_row(kd, 3, 1, last, hvA, wA0, wA1, hvB, wB0, wB1);
-        tap_row(kd, 4, 2, last, hvA, wA0, wA1, hvB, wB0, wB1);
-        if (!last) {
+        const int w1 = wb0 == 2 ? 0 : wb0 + 1, w2 = w1 == 2 ? 0 : w1 + 1;     // (wb0 + 1) % 3, (wb0 + 2) % 3
+        tap_row(kd, 0, 0, last, wb0, w2, hvB, hvA);
+        tap_row(kd, 1, 0, last, w1, wb0, hvA, hvB);
+        tap_row(kd, 2, 0, last, w2, w1, hvB, hvA);
+        tap_row(kd, 3, 1, last, wb0, w2, hvA, hvB);
+        tap_row(kd, 4, 2, last, w1, wb0, hvA, hvB);
+        wb0 = w2;                                     // (wb0 + 5) % 3
+        if (!last && !(DBG & 4)) {
             const int shn = (kd - 1) * H;
             pro_store(shn, 0, hvP0); pro_store(shn, 1, hvP1); pro_store(shn, 2, hvP2); pro_store(shn, 3, hvP3); pro_store(shn, 4, hvP4);
-            store_w(0, wP0, wP1);
             C3_BARRIER();
         }
     }
+    C6_STAMP(202);
     // ---- epilogue: the wave's [32 px][32 co] tile through LDS (the ring is free after the last barrier), 16-byte stores ----
     float* tb = reinterpret_cast<float*>(ring) + wid * (32 * OP);
 #pragma unroll
@@ -491,9 +531,19 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
         }
     }
     if (a.ymax) amax_publish_last(vmax, a.ymax, reinterpret_cast<unsigned*>(smem_c6 + AMAX_LDS));
+#ifdef SOL_C6_PROF
+    C6_STAMP(203);
+    if (lane == 0) c6_st[205] = (unsigned)__builtin_amdgcn_s_memrealtime();
+    if (g_c6_prof)
+        for (int i = lane; i < C6_NSTAMP; i += 64) g_c6_prof[((size_t)blockIdx.x * 12 + wid) * C6_NSTAMP + i] = c6_st[i];
+#endif
 }
 
-constexpr size_t c6_lds() { return (size_t)8 * 68 * 160 + 2 * (size_t)5 * 32 * 160 + 16; }
+#ifdef SOL_C6_PROF
+constexpr size_t c6_lds() { return (size_t)8 * 68 * 160 + 3 * (size_t)5 * 2 * 32 * 64 + 32 + 12 * C6_NSTAMP * 4; }
+#else
+constexpr size_t c6_lds() { return (size_t)8 * 68 * 160 + 3 * (size_t)5 * 2 * 32 * 64 + 16; }
+#endif
 
 // fp16 weight planes of all 125 taps with ONE power-of-two scale: header {2^shift_w, 2^-shift_w, 0, 0}, then
 // out[tap = (kd*5 + dy)*5 + dx][plane 2][o 32][chunk s][j] in the LDS image order of the 2-D kernels (k_pack_sh).
@@ -558,10 +608,14 @@ int sol_conv3d_sb_launch(hipStream_t s, const float* x, const float* wsh, const 
     a.wsh = wsh; a.xmax = x_absmax; a.ymax = y_absmax; a.tiles_x = 1;
     const int nrows = B * D * H;
     if (sol_opt().k3d_conv_rows6) {                   // six rows per workgroup, 32 x 32 tile per wave
-        static int rc6 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
-        SOL_REQUIRE(rc6 == 0, "hipFuncSetAttribute(k_conv3d_sb6) failed");
         const int nt6 = (nrows + 5) / 6, grid6 = (nt6 + 7) / 8 * 8;
-        SOL_LAUNCH(k_conv3d_sb6, dim3(grid6), dim3(768), c6_lds(), s, a, nrows, D);
+#define C6_DBG(N) case N: { static int rcd = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb6<N>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)rcd; \
+            SOL_LAUNCH(k_conv3d_sb6<N>, dim3(grid6), dim3(768), c6_lds(), s, a, nrows, D); break; }
+        switch (sol_opt().dbg_skip) { C6_DBG(512) default: break; }
+        if (sol_opt().dbg_skip) { SOL_LAUNCH_CHECK(); return SOL_OK; }
+        static int rc6 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb6<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
+        SOL_REQUIRE(rc6 == 0, "hipFuncSetAttribute(k_conv3d_sb6) failed");
+        SOL_LAUNCH(k_conv3d_sb6<0>, dim3(grid6), dim3(768), c6_lds(), s, a, nrows, D);
         SOL_LAUNCH_CHECK();
         return SOL_OK;
     }

@@ -58,6 +58,16 @@ for rows6 in (0, 1):                       # three-row / six-row Conv3D kernel; 
     torch.cuda.synchronize()
     out["cnn_ms_rows6_%d" % rows6] = e0.elapsed_time(e1) / steps
 out["cnn_ms"] = out["cnn_ms_rows6_1"]
+for dbg in (512,):          # timing experiments (results invalid): 1 no taps, 2 operands read once per tap row, 4 no staging, 8 no barrier
+    sol_amd._lib.set_option("dbg_skip", dbg)
+    ro.correction()
+    e0.record()
+    for _ in range(steps):
+        ro.correction()
+    e1.record()
+    torch.cuda.synchronize()
+    out["cnn_ms_dbg%d" % dbg] = e0.elapsed_time(e1) / steps
+sol_amd._lib.set_option("dbg_skip", 0)
 e0.record()
 s2 = st
 for _ in range(steps):
