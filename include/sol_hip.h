@@ -55,8 +55,8 @@ int sol_abi_sizes(int32_t* karman_cfg, int32_t* burgers_cfg, int32_t* train_cfg)
  *   k3d_conv_fused (1)  32 -> 32 Conv3D layers (W == 64, operand absmax given) as ONE launch that keeps its accumulators over all
  *                       125 taps (0: five passes of the 2-D kernel with the running sum in HBM); k3d_fused_tf (1): sine transforms
  *                       of the 3-D pressure solve as LDS-resident plane / slab kernels (0: batched GEMMs)
- *   k3d_conv_rows6 (1)  the one-launch Conv3D kernel with six output rows per workgroup and 32 px x 32 co wave tiles (a third
- *                       fewer LDS operand reads per MFMA); 0: three rows, 16 x 32 tiles
+ *   k3d_conv_rows (8)   rows per workgroup of the one-launch Conv3D kernel: 8 = one 64 px x 32 co tile per wave, eight waves (two per
+ *                       SIMD), operands prefetched one tap ahead; 6 = 32 x 32 tiles, twelve waves; 3 = 16 x 32 tiles, twelve waves
  *   k3d_tile (0)        1: karman-3d advection from LDS tiles that hold the full z column + halo; 0: wave-per-column gathers
  *                       straight from the L2-resident fields (measured 3x faster at batch 1-2: the tile form is instruction bound)
  *   bww_chunk (0), bww_side (1), streams (1), cpt (0), conv_split3 (0), dbg_skip (0), step_prof (0): experiments, debugging */

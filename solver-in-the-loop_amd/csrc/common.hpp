@@ -149,7 +149,7 @@ struct SolOptions {
                           //    measured equal to the per-layer launches end to end, kept as a verified experiment
     int graph_stream;     // 1: sol_train_graph_launch replays on an internal stream fenced by events against the caller's stream
     int k3d_fused_tf;     // 1 (default): the sine transforms of the karman-3d pressure solve as LDS-resident plane / column-slab kernels; 0: batched GEMMs
-    int k3d_conv_rows6;   // 1: the one-launch Conv3D kernel with six rows per workgroup and 32 x 32 wave tiles (k_conv3d_sb6); 0: three rows, 16 x 32 tiles
+    int k3d_conv_rows;    // rows per workgroup of the one-launch Conv3D kernel: 8 (k_conv3d_sb8, 64 x 32 wave tiles), 6 (k_conv3d_sb6, 32 x 32), 3 (k_conv3d_sb, 16 x 32)
     int k3d_conv_fused;   // 1 (default): 32 -> 32 Conv3D layers with W == 64 and a known operand absmax as ONE launch (conv3d_sb.hip); 0: five passes of the 2-D kernel
     int k3d_tile;         // 1: karman-3d advection from LDS tiles holding the full z column + halo; 0 (default, measured faster at B <= 2): wave-per-column gathers from global memory
 };

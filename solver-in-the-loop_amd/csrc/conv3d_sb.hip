@@ -545,6 +545,251 @@ constexpr size_t c6_lds() { return (size_t)8 * 68 * 160 + 3 * (size_t)5 * 2 * 32
 constexpr size_t c6_lds() { return (size_t)8 * 68 * 160 + 3 * (size_t)5 * 2 * 32 * 64 + 16; }
 #endif
 
+// ------------------------------------------------------------------------------------------------------------------------
+// k_conv3d_sb8: EIGHT rows per workgroup, one whole 64-pixel row x 32 channels per wave, eight waves (two per SIMD, 256 VGPRs).
+// What the phase stamps of k_conv3d_sb6 show (profiles/r03_conv3d_sb6_phase_timeline.txt): no single bound -- the operand
+// reads (LDS 55 % busy), the staging blocks and the per-tap-row barrier each cost 13-29 % because twelve waves in near lock
+// step leave the matrix pipe idle whenever two of a SIMD's three waves stage or wait.  This form lowers all three per MFMA:
+//   * a wave's weight fragments serve four pixel tiles: 12 ds_read_b128 (8 A + 4 B) per 24 MFMAs (0.5 per MFMA; 0.67 / 1.0 above);
+//   * the operands of tap dx + 1 are read before the MFMAs of tap dx (the registers are there at two waves per SIMD);
+//   * a weight set (LDS-DMA, three rotating buffers) and one new input row serve eight output rows; eight waves per barrier;
+//   * the always-zero halo pixels are written once, so a row is exactly one float4 per thread;
+//   * 8 192 rows / 8 = 1 024 workgroups = four full rounds of the 256 CUs at one simulation (1 366 six-row workgroups: 5.3).
+// Input rows rr = 0..11 of a depth slice (global row G0 - 2 + rr) live in 11 LDS slots in the XOR layout of the kernels above
+// (slot rr; row 11 reuses slot 0, dead since tap row 0): the A address of tap dx is one of five lane-dependent registers plus
+// immediates (pixel tile, plane).
+// ------------------------------------------------------------------------------------------------------------------------
+#ifndef C8_PREFETCH
+#define C8_PREFETCH 1
+#endif
+template <int DBG>
+__global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D) {
+    constexpr int OP = 32, HWP = 68;
+    constexpr int PLANE = HWP * 64, SLOT = 2 * PLANE, WPL = OP * 64, WSET = 5 * 2 * WPL;
+    constexpr int NSLOT = 11, ROWS = 8, NWB = 3;
+    constexpr int AMAX_LDS = NWB * WSET + NSLOT * SLOT;
+    extern __shared__ __align__(16) unsigned char smem_c8[];
+    if (threadIdx.x == 0) *reinterpret_cast<uint2*>(smem_c8 + AMAX_LDS) = make_uint2(0u, 0u);
+    const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = wid;                                // this wave's row of the workgroup
+    const int g = lane >> 4, li = lane & 15;
+    const int H = a.H;
+    constexpr int W = 64;
+    const int bx = xcd_tile(blockIdx.x, gridDim.x);
+    const int G0 = bx * ROWS;
+    const int gy = G0 + r;
+    const bool tvalid = gy < nrows;
+    const int plane = (tvalid ? gy : 0) / H, dpl = plane % D;
+    const int row_lo = plane * H, row_hi = row_lo + H;
+    unsigned char* Wt = smem_c8;                      // weight buffers first: LDS-DMA destinations (M0) below 64 KB
+    unsigned char* ring = smem_c8 + NWB * WSET;
+    const float4* gx = reinterpret_cast<const float4*>(a.x);
+    const unsigned char* gw = reinterpret_cast<const unsigned char*>(a.wsh) + 16;
+    float sa = 1.f, out_scale = 1.f;
+
+    // halo pixels hc = 0, 1, 66, 67 (x = -2, -1, 64, 65) of every slot and plane are zero for the whole launch
+    if (tid < NSLOT * 2 * 4 * 4) {
+        const int c = tid & 3, px = (tid >> 2) & 3, pl = (tid >> 4) & 1, sl = tid >> 5;
+        *reinterpret_cast<uint4*>(ring + sl * SLOT + pl * PLANE + (px < 2 ? px : 64 + px) * 64 + c * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    // a row = 64 pixels x 8 float4 = one item per thread: pixel x = tid >> 3 (LDS column hc = x + 2), channels 4 (tid & 7) ..
+    const int st_off = ((tid >> 3) + 2) * 64 + (((((tid & 7) >> 1) ^ swzb((tid >> 3) + 2)) << 4) | ((tid & 1) << 3));
+    auto row_in = [&](int gr) { return gr >= 0 && gr < nrows; };
+    auto load_row = [&](int gr) {
+        if (DBG & 64) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return gx[row_in(gr) ? (size_t)gr * (W * 8) + tid : (size_t)tid];
+    };
+    auto store_row = [&](int slot, int gr, float4 v) {
+        if (DBG & 64) return;
+        if (!row_in(gr)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned p0[2], p1[2];
+        split2h(v.x, v.y, sa, p0[0], p1[0]);
+        split2h(v.z, v.w, sa, p0[1], p1[1]);
+        unsigned char* q = ring + slot * SLOT + st_off;
+        *reinterpret_cast<uint2*>(q) = make_uint2(p0[0], p0[1]);
+        *reinterpret_cast<uint2*>(q + PLANE) = make_uint2(p1[0], p1[1]);
+    };
+    // LDS-DMA: 16 bytes per active lane from per-lane global addresses to dst + 16 * lane (conv5x5_sb.hip explains the form)
+    auto lds_dma16 = [&](const void* src, unsigned char* dst_wave_uniform) __attribute__((always_inline)) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst_wave_uniform);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(lo));
+    };
+    // weight set t (one tap row, 20 480 bytes) into buffer buf: wave w moves bytes [2560 w, 2560 (w + 1)) as 1024 + 1024 + 512
+    // (THREE vector-memory operations per wave and set: the count the waits below rely on)
+    auto dma_w = [&](int t, int buf) __attribute__((always_inline)) {
+        if (DBG & 32) return;
+        const unsigned char* src = gw + (size_t)t * WSET + wid * 2560 + lane * 16;
+        unsigned char* dst = Wt + buf * WSET + wid * 2560;
+        lds_dma16(src, dst);
+        lds_dma16(src + 1024, dst + 1024);
+        if (lane < 32) lds_dma16(src + 2048, dst + 2048);
+    };
+
+    float biasv[2];
+    float4 hvA = make_float4(0.f, 0.f, 0.f, 0.f), hvB = hvA;
+    float4 hvP[ROWS];
+    {
+        const int sh = -2 * H;
+        uint4 am = amax_load(a.xmax);
+        const float winv = reinterpret_cast<const float*>(a.wsh)[1];
+        {
+            const float* bp = a.bias ? a.bias : a.x;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) biasv[n] = bp[a.bias ? n * 16 + li : 0];
+        }
+#pragma unroll
+        for (int n = 0; n < ROWS; ++n) hvP[n] = load_row(G0 - 2 + n + sh);
+        hvA = load_row(G0 + 6 + sh);                  // rr = 8: the new row of tap row 1
+        __builtin_amdgcn_sched_barrier(0);
+        dma_w(0, 0);
+        dma_w(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        float sai;
+        amax_scale_of(am, sa, sai);
+        out_scale = sai * winv;
+#pragma unroll
+        for (int n = 0; n < ROWS; ++n) store_row(n, G0 - 2 + n + sh, hvP[n]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    C3_BARRIER();
+
+    f32x4 acc[4][2], acl[4][2];                       // [pixel tile][channel tile]
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) { acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; acl[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    int a_off[5];                                     // A: pixel tile 0 of tap dx (tile m: + 1024 m; lo plane: + PLANE)
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) a_off[dx] = (li + dx) * 64 + ((g ^ swzb(li + dx)) << 4);
+    const unsigned char* b_lane = Wt + li * 64 + ((g ^ swzb(li)) << 4);   // B: channel tile 0 (tile n: + 1024 n; tap dx: + dx * 2 * WPL)
+
+    // one tap row of depth slice kd (weight set t = 5 kd + dy in buffer wb).  MODE 0: request the row of tap row dy + 2 of this
+    // slice into hin; MODE 1 (dy == 3): request the next slice's first eight rows into hvP; MODE 2 (dy == 4): request the next
+    // slice's row rr = 8 into hin.  last: no next slice.  Between the taps: hout = row rr = dy + 8 of this slice goes to LDS
+    // (dy < 4) and weight set t + 2 is requested into buffer wb2 (free since the barrier of tap row t - 1).
+    auto tap_row = [&](const int kd, const int dy, const int mode, const bool last, const int wb, const int wb2, float4& hin,
+                       const float4& hout) __attribute__((always_inline)) {
+        const int sh = (kd - 2) * H, shn = (kd - 1) * H;
+        if (mode == 0) {
+            hin = load_row(G0 + dy + 7 + sh);         // rr = dy + 9
+        } else if (!last) {
+            if (mode == 1) {
+#pragma unroll
+                for (int n = 0; n < ROWS; ++n) hvP[n] = load_row(G0 - 2 + n + shn);
+            } else {
+                hin = load_row(G0 + 6 + shn);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int src = gy + sh + dy - 2;
+        const bool plane_ok = dpl + kd - 2 >= 0 && dpl + kd - 2 < D;
+        const bool has_taps = !(DBG & 1) && tvalid && plane_ok && src >= row_lo + sh && src < row_hi + sh;
+        const int rs = r + dy == NSLOT ? 0 : r + dy;
+        const unsigned char* hrow = ring + rs * SLOT;
+        const unsigned char* wbuf = b_lane + wb * WSET;
+        constexpr int PF = C8_PREFETCH;               // 1: the operands of tap dx + 1 are read before the MFMAs of tap dx
+        uint4 ao[PF + 1][4][2], bo[PF + 1][2][2];     // [buffer][tile][plane]
+        auto load_ab = [&](int dx, int q) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                bo[q][n][0] = *reinterpret_cast<const uint4*>(wbuf + dx * 2 * WPL + 1024 * n);
+                bo[q][n][1] = *reinterpret_cast<const uint4*>(wbuf + dx * 2 * WPL + 1024 * n + WPL);
+            }
+            const unsigned char* ap = hrow + a_off[dx];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                ao[q][m][0] = *reinterpret_cast<const uint4*>(ap + 1024 * m);
+                ao[q][m][1] = *reinterpret_cast<const uint4*>(ap + 1024 * m + PLANE);
+            }
+        };
+        auto taps = [&](const int dx0, const int dx1) __attribute__((always_inline)) {
+            if (PF && dx0 == 0) load_ab(0, 0);
+#pragma unroll
+            for (int dx = dx0; dx < dx1; ++dx) {
+                const int q = PF ? (dx & 1) : 0;
+                if (PF) { if (dx < 4) load_ab(dx + 1, q ^ 1); }
+                else load_ab(dx, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const f16x8 a1 = __builtin_bit_cast(f16x8, ao[q][m][0]), a2 = __builtin_bit_cast(f16x8, ao[q][m][1]);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const f16x8 b1 = __builtin_bit_cast(f16x8, bo[q][n][0]), b2 = __builtin_bit_cast(f16x8, bo[q][n][1]);
+                        acl[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, acl[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, acc[m][n], 0, 0, 0);
+                        acl[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, acl[m][n], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (has_taps) taps(0, 2);
+        if (dy < 4) { store_row(dy + 8 == NSLOT ? 0 : dy + 8, G0 + dy + 6 + sh, hout); __builtin_amdgcn_sched_barrier(0); }
+        if (has_taps) taps(2, 4);
+        const bool more_w = !last || dy < 3;          // set t + 2 exists (t + 2 <= 124)
+        if (more_w) { dma_w(kd * 5 + dy + 2, wb2); __builtin_amdgcn_sched_barrier(0); }
+        if (has_taps) taps(4, 5);
+        // weight set t + 1 (requested during tap row t - 1) must have landed before the barrier publishes it: every vector-memory
+        // operation of THIS tap row is younger -- the row request(s) at its head and this wave's three DMA pieces
+        if (mode == 1 && !last) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+        else if (mode != 0 && last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (!(DBG & 8)) C3_BARRIER();
+    };
+
+    int wb0 = 0;                                      // buffer of weight set 5 kd
+    for (int kd = 0; kd < 5; ++kd) {
+        const bool last = kd == 4;
+        const int w1 = wb0 == 2 ? 0 : wb0 + 1, w2 = w1 == 2 ? 0 : w1 + 1;     // (wb0 + 1) % 3, (wb0 + 2) % 3
+        tap_row(kd, 0, 0, last, wb0, w2, hvB, hvA);
+        tap_row(kd, 1, 0, last, w1, wb0, hvA, hvB);
+        tap_row(kd, 2, 0, last, w2, w1, hvB, hvA);
+        tap_row(kd, 3, 1, last, wb0, w2, hvA, hvB);
+        tap_row(kd, 4, 2, last, w1, wb0, hvA, hvB);
+        wb0 = w2;                                     // (wb0 + 5) % 3
+        if (!last) {
+            // slice boundary: every wave is past the barrier of tap row 4, the eight slots are free; the rows were requested two tap rows ago
+            const int shn = (kd - 1) * H;
+#pragma unroll
+            for (int n = 0; n < ROWS; ++n) store_row(n, G0 - 2 + n + shn, hvP[n]);
+            C3_BARRIER();
+        }
+    }
+    // ---- epilogue: the wave's [64 px][32 co] tile through LDS (the ring is free after the last barrier), 16-byte stores ----
+    float* tb = reinterpret_cast<float*>(ring) + wid * (64 * OP);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const float bias = a.bias ? biasv[n] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                tb[(16 * m + 4 * g + q) * OP + n * 16 + li] = (acc[m][n][q] + acl[m][n][q] * (1.f / 2048.f)) * out_scale + bias;
+        }
+    float vmax = 0.f;
+    if (tvalid) {
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {                 // 512 float4 per wave
+            const int e = lane + n * 64, px = e >> 3, c4 = e & 7;
+            float4 v = *reinterpret_cast<const float4*>(&tb[px * OP + c4 * 4]);
+            const size_t o4 = ((size_t)gy * W + px) * (OP / 4) + c4;
+            if (a.res) { const float4 q = reinterpret_cast<const float4*>(a.res)[o4]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+            if (a.epi == SOL_EPI_LRELU) {
+                v.x = v.x > 0.f ? v.x : a.slope * v.x; v.y = v.y > 0.f ? v.y : a.slope * v.y;
+                v.z = v.z > 0.f ? v.z : a.slope * v.z; v.w = v.w > 0.f ? v.w : a.slope * v.w;
+            }
+            vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            reinterpret_cast<float4*>(a.y)[o4] = v;
+        }
+    }
+    if (a.ymax) amax_publish_last(vmax, a.ymax, reinterpret_cast<unsigned*>(smem_c8 + AMAX_LDS));
+}
+
+constexpr size_t c8_lds() { return (size_t)3 * 5 * 2 * 32 * 64 + (size_t)11 * 2 * 68 * 64 + 16; }
+
 // fp16 weight planes of all 125 taps with ONE power-of-two scale: header {2^shift_w, 2^-shift_w, 0, 0}, then
 // out[tap = (kd*5 + dy)*5 + dx][plane 2][o 32][chunk s][j] in the LDS image order of the 2-D kernels (k_pack_sh).
 // mode SOL_CONV_BWD_DATA: the flipped kernel with swapped channel axes (w is the FORWARD kernel [125][cout_run][cin_run]).
@@ -607,12 +852,16 @@ int sol_conv3d_sb_launch(hipStream_t s, const float* x, const float* wsh, const 
     a.x = x; a.bias = bias; a.res = residual; a.y = y; a.B = B * D; a.H = H; a.W = 64; a.CO = 32; a.epi = epilogue; a.slope = slope;
     a.wsh = wsh; a.xmax = x_absmax; a.ymax = y_absmax; a.tiles_x = 1;
     const int nrows = B * D * H;
-    if (sol_opt().k3d_conv_rows6) {                   // six rows per workgroup, 32 x 32 tile per wave
+    if (sol_opt().k3d_conv_rows == 8) {               // eight rows per workgroup, 64 x 32 tile per wave, two waves per SIMD
+        static int rc8 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb8<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
+        SOL_REQUIRE(rc8 == 0, "hipFuncSetAttribute(k_conv3d_sb8) failed");
+        const int nt8 = (nrows + 7) / 8, grid8 = (nt8 + 7) / 8 * 8;
+        SOL_LAUNCH(k_conv3d_sb8<0>, dim3(grid8), dim3(512), c8_lds(), s, a, nrows, D);
+        SOL_LAUNCH_CHECK();
+        return SOL_OK;
+    }
+    if (sol_opt().k3d_conv_rows == 6) {               // six rows per workgroup, 32 x 32 tile per wave
         const int nt6 = (nrows + 5) / 6, grid6 = (nt6 + 7) / 8 * 8;
-#define C6_DBG(N) case N: { static int rcd = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb6<N>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)rcd; \
-            SOL_LAUNCH(k_conv3d_sb6<N>, dim3(grid6), dim3(768), c6_lds(), s, a, nrows, D); break; }
-        switch (sol_opt().dbg_skip) { C6_DBG(512) default: break; }
-        if (sol_opt().dbg_skip) { SOL_LAUNCH_CHECK(); return SOL_OK; }
         static int rc6 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb6<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
         SOL_REQUIRE(rc6 == 0, "hipFuncSetAttribute(k_conv3d_sb6) failed");
         SOL_LAUNCH(k_conv3d_sb6<0>, dim3(grid6), dim3(768), c6_lds(), s, a, nrows, D);

@@ -118,7 +118,7 @@ def _oracle_conv(x, w, b, res, lrelu, slope=0.3):
     ((1, 4, 64, 64), 32, 32, True, True),          # W = 64: the split fp16 / bf16 MFMA kernels (with absmax: the one-launch kernel)
     ((2, 6, 64, 64), 32, 32, False, True),         # two simulations, six planes: slice validity at both ends and across samples
     ((2, 3, 20, 64), 32, 32, True, True),          # H not a multiple of the rows per workgroup: tiles span planes and samples
-    ((1, 7, 5, 64), 32, 32, False, False),         # H smaller than a workgroup's six rows
+    ((1, 7, 5, 64), 32, 32, False, False),         # H smaller than a workgroup's rows
     ((1, 3, 64, 64), 4, 32, False, True),
     ((1, 3, 64, 64), 32, 3, False, False),
 ])
@@ -151,13 +151,14 @@ def test_conv3d_against_oracle(shape, cin, cout, res, lrelu):
             finally:
                 sol_amd._lib.set_option("k3d_conv_fused", 1)
             assert not torch.equal(y, y5) and rel(y, y5) < 1e-6
-            # ... and so must the three-rows-per-workgroup form of the one-launch kernel (same tap order: same bits)
-            sol_amd._lib.set_option("k3d_conv_rows6", 0)
-            try:
-                y3 = k3.conv3d(xd, packed, f32(b), f32(r) if res else None, cout, lrelu, 0.3, amax, None)
-            finally:
-                sol_amd._lib.set_option("k3d_conv_rows6", 1)
-            assert rel(y, y3) < 1e-6, rel(y, y3)
+            # ... and so must the three- and six-rows-per-workgroup forms of the one-launch kernel (default: eight rows)
+            for rows in (3, 6):
+                sol_amd._lib.set_option("k3d_conv_rows", rows)
+                try:
+                    y3 = k3.conv3d(xd, packed, f32(b), f32(r) if res else None, cout, lrelu, 0.3, amax, None)
+                finally:
+                    sol_amd._lib.set_option("k3d_conv_rows", 8)
+                assert rel(y, y3) < 1e-6, (rows, rel(y, y3))
 
 
 def test_network_and_rollout_against_golden(fixture3d, scene_small):

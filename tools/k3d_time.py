@@ -48,26 +48,16 @@ for tile, ftf in ((1, 1), (0, 1), (0, 0)):
 sol_amd._lib.set_option("k3d_tile", 0)
 sol_amd._lib.set_option("k3d_fused_tf", 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-for rows6 in (0, 1):                       # three-row / six-row Conv3D kernel; the default (1) is timed last and stays on
-    sol_amd._lib.set_option("k3d_conv_rows6", rows6)
+for rows in (3, 6, 8):                     # rows per workgroup of the one-launch Conv3D kernel; the default (8) is timed last and stays on
+    sol_amd._lib.set_option("k3d_conv_rows", rows)
     ro.correction()
     e0.record()
     for _ in range(steps):
         ro.correction()
     e1.record()
     torch.cuda.synchronize()
-    out["cnn_ms_rows6_%d" % rows6] = e0.elapsed_time(e1) / steps
-out["cnn_ms"] = out["cnn_ms_rows6_1"]
-for dbg in (512,):          # timing experiments (results invalid): 1 no taps, 2 operands read once per tap row, 4 no staging, 8 no barrier
-    sol_amd._lib.set_option("dbg_skip", dbg)
-    ro.correction()
-    e0.record()
-    for _ in range(steps):
-        ro.correction()
-    e1.record()
-    torch.cuda.synchronize()
-    out["cnn_ms_dbg%d" % dbg] = e0.elapsed_time(e1) / steps
-sol_amd._lib.set_option("dbg_skip", 0)
+    out["cnn_ms_rows%d" % rows] = e0.elapsed_time(e1) / steps
+out["cnn_ms"] = out["cnn_ms_rows8"]
 e0.record()
 s2 = st
 for _ in range(steps):
