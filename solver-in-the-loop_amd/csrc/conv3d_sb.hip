@@ -601,10 +601,10 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
     };
     auto store_row = [&](int slot, int gr, float4 v) {
         if (DBG & 64) return;
-        if (!row_in(gr)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float sc = row_in(gr) ? sa : 0.f;       // rows outside the tensor: the (finite) clamped load times zero
         unsigned p0[2], p1[2];
-        split2h(v.x, v.y, sa, p0[0], p1[0]);
-        split2h(v.z, v.w, sa, p0[1], p1[1]);
+        split2h(v.x, v.y, sc, p0[0], p1[0]);
+        split2h(v.z, v.w, sc, p0[1], p1[1]);
         unsigned char* q = ring + slot * SLOT + st_off;
         *reinterpret_cast<uint2*>(q) = make_uint2(p0[0], p0[1]);
         *reinterpret_cast<uint2*>(q + PLANE) = make_uint2(p1[0], p1[1]);
@@ -629,7 +629,7 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
 
     float biasv[2];
     float4 hvA = make_float4(0.f, 0.f, 0.f, 0.f), hvB = hvA;
-    float4 hvP[ROWS];
+    float4 hvP[ROWS + 1];
     {
         const int sh = -2 * H;
         uint4 am = amax_load(a.xmax);
@@ -640,8 +640,8 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
             for (int n = 0; n < 2; ++n) biasv[n] = bp[a.bias ? n * 16 + li : 0];
         }
 #pragma unroll
-        for (int n = 0; n < ROWS; ++n) hvP[n] = load_row(G0 - 2 + n + sh);
-        hvA = load_row(G0 + 6 + sh);                  // rr = 8: the new row of tap row 1
+        for (int n = 0; n <= ROWS; ++n) hvP[n] = load_row(G0 - 2 + n + sh);     // rr = 0..8: the rows of tap rows 0 and 1
+        hvA = load_row(G0 + 7 + sh);                  // rr = 9: the new row of tap row 2
         __builtin_amdgcn_sched_barrier(0);
         dma_w(0, 0);
         dma_w(1, 1);
@@ -650,7 +650,7 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
         amax_scale_of(am, sa, sai);
         out_scale = sai * winv;
 #pragma unroll
-        for (int n = 0; n < ROWS; ++n) store_row(n, G0 - 2 + n + sh, hvP[n]);
+        for (int n = 0; n <= ROWS; ++n) store_row(n, G0 - 2 + n + sh, hvP[n]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     C3_BARRIER();
@@ -664,40 +664,48 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
 #pragma unroll
     for (int dx = 0; dx < 5; ++dx) a_off[dx] = (li + dx) * 64 + ((g ^ swzb(li + dx)) << 4);
     const unsigned char* b_lane = Wt + li * 64 + ((g ^ swzb(li)) << 4);   // B: channel tile 0 (tile n: + 1024 n; tap dx: + dx * 2 * WPL)
+    uint4 ao[2][4][2], bo[2][2][2];                   // operands, [buffer][tile][plane]: tap (dy, dx) uses buffer (dy + dx) & 1
+    const bool early = wid >= 4;                      // waves 4..7 (the SIMD partners of waves 0..3) stage at the head of a tap row
 
-    // one tap row of depth slice kd (weight set t = 5 kd + dy in buffer wb).  MODE 0: request the row of tap row dy + 2 of this
-    // slice into hin; MODE 1 (dy == 3): request the next slice's first eight rows into hvP; MODE 2 (dy == 4): request the next
-    // slice's row rr = 8 into hin.  last: no next slice.  Between the taps: hout = row rr = dy + 8 of this slice goes to LDS
-    // (dy < 4) and weight set t + 2 is requested into buffer wb2 (free since the barrier of tap row t - 1).
-    auto tap_row = [&](const int kd, const int dy, const int mode, const bool last, const int wb, const int wb2, float4& hin,
-                       const float4& hout) __attribute__((always_inline)) {
+    // One tap row of depth slice kd (weight set t = 5 kd + dy in buffer wb).
+    // Staging block (once per tap row; waves 4..7 at the head, waves 0..3 after tap 1, so that the two waves of a SIMD never
+    // stage at the same time): the row of tap row dy + 2 (requested a tap row ago) goes to LDS, the row after it is requested,
+    // weight set t + 2 is requested into buffer wb2 (free since the barrier of tap row t - 1).  dy == 3 / 4 request the next
+    // slice's rows rr = 0..8 / rr = 9 instead (last: no next slice).
+    // Before tap 4 the A fragments of tap (dy + 1, 0) are read: every row of the next tap row was published a barrier ago
+    // (rows are staged TWO tap rows ahead), so after the barrier only the four B reads stand before the first MFMA.
+    auto tap_row = [&](const int kd, const int dy, const bool last, const int wb, const int wb2) __attribute__((always_inline)) {
         const int sh = (kd - 2) * H, shn = (kd - 1) * H;
-        if (mode == 0) {
-            hin = load_row(G0 + dy + 7 + sh);         // rr = dy + 9
-        } else if (!last) {
-            if (mode == 1) {
+        const bool more_w = !last || dy < 3;          // set t + 2 exists (t + 2 <= 124)
+        auto block = [&]() __attribute__((always_inline)) {
+            if (dy == 0) { store_row(9, G0 + 7 + sh, hvA); hvB = load_row(G0 + 8 + sh); }
+            if (dy == 1) { store_row(10, G0 + 8 + sh, hvB); hvA = load_row(G0 + 9 + sh); }
+            if (dy == 2) { store_row(0, G0 + 9 + sh, hvA); }                      // rr = 11 in slot 0 (row 0: dead since tap row 0)
+            if (dy == 3 && !last) {
 #pragma unroll
-                for (int n = 0; n < ROWS; ++n) hvP[n] = load_row(G0 - 2 + n + shn);
-            } else {
-                hin = load_row(G0 + 6 + shn);
+                for (int n = 0; n <= ROWS; ++n) hvP[n] = load_row(G0 - 2 + n + shn);
             }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            if (dy == 4 && !last) hvA = load_row(G0 + 7 + shn);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more_w) dma_w(kd * 5 + dy + 2, wb2);
+            __builtin_amdgcn_sched_barrier(0);
+        };
         const int src = gy + sh + dy - 2;
         const bool plane_ok = dpl + kd - 2 >= 0 && dpl + kd - 2 < D;
         const bool has_taps = !(DBG & 1) && tvalid && plane_ok && src >= row_lo + sh && src < row_hi + sh;
-        const int rs = r + dy == NSLOT ? 0 : r + dy;
+        const int rs = r + dy == NSLOT ? 0 : r + dy, rsn = r + dy + 1 == NSLOT ? 0 : r + dy + 1;
         const unsigned char* hrow = ring + rs * SLOT;
+        const unsigned char* hnext = ring + rsn * SLOT;
         const unsigned char* wbuf = b_lane + wb * WSET;
-        constexpr int PF = C8_PREFETCH;               // 1: the operands of tap dx + 1 are read before the MFMAs of tap dx
-        uint4 ao[PF + 1][4][2], bo[PF + 1][2][2];     // [buffer][tile][plane]
-        auto load_ab = [&](int dx, int q) {
+        auto load_b = [&](int dx, int q) {
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 bo[q][n][0] = *reinterpret_cast<const uint4*>(wbuf + dx * 2 * WPL + 1024 * n);
                 bo[q][n][1] = *reinterpret_cast<const uint4*>(wbuf + dx * 2 * WPL + 1024 * n + WPL);
             }
-            const unsigned char* ap = hrow + a_off[dx];
+        };
+        auto load_a = [&](const unsigned char* row, int dx, int q) {
+            const unsigned char* ap = row + a_off[dx];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 ao[q][m][0] = *reinterpret_cast<const uint4*>(ap + 1024 * m);
@@ -705,12 +713,11 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
             }
         };
         auto taps = [&](const int dx0, const int dx1) __attribute__((always_inline)) {
-            if (PF && dx0 == 0) load_ab(0, 0);
 #pragma unroll
             for (int dx = dx0; dx < dx1; ++dx) {
-                const int q = PF ? (dx & 1) : 0;
-                if (PF) { if (dx < 4) load_ab(dx + 1, q ^ 1); }
-                else load_ab(dx, 0);
+                const int q = (dy + dx) & 1;
+                if (dx == 0) { load_b(0, q); if (dy == 0) load_a(hrow, 0, q); }     // A of tap 0: read before the last barrier (dy > 0)
+                if (dx < 4) { load_b(dx + 1, q ^ 1); load_a(hrow, dx + 1, q ^ 1); }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
@@ -726,35 +733,41 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
+        if (early) block();
         if (has_taps) taps(0, 2);
-        if (dy < 4) { store_row(dy + 8 == NSLOT ? 0 : dy + 8, G0 + dy + 6 + sh, hout); __builtin_amdgcn_sched_barrier(0); }
+        if (!early) block();
         if (has_taps) taps(2, 4);
-        const bool more_w = !last || dy < 3;          // set t + 2 exists (t + 2 <= 124)
-        if (more_w) { dma_w(kd * 5 + dy + 2, wb2); __builtin_amdgcn_sched_barrier(0); }
+        if (dy < 4) { load_a(hnext, 0, (dy + 1) & 1); __builtin_amdgcn_sched_barrier(0); }
         if (has_taps) taps(4, 5);
-        // weight set t + 1 (requested during tap row t - 1) must have landed before the barrier publishes it: every vector-memory
-        // operation of THIS tap row is younger -- the row request(s) at its head and this wave's three DMA pieces
-        if (mode == 1 && !last) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-        else if (mode != 0 && last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Weight set t + 1 (requested during tap row t - 1) must have landed before the barrier publishes it.  Younger vector-memory
+        // operations of this wave: the row requests of this tap row's staging block and its three DMA pieces.
+        if (dy < 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (dy == 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (dy == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        if (!(DBG & 8)) C3_BARRIER();
+        if (!(DBG & 8)) {
+            // LDS operations complete in order: lgkmcnt(8) leaves the eight prefetched A reads in flight and drains the staging stores
+            if (dy < 4) asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
+            else C3_BARRIER();
+        }
     };
 
     int wb0 = 0;                                      // buffer of weight set 5 kd
     for (int kd = 0; kd < 5; ++kd) {
         const bool last = kd == 4;
         const int w1 = wb0 == 2 ? 0 : wb0 + 1, w2 = w1 == 2 ? 0 : w1 + 1;     // (wb0 + 1) % 3, (wb0 + 2) % 3
-        tap_row(kd, 0, 0, last, wb0, w2, hvB, hvA);
-        tap_row(kd, 1, 0, last, w1, wb0, hvA, hvB);
-        tap_row(kd, 2, 0, last, w2, w1, hvB, hvA);
-        tap_row(kd, 3, 1, last, wb0, w2, hvA, hvB);
-        tap_row(kd, 4, 2, last, w1, wb0, hvA, hvB);
+        tap_row(kd, 0, last, wb0, w2);
+        tap_row(kd, 1, last, w1, wb0);
+        tap_row(kd, 2, last, w2, w1);
+        tap_row(kd, 3, last, wb0, w2);
+        tap_row(kd, 4, last, w1, wb0);
         wb0 = w2;                                     // (wb0 + 5) % 3
         if (!last) {
-            // slice boundary: every wave is past the barrier of tap row 4, the eight slots are free; the rows were requested two tap rows ago
+            // slice boundary: every wave is past the barrier of tap row 4, slots 0..8 are free; the rows were requested two tap rows ago
             const int shn = (kd - 1) * H;
 #pragma unroll
-            for (int n = 0; n < ROWS; ++n) store_row(n, G0 - 2 + n + shn, hvP[n]);
+            for (int n = 0; n <= ROWS; ++n) store_row(n, G0 - 2 + n + shn, hvP[n]);
             C3_BARRIER();
         }
     }
@@ -856,6 +869,10 @@ int sol_conv3d_sb_launch(hipStream_t s, const float* x, const float* wsh, const 
         static int rc8 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb8<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
         SOL_REQUIRE(rc8 == 0, "hipFuncSetAttribute(k_conv3d_sb8) failed");
         const int nt8 = (nrows + 7) / 8, grid8 = (nt8 + 7) / 8 * 8;
+#define C8_DBG(N) case N: { static int rcd = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb8<N>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)rcd; \
+            SOL_LAUNCH(k_conv3d_sb8<N>, dim3(grid8), dim3(512), c8_lds(), s, a, nrows, D); break; }
+        switch (sol_opt().dbg_skip) { C8_DBG(1) C8_DBG(8) C8_DBG(32) C8_DBG(64) C8_DBG(96) C8_DBG(104) default: break; }
+        if (sol_opt().dbg_skip) { SOL_LAUNCH_CHECK(); return SOL_OK; }
         SOL_LAUNCH(k_conv3d_sb8<0>, dim3(grid8), dim3(512), c8_lds(), s, a, nrows, D);
         SOL_LAUNCH_CHECK();
         return SOL_OK;

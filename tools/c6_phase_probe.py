@@ -19,7 +19,7 @@ if "--build" in sys.argv:
     objdir = os.path.join(PKG, "build")
     hipcc = b._hipcc()
     obj = os.path.join(objdir, "conv3d_sb_prof.o")
-    subprocess.check_call([hipcc] + b.FLAGS + ["-DSOL_C6_PROF", "-c", os.path.join(PKG, "csrc", "conv3d_sb.hip"), "-o", obj])
+    subprocess.check_call([hipcc] + b.FLAGS + b.EXTRA.get("conv3d_sb.hip", []) + ["-DSOL_C6_PROF", "-c", os.path.join(PKG, "csrc", "conv3d_sb.hip"), "-o", obj])
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in b.SOURCES if s != "conv3d_sb.hip"] + [obj]
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", PROF_LIB])
     print(PROF_LIB)
