@@ -277,10 +277,6 @@ extern "C" int sol_c6_prof_set(unsigned* buf) { return hipMemcpyToSymbol(HIP_SYM
 #else
 #define C6_STAMP(i) do { } while (0)
 #endif
-#ifndef C6_PREFETCH
-#define C6_PREFETCH 0
-#endif
-template <int DBG>
 __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D) {
     constexpr int OP = 32, HWP = 68;
     // Input rows in LDS with a PADDED pixel stride instead of the XOR swizzle of the kernels above: a pixel is 160 bytes = 64 B hi
@@ -322,12 +318,10 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
         return e < HWP * 8 && gr >= 0 && gr < nrows && xx >= 0 && xx < W;
     };
     auto load_row = [&](int gr, int e) {
-        if (DBG & 64) return make_float4(0.f, 0.f, 0.f, 0.f);
         const int xx = (e >> 3) - 2;
         return gx[row_ok(gr, e) ? ((size_t)gr * W + xx) * 8 + (e & 7) : (size_t)0];
     };
     auto store_row = [&](int slot, int gr, float4 v, int e) {
-        if (DBG & 64) return;
         if (!row_ok(gr, e)) v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e < HWP * 8) {
             const int hc = e >> 3, c4 = e & 7;
@@ -348,7 +342,6 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
     };
     // weight set t (one tap row: 20 one-KB pieces) into buffer buf: piece wid by every wave, piece wid + 12 by waves 0..7
     auto dma_w = [&](int t, int buf) __attribute__((always_inline)) {
-        if (DBG & 32) return;
         const unsigned char* src = gw + (size_t)t * WSET + lane * 16;
         unsigned char* dst = Wt + buf * WSET;
         lds_dma16(src + wid * 1024, dst + wid * 1024);
@@ -408,8 +401,7 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
                        const float4& hout) __attribute__((always_inline)) {
         const int sh = (kd - 2) * H, shn = (kd - 1) * H;
         C6_STAMP((kd * 5 + dy) * 8 + 0);
-        if (DBG & 4) {
-        } else if (mode == 0) {
+        if (mode == 0) {
             hin = load_row(G0 + dy + 5 + sh, tid);    // rr = dy + 7: the new row of tap row dy + 2
         } else if (!last) {
             if (mode == 1) {
@@ -421,40 +413,33 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
         __builtin_amdgcn_sched_barrier(0);
         const int src = gy + sh + dy - 2;
         const bool plane_ok = dpl + kd - 2 >= 0 && dpl + kd - 2 < D;
-        const bool has_taps = !(DBG & 1) && tvalid && plane_ok && src >= row_lo + sh && src < row_hi + sh;
+        const bool has_taps = tvalid && plane_ok && src >= row_lo + sh && src < row_hi + sh;
         const unsigned char* hrow = ring + ((r + dy) & 7) * SLOT + a_lane;
         const unsigned char* wbuf = b_lane + wb * WSET;
         // operands are NOT double buffered across taps (the registers are not there at three waves per SIMD); three waves per
         // SIMD cover the LDS latency
-        constexpr int PF = (DBG & 512) ? 1 : C6_PREFETCH;   // 1: operands of tap dx + 1 are read before the MFMAs of tap dx
-        uint4 ao[PF + 1][2][2], bo[PF + 1][2][2];     // [buffer][tile][plane]
-        auto load_ab = [&](int dx, int q) {
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                bo[q][n][0] = *reinterpret_cast<const uint4*>(wbuf + dx * 2 * WPL + 16 * n * 64);
-                bo[q][n][1] = *reinterpret_cast<const uint4*>(wbuf + dx * 2 * WPL + 16 * n * 64 + WPL);
-            }
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                ao[q][m][0] = *reinterpret_cast<const uint4*>(hrow + (16 * m + dx) * PS);
-                ao[q][m][1] = *reinterpret_cast<const uint4*>(hrow + (16 * m + dx) * PS + 64);
-            }
-        };
+        // operands are not double buffered across taps (measured: no gain; three waves per SIMD cover the LDS latency)
+        uint4 ao[2][2], bo[2][2];                     // [tile][plane]
         auto taps = [&](const int dx0, const int dx1) __attribute__((always_inline)) {
-            if (PF && dx0 == 0) load_ab(0, 0);
 #pragma unroll
             for (int dx = dx0; dx < dx1; ++dx) {
-                const int q = PF ? (dx & 1) : 0;
-                if (PF) { if (dx < 4) load_ab(dx + 1, q ^ 1); }
-                else if (!(DBG & 2) || dx == 0) load_ab(dx, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (PF) { if (dx < 4) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    bo[n][0] = *reinterpret_cast<const uint4*>(wbuf + dx * 2 * WPL + 16 * n * 64);
+                    bo[n][1] = *reinterpret_cast<const uint4*>(wbuf + dx * 2 * WPL + 16 * n * 64 + WPL);
+                }
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const f16x8 a1 = __builtin_bit_cast(f16x8, ao[q][m][0]), a2 = __builtin_bit_cast(f16x8, ao[q][m][1]);
+                    ao[m][0] = *reinterpret_cast<const uint4*>(hrow + (16 * m + dx) * PS);
+                    ao[m][1] = *reinterpret_cast<const uint4*>(hrow + (16 * m + dx) * PS + 64);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const f16x8 a1 = __builtin_bit_cast(f16x8, ao[m][0]), a2 = __builtin_bit_cast(f16x8, ao[m][1]);
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
-                        const f16x8 b1 = __builtin_bit_cast(f16x8, bo[q][n][0]), b2 = __builtin_bit_cast(f16x8, bo[q][n][1]);
+                        const f16x8 b1 = __builtin_bit_cast(f16x8, bo[n][0]), b2 = __builtin_bit_cast(f16x8, bo[n][1]);
                         acl[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, acl[m][n], 0, 0, 0);
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, acc[m][n], 0, 0, 0);
                         acl[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, acl[m][n], 0, 0, 0);
@@ -465,24 +450,22 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
         };
         if (has_taps) taps(0, 2);
         C6_STAMP((kd * 5 + dy) * 8 + 1);
-        if (dy < 4 && !(DBG & 4)) { store_row((dy + 6) & 7, G0 + dy + 4 + sh, hout, tid); __builtin_amdgcn_sched_barrier(0); }
+        if (dy < 4) { store_row((dy + 6) & 7, G0 + dy + 4 + sh, hout, tid); __builtin_amdgcn_sched_barrier(0); }
         C6_STAMP((kd * 5 + dy) * 8 + 2);
         if (has_taps) taps(2, 4);
         C6_STAMP((kd * 5 + dy) * 8 + 3);
         const bool more_w = !last || dy < 3;          // set t + 2 exists (t + 2 <= 124)
-        if (more_w && !(DBG & 4)) { dma_w(kd * 5 + dy + 2, wb2); __builtin_amdgcn_sched_barrier(0); }
+        if (more_w) { dma_w(kd * 5 + dy + 2, wb2); __builtin_amdgcn_sched_barrier(0); }
         C6_STAMP((kd * 5 + dy) * 8 + 4);
         if (has_taps) taps(4, 5);
         C6_STAMP((kd * 5 + dy) * 8 + 5);
         // weight set t + 1 (requested during tap row t - 1) must have landed before the barrier publishes it: every vector-memory
         // operation of THIS tap row is younger -- the row request(s) at its head and this wave's one or two DMA pieces
-        if (!(DBG & 4) && !(DBG & 128)) {
-            if (mode == 1 && !last) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (mode != 0 && last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        }
+        if (mode == 1 && !last) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (mode != 0 && last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         C6_STAMP((kd * 5 + dy) * 8 + 6);
-        if (!(DBG & 8)) C3_BARRIER();
+        C3_BARRIER();
         C6_STAMP((kd * 5 + dy) * 8 + 7);
     };
 
@@ -496,7 +479,7 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
         tap_row(kd, 3, 1, last, wb0, w2, hvA, hvB);
         tap_row(kd, 4, 2, last, w1, wb0, hvA, hvB);
         wb0 = w2;                                     // (wb0 + 5) % 3
-        if (!last && !(DBG & 4)) {
+        if (!last) {
             const int shn = (kd - 1) * H;
             pro_store(shn, 0, hvP0); pro_store(shn, 1, hvP1); pro_store(shn, 2, hvP2); pro_store(shn, 3, hvP3); pro_store(shn, 4, hvP4);
             C3_BARRIER();
@@ -547,21 +530,26 @@ constexpr size_t c6_lds() { return (size_t)8 * 68 * 160 + 3 * (size_t)5 * 2 * 32
 
 // ------------------------------------------------------------------------------------------------------------------------
 // k_conv3d_sb8: EIGHT rows per workgroup, one whole 64-pixel row x 32 channels per wave, eight waves (two per SIMD, 256 VGPRs).
-// What the phase stamps of k_conv3d_sb6 show (profiles/r03_conv3d_sb6_phase_timeline.txt): no single bound -- the operand
-// reads (LDS 55 % busy), the staging blocks and the per-tap-row barrier each cost 13-29 % because twelve waves in near lock
-// step leave the matrix pipe idle whenever two of a SIMD's three waves stage or wait.  This form lowers all three per MFMA:
+// What the phase stamps and the timing experiments on k_conv3d_sb6 show (profiles/r03_conv3d_sb6_phase_timeline.txt):
+// no single bound -- operand reads (LDS 55 % busy), the staging blocks and the per-tap-row barrier each cost 13-29 %, and
+// removing any one of them alone recovers only its share.  This form lowers all three per MFMA:
 //   * a wave's weight fragments serve four pixel tiles: 12 ds_read_b128 (8 A + 4 B) per 24 MFMAs (0.5 per MFMA; 0.67 / 1.0 above);
-//   * the operands of tap dx + 1 are read before the MFMAs of tap dx (the registers are there at two waves per SIMD);
 //   * a weight set (LDS-DMA, three rotating buffers) and one new input row serve eight output rows; eight waves per barrier;
 //   * the always-zero halo pixels are written once, so a row is exactly one float4 per thread;
-//   * 8 192 rows / 8 = 1 024 workgroups = four full rounds of the 256 CUs at one simulation (1 366 six-row workgroups: 5.3).
+//   * 8 192 rows / 8 = 1 024 workgroups = four full rounds of the 256 CUs at one simulation (1 366 six-row workgroups: 5.3);
+//   * the operands of tap dx + 1 are read before the MFMAs of tap dx, and the A fragments of the NEXT tap row before the barrier
+//     (rows are staged two tap rows ahead, so they are published a barrier early) -- the registers are there at two waves per SIMD.
+// Measured at 128 x 64 x 64 (per launch): 279 us against 334 (six rows) and 412 (three rows); the tap loop alone (no staging,
+// no barriers) runs at the matrix pipe's pace (198 us = 24.6 M MFMAs x 16 cycles / 1024 SIMDs at the 1.95 GHz the chip holds
+// under this load).  What is left: row staging 61 us (29 the loads, 35 the VGPR -> LDS writes; the fp16 split itself is free
+// once the SLP vectoriser is kept from packing it into v_pk_*_f32), weight DMA 32 us, barriers 40 us.  Neutral when tried:
+// staggering the staging block between the two waves of a SIMD (kept), reading the next tap row's B fragments before the
+// barrier as well, waiting for a weight set in the tap row that requests it.
 // Input rows rr = 0..11 of a depth slice (global row G0 - 2 + rr) live in 11 LDS slots in the XOR layout of the kernels above
 // (slot rr; row 11 reuses slot 0, dead since tap row 0): the A address of tap dx is one of five lane-dependent registers plus
 // immediates (pixel tile, plane).
+// DBG (option dbg_skip, timing experiments only, results invalid): 1 no taps, 8 no barriers, 32 no weight DMA, 64 no rows.
 // ------------------------------------------------------------------------------------------------------------------------
-#ifndef C8_PREFETCH
-#define C8_PREFETCH 1
-#endif
 template <int DBG>
 __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D) {
     constexpr int OP = 32, HWP = 68;
@@ -737,7 +725,10 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
         if (has_taps) taps(0, 2);
         if (!early) block();
         if (has_taps) taps(2, 4);
-        if (dy < 4) { load_a(hnext, 0, (dy + 1) & 1); __builtin_amdgcn_sched_barrier(0); }
+        if (dy < 4) {
+            load_a(hnext, 0, (dy + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (has_taps) taps(4, 5);
         // Weight set t + 1 (requested during tap row t - 1) must have landed before the barrier publishes it.  Younger vector-memory
         // operations of this wave: the row requests of this tap row's staging block and its three DMA pieces.
@@ -871,7 +862,7 @@ int sol_conv3d_sb_launch(hipStream_t s, const float* x, const float* wsh, const 
         const int nt8 = (nrows + 7) / 8, grid8 = (nt8 + 7) / 8 * 8;
 #define C8_DBG(N) case N: { static int rcd = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb8<N>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)rcd; \
             SOL_LAUNCH(k_conv3d_sb8<N>, dim3(grid8), dim3(512), c8_lds(), s, a, nrows, D); break; }
-        switch (sol_opt().dbg_skip) { C8_DBG(1) C8_DBG(8) C8_DBG(32) C8_DBG(64) C8_DBG(96) C8_DBG(104) default: break; }
+        switch (sol_opt().dbg_skip) { C8_DBG(1) C8_DBG(8) C8_DBG(32) C8_DBG(64) C8_DBG(104) default: break; }
         if (sol_opt().dbg_skip) { SOL_LAUNCH_CHECK(); return SOL_OK; }
         SOL_LAUNCH(k_conv3d_sb8<0>, dim3(grid8), dim3(512), c8_lds(), s, a, nrows, D);
         SOL_LAUNCH_CHECK();
@@ -879,9 +870,9 @@ int sol_conv3d_sb_launch(hipStream_t s, const float* x, const float* wsh, const 
     }
     if (sol_opt().k3d_conv_rows == 6) {               // six rows per workgroup, 32 x 32 tile per wave
         const int nt6 = (nrows + 5) / 6, grid6 = (nt6 + 7) / 8 * 8;
-        static int rc6 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb6<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
+        static int rc6 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
         SOL_REQUIRE(rc6 == 0, "hipFuncSetAttribute(k_conv3d_sb6) failed");
-        SOL_LAUNCH(k_conv3d_sb6<0>, dim3(grid6), dim3(768), c6_lds(), s, a, nrows, D);
+        SOL_LAUNCH(k_conv3d_sb6, dim3(grid6), dim3(768), c6_lds(), s, a, nrows, D);
         SOL_LAUNCH_CHECK();
         return SOL_OK;
     }

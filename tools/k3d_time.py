@@ -58,7 +58,7 @@ for rows in (3, 6, 8):                     # rows per workgroup of the one-launc
     torch.cuda.synchronize()
     out["cnn_ms_rows%d" % rows] = e0.elapsed_time(e1) / steps
 out["cnn_ms"] = out["cnn_ms_rows8"]
-for dbg in (1, 8, 32, 64, 96, 104):          # timing experiments (results invalid): 1 no taps, 8 no barrier, 32 no weights, 64 no rows, 128 no operand prefetch
+for dbg in (1, 8, 32, 64, 104):          # timing experiments (results invalid): 1 no taps, 8 no barrier, 32 no weights, 64 no rows
     sol_amd._lib.set_option("dbg_skip", dbg)
     ro.correction()
     e0.record()
