@@ -8,13 +8,15 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libsol_hip.so")
+LIB = os.environ.get("SOL_HIP_LIB") or os.path.join(LIBDIR, "libsol_hip.so")
 SOURCES = ["karman_step.hip", "karman_large.hip", "karman3d.hip", "conv3d_sb.hip", "burgers_step.hip", "conv5x5.hip", "conv5x5_sb.hip", "train.hip", "comm.hip", "cnn_chain.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 # the CG loop packs its vector updates by hand (float2); the SLP vectoriser only adds v_mov traffic there
 # conv3d_sb.hip: packed-f32 VALU (v_pk_mul/fma_f32, what SLP makes of the fp16 split of the row staging) costs ~22 cycles each
 # beside MFMAs (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
-EXTRA = {"karman_step.hip": ["-fno-slp-vectorize"], "conv3d_sb.hip": ["-fno-slp-vectorize"]}
+# The conv / trainer sources likewise: A/B on one box (tools/ab_lib.py) 13.725 -> 13.586 ms per training step.
+_NOSLP = ["-fno-slp-vectorize"]
+EXTRA = {"karman_step.hip": _NOSLP, "conv3d_sb.hip": _NOSLP, "conv5x5_sb.hip": _NOSLP, "conv5x5.hip": _NOSLP, "train.hip": _NOSLP, "cnn_chain.hip": _NOSLP}
 
 
 def _hipcc():
@@ -51,6 +53,8 @@ def _source_hash():
 
 
 def _stale():
+    if os.environ.get("SOL_HIP_LIB"):             # an explicitly named prebuilt library (tools/ab_lib.py variants): never rebuilt
+        return False
     if not os.path.exists(LIB):
         return True
     try:

@@ -99,7 +99,7 @@ _SIGS = {
     "sol_karman3d_correct": (C.c_int, [_P, _P, C.c_int32] + [C.c_float] * 3 + [_P] * 3 + [C.c_int32] * 4),
     "sol_conv3d_packed_floats": (C.c_size_t, [C.c_int32] * 2),
     "sol_conv3d_pack": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
-    "sol_conv3d": (C.c_int, [_P] * 6 + [C.c_int32] * 7 + [C.c_float] + [_P] * 2),
+    "sol_conv3d": (C.c_int, [_P] * 7 + [C.c_int32] * 7 + [C.c_float] + [_P] * 2),
     "sol_conv3d_bwd_weight_ws_floats": (C.c_size_t, [C.c_int32] * 6),
     "sol_conv3d_bwd_weight": (C.c_int, [_P] * 9 + [C.c_int32] * 8),
     "sol_mars_moon_layer": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -120,7 +120,7 @@ def lib_path():
     return _build.LIB
 
 
-ABI_VERSION = 210     # sol_version() of the library these bindings were written against
+ABI_VERSION = 211     # sol_version() of the library these bindings were written against
 
 # Debugging overrides: environment variable -> (option, value).  Read ONCE here, in Python, when the library is loaded;
 # the library itself never reads the environment (options are set through sol_set_option, include/sol_hip.h).

@@ -247,6 +247,10 @@ __global__ void __launch_bounds__(768) k_conv3d_sb(ConvArgs a, int nrows, int D)
             if (a.epi == SOL_EPI_LRELU) {
                 v.x = v.x > 0.f ? v.x : a.slope * v.x; v.y = v.y > 0.f ? v.y : a.slope * v.y;
                 v.z = v.z > 0.f ? v.z : a.slope * v.z; v.w = v.w > 0.f ? v.w : a.slope * v.w;
+            } else if (a.epi == SOL_EPI_DLRELU) {     // backward: times LeakyReLU'(activation reference)
+                const float4 q = reinterpret_cast<const float4*>(a.act)[o4];
+                v.x *= q.x > 0.f ? 1.f : a.slope; v.y *= q.y > 0.f ? 1.f : a.slope;
+                v.z *= q.z > 0.f ? 1.f : a.slope; v.w *= q.w > 0.f ? 1.f : a.slope;
             }
             vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
             reinterpret_cast<float4*>(a.y)[o4] = v;
@@ -508,6 +512,10 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
             if (a.epi == SOL_EPI_LRELU) {
                 v.x = v.x > 0.f ? v.x : a.slope * v.x; v.y = v.y > 0.f ? v.y : a.slope * v.y;
                 v.z = v.z > 0.f ? v.z : a.slope * v.z; v.w = v.w > 0.f ? v.w : a.slope * v.w;
+            } else if (a.epi == SOL_EPI_DLRELU) {     // backward: times LeakyReLU'(activation reference)
+                const float4 q = reinterpret_cast<const float4*>(a.act)[o4];
+                v.x *= q.x > 0.f ? 1.f : a.slope; v.y *= q.y > 0.f ? 1.f : a.slope;
+                v.z *= q.z > 0.f ? 1.f : a.slope; v.w *= q.w > 0.f ? 1.f : a.slope;
             }
             vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
             reinterpret_cast<float4*>(a.y)[o4] = v;
@@ -784,6 +792,10 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
             if (a.epi == SOL_EPI_LRELU) {
                 v.x = v.x > 0.f ? v.x : a.slope * v.x; v.y = v.y > 0.f ? v.y : a.slope * v.y;
                 v.z = v.z > 0.f ? v.z : a.slope * v.z; v.w = v.w > 0.f ? v.w : a.slope * v.w;
+            } else if (a.epi == SOL_EPI_DLRELU) {     // backward: times LeakyReLU'(activation reference)
+                const float4 q = reinterpret_cast<const float4*>(a.act)[o4];
+                v.x *= q.x > 0.f ? 1.f : a.slope; v.y *= q.y > 0.f ? 1.f : a.slope;
+                v.z *= q.z > 0.f ? 1.f : a.slope; v.w *= q.w > 0.f ? 1.f : a.slope;
             }
             vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
             reinterpret_cast<float4*>(a.y)[o4] = v;
@@ -843,7 +855,7 @@ int sol_conv3d_sh_pack(hipStream_t s, const float* w_dhwio, int mode, float* out
 }
 
 // y = epi(conv3d(x, w) + bias (+ residual)), x / y [nplanes = B*D][H][64][32]; wsh from sol_conv3d_sh_pack; x_absmax required
-int sol_conv3d_sb_launch(hipStream_t s, const float* x, const float* wsh, const float* bias, const float* residual, float* y,
+int sol_conv3d_sb_launch(hipStream_t s, const float* x, const float* wsh, const float* bias, const float* residual, const float* act_ref, float* y,
                          int B, int D, int H, int epilogue, float slope, const unsigned* x_absmax, unsigned* y_absmax) {
     static int rc = [] {
         hipFuncAttributes fa;
@@ -853,7 +865,7 @@ int sol_conv3d_sb_launch(hipStream_t s, const float* x, const float* wsh, const 
     }();
     SOL_REQUIRE(rc == 0, "hipFuncSetAttribute(k_conv3d_sb) failed");
     ConvArgs a{};
-    a.x = x; a.bias = bias; a.res = residual; a.y = y; a.B = B * D; a.H = H; a.W = 64; a.CO = 32; a.epi = epilogue; a.slope = slope;
+    a.x = x; a.bias = bias; a.res = residual; a.act = act_ref; a.y = y; a.B = B * D; a.H = H; a.W = 64; a.CO = 32; a.epi = epilogue; a.slope = slope;
     a.wsh = wsh; a.xmax = x_absmax; a.ymax = y_absmax; a.tiles_x = 1;
     const int nrows = B * D * H;
     if (sol_opt().k3d_conv_rows == 8) {               // eight rows per workgroup, 64 x 32 tile per wave, two waves per SIMD

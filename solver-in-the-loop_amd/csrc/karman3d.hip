@@ -937,18 +937,19 @@ extern "C" int sol_conv3d_pack(void* stream, const float* w_dhwio, int32_t cin, 
     return SOL_OK;
 }
 
-extern "C" int sol_conv3d(void* stream, const float* x, const float* packed, const float* bias, const float* residual, float* y,
+extern "C" int sol_conv3d(void* stream, const float* x, const float* packed, const float* bias, const float* residual, const float* act_ref, float* y,
                           int32_t B, int32_t D, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t epilogue, float slope,
                           const uint32_t* x_absmax, uint32_t* y_absmax) {
     SOL_REQUIRE(x && packed && y && x != y, "sol_conv3d: NULL pointer / in-place call");
     SOL_REQUIRE(B >= 1 && D >= 3, "sol_conv3d: B >= 1, D >= 3 (got %d, %d)", B, D);
-    SOL_REQUIRE(epilogue == SOL_EPI_NONE || epilogue == SOL_EPI_LRELU, "sol_conv3d: epilogue must be SOL_EPI_NONE or SOL_EPI_LRELU");
+    SOL_REQUIRE(epilogue == SOL_EPI_NONE || epilogue == SOL_EPI_LRELU || epilogue == SOL_EPI_DLRELU, "sol_conv3d: epilogue must be SOL_EPI_NONE, SOL_EPI_LRELU or SOL_EPI_DLRELU");
+    SOL_REQUIRE((epilogue == SOL_EPI_DLRELU) == (act_ref != nullptr) && act_ref != y, "sol_conv3d: SOL_EPI_DLRELU needs an activation reference (and only it does), distinct from y");
     hipStream_t s = (hipStream_t)stream;
     const int cin_k = cin <= 4 ? 4 : 32;
     SOL_REQUIRE(cin == cin_k, "sol_conv3d: input channels must be 4 (zero padded) or 32 (got %d)", cin);
     const size_t per = align_up(sol_conv5x5_packed_floats(cin, cout, SOL_CONV_FWD), 64);
     if (conv3d_fusable_shape(cin, cout) && W == 64 && x_absmax && sol_opt().conv_precision == 0 && sol_opt().k3d_conv_fused && residual != y)
-        return sol_conv3d_sb_launch(s, x, packed + 5 * per, bias, residual, y, B, D, H, epilogue, slope, x_absmax, y_absmax);
+        return sol_conv3d_sb_launch(s, x, packed + 5 * per, bias, residual, act_ref, y, B, D, H, epilogue, slope, x_absmax, y_absmax);
     const size_t pin = (size_t)H * W * cin, pout = (size_t)H * W * cout;      // floats per plane
     for (int b = 0; b < B; ++b) {
         const float* xb = x + (size_t)b * D * pin;
@@ -967,7 +968,7 @@ extern "C" int sol_conv3d(void* stream, const float* x, const float* packed, con
         if (int e = sol_conv5x5_scaled(stream, xb + 2 * pin, packed + 4 * per, nullptr, yb, nullptr, yb, D - 2, H, W, cin, cout, SOL_EPI_NONE, slope, x_absmax, nullptr)) return e;
     }
     // kd = 2 (centre): every plane of the batch, with bias / activation / absmax publish
-    return sol_conv5x5_scaled(stream, x, packed + 2 * per, bias, y, nullptr, y, B * D, H, W, cin, cout, epilogue, slope, x_absmax, y_absmax);
+    return sol_conv5x5_scaled(stream, x, packed + 2 * per, bias, y, act_ref, y, B * D, H, W, cin, cout, epilogue, slope, x_absmax, y_absmax);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

@@ -21,7 +21,7 @@ import torch
 from . import _lib
 from ._lib import Karman3DCfg, check, ptr, stream
 
-EPI_NONE, EPI_LRELU = 0, 1
+EPI_NONE, EPI_LRELU, EPI_DLRELU = 0, 1, 2
 
 
 def scene_arrays3d(Y, X, Z, length=100.0, obstacle="sphere"):
@@ -206,9 +206,13 @@ class MarsMoon3D:
                 self._tpacks.append((_pack3d(w, 4 if cin <= 4 else 32, cout, 0), _pack3d(w, cout, cin, 1)))
         return self._tpacks
 
+    fused_backward = True      # one autograd node with a hand-written reverse sweep (False: one node per layer, torch glue)
+
     def __call__(self, x):
         """Differentiable forward (training): x [B,Y,X,Z,4] -> [B,Y,X,Z,cout]; gradients flow to self.params (set
         `net.params.requires_grad_(True)`) and to x."""
+        if self.fused_backward:
+            return _MarsMoon3DFn.apply(x, self.params, self)
         p = self.tensors()
         pk = self.train_packs()
         sl = self.slope
@@ -255,13 +259,15 @@ class MarsMoon3D:
         return self._packed
 
 
-def conv3d(x, packed, bias, residual, cout, lrelu, slope, x_absmax=None, y_absmax=None, out=None):
-    """sol_conv3d: x [B,Y,X,Z,cin] -> [B,Y,X,Z,cout]."""
+def conv3d(x, packed, bias, residual, cout, lrelu, slope, x_absmax=None, y_absmax=None, out=None, act_ref=None):
+    """sol_conv3d: x [B,Y,X,Z,cin] -> [B,Y,X,Z,cout].  act_ref: the result (conv + residual) is multiplied by LeakyReLU'(act_ref)
+    (SOL_EPI_DLRELU, the backward pass's fused form) instead of being activated."""
     lib = _lib.load()
     B, D, H, W, cin = x.shape
     y = out if out is not None else torch.empty(B, D, H, W, cout, dtype=torch.float32, device=x.device)
-    check(lib.sol_conv3d(stream(), ptr(x), ptr(packed), ptr(bias), ptr(residual), ptr(y), B, D, H, W, cin, cout,
-                         EPI_LRELU if lrelu else EPI_NONE, float(slope), ptr(x_absmax), ptr(y_absmax)))
+    epi = EPI_DLRELU if act_ref is not None else (EPI_LRELU if lrelu else EPI_NONE)
+    check(lib.sol_conv3d(stream(), ptr(x), ptr(packed), ptr(bias), ptr(residual), ptr(act_ref), ptr(y), B, D, H, W, cin, cout,
+                         epi, float(slope), ptr(x_absmax), ptr(y_absmax)))
     return y
 
 
@@ -283,7 +289,7 @@ def _pad_ch(x, c):
     return x.contiguous() if x.shape[-1] == c else torch.nn.functional.pad(x, (0, c - x.shape[-1])).contiguous()
 
 
-def conv3d_bwd_weight(xk, dz, cin, cout):
+def conv3d_bwd_weight(xk, dz, cin, cout, xmax=None, zmax=None):
     """dW [5,5,5,cin,cout], db [cout] of y = conv3d(x, W) + b from xk [B,D,H,W,cin_k] (channels padded to 4 / 32) and dz
     [B,D,H,W,cout]: sol_conv3d_bwd_weight (five passes of the batched 2-D weight-gradient kernels over the shifted plane
     ranges; fp16 three-product operands for the 32 -> 32 case, scaled by the absmax of x and dz)."""
@@ -299,8 +305,9 @@ def conv3d_bwd_weight(xk, dz, cin, cout):
     both32 = cin_k == 32 and co_k == 32
     # (the slot tensors must outlive the call: a temporary inside ptr(...) is freed -- and its block handed to the next
     # allocation -- before the launch is even enqueued)
-    xmax = _absmax(xk) if both32 else None
-    zmax = _absmax(dzk) if both32 else None
+    # (xmax / zmax given: the slots the producing conv launches published -- no pass over the tensors)
+    xmax = (xmax if xmax is not None else _absmax(xk)) if both32 else None
+    zmax = (zmax if zmax is not None and dzk is dz else _absmax(dzk)) if both32 else None
     check(lib.sol_conv3d_bwd_weight(stream(), ptr(xk), ptr(dzk), ptr(xmax), ptr(zmax),
                                     ptr(part), ptr(dW), ptr(db), ptr(scratch), B, D, H, W, cin_k, co_k, cin, co_k))
     return dW[..., :cout].contiguous(), db[:cout].clone()
@@ -343,6 +350,55 @@ class _Conv3DFn(torch.autograd.Function):
         dzk = _pad_ch(dz, co_k)
         dx = conv3d(dzk, packed, None, None, cin, False, slope, _absmax(dzk) if co_k == 32 else None)
         return dx, dW, db, (dz if has_res else None), None, None, None
+
+
+class _MarsMoon3DFn(torch.autograd.Function):
+    """model_mars_moon (3-D) as ONE autograd node.  Forward: the twelve sol_conv3d launches, every layer handing the absmax slots
+    it published to its consumer (no pass over a tensor just to find its maximum).  Reverse sweep, written out by hand
+    (karman_train.py:101-138 differentiated): per layer the weight gradient (sol_conv3d_bwd_weight) and ONE data-gradient launch
+    whose epilogue adds the skip gradient of the residual block and multiplies by LeakyReLU'(saved activation)
+    (SOL_EPI_DLRELU) -- the compare / where / multiply / add / absmax passes of the per-layer form are gone."""
+
+    @staticmethod
+    def forward(ctx, x, params, net):
+        _lib.require_gpu()
+        p = [t.detach() for t in net.tensors()]
+        pk = net.train_packs()
+        sl, cout = net.slope, net.cout
+        xk = _pad_ch(_lib.f32(x.detach()), 4)
+        amax = torch.zeros(11, 256, dtype=torch.int32, device=xk.device)       # absmax slots of the eleven 32-channel activations
+        acts = [conv3d(xk, pk[0][0], p[1], None, 32, True, sl, None, amax[0])]
+        for k in range(5):
+            a = conv3d(acts[-1], pk[1 + 2 * k][0], p[3 + 4 * k], None, 32, True, sl, amax[2 * k], amax[2 * k + 1])
+            acts.append(a)
+            acts.append(conv3d(a, pk[2 + 2 * k][0], p[5 + 4 * k], acts[-2], 32, True, sl, amax[2 * k + 1], amax[2 * k + 2]))
+        out = conv3d(acts[-1], pk[11][0], p[23], None, cout, False, sl, amax[10], None)
+        ctx.net = net
+        ctx.save_for_backward(xk, amax, *acts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        net = ctx.net
+        xk, amax, *acts = ctx.saved_tensors
+        pk = net.train_packs()
+        sl, cin, cout = net.slope, net.cin, net.cout
+        grads = [None] * 24
+        zm = torch.zeros(11, 256, dtype=torch.int32, device=xk.device)         # absmax slots of the eleven pre-activation gradients
+        g = _lib.f32(g_out).contiguous()
+        grads[22], grads[23] = conv3d_bwd_weight(acts[10], g, 32, cout, xmax=amax[10])
+        # d loss / d (pre-activation of the last residual block's output) = conv3d(g, flip(w11)^T) * lrelu'(h5)
+        dz = conv3d(_pad_ch(g, 4), pk[11][1], None, None, 32, False, sl, None, zm[10], act_ref=acts[10])
+        for k in range(4, -1, -1):
+            a, hprev = acts[1 + 2 * k], acts[2 * k]
+            # block k: h_k = lrelu(conv_b(a) + h_{k-1}), a = lrelu(conv_a(h_{k-1}))
+            grads[4 + 4 * k], grads[5 + 4 * k] = conv3d_bwd_weight(a, dz, 32, 32, xmax=amax[2 * k + 1], zmax=zm[2 * k + 2])
+            dz1 = conv3d(dz, pk[2 + 2 * k][1], None, None, 32, False, sl, zm[2 * k + 2], zm[2 * k + 1], act_ref=a)
+            grads[2 + 4 * k], grads[3 + 4 * k] = conv3d_bwd_weight(hprev, dz1, 32, 32, xmax=amax[2 * k], zmax=zm[2 * k + 1])
+            dz = conv3d(dz1, pk[1 + 2 * k][1], None, dz, 32, False, sl, zm[2 * k + 1], zm[2 * k], act_ref=hprev)
+        grads[0], grads[1] = conv3d_bwd_weight(xk, dz, cin, 32)
+        dx = conv3d(dz, pk[0][1], None, None, xk.shape[-1], False, sl, zm[0], None)
+        return dx[..., :cin], torch.cat([t.reshape(-1) for t in grads]), None
 
 
 def conv3d_fn(x, w, b, residual=None, lrelu=False, slope=0.3, packs=None):

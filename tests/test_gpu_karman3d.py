@@ -264,6 +264,36 @@ def test_conv3d_gradients_against_oracle(shape, cin, cout, res, lrelu):
         assert rel(hr.grad, r.grad) < 5e-6
 
 
+@pytest.mark.parametrize("shape", [(1, 4, 64, 64), (2, 5, 16, 16)])
+def test_network_fused_reverse_sweep_equals_per_layer_autograd(shape):
+    """MarsMoon3D as one autograd node (data gradient + skip gradient + LeakyReLU' in the conv epilogues, absmax slots handed
+    from producer to consumer) against the per-layer composition with torch glue: outputs bit-equal, input and parameter
+    gradients to round-off.  W = 64 runs the one-launch Conv3D kernels with the SOL_EPI_DLRELU epilogue, W = 16 the five-pass
+    form; the per-layer path itself is held to the float64 oracle by test_conv3d_gradients_against_oracle and the trainer test."""
+    import make_golden as mg
+    B, D, H, W = shape
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(B, D, H, W, 4, generator=gen, dtype=torch.float32).to(DEV)
+    gy = (torch.randn(B, D, H, W, 3, generator=gen, dtype=torch.float32) * 1e-3).to(DEV)
+    res = {}
+    for fused in (True, False):
+        net = k3.MarsMoon3D(device=DEV)
+        net.set_weights([p.numpy() for p in mg.k3d_params()])
+        net.fused_backward = fused
+        net.params.requires_grad_(True)
+        xi = x.clone().requires_grad_(True)
+        out = net(xi)
+        (out * gy).sum().backward()
+        torch.cuda.synchronize()
+        res[fused] = (out.detach(), xi.grad, net.params.grad)
+    assert torch.equal(res[True][0], res[False][0])
+    assert rel(res[True][1], res[False][1]) < 2e-6, rel(res[True][1], res[False][1])
+    assert rel(res[True][2], res[False][2]) < 2e-6, rel(res[True][2], res[False][2])
+    off = k3.MarsMoon3D(device="cpu").offsets
+    per = [rel(res[True][2][off[k]:off[k + 1]], res[False][2][off[k]:off[k + 1]]) for k in range(24)]
+    assert max(per) < 1e-5, per
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_karman3d_trainer_sol2_against_oracle(use_graph):
     """SOL-2 at 32 x 16 x 16, B = 2: loss, the full 1.3 M-element gradient and one TF-Adam update against the float64 oracle
