@@ -407,7 +407,7 @@ int sol_conv3d(void* stream, const float* x, const float* packed, const float* b
 /* Conv3D weight gradient: dw_dhwio [5,5,5,cin_real,cout] = sum_px x[px + tap] * dz[px], db [cout] = sum_px dz[px]; five passes
  * of the 2-D weight-gradient kernels over the shifted plane ranges.  x [B,D,H,W,cin] (cin in {4, 32}, zero padded from
  * cin_real), dz [B,D,H,W,cout] (cout in {2, 32}); x_absmax / dz_absmax (or NULL): absmax slots of the two tensors -> fp16
- * three-product kernels for the 32 -> 32 case.  partial: sol_conv3d_bwd_weight_ws_floats() floats of scratch; db_scratch: cout floats. */
+ * three-product kernels for the 32 -> 32 case.  partial: sol_conv3d_bwd_weight_ws_floats() floats of scratch; db_scratch: 5 * cout floats. */
 size_t sol_conv3d_bwd_weight_ws_floats(int32_t B, int32_t D, int32_t H, int32_t W, int32_t cin, int32_t cout);
 int sol_conv3d_bwd_weight(void* stream, const float* x, const float* dz, const uint32_t* x_absmax, const uint32_t* dz_absmax,
                           float* partial, float* dw_dhwio, float* db, float* db_scratch,

@@ -977,8 +977,15 @@ extern "C" int sol_conv3d(void* stream, const float* x, const float* packed, con
 // three-product operands when the absmax of both tensors is given) over the shifted plane ranges, each into `partial` and
 // reduced into its depth slice of dw; db from the centre pass (all planes).
 // ------------------------------------------------------------------------------------------------------------------------
+static size_t conv3d_bww_part_floats(int D, int H, int cin, int cout) {    // the block layout depends on the plane count of a pass
+    size_t m = 0;
+    for (int np = D - 2; np <= D; ++np) m = std::max(m, sol_bww_batched_ws_floats(1, np, H, cin, cout));
+    return align_up(m, 64);
+}
+
 extern "C" size_t sol_conv3d_bwd_weight_ws_floats(int32_t B, int32_t D, int32_t H, int32_t /*W*/, int32_t cin, int32_t cout) {
-    return sol_bww_batched_ws_floats(1, B * D, H, cin, cout);
+    (void)B;
+    return 5 * conv3d_bww_part_floats(D, H, cin, cout);                           // one partial buffer per depth slice
 }
 
 extern "C" int sol_conv3d_bwd_weight(void* stream, const float* x, const float* dz, const uint32_t* x_absmax, const uint32_t* dz_absmax,
@@ -990,19 +997,20 @@ extern "C" int sol_conv3d_bwd_weight(void* stream, const float* x, const float* 
     SOL_REQUIRE(cout_real == cout, "sol_conv3d_bwd_weight: the reduce writes dw with the kernel's output-channel count (pad dz and slice the result)");
     const size_t pin = (size_t)H * W * cin, pout = (size_t)H * W * cout;
     const size_t slice = (size_t)25 * cin_real * cout_real;
+    const size_t per = conv3d_bww_part_floats(D, H, cin, cout);
+    // Five passes (depth slices) x B simulations into five partial buffers -- a simulation's pass accumulates onto the previous
+    // one's blocks (same plane range, same block layout) --, then ONE two-stage reduce launch pair for all five slices
+    // (it was a pair per slice and simulation: 10 B launches of a few microseconds of work each per layer).
+    float* parts[5]; float* dws[5]; float* dbs[5]; int rows[5], rbs[5], cins[5], couts[5];
     for (int kd = 0; kd < 5; ++kd) {
         const int lo = kd < 2 ? 2 - kd : 0, hi = kd > 2 ? D + 2 - kd : D;       // output planes that see input plane d + kd - 2
-        if (kd == 2) {
-            if (int e = sol_bww_batched(stream, x, dz, partial, 1, 1, 1, 0, 0, B * D, H, W, cin, cout, x_absmax, dz_absmax, 0, 0)) return e;
-            if (int e = sol_bww_batched_reduce(stream, partial, dw_dhwio + kd * slice, db, 1, B * D, H, cin_real, cout_real, 0)) return e;
-            continue;
-        }
+        parts[kd] = partial + kd * per; dws[kd] = dw_dhwio + kd * slice; dbs[kd] = kd == 2 ? db : db_scratch + (size_t)kd * cout;
+        rows[kd] = (hi - lo) * H; rbs[kd] = 0; cins[kd] = cin_real; couts[kd] = cout_real;
         for (int b = 0; b < B; ++b) {
             const float* xb = x + ((size_t)b * D + lo + kd - 2) * pin;
             const float* zb = dz + ((size_t)b * D + lo) * pout;
-            if (int e = sol_bww_batched(stream, xb, zb, partial, 1, 1, 1, 0, 0, hi - lo, H, W, cin, cout, x_absmax, dz_absmax, 0, 0)) return e;
-            if (int e = sol_bww_batched_reduce(stream, partial, dw_dhwio + kd * slice, db_scratch, 1, hi - lo, H, cin_real, cout_real, b ? 1 : 0)) return e;
+            if (int e = sol_bww_batched(stream, xb, zb, parts[kd], 1, 1, b == 0, 0, 0, hi - lo, H, W, cin, cout, x_absmax, dz_absmax, 0, 0)) return e;
         }
     }
-    return SOL_OK;
+    return sol_bww_reduce_layers(stream, 5, parts, dws, dbs, rows, rbs, cins, couts, 0, 0);
 }

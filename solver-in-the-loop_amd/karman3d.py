@@ -301,7 +301,7 @@ def conv3d_bwd_weight(xk, dz, cin, cout, xmax=None, zmax=None):
     part = torch.empty(lib.sol_conv3d_bwd_weight_ws_floats(B, D, H, W, cin_k, co_k), dtype=torch.float32, device=dev)
     dW = torch.empty(5, 5, 5, cin, co_k, dtype=torch.float32, device=dev)
     db = torch.empty(co_k, dtype=torch.float32, device=dev)
-    scratch = torch.empty(co_k, dtype=torch.float32, device=dev)
+    scratch = torch.empty(5 * co_k, dtype=torch.float32, device=dev)
     both32 = cin_k == 32 and co_k == 32
     # (the slot tensors must outlive the call: a temporary inside ptr(...) is freed -- and its block handed to the next
     # allocation -- before the launch is even enqueued)
