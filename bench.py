@@ -44,6 +44,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the strict-fp32 leg, the 64x32 recipe, the roll-out and the full-chip solver launch")
     p.add_argument("--no-graph", action="store_true", help="launch the ~1000 kernels of a step eagerly instead of replaying the hipGraph")
+    p.add_argument("--k3d-dp", action="store_true", help="N > 1: also time the karman-3d SOL-16 step data parallel (one simulation per rank, BASELINE "
+                                                         "configs[4]); off by default: a second collective path must not be able to hang the contract line")
     p.add_argument("--precision", default="split", choices=["split", "bf16x6", "fp32"], help="conv arithmetic of the timed steps")
     p.add_argument("--cpu-msteps", type=int, default=2, help="msteps of the bounded CPU-baseline sample")
     return p.parse_args()
@@ -244,6 +246,42 @@ def karman3d_leg(sol_amd, dev, B=1, steps=8):
             "kernels": kern}
 
 
+def karman3d_dp_leg(sol_amd, dev, world, barrier):
+    """karman-3d 128x64x64 SOL-16 training step, one simulation per rank, ONE all-reduce of [gradient | loss] per step (every rank calls this)."""
+    from sol_amd import karman3d as k3, synthetic
+    Y, X, Z, ms3 = 128, 64, 64, 16
+    sc = k3.Scene3D(Y, X, Z, device=dev)
+    net = k3.MarsMoon3D(device=dev)
+    w = net.get_weights()
+    w[22] = w[22] * 0.01
+    net.set_weights(w)
+    tr = k3.Karman3DTrainer(net, sc, 1, ms3, (0.2, 0.2, 0.2), synthetic.STD_RE, use_graph=True)
+    gen = torch.Generator().manual_seed(1 + (torch.distributed.get_rank() if world > 1 else 0))
+    f = lambda *s: torch.randn(*s, generator=gen)
+    st = (torch.rand(1, Y, X, Z, generator=gen).to(dev), (1.0 + 0.1 * f(1, Y + 1, X, Z)).to(dev), (0.1 * f(1, Y, X + 1, Z)).to(dev), (0.1 * f(1, Y, X, Z + 1)).to(dev))
+    re = synthetic.reynolds(1).float().to(dev)
+    gts, gs = [], st
+    with torch.no_grad():
+        for _ in range(ms3):
+            gs = tr.sim.step(gs[0], gs[1], gs[2], gs[3], re)
+            gts.append(tuple(t + 0.01 * torch.randn_like(t) for t in gs[1:]))
+    c0 = tr._dp.collectives
+    l0 = float(tr.train_step(*st, re, gts, lr=1e-7))
+    per_step = tr._dp.collectives - c0
+    barrier()
+    t0 = time.perf_counter()
+    nrep = 3
+    for _ in range(nrep):
+        l1 = float(tr.train_step(*st, re, gts, lr=1e-7))
+    barrier()
+    t = torch.tensor([(time.perf_counter() - t0) / nrep], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    t = float(t.item())
+    return {"workload": "karman-3d 128x64x64 SOL-16, 1 simulation per rank, %d rank(s)" % world, "ms_per_step": t * 1e3, "sim_steps_per_s": world * ms3 / t,
+            "collectives_per_step": per_step, "allreduce_bytes": tr._flat.numel() * 4, "loss": l1, "loss_first": l0, "finite": bool(math.isfinite(l1))}
+
+
 def load_traffic():
     """{'kernel|grid': {'FETCH_SIZE': KB, 'WRITE_SIZE': KB}} from the committed rocprofv3 --pmc summary -- but only when it was
     collected for THIS build: the file carries the content hash of the library sources it was taken at
@@ -341,6 +379,9 @@ def main():
         if not dp["weights_bit_identical_across_ranks"]:
             raise SystemExit("bench.py: the replicas' weights diverged")
 
+    k3d_dp = None
+    if args.k3d_dp and world > 1:
+        k3d_dp = karman3d_dp_leg(sol_amd, dev, world, barrier)
     out = None
     if rank == 0:
         N = Y * X
@@ -536,6 +577,8 @@ def main():
                 out["karman3d"] = karman3d_leg(sol_amd, dev)
             except Exception as e:
                 out["karman3d"] = {"error": str(e)}
+        if k3d_dp is not None:
+            out["karman3d_data_parallel"] = k3d_dp
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, Y, X, B)
         else:

@@ -413,11 +413,12 @@ class Karman3DTrainer:
     (sol_adam_tf_step).  gts: [msteps] of (vy, vx, vz) ground-truth frames."""
 
     def __init__(self, net, scene, B, msteps, std_v, std_re, dt=1.0, res=None, beta1=0.9, beta2=0.999, eps=1e-8, conv_precision="split",
-                 use_graph=False, **solver):
+                 use_graph=False, group=None, comm=None, **solver):
         """use_graph: capture the whole forward unroll + reverse sweep ONCE into a hipGraph over static input buffers (the
         TF1 "build the graph, sess.run many" shape, as trainer.GraphTrainer does for the 2-D mercury model): a step then
         copies the batch in and replays ~3000 launches with one host call."""
         from .trainer import _conv_precision_code
+        from .dist import DPStep
         _lib.require_gpu()
         self.lib = _lib.load()
         self.net, self.scene, self.B, self.ms = net, scene, B, msteps
@@ -438,7 +439,11 @@ class Karman3DTrainer:
         self._gt = [f(msteps, B, Y + 1, X, Z), f(msteps, B, Y, X + 1, Z), f(msteps, B, Y, X, Z + 1)]
         self.loss_steps = f(msteps)
         self._loss = f(())
-        self._grads = f(net.n_params)
+        # gradient + one slot for the loss: the data-parallel exchange (B simulations per rank, BASELINE configs[4]: 8 GPUs) is ONE
+        # all-reduce(SUM) of this buffer per training step, as for the 2-D trainers (dist.DPStep; group / comm as there)
+        self._flat = f(net.n_params + 1)
+        self._grads = self._flat[:net.n_params]
+        self._dp = DPStep(lambda *b: (self.fwd_bwd(*b), self._grads), lambda g, lr: self.apply_gradients(lr), group=group, comm=comm, flat=self._flat)
         self._fin = [f(B, Y, X, Z), f(B, Y + 1, X, Z), f(B, Y, X + 1, Z), f(B, Y, X, Z + 1)]
         self.final = None
         self.use_graph, self._graph = bool(use_graph), None
@@ -507,9 +512,8 @@ class Karman3DTrainer:
         self.net._packed = None
 
     def train_step(self, d, vy, vx, vz, re, gts, lr):
-        loss = self.fwd_bwd(d, vy, vx, vz, re, gts)
-        self.apply_gradients(lr)
-        return loss
+        """One training step on this rank's simulations; returns the GLOBAL loss tensor (the sum over all ranks' simulations)."""
+        return self._dp(d, vy, vx, vz, re, gts, lr=lr)
 
 
 class Karman3DRollout:

@@ -45,10 +45,37 @@ def run(Bg, Y, X, ms, rank, world, group=None, steps=2, lr=1e-4):
     return np.array(losses), grads0, net.params.detach().cpu().numpy()
 
 
+def run3d(Bg, Y, X, Z, ms, rank, world, group=None, steps=2, lr=1e-4):
+    """the same for Karman3DTrainer (karman-3d, BASELINE configs[4] shards simulations over the GPUs exactly like the 2-D scene)"""
+    import sol_oracle3d as o3
+    from sol_amd import karman3d as k3
+    dev = "cuda:0"
+    d, v = o3.synthetic_state(Bg, Y, X, Z, 77)
+    re = torch.tensor([o3.RE_TRAIN[i % len(o3.RE_TRAIN)] for i in range(Bg)], dtype=torch.float64)
+    gts = [o3.synthetic_state(Bg, Y, X, Z, 500 + i)[1] for i in range(ms)]
+    lo, hi = sol_amd.dist.shard_range(Bg, rank, world)
+    f = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+    sc = k3.Scene3D(Y, X, Z, device=dev)
+    net = k3.MarsMoon3D(seed=3, device=dev)
+    tr = k3.Karman3DTrainer(net, sc, hi - lo, ms, (0.2, 0.25, 0.3), o3.STD_RE, group=group)
+    args = (f(d[lo:hi]), f(v[0][lo:hi]), f(v[1][lo:hi]), f(v[2][lo:hi]), f(re[lo:hi]), [tuple(f(c[lo:hi]) for c in g) for g in gts])
+    losses, grads0 = [], None
+    for s in range(steps):
+        losses.append(float(tr.train_step(*args, lr=lr)))
+        if s == 0:
+            grads0 = tr.grads.detach().cpu().numpy().copy()
+    torch.cuda.synchronize()
+    return np.array(losses), grads0, net.params.detach().cpu().numpy()
+
+
 if __name__ == "__main__":
     rank, world, _ = sol_amd.dist.init_from_env("gloo")
-    Bg, Y, X, ms = (int(v) for v in sys.argv[2:6])
-    losses, grads0, params = run(Bg, Y, X, ms, rank, world)
+    if sys.argv[2] == "k3d":
+        Bg, Y, X, Z, ms = (int(v) for v in sys.argv[3:8])
+        losses, grads0, params = run3d(Bg, Y, X, Z, ms, rank, world)
+    else:
+        Bg, Y, X, ms = (int(v) for v in sys.argv[2:6])
+        losses, grads0, params = run(Bg, Y, X, ms, rank, world)
     np.savez(sys.argv[1] + "_rank%d.npz" % rank, losses=losses, grads0=grads0, params=params)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

@@ -340,6 +340,34 @@ def test_karman3d_trainer_sol2_against_oracle(use_graph):
     assert rel(net.params.detach(), torch.cat([p.reshape(-1) for p in p2])) < 1e-4
 
 
+def test_karman3d_data_parallel_two_ranks_one_gpu(tmp_path):
+    """Karman3DTrainer with world_size 2 (both ranks on cuda:0, gloo transport, one simulation each) against the single process with
+    both simulations: ONE all-reduce of [gradient | loss] per step gives the global-batch gradient and loss, the replicas hold
+    bit-identical weights after two Adam steps (BASELINE configs[4] shards the simulations over 8 GPUs this way)."""
+    import subprocess
+    import socket
+    import dp_worker
+    Bg, Y, X, Z, ms = 2, 32, 16, 16, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    prefix = str(tmp_path / "dp3")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(os.path.dirname(__file__), "dp_worker.py"), prefix, "k3d"] +
+                                      [str(v) for v in (Bg, Y, X, Z, ms)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    r0, r1 = (np.load(prefix + "_rank%d.npz" % r) for r in range(2))
+    assert np.array_equal(r0["params"], r1["params"])
+    assert np.array_equal(r0["grads0"], r1["grads0"]) and np.array_equal(r0["losses"], r1["losses"])
+    losses, grads0, params = dp_worker.run3d(Bg, Y, X, Z, ms, 0, 1)
+    assert np.allclose(r0["losses"], losses, rtol=2e-5)
+    assert rel(torch.as_tensor(r0["grads0"]), torch.as_tensor(grads0)) < 2e-5
+    assert rel(torch.as_tensor(r0["params"]), torch.as_tensor(params)) < 1e-5
+
+
 def test_karman3d_script(tmp_path):
     """scripts/karman3d.py: data generation at 16 x 8 x 8, a SOL-2 training demo on those frames, and a corrected roll-out
     with the model it wrote."""
