@@ -36,5 +36,13 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc3d_$C -o pmc -- python $R/tools/k3d_time.py 1 2 > /dev/null 2>>$OUT/rocprof.err
   python $R/tools/pmc_summary.py $OUT/pmc3d_$C "k" > $OUT/pmc3d_$C.txt
 done
-rm -rf $OUT/trace $OUT/trace3d $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq $OUT/pmc3d_FETCH_SIZE $OUT/pmc3d_WRITE_SIZE
+# SQ counters of the one-launch Conv3D kernels (three-, six-, eight-row forms; tools/k3d_time.py runs all three)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F16 \
+  --output-format csv -d $OUT/pmc3d_sq -o pmc -- python $R/tools/k3d_time.py 1 2 > /dev/null 2>>$OUT/rocprof.err
+python $R/tools/pmc_summary.py $OUT/pmc3d_sq "k_conv3d" > $OUT/pmc_sq_conv3d.txt
+rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD \
+  --output-format csv -d $OUT/pmc3d_sq2 -o pmc -- python $R/tools/k3d_time.py 1 2 > /dev/null 2>>$OUT/rocprof.err
+python $R/tools/pmc_summary.py $OUT/pmc3d_sq2 "k_conv3d" >> $OUT/pmc_sq_conv3d.txt
+python $R/tools/k3d_time.py 1 4 > $OUT/k3d_time_b1.txt 2>>$OUT/rocprof.err
+rm -rf $OUT/trace $OUT/trace3d $OUT/pmc3d_sq $OUT/pmc3d_sq2 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq $OUT/pmc3d_FETCH_SIZE $OUT/pmc3d_WRITE_SIZE
 ls -la $OUT
