@@ -52,7 +52,7 @@ int sol_abi_sizes(int32_t* karman_cfg, int32_t* burgers_cfg, int32_t* train_cfg)
  *                       neighbouring workgroups) where the shape allows it (W == 64, ceil(B*H/3) <= #CUs); measured on par
  *                       with the per-layer launches at B = 6
  *   bww_fuse (1), correct_fuse (1), density_mode (0), conv_thin (1), conv_r3 (1), conv_bww32 (1): fusion / kernel choices
- *   k3d_conv_fused (1)  32 -> 32 Conv3D layers (W == 64, operand absmax given) as ONE launch that keeps its accumulators over all
+ *   k3d_conv_fused (1)  32 -> 32 and 32 -> (<= 16) Conv3D layers (W == 64, operand absmax given) as ONE launch that keeps its accumulators over all
  *                       125 taps (0: five passes of the 2-D kernel with the running sum in HBM); k3d_fused_tf (1): sine transforms
  *                       of the 3-D pressure solve as LDS-resident plane / slab kernels (0: batched GEMMs)
  *   k3d_conv_rows (8)   rows per workgroup of the one-launch Conv3D kernel: 8 = one 64 px x 32 co tile per wave, eight waves (two per

@@ -121,11 +121,11 @@ int sol_conv_sh_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int 
 int sol_conv_sb_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int mode, void* out);
 int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles);
 
-// fused 5x5x5 convolution, 32 -> 32 channels, W == 64 (conv3d_sb.hip)
-size_t sol_conv3d_sh_packed_floats();
-int sol_conv3d_sh_pack(hipStream_t s, const float* w_dhwio, int mode, float* out);
+// fused 5x5x5 convolution, 32 -> 32 or 32 -> (<= 16) channels, W == 64 (conv3d_sb.hip)
+size_t sol_conv3d_sh_packed_floats(int cout);
+int sol_conv3d_sh_pack(hipStream_t s, const float* w_dhwio, int mode, int cout, float* out);
 int sol_conv3d_sb_launch(hipStream_t s, const float* x, const float* wsh, const float* bias, const float* residual, const float* act_ref, float* y,
-                         int B, int D, int H, int epilogue, float slope, const unsigned* x_absmax, unsigned* y_absmax);
+                         int B, int D, int H, int cout, int epilogue, float slope, const unsigned* x_absmax, unsigned* y_absmax);
 
 // ---- process-wide options (sol_set_option / sol_get_option, include/sol_hip.h) ----------------------------------
 // Read at every call (plain ints, no caching in function-local statics), so a host may switch e.g. the convolution

@@ -558,9 +558,12 @@ constexpr size_t c6_lds() { return (size_t)8 * 68 * 160 + 3 * (size_t)5 * 2 * 32
 // immediates (pixel tile, plane).
 // DBG (option dbg_skip, timing experiments only, results invalid): 1 no taps, 8 no barriers, 32 no weight DMA, 64 no rows.
 // ------------------------------------------------------------------------------------------------------------------------
-template <int DBG>
+template <int DBG> __device__ __forceinline__ void c8_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DBG) : "memory"); }
+// NT = output-channel tiles of 16: 2 for the 32 -> 32 layers, 1 for the thin 32 -> (<= 16) layers (32 -> 3 forward, 32 -> 4 data
+// gradient of the first layer): half the MFMAs and weight bytes on the same staging skeleton, outputs stored channel by channel.
+template <int NT, int DBG>
 __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D) {
-    constexpr int OP = 32, HWP = 68;
+    constexpr int OP = NT * 16, HWP = 68;
     constexpr int PLANE = HWP * 64, SLOT = 2 * PLANE, WPL = OP * 64, WSET = 5 * 2 * WPL;
     constexpr int NSLOT = 11, ROWS = 8, NWB = 3;
     constexpr int AMAX_LDS = NWB * WSET + NSLOT * SLOT;
@@ -612,18 +615,22 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(src), "s"(lo));
     };
-    // weight set t (one tap row, 20 480 bytes) into buffer buf: wave w moves bytes [2560 w, 2560 (w + 1)) as 1024 + 1024 + 512
-    // (THREE vector-memory operations per wave and set: the count the waits below rely on)
+    // weight set t (one tap row, WSET = 20 480 / 10 240 bytes) into buffer buf: wave w moves bytes [CW w, CW (w + 1)), CW = WSET / 8,
+    // in NDMA = 3 / 2 pieces of at most 1 KB (NDMA vector-memory operations per wave and set: the count the waits below rely on)
+    constexpr int CW = WSET / 8, NDMA = (CW + 1023) / 1024;
     auto dma_w = [&](int t, int buf) __attribute__((always_inline)) {
         if (DBG & 32) return;
-        const unsigned char* src = gw + (size_t)t * WSET + wid * 2560 + lane * 16;
-        unsigned char* dst = Wt + buf * WSET + wid * 2560;
-        lds_dma16(src, dst);
-        lds_dma16(src + 1024, dst + 1024);
-        if (lane < 32) lds_dma16(src + 2048, dst + 2048);
+        const unsigned char* src = gw + (size_t)t * WSET + wid * CW + lane * 16;
+        unsigned char* dst = Wt + buf * WSET + wid * CW;
+#pragma unroll
+        for (int pc = 0; pc < NDMA; ++pc) {
+            constexpr int full = 64;
+            const int lanes = (CW - pc * 1024) / 16;          // 64 except for the last piece
+            if (lanes >= full || lane < lanes) lds_dma16(src + pc * 1024, dst + pc * 1024);
+        }
     };
 
-    float biasv[2];
+    float biasv[NT];
     float4 hvA = make_float4(0.f, 0.f, 0.f, 0.f), hvB = hvA;
     float4 hvP[ROWS + 1];
     {
@@ -633,7 +640,7 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
         {
             const float* bp = a.bias ? a.bias : a.x;
 #pragma unroll
-            for (int n = 0; n < 2; ++n) biasv[n] = bp[a.bias ? n * 16 + li : 0];
+            for (int n = 0; n < NT; ++n) biasv[n] = bp[a.bias ? (n * 16 + li < a.CO ? n * 16 + li : 0) : 0];
         }
 #pragma unroll
         for (int n = 0; n <= ROWS; ++n) hvP[n] = load_row(G0 - 2 + n + sh);     // rr = 0..8: the rows of tap rows 0 and 1
@@ -651,16 +658,16 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
     }
     C3_BARRIER();
 
-    f32x4 acc[4][2], acl[4][2];                       // [pixel tile][channel tile]
+    f32x4 acc[4][NT], acl[4][NT];                     // [pixel tile][channel tile]
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) { acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; acl[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int n = 0; n < NT; ++n) { acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; acl[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     int a_off[5];                                     // A: pixel tile 0 of tap dx (tile m: + 1024 m; lo plane: + PLANE)
 #pragma unroll
     for (int dx = 0; dx < 5; ++dx) a_off[dx] = (li + dx) * 64 + ((g ^ swzb(li + dx)) << 4);
     const unsigned char* b_lane = Wt + li * 64 + ((g ^ swzb(li)) << 4);   // B: channel tile 0 (tile n: + 1024 n; tap dx: + dx * 2 * WPL)
-    uint4 ao[2][4][2], bo[2][2][2];                   // operands, [buffer][tile][plane]: tap (dy, dx) uses buffer (dy + dx) & 1
+    uint4 ao[2][4][2], bo[2][NT][2];                   // operands, [buffer][tile][plane]: tap (dy, dx) uses buffer (dy + dx) & 1
     const bool early = wid >= 4;                      // waves 4..7 (the SIMD partners of waves 0..3) stage at the head of a tap row
 
     // One tap row of depth slice kd (weight set t = 5 kd + dy in buffer wb).
@@ -695,7 +702,7 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
         const unsigned char* wbuf = b_lane + wb * WSET;
         auto load_b = [&](int dx, int q) {
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int n = 0; n < NT; ++n) {
                 bo[q][n][0] = *reinterpret_cast<const uint4*>(wbuf + dx * 2 * WPL + 1024 * n);
                 bo[q][n][1] = *reinterpret_cast<const uint4*>(wbuf + dx * 2 * WPL + 1024 * n + WPL);
             }
@@ -719,7 +726,7 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
                 for (int m = 0; m < 4; ++m) {
                     const f16x8 a1 = __builtin_bit_cast(f16x8, ao[q][m][0]), a2 = __builtin_bit_cast(f16x8, ao[q][m][1]);
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) {
+                    for (int n = 0; n < NT; ++n) {
                         const f16x8 b1 = __builtin_bit_cast(f16x8, bo[q][n][0]), b2 = __builtin_bit_cast(f16x8, bo[q][n][1]);
                         acl[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, acl[m][n], 0, 0, 0);
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, acc[m][n], 0, 0, 0);
@@ -740,11 +747,11 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
         if (has_taps) taps(4, 5);
         // Weight set t + 1 (requested during tap row t - 1) must have landed before the barrier publishes it.  Younger vector-memory
         // operations of this wave: the row requests of this tap row's staging block and its three DMA pieces.
-        if (dy < 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (dy == 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (dy == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (dy < 2) c8_wait_vm<1 + NDMA>();
+        else if (dy == 2) c8_wait_vm<NDMA>();
+        else if (last) c8_wait_vm<0>();
+        else if (dy == 3) c8_wait_vm<9 + NDMA>();
+        else c8_wait_vm<1 + NDMA>();
         if (!(DBG & 8)) {
             // LDS operations complete in order: lgkmcnt(8) leaves the eight prefetched A reads in flight and drains the staging stores
             if (dy < 4) asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
@@ -770,22 +777,22 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
             C3_BARRIER();
         }
     }
-    // ---- epilogue: the wave's [64 px][32 co] tile through LDS (the ring is free after the last barrier), 16-byte stores ----
+    // ---- epilogue: the wave's [64 px][OP] tile through LDS (the ring is free after the last barrier) ----
     float* tb = reinterpret_cast<float*>(ring) + wid * (64 * OP);
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
+        for (int n = 0; n < NT; ++n) {
             const float bias = a.bias ? biasv[n] : 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 tb[(16 * m + 4 * g + q) * OP + n * 16 + li] = (acc[m][n][q] + acl[m][n][q] * (1.f / 2048.f)) * out_scale + bias;
         }
     float vmax = 0.f;
-    if (tvalid) {
+    if (tvalid && a.CO == OP) {                       // full channel tiles: 16-byte stores
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {                 // 512 float4 per wave
-            const int e = lane + n * 64, px = e >> 3, c4 = e & 7;
+        for (int n = 0; n < OP / 4; ++n) {            // 64 * OP / 4 float4 per wave
+            const int e = lane + n * 64, px = e / (OP / 4), c4 = e % (OP / 4);
             float4 v = *reinterpret_cast<const float4*>(&tb[px * OP + c4 * 4]);
             const size_t o4 = ((size_t)gy * W + px) * (OP / 4) + c4;
             if (a.res) { const float4 q = reinterpret_cast<const float4*>(a.res)[o4]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
@@ -800,19 +807,34 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
             vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
             reinterpret_cast<float4*>(a.y)[o4] = v;
         }
+    } else if (tvalid) {                              // CO < OP stored channels per pixel (the thin layers): the row's 64 * CO floats are contiguous
+        const int n_out = 64 * a.CO;
+        for (int e = lane; e < n_out; e += 64) {
+            const int px = e / a.CO, c = e - px * a.CO;
+            float v = tb[px * OP + c];
+            const size_t o = (size_t)gy * W * a.CO + e;
+            if (a.res) v += a.res[o];
+            if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
+            else if (a.epi == SOL_EPI_DLRELU) v *= a.act[o] > 0.f ? 1.f : a.slope;
+            vmax = fmaxf(vmax, fabsf(v));
+            a.y[o] = v;
+        }
     }
     if (a.ymax) amax_publish_last(vmax, a.ymax, reinterpret_cast<unsigned*>(smem_c8 + AMAX_LDS));
 }
 
-constexpr size_t c8_lds() { return (size_t)3 * 5 * 2 * 32 * 64 + (size_t)11 * 2 * 68 * 64 + 16; }
+constexpr size_t c8_lds(int NT) { return (size_t)3 * 5 * 2 * (NT * 16) * 64 + (size_t)11 * 2 * 68 * 64 + 16; }
 
 // fp16 weight planes of all 125 taps with ONE power-of-two scale: header {2^shift_w, 2^-shift_w, 0, 0}, then
 // out[tap = (kd*5 + dy)*5 + dx][plane 2][o 32][chunk s][j] in the LDS image order of the 2-D kernels (k_pack_sh).
 // mode SOL_CONV_BWD_DATA: the flipped kernel with swapped channel axes (w is the FORWARD kernel [125][cout_run][cin_run]).
-__global__ void __launch_bounds__(256) k_pack3_sh(const float* __restrict__ w, float* __restrict__ hdr, unsigned short* __restrict__ out, int mode) {
+__global__ void __launch_bounds__(256) k_pack3_sh(const float* __restrict__ w, float* __restrict__ hdr, unsigned short* __restrict__ out, int mode,
+                                                  int cout_run, int OP) {
+    // run channels: 32 in, cout_run <= OP out (OP = 16 or 32 rows per plane, rows >= cout_run are zero).  FORWARD kernel layout of w:
+    // SOL_CONV_FWD [125][32][cout_run]; SOL_CONV_BWD_DATA [125][cout_run][32] (the forward layer's cin = cout_run)
     __shared__ float red[4];
     float m = 0.f;
-    for (int e = threadIdx.x; e < 125 * 32 * 32; e += 256) m = fmaxf(m, fabsf(w[e]));       // every workgroup finds the same maximum
+    for (int e = threadIdx.x; e < 125 * 32 * cout_run; e += 256) m = fmaxf(m, fabsf(w[e]));       // every workgroup finds the same maximum
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -823,21 +845,21 @@ __global__ void __launch_bounds__(256) k_pack3_sh(const float* __restrict__ w, f
     ex = mb == 0u ? 0 : min(max(ex, -100), 100);
     const float sc = __uint_as_float((unsigned)(14 - ex + 127) << 23), inv = __uint_as_float((unsigned)(ex - 14 + 127) << 23);
     if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[0] = sc; hdr[1] = inv; hdr[2] = 0.f; hdr[3] = 0.f; }
-    const int total = 125 * 32 * 16;                 // pairs of input channels
+    const int total = 125 * OP * 16;                 // pairs of input channels
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const int jp = e & 3, s = (e >> 2) & 3, o = (e >> 4) & 31, tap = e >> 9;
+        const int jp = e & 3, s = (e >> 2) & 3, o = (e >> 4) % OP, tap = e / (16 * OP);
         const int i0 = 8 * (s ^ swzb(o)) + 2 * jp;
         float v[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int i = i0 + q;
-            v[q] = mode == SOL_CONV_FWD ? w[((size_t)tap * 32 + i) * 32 + o] : w[((size_t)(124 - tap) * 32 + o) * 32 + i];
+            v[q] = o >= cout_run ? 0.f : mode == SOL_CONV_FWD ? w[((size_t)tap * 32 + i) * cout_run + o] : w[((size_t)(124 - tap) * cout_run + o) * 32 + i];
         }
         unsigned p[2];
         split2h(v[0], v[1], sc, p[0], p[1]);
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
-            *reinterpret_cast<unsigned*>(out + ((((size_t)tap * 2 + pl) * 32 + o) * 4 + s) * 8 + 2 * jp) = p[pl];
+            *reinterpret_cast<unsigned*>(out + ((((size_t)tap * 2 + pl) * OP + o) * 4 + s) * 8 + 2 * jp) = p[pl];
     }
 }
 
@@ -845,18 +867,18 @@ constexpr size_t c3_lds() { return (size_t)4 * 2 * 68 * 64 + 2 * (size_t)5 * 2 *
 
 }  // namespace
 
-// floats of the fused kernel's weight section: header (4) + 125 taps x 2 planes x 32 x 32 fp16
-size_t sol_conv3d_sh_packed_floats() { return 4 + (size_t)125 * 2 * 32 * 16; }
+// floats of the fused kernel's weight section: header (4) + 125 taps x 2 planes x OP x 32 fp16 (OP = 32, or 16 for cout <= 16)
+size_t sol_conv3d_sh_packed_floats(int cout) { return 4 + (size_t)125 * 2 * (cout <= 16 ? 16 : 32) * 16; }
 
-int sol_conv3d_sh_pack(hipStream_t s, const float* w_dhwio, int mode, float* out) {
-    SOL_LAUNCH(k_pack3_sh, dim3(64), dim3(256), 0, s, w_dhwio, out, reinterpret_cast<unsigned short*>(out + 4), mode);
+int sol_conv3d_sh_pack(hipStream_t s, const float* w_dhwio, int mode, int cout, float* out) {
+    SOL_LAUNCH(k_pack3_sh, dim3(64), dim3(256), 0, s, w_dhwio, out, reinterpret_cast<unsigned short*>(out + 4), mode, cout, cout <= 16 ? 16 : 32);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }
 
 // y = epi(conv3d(x, w) + bias (+ residual)), x / y [nplanes = B*D][H][64][32]; wsh from sol_conv3d_sh_pack; x_absmax required
 int sol_conv3d_sb_launch(hipStream_t s, const float* x, const float* wsh, const float* bias, const float* residual, const float* act_ref, float* y,
-                         int B, int D, int H, int epilogue, float slope, const unsigned* x_absmax, unsigned* y_absmax) {
+                         int B, int D, int H, int cout, int epilogue, float slope, const unsigned* x_absmax, unsigned* y_absmax) {
     static int rc = [] {
         hipFuncAttributes fa;
         if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_conv3d_sb)) != hipSuccess) return -1;
@@ -865,18 +887,26 @@ int sol_conv3d_sb_launch(hipStream_t s, const float* x, const float* wsh, const 
     }();
     SOL_REQUIRE(rc == 0, "hipFuncSetAttribute(k_conv3d_sb) failed");
     ConvArgs a{};
-    a.x = x; a.bias = bias; a.res = residual; a.act = act_ref; a.y = y; a.B = B * D; a.H = H; a.W = 64; a.CO = 32; a.epi = epilogue; a.slope = slope;
+    a.x = x; a.bias = bias; a.res = residual; a.act = act_ref; a.y = y; a.B = B * D; a.H = H; a.W = 64; a.CO = cout; a.epi = epilogue; a.slope = slope;
     a.wsh = wsh; a.xmax = x_absmax; a.ymax = y_absmax; a.tiles_x = 1;
     const int nrows = B * D * H;
+    if (cout <= 16) {                                 // thin layers: the eight-row kernel with one output-channel tile
+        static int rc1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb8<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
+        SOL_REQUIRE(rc1 == 0, "hipFuncSetAttribute(k_conv3d_sb8<1>) failed");
+        const int nt8 = (nrows + 7) / 8, grid8 = (nt8 + 7) / 8 * 8;
+        SOL_LAUNCH((k_conv3d_sb8<1, 0>), dim3(grid8), dim3(512), c8_lds(1), s, a, nrows, D);
+        SOL_LAUNCH_CHECK();
+        return SOL_OK;
+    }
     if (sol_opt().k3d_conv_rows == 8) {               // eight rows per workgroup, 64 x 32 tile per wave, two waves per SIMD
-        static int rc8 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb8<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
+        static int rc8 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb8<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
         SOL_REQUIRE(rc8 == 0, "hipFuncSetAttribute(k_conv3d_sb8) failed");
         const int nt8 = (nrows + 7) / 8, grid8 = (nt8 + 7) / 8 * 8;
-#define C8_DBG(N) case N: { static int rcd = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb8<N>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)rcd; \
-            SOL_LAUNCH(k_conv3d_sb8<N>, dim3(grid8), dim3(512), c8_lds(), s, a, nrows, D); break; }
+#define C8_DBG(N) case N: { static int rcd = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb8<2, N>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)rcd; \
+            SOL_LAUNCH((k_conv3d_sb8<2, N>), dim3(grid8), dim3(512), c8_lds(2), s, a, nrows, D); break; }
         switch (sol_opt().dbg_skip) { C8_DBG(1) C8_DBG(8) C8_DBG(32) C8_DBG(64) C8_DBG(104) default: break; }
         if (sol_opt().dbg_skip) { SOL_LAUNCH_CHECK(); return SOL_OK; }
-        SOL_LAUNCH(k_conv3d_sb8<0>, dim3(grid8), dim3(512), c8_lds(), s, a, nrows, D);
+        SOL_LAUNCH((k_conv3d_sb8<2, 0>), dim3(grid8), dim3(512), c8_lds(2), s, a, nrows, D);
         SOL_LAUNCH_CHECK();
         return SOL_OK;
     }

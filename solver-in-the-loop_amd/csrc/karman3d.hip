@@ -917,10 +917,10 @@ extern "C" int sol_karman3d_correct(void* stream, const float* out, int32_t cout
 // kernels' residual operand); the centre slice runs LAST over all B*D planes and carries bias, activation and the absmax
 // publish.  Same arithmetic per product as the 2-D layers (split fp16 / bf16 MFMA or fp32 MFMA, option conv_precision).
 // ------------------------------------------------------------------------------------------------------------------------
-static bool conv3d_fusable_shape(int cin, int cout) { return cin == 32 && cout == 32; }
-// five 2-D packed buffers (one per depth slice) + for 32 -> 32 layers the fused kernel's weight section (conv3d_sb.hip)
+static bool conv3d_fusable_shape(int cin, int cout) { return cin == 32 && (cout == 32 || cout <= 16); }
+// five 2-D packed buffers (one per depth slice) + for 32 -> 32 and 32 -> (<= 16) layers the one-launch kernel's weight section (conv3d_sb.hip)
 extern "C" size_t sol_conv3d_packed_floats(int32_t cin, int32_t cout) {
-    return 5 * align_up(sol_conv5x5_packed_floats(cin, cout, SOL_CONV_FWD), 64) + (conv3d_fusable_shape(cin, cout) ? sol_conv3d_sh_packed_floats() : 0);
+    return 5 * align_up(sol_conv5x5_packed_floats(cin, cout, SOL_CONV_FWD), 64) + (conv3d_fusable_shape(cin, cout) ? sol_conv3d_sh_packed_floats(cout) : 0);
 }
 
 extern "C" int sol_conv3d_pack(void* stream, const float* w_dhwio, int32_t cin, int32_t cout, int32_t mode, float* packed) {
@@ -933,7 +933,7 @@ extern "C" int sol_conv3d_pack(void* stream, const float* w_dhwio, int32_t cin, 
         const int src = mode == SOL_CONV_FWD ? kd : 4 - kd;
         if (int e = sol_conv5x5_pack(stream, w_dhwio + (size_t)src * 25 * cin * cout, cin, cout, mode, packed + kd * per)) return e;
     }
-    if (conv3d_fusable_shape(cin, cout)) return sol_conv3d_sh_pack((hipStream_t)stream, w_dhwio, mode, packed + 5 * per);
+    if (conv3d_fusable_shape(cin, cout)) return sol_conv3d_sh_pack((hipStream_t)stream, w_dhwio, mode, cout, packed + 5 * per);
     return SOL_OK;
 }
 
@@ -949,7 +949,7 @@ extern "C" int sol_conv3d(void* stream, const float* x, const float* packed, con
     SOL_REQUIRE(cin == cin_k, "sol_conv3d: input channels must be 4 (zero padded) or 32 (got %d)", cin);
     const size_t per = align_up(sol_conv5x5_packed_floats(cin, cout, SOL_CONV_FWD), 64);
     if (conv3d_fusable_shape(cin, cout) && W == 64 && x_absmax && sol_opt().conv_precision == 0 && sol_opt().k3d_conv_fused && residual != y)
-        return sol_conv3d_sb_launch(s, x, packed + 5 * per, bias, residual, act_ref, y, B, D, H, epilogue, slope, x_absmax, y_absmax);
+        return sol_conv3d_sb_launch(s, x, packed + 5 * per, bias, residual, act_ref, y, B, D, H, cout, epilogue, slope, x_absmax, y_absmax);
     const size_t pin = (size_t)H * W * cin, pout = (size_t)H * W * cout;      // floats per plane
     for (int b = 0; b < B; ++b) {
         const float* xb = x + (size_t)b * D * pin;

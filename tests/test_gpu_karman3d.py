@@ -121,6 +121,8 @@ def _oracle_conv(x, w, b, res, lrelu, slope=0.3):
     ((1, 7, 5, 64), 32, 32, False, False),         # H smaller than a workgroup's rows
     ((1, 3, 64, 64), 4, 32, False, True),
     ((1, 3, 64, 64), 32, 3, False, False),
+    ((2, 5, 24, 64), 32, 3, False, False),         # thin output layer in one launch, tiles spanning planes and samples
+    ((1, 4, 64, 64), 32, 4, True, True),           # 32 -> 4 (the first layer's data gradient shape) with residual and activation
 ])
 def test_conv3d_against_oracle(shape, cin, cout, res, lrelu):
     B, D, H, W = shape
@@ -143,8 +145,8 @@ def test_conv3d_against_oracle(shape, cin, cout, res, lrelu):
         assert rel(y, ref) < 2e-6, (use_amax, rel(y, ref))
         pub = float(ymax.max().view(torch.float32))
         assert abs(pub - float(y.abs().max())) <= 1e-6 * pub            # the centre pass publishes max|y| of the finished tensor
-        if use_amax and cin == 32 and cout == 32 and W == 64:
-            # this call ran the one-launch 5x5x5 kernel (conv3d_sb.hip); the five-pass composition must agree with it
+        if use_amax and cin == 32 and W == 64:
+            # this call ran the one-launch 5x5x5 kernel (conv3d_sb.hip; cout = 3: its one-channel-tile form); the five-pass composition must agree with it
             sol_amd._lib.set_option("k3d_conv_fused", 0)
             try:
                 y5 = k3.conv3d(xd, packed, f32(b), f32(r) if res else None, cout, lrelu, 0.3, amax, None)
