@@ -266,6 +266,42 @@ def test_conv3d_gradients_against_oracle(shape, cin, cout, res, lrelu):
         assert rel(hr.grad, r.grad) < 5e-6
 
 
+@pytest.mark.parametrize("cout,res,mode", [(32, True, "lrelu"), (32, True, "dlrelu"), (3, False, "none"), (4, False, "none")])
+def test_conv3d_full_size_one_launch_against_five_pass_and_shift_property(cout, res, mode):
+    """BASELINE configs[4] size (128 x 64 x 64, all 1 024 workgroups and every XCD tile mapping of the one-launch kernel): (i) the
+    one-launch kernel against the five-pass composition of the 2-D kernels (an independent code path held to the float64 oracle
+    at small sizes), (ii) a size-independent property: shifting the input by one (y) plane shifts the output by one plane --
+    bit for bit on the interior planes, since the per-tensor scales are unchanged and every output sees the same products in the
+    same order."""
+    B, D, H, W = 1, 128, 64, 64
+    gen = torch.Generator().manual_seed(5 + cout)
+    x = torch.randn(B, D, H, W, 32, generator=gen, dtype=torch.float32)
+    x[:, :3] = 0
+    x[:, -3:] = 0                                                    # zero planes at both ends: a cyclic roll is a shift
+    x = x.to(DEV)
+    w = (torch.randn(5, 5, 5, 32, cout, generator=gen, dtype=torch.float32) / np.sqrt(125 * 32)).to(DEV)
+    b = torch.randn(cout, generator=gen, dtype=torch.float32).to(DEV)
+    r = torch.randn(B, D, H, W, cout, generator=gen, dtype=torch.float32).to(DEV) if res else None
+    act = torch.randn(B, D, H, W, cout, generator=gen, dtype=torch.float32).to(DEV) if mode == "dlrelu" else None
+    lib = sol_amd.load()
+    packed = torch.empty(lib.sol_conv3d_packed_floats(32, cout), dtype=torch.float32, device=DEV)
+    sol_amd._lib.check(lib.sol_conv3d_pack(sol_amd._lib.stream(), sol_amd._lib.ptr(w), 32, cout, 0, sol_amd._lib.ptr(packed)))
+    amax = sol_amd.ops.absmax_slots(x)
+    run = lambda xx, rr, aa: k3.conv3d(xx, packed, None if mode == "dlrelu" else b, rr, cout, mode == "lrelu", 0.3, amax, None, act_ref=aa)
+    y = run(x, r, act)
+    sol_amd._lib.set_option("k3d_conv_fused", 0)
+    try:
+        y5 = run(x, r, act)
+    finally:
+        sol_amd._lib.set_option("k3d_conv_fused", 1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all() and rel(y, y5) < 1e-6, rel(y, y5)
+    roll = lambda t: None if t is None else torch.roll(t, 1, dims=1).contiguous()
+    ys = run(roll(x), roll(r), roll(act))
+    torch.cuda.synchronize()
+    assert torch.equal(ys[:, 4:-4], torch.roll(y, 1, dims=1)[:, 4:-4])
+
+
 @pytest.mark.parametrize("shape", [(1, 4, 64, 64), (2, 5, 16, 16)])
 def test_network_fused_reverse_sweep_equals_per_layer_autograd(shape):
     """MarsMoon3D as one autograd node (data gradient + skip gradient + LeakyReLU' in the conv epilogues, absmax slots handed
