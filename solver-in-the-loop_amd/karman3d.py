@@ -222,6 +222,12 @@ class MarsMoon3D:
             h = conv3d_fn(a, p[4 + 4 * k], p[5 + 4 * k], h, True, sl, pk[2 + 2 * k])
         return conv3d_fn(h, p[22], p[23], None, False, sl, pk[11])
 
+    def activations(self, x):
+        """The eleven 32-channel activations h0, a1, h1, ..., a5, h5 of the forward pass (no gradient; the same launches as
+        __call__) -- for checks that need the LeakyReLU masks the backward pass will use."""
+        with torch.no_grad():
+            return _MarsMoon3DFn.run_forward(self, x)[3]
+
     @property
     def n_params(self):
         return int(self.offsets[-1])
@@ -360,7 +366,8 @@ class _MarsMoon3DFn(torch.autograd.Function):
     (SOL_EPI_DLRELU) -- the compare / where / multiply / add / absmax passes of the per-layer form are gone."""
 
     @staticmethod
-    def forward(ctx, x, params, net):
+    def run_forward(net, x):
+        """(out, xk, amax, acts): the twelve launches; acts = the eleven 32-channel activations h0, a1, h1, ..., a5, h5"""
         _lib.require_gpu()
         p = [t.detach() for t in net.tensors()]
         pk = net.train_packs()
@@ -373,6 +380,11 @@ class _MarsMoon3DFn(torch.autograd.Function):
             acts.append(a)
             acts.append(conv3d(a, pk[2 + 2 * k][0], p[5 + 4 * k], acts[-2], 32, True, sl, amax[2 * k + 1], amax[2 * k + 2]))
         out = conv3d(acts[-1], pk[11][0], p[23], None, cout, False, sl, amax[10], None)
+        return out, xk, amax, acts
+
+    @staticmethod
+    def forward(ctx, x, params, net):
+        out, xk, amax, acts = _MarsMoon3DFn.run_forward(net, x)
         ctx.net = net
         ctx.save_for_backward(xk, amax, *acts)
         return out
