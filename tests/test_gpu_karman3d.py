@@ -243,6 +243,34 @@ def test_karman3d_step_adjoint_against_oracle_autograd(shape, kw):
     assert not hout[0].requires_grad                      # the density is a passive tracer
 
 
+@pytest.mark.timeout(1500)
+def test_karman3d_full_size_step_adjoint_against_oracle():
+    """BASELINE configs[4] grid: the ADJOINT of one step at 128 x 64 x 64 (diffusion^T, the scatter form of the advection's
+    trilinear gathers with fp32 atomics, the second direct solve of the projection) against autograd through the float64 oracle
+    (DST-preconditioned CG solves forward and backward)."""
+    B, Y, X, Z = 1, 128, 64, 64
+    g = o.geometry(Y, X, Z)
+    d, v = o.synthetic_state(B, Y, X, Z, 4321)
+    re = torch.tensor([o.RE_TRAIN[1]])
+    with torch.no_grad():
+        d, v = o.karman3d_step(d, v, re, g)                       # spin-up: a divergence-free state consistent with the BCs
+    d, v = d.float().double(), tuple(c.float().double() for c in v)
+    gen = torch.Generator().manual_seed(9)
+    w = [torch.randn(c.shape, generator=gen, dtype=torch.float64).float().double() for c in v]
+    vr = tuple(c.clone().requires_grad_(True) for c in v)
+    _, out = o.karman3d_step(d, vr, re, g)
+    sum((a * b).sum() for a, b in zip(out, w)).backward()
+    sc = k3.Scene3D(Y, X, Z, device=DEV)
+    sim = k3.Karman3DFlow(sc, B)
+    hv = [f32(c).requires_grad_(True) for c in v]
+    hout = sim.step(f32(d), hv[0], hv[1], hv[2], f32(re))
+    assert max(rel(a, b) for a, b in zip(hout[1:], out)) < TOL_FIELD
+    sum((a * f32(b)).sum() for a, b in zip(hout[1:], w)).backward()
+    torch.cuda.synchronize()
+    errs = [rel(a.grad, b.grad) for a, b in zip(hv, vr)]
+    assert max(errs) < TOL_GRAD, errs
+
+
 @pytest.mark.parametrize("shape,cin,cout,res,lrelu", [
     ((1, 5, 16, 16), 4, 32, False, True), ((2, 4, 16, 16), 32, 32, True, True), ((1, 4, 16, 16), 32, 3, False, False),
     ((1, 3, 64, 64), 32, 32, True, True), ((1, 3, 64, 64), 32, 3, False, False), ((1, 3, 64, 64), 4, 32, False, True)])
