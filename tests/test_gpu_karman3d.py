@@ -243,6 +243,41 @@ def test_karman3d_step_adjoint_against_oracle_autograd(shape, kw):
     assert not hout[0].requires_grad                      # the density is a passive tracer
 
 
+def test_karman3d_step_adjoint_identity_by_finite_differences():
+    """<J u, w> = <u, J^T w> for the 3-D step at 128 x 64 x 64 with the HIP forward on both sides (central differences of the forward
+    kernels against the adjoint kernels; no oracle involved).  fp32 differences limit the agreement to ~1e-3."""
+    from sol_amd import synthetic
+    B, Y, X, Z = 1, 128, 64, 64
+    sc = k3.Scene3D(Y, X, Z, device=DEV)
+    sim = k3.Karman3DFlow(sc, B)
+    gen = torch.Generator().manual_seed(23)
+    rn = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float32)
+    st = (torch.rand(B, Y, X, Z, generator=gen).to(DEV), (1.0 + 0.1 * rn(B, Y + 1, X, Z)).to(DEV), (0.1 * rn(B, Y, X + 1, Z)).to(DEV), (0.1 * rn(B, Y, X, Z + 1)).to(DEV))
+    re = synthetic.reynolds(B).float().to(DEV)
+    with torch.no_grad():
+        for _ in range(2):
+            st = sim.step(*st, re)
+    d0, v = st[0], [t.clone() for t in st[1:]]
+    smooth = lambda t: torch.nn.functional.avg_pool3d(t[:, None], 5, 1, 2)[:, 0]
+    u = [smooth(rn(*t.shape)).to(DEV) for t in v]
+    w = [rn(*t.shape).to(DEV) for t in v]
+    a = [t.clone().requires_grad_(True) for t in v]
+    out = sim.step(d0, a[0], a[1], a[2], re)
+    sum((o_ * w_).sum() for o_, w_ in zip(out[1:], w)).backward()
+    dot = lambda xs, ys: float(sum((x.double() * y.double()).sum() for x, y in zip(xs, ys)))
+    rhs = dot([t.grad for t in a], u)
+    res = {}
+    for eps in (2e-2, 1e-2, 5e-3):
+        with torch.no_grad():
+            p = sim.step(d0, *[t + eps * du for t, du in zip(v, u)], re)[1:]
+            m = sim.step(d0, *[t - eps * du for t, du in zip(v, u)], re)[1:]
+        res[eps] = dot([x.double() - y.double() for x, y in zip(p, m)], w) / (2 * eps)
+    torch.cuda.synchronize()
+    scale = dot([t.grad for t in a], [t.grad for t in a]) ** 0.5 * dot(u, u) ** 0.5
+    print("adjoint identity 3-D: <u, J^T w> = %.6e, <J u, w> by central differences %s, |u||J^T w| = %.3e" % (rhs, res, scale))
+    assert min(abs(x - rhs) for x in res.values()) < 2e-3 * abs(rhs) + 2e-4 * scale, (rhs, res, scale)
+
+
 @pytest.mark.timeout(1500)
 def test_karman3d_full_size_step_adjoint_against_oracle():
     """BASELINE configs[4] grid: the ADJOINT of one step at 128 x 64 x 64 (diffusion^T, the scatter form of the advection's

@@ -405,6 +405,43 @@ def test_mars_moon_network_full_size_against_torch_float64_autograd():
     assert e_out < 5e-6 and e_x < 1e-5 and max(per[0::2]) < 3e-5 and max(per[1::2]) < 1e-4, (e_out, e_x, per)
 
 
+def test_karman_step_adjoint_identity_by_finite_differences():
+    """<J u, w> = <u, J^T w> for the fused step at 128 x 64 with the HIP forward on both sides: J u from central differences of
+    the forward kernel, J^T w from the adjoint kernel.  No oracle involved -- the adjoint must be the adjoint of THIS forward
+    (semi-Lagrangian gathers, diffusion, projection).  fp32 differences limit the agreement to ~1e-3."""
+    from sol_amd import ops, synthetic
+    B, Y, X = 2, 128, 64
+    dom = sol_amd.Domain([Y, X], box=sol_amd.box[0:200, 0:100])
+    active, inflow = sol_amd.KarmanFlow().scene_arrays(dom)
+    bcv, bcm = sol_amd.velocity_bc_masks(Y, X)
+    masks = ops.SceneMasks(active, inflow, bcv.reshape(Y + 1, X), bcm.reshape(Y + 1, X), DEV)
+    cfg = ops.karman_cfg(B, Y, X, dom.dx[1], masks=masks)
+    d0, vy, vx = (f32(t) for t in synthetic.state(B, Y, X, 99))
+    re = f32(synthetic.reynolds(B))
+    with torch.no_grad():
+        for _ in range(2):                            # spin-up: smooth, divergence free, consistent with the BCs
+            d0, vy, vx = ops.karman_step(d0, vy, vx, re, cfg, masks)
+    gen = torch.Generator().manual_seed(17)
+    smooth = lambda t: torch.nn.functional.avg_pool2d(t[:, None], 5, 1, 2)[:, 0]
+    uy, ux = f32(smooth(torch.randn(vy.shape, generator=gen))), f32(smooth(torch.randn(vx.shape, generator=gen)))
+    wy, wx = f32(torch.randn(vy.shape, generator=gen)), f32(torch.randn(vx.shape, generator=gen))
+    ay, ax = vy.clone().requires_grad_(True), vx.clone().requires_grad_(True)
+    _, py, px = ops.karman_step(d0, ay, ax, re, cfg, masks)
+    ((py * wy).sum() + (px * wx).sum()).backward()
+    rhs = float((ay.grad.double() * uy.double()).sum() + (ax.grad.double() * ux.double()).sum())
+    res = {}
+    for eps in (2e-2, 1e-2, 5e-3):
+        with torch.no_grad():
+            _, p1y, p1x = ops.karman_step(d0, vy + eps * uy, vx + eps * ux, re, cfg, masks)
+            _, m1y, m1x = ops.karman_step(d0, vy - eps * uy, vx - eps * ux, re, cfg, masks)
+        lhs = float((((p1y.double() - m1y.double()) * wy.double()).sum() + ((p1x.double() - m1x.double()) * wx.double()).sum()) / (2 * eps))
+        res[eps] = lhs
+    torch.cuda.synchronize()
+    scale = float((ay.grad.double().norm() ** 2 + ax.grad.double().norm() ** 2).sqrt() * (uy.double().norm() ** 2 + ux.double().norm() ** 2).sqrt())
+    print("adjoint identity: <u, J^T w> = %.6e, <J u, w> by central differences %s, |u||J^T w| = %.3e" % (rhs, res, scale))
+    assert min(abs(v - rhs) for v in res.values()) < 2e-3 * abs(rhs) + 2e-4 * scale, (rhs, res, scale)
+
+
 def test_per_op_autograd_path_equals_fused_trainer():
     """The reference-shaped Python surface (KarmanFlow.step, to_feature, model, to_staggered) composed
     with torch autograd must give the same loss and gradient as the fused C++ training step."""
