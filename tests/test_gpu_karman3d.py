@@ -441,6 +441,53 @@ def test_network_fused_reverse_sweep_equals_per_layer_autograd(shape):
     assert max(per) < 1e-5, per
 
 
+def test_karman3d_training_step_gradient_by_finite_differences():
+    """d loss / d weights of the SOL-2 3-D training step (32 x 16 x 16, B = 2) along a random direction in parameter space against
+    central differences of the same engine's loss -- no oracle.  fp32 losses limit the agreement to ~1e-3."""
+    from sol_amd import synthetic
+    B, Y, X, Z, ms = 2, 32, 16, 16, 2
+    sc = k3.Scene3D(Y, X, Z, device=DEV)
+    net = k3.MarsMoon3D(seed=4, device=DEV)
+    w = net.get_weights()
+    w[22] = w[22] * 0.1
+    net.set_weights(w)
+    tr = k3.Karman3DTrainer(net, sc, B, ms, (0.2, 0.2, 0.2), synthetic.STD_RE)
+    gen = torch.Generator().manual_seed(8)
+    rn = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float32)
+    st = (torch.rand(B, Y, X, Z, generator=gen).to(DEV), (1.0 + 0.1 * rn(B, Y + 1, X, Z)).to(DEV), (0.1 * rn(B, Y, X + 1, Z)).to(DEV), (0.1 * rn(B, Y, X, Z + 1)).to(DEV))
+    re = synthetic.reynolds(B).float().to(DEV)
+    gts = []
+    with torch.no_grad():
+        st = tr.sim.step(*st, re)
+        gs = (st[0], st[1] + 0.02, st[2], st[3])
+        for _ in range(ms):
+            gs = tr.sim.step(*gs, re)
+            gts.append(tuple(t.clone() for t in gs[1:]))
+    loss = float(tr.fwd_bwd(*st, re, gts))
+    g = tr.grads.detach().double().clone()
+    u = torch.zeros(net.n_params, dtype=torch.float64)
+    for k in range(len(net.shapes)):
+        sl = slice(int(net.offsets[k]), int(net.offsets[k + 1]))
+        wk = net.params.detach()[sl].double().cpu()
+        u[sl] = torch.randn(wk.numel(), generator=gen, dtype=torch.float64) * (float(wk.abs().mean()) + 1e-3)
+    u = u.to(DEV)
+    rhs = float((g * u).sum())
+    p0 = net.params.detach().clone()
+    res = {}
+    for eps in (3e-2, 1e-2, 3e-3):
+        vals = []
+        for sgn in (1.0, -1.0):
+            with torch.no_grad():
+                net.params.copy_((p0.double() + sgn * eps * u).float())
+            net._tpacks = None
+            vals.append(float(tr.fwd_bwd(*st, re, gts)))
+        res[eps] = (vals[0] - vals[1]) / (2 * eps)
+    with torch.no_grad():
+        net.params.copy_(p0)
+    print("3-D training-step gradient: loss %.6e, <grad, u> = %.6e, central differences %s" % (loss, rhs, res))
+    assert min(abs(v - rhs) for v in res.values()) < 3e-3 * abs(rhs), (rhs, res)
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_karman3d_trainer_sol2_against_oracle(use_graph):
     """SOL-2 at 32 x 16 x 16, B = 2: loss, the full 1.3 M-element gradient and one TF-Adam update against the float64 oracle

@@ -442,6 +442,41 @@ def test_karman_step_adjoint_identity_by_finite_differences():
     assert min(abs(v - rhs) for v in res.values()) < 2e-3 * abs(rhs) + 2e-4 * scale, (rhs, res, scale)
 
 
+def test_training_step_gradient_by_finite_differences():
+    """d loss / d weights of the fused SOL-4 training step (64 x 32, B = 3: forward unroll, reverse sweep through solver adjoints and
+    network) along a random direction in parameter space against central differences of the SAME engine's loss -- no oracle.
+    The direction is scaled per tensor to the weights' magnitude; fp32 losses limit the agreement to ~1e-3."""
+    import bench
+    dev = torch.device(DEV)
+    wl = bench.Workload(sol_amd, dev, 3, 64, 32, 4, 0, use_graph=False)      # the bench workload's construction at the reference's recipe size
+    tr, net = wl.trainer, wl.net
+    args = (wl.d0, wl.vy0, wl.vx0, wl.re, wl.gt_vy, wl.gt_vx)
+    loss = float(tr.fwd_bwd(*args))
+    g = tr.grads.detach().double().clone()
+    gen = torch.Generator().manual_seed(3)
+    u = torch.zeros(net.n_params, dtype=torch.float64)
+    for k in range(len(net.shapes)):
+        sl = slice(int(net.offsets[k]), int(net.offsets[k + 1]))
+        wk = net.params.detach()[sl].double().cpu()
+        u[sl] = torch.randn(wk.numel(), generator=gen, dtype=torch.float64) * (float(wk.abs().mean()) + 1e-3)
+    u = u.to(dev)
+    rhs = float((g * u).sum())
+    p0 = net.params.detach().clone()
+    res = {}
+    for eps in (3e-2, 1e-2, 3e-3):
+        with torch.no_grad():
+            net.params.copy_((p0.double() + eps * u).float())
+        lp = float(tr.fwd_bwd(*args))
+        with torch.no_grad():
+            net.params.copy_((p0.double() - eps * u).float())
+        lm = float(tr.fwd_bwd(*args))
+        res[eps] = (lp - lm) / (2 * eps)
+    with torch.no_grad():
+        net.params.copy_(p0)
+    print("training-step gradient: loss %.6e, <grad, u> = %.6e, central differences %s" % (loss, rhs, res))
+    assert min(abs(v - rhs) for v in res.values()) < 3e-3 * abs(rhs), (rhs, res)
+
+
 def test_per_op_autograd_path_equals_fused_trainer():
     """The reference-shaped Python surface (KarmanFlow.step, to_feature, model, to_staggered) composed
     with torch autograd must give the same loss and gradient as the fused C++ training step."""
