@@ -195,6 +195,12 @@ def karman3d_leg(sol_amd, dev, B=1, steps=8):
     b.record()
     torch.cuda.synchronize()
     ms_step = a.elapsed_time(b) / steps
+    a.record()
+    for _ in range(steps):
+        ro.correction()
+    b.record()
+    torch.cuda.synchronize()
+    ms_cnn = a.elapsed_time(b) / steps               # the twelve CNN launches back to back (warm caches)
     with _lib.profile() as p:
         ro.step(*st, re)
     N = Y * X * Z
@@ -211,6 +217,18 @@ def karman3d_leg(sol_amd, dev, B=1, steps=8):
             e["frac_of_hbm_peak"] = e["algorithmic_GBps"] / PEAK_HBM_GBS
         kern[nm] = e
     flop = 2.0 * 125 * (4 * 32 + 10 * 32 * 32 + 32 * 3) * B * N
+    # roofline of the dominant 3-D kernel (the one-launch 32 -> 32 Conv3D): algorithmic fp32 FLOP / event time / the 16-bit matrix peak
+    roof3 = None
+    for nm, e in kern.items():
+        if nm.startswith("k_conv3d_sb") and "<1" not in nm:
+            fl = 2.0 * 125 * 32 * 32 * B * N
+            roof3 = {"kernel": nm, "bound": "mfma", "achieved": fl / (e["avg_us"] * 1e-6) / 1e12, "peak": PEAK_MFMA16_TF, "unit": "TFLOP/s",
+                     "launch_us": e["avg_us"], "algorithmic_fp32_flop_per_launch": fl}
+            roof3["frac"] = roof3["achieved"] / roof3["peak"]
+            roof3["mfma_pipe_busy"] = 3.0 * roof3["frac"]
+            roof3["note"] = ("launch_us from per-launch HIP events with a synchronisation after every launch (cold operands); back to back the twelve "
+                             "launches of a CNN pass take cnn_ms_back_to_back (tools/k3d_time.py: 279-292 us per 32 -> 32 launch)")
+            break
     t_cnn = sum(t for k, (c, t) in p.kernels.items() if "conv" in k or k == "k3_fill")
     # SOL-16 training step (BASELINE configs[4]: forward unroll, loss, reverse sweep through the HIP adjoints, TF-Adam)
     train = None
@@ -243,7 +261,7 @@ def karman3d_leg(sol_amd, dev, B=1, steps=8):
     return {"train_sol16": train,"workload": "karman-3d %dx%dx%d, batch %d, forward roll-out (solver step + Conv3D(5) mars_moon correction; BASELINE configs[4] grid)" % (Y, X, Z, B),
             "ms_per_sim_step": ms_step, "sim_steps_per_s": B * 1e3 / ms_step, "finite": bool(torch.isfinite(s2[1]).all()),
             "cnn_fp32_equiv_TFLOPs": flop / (t_cnn * 1e-6) / 1e12, "solver_us": sum(t for k, (c, t) in p.kernels.items() if "conv" not in k and k not in ("k3_fill", "k3_correct")),
-            "kernels": kern}
+            "cnn_ms_back_to_back": ms_cnn, "cnn_fp32_equiv_TFLOPs_back_to_back": flop / (ms_cnn * 1e-3) / 1e12, "roofline": roof3, "kernels": kern}
 
 
 def karman3d_dp_leg(sol_amd, dev, world, barrier):
