@@ -389,15 +389,17 @@ int sol_karman3d_correct(void* stream, const float* out, int32_t cout, float s0,
                          float* vy, float* vx, float* vz, int32_t B, int32_t Y, int32_t X, int32_t Z);
 
 /* 5 x 5 x 5 SAME convolution, NDHWC fp32 (keras.layers.Conv3D(filters, 5, padding='same') + bias / LeakyReLU / add).
- * w_dhwio [5,5,5,cin,cout] (Keras layout, D = y).  Runs as five passes of the 2-D kernels over the (H, W) planes with the
- * running sum in y, the centre slice last (bias, activation, absmax publish): same per-product arithmetic as sol_conv5x5.
+ * w_dhwio [5,5,5,cin,cout] (Keras layout, D = y).  Layers with cin = 32 and cout = 32 or <= 16 on W == 64 with x_absmax given run as
+ * ONE launch that keeps its accumulators over all 125 taps (conv3d_sb.hip; options k3d_conv_fused, k3d_conv_rows); everything
+ * else runs as five passes of the 2-D kernels over the (H, W) planes with the running sum in y, the centre slice last (bias,
+ * activation, absmax publish).  Same per-product arithmetic as sol_conv5x5 in both forms.
  * x [B,D,H,W,cin] with cin in {4 (zero padded), 32}; residual [B,D,H,W,cout] or NULL is added before the activation;
  * epilogue SOL_EPI_NONE / SOL_EPI_LRELU / SOL_EPI_DLRELU (times LeakyReLU'(act_ref), act_ref [B,D,H,W,cout]: the backward pass'
  * "data gradient (+ skip gradient) times the activation derivative" in one launch; act_ref NULL otherwise); x_absmax / y_absmax
  * as in sol_conv5x5_scaled (may be NULL).  x != y, D >= 3.
  * Backward-data is the same entry point on weights packed with mode SOL_CONV_BWD_DATA (cin = channels of dy = the forward
  * layer's cout, cout = channels of dx = the forward layer's cin; w_dhwio is the FORWARD kernel): dx = conv3d(dy, flip(w)^T).
- * The weight gradient is five calls of sol_conv5x5_bwd_weight on the shifted plane ranges (ops composed on the host). */
+ * The weight gradient: sol_conv3d_bwd_weight below. */
 size_t sol_conv3d_packed_floats(int32_t cin, int32_t cout);
 int sol_conv3d_pack(void* stream, const float* w_dhwio, int32_t cin, int32_t cout, int32_t mode, float* packed);
 int sol_conv3d(void* stream, const float* x, const float* packed, const float* bias, const float* residual, const float* act_ref, float* y,

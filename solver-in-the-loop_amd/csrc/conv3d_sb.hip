@@ -12,7 +12,11 @@
 // weight sets of slice kd + 1 are REQUESTED during tap rows 3 and 4 of slice kd, so that the only exposed cost of a slice
 // boundary is one LDS write round + barrier.  One prologue round trip and one epilogue per 125 taps instead of per 25.
 //
-// Work decomposition, operand layout (ds_read_b128 fragments, XOR swizzle), epilogue: as k_conv5x5_sb<2, 2>.
+// Work decomposition, operand layout (ds_read_b128 fragments, XOR swizzle), epilogue of the first form: as k_conv5x5_sb<2, 2>.
+// Three forms live here (option k3d_conv_rows; DESIGN.md 4.8 has the measurements that led from one to the next):
+//   k_conv3d_sb          3 rows per workgroup, 16 px x 32 co per wave, 12 waves     412 us per launch at 128 x 64 x 64
+//   k_conv3d_sb6         6 rows, 32 x 32, 12 waves, padded strides, LDS-DMA weights 334 us
+//   k_conv3d_sb8<NT>     8 rows, 64 x (16 NT), 8 waves, operand prefetch            279-292 us (default; NT = 1: the thin 32 -> 3 / 4 layers)
 #include "split_kernels.hpp"
 
 namespace {
@@ -266,10 +270,11 @@ __global__ void __launch_bounds__(768) k_conv3d_sb(ConvArgs a, int nrows, int D)
 // both: 8 reads (4 A + 4 B) per 12 MFMAs -- one third less LDS traffic per matrix instruction.  With three rows per workgroup that
 // would leave six waves for four SIMDs (why the 2-D kernel cannot do it at 768 rows); the 3-D launches have 8 192 rows per
 // simulation, so six rows per workgroup still fill the chip five times over.  12 waves: wave = (row r = wid / 2, pixel half).
-// Input rows live in an 8-slot ring (row G0-2+rr in slot rr & 7: six live rows + the incoming one); everything else -- split
-// staging, double-buffered tap-row weight sets, next-slice prefetch during tap rows 3 / 4, one LDS-only barrier per five taps,
-// epilogue through LDS -- as above.  The residual is read straight from global memory in the epilogue (no LDS-DMA region: the
-// ring takes 70 KB).
+// Input rows live in an 8-slot ring (row G0-2+rr in slot rr & 7: six live rows + the incoming one) with a padded 160-byte pixel
+// stride (operand addresses = one VGPR + immediates, see the kernel body); the tap-row weight sets arrive by LDS-DMA into three
+// rotating buffers; split staging of the rows, next-slice prefetch during tap rows 3 / 4, one LDS-only barrier per five taps and
+// the epilogue through LDS are as above.  The residual is read straight from global memory in the epilogue.
+// Kept as option k3d_conv_rows = 6 (the default is the eight-row kernel below) and as the subject of tools/c6_phase_probe.py.
 // ------------------------------------------------------------------------------------------------------------------------
 // -DSOL_C6_PROF (tools/c6_phase_probe.py builds such a library next to the product one): per-wave s_memtime stamps (low 32 bits,
 // kept in LDS, dumped at the end) -- 8 per tap row -- into the buffer set with sol_c6_prof_set().
