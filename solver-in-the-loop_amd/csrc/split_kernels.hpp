@@ -71,6 +71,9 @@ __device__ __forceinline__ void split2u(float x, float y, float scale, unsigned&
 // renaming (dx even) -- no unaligned LDS access and the x operand is reused for all five tap rows.
 // LDS rows: x 16 chunks of 16 B per channel (68 px used), chunk ^= ci & 15; dz 8 chunks, chunk ^= (co >> 1) & 7
 // (both conflict-free for the CDNA4 ds_read_b128 lane groups).
+#ifndef BWW_B_UPFRONT
+#define BWW_B_UPFRONT 1
+#endif
 constexpr int BW_XPL = 32 * 256;                          // bytes: x plane of one row stage
 constexpr int BW_ZPL = 32 * 128;                          // bytes: dz plane of one row stage
 constexpr int BW_LDS = 2 * 3 * BW_XPL + 6 * 3 * BW_ZPL;   // 122,880 B (three planes; also >= the 102,400 B fold buffer)
@@ -225,32 +228,59 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
                                       __builtin_amdgcn_alignbit(e.x, q.w, 16), __builtin_amdgcn_alignbit(e.y, e.x, 16));
             }
         }
+        if constexpr (KIND == 2 && BWW_B_UPFRONT) {
+            // the dz fragments of ALL five tap rows are read with the x fragments at the head of the row (40 VGPRs): one exposed LDS
+            // round trip per row instead of one per tap row in front of every group of 15 MFMAs (rows outside the image: the read
+            // hits a valid ring slot and is dropped)
+            uint4 Bv[5][NPL];
 #pragma unroll
-        for (int dy = 0; dy < 5; ++dy) {
-            const int yz = y + 2 - dy;
-            if (yz < 0 || yz >= H) continue;            // workgroup uniform
-            const int gz = gr + 2 - dy;
-            const unsigned char* zs = ZS + ((gz + 6) % 6) * BW_ZST + (16 * nt + li) * 128 + ((c0 ^ ((li >> 1) & 7)) << 4);
-            uint4 Bv[NPL];
+            for (int dy = 0; dy < 5; ++dy) {
+                const int gz = gr + 2 - dy;
+                const unsigned char* zs = ZS + ((gz + 6) % 6) * BW_ZST + (16 * nt + li) * 128 + ((c0 ^ ((li >> 1) & 7)) << 4);
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) Bv[pl] = *reinterpret_cast<const uint4*>(zs + pl * BW_ZPL);
-            if constexpr (KIND == 2) {
+                for (int pl = 0; pl < NPL; ++pl) Bv[dy][pl] = *reinterpret_cast<const uint4*>(zs + pl * BW_ZPL);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dy = 0; dy < 5; ++dy) {
+                const int yz = y + 2 - dy;
+                if (yz < 0 || yz >= H) continue;        // workgroup uniform
                 constexpr int QA[3] = {1, 0, 0}, QB[3] = {0, 1, 0};     // a2 b1, a1 b2, a1 b1
 #pragma unroll
                 for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
                     for (int dx = 0; dx < 5; ++dx)
-                        acc[dy * 5 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[QA[pr]][dx]), __builtin_bit_cast(f16x8, Bv[QB[pr]]),
+                        acc[dy * 5 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[QA[pr]][dx]), __builtin_bit_cast(f16x8, Bv[dy][QB[pr]]),
                                                                                   acc[dy * 5 + dx], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int pr = 0; pr < 6; ++pr)
-#pragma unroll
-                    for (int dx = 0; dx < 5; ++dx)
-                        acc[dy * 5 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[PA[pr]][dx]), __builtin_bit_cast(bf16x8, Bv[PB[pr]]),
-                                                                                   acc[dy * 5 + dx], 0, 0, 0);
             }
-        }
+        } else {
+#pragma unroll
+            for (int dy = 0; dy < 5; ++dy) {
+                const int yz = y + 2 - dy;
+                if (yz < 0 || yz >= H) continue;            // workgroup uniform
+                const int gz = gr + 2 - dy;
+                const unsigned char* zs = ZS + ((gz + 6) % 6) * BW_ZST + (16 * nt + li) * 128 + ((c0 ^ ((li >> 1) & 7)) << 4);
+                uint4 Bv[NPL];
+    #pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) Bv[pl] = *reinterpret_cast<const uint4*>(zs + pl * BW_ZPL);
+                if constexpr (KIND == 2) {
+                    constexpr int QA[3] = {1, 0, 0}, QB[3] = {0, 1, 0};     // a2 b1, a1 b2, a1 b1
+    #pragma unroll
+                    for (int pr = 0; pr < 3; ++pr)
+    #pragma unroll
+                        for (int dx = 0; dx < 5; ++dx)
+                            acc[dy * 5 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[QA[pr]][dx]), __builtin_bit_cast(f16x8, Bv[QB[pr]]),
+                                                                                      acc[dy * 5 + dx], 0, 0, 0);
+                } else {
+    #pragma unroll
+                    for (int pr = 0; pr < 6; ++pr)
+    #pragma unroll
+                        for (int dx = 0; dx < 5; ++dx)
+                            acc[dy * 5 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[PA[pr]][dx]), __builtin_bit_cast(bf16x8, Bv[PB[pr]]),
+                                                                                       acc[dy * 5 + dx], 0, 0, 0);
+                }
+            }
+}
         __builtin_amdgcn_sched_barrier(0);
         if (xrole ? gr + 1 < r1 : z_in_range(gr + 3)) stage(gr + 1, gr + 3, o0, o1);
         BW_BARRIER();
