@@ -19,6 +19,8 @@ _LIB.define("karman_step(Tensor d, Tensor vy, Tensor vx, Tensor re, int scene) -
 _LIB.define("karman_step_bwd(Tensor svy, Tensor svx, Tensor re, Tensor gvy, Tensor gvx, int scene) -> (Tensor, Tensor)")
 _LIB.define("karman_step_fwd_saved(Tensor d, Tensor vy, Tensor vx, Tensor re, int scene) -> (Tensor, Tensor, Tensor, Tensor, Tensor)")
 _LIB.define("conv5x5(Tensor x, Tensor w, Tensor b, Tensor? residual, bool lrelu, float slope) -> Tensor")
+_LIB.define("karman3d_step(Tensor d, Tensor vy, Tensor vx, Tensor vz, Tensor re, int scene) -> (Tensor, Tensor, Tensor, Tensor)")
+_LIB.define("conv3d(Tensor x, Tensor w, Tensor b, Tensor? residual, bool lrelu, float slope) -> Tensor")
 _LIB.define("burgers_step(Tensor vy, Tensor vx, Tensor? fy, Tensor? fx, float dx, float dt, float nu) -> (Tensor, Tensor)")
 _LIB.define("adam_tf_step(Tensor(a!) params, Tensor grads, Tensor(b!) m, Tensor(c!) v, int t, float lr, float beta1, float beta2, float eps) -> ()")
 
@@ -101,3 +103,28 @@ def _adam(params, grads, m, v, t, lr, beta1, beta2, eps):
 
 
 _LIB.impl("adam_tf_step", _adam, "CUDA")
+
+
+# ---- karman-3d (BASELINE configs[4]): the step with its hand-written adjoint and Conv3D(5) with forward / backward-data / weight gradient ----
+_SIMS3D = {}
+
+
+def register_scene3d(sim):
+    """-> handle of a karman3d.Karman3DFlow (scene + direct-solver blob + workspace) for torch.ops.sol.karman3d_step."""
+    h = len(_SIMS3D) + 1
+    _SIMS3D[h] = sim
+    return h
+
+
+def _karman3d_step(d, vy, vx, vz, re, scene):
+    from . import karman3d as k3
+    return k3._Karman3DStepFn.apply(_SIMS3D[scene], _lib.f32(d), _lib.f32(vy), _lib.f32(vx), _lib.f32(vz), _lib.f32(re))
+
+
+def _conv3d(x, w, b, residual, lrelu, slope):
+    from . import karman3d as k3
+    return k3._Conv3DFn.apply(x, w, b, residual, lrelu, slope, None)
+
+
+_LIB.impl("karman3d_step", _karman3d_step, "AutogradCUDA")
+_LIB.impl("conv3d", _conv3d, "AutogradCUDA")

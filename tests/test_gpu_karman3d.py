@@ -562,6 +562,35 @@ def test_karman3d_data_parallel_two_ranks_one_gpu(tmp_path):
     assert rel(torch.as_tensor(r0["params"]), torch.as_tensor(params)) < 1e-5
 
 
+def test_torch_library_ops_3d_are_registered_and_differentiable(scene_small):
+    """torch.ops.sol.karman3d_step / conv3d: the dispatcher entries run the same C-ABI entry points and hand-written adjoints as the
+    module-level functions (bit-equal outputs and gradients)."""
+    import sol_amd.torch_ops as tops
+    B, Y, X, Z = 2, 32, 16, 16
+    d, v = o.synthetic_state(B, Y, X, Z, 3)
+    re = f32(torch.tensor(o.RE_TRAIN[:B]))
+    sim = k3.Karman3DFlow(scene_small, B)
+    h = tops.register_scene3d(sim)
+    res = []
+    for use_op in (True, False):
+        hv = [f32(c).requires_grad_(True) for c in v]
+        out = torch.ops.sol.karman3d_step(f32(d), hv[0], hv[1], hv[2], re, h) if use_op else sim.step(f32(d), hv[0], hv[1], hv[2], re)
+        (out[1].sum() + 2 * out[2].sum() - out[3].sum()).backward()
+        res.append(([t.detach() for t in out], [t.grad for t in hv]))
+    assert all(torch.equal(a, b) for a, b in zip(res[0][0], res[1][0]))
+    assert all(rel(a, b) < 1e-6 for a, b in zip(res[0][1], res[1][1]))            # (the advection adjoint scatters with fp32 atomics)
+    x = torch.randn(1, 4, 16, 16, 32, device=DEV, dtype=torch.float32, requires_grad=True)
+    w = (torch.randn(5, 5, 5, 32, 32, device=DEV, dtype=torch.float32) * 0.02).requires_grad_(True)
+    b = torch.zeros(32, device=DEV, dtype=torch.float32, requires_grad=True)
+    y1 = torch.ops.sol.conv3d(x, w, b, None, True, 0.3)
+    y1.square().sum().backward()
+    gx1, gw1 = x.grad.clone(), w.grad.clone()
+    x.grad = w.grad = b.grad = None
+    y2 = k3.conv3d_fn(x, w, b, None, True, 0.3)
+    y2.square().sum().backward()
+    assert torch.equal(y1, y2) and torch.equal(gx1, x.grad) and torch.equal(gw1, w.grad)
+
+
 def test_karman3d_script(tmp_path):
     """scripts/karman3d.py: data generation at 16 x 8 x 8, a SOL-2 training demo on those frames, and a corrected roll-out
     with the model it wrote."""
