@@ -74,6 +74,9 @@ __device__ __forceinline__ void split2u(float x, float y, float scale, unsigned&
 #ifndef BWW_B_UPFRONT
 #define BWW_B_UPFRONT 1
 #endif
+#ifndef BWW_DBG        // timing experiments (tools/ab_lib.py variants + tools/bww3d_time.py; results invalid): 1 no MFMAs, 2 no staging (the
+#define BWW_DBG 0      // requests die with it), 4 no row barrier, 8 no requests.  Measured per 32 -> 32 Conv3D layer at 128 x 64 x 64 (five
+#endif                 // passes + reduce, 464 us): 187 / 345 / 404 / 354 us; staging interleaved into the MFMA stream (branch-free, one basic block): 460 us
 constexpr int BW_XPL = 32 * 256;                          // bytes: x plane of one row stage
 constexpr int BW_ZPL = 32 * 128;                          // bytes: dz plane of one row stage
 constexpr int BW_LDS = 2 * 3 * BW_XPL + 6 * 3 * BW_ZPL;   // 122,880 B (three planes; also >= the 102,400 B fold buffer)
@@ -130,6 +133,7 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
         typedef const f32x4 __attribute__((address_space(1)))* gf4p;
         const int rr = gr >= 0 && gr < R ? gr : r0, seg = rr / RPS, grs = rr - seg * RPS;
         gf4p rp = (gf4p)(role_base + ((unsigned long long)seg * role_seg + (unsigned long long)grs * W * 32) * sizeof(float));
+        if (BWW_DBG & 8) { v0 = v1 = make_float4(1e-3f, 2e-3f, -1e-3f, 5e-4f); return; }
         const f32x4 q0 = rp[(2 * pxg) * 8 + c4], q1 = rp[(2 * pxg + 1) * 8 + c4];
         v0 = make_float4(q0[0], q0[1], q0[2], q0[3]);
         v1 = make_float4(q1[0], q1[1], q1[2], q1[3]);
@@ -244,7 +248,7 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
 #pragma unroll
             for (int dy = 0; dy < 5; ++dy) {
                 const int yz = y + 2 - dy;
-                if (yz < 0 || yz >= H) continue;        // workgroup uniform
+                if (yz < 0 || yz >= H || (BWW_DBG & 1)) continue;        // workgroup uniform
                 constexpr int QA[3] = {1, 0, 0}, QB[3] = {0, 1, 0};     // a2 b1, a1 b2, a1 b1
 #pragma unroll
                 for (int pr = 0; pr < 3; ++pr)
@@ -282,8 +286,8 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
             }
 }
         __builtin_amdgcn_sched_barrier(0);
-        if (xrole ? gr + 1 < r1 : z_in_range(gr + 3)) stage(gr + 1, gr + 3, o0, o1);
-        BW_BARRIER();
+        if (!(BWW_DBG & 2) && (xrole ? gr + 1 < r1 : z_in_range(gr + 3))) stage(gr + 1, gr + 3, o0, o1);
+        if (!(BWW_DBG & 4)) BW_BARRIER();
     };
     // (six rows per trip: at the loop's back edge the compiler's wait-count pass gives up on the requests in flight and waits
     // for all of them -- once per six rows instead of once per three)
