@@ -90,6 +90,27 @@ def test_workspace_sizes_and_layer_table(lib):
     assert lib.sol_conv5x5_packed_floats(2, 3, 1) == 25 * 4 * 16
 
 
+def test_conv3d_sizes_and_options(lib):
+    """Host-side arithmetic of the Conv3D entry points (no GPU): packed-buffer sizes incl. the one-launch kernels' weight sections
+    (32 -> 32: 32 rows per plane, 32 -> <= 16: 16 rows; other shapes: five 2-D sections only), the weight-gradient workspace (five
+    partial buffers, sized for the largest of the D-2 / D-1 / D plane passes) and the 3-D option defaults."""
+    al = lambda v: (v + 63) // 64 * 64
+    per = lambda ci, co: al(lib.sol_conv5x5_packed_floats(ci, co, 0))
+    sect = lambda op: 4 + 125 * 2 * op * 16
+    assert lib.sol_conv3d_packed_floats(32, 32) == 5 * per(32, 32) + sect(32)
+    assert lib.sol_conv3d_packed_floats(32, 3) == 5 * per(32, 3) + sect(16)
+    assert lib.sol_conv3d_packed_floats(32, 4) == 5 * per(32, 4) + sect(16)
+    assert lib.sol_conv3d_packed_floats(4, 32) == 5 * per(4, 32)
+    ws = lib.sol_conv3d_bwd_weight_ws_floats(1, 128, 64, 64, 32, 32)
+    assert ws % 5 == 0 and ws // 5 >= 256 * (25 * 1024 + 32) > 0             # >= one [25][32][32] + bias partial per CU
+    assert lib.sol_conv3d_bwd_weight_ws_floats(3, 128, 64, 64, 32, 32) == ws    # simulations accumulate onto the same partial blocks
+    assert lib.sol_conv3d_bwd_weight_ws_floats(1, 16, 16, 16, 32, 32) <= ws
+    for k, v in {"k3d_conv_fused": 1, "k3d_conv_rows": 8, "k3d_tile": 0, "k3d_fused_tf": 1}.items():
+        assert _lib.get_option(k) == v, k
+    with pytest.raises(sol_amd.SolError, match="must be in"):
+        _lib.set_option("k3d_conv_rows", 9)
+
+
 def test_options_table_and_abi_checks(lib):
     """sol_set_option / sol_get_option (no GPU needed): defaults, range and name checks; the library never reads the
     environment, the Python loader forwards SOL_* debugging overrides once."""
