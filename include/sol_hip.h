@@ -339,8 +339,9 @@ int sol_comm_destroy(sol_comm* comm);
  * these entry points are the dimension-generic twins of the 2-D ones: the same KarmanFlow.step
  * (karman-2d/karman_train.py:173-185) with a third axis, and model_mars_moon (karman_train.py:101-138) with Conv3D(5)
  * layers.  Layout: density [B,Y,X,Z], v_y [B,Y+1,X,Z], v_x [B,Y,X+1,Z], v_z [B,Y,X,Z+1] (y = flow direction, z
- * contiguous); CNN tensors NDHWC = [B,Y,X,Z,C].  FORWARD ONLY in this version (roll-out / data generation; the adjoint is
- * the next row of DESIGN.md section 7).
+ * contiguous); CNN tensors NDHWC = [B,Y,X,Z,C].  Forward step (sol_karman3d_step_fwd), its adjoint w.r.t. the input
+ * velocity (sol_karman3d_step_bwd), the Conv3D forward / backward-data (sol_conv3d, incl. the fused SOL_EPI_DLRELU reverse
+ * sweep epilogue) and the Conv3D weight gradient (sol_conv3d_bwd_weight): everything karman3d.Karman3DTrainer composes.
  * ---------------------------------------------------------------------------------- */
 typedef struct sol_karman3d_cfg {
     int32_t B, Y, X, Z;     /* batch, cells per axis                                                   */
@@ -374,8 +375,9 @@ int sol_karman3d_step_fwd(const sol_karman3d_cfg* cfg, void* stream,
 /* Adjoint of the step w.r.t. its input velocity (the density is a passive tracer: buoyancy_factor = 0, karman_train.py:363).
  * saved_v*: the post-diffusion + BC velocity the forward call stored (saved_vy/vx/vz, all three or NULL there).  The
  * pressure adjoint is a second direct solve with the same symmetric matrix (PhiFlow's custom gradient of the CG solve).
- * The advection adjoint scatters with fp32 global atomics: reproducible to round-off, not bit for bit.
- * workspace: sol_karman3d_step_bwd_workspace_bytes(cfg). */
+ * The advection adjoint scatters in 64-bit fixed point (integer global atomics, power-of-two scale from max|gradient|):
+ * the result is reproducible BIT FOR BIT from run to run.
+ * workspace: sol_karman3d_step_bwd_workspace_bytes(cfg) bytes, 16-byte aligned. */
 size_t sol_karman3d_step_bwd_workspace_bytes(const sol_karman3d_cfg* cfg);
 int sol_karman3d_step_bwd(const sol_karman3d_cfg* cfg, void* stream,
                           const float* saved_vy, const float* saved_vx, const float* saved_vz,

@@ -8,7 +8,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.environ.get("SOL_HIP_LIB") or os.path.join(LIBDIR, "libsol_hip.so")
+DEFAULT_LIB = os.path.join(LIBDIR, "libsol_hip.so")
+LIB = os.environ.get("SOL_HIP_LIB") or DEFAULT_LIB      # SOL_HIP_LIB: an explicitly named PREBUILT variant (tools/ab_lib.py); never built, never stamped
 SOURCES = ["karman_step.hip", "karman_large.hip", "karman3d.hip", "conv3d_sb.hip", "burgers_step.hip", "conv5x5.hip", "conv5x5_sb.hip", "train.hip", "comm.hip", "cnn_chain.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 # the CG loop packs its vector updates by hand (float2); the SLP vectoriser only adds v_mov traffic there
@@ -59,6 +60,8 @@ def _source_hash():
 
 def _stale():
     if os.environ.get("SOL_HIP_LIB"):             # an explicitly named prebuilt library (tools/ab_lib.py variants): never rebuilt
+        if not os.path.exists(LIB):
+            raise RuntimeError("SOL_HIP_LIB=%s does not exist (the override names a prebuilt library; it is never built)" % LIB)
         return False
     if not os.path.exists(LIB):
         return True
@@ -72,6 +75,13 @@ def _stale():
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link libsol_hip.so.  Returns the path.
     Serialised by a lock file: several ranks of one node may import the package at the same time."""
+    if os.environ.get("SOL_HIP_LIB"):
+        # the stamp belongs to the default library: building "over" the override would link a product build onto the named
+        # variant and mark the untouched default library as current
+        if force:
+            raise RuntimeError("build(force=True) with SOL_HIP_LIB set: unset the override to rebuild the product library")
+        _stale()                                  # diagnoses a missing file
+        return LIB
     if not force and not _stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)

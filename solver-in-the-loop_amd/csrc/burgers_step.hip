@@ -309,12 +309,8 @@ int bcheck(const sol_burgers_cfg* c) {
 template <typename K>
 int blaunch(K kernel, const sol_burgers_cfg* c, void* stream, const BArgs& a) {
     const size_t lds = blds_bytes(c->Y, c->X);
-    static int rc_attr = [] {
-        for (const void* k : {reinterpret_cast<const void*>(k_burgers_fwd), reinterpret_cast<const void*>(k_burgers_bwd)})
-            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
-        return 0;
-    }();
-    if (rc_attr) return sol_set_error(SOL_ERR_HIP, "hipFuncSetAttribute(burgers kernels) failed");
+    static std::atomic<unsigned long long> optin{0};
+    if (int e = sol_lds_optin(optin, {SOL_K(k_burgers_fwd), SOL_K(k_burgers_bwd)}, "burgers kernels")) return e;
     SOL_LAUNCH_NAMED("k_burgers", kernel, dim3(c->B), dim3(NT), lds, (hipStream_t)stream, a);
     SOL_LAUNCH_CHECK();
     return SOL_OK;

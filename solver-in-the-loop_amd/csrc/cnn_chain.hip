@@ -508,9 +508,8 @@ __global__ void __launch_bounds__(768) k_cnn_chain(ChainArgs a) {
 }
 
 int init_chain_kernel() {
-    static int rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k_cnn_chain), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                        ? SOL_OK : sol_set_error(SOL_ERR_HIP, "hipFuncSetAttribute(k_cnn_chain) failed");
-    return rc;
+    static std::atomic<unsigned long long> optin{0};
+    return sol_lds_optin(optin, {SOL_K(k_cnn_chain)}, "k_cnn_chain");
 }
 
 int chain_cus() {

@@ -5,6 +5,8 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
+#include <initializer_list>
 
 #include "../../include/sol_hip.h"
 
@@ -185,6 +187,30 @@ inline void sol_launch_impl(const char* name, void (*kernel)(KA...), dim3 g, dim
     do {                                                                                     \
         if (!(cond)) return sol_set_error(SOL_ERR_ARG, __VA_ARGS__);                         \
     } while (0)
+
+// Dynamic LDS beyond 64 KB is an opt-in PER KERNEL AND PER DEVICE (hipFuncSetAttribute acts on the current device): every call
+// site keeps one bit per device ordinal and repeats the opt-in when the process has switched devices (a function-local
+// `static int rc = hipFuncSetAttribute(...)` only ever covered the device of the first call).  minus_static: the kernel's static
+// LDS counts against the same 160 KB.  Not a stream operation: legal during graph capture.
+#define SOL_K(...) reinterpret_cast<const void*>(__VA_ARGS__)
+inline int sol_lds_optin(std::atomic<unsigned long long>& done, std::initializer_list<const void*> kernels, const char* what, bool minus_static = false) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return sol_set_error(SOL_ERR_HIP, "hipGetDevice failed (%s)", what);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return SOL_OK;
+    for (const void* k : kernels) {
+        int bytes = 160 * 1024;
+        if (minus_static) {
+            hipFuncAttributes fa;
+            if (hipFuncGetAttributes(&fa, k) != hipSuccess) return sol_set_error(SOL_ERR_HIP, "hipFuncGetAttributes(%s) failed", what);
+            bytes -= (int)fa.sharedSizeBytes;
+        }
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+            return sol_set_error(SOL_ERR_HIP, "hipFuncSetAttribute(%s) failed on device %d", what, dev);
+    }
+    done.fetch_or(bit, std::memory_order_release);
+    return SOL_OK;
+}
 
 // wave64 all-reduce (every lane gets the sum)
 __device__ __forceinline__ float wave_sum(float v) {

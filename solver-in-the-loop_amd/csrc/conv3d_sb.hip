@@ -884,30 +884,25 @@ int sol_conv3d_sh_pack(hipStream_t s, const float* w_dhwio, int mode, int cout, 
 // y = epi(conv3d(x, w) + bias (+ residual)), x / y [nplanes = B*D][H][64][32]; wsh from sol_conv3d_sh_pack; x_absmax required
 int sol_conv3d_sb_launch(hipStream_t s, const float* x, const float* wsh, const float* bias, const float* residual, const float* act_ref, float* y,
                          int B, int D, int H, int cout, int epilogue, float slope, const unsigned* x_absmax, unsigned* y_absmax) {
-    static int rc = [] {
-        hipFuncAttributes fa;
-        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_conv3d_sb)) != hipSuccess) return -1;
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024 - (int)fa.sharedSizeBytes) == hipSuccess ? 0 : -1;
-    }();
-    SOL_REQUIRE(rc == 0, "hipFuncSetAttribute(k_conv3d_sb) failed");
+    static std::atomic<unsigned long long> optin3{0}, optin8{0}, optin6{0};
+    if (int e = sol_lds_optin(optin3, {SOL_K(k_conv3d_sb)}, "k_conv3d_sb", true)) return e;
     ConvArgs a{};
     a.x = x; a.bias = bias; a.res = residual; a.act = act_ref; a.y = y; a.B = B * D; a.H = H; a.W = 64; a.CO = cout; a.epi = epilogue; a.slope = slope;
     a.wsh = wsh; a.xmax = x_absmax; a.ymax = y_absmax; a.tiles_x = 1;
     const int nrows = B * D * H;
     if (cout <= 16) {                                 // thin layers: the eight-row kernel with one output-channel tile
-        static int rc1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb8<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
-        SOL_REQUIRE(rc1 == 0, "hipFuncSetAttribute(k_conv3d_sb8<1>) failed");
+        if (int e = sol_lds_optin(optin8, {SOL_K(k_conv3d_sb8<1, 0>), SOL_K(k_conv3d_sb8<2, 0>), SOL_K(k_conv3d_sb8<2, 1>), SOL_K(k_conv3d_sb8<2, 8>),
+                                           SOL_K(k_conv3d_sb8<2, 32>), SOL_K(k_conv3d_sb8<2, 64>), SOL_K(k_conv3d_sb8<2, 104>)}, "k_conv3d_sb8")) return e;
         const int nt8 = (nrows + 7) / 8, grid8 = (nt8 + 7) / 8 * 8;
         SOL_LAUNCH((k_conv3d_sb8<1, 0>), dim3(grid8), dim3(512), c8_lds(1), s, a, nrows, D);
         SOL_LAUNCH_CHECK();
         return SOL_OK;
     }
     if (sol_opt().k3d_conv_rows == 8) {               // eight rows per workgroup, 64 x 32 tile per wave, two waves per SIMD
-        static int rc8 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb8<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
-        SOL_REQUIRE(rc8 == 0, "hipFuncSetAttribute(k_conv3d_sb8) failed");
+        if (int e = sol_lds_optin(optin8, {SOL_K(k_conv3d_sb8<1, 0>), SOL_K(k_conv3d_sb8<2, 0>), SOL_K(k_conv3d_sb8<2, 1>), SOL_K(k_conv3d_sb8<2, 8>),
+                                           SOL_K(k_conv3d_sb8<2, 32>), SOL_K(k_conv3d_sb8<2, 64>), SOL_K(k_conv3d_sb8<2, 104>)}, "k_conv3d_sb8")) return e;
         const int nt8 = (nrows + 7) / 8, grid8 = (nt8 + 7) / 8 * 8;
-#define C8_DBG(N) case N: { static int rcd = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb8<2, N>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)rcd; \
+#define C8_DBG(N) case N: { \
             SOL_LAUNCH((k_conv3d_sb8<2, N>), dim3(grid8), dim3(512), c8_lds(2), s, a, nrows, D); break; }
         switch (sol_opt().dbg_skip) { C8_DBG(1) C8_DBG(8) C8_DBG(32) C8_DBG(64) C8_DBG(104) default: break; }
         if (sol_opt().dbg_skip) { SOL_LAUNCH_CHECK(); return SOL_OK; }
@@ -917,8 +912,7 @@ int sol_conv3d_sb_launch(hipStream_t s, const float* x, const float* wsh, const 
     }
     if (sol_opt().k3d_conv_rows == 6) {               // six rows per workgroup, 32 x 32 tile per wave
         const int nt6 = (nrows + 5) / 6, grid6 = (nt6 + 7) / 8 * 8;
-        static int rc6 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_sb6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
-        SOL_REQUIRE(rc6 == 0, "hipFuncSetAttribute(k_conv3d_sb6) failed");
+        if (int e = sol_lds_optin(optin6, {SOL_K(k_conv3d_sb6)}, "k_conv3d_sb6")) return e;
         SOL_LAUNCH(k_conv3d_sb6, dim3(grid6), dim3(768), c6_lds(), s, a, nrows, D);
         SOL_LAUNCH_CHECK();
         return SOL_OK;

@@ -1028,15 +1028,8 @@ extern "C" int sol_conv5x5_pack(void* stream, const float* w_hwio, int32_t cin, 
 }
 
 int sol_init_conv_kernels() {
-    static int rc = [] {
-        const void* ks[] = {reinterpret_cast<const void*>(k_conv5x5_r3<1>), reinterpret_cast<const void*>(k_conv5x5_r3<2>),
-                            reinterpret_cast<const void*>(k_conv5x5_c32<1>), reinterpret_cast<const void*>(k_conv5x5_c32<2>)};
-        for (const void* k : ks)
-            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return sol_set_error(SOL_ERR_HIP, "hipFuncSetAttribute(conv kernels) failed");
-        return SOL_OK;
-    }();
-    return rc;
+    static std::atomic<unsigned long long> optin{0};
+    return sol_lds_optin(optin, {SOL_K(k_conv5x5_r3<1>), SOL_K(k_conv5x5_r3<2>), SOL_K(k_conv5x5_c32<1>), SOL_K(k_conv5x5_c32<2>)}, "conv kernels");
 }
 
 static int conv_impl(void* stream, const float* x, const float* packed, const float* bias,

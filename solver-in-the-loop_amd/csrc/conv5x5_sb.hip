@@ -555,20 +555,11 @@ __global__ void __launch_bounds__(256) k_pack_jobs(PackJobs jobs) {
 constexpr size_t sb_lds(int OP) { return (size_t)4 * 3 * 68 * 64 + 2 * (size_t)5 * 3 * OP * 64 + 16; }
 
 int init_sb_kernels() {
-    static int rc = [] {
-        const void* ks[] = {reinterpret_cast<const void*>(k_conv5x5_bww_sb<0>), reinterpret_cast<const void*>(k_conv5x5_bww_sb<2>), reinterpret_cast<const void*>(k_conv5x5_sb<1, 0>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 0>),
-                            reinterpret_cast<const void*>(k_conv5x5_sb<1, 1>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 1>),
-                            reinterpret_cast<const void*>(k_conv5x5_sb<1, 2>), reinterpret_cast<const void*>(k_conv5x5_sb<2, 2>)};
-        for (const void* k : ks) {
-            // static LDS (the conv kernels' epilogue-prefetch regions) counts against the same 160 KB
-            hipFuncAttributes fa;
-            if (hipFuncGetAttributes(&fa, k) != hipSuccess) return sol_set_error(SOL_ERR_HIP, "hipFuncGetAttributes(split conv kernels) failed");
-            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes) != hipSuccess)
-                return sol_set_error(SOL_ERR_HIP, "hipFuncSetAttribute(split-bf16 conv kernels) failed");
-        }
-        return SOL_OK;
-    }();
-    return rc;
+    // static LDS (the conv kernels' epilogue-prefetch regions) counts against the same 160 KB
+    static std::atomic<unsigned long long> optin{0};
+    return sol_lds_optin(optin, {SOL_K(k_conv5x5_bww_sb<0>), SOL_K(k_conv5x5_bww_sb<2>), SOL_K(k_conv5x5_sb<1, 0>), SOL_K(k_conv5x5_sb<2, 0>),
+                                 SOL_K(k_conv5x5_sb<1, 1>), SOL_K(k_conv5x5_sb<2, 1>), SOL_K(k_conv5x5_sb<1, 2>), SOL_K(k_conv5x5_sb<2, 2>)},
+                         "split conv kernels", true);
 }
 
 }  // namespace

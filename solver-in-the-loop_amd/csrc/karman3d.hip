@@ -1,4 +1,4 @@
-// karman-3d forward solver step (BASELINE.json configs[4]: 128 x 64 x 64, SOL-16) for gfx950.
+// karman-3d solver step and its adjoint (BASELINE.json configs[4]: 128 x 64 x 64, SOL-16) for gfx950.
 //
 // The reference has no 3-D code (/root/reference/README.md:37-38); the algorithm is the dimension-generic restatement of
 // KarmanFlow.step (/root/reference/karman-2d/karman_train.py:173-185) + PhiFlow's IncompressibleFlow.step, exactly as
@@ -19,7 +19,8 @@
 //                   Laplacian diagonalised by three sine transforms (batched fp32 GEMMs along z, x, y) and the capacitance
 //                   correction of the obstacle cells (precond3d.direct_solver_blob3d): 12 transform passes + k3_capacitance
 //   k3_project      v -= mask * grad p, fused to_feature (4 channels: three components + Re)
-// Forward only: the adjoint of the 3-D step is the next row.
+// The adjoint of the step (sol_karman3d_step_bwd: k3b_* kernels, second half of this file) reverses these stages; its
+// advection scatter runs in 64-bit fixed point and is bit-reproducible.
 #include "common.hpp"
 
 namespace {
@@ -543,8 +544,8 @@ int pressure_solve3d(hipStream_t s, const sol_karman3d_cfg* c, const int32_t* hd
     const bool fused_tf = sol_opt().k3d_fused_tf && X <= 64 && Z <= 64 && Y <= 128 && X % 4 == 0 && Z % 4 == 0 && Y % 16 == 0 && (X * Z) % 32 == 0;
     const size_t ty_lds = ((size_t)Y * (Y + 4) + (size_t)Y * 36) * sizeof(float);
     auto Gf = [&](float* src, float* t1, float* t2) -> int {
-        static int rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k3_ty), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
-        SOL_REQUIRE(rc == 0, "hipFuncSetAttribute(k3_ty) failed");
+        static std::atomic<unsigned long long> optin{0};
+        if (int e = sol_lds_optin(optin, {SOL_K(k3_ty)}, "k3_ty")) return e;
         SOL_LAUNCH(k3_tzx, dim3(B * Y), dim3(256), 0, s, src, t1, Qx, Qz, X, Z);
         SOL_LAUNCH(k3_ty, dim3(X * Z / 32, B), dim3(256), ty_lds, s, t1, t2, Qy, il, Y, X * Z);
         SOL_LAUNCH(k3_tzx, dim3(B * Y), dim3(256), 0, s, t2, t1, Qx, Qz, X, Z);
@@ -586,9 +587,13 @@ int check_blob3d(const sol_karman3d_cfg* c, const int32_t* hdr) {
 //   pressure       g_div = M^-1 q                           (second solve with the same symmetric matrix: PhiFlow's custom gradient)
 //   k3b_gva        g_a = mask . (g_out + D^T g_div)          (adjoint of the divergence and of the hard-BC face masks)
 //   k3b_advect_adj scatter of g_a through the trilinear gathers of the semi-Lagrangian step, for the field term AND the
-//                  back-trace (velocity) term, into g_c (fp32 global atomics: the summation order is not fixed, the result is
-//                  reproducible to round-off only -- the 2-D kernels scatter in int32 fixed point into LDS)
-//   k3b_diffuse_adj g_in = (I + alpha L^T)(g_c . (1 - bcm))  (gather form of the transposed replicate-padded Laplacian)
+//                  back-trace (velocity) term, into g_c.  The scatter runs in 64-bit FIXED POINT (global_atomic_add_x2 on
+//                  int64 accumulators, scale = a power of two with max|g_a| * scale in [2^37, 2^38): integer addition is
+//                  order independent, so the adjoint is reproducible BIT FOR BIT (run twice, compare) --
+//                  the scheme of the 2-D kernels (int32 into LDS) with the headroom global memory affords:
+//                  2^25 single-contribution range above max|g_a|, resolution 2^-37 max|g_a|.
+//   k3b_diffuse_adj g_in = (I + alpha L^T)(g_c . (1 - bcm))  (gather form of the transposed replicate-padded Laplacian; converts
+//                  the fixed-point g_c back to fp32 as it reads it)
 // ========================================================================================================================
 struct K3BArgs {
     int B, Y, X, Z;
@@ -599,11 +604,23 @@ struct K3BArgs {
     const float *svy, *svx, *svz;           // saved post-diffusion velocity
     const float *goy, *gox, *goz;           // gradient w.r.t. the step's output velocity
     float *gay, *gax, *gaz;                 // g_a
-    float *gcy, *gcx, *gcz;                 // g_c (zeroed before the scatter)
+    long long *gcy, *gcx, *gcz;             // g_c: int64 fixed-point accumulators (zeroed by k3b_rhs before the scatter)
+    unsigned* gmax;                         // [B][K3B_SLOTS] bits of max|g_a| per simulation (zeroed by k3b_rhs, published by k3b_gva)
     float *giy, *gix, *giz;                 // result: gradient w.r.t. the step's input velocity
     float* rhs;
     const float* gdiv;
 };
+
+constexpr int K3B_SLOTS = 64;            // absmax slots per simulation (one per lane of the reading wave; same-address atomics serialise in the L2)
+constexpr int K3B_FIXBITS = 37;           // max|g_a| * 2^shift lies in [2^37, 2^38)
+// power-of-two fixed-point scale of simulation b's scatter and its inverse, from the published max|g_a| (wave-uniform result)
+__device__ __forceinline__ void k3b_scale(const unsigned* gmax_b, float& qs, float& qi) {
+    const unsigned m = amax_wave_max(gmax_b[threadIdx.x & (K3B_SLOTS - 1)]);
+    int e = (int)(m >> 23) - 127;
+    e = m == 0u ? 0 : min(max(e, -80), 120);
+    qs = __uint_as_float((unsigned)(K3B_FIXBITS - e + 127) << 23);
+    qi = __uint_as_float((unsigned)(e - K3B_FIXBITS + 127) << 23);
+}
 
 template <int AX>
 __device__ __forceinline__ bool boundary_face(int Y, int X, int Z, int j, int i, int k) {
@@ -624,6 +641,11 @@ __global__ void __launch_bounds__(256) k3b_rhs(K3BArgs a) {
         auto wz = [&](int kk) { return (keep || (kk != 0 && kk != Z)) ? face_mask<2>(a.active, Y, X, Z, j, i, kk) * gz[((size_t)j * X + i) * (Z + 1) + kk] : 0.f; };
         a.rhs[(size_t)b * N + c] = (wy(j) - wy(j + 1)) + (wx(i) - wx(i + 1)) + (wz(k) - wz(k + 1));
     }
+    // side job: clear this simulation's fixed-point accumulators (the three components are contiguous) and its absmax slots
+    const size_t faces = (size_t)(Y + 1) * X * Z + (size_t)Y * (X + 1) * Z + (size_t)Y * X * (Z + 1);
+    uint4* zc = reinterpret_cast<uint4*>(a.gcy) + (size_t)b * (faces / 2);     // faces is even for the grids check_blob3d admits (asserted by the host)
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < faces / 2; e += (size_t)gridDim.x * blockDim.x) zc[e] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0 && threadIdx.x < K3B_SLOTS) a.gmax[b * K3B_SLOTS + threadIdx.x] = 0u;
 }
 
 __global__ void __launch_bounds__(256) k3b_gva(K3BArgs a) {
@@ -632,23 +654,39 @@ __global__ void __launch_bounds__(256) k3b_gva(K3BArgs a) {
     const int b = blockIdx.y;
     const float* P = a.gdiv + (size_t)b * N;
     auto cell = [&](int j, int i, int k) { return ((unsigned)j < (unsigned)Y && (unsigned)i < (unsigned)X && (unsigned)k < (unsigned)Z) ? P[((size_t)j * X + i) * Z + k] : 0.f; };
+    float vmax = 0.f;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nVy + nVx + nVz; e += gridDim.x * blockDim.x) {
+        float v;
         if (e < nVy) {
             const int k = e % Z, i = (e / Z) % X, j = e / (Z * X);
-            a.gay[(size_t)b * nVy + e] = face_mask<0>(a.active, Y, X, Z, j, i, k) * (a.goy[(size_t)b * nVy + e] + cell(j - 1, i, k) - cell(j, i, k));
+            a.gay[(size_t)b * nVy + e] = v = face_mask<0>(a.active, Y, X, Z, j, i, k) * (a.goy[(size_t)b * nVy + e] + cell(j - 1, i, k) - cell(j, i, k));
         } else if (e < nVy + nVx) {
             const int q = e - nVy, k = q % Z, i = (q / Z) % (X + 1), j = q / (Z * (X + 1));
-            a.gax[(size_t)b * nVx + q] = face_mask<1>(a.active, Y, X, Z, j, i, k) * (a.gox[(size_t)b * nVx + q] + cell(j, i - 1, k) - cell(j, i, k));
+            a.gax[(size_t)b * nVx + q] = v = face_mask<1>(a.active, Y, X, Z, j, i, k) * (a.gox[(size_t)b * nVx + q] + cell(j, i - 1, k) - cell(j, i, k));
         } else {
             const int q = e - nVy - nVx, k = q % (Z + 1), i = (q / (Z + 1)) % X, j = q / ((Z + 1) * X);
-            a.gaz[(size_t)b * nVz + q] = face_mask<2>(a.active, Y, X, Z, j, i, k) * (a.goz[(size_t)b * nVz + q] + cell(j, i, k - 1) - cell(j, i, k));
+            a.gaz[(size_t)b * nVz + q] = v = face_mask<2>(a.active, Y, X, Z, j, i, k) * (a.goz[(size_t)b * nVz + q] + cell(j, i, k - 1) - cell(j, i, k));
         }
+        vmax = fmaxf(vmax, fabsf(v));
+    }
+    // max|g_a| of this simulation -> the scale of the fixed-point scatter (one atomic per workgroup; a NaN gradient publishes
+    // nothing and scatters nothing: the consumer then sees zeros instead of undefined integer conversions)
+    __shared__ float red[16];
+    vmax = __uint_as_float(amax_wave_max(__float_as_uint(vmax)));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
+        atomicMax(&a.gmax[b * K3B_SLOTS + (blockIdx.x & (K3B_SLOTS - 1))], __float_as_uint(m));
     }
 }
 
 // adjoint of one advected face value of component C at (j, i, k): gs = g_a there
 template <int C>
-__device__ __forceinline__ void advect_adj_point(const K3BArgs& a, const GR& r, float* gy, float* gx, float* gz, int j, int i, int k, float gs) {
+__device__ __forceinline__ void advect_adj_point(const K3BArgs& a, const GR& r, long long* gy, long long* gx, long long* gz, float qs, int j, int i, int k, float gs) {
+    // order-independent accumulation: round to the fixed-point grid FIRST (each contribution on its own), then integer add
+    auto atomicAdd = [qs](long long* p, float v) { ::atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__float2ll_rn(v * qs)); };
     const int Y = a.Y, X = a.X, Z = a.Z;
     auto iy = [&](int jj, int ii, int kk) { return ((size_t)jj * X + ii) * Z + kk; };
     auto ix = [&](int jj, int ii, int kk) { return ((size_t)jj * (X + 1) + ii) * Z + kk; };
@@ -679,7 +717,7 @@ __device__ __forceinline__ void advect_adj_point(const K3BArgs& a, const GR& r, 
     const int j0 = clampi(j + (int)fy, 0, n0 - 1), j1 = clampi(j + (int)fy + 1, 0, n0 - 1);
     const int i0 = clampi(i + (int)fx, 0, n1 - 1), i1 = clampi(i + (int)fx + 1, 0, n1 - 1);
     const int k0 = clampi(k + (int)fz, 0, n2 - 1), k1 = clampi(k + (int)fz + 1, 0, n2 - 1);
-    float* gT = C == 0 ? gy : (C == 1 ? gx : gz);
+    long long* gT = C == 0 ? gy : (C == 1 ? gx : gz);
     auto idx = [&](int jj, int ii, int kk) { return C == 0 ? iy(jj, ii, kk) : (C == 1 ? ix(jj, ii, kk) : iz(jj, ii, kk)); };
     auto val = [&](int jj, int ii, int kk) { return C == 0 ? r.y(jj, ii, kk) : (C == 1 ? r.x(jj, ii, kk) : r.z(jj, ii, kk)); };
     float dy = 0.f, dx = 0.f, dz = 0.f;          // d(sample) / d(offset) along each axis
@@ -723,9 +761,11 @@ __global__ void __launch_bounds__(256) k3b_advect_adj(K3BArgs a) {
     const int b = blockIdx.y;
     GR r;
     r.sy = a.svy + (size_t)b * nVy; r.sx = a.svx + (size_t)b * nVx; r.sz = a.svz + (size_t)b * nVz; r.Y = Y; r.X = X; r.Z = Z;
-    float* gy = a.gcy + (size_t)b * nVy;
-    float* gx = a.gcx + (size_t)b * nVx;
-    float* gz = a.gcz + (size_t)b * nVz;
+    long long* gy = a.gcy + (size_t)b * nVy;
+    long long* gx = a.gcx + (size_t)b * nVx;
+    long long* gz = a.gcz + (size_t)b * nVz;
+    float qs, qi;
+    k3b_scale(a.gmax + b * K3B_SLOTS, qs, qi);
     const int cY = (Y + 1) * X, cX = Y * (X + 1), cC = Y * X;
     const int lane = threadIdx.x & 63;
     const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
@@ -733,24 +773,24 @@ __global__ void __launch_bounds__(256) k3b_advect_adj(K3BArgs a) {
     for (int c = wave0; c < cY + cX + cC; c += nwaves) {
         if (c < cY) {
             const int j = c / X, i = c % X;
-            for (int k = lane; k < Z; k += 64) { const float g = a.gay[(size_t)b * nVy + ((size_t)j * X + i) * Z + k]; if (g != 0.f) advect_adj_point<0>(a, r, gy, gx, gz, j, i, k, g); }
+            for (int k = lane; k < Z; k += 64) { const float g = a.gay[(size_t)b * nVy + ((size_t)j * X + i) * Z + k]; if (g != 0.f) advect_adj_point<0>(a, r, gy, gx, gz, qs, j, i, k, g); }
         } else if (c < cY + cX) {
             const int q = c - cY, j = q / (X + 1), i = q % (X + 1);
-            for (int k = lane; k < Z; k += 64) { const float g = a.gax[(size_t)b * nVx + ((size_t)j * (X + 1) + i) * Z + k]; if (g != 0.f) advect_adj_point<1>(a, r, gy, gx, gz, j, i, k, g); }
+            for (int k = lane; k < Z; k += 64) { const float g = a.gax[(size_t)b * nVx + ((size_t)j * (X + 1) + i) * Z + k]; if (g != 0.f) advect_adj_point<1>(a, r, gy, gx, gz, qs, j, i, k, g); }
         } else {
             const int q = c - cY - cX, j = q / X, i = q % X;
-            for (int k = lane; k <= Z; k += 64) { const float g = a.gaz[(size_t)b * nVz + ((size_t)j * X + i) * (Z + 1) + k]; if (g != 0.f) advect_adj_point<2>(a, r, gy, gx, gz, j, i, k, g); }
+            for (int k = lane; k <= Z; k += 64) { const float g = a.gaz[(size_t)b * nVz + ((size_t)j * X + i) * (Z + 1) + k]; if (g != 0.f) advect_adj_point<2>(a, r, gy, gx, gz, qs, j, i, k, g); }
         }
     }
 }
 
 // (I + alpha L^T) g at (j, i, k) of a component array [n0][n1][n2]: the transposed replicate-padded 7-point Laplacian in gather
 // form -- a neighbour q - delta inside the array contributes g there, a direction that leaves the array contributes g[q] itself
-__device__ __forceinline__ float lapT7(const float* g, float sc_here, const float* scm, int n0, int n1, int n2, int j, int i, int k) {
+__device__ __forceinline__ float lapT7(const long long* g, float qi, float sc_here, const float* scm, int n0, int n1, int n2, int j, int i, int k) {
     const size_t s0 = (size_t)n1 * n2, s1 = n2;
     const size_t c = (size_t)j * s0 + (size_t)i * s1 + k;
-    auto at = [&](size_t q) { return scm ? g[q] * (1.f - scm[q]) : g[q]; };
-    const float v = g[c] * sc_here;
+    auto at = [&](size_t q) { const float v = __ll2float_rn(g[q]) * qi; return scm ? v * (1.f - scm[q]) : v; };
+    const float v = __ll2float_rn(g[c]) * qi * sc_here;
     float acc = -6.f * v;
     acc += j + 1 < n0 ? at(c + s0) : v;
     acc += j > 0 ? at(c - s0) : v;
@@ -766,21 +806,23 @@ __global__ void __launch_bounds__(256) k3b_diffuse_adj(K3BArgs a) {
     const int nVy = (Y + 1) * X * Z, nVx = Y * (X + 1) * Z, nVz = Y * X * (Z + 1);
     const int b = blockIdx.y;
     const float alpha = a.adt / a.re[b];
+    float qs, qi;
+    k3b_scale(a.gmax + b * K3B_SLOTS, qs, qi);
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nVy + nVx + nVz; e += gridDim.x * blockDim.x) {
         if (e < nVy) {
             const int k = e % Z, i = (e / Z) % X, j = e / (Z * X);
-            const float* g = a.gcy + (size_t)b * nVy;
+            const long long* g = a.gcy + (size_t)b * nVy;
             const float* m = a.bcm + (size_t)b * a.bc_stride;          // g' = g . (1 - bcm): the BC blend's adjoint
             const float sc = 1.f - m[e];
-            a.giy[(size_t)b * nVy + e] = g[e] * sc + alpha * lapT7(g, sc, m, Y + 1, X, Z, j, i, k);
+            a.giy[(size_t)b * nVy + e] = __ll2float_rn(g[e]) * qi * sc + alpha * lapT7(g, qi, sc, m, Y + 1, X, Z, j, i, k);
         } else if (e < nVy + nVx) {
             const int q = e - nVy, k = q % Z, i = (q / Z) % (X + 1), j = q / (Z * (X + 1));
-            const float* g = a.gcx + (size_t)b * nVx;
-            a.gix[(size_t)b * nVx + q] = g[q] + alpha * lapT7(g, 1.f, nullptr, Y, X + 1, Z, j, i, k);
+            const long long* g = a.gcx + (size_t)b * nVx;
+            a.gix[(size_t)b * nVx + q] = __ll2float_rn(g[q]) * qi + alpha * lapT7(g, qi, 1.f, nullptr, Y, X + 1, Z, j, i, k);
         } else {
             const int q = e - nVy - nVx, k = q % (Z + 1), i = (q / (Z + 1)) % X, j = q / ((Z + 1) * X);
-            const float* g = a.gcz + (size_t)b * nVz;
-            a.giz[(size_t)b * nVz + q] = g[q] + alpha * lapT7(g, 1.f, nullptr, Y, X, Z + 1, j, i, k);
+            const long long* g = a.gcz + (size_t)b * nVz;
+            a.giz[(size_t)b * nVz + q] = __ll2float_rn(g[q]) * qi + alpha * lapT7(g, qi, 1.f, nullptr, Y, X, Z + 1, j, i, k);
         }
     }
 }
@@ -838,8 +880,8 @@ extern "C" int sol_karman3d_step_fwd(const sol_karman3d_cfg* c, void* stream,
     SOL_LAUNCH(k3_diffuse, dim3(grid_for(faces), B), dim3(256), 0, s, a);
     const size_t tile_lds = ((size_t)(TR + 1) * TR * Z + (size_t)TR * (TR + 1) * Z + (size_t)TR * TR * (Z + 1)) * sizeof(float) + (size_t)TR * TR * Z;
     if (sol_opt().k3d_tile && tile_lds <= 160 * 1024) {
-        static int rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k3_advect_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
-        SOL_REQUIRE(rc == 0, "hipFuncSetAttribute(k3_advect_tile) failed");
+        static std::atomic<unsigned long long> optin{0};
+        if (int e = sol_lds_optin(optin, {SOL_K(k3_advect_tile)}, "k3_advect_tile")) return e;
         const int tiles_y = (Y + T3 - 1) / T3, tiles_x = (X + T3 - 1) / T3;
         SOL_LAUNCH(k3_advect_tile, dim3(tiles_y * tiles_x, B), dim3(ADV_T), tile_lds, s, a, tiles_x);
     } else {
@@ -859,8 +901,8 @@ extern "C" int sol_karman3d_step_fwd(const sol_karman3d_cfg* c, void* stream,
 extern "C" size_t sol_karman3d_step_bwd_workspace_bytes(const sol_karman3d_cfg* c) {
     if (!c) return 0;
     const size_t B = c->B, Y = c->Y, X = c->X, Z = c->Z;
-    // g_a and g_c (three components each) + rhs + two transform buffers
-    const size_t floats = B * (2 * ((Y + 1) * X * Z + Y * (X + 1) * Z + Y * X * (Z + 1)) + 3 * Y * X * Z) + 256;
+    // g_a (fp32) and g_c (int64 fixed point), three components each + rhs + two transform buffers + the absmax slots
+    const size_t floats = B * (3 * ((Y + 1) * X * Z + Y * (X + 1) * Z + Y * X * (Z + 1)) + 3 * Y * X * Z + K3B_SLOTS) + 256;
     return floats * sizeof(float);
 }
 
@@ -884,8 +926,13 @@ extern "C" int sol_karman3d_step_bwd(const sol_karman3d_cfg* c, void* stream,
     a.B = B; a.Y = Y; a.X = X; a.Z = Z; a.dtdx = c->dt / c->dx; a.adt = c->dt * c->res * c->res; a.grad_pad = c->grad_pad;
     a.re = re; a.active = active; a.bcm = velBCyMask; a.bc_stride = bc_batch_stride;
     a.svy = saved_vy; a.svx = saved_vx; a.svz = saved_vz; a.goy = g_vy_out; a.gox = g_vx_out; a.goz = g_vz_out;
+    SOL_REQUIRE(faces % 2 == 0, "sol_karman3d_step_bwd: odd face count (%zu): even X, Z expected", faces);
+    // per-simulation layout of g_c: [b][y faces | x faces | z faces] int64 -- k3b_rhs clears simulation b's block
+    SOL_REQUIRE(reinterpret_cast<uintptr_t>(workspace) % 16 == 0, "sol_karman3d_step_bwd: workspace must be 16-byte aligned");
+    long long* gc = reinterpret_cast<long long*>(w); w += 2 * B * faces;
+    a.gcy = gc; a.gcx = gc + B * nVy; a.gcz = a.gcx + B * nVx;
     a.gay = w; w += B * nVy; a.gax = w; w += B * nVx; a.gaz = w; w += B * nVz;
-    a.gcy = w; w += B * nVy; a.gcx = w; w += B * nVx; a.gcz = w; w += B * nVz;
+    a.gmax = reinterpret_cast<unsigned*>(w); w += (size_t)B * K3B_SLOTS;
     float* R = w; w += (size_t)B * N;
     float* T1 = w; w += (size_t)B * N;
     float* T2 = w; w += (size_t)B * N;
@@ -896,7 +943,6 @@ extern "C" int sol_karman3d_step_bwd(const sol_karman3d_cfg* c, void* stream,
     if (int e = pressure_solve3d(s, c, direct_header_host, R, T1, T2, &res)) return e;
     a.gdiv = res;
     SOL_LAUNCH(k3b_gva, dim3(grid_for(faces), B), dim3(256), 0, s, a);
-    SOL_LAUNCH(k3_fill, dim3(grid_for(B * faces)), dim3(256), 0, s, a.gcy, (const float*)nullptr, B * faces);     // g_c: three contiguous components
     SOL_LAUNCH(k3b_advect_adj, dim3(grid_for((size_t)((Y + 1) * X + Y * (X + 1) + Y * X) * 64), B), dim3(256), 0, s, a);
     SOL_LAUNCH(k3b_diffuse_adj, dim3(grid_for(faces), B), dim3(256), 0, s, a);
     SOL_LAUNCH_CHECK();

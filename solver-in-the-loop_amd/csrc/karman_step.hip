@@ -1687,19 +1687,11 @@ void fill_common(StepArgs& a, const sol_karman_cfg* c) {
 
 // one-time: allow the full 160 KiB of dynamic LDS (not a stream operation -> done outside graph capture)
 int sol_init_karman_kernels() {
-    static int rc = [] {
-        const void* ks[] = {reinterpret_cast<const void*>(k_karman_fwd<8, 0>), reinterpret_cast<const void*>(k_karman_bwd<8, 0>),
-                            reinterpret_cast<const void*>(k_karman_fwd<8, 2>), reinterpret_cast<const void*>(k_karman_bwd<8, 2>),
-                            reinterpret_cast<const void*>(k_karman_fwd<16, 0>), reinterpret_cast<const void*>(k_karman_bwd<16, 0>),
-                            reinterpret_cast<const void*>(k_karman_fwd<16, 1>), reinterpret_cast<const void*>(k_karman_bwd<16, 1>),
-                            reinterpret_cast<const void*>(k_karman_fwd<16, 2>), reinterpret_cast<const void*>(k_karman_bwd<16, 2>),
-                            reinterpret_cast<const void*>(k_karman_bwd_bww), reinterpret_cast<const void*>(k_karman_fwd_dens)};
-        for (const void* k : ks)
-            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return sol_set_error(SOL_ERR_HIP, "hipFuncSetAttribute(karman kernels) failed");
-        return SOL_OK;
-    }();
-    return rc;
+    static std::atomic<unsigned long long> optin{0};
+    return sol_lds_optin(optin, {SOL_K(k_karman_fwd<8, 0>), SOL_K(k_karman_bwd<8, 0>), SOL_K(k_karman_fwd<8, 2>), SOL_K(k_karman_bwd<8, 2>),
+                                 SOL_K(k_karman_fwd<16, 0>), SOL_K(k_karman_bwd<16, 0>), SOL_K(k_karman_fwd<16, 1>), SOL_K(k_karman_bwd<16, 1>),
+                                 SOL_K(k_karman_fwd<16, 2>), SOL_K(k_karman_bwd<16, 2>), SOL_K(k_karman_bwd_bww), SOL_K(k_karman_fwd_dens)},
+                         "karman kernels");
 }
 
 namespace {
@@ -1753,9 +1745,8 @@ int sol_density_chain(const sol_karman_cfg* c, void* stream, int ms, const float
     SOL_REQUIRE(d0 && svy && svx && inflow && ms >= 1, "sol_density_chain: NULL pointer argument");
     const size_t lds = 2 * (size_t)c->Y * c->X * sizeof(float);
     SOL_REQUIRE(lds <= 160 * 1024, "sol_density_chain: grid does not fit the LDS");
-    static int rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k_density_chain), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
-                        ? SOL_OK : sol_set_error(SOL_ERR_HIP, "hipFuncSetAttribute(k_density_chain) failed");
-    if (rc) return rc;
+    static std::atomic<unsigned long long> optin{0};
+    if (int e = sol_lds_optin(optin, {SOL_K(k_density_chain)}, "k_density_chain")) return e;
     DensArgs a{};
     a.B = c->B; a.Y = c->Y; a.X = c->X; a.ms = ms; a.inflow_before = c->inflow_before;
     a.dtdx = c->dt / c->dx; a.dt = c->dt;

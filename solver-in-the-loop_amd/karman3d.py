@@ -197,14 +197,23 @@ class MarsMoon3D:
     def train_packs(self):
         """Per layer (forward-packed, backward-data-packed) weights, built once and reused by every unrolled step of a
         training step (the weights only change between steps: whoever updates them resets `_tpacks`)."""
-        if getattr(self, "_tpacks", None) is None:
+        key = self._params_key()
+        if getattr(self, "_tpacks", None) is None or getattr(self, "_tpacks_key", None) != key:
             t = self.tensors()
             self._tpacks = []
             for l in range(12):
                 cin, cout = self.chans[l], self.chans[l + 1]
+                cin_k = 4 if cin <= 4 else 32
                 w = t[2 * l].detach()
-                self._tpacks.append((_pack3d(w, 4 if cin <= 4 else 32, cout, 0), _pack3d(w, cout, cin, 1)))
+                wf = w if cin_k == cin else torch.nn.functional.pad(w, (0, 0, 0, cin_k - cin))   # the forward kernels read cin_k input channels (as pack())
+                self._tpacks.append((_pack3d(wf, cin_k, cout, 0), _pack3d(w, cout, cin, 1)))
+            self._tpacks_key = key
         return self._tpacks
+
+    def _params_key(self):
+        """Identity of the weight buffer's CONTENT as far as torch can see it: an optimizer that updates `params` in place through
+        torch bumps `_version`; the library's own Adam (ctypes) does not -- Karman3DTrainer.apply_gradients resets the caches itself."""
+        return (self.params.data_ptr(), self.params._version)
 
     fused_backward = True      # one autograd node with a hand-written reverse sweep (False: one node per layer, torch glue)
 
@@ -248,7 +257,9 @@ class MarsMoon3D:
 
     def pack(self):
         """(packed weights, padded biases) per layer in the layout the conv kernels consume; cached until set_weights."""
-        if self._packed is None:
+        key = self._params_key()
+        if self._packed is None or getattr(self, "_packed_key", None) != key:
+            self._packed_key = key
             lib = _lib.load()
             t = self.tensors()
             self._packed = []
@@ -521,7 +532,8 @@ class Karman3DTrainer:
         p = self.net.params.detach()
         check(self.lib.sol_adam_tf_step(stream(), ptr(p), ptr(self._grads), ptr(self.m), ptr(self.v),
                                         self.net.n_params, self.t, float(lr), self.beta1, self.beta2, self.eps, 0.0, None, 0, None))
-        self.net._packed = None
+        self.net._packed = None                     # both pack caches are stale now (the forward packs AND the training packs)
+        self.net._tpacks = None
 
     def train_step(self, d, vy, vx, vz, re, gts, lr):
         """One training step on this rank's simulations; returns the GLOBAL loss tensor (the sum over all ranks' simulations)."""
