@@ -309,6 +309,19 @@ int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* params,
                 const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
                 int32_t nsteps, void* workspace, size_t workspace_bytes, int32_t* iters);
 
+/* Stand-alone loss of ONE unrolled step (karman_train.py:428-436: tf.nn.l2_loss((gt.staggered - prd.staggered) / std_v)):
+ *   loss (+)= 0.5 * sum_c sum_e ((gt_c[e] - v_c[e]) / std[c])^2        (accumulate_loss = 0 overwrites loss[0])
+ *   g_c[e] (+)= gscale * (v_c[e] - gt_c[e]) / std[c]^2                  (d loss / d v; g may be NULL: forward only; gscale = 1/msteps
+ *                                                                        for the reference's loss = sum_i / msteps, l.436)
+ * v / gt / g / n / std: HOST arrays of ncomp (1..3) entries -- the staggered components v_y [B,Y+1,X], v_x [B,Y,X+1] (, v_z): the
+ * zero-padded faces of staggered_tensor() contribute nothing.  scratch: sol_l2_loss_scratch_floats() device floats.  The sum is
+ * folded in a fixed order (bit-reproducible).  The trainers (sol_train_*) fuse this loss into their last CNN layer; this entry
+ * point serves hosts that compose the step from the per-op ABI. */
+int32_t sol_l2_loss_scratch_floats(void);
+int sol_l2_loss_fwd_bwd(void* stream, int32_t ncomp, const float* const* v, const float* const* gt, float* const* g,
+                        const int64_t* n, const float* std, float gscale, int32_t accumulate_g,
+                        float* loss, int32_t accumulate_loss, float* scratch);
+
 /* tf.compat.v1.train.AdamOptimizer update (karman_train.py:449-457), epsilon-hat form:
  *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  p -= lr_t*m/(sqrt(v)+eps).
  * clip_norm > 0: per-tensor tf.clip_by_norm(g, clip_norm) first (l.451-454), tensors given

@@ -86,6 +86,8 @@ _SIGS = {
     "sol_train_graph_destroy": (C.c_int, [_P]),
     "sol_rollout_workspace_bytes": (C.c_size_t, [C.POINTER(TrainCfg)]),
     "sol_rollout": (C.c_int, [C.POINTER(TrainCfg), _P] + [_P] * 9 + [C.c_int64, C.c_int32, _P, C.c_size_t, _P]),
+    "sol_l2_loss_scratch_floats": (C.c_int32, []),
+    "sol_l2_loss_fwd_bwd": (C.c_int, [_P, C.c_int32] + [C.POINTER(C.c_void_p)] * 3 + [C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_float, C.c_int32, _P, C.c_int32, _P]),
     "sol_adam_tf_step": (C.c_int, [_P] * 5 + [C.c_int64, C.c_int32] + [C.c_float] * 5 + [C.POINTER(C.c_int64), C.c_int32, _P]),
     "sol_comm_unique_id": (C.c_int, [C.c_char_p]),
     "sol_comm_init": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),

@@ -947,6 +947,56 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
     return SOL_OK;
 }
 
+// ---- stand-alone l2 loss of one unrolled step (karman_train.py:428-436), SURVEY 8b2 -------------------------------------
+// loss (+)= 0.5 * sum_c sum_e ((gt_c[e] - v_c[e]) / std_c)^2;  g_c[e] (+)= gscale * (v_c[e] - gt_c[e]) / std_c^2.
+// The trainers never call it (their loss is fused into the last CNN layer / k_seed); it exists so that a host binding the
+// per-op ABI can compose the reference's loss.  Deterministic: per-workgroup partial sums in a fixed layout, folded in a fixed
+// order by one wave (no floating-point atomics).
+namespace {
+constexpr int L2_BLOCKS = 256;
+struct L2Args { const float* v[3]; const float* gt[3]; float* g[3]; long n[3]; float il[3]; int nc; };
+__global__ void __launch_bounds__(256) k_l2_loss(L2Args a, float gscale, int acc_g, float* __restrict__ part) {
+    __shared__ float red[64];
+    float s = 0.f;
+    for (int c = 0; c < a.nc; ++c) {
+        const float il = a.il[c], gs = gscale * il * il;
+        for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < a.n[c]; e += (long)gridDim.x * blockDim.x) {
+            const float d = a.v[c][e] - a.gt[c][e], q = d * il;
+            s += 0.5f * q * q;
+            if (a.g[c]) a.g[c][e] = (acc_g ? a.g[c][e] : 0.f) + gs * d;
+        }
+    }
+    s = block_sum(s, red, 0);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(64) k_l2_fold(const float* __restrict__ part, int n, float* __restrict__ loss, int acc) {
+    float s = 0.f;
+    for (int k = threadIdx.x; k < n; k += 64) s += part[k];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) loss[0] = (acc ? loss[0] : 0.f) + s;
+}
+}  // namespace
+extern "C" int32_t sol_l2_loss_scratch_floats(void) { return L2_BLOCKS; }
+extern "C" int sol_l2_loss_fwd_bwd(void* stream, int32_t ncomp, const float* const* v, const float* const* gt, float* const* g,
+                                   const int64_t* n, const float* std, float gscale, int32_t accumulate_g,
+                                   float* loss, int32_t accumulate_loss, float* scratch) {
+    SOL_REQUIRE(ncomp >= 1 && ncomp <= 3 && v && gt && n && std && loss && scratch, "sol_l2_loss_fwd_bwd: bad arguments (1..3 components)");
+    L2Args a{};
+    a.nc = ncomp;
+    long total = 0;
+    for (int c = 0; c < ncomp; ++c) {
+        SOL_REQUIRE(v[c] && gt[c] && n[c] > 0 && std[c] > 0.f, "sol_l2_loss_fwd_bwd: component %d: NULL pointer, empty or std <= 0", c);
+        a.v[c] = v[c]; a.gt[c] = gt[c]; a.g[c] = g ? g[c] : nullptr; a.n[c] = (long)n[c]; a.il[c] = 1.f / std[c];
+        total += (long)n[c];
+    }
+    hipStream_t hs = (hipStream_t)stream;
+    const int grid = (int)std::min<long>(L2_BLOCKS, (total + 255) / 256);
+    SOL_LAUNCH(k_l2_loss, dim3(grid), dim3(256), 0, hs, a, gscale, (int)accumulate_g, scratch);
+    SOL_LAUNCH(k_l2_fold, dim3(1), dim3(64), 0, hs, (const float*)scratch, grid, loss, (int)accumulate_loss);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
 extern "C" int sol_adam_tf_step(void* stream, float* params, const float* grads, float* m, float* v,
                                 int64_t n, int32_t t, float lr, float beta1, float beta2, float eps,
                                 float clip_norm, const int64_t* tensor_offsets, int32_t n_tensors, float* scratch) {

@@ -310,3 +310,25 @@ def burgers_step_large(vy, vx, fy, fx, cfg, circ, workspace=None):
                                          ptr(circ[0]), ptr(circ[1]), ptr(circ[2]), ptr(circ[3]), ptr(oy), ptr(ox),
                                          ptr(workspace), workspace.numel() * 4))
     return oy, ox
+
+
+def l2_loss_fwd_bwd(pred, gt, std, gscale=1.0, want_grad=True, loss=None, grads=None):
+    """sol_l2_loss_fwd_bwd: the loss of ONE unrolled step, karman_train.py:428-436 -- 0.5 * sum(((gt - pred) / std)^2) over the
+    staggered components `pred` / `gt` (tuples of 1..3 device tensors, e.g. (v_y [B,Y+1,X], v_x [B,Y,X+1])), `std` one scale per
+    component.  Returns (loss [1] device tensor, tuple of d loss / d pred times gscale, or None).  `loss` / `grads` given: accumulated into."""
+    lib = _lib.load()
+    nc = len(pred)
+    assert 1 <= nc <= 3 and len(gt) == nc and len(std) == nc
+    pred = [_lib.f32(t) for t in pred]
+    gt = [_lib.f32(t) for t in gt]
+    acc_g = grads is not None
+    g = list(grads) if acc_g else ([torch.empty_like(t) for t in pred] if want_grad else None)
+    acc_l = loss is not None
+    if loss is None:
+        loss = torch.empty(1, dtype=torch.float32, device=pred[0].device)
+    scratch = torch.empty(lib.sol_l2_loss_scratch_floats(), dtype=torch.float32, device=pred[0].device)
+    arr = lambda ts: (C.c_void_p * nc)(*[ptr(t) for t in ts])
+    check(lib.sol_l2_loss_fwd_bwd(stream(), nc, arr(pred), arr(gt), arr(g) if g is not None else None,
+                                  (C.c_int64 * nc)(*[t.numel() for t in pred]), (C.c_float * nc)(*[float(v) for v in std]),
+                                  float(gscale), int(acc_g), ptr(loss), int(acc_l), ptr(scratch)))
+    return loss, (tuple(g) if g is not None else None)

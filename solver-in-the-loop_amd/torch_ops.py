@@ -22,6 +22,7 @@ _LIB.define("conv5x5(Tensor x, Tensor w, Tensor b, Tensor? residual, bool lrelu,
 _LIB.define("karman3d_step(Tensor d, Tensor vy, Tensor vx, Tensor vz, Tensor re, int scene) -> (Tensor, Tensor, Tensor, Tensor)")
 _LIB.define("conv3d(Tensor x, Tensor w, Tensor b, Tensor? residual, bool lrelu, float slope) -> Tensor")
 _LIB.define("burgers_step(Tensor vy, Tensor vx, Tensor? fy, Tensor? fx, float dx, float dt, float nu) -> (Tensor, Tensor)")
+_LIB.define("l2_loss(Tensor vy, Tensor vx, Tensor gt_vy, Tensor gt_vx, float std_vy, float std_vx) -> Tensor")
 _LIB.define("adam_tf_step(Tensor(a!) params, Tensor grads, Tensor(b!) m, Tensor(c!) v, int t, float lr, float beta1, float beta2, float eps) -> ()")
 
 
@@ -103,6 +104,25 @@ def _adam(params, grads, m, v, t, lr, beta1, beta2, eps):
 
 
 _LIB.impl("adam_tf_step", _adam, "CUDA")
+
+
+class _L2LossFn(torch.autograd.Function):
+    """tf.nn.l2_loss((gt.staggered - prd.staggered) / std_v) of one unrolled step (karman_train.py:428-436): sol_l2_loss_fwd_bwd
+    computes the value and d loss / d prd in one pass; backward scales the saved gradient."""
+
+    @staticmethod
+    def forward(ctx, vy, vx, gt_vy, gt_vx, std_vy, std_vx):
+        loss, g = ops.l2_loss_fwd_bwd((vy, vx), (gt_vy, gt_vx), (std_vy, std_vx))
+        ctx.save_for_backward(*g)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        gy, gx = ctx.saved_tensors
+        return gl * gy, gl * gx, None, None, None, None
+
+
+_LIB.impl("l2_loss", lambda vy, vx, gt_vy, gt_vx, sy, sx: _L2LossFn.apply(vy, vx, gt_vy, gt_vx, sy, sx), "AutogradCUDA")
 
 
 # ---- karman-3d (BASELINE configs[4]): the step with its hand-written adjoint and Conv3D(5) with forward / backward-data / weight gradient ----

@@ -1,0 +1,276 @@
+"""Run-twice bit-compare tests (pytest -m gpu) -- SURVEY.md section 5: ROCm has no racecheck tool, so device-side races and
+order-dependent reductions are caught by running every stage of the hot path twice on the same inputs and comparing BIT FOR
+BIT: the scatter-add of the advection adjoints (2-D: int32 fixed point in LDS, 3-D: int64 fixed point in global memory), the
+cross-wave reductions of the pressure solvers, the split-precision convolutions (absmax publish by atomic max), the
+two-stage weight-gradient reduces, the stand-alone l2 loss and the whole training steps (eager and replayed hipGraph).
+Also the parity tests of the stand-alone loss entry point sol_l2_loss_fwd_bwd (karman_train.py:428-436)."""
+import numpy as np
+import pytest
+import torch
+
+import sol_amd
+import sol_oracle as o
+import sol_oracle3d as o3
+from sol_amd import karman3d as k3, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def f32(t):
+    return torch.as_tensor(np.asarray(t), dtype=torch.float32).to(DEV).contiguous()
+
+
+def bits(t):
+    return t.detach().contiguous().view(torch.int32).cpu()
+
+
+def same_bits(a, b):
+    return bool((bits(a) == bits(b)).all())
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), torch.as_tensor(np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b), dtype=torch.float64)
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def _scramble():
+    """Different co-runners between the two runs: a chip-filling dummy launch shifts which workgroups start first."""
+    x = torch.randn(1 << 22, device=DEV)
+    (x * 1.0001).sum().item()
+
+
+# ---------------------------------------------------------------------------------------------
+# 2-D solver step, forward and adjoint, every pressure solver
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Y,X,solver", [(128, 64, "direct"), (128, 64, "pcg"), (128, 64, "cg"), (64, 32, "direct"), (16, 8, "cg")])
+def test_karman_step_forward_and_adjoint_are_bit_reproducible(Y, X, solver):
+    B = 3
+    g = o.geometry(Y, X)
+    pre = solver != "cg"
+    mk = ops.SceneMasks(g.active, g.inflow, g.bc_mask, g.bc_mask, precondition=pre, pressure_solver="auto" if solver == "direct" else "cg")
+    cfg = ops.karman_cfg(B, Y, X, g.dx, masks=mk)
+    d, vy, vx = (f32(t) for t in o.synthetic_state(B, Y, X, 21, project_it=False))
+    re = f32(torch.tensor(o.RE_TRAIN[:B]))
+    gen = torch.Generator().manual_seed(5)
+    wy, wx = f32(torch.randn(vy.shape, generator=gen)), f32(torch.randn(vx.shape, generator=gen))
+    runs = []
+    for r in range(3):
+        a, b = vy.clone().requires_grad_(True), vx.clone().requires_grad_(True)
+        d2, py, px = ops.karman_step(d, a, b, re, cfg, mk)
+        ((py * wy).sum() + (px * wx).sum()).backward()
+        runs.append((d2, py, px, a.grad, b.grad))
+        _scramble()
+    for r in (1, 2):
+        for t0, t1, name in zip(runs[0], runs[r], ("density", "v_y", "v_x", "grad v_y", "grad v_x")):
+            assert same_bits(t0, t1), "%s differs between two runs of the same step (%s, %dx%d)" % (name, solver, Y, X)
+    assert float(runs[0][3].abs().max()) > 0
+
+
+# ---------------------------------------------------------------------------------------------
+# 3-D solver step, forward and adjoint (the int64 fixed-point scatter)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 32, 16, 16), (1, 128, 64, 64)])
+def test_karman3d_step_forward_and_adjoint_are_bit_reproducible(shape):
+    B, Y, X, Z = shape
+    sc = k3.Scene3D(Y, X, Z, device=DEV)
+    sim = k3.Karman3DFlow(sc, B)
+    gen = torch.Generator().manual_seed(9)
+    r = lambda *s: torch.randn(*s, generator=gen)
+    d = f32(torch.rand(B, Y, X, Z, generator=gen))
+    v = [f32(1.0 + 0.3 * r(B, Y + 1, X, Z)), f32(0.3 * r(B, Y, X + 1, Z)), f32(0.3 * r(B, Y, X, Z + 1))]
+    w = [f32(r(*c.shape)) for c in v]
+    re = f32(torch.tensor(o3.RE_TRAIN[:B]))
+    runs = []
+    for _ in range(3):
+        hv = [c.clone().requires_grad_(True) for c in v]
+        out = sim.step(d, hv[0], hv[1], hv[2], re)
+        sum((a * b).sum() for a, b in zip(out[1:], w)).backward()
+        runs.append(tuple(out) + tuple(c.grad for c in hv))
+        _scramble()
+    names = ("density", "v_y", "v_x", "v_z", "grad v_y", "grad v_x", "grad v_z")
+    for rr in (1, 2):
+        for t0, t1, name in zip(runs[0], runs[rr], names):
+            assert same_bits(t0, t1), "%s differs between two runs of the same 3-D step %s" % (name, shape)
+    assert min(float(t.abs().max()) for t in runs[0][4:]) > 0
+
+
+def test_karman3d_fixed_point_scatter_resolution_and_range():
+    """The scale of the int64 scatter follows max|gradient| (a power of two): the adjoint of g and of 2^k g agree up to the exact
+    factor for gradients of very different magnitude (no fixed-point underflow or overflow), and a zero gradient gives zeros."""
+    B, Y, X, Z = 1, 32, 16, 16
+    sc = k3.Scene3D(Y, X, Z, device=DEV)
+    sim = k3.Karman3DFlow(sc, B)
+    gen = torch.Generator().manual_seed(2)
+    r = lambda *s: torch.randn(*s, generator=gen)
+    d = f32(torch.rand(B, Y, X, Z, generator=gen))
+    v = [f32(1.0 + 0.3 * r(B, Y + 1, X, Z)), f32(0.3 * r(B, Y, X + 1, Z)), f32(0.3 * r(B, Y, X, Z + 1))]
+    w = [f32(r(*c.shape)) for c in v]
+    re = f32(torch.tensor(o3.RE_TRAIN[:B]))
+    grads = {}
+    for k in (0, 40, -60):
+        hv = [c.clone().requires_grad_(True) for c in v]
+        out = sim.step(d, hv[0], hv[1], hv[2], re)
+        sum((a * (b * 2.0 ** k)).sum() for a, b in zip(out[1:], w)).backward()
+        grads[k] = [c.grad * 2.0 ** -k for c in hv]
+    for k in (40, -60):
+        for a, b in zip(grads[0], grads[k]):
+            assert rel(b, a) < 2e-6, (k, rel(b, a))          # the solves are linear in g up to fp32 round-off
+    hv = [c.clone().requires_grad_(True) for c in v]
+    out = sim.step(d, hv[0], hv[1], hv[2], re)
+    sum((a * 0.0).sum() for a in out[1:]).backward()
+    assert all(float(c.grad.abs().max()) == 0.0 for c in hv)
+
+
+# ---------------------------------------------------------------------------------------------
+# training steps: gradient, per-step losses and final state, eager and replayed graph
+# ---------------------------------------------------------------------------------------------
+def _trainer2d(B, Y, X, ms, use_graph, seed=0):
+    g = o.geometry(Y, X)
+    mk = ops.SceneMasks(g.active, g.inflow, g.bc_mask, g.bc_mask)
+    net = sol_amd.model_mars_moon(cin=3, cout=2, seed=seed, device=DEV)
+    with torch.no_grad():
+        net.tensors()[22].mul_(0.05)
+    tr = sol_amd.SolTrainer(net, mk, B, Y, X, ms, g.dx, (0.2, 0.25), o.STD_RE, use_graph=use_graph)
+    d, vy, vx = (f32(t) for t in o.synthetic_state(B, Y, X, 31, project_it=False))
+    re = f32(torch.tensor([o.RE_TRAIN[i % 6] for i in range(B)]))
+    gts = [o.synthetic_state(B, Y, X, 600 + i, project_it=False) for i in range(ms)]
+    gy, gx = f32(torch.stack([s[1] for s in gts])), f32(torch.stack([s[2] for s in gts]))
+    return tr, (d, vy, vx, re, gy, gx)
+
+
+@pytest.mark.parametrize("B,Y,X,ms,use_graph", [(6, 128, 64, 4, True), (6, 128, 64, 4, False), (3, 64, 32, 4, True), (2, 16, 8, 2, False)])
+def test_training_step_2d_is_bit_reproducible(B, Y, X, ms, use_graph):
+    tr, batch = _trainer2d(B, Y, X, ms, use_graph)
+    runs = []
+    for _ in range(3):
+        tr.grads.zero_()
+        tr.fwd_bwd(*batch, want_final=True)
+        torch.cuda.synchronize()
+        runs.append((tr.grads.clone(), tr.loss_steps.clone()) + tuple(t.clone() for t in tr.final))
+        _scramble()
+    for rr in (1, 2):
+        assert same_bits(runs[0][0], runs[rr][0]), "gradient differs between two runs of the same training step"
+        for t0, t1 in zip(runs[0][2:], runs[rr][2:]):
+            assert same_bits(t0, t1), "final state differs between two runs"
+        # the per-step losses are sums folded by floating-point atomics across workgroups: equal to round-off, not bit for bit
+        assert rel(runs[rr][1], runs[0][1]) < 1e-6
+    assert float(runs[0][0].abs().max()) > 0
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_training_step_3d_is_bit_reproducible(use_graph):
+    B, Y, X, Z, ms = 1, 32, 16, 64, 2          # W = 64: the one-launch Conv3D kernels and the batched weight gradients run
+    sc = k3.Scene3D(Y, X, Z, device=DEV)
+    net = k3.MarsMoon3D(device=DEV)
+    w = net.get_weights()
+    w[22] = w[22] * 0.05
+    net.set_weights(w)
+    tr = k3.Karman3DTrainer(net, sc, B, ms, (0.2, 0.25, 0.3), o3.STD_RE, use_graph=use_graph)
+    gen = torch.Generator().manual_seed(4)
+    r = lambda *s: torch.randn(*s, generator=gen)
+    st = (torch.rand(B, Y, X, Z, generator=gen), 1.0 + 0.2 * r(B, Y + 1, X, Z), 0.2 * r(B, Y, X + 1, Z), 0.2 * r(B, Y, X, Z + 1))
+    re = torch.tensor(o3.RE_TRAIN[:B])
+    gts = [(1.0 + 0.2 * r(B, Y + 1, X, Z), 0.2 * r(B, Y, X + 1, Z), 0.2 * r(B, Y, X, Z + 1)) for _ in range(ms)]
+    runs = []
+    for _ in range(3):
+        tr._grads.zero_()
+        loss = tr.fwd_bwd(*st, re, gts)
+        torch.cuda.synchronize()
+        runs.append((tr.grads.clone(), loss.clone().reshape(1)) + tuple(t.clone() for t in tr.final))
+        _scramble()
+    for rr in (1, 2):
+        assert same_bits(runs[0][0], runs[rr][0]), "3-D gradient differs between two runs of the same training step"
+        assert same_bits(runs[0][1], runs[rr][1]), "3-D loss differs between two runs"
+        for t0, t1 in zip(runs[0][2:], runs[rr][2:]):
+            assert same_bits(t0, t1)
+    assert float(runs[0][0].abs().max()) > 0
+
+
+# ---------------------------------------------------------------------------------------------
+# stand-alone l2 loss (sol_l2_loss_fwd_bwd)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,Y,X", [(3, 64, 32), (6, 128, 64), (1, 16, 8)])
+def test_l2_loss_against_the_reference_formula(B, Y, X):
+    """karman_train.py:428-436: tf.nn.l2_loss((gt.staggered - prd.staggered) / (std_v0, std_v1)) = 0.5 * sum over the padded
+    [B, Y+1, X+1, 2] tensor (the padding is zero in both operands) -- value and gradient against float64, accumulation modes,
+    bit reproducibility, and the torch op with autograd."""
+    gen = torch.Generator().manual_seed(8)
+    vy, vx = torch.randn(B, Y + 1, X, generator=gen, dtype=torch.float64), torch.randn(B, Y, X + 1, generator=gen, dtype=torch.float64)
+    gy, gx = torch.randn(B, Y + 1, X, generator=gen, dtype=torch.float64), torch.randn(B, Y, X + 1, generator=gen, dtype=torch.float64)
+    std = (0.2, 0.31)
+    a, b = vy.float().double().requires_grad_(True), vx.float().double().requires_grad_(True)
+    gy, gx = gy.float().double(), gx.float().double()
+    # the reference's formula on the padded staggered tensors of the oracle
+    diff = (o.staggered_tensor(gy, gx) - o.staggered_tensor(a, b)) / torch.tensor(std, dtype=torch.float64)
+    ref = 0.5 * (diff ** 2).sum()
+    ref.backward()
+    loss, g = ops.l2_loss_fwd_bwd((f32(a), f32(b)), (f32(gy), f32(gx)), std, gscale=0.25)
+    assert abs(float(loss) - float(ref)) < 2e-6 * float(ref)
+    assert rel(g[0], 0.25 * a.grad) < 1e-6 and rel(g[1], 0.25 * b.grad) < 1e-6
+    # accumulate into an existing loss / gradient (the unroll: loss = sum_i, gradient += at every step)
+    loss2, g2 = ops.l2_loss_fwd_bwd((f32(a), f32(b)), (f32(gy), f32(gx)), std, gscale=0.25, loss=loss.clone(), grads=[t.clone() for t in g])
+    assert abs(float(loss2) - 2 * float(ref)) < 2e-6 * 2 * float(ref) and rel(g2[0], 0.5 * a.grad) < 1e-6
+    # forward only
+    loss3, g3 = ops.l2_loss_fwd_bwd((f32(a), f32(b)), (f32(gy), f32(gx)), std, want_grad=False)
+    assert g3 is None and same_bits(loss3, loss)
+    for _ in range(2):
+        _scramble()
+        l4, g4 = ops.l2_loss_fwd_bwd((f32(a), f32(b)), (f32(gy), f32(gx)), std, gscale=0.25)
+        assert same_bits(l4, loss) and same_bits(g4[0], g[0]) and same_bits(g4[1], g[1])
+    # torch.ops.sol.l2_loss with autograd
+    ta, tb = f32(a).requires_grad_(True), f32(b).requires_grad_(True)
+    tl = torch.ops.sol.l2_loss(ta, tb, f32(gy), f32(gx), std[0], std[1])
+    (3.0 * tl).backward()
+    assert abs(float(tl) - float(ref)) < 2e-6 * float(ref) and rel(ta.grad, 3.0 * a.grad) < 1e-6 and rel(tb.grad, 3.0 * b.grad) < 1e-6
+
+
+def test_l2_loss_three_components_and_bad_arguments():
+    gen = torch.Generator().manual_seed(1)
+    v = [torch.randn(2, 9, 8, 8, generator=gen), torch.randn(2, 8, 9, 8, generator=gen), torch.randn(2, 8, 8, 9, generator=gen)]
+    gt = [torch.randn(t.shape, generator=gen) for t in v]
+    std = (0.2, 0.25, 0.3)
+    ref = sum(0.5 * (((g.double() - a.double()) / s) ** 2).sum() for g, a, s in zip(gt, v, std))
+    loss, g = ops.l2_loss_fwd_bwd([f32(t) for t in v], [f32(t) for t in gt], std)
+    assert abs(float(loss) - float(ref)) < 2e-6 * float(ref)
+    assert rel(g[2], (v[2].double() - gt[2].double()) / std[2] ** 2) < 1e-6
+    with pytest.raises(sol_amd.SolError):
+        ops.l2_loss_fwd_bwd([f32(v[0])], [f32(gt[0])], (0.0,))
+
+
+def test_reference_loss_composed_from_the_per_op_abi_equals_the_fused_trainer():
+    """A host that binds only the per-op ABI composes the reference's unrolled loss (karman_train.py:397-447) from
+    torch.ops.sol.karman_step + conv5x5 + l2_loss; it must equal the fused trainer's loss and gradient."""
+    from sol_amd import torch_ops
+    B, Y, X, ms = 2, 64, 32, 2
+    tr, (d, vy, vx, re, gy, gx) = _trainer2d(B, Y, X, ms, use_graph=False)
+    hl = tr.fwd_bwd(d, vy, vx, re, gy, gx)
+    g = o.geometry(Y, X)
+    mk = tr.masks if hasattr(tr, "masks") else ops.SceneMasks(g.active, g.inflow, g.bc_mask, g.bc_mask)
+    scene = torch_ops.register_scene(ops.karman_cfg(B, Y, X, g.dx, masks=mk), mk)
+    net = tr.net
+    params = net.params.detach().clone().requires_grad_(True)
+    p = [params[net.offsets[k]:net.offsets[k + 1]].reshape(net.shapes[k]) for k in range(len(net.shapes))]
+    sl = net.slope
+    std_v = (0.2, 0.25)
+
+    def cnn(x):
+        h = torch.ops.sol.conv5x5(x, p[0], p[1], None, True, sl)
+        for k in range(5):
+            a = torch.ops.sol.conv5x5(h, p[2 + 4 * k], p[3 + 4 * k], None, True, sl)
+            h = torch.ops.sol.conv5x5(a, p[4 + 4 * k], p[5 + 4 * k], h, True, sl)
+        return torch.ops.sol.conv5x5(h, p[22], p[23], None, False, sl)
+
+    dd, a, b = d, vy, vx
+    total = 0.0
+    for i in range(ms):
+        dd, a, b = torch.ops.sol.karman_step(dd, a, b, re, scene)
+        feat = torch.stack([a[:, :Y] / std_v[0], b[:, :, :X] / std_v[1], (re / o.STD_RE).reshape(B, 1, 1).expand(B, Y, X)], dim=-1)
+        out = cnn(feat.contiguous())
+        a = a + torch.nn.functional.pad(out[..., 0] * std_v[0], (0, 0, 0, 1))
+        b = b + torch.nn.functional.pad(out[..., 1] * std_v[1], (0, 1))
+        total = total + torch.ops.sol.l2_loss(a.contiguous(), b.contiguous(), gy[i], gx[i], std_v[0], std_v[1])
+    loss = total / ms
+    loss.backward()
+    assert abs(float(loss) - float(hl)) < 1e-5 * abs(float(hl)), (float(loss), float(hl))
+    assert rel(params.grad, tr.grads) < 1e-4, rel(params.grad, tr.grads)
