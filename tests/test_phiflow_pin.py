@@ -1,0 +1,204 @@
+"""The PIN for the oracle (CPU, `-m "not gpu"`): compares oracle/sol_oracle.py with fixtures produced by the REFERENCE's own code
+under phiflow 1.5.1 / TensorFlow 1.15 (tests/golden/phiflow_*.npz, written by tests/golden/make_phiflow_fixtures.py where those
+packages exist).  While no such fixture is committed the pin tests SKIP -- parity stays "unpinned"  -- but the
+comparator itself is tested against stand-in fixtures generated with NON-default settings of the recalled choices Q2-Q7 (SURVEY
+appendix A): it must name the setting that produced them and reject the default."""
+import glob
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import sol_oracle as o
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL_FIELD, TOL_GRAD, TOL_LOSS = 1e-5, 1e-4, 1e-5
+
+# candidate settings of the recalled choices: name -> (karman_step kwargs, geometry kwargs)
+KARMAN_SETTINGS = {
+    "default": ({}, {}),
+    "Q2 inflow_order=before": (dict(inflow_order="before"), {}),
+    "Q3 inflow_antialias": ({}, dict(inflow_antialias=True)),
+    "Q4 den_mode=zero_box": (dict(den_mode="zero_box"), {}),
+    "Q5 grad_pad=dirichlet0": (dict(grad_pad="dirichlet0"), {}),
+    "Q6 solver=cg": (dict(solver="cg"), {}),
+    "Q2+Q5": (dict(inflow_order="before", grad_pad="dirichlet0"), {}),
+}
+BURGERS_SETTINGS = {"default": dict(periodic_faces="array"), "Q7 periodic_faces=domain": dict(periodic_faces="domain")}
+
+
+def rel(a, b):
+    a = torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    b = torch.as_tensor(np.asarray(b), dtype=torch.float64)
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def t64(a):
+    return torch.as_tensor(np.asarray(a), dtype=torch.float64)
+
+
+def compare_karman_step(z):
+    """{setting: {output: relative L2 error of the oracle against the fixture}}"""
+    B, Y, X = z["d"].shape
+    res = {}
+    for name, (kw, gkw) in KARMAN_SETTINGS.items():
+        g = o.geometry(Y, X, **gkw)
+        vy, vx = t64(z["vy"]).requires_grad_(True), t64(z["vx"]).requires_grad_(True)
+        d2, py, px = o.karman_step(t64(z["d"]), vy, vx, t64(z["re"]), g, **kw)
+        ((py * t64(z["wy"])).sum() + (px * t64(z["wx"])).sum()).backward()
+        res[name] = {"d_out": rel(d2.detach(), z["d_out"]), "vy_out": rel(py.detach(), z["vy_out"]), "vx_out": rel(px.detach(), z["vx_out"]),
+                     "g_vy": rel(vy.grad, z["g_vy"]), "g_vx": rel(vx.grad, z["g_vx"])}
+    return res
+
+
+def compare_burgers_step(z):
+    res = {}
+    for name, kw in BURGERS_SETTINGS.items():
+        vy, vx = t64(z["vy"]).requires_grad_(True), t64(z["vx"]).requires_grad_(True)
+        ay, ax = o.burgers_step(vy, vx, float(z["dt"]), float(z["nu"]), t64(z["fy"]), t64(z["fx"]), **kw)
+        ((ay * t64(z["wy"])).sum() + (ax * t64(z["wx"])).sum()).backward()
+        res[name] = {"vy_out": rel(ay.detach(), z["vy_out"]), "vx_out": rel(ax.detach(), z["vx_out"]), "g_vy": rel(vy.grad, z["g_vy"]), "g_vx": rel(vx.grad, z["g_vx"])}
+    return res
+
+
+def compare_train(z, inputs):
+    """z: phiflow_train_16x8_sol2.npz (results), inputs: train_16x8_sol2.npz (the oracle fixture holding the inputs)"""
+    from test_golden_oracle import golden_train_params
+    i = inputs
+    B, Y, X = i["d"].shape
+    ms = i["gt_vy"].shape[0]
+    res = {}
+    for name, (kw, gkw) in KARMAN_SETTINGS.items():
+        g = o.geometry(Y, X, **gkw)
+        params = [p.clone().requires_grad_(True) for p in golden_train_params(i)]
+        loss, losses, states = o.unrolled_loss(params, t64(i["d"]), t64(i["vy"]), t64(i["vx"]), t64(i["re"]),
+                                               [t64(i["gt_vy"][k]) for k in range(ms)], [t64(i["gt_vx"][k]) for k in range(ms)], g,
+                                               tuple(float(v) for v in i["std_v"]), float(i["std_re"]), return_states=True, **kw)
+        loss.backward()
+        flat = torch.cat([p.grad.reshape(-1) for p in params])
+        res[name] = {"loss": abs(float(loss) - float(z["loss"])) / abs(float(z["loss"])),
+                     "loss_steps": rel(torch.stack(losses).detach(), z["loss_steps"]),
+                     "vy_final": rel(states[-1][1].detach(), z["vy_final"]), "vx_final": rel(states[-1][2].detach(), z["vx_final"]),
+                     "grads_sub16": rel(flat[::16], z["grads_sub16"])}
+    return res
+
+
+def tolerance(key):
+    return TOL_GRAD if key.startswith("g") else (TOL_LOSS if key.startswith("loss") else TOL_FIELD)
+
+
+def matches(res):
+    """settings whose every output is within tolerance"""
+    return [n for n, r in res.items() if all(v < tolerance(k) for k, v in r.items())]
+
+
+def report(res):
+    return "\n".join("  %-28s %s" % (n, "  ".join("%s %.2e" % kv for kv in r.items())) for n, r in res.items())
+
+
+def verdict(res, what):
+    ok = matches(res)
+    msg = "%s: oracle vs PhiFlow fixture\n%s\n" % (what, report(res))
+    assert ok, msg + "NO setting of the recalled choices reproduces the reference: the oracle restates something wrongly (not one of Q2-Q7)"
+    assert "default" in ok, msg + ("the DEFAULT setting does not reproduce the reference but %s does: make that the default of oracle/sol_oracle.py "
+                                   "AND of the HIP path (ops.karman_cfg), then regenerate tests/golden/*.npz" % ok)
+    return ok
+
+
+# ---------------------------------------------------------------------------------------------
+# the pin proper: runs when the reference-generated fixtures are present
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["phiflow_karman_step_64x32", "phiflow_karman_step_16x8"])
+def test_oracle_karman_step_against_phiflow(name):
+    path = os.path.join(GOLDEN, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip("PARITY UNPINNED: %s.npz is absent (generate it with tests/golden/make_phiflow_fixtures.py where phiflow 1.5.1 + TF 1.15 are installed)" % name)
+    verdict(compare_karman_step(np.load(path)), name)
+
+
+def test_oracle_burgers_step_against_phiflow():
+    path = os.path.join(GOLDEN, "phiflow_burgers_step_32x32.npz")
+    if not os.path.exists(path):
+        pytest.skip("PARITY UNPINNED: phiflow_burgers_step_32x32.npz is absent (tests/golden/make_phiflow_fixtures.py)")
+    verdict(compare_burgers_step(np.load(path)), "burgers step_with_f")
+
+
+def test_oracle_unrolled_loss_against_phiflow():
+    path = os.path.join(GOLDEN, "phiflow_train_16x8_sol2.npz")
+    if not os.path.exists(path):
+        pytest.skip("PARITY UNPINNED: phiflow_train_16x8_sol2.npz is absent (tests/golden/make_phiflow_fixtures.py)")
+    verdict(compare_train(np.load(path), np.load(os.path.join(GOLDEN, "train_16x8_sol2.npz"))), "unrolled SOL-2 loss")
+
+
+def test_pin_status_is_reported():
+    """One line in the test log that says whether the oracle is pinned (nothing is asserted about the status itself)."""
+    have = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "phiflow_*.npz")))
+    print("oracle pin status: %s" % ("PINNED by " + ", ".join(have) if have else "UNPINNED (no tests/golden/phiflow_*.npz)"))
+
+
+# ---------------------------------------------------------------------------------------------
+# the comparator and the generator script, tested without PhiFlow
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("setting", ["Q2 inflow_order=before", "Q5 grad_pad=dirichlet0", "Q4 den_mode=zero_box", "Q3 inflow_antialias"])
+def test_comparator_names_the_setting_that_generated_a_stand_in_fixture(setting):
+    """A stand-in "reference" fixture generated by the oracle under a NON-default setting: the comparator must single that
+    setting out and refuse the default."""
+    z = dict(np.load(os.path.join(GOLDEN, "karman_step_16x8.npz")))
+    kw, gkw = KARMAN_SETTINGS[setting]
+    B, Y, X = z["d"].shape
+    g = o.geometry(Y, X, **gkw)
+    vy, vx = t64(z["vy"]).requires_grad_(True), t64(z["vx"]).requires_grad_(True)
+    d2, py, px = o.karman_step(t64(z["d"]), vy, vx, t64(z["re"]), g, **kw)
+    ((py * t64(z["wy"])).sum() + (px * t64(z["wx"])).sum()).backward()
+    z.update(d_out=d2.detach().numpy(), vy_out=py.detach().numpy(), vx_out=px.detach().numpy(), g_vy=vy.grad.numpy(), g_vx=vx.grad.numpy())
+    res = compare_karman_step(z)
+    ok = matches(res)
+    assert setting in ok and "default" not in ok, report(res)
+    with pytest.raises(AssertionError, match="DEFAULT setting does not reproduce"):
+        verdict(res, "stand-in")
+
+
+def test_comparator_accepts_the_committed_oracle_fixtures_as_default():
+    """Sanity of the tolerances: the oracle's own fixtures match under "default" (and under switches that do not touch that output)."""
+    ok = verdict(compare_karman_step(np.load(os.path.join(GOLDEN, "karman_step_16x8.npz"))), "oracle fixture 16x8")
+    assert "default" in ok and "Q5 grad_pad=dirichlet0" not in ok
+    okb = verdict(compare_burgers_step(np.load(os.path.join(GOLDEN, "burgers_step_32x32.npz"))), "oracle burgers fixture")
+    assert okb == ["default"]
+
+
+def test_train_comparator_on_the_committed_oracle_fixture():
+    z = np.load(os.path.join(GOLDEN, "train_16x8_sol2.npz"))
+    res = compare_train(z, z)
+    ok = matches(res)
+    assert "default" in ok and "Q5 grad_pad=dirichlet0" not in ok and "Q2+Q5" not in ok, report(res)
+
+
+def test_generator_script_fails_clearly_without_the_reference_stack_and_finds_the_reference_definitions():
+    script = os.path.join(GOLDEN, "make_phiflow_fixtures.py")
+    try:
+        import phi  # noqa: F401
+        have_phi = True
+    except ImportError:
+        have_phi = False
+    if not have_phi:
+        r = subprocess.run([sys.executable, script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode != 0 and "phiflow==1.5.1" in r.stdout and "tensorflow 1.15" in r.stdout
+    ref = "/root/reference"
+    if not os.path.exists(os.path.join(ref, "karman-2d", "karman_train.py")):
+        pytest.skip("reference checkout absent (GPU box): the definition lookup is checked in the build container")
+    sys.path.insert(0, GOLDEN)
+    import make_phiflow_fixtures as mk
+    # the named definitions exist in the reference and are plain def / class statements the extractor can lift; executing them needs
+    # phi, so here only the lookup is exercised (with stand-ins for the base classes)
+    class _Base:                                            # noqa: E306
+        def __init__(self, *a, **k):
+            pass
+    ns = {"IncompressibleFlow": _Base, "Gravity": lambda: None, "Burgers": _Base, "BurgersVelocity": _Base, "DomainState": type("D", (), {"domain": None}),
+          "struct": type("S", (), {"definition": staticmethod(lambda: (lambda c: c)), "variable": staticmethod(lambda **k: (lambda f: f))})}
+    mk.reference_defs(os.path.join(ref, "karman-2d", "karman_train.py"), ["to_feature", "to_staggered", "model_mars_moon", "KarmanFlow"], ns)
+    mk.reference_defs(os.path.join(ref, "burgers", "burgers_train.py"), ["BurgersVelocitySMAC", "BurgersTest"], ns)
+    assert all(k in ns for k in ("KarmanFlow", "to_feature", "to_staggered", "model_mars_moon", "BurgersTest", "BurgersVelocitySMAC"))
+    assert mk.velocity_bc(64, 32, 1).sum() == 190 and mk.velocity_bc(128, 64, 1).sum() == 382         # the BC-cell counts of the known-answer tests
