@@ -122,6 +122,9 @@ int sol_pack_jobs(hipStream_t s, int n, const float* const* w, float* const* out
 int sol_conv_sh_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int mode, void* out);
 int sol_conv_sb_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int mode, void* out);
 int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles);
+// dx-major form of the 32 -> 32 fp16 three-product kernel (conv5x5_dx.hip; option conv_dx)
+bool sol_conv_dx_usable(const ConvArgs& a, int NT);
+int sol_conv_dx_launch(hipStream_t s, const ConvArgs& a, int ntiles);
 
 // fused 5x5x5 convolution, 32 -> 32 or 32 -> (<= 16) channels, W == 64 (conv3d_sb.hip)
 size_t sol_conv3d_sh_packed_floats(int cout);
@@ -153,6 +156,8 @@ struct SolOptions {
     int k3d_fused_tf;     // 1 (default): the sine transforms of the karman-3d pressure solve as LDS-resident plane / column-slab kernels; 0: batched GEMMs
     int k3d_conv_rows;    // rows per workgroup of the one-launch Conv3D kernel: 8 (k_conv3d_sb8, 64 x 32 wave tiles), 6 (k_conv3d_sb6, 32 x 32), 3 (k_conv3d_sb, 16 x 32)
     int k3d_conv_fused;   // 1 (default): 32 -> 32 Conv3D layers with W == 64 and a known operand absmax as ONE launch (conv3d_sb.hip); 0: five passes of the 2-D kernel
+    int conv_dx;          // 1 (default): the 32 -> 32 fp16 three-product convolutions run the dx-major kernel (conv5x5_dx.hip: a wave owns a pixel segment of all
+                          //    three output rows, 0.53 LDS operand reads per MFMA); 0: k_conv5x5_sb (one output row per wave, 1.0 reads per MFMA)
     int k3d_tile;         // 1: karman-3d advection from LDS tiles holding the full z column + halo; 0 (default, measured faster at B <= 2): wave-per-column gathers from global memory
 };
 SolOptions& sol_opt();

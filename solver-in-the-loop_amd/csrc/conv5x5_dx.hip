@@ -1,0 +1,341 @@
+// 5x5 SAME convolution, 32 -> 32 channels, fp16 three-product arithmetic (KIND 2 of conv5x5_sb.hip: same operand splits, same
+// per-product arithmetic, same packed weight buffer) in a "dx-major" schedule that makes the tap loop matrix-pipe bound.
+//
+// Why (round-3 verdict): in k_conv5x5_sb every wave owns one 16 px x 32 co tile of ONE output row and reads
+// six 16-byte operands from LDS for six MFMAs per tap -- 72 ds_read_b128 per tap and CU (~390 clocks of the LDS pipe) for 288
+// clocks of MFMA per SIMD: the loop is operand bound.  The reuse that is left lies ACROSS OUTPUT ROWS: input row s meets output
+// row j at tap row dy = s - j, so one pixel operand A(s, dx) serves up to three output rows, and one weight operand B(dy, dx)
+// serves all seven input rows of a workgroup.  Here a wave owns a 16-pixel segment of ALL THREE output rows of the workgroup
+// and one 16-channel output tile (8 waves = 4 segments x 2 channel tiles, two waves per SIMD):
+//   for dx in 0..4:                                    (phase: one barrier each; the 20 KB weight set of a phase is double buffered)
+//       B(dy, dx), dy = 0..4        -> 40 VGPRs        (10 ds_read_b128)
+//       for s in 0..6:  A(s, dx)                       ( 2 ds_read_b128)
+//           for j with 0 <= s - j <= 4:  three MFMAs   (45 MFMAs per phase)
+// = 24 operand reads per 45 MFMAs (0.53 per MFMA instead of 1.0): 960 reads per launch and CU instead of 1800, under 7200
+// clocks of MFMA per SIMD.  All seven input rows are staged ONCE in the prologue (no row staging inside the loop), the
+// accumulators come out as D[co][px] (weights as the A operand of the MFMA), i.e. a lane holds four consecutive output channels
+// of one pixel: the epilogue stores 16-byte pieces straight from registers -- no LDS transposition, no epilogue barrier, and the
+// residual / activation-reference operands are prefetched into registers in the same layout.
+//
+// Replaces keras.layers.Conv2D(32, 5, padding='same') (+ bias, LeakyReLU, residual add) of model_mars_moon
+// (/root/reference/karman-2d/karman_train.py:101-138) for the ten 32 -> 32 layers, forward and backward-data.
+#include "split_kernels.hpp"
+
+namespace {
+
+using namespace sbk;
+
+constexpr int DX_HWP = 68;                         // halo pixels per row (64 + 4)
+constexpr int DX_PLANE = DX_HWP * 64;              // bytes per fp16 plane of one halo row
+constexpr int DX_SLOT = 2 * DX_PLANE;              // hi + lo plane
+constexpr int DX_NS = 7;                           // input rows of three output rows
+constexpr int DX_WPL = 32 * 64;                    // bytes per (tap, plane) weight block: 32 co x 32 ci fp16
+constexpr int DX_WPH = 5 * 2 * DX_WPL;             // bytes per dx phase: five dy x two planes
+constexpr int DX_LDS = DX_NS * DX_SLOT + 2 * DX_WPH + 16;
+
+#define DX_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// -DSOL_CONV_PROF (tools/conv_dx_probe.py builds such a library next to the product one): phase stamps (100 MHz s_memrealtime,
+// thread 0 of every workgroup, 16 per workgroup) into the buffer set with sol_conv_dx_prof_set().
+#ifdef SOL_CONV_PROF
+__device__ long long* g_dx_prof = nullptr;          // [cap launches][grid][16] stamps; g_dx_prof_ctl = {launch counter, cap}
+__device__ unsigned g_dx_prof_ctl[2] = {0u, 1u};
+// (the buffer pointer is read ONCE into scalar registers: a stamp that reloads it costs a scalar-memory round trip, ~0.5 us each)
+#define DX_STAMP(k) do { if (threadIdx.x == 0 && dx_prof) dx_prof[(k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DX_STAMP(k) do { } while (0)
+#endif
+
+__global__ void __launch_bounds__(512) k_conv5x5_dx(ConvArgs a, int nrows) {
+    extern __shared__ __align__(16) unsigned char smem_dx[];
+    unsigned char* const ring = smem_dx;                        // [7 slots][2 planes][68 px][64 B]
+    unsigned char* const Wt = smem_dx + DX_NS * DX_SLOT;        // [2 buffers][5 dy][2 planes][32 co][64 B]
+    unsigned* const amax_lds = reinterpret_cast<unsigned*>(smem_dx + DX_NS * DX_SLOT + 2 * DX_WPH);
+    const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int seg = wid & 3, cot = wid >> 2;                    // 16-pixel segment, 16-channel output tile (wave uniform)
+    const int g = lane >> 4, li = lane & 15;
+    const int H = a.H, W = a.W;
+#ifdef SOL_CONV_PROF
+    long long* __restrict__ dx_prof = g_dx_prof;
+    if (dx_prof) dx_prof += ((size_t)(g_dx_prof_ctl[0] % g_dx_prof_ctl[1]) * gridDim.x + blockIdx.x) * 16;
+#endif
+    DX_STAMP(0);
+    if (tid == 0) *reinterpret_cast<uint2*>(amax_lds) = make_uint2(0u, 0u);
+    // What needs no tile coordinates is requested first, in the shadow of the scalar preamble: the absmax slots and the role's weight set
+    // (phase 0 / phase 1: piece k = dy block k, position t).  NAMED registers: an array captured by the staging lambda was put into
+    // scratch memory (a store behind every load: the requests serialised, first MFMA at 5.4 us).
+    const bool late = wid >= 4;                                  // wave uniform (SGPR): staging role, see below
+    const int t = tid & 255;
+    const uint4 am = amax_load(a.xmax);
+    const uint4* gw = reinterpret_cast<const uint4*>(a.wsh) + 1;          // behind the header {2^shift_w, 2^-shift_w, 0, 0}
+    const uint4* wsrc = gw + (size_t)(late ? 1 : 0) * 256 + t;
+    const uint4 wq0 = wsrc[0 * 5 * 256], wq1 = wsrc[1 * 5 * 256], wq2 = wsrc[2 * 5 * 256], wq3 = wsrc[3 * 5 * 256], wq4 = wsrc[4 * 5 * 256];
+    const float winv = reinterpret_cast<const float*>(a.wsh)[1];
+    // Scalar preamble, kept short: it runs before the first request can go out (its first form -- four integer divisions on the
+    // VALU with read-first-lane round trips and a compare chain per (s, j) pair, 330 instructions -- cost 1.2 us of every launch).
+    const int bx = xcd_tile(blockIdx.x, gridDim.x);
+    int tx = 0, ty = bx;
+    if (a.tiles_x != 1) { tx = bx % a.tiles_x; ty = bx / a.tiles_x; }      // (W == 64: one column block, no division)
+    const int G0 = ty * 3, x0 = tx * 64;
+    // image of row G0: H is a power of two in every shipped configuration (a.RPW = log2 H, set by the launcher; -1: one division)
+    const int b0 = a.RPW >= 0 ? (G0 >> a.RPW) : G0 / H;
+    const int lo0 = b0 * H, hi0 = lo0 + H;
+    // validity of (input slot s, output row j): the input row G0 - 2 + s must lie in the image of output row G0 + j; the three
+    // rows span at most two images, and for one j the valid s form a range
+    unsigned vmask = 0u;                                        // bit j * 8 + s  (wave uniform: SGPR)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int gj = G0 + j;
+        const int lo = gj >= hi0 ? hi0 : lo0;                   // first row of gj's image
+        const int smin = max(j, lo - (G0 - 2)), smax = min(j + 4, lo + H - 1 - (G0 - 2));
+        if (gj < nrows && smax >= smin) vmask |= (((2u << smax) - 1u) & ~((1u << smin) - 1u)) << (j * 8);
+    }
+    vmask = __builtin_amdgcn_readfirstlane(vmask);
+
+    const float4* gx = reinterpret_cast<const float4*>(a.x);
+    // ---- prologue: every request goes out before anything is waited for ------------------------------------------------------
+    // Staging by ROLE.  A CU's vector-memory path moves ~64 B per clock and a wave issues in order: the 105 KB a workgroup needs
+    // before its second barrier (seven input rows, the weight sets of phases 0 and 1) take ~0.85 us to pass through it, and a wave
+    // that has to push its share of ALL of it through before it may touch the first row that came back sits on the critical path
+    // for all of that time (first form of this kernel: first MFMA 3.7 us after the launch).  So waves 0..3 ("early") request, split
+    // and stage only what the first three steps read -- rows 0..2, their halo pixels, the weight set of phase 0 -- and waves 4..7
+    // ("late") request rows 3..6, their halo and the weight set of phase 1, go straight to the first barrier, run steps 0..2 and
+    // stage their share behind them (stage_late, in front of the phase's own barrier), when it has long arrived.
+    // Thread map of a role (256 threads): channel quad c4 = t & 7 of pixels p, p + 32 (p = t >> 3) of each of the role's rows --
+    // one base address, constant LDS destination + immediates, no predicate (W % 64 == 0; rows outside [0, nrows) come from a
+    // clamped row and are never used: `vmask` masks every pair that would read them).  Halo pixels (x0 - 2, x0 - 1, x0 + 64,
+    // x0 + 65; zero unless a neighbouring column block exists): one item for the first 32 threads per row of the role.
+    const int c4 = t & 7, p = t >> 3;
+    const int s_base = late ? 3 : 0, n_rows = late ? 4 : 3;
+    const int hrow = t >> 5, hp = (t >> 3) & 3, hc_h = hp < 2 ? hp : hp + 64;     // halo item: row s_base + hrow (if hrow < n_rows), halo position hc_h
+    const int hxx = x0 + hc_h - 2;
+    const bool hok = hxx >= 0 && hxx < W;
+    // weight set of phase dx as three 16-byte pieces of every thread (later phases): 1280 uint4 = five (dy) blocks of 256
+    auto load_w = [&](int dx, uint4& p0, uint4& p1, uint4& p2) {
+        const int i0 = tid, i1 = tid + 512, i2 = (tid & 255) + 1024;
+        p0 = gw[(size_t)((i0 >> 8) * 5 + dx) * 256 + (i0 & 255)];
+        p1 = gw[(size_t)((i1 >> 8) * 5 + dx) * 256 + (i1 & 255)];
+        p2 = gw[(size_t)((i2 >> 8) * 5 + dx) * 256 + (i2 & 255)];
+    };
+    auto store_w = [&](int buf, const uint4& p0, const uint4& p1, const uint4& p2) {
+        uint4* dst = reinterpret_cast<uint4*>(Wt + buf * DX_WPH);
+        dst[tid] = p0;
+        dst[tid + 512] = p1;
+        if (tid < 256) dst[tid + 1024] = p2;
+    };
+    auto row_of = [&](int s_) { const int gr = G0 - 2 + s_; return gr < 0 ? 0 : (gr >= nrows ? nrows - 1 : gr); };    // scalar clamp
+    float4 hv[8], hh;                                            // item n: row s_base + (n >> 1), pixel p + 32 (n & 1); the early role has six
+    const float4* src = gx + ((size_t)(x0 + p)) * 8 + c4;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int s_ = s_base + ((n >> 1) < n_rows ? (n >> 1) : n_rows - 1);          // (early role, n = 6, 7: a repeat of row 2, dropped)
+        hv[n] = src[(size_t)row_of(s_) * W * 8 + (n & 1) * 32 * 8];
+    }
+    hh = gx[((size_t)row_of(s_base + (hrow < n_rows ? hrow : n_rows - 1)) * W + (hok ? hxx : 0)) * 8 + c4];
+    __builtin_amdgcn_sched_barrier(0);
+    DX_STAMP(1);
+    float sa, sai;
+    amax_scale_of(am, sa, sai);
+    const float out_scale = sai * winv;
+    DX_STAMP(2);
+    auto put = [&](unsigned char* q, const float4& v) __attribute__((always_inline)) {
+        unsigned p00, p10, p01, p11;
+        split2h(v.x, v.y, sa, p00, p10);
+        split2h(v.z, v.w, sa, p01, p11);
+        *reinterpret_cast<uint2*>(q) = make_uint2(p00, p01);
+        *reinterpret_cast<uint2*>(q + DX_PLANE) = make_uint2(p10, p11);
+    };
+    auto stage_role = [&]() __attribute__((always_inline)) {
+        unsigned char* q0 = ring + s_base * DX_SLOT;
+        const int hcA = p + 2, hcB = p + 34;
+        unsigned char* qA = q0 + hcA * 64 + ((((c4 >> 1) ^ swzb(hcA)) << 4) | ((c4 & 1) << 3));
+        unsigned char* qB = q0 + hcB * 64 + ((((c4 >> 1) ^ swzb(hcB)) << 4) | ((c4 & 1) << 3));
+#pragma unroll
+        for (int n = 0; n < 6; ++n) put(((n & 1) ? qB : qA) + (n >> 1) * DX_SLOT, hv[n]);
+        if (late) { put(qA + 3 * DX_SLOT, hv[6]); put(qB + 3 * DX_SLOT, hv[7]); }
+        if (!hok) hh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hrow < n_rows) put(q0 + hrow * DX_SLOT + hc_h * 64 + ((((c4 >> 1) ^ swzb(hc_h)) << 4) | ((c4 & 1) << 3)), hh);
+        uint4* dst = reinterpret_cast<uint4*>(Wt + (late ? 1 : 0) * DX_WPH) + t;
+        dst[0] = wq0; dst[256] = wq1; dst[512] = wq2; dst[768] = wq3; dst[1024] = wq4;
+    };
+    auto stage_late = [&]() __attribute__((always_inline)) { if (late) stage_role(); };
+    if (!late) stage_role();
+    uint4 wA0, wA1, wA2, wB0, wB1, wB2;
+    wA0 = wA1 = wA2 = wB0 = wB1 = wB2 = make_uint4(0u, 0u, 0u, 0u);
+    DX_STAMP(12);
+    DX_BARRIER();
+    DX_STAMP(3);
+    float4 biasv = make_float4(0.f, 0.f, 0.f, 0.f);           // output channels cot * 16 + 4 g .. + 3 (epilogue): requested behind the barrier,
+    if (a.bias) {                                                // off the critical path (four dword loads: a caller's bias slice need not be 16-byte aligned)
+        const float* bp = a.bias + cot * 16 + 4 * g;
+        biasv = make_float4(bp[0], bp[1], bp[2], bp[3]);
+    }
+
+    f32x4 acc[3], acl[3];                                       // acl: the 2^-11 weighted cross terms
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acl[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    // epilogue operands (residual, activation reference): requested at the start of the last phase, consumed after the last MFMA
+    float4 resv[3], actv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { resv[j] = make_float4(0.f, 0.f, 0.f, 0.f); actv[j] = make_float4(1.f, 1.f, 1.f, 1.f); }
+    const int pcc = seg * 16 + li;                              // this lane's pixel inside the 64-pixel row
+    const int co_l = cot * 16 + li;                             // this lane's weight row (output channel) of the A operand
+    auto out_f4 = [&](int j) { return ((size_t)(G0 + j) * W + x0 + pcc) * 8 + cot * 4 + g; };   // float4 index of (row j, this pixel, co 4g..)
+    const unsigned char* const wlane = Wt + co_l * 64 + ((g ^ swzb(co_l)) << 4);
+    auto a_base = [&](int dx) { const int hc = pcc + dx; return ring + hc * 64 + ((g ^ swzb(hc)) << 4); };
+
+    // Operand registers: TWO weight sets (the set of phase dx + 1 is read during steps 4..6 of phase dx, behind the phase's only
+    // barrier) and two pixel operands (one step of look-ahead).  The stream of MFMAs therefore runs across the phase boundary
+    // without a bubble; the one barrier of a phase sits in its middle (after step 2, where the next phase's weights are
+    // written), when every wave is deep inside a run of MFMAs.
+    uint4 bw[2][5][2], ao[2][2];
+    auto read_b = [&](int set, int dx, int dy) __attribute__((always_inline)) {
+        bw[set][dy][0] = *reinterpret_cast<const uint4*>(wlane + (dx & 1) * DX_WPH + dy * 2 * DX_WPL);
+        bw[set][dy][1] = *reinterpret_cast<const uint4*>(wlane + (dx & 1) * DX_WPH + dy * 2 * DX_WPL + DX_WPL);
+    };
+    auto read_a = [&](int slot, int dx, int s_) __attribute__((always_inline)) {
+        const unsigned char* ab = a_base(dx);
+        ao[slot][0] = *reinterpret_cast<const uint4*>(ab + s_ * DX_SLOT);
+        ao[slot][1] = *reinterpret_cast<const uint4*>(ab + s_ * DX_SLOT + DX_PLANE);
+    };
+    read_b(0, 0, 0);
+    read_a(0, 0, 0);
+#pragma unroll
+    for (int dy = 1; dy < 5; ++dy) read_b(0, 0, dy);
+
+    auto phase = [&](const int dx, const int nxt, uint4& wi0, uint4& wi1, uint4& wi2, const uint4& wo0, const uint4& wo1, const uint4& wo2)
+                     __attribute__((always_inline)) {
+        const int set = dx & 1;
+        if (nxt >= 0) load_w(nxt, wi0, wi1, wi2);              // two phases of look-ahead (named register sets)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < DX_NS; ++s) {
+            // operands of the next step: A(s + 1) of this phase, or A(0) of the next one; behind the barrier also the next weight set
+            const int aslot = (dx * DX_NS + s) & 1;             // (7 steps per phase: the slot parity runs on across phases)
+            const bool late_a = dx == 0 && s == 2;              // row 3 is only staged behind this step (first phase)
+            if (s + 1 < DX_NS && !late_a) read_a(aslot ^ 1, dx, s + 1);
+            else if (dx < 4) read_a(aslot ^ 1, dx + 1, 0);
+            if (dx < 4) {
+                if (s == 4) { read_b(set ^ 1, dx + 1, 0); read_b(set ^ 1, dx + 1, 1); }
+                if (s == 5) { read_b(set ^ 1, dx + 1, 2); read_b(set ^ 1, dx + 1, 3); }
+                if (s == 6) read_b(set ^ 1, dx + 1, 4);
+            }
+            // Epilogue operands (residual: phase 2, activation reference: phase 3), ONE request per step 3..5 -- behind the LAST weight
+            // request (vmcnt retires in order: a weight set requested after these HBM-cold operands could not be waited for without
+            // them) and spread out: a lane's 16 bytes sit 128 bytes from its neighbour's, so each request occupies the CU's
+            // vector-memory path for 16 cache lines, and six of them back to back from all eight waves stalled every wave at issue
+            // (+0.8 us in that phase).  UNCONDITIONAL requests -- a launch without a residual / activation reference reads the same
+            // positions of x and drops the values: requests inside `if (a.res)` blocks make the compiler's next vmcnt wait a wait
+            // for everything in flight.
+            if ((dx == 2 || dx == 3) && s >= 3 && s <= 5) {
+                const int j = s - 3, jj = G0 + j < nrows ? j : 0;       // (scalar) rows beyond the tensor: any valid position
+                if (dx == 2) resv[j] = reinterpret_cast<const float4*>(a.res ? a.res : a.x)[out_f4(jj)];
+                else actv[j] = reinterpret_cast<const float4*>(a.epi == SOL_EPI_DLRELU ? a.act : a.x)[out_f4(jj)];
+            }
+            __builtin_amdgcn_sched_barrier(0);                  // keep the prefetch reads above this step's MFMAs
+            const f16x8 x1 = __builtin_bit_cast(f16x8, ao[aslot][0]), x2 = __builtin_bit_cast(f16x8, ao[aslot][1]);
+            const int jlo = s - 4 > 0 ? s - 4 : 0, jhi = s < 2 ? s : 2;      // (constants once the s loop is unrolled)
+            unsigned need = 0u;
+#pragma unroll
+            for (int j = jlo; j <= jhi; ++j) need |= 1u << (j * 8 + s);
+            if ((vmask & need) == need) {
+                // the common case (every pair of this step valid): one straight block, the three rows' chains interleaved
+#pragma unroll
+                for (int j = jlo; j <= jhi; ++j)
+                    acl[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bw[set][s - j][0]), x2, acl[j], 0, 0, 0);
+#pragma unroll
+                for (int j = jlo; j <= jhi; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bw[set][s - j][0]), x1, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = jlo; j <= jhi; ++j)
+                    acl[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bw[set][s - j][1]), x1, acl[j], 0, 0, 0);
+            } else {
+                // border / image-straddling workgroups: the pairs whose input row lies in another image are skipped
+#pragma unroll
+                for (int j = jlo; j <= jhi; ++j)
+                    if (vmask & (1u << (j * 8 + s))) {
+                        const f16x8 b1 = __builtin_bit_cast(f16x8, bw[set][s - j][0]), b2 = __builtin_bit_cast(f16x8, bw[set][s - j][1]);
+                        acl[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1, x2, acl[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1, x1, acc[j], 0, 0, 0);
+                        acl[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2, x1, acl[j], 0, 0, 0);
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s == 2 && dx < 4) {
+                // next phase's weights: their buffer was last read (as the set of phase dx - 1) before the previous phase's barrier;
+                // in the first phase also the input rows 3..6 (steps 3..6 read them)
+                if (dx == 0) stage_late();                        // rows 3..6 AND the weight set of phase 1 (late role)
+                else store_w((dx + 1) & 1, wo0, wo1, wo2);
+                DX_BARRIER();
+                if (late_a) read_a(aslot ^ 1, dx, s + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        DX_STAMP(4 + dx);
+    };
+    phase(0, 2, wB0, wB1, wB2, wA0, wA1, wA2);
+    phase(1, 3, wA0, wA1, wA2, wB0, wB1, wB2);
+    phase(2, 4, wB0, wB1, wB2, wA0, wA1, wA2);
+    phase(3, -1, wA0, wA1, wA2, wB0, wB1, wB2);
+    phase(4, -1, wA0, wA1, wA2, wA0, wA1, wA2);
+
+    // ---- epilogue: lane (li, g) holds output channels cot*16 + 4g .. + 3 of pixel pcc of the three rows -----------------------
+    float vmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (G0 + j < nrows) {                                   // wave uniform
+            float4 v;
+            v.x = (acc[j][0] + acl[j][0] * (1.f / 2048.f)) * out_scale + biasv.x;
+            v.y = (acc[j][1] + acl[j][1] * (1.f / 2048.f)) * out_scale + biasv.y;
+            v.z = (acc[j][2] + acl[j][2] * (1.f / 2048.f)) * out_scale + biasv.z;
+            v.w = (acc[j][3] + acl[j][3] * (1.f / 2048.f)) * out_scale + biasv.w;
+            if (a.res) { v.x += resv[j].x; v.y += resv[j].y; v.z += resv[j].z; v.w += resv[j].w; }     // (uniform branch; without a residual the prefetched dummy is dropped)
+            if (a.epi == SOL_EPI_LRELU) {
+                v.x = v.x > 0.f ? v.x : a.slope * v.x; v.y = v.y > 0.f ? v.y : a.slope * v.y;
+                v.z = v.z > 0.f ? v.z : a.slope * v.z; v.w = v.w > 0.f ? v.w : a.slope * v.w;
+            } else if (a.epi == SOL_EPI_DLRELU) {
+                v.x *= actv[j].x > 0.f ? 1.f : a.slope; v.y *= actv[j].y > 0.f ? 1.f : a.slope;
+                v.z *= actv[j].z > 0.f ? 1.f : a.slope; v.w *= actv[j].w > 0.f ? 1.f : a.slope;
+            }
+            vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            reinterpret_cast<float4*>(a.y)[out_f4(j)] = v;
+        }
+    }
+    DX_STAMP(9);
+    if (a.ymax) amax_publish_last(vmax, a.ymax, amax_lds);
+    DX_STAMP(10);
+#ifdef SOL_CONV_PROF
+    __builtin_amdgcn_s_waitcnt(0);
+    DX_STAMP(11);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_dx_prof_ctl[0], 1u);
+#endif
+}
+
+}  // namespace
+
+#ifdef SOL_CONV_PROF
+extern "C" int sol_conv_dx_prof_set(long long* buf, unsigned cap) {
+    const unsigned ctl[2] = {0u, cap ? cap : 1u};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_dx_prof_ctl), ctl, sizeof(ctl)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_dx_prof), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+bool sol_conv_dx_usable(const ConvArgs& a, int NT) {
+    return sol_opt().conv_dx && NT == 2 && a.CO == 32 && a.xmax && a.wsh && !a.cvy && a.W % 64 == 0;
+}
+
+int sol_conv_dx_launch(hipStream_t s, const ConvArgs& a_in, int ntiles) {
+    ConvArgs a = a_in;
+    a.RPW = -1;                                           // (field unused by this kernel otherwise) log2 H, or -1
+    for (int k = 0; k < 20; ++k) if ((1 << k) == a.H) a.RPW = k;
+    static std::atomic<unsigned long long> optin{0};
+    if (int e = sol_lds_optin(optin, {SOL_K(k_conv5x5_dx)}, "k_conv5x5_dx")) return e;
+    const int nrows = ntiles / a.tiles_x;                 // global image rows B*H
+    int grid3 = ((nrows + 2) / 3) * a.tiles_x;            // three consecutive rows of one column block per workgroup
+    if (grid3 > 64) grid3 = (grid3 + 7) / 8 * 8;          // XCD-aware tile order needs a multiple of 8 (xcd_tile); padding tiles own no rows
+    SOL_LAUNCH(k_conv5x5_dx, dim3(grid3), dim3(512), DX_LDS, s, a, nrows);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}

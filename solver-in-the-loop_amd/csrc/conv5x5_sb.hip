@@ -95,9 +95,14 @@ __global__ void k_pack_sb(const float* __restrict__ w, unsigned short* __restric
 // s_memrealtime, thread 0 of every workgroup, 16 per workgroup) into the buffer set with sol_conv_prof_set().
 // -DSOL_CONV_TRUNC=0|1|2 (tools/conv_variants.py): return at kernel entry / after the prologue / after the tap-row loop.
 #ifdef SOL_CONV_PROF
-__device__ long long* g_conv_prof = nullptr;
-extern "C" int sol_conv_prof_set(long long* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_conv_prof), &buf, sizeof(buf)) == hipSuccess ? 0 : -1; }
-#define SOL_CSTAMP(k) do { if (threadIdx.x == 0 && g_conv_prof) g_conv_prof[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ long long* g_conv_prof = nullptr;        // [cap launches][grid][16] stamps; g_conv_prof_ctl = {launch counter, cap}
+__device__ unsigned g_conv_prof_ctl[2] = {0u, 1u};
+extern "C" int sol_conv_prof_set(long long* buf, unsigned cap) {
+    const unsigned ctl[2] = {0u, cap ? cap : 1u};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_conv_prof_ctl), ctl, sizeof(ctl)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_conv_prof), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#define SOL_CSTAMP(k) do { if (NT == 2 && KIND == 2 && threadIdx.x == 0 && cv_prof) cv_prof[(k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define SOL_CSTAMP(k) do { } while (0)
 #endif
@@ -117,6 +122,10 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     constexpr int AMAX_LDS = 4 * SLOT + 2 * WBUF;  // two words behind the ring and the weight buffers: workgroup max|y|, wave counter
     extern __shared__ __align__(16) unsigned char smem_sb[];
     if (SOL_CONV_TRUNC == 0) return;
+#ifdef SOL_CONV_PROF
+    long long* __restrict__ cv_prof = g_conv_prof;            // read once into scalar registers (a reload per stamp costs ~0.5 us each)
+    if (cv_prof) cv_prof += ((size_t)(g_conv_prof_ctl[0] % g_conv_prof_ctl[1]) * gridDim.x + blockIdx.x) * 16;
+#endif
     SOL_CSTAMP(0);
     if (threadIdx.x == 0) *reinterpret_cast<uint2*>(smem_sb + AMAX_LDS) = make_uint2(0u, 0u);      // see amax_publish_last
     // the wave index is read into an SGPR: everything derived from it (tile row, image bounds, "does this wave have taps in
@@ -480,6 +489,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
 #ifdef SOL_CONV_PROF
     __builtin_amdgcn_s_waitcnt(0);
     SOL_CSTAMP(9);
+    if (NT == 2 && KIND == 2 && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_conv_prof_ctl[0], 1u);
 #endif
 }
 
@@ -608,6 +618,7 @@ int sol_conv_sh_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int 
 // SOL_CONV_SPLIT=3 runs the three leading products only (~2^-17 relative error per product): an
 // experiment knob, NOT the default and not what bench.py or the parity tests use.
 int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles) {
+    if (sol_conv_dx_usable(a, NT)) return sol_conv_dx_launch(s, a, ntiles);
     if (int e = init_sb_kernels()) return e;
     const int nprod = sol_opt().conv_split3 ? 3 : 6;
     const int nrows = ntiles / a.tiles_x;             // global image rows B*H

@@ -34,7 +34,7 @@ _build.LIB = PROF_LIB                       # load the instrumented library inst
 from sol_amd._lib import ptr, stream, check
 
 lib = _lib.load()
-lib.sol_conv_prof_set.argtypes = [C.c_void_p]
+lib.sol_conv_prof_set.argtypes = [C.c_void_p, C.c_uint]
 B, Y, X = 6, 128, 64
 dev = "cuda"
 x = torch.randn(B, Y, X, 32, device=dev)
@@ -50,7 +50,7 @@ call = lambda: check(lib.sol_conv5x5_scaled(stream(), ptr(x), ptr(packed), ptr(b
                                              ops.EPI_LRELU, 0.3, ptr(xam), ptr(yam)))
 for _ in range(5):
     call()
-assert lib.sol_conv_prof_set(ptr(st)) == 0
+assert lib.sol_conv_prof_set(C.c_void_p(st.data_ptr()), 1) == 0
 torch.cuda.synchronize()
 for rep in range(3):
     call(); torch.cuda.synchronize()
@@ -69,7 +69,7 @@ for _ in range(100):
     call()
 e1.record(); torch.cuda.synchronize()
 print("launch: %.2f us (with stamps)" % (e0.elapsed_time(e1) * 10))
-assert lib.sol_conv_prof_set(None) == 0
+assert lib.sol_conv_prof_set(None, 1) == 0
 torch.cuda.synchronize()
 # GPU-bound timing: 50 launches captured in one graph (a ctypes call costs ~8 us of host time)
 side = torch.cuda.Stream()
