@@ -462,10 +462,10 @@ def main():
             return None, None
 
         # (1) dominant kernel: the 32->32 conv (forward and backward-data launches share one kernel)
-        conv_names = {"split": ("k_conv5x5_sb<2, 2>", "k_conv5x5_sb<2, 0>"), "bf16x6": ("k_conv5x5_sb<2, 0>",), "fp32": ("k_conv5x5_r3<2>",)}[args.precision]
+        conv_names = {"split": ("k_conv5x5_dx<3>", "k_conv5x5_dx<1>", "k_conv5x5_sb<2, 2>", "k_conv5x5_sb<2, 0>"), "bf16x6": ("k_conv5x5_sb<2, 0>",), "fp32": ("k_conv5x5_r3<2>",)}[args.precision]
         cname, cst = pick(*conv_names)
         flop_conv = 2.0 * 25 * 32 * 32 * B * N
-        nprod = {"k_conv5x5_sb<2, 2>": 3, "k_conv5x5_sb<2, 0>": 6}.get(cname, 1)
+        nprod = {"k_conv5x5_dx<3>": 3, "k_conv5x5_dx<1>": 3, "k_conv5x5_sb<2, 2>": 3, "k_conv5x5_sb<2, 0>": 6}.get(cname, 1)
         roof_conv = None
         if cst:
             t_conv = cst["avg_us"] * 1e-6
@@ -473,7 +473,7 @@ def main():
             alg = flop_conv / t_conv / 1e12              # ALGORITHMIC fp32 FLOP of the convolution per launch / launch duration
             roof_conv = {"kernel": cname, "bound": "mfma", "achieved": alg, "peak": peak, "unit": "TFLOP/s", "frac": alg / peak,
                          "mfma_pipe_busy": nprod * alg / peak,
-                         "traffic": traffic_bytes(traffic, cname, ((B * Y + 2) // 3) * max(1, X // 64) * 768),
+                         "traffic": traffic_bytes(traffic, cname, ((B * Y + 2) // 3) * max(1, X // 64) * (512 if cname.startswith("k_conv5x5_dx") else 768)),
                          "launch_us": cst["avg_us"], "launches_per_train_step": cst["calls"], "share_of_step_kernel_time": cst["total_us"] / tot_prof,
                          "algorithmic_fp32_flop_per_launch": flop_conv, "executed_mfma_flop_per_launch": nprod * flop_conv,
                          "frac_of_fp32_matrix_peak": alg / PEAK_MFMA32_TF,

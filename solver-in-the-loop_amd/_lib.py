@@ -265,3 +265,4 @@ def f32(t, device=None):
     if not isinstance(t, torch.Tensor):
         t = torch.as_tensor(t)
     return t.to(device=device or "cuda", dtype=torch.float32).contiguous()
+

@@ -153,6 +153,7 @@ class BurgersTrainer:
         Y, X = domain.resolution
         self.sim = BurgersTest(default_viscosity=viscosity)
         self.std_v = torch.as_tensor(std_v, dtype=torch.float32, device=dev).reshape(2)
+        self._std_v_host = tuple(float(v) for v in np.asarray(std_v, dtype=np.float64).reshape(2))
         if noforce:
             self.std_in = self.std_v
         else:
@@ -175,8 +176,10 @@ class BurgersTrainer:
             feat = to_feature_noforce([st]) if self.noforce else to_feature([st], [fr])
             corr = to_staggered(self.net(feat / self.std_in) * self.std_v, self.dom.box)
             st = st.copied_with(velocity=st.velocity + corr)
-            diff = (self.velo[k + 1] - st.velocity.staggered_tensor()) / self.std_v
-            losses.append(0.5 * (diff * diff).sum())
+            # l2_loss((gt.staggered - prd.staggered) / std_v), burgers_train.py:421-428, channel by channel: one kernel per step, no torch
+            # reduction (a multi-workgroup torch .sum() puts a memset node into the captured graph: ops.L2LossFn)
+            vt, gt_t = st.velocity.staggered_tensor(), self.velo[k + 1]
+            losses.append(ops.l2_loss((vt[..., 0].contiguous(), vt[..., 1].contiguous()), (gt_t[..., 0].contiguous(), gt_t[..., 1].contiguous()), self._std_v_host))
         return torch.stack(losses).sum() / self.ms
 
     def _eager(self):

@@ -28,10 +28,13 @@ using namespace sbk;
 constexpr int DX_HWP = 68;                         // halo pixels per row (64 + 4)
 constexpr int DX_PLANE = DX_HWP * 64;              // bytes per fp16 plane of one halo row
 constexpr int DX_SLOT = 2 * DX_PLANE;              // hi + lo plane
-constexpr int DX_NS = 7;                           // input rows of three output rows
+// R output rows per workgroup need R + 4 input rows.  R = 3 (one workgroup per CU at 128x64 x 6) is the form described above; R = 1
+// serves launches with few image rows (the reference's 64x32 x 3 recipe: 96 rows = 32 workgroups of three rows on 256 CUs, every
+// launch pure latency): three times the workgroups, a third of the loop each -- the rows no longer share pixel operands, which does
+// not matter where the loop is a fraction of the launch.
 constexpr int DX_WPL = 32 * 64;                    // bytes per (tap, plane) weight block: 32 co x 32 ci fp16
 constexpr int DX_WPH = 5 * 2 * DX_WPL;             // bytes per dx phase: five dy x two planes
-constexpr int DX_LDS = DX_NS * DX_SLOT + 2 * DX_WPH + 16;
+constexpr int dx_lds(int R) { return (R + 4) * DX_SLOT + 2 * DX_WPH + 16; }
 
 #define DX_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -46,7 +49,10 @@ __device__ unsigned g_dx_prof_ctl[2] = {0u, 1u};
 #define DX_STAMP(k) do { } while (0)
 #endif
 
+template <int R>
 __global__ void __launch_bounds__(512) k_conv5x5_dx(ConvArgs a, int nrows) {
+    constexpr int DX_NS = R + 4;                                // input rows (LDS slots) of R output rows
+    static_assert(R >= 1 && R <= 3, "one to three output rows per workgroup");
     extern __shared__ __align__(16) unsigned char smem_dx[];
     unsigned char* const ring = smem_dx;                        // [7 slots][2 planes][68 px][64 B]
     unsigned char* const Wt = smem_dx + DX_NS * DX_SLOT;        // [2 buffers][5 dy][2 planes][32 co][64 B]
@@ -76,7 +82,7 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(ConvArgs a, int nrows) {
     const int bx = xcd_tile(blockIdx.x, gridDim.x);
     int tx = 0, ty = bx;
     if (a.tiles_x != 1) { tx = bx % a.tiles_x; ty = bx / a.tiles_x; }      // (W == 64: one column block, no division)
-    const int G0 = ty * 3, x0 = tx * 64;
+    const int G0 = ty * R, x0 = tx * 64;
     // image of row G0: H is a power of two in every shipped configuration (a.RPW = log2 H, set by the launcher; -1: one division)
     const int b0 = a.RPW >= 0 ? (G0 >> a.RPW) : G0 / H;
     const int lo0 = b0 * H, hi0 = lo0 + H;
@@ -84,7 +90,7 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(ConvArgs a, int nrows) {
     // rows span at most two images, and for one j the valid s form a range
     unsigned vmask = 0u;                                        // bit j * 8 + s  (wave uniform: SGPR)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < R; ++j) {
         const int gj = G0 + j;
         const int lo = gj >= hi0 ? hi0 : lo0;                   // first row of gj's image
         const int smin = max(j, lo - (G0 - 2)), smax = min(j + 4, lo + H - 1 - (G0 - 2));
@@ -106,7 +112,7 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(ConvArgs a, int nrows) {
     // clamped row and are never used: `vmask` masks every pair that would read them).  Halo pixels (x0 - 2, x0 - 1, x0 + 64,
     // x0 + 65; zero unless a neighbouring column block exists): one item for the first 32 threads per row of the role.
     const int c4 = t & 7, p = t >> 3;
-    const int s_base = late ? 3 : 0, n_rows = late ? 4 : 3;
+    const int s_base = late ? 3 : 0, n_rows = late ? DX_NS - 3 : 3;
     const int hrow = t >> 5, hp = (t >> 3) & 3, hc_h = hp < 2 ? hp : hp + 64;     // halo item: row s_base + hrow (if hrow < n_rows), halo position hc_h
     const int hxx = x0 + hc_h - 2;
     const bool hok = hxx >= 0 && hxx < W;
@@ -151,8 +157,8 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(ConvArgs a, int nrows) {
         unsigned char* qA = q0 + hcA * 64 + ((((c4 >> 1) ^ swzb(hcA)) << 4) | ((c4 & 1) << 3));
         unsigned char* qB = q0 + hcB * 64 + ((((c4 >> 1) ^ swzb(hcB)) << 4) | ((c4 & 1) << 3));
 #pragma unroll
-        for (int n = 0; n < 6; ++n) put(((n & 1) ? qB : qA) + (n >> 1) * DX_SLOT, hv[n]);
-        if (late) { put(qA + 3 * DX_SLOT, hv[6]); put(qB + 3 * DX_SLOT, hv[7]); }
+        for (int n = 0; n < 8; ++n)
+            if ((n >> 1) < n_rows) put(((n & 1) ? qB : qA) + (n >> 1) * DX_SLOT, hv[n]);       // (uniform: the role's row count)
         if (!hok) hh = make_float4(0.f, 0.f, 0.f, 0.f);
         if (hrow < n_rows) put(q0 + hrow * DX_SLOT + hc_h * 64 + ((((c4 >> 1) ^ swzb(hc_h)) << 4) | ((c4 & 1) << 3)), hh);
         uint4* dst = reinterpret_cast<uint4*>(Wt + (late ? 1 : 0) * DX_WPH) + t;
@@ -171,14 +177,14 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(ConvArgs a, int nrows) {
         biasv = make_float4(bp[0], bp[1], bp[2], bp[3]);
     }
 
-    f32x4 acc[3], acl[3];                                       // acl: the 2^-11 weighted cross terms
+    f32x4 acc[R], acl[R];                                       // acl: the 2^-11 weighted cross terms
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acl[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int j = 0; j < R; ++j) { acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acl[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     // epilogue operands (residual, activation reference): requested at the start of the last phase, consumed after the last MFMA
-    float4 resv[3], actv[3];
+    float4 resv[R], actv[R];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { resv[j] = make_float4(0.f, 0.f, 0.f, 0.f); actv[j] = make_float4(1.f, 1.f, 1.f, 1.f); }
+    for (int j = 0; j < R; ++j) { resv[j] = make_float4(0.f, 0.f, 0.f, 0.f); actv[j] = make_float4(1.f, 1.f, 1.f, 1.f); }
     const int pcc = seg * 16 + li;                              // this lane's pixel inside the 64-pixel row
     const int co_l = cot * 16 + li;                             // this lane's weight row (output channel) of the A operand
     auto out_f4 = [&](int j) { return ((size_t)(G0 + j) * W + x0 + pcc) * 8 + cot * 4 + g; };   // float4 index of (row j, this pixel, co 4g..)
@@ -216,10 +222,10 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(ConvArgs a, int nrows) {
             const bool late_a = dx == 0 && s == 2;              // row 3 is only staged behind this step (first phase)
             if (s + 1 < DX_NS && !late_a) read_a(aslot ^ 1, dx, s + 1);
             else if (dx < 4) read_a(aslot ^ 1, dx + 1, 0);
-            if (dx < 4) {
-                if (s == 4) { read_b(set ^ 1, dx + 1, 0); read_b(set ^ 1, dx + 1, 1); }
-                if (s == 5) { read_b(set ^ 1, dx + 1, 2); read_b(set ^ 1, dx + 1, 3); }
-                if (s == 6) read_b(set ^ 1, dx + 1, 4);
+            if (dx < 4) {                                       // the next weight set, over the steps behind the barrier
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    if (s == (DX_NS == 7 ? 4 + k / 2 : (DX_NS == 6 ? 3 + k / 2 : 3 + k / 3))) read_b(set ^ 1, dx + 1, k);
             }
             // Epilogue operands (residual: phase 2, activation reference: phase 3), ONE request per step 3..5 -- behind the LAST weight
             // request (vmcnt retires in order: a weight set requested after these HBM-cold operands could not be waited for without
@@ -228,14 +234,14 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(ConvArgs a, int nrows) {
             // (+0.8 us in that phase).  UNCONDITIONAL requests -- a launch without a residual / activation reference reads the same
             // positions of x and drops the values: requests inside `if (a.res)` blocks make the compiler's next vmcnt wait a wait
             // for everything in flight.
-            if ((dx == 2 || dx == 3) && s >= 3 && s <= 5) {
+            if ((dx == 2 || dx == 3) && s >= 3 && s - 3 < R) {
                 const int j = s - 3, jj = G0 + j < nrows ? j : 0;       // (scalar) rows beyond the tensor: any valid position
                 if (dx == 2) resv[j] = reinterpret_cast<const float4*>(a.res ? a.res : a.x)[out_f4(jj)];
                 else actv[j] = reinterpret_cast<const float4*>(a.epi == SOL_EPI_DLRELU ? a.act : a.x)[out_f4(jj)];
             }
             __builtin_amdgcn_sched_barrier(0);                  // keep the prefetch reads above this step's MFMAs
             const f16x8 x1 = __builtin_bit_cast(f16x8, ao[aslot][0]), x2 = __builtin_bit_cast(f16x8, ao[aslot][1]);
-            const int jlo = s - 4 > 0 ? s - 4 : 0, jhi = s < 2 ? s : 2;      // (constants once the s loop is unrolled)
+            const int jlo = s - 4 > 0 ? s - 4 : 0, jhi = s < R - 1 ? s : R - 1;      // (constants once the s loop is unrolled)
             unsigned need = 0u;
 #pragma unroll
             for (int j = jlo; j <= jhi; ++j) need |= 1u << (j * 8 + s);
@@ -283,7 +289,7 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(ConvArgs a, int nrows) {
     // ---- epilogue: lane (li, g) holds output channels cot*16 + 4g .. + 3 of pixel pcc of the three rows -----------------------
     float vmax = 0.f;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < R; ++j) {
         if (G0 + j < nrows) {                                   // wave uniform
             float4 v;
             v.x = (acc[j][0] + acl[j][0] * (1.f / 2048.f)) * out_scale + biasv.x;
@@ -331,11 +337,14 @@ int sol_conv_dx_launch(hipStream_t s, const ConvArgs& a_in, int ntiles) {
     a.RPW = -1;                                           // (field unused by this kernel otherwise) log2 H, or -1
     for (int k = 0; k < 20; ++k) if ((1 << k) == a.H) a.RPW = k;
     static std::atomic<unsigned long long> optin{0};
-    if (int e = sol_lds_optin(optin, {SOL_K(k_conv5x5_dx)}, "k_conv5x5_dx")) return e;
+    if (int e = sol_lds_optin(optin, {SOL_K(k_conv5x5_dx<1>), SOL_K(k_conv5x5_dx<3>)}, "k_conv5x5_dx")) return e;
     const int nrows = ntiles / a.tiles_x;                 // global image rows B*H
-    int grid3 = ((nrows + 2) / 3) * a.tiles_x;            // three consecutive rows of one column block per workgroup
-    if (grid3 > 64) grid3 = (grid3 + 7) / 8 * 8;          // XCD-aware tile order needs a multiple of 8 (xcd_tile); padding tiles own no rows
-    SOL_LAUNCH(k_conv5x5_dx, dim3(grid3), dim3(512), DX_LDS, s, a, nrows);
+    // three rows per workgroup where that fills the chip; one row where the launch is small (< 128 three-row workgroups)
+    const int R = ((nrows + 2) / 3) * a.tiles_x >= 128 ? 3 : 1;
+    int grid = ((nrows + R - 1) / R) * a.tiles_x;
+    if (grid > 64) grid = (grid + 7) / 8 * 8;             // XCD-aware tile order needs a multiple of 8 (xcd_tile); padding tiles own no rows
+    if (R == 3) SOL_LAUNCH(k_conv5x5_dx<3>, dim3(grid), dim3(512), dx_lds(3), s, a, nrows);
+    else SOL_LAUNCH(k_conv5x5_dx<1>, dim3(grid), dim3(512), dx_lds(1), s, a, nrows);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }

@@ -429,6 +429,11 @@ def conv3d_fn(x, w, b, residual=None, lrelu=False, slope=0.3, packs=None):
     return _Conv3DFn.apply(x, w, b, residual, lrelu, slope, packs)
 
 
+def ops_l2_loss(pred, gt, std):
+    from .ops import l2_loss
+    return l2_loss(pred, gt, std)
+
+
 class Karman3DTrainer:
     """SOL-n training step of the 3-D scene: msteps x [solver step -> features / std -> mars_moon3d -> velocity += std *
     to_staggered(correction)], loss = sum_i l2_loss((gt_i - prd_i) / std_v) / msteps (karman_train.py:397-447 with three
@@ -448,6 +453,7 @@ class Karman3DTrainer:
         self.sim = Karman3DFlow(scene, B, dt=dt, res=res, **solver)
         dev = scene.active.device
         self.std_v = torch.tensor([float(v) for v in std_v], dtype=torch.float32, device=dev)
+        self._std_v_host = tuple(float(v) for v in std_v)
         self.std_in = torch.tensor([float(v) for v in std_v] + [float(std_re)], dtype=torch.float32, device=dev)
         self.conv_precision = _conv_precision_code(conv_precision)
         net.params.requires_grad_(True)
@@ -481,7 +487,8 @@ class Karman3DTrainer:
             d, *v = self.sim.step(d, v[0], v[1], v[2], re)
             out = self.net(to_feature3d(v[0], v[1], v[2], re) / self.std_in) * self.std_v
             v = tuple(a + c for a, c in zip(v, to_staggered3d(out)))
-            losses.append(sum(0.5 * (((g[i] - a) / s) ** 2).sum() for g, a, s in zip(self._gt, v, self.std_v)))
+            # (one kernel, no torch reduction: a multi-workgroup torch .sum() puts a memset node into the captured graph, ops.L2LossFn)
+            losses.append(ops_l2_loss(v, tuple(g[i] for g in self._gt), self._std_v_host))
         losses = torch.stack(losses)
         loss = losses.sum() / self.ms
         loss.backward()

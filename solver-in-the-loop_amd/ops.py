@@ -332,3 +332,31 @@ def l2_loss_fwd_bwd(pred, gt, std, gscale=1.0, want_grad=True, loss=None, grads=
                                   (C.c_int64 * nc)(*[t.numel() for t in pred]), (C.c_float * nc)(*[float(v) for v in std]),
                                   float(gscale), int(acc_g), ptr(loss), int(acc_l), ptr(scratch)))
     return loss, (tuple(g) if g is not None else None)
+
+
+class L2LossFn(torch.autograd.Function):
+    """tf.nn.l2_loss((gt - prd) / std) of one unrolled step over 1..3 staggered components (karman_train.py:428-436) as ONE
+    autograd node: sol_l2_loss_fwd_bwd computes the value and d loss / d prd in one pass, backward scales the saved gradient.
+    Why the trainers that are captured into a hipGraph use THIS and not `(diff * diff).sum()`: a torch reduction over more
+    elements than one workgroup handles allocates semaphores and clears them with cudaMemsetAsync -- a MEMSET NODE in the captured
+    graph, and memset nodes of a replayed hipGraph are unreliable on ROCm 7.2: after a few replays the
+    reduction folded its partial sums early and the reported per-step losses were 0.5x / 2x the true values while state and
+    gradient stayed right (found by the full-size SOL-16 test).  This kernel has no memset, no atomics and a fixed summation order."""
+
+    @staticmethod
+    def forward(ctx, std, n, *tensors):
+        pred, gt = tensors[:n], tensors[n:]
+        loss, g = l2_loss_fwd_bwd(pred, gt, std)
+        ctx.save_for_backward(*g)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        return (None, None) + tuple(gl * g for g in ctx.saved_tensors) + (None,) * len(ctx.saved_tensors)
+
+
+def l2_loss(pred, gt, std):
+    """0.5 * sum_c sum(((gt_c - pred_c) / std_c)^2), differentiable w.r.t. the `pred` tensors (tuples of 1..3 device tensors)."""
+    pred = tuple(_lib.f32(t) for t in pred)
+    gt = tuple(_lib.f32(t.detach()) for t in gt)
+    return L2LossFn.apply(tuple(float(v) for v in std), len(pred), *pred, *gt)

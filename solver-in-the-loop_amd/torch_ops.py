@@ -106,23 +106,7 @@ def _adam(params, grads, m, v, t, lr, beta1, beta2, eps):
 _LIB.impl("adam_tf_step", _adam, "CUDA")
 
 
-class _L2LossFn(torch.autograd.Function):
-    """tf.nn.l2_loss((gt.staggered - prd.staggered) / std_v) of one unrolled step (karman_train.py:428-436): sol_l2_loss_fwd_bwd
-    computes the value and d loss / d prd in one pass; backward scales the saved gradient."""
-
-    @staticmethod
-    def forward(ctx, vy, vx, gt_vy, gt_vx, std_vy, std_vx):
-        loss, g = ops.l2_loss_fwd_bwd((vy, vx), (gt_vy, gt_vx), (std_vy, std_vx))
-        ctx.save_for_backward(*g)
-        return loss.reshape(())
-
-    @staticmethod
-    def backward(ctx, gl):
-        gy, gx = ctx.saved_tensors
-        return gl * gy, gl * gx, None, None, None, None
-
-
-_LIB.impl("l2_loss", lambda vy, vx, gt_vy, gt_vx, sy, sx: _L2LossFn.apply(vy, vx, gt_vy, gt_vx, sy, sx), "AutogradCUDA")
+_LIB.impl("l2_loss", lambda vy, vx, gt_vy, gt_vx, sy, sx: ops.l2_loss((vy, vx), (gt_vy, gt_vx), (sy, sx)), "AutogradCUDA")
 
 
 # ---- karman-3d (BASELINE configs[4]): the step with its hand-written adjoint and Conv3D(5) with forward / backward-data / weight gradient ----

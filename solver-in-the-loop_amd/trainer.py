@@ -280,6 +280,7 @@ class GraphTrainer:
             self.bcv, self.bcm = karman.velocity_bc_masks(Y, X, batch_size=B)
         t = lambda v: torch.tensor([float(a) for a in v], dtype=torch.float32, device=dev)
         self.scale_loss = t(std_v)
+        self._std_loss_host = (float(std_v[0]), float(std_v[1]))
         self.scale_in = t(list(in_std_v if in_std_v is not None else std_v) + [std_re])
         self.scale_out = t(out_std_v if out_std_v is not None else std_v)
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
@@ -311,8 +312,10 @@ class GraphTrainer:
             st = self.sim.step(st, re=re, res=self.res, velBCy=self.bcv, velBCyMask=self.bcm, dt=self.dt)
             corr = karman.to_staggered(self.net(karman.to_feature(st, re) / self.scale_in) * self.scale_out, self.dom.box)
             st = st.copied_with(velocity=st.velocity + corr)
-            diff = (stag(gt_vy[i], gt_vx[i]) - st.velocity.staggered_tensor()) / self.scale_loss
-            losses.append(0.5 * (diff * diff).sum())
+            # l2_loss((gt.staggered - prd.staggered) / std_v), karman_train.py:428-436, channel by channel over the padded staggered tensors.
+            # One kernel per step, no torch reduction (a multi-workgroup torch .sum() puts a memset node into the captured graph: ops.L2LossFn)
+            vt, gt_t = st.velocity.staggered_tensor(), stag(gt_vy[i], gt_vx[i])
+            losses.append(ops.l2_loss((vt[..., 0].contiguous(), vt[..., 1].contiguous()), (gt_t[..., 0].contiguous(), gt_t[..., 1].contiguous()), self._std_loss_host))
         losses = torch.stack(losses)
         self.net.params.grad = None
         (losses.sum() / self.msteps).backward()

@@ -488,6 +488,92 @@ def test_karman3d_training_step_gradient_by_finite_differences():
     assert min(abs(v - rhs) for v in res.values()) < 3e-3 * abs(rhs), (rhs, res)
 
 
+@pytest.mark.timeout(1500)
+def test_karman3d_sol16_full_size_replay_equals_eager_and_directional_derivative():
+    """BASELINE configs[4] at its REAL depth: SOL-16 at 128 x 64 x 64 (B = 1, the per-GPU share of the 8-GPU config), the unroll of
+    karman_train.py:397-457 with three components.  The float64 oracle cannot afford this size (16 unrolled steps with autograd
+    through DST-preconditioned CG solves), so the step is held to properties instead:
+      (1) the replayed hipGraph equals the eager composition BIT FOR BIT (loss, the 1.3 M-element gradient, final state) -- every
+          kernel of the step is deterministic since the advection adjoint scatters in fixed point;
+      (2) a second replay reproduces the first bit for bit, the loss is finite and non-trivial;
+      (3) <grad, u> along a random direction in parameter space equals the central difference of the engine's own loss
+          (the reverse sweep through 16 solver adjoints and 16 x 24 convolutions is the derivative of the forward unroll);
+      (4) one TF-Adam step with the gradient changes every parameter tensor and lowers the loss at a small learning rate."""
+    from sol_amd import synthetic
+    B, Y, X, Z, ms = 1, 128, 64, 64, 16
+    sc = k3.Scene3D(Y, X, Z, device=DEV)
+    gen = torch.Generator().manual_seed(11)
+    rn = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float32)
+    st = (torch.rand(B, Y, X, Z, generator=gen).to(DEV), (1.0 + 0.1 * rn(B, Y + 1, X, Z)).to(DEV), (0.1 * rn(B, Y, X + 1, Z)).to(DEV), (0.1 * rn(B, Y, X, Z + 1)).to(DEV))
+    re = synthetic.reynolds(B).float().to(DEV)
+
+    def make(use_graph):
+        net = k3.MarsMoon3D(seed=3, device=DEV)
+        w = net.get_weights()
+        w[22] = w[22] * 0.01
+        net.set_weights(w)
+        return net, k3.Karman3DTrainer(net, sc, B, ms, (0.2, 0.2, 0.2), synthetic.STD_RE, use_graph=use_graph)
+
+    net_g, tr_g = make(True)
+    gts = []
+    with torch.no_grad():
+        st = tr_g.sim.step(*st, re)                     # spin-up: consistent with the boundary conditions
+        gs = (st[0], st[1] + 0.02, st[2], st[3])
+        for _ in range(ms):
+            gs = tr_g.sim.step(*gs, re)
+            gts.append(tuple(t.clone() for t in gs[1:]))
+    bits = lambda t: t.detach().contiguous().view(torch.int32)
+    l1 = tr_g.fwd_bwd(*st, re, gts).clone()
+    assert tr_g._graph is not None
+    g1, f1 = tr_g.grads.clone(), [t.clone() for t in tr_g.final]
+    tr_g._grads.zero_()
+    l2 = tr_g.fwd_bwd(*st, re, gts).clone()             # a pure replay
+    assert bool((bits(l1) == bits(l2)).all()) and bool((bits(g1) == bits(tr_g.grads)).all()), "two replays of the SOL-16 step differ"
+    assert np.isfinite(float(l1)) and float(l1) > 0 and float(g1.abs().max()) > 0 and bool(torch.isfinite(g1).all())
+    # (1) eager composition
+    net_e, tr_e = make(False)
+    le = tr_e.fwd_bwd(*st, re, gts)
+    assert bool((bits(le) == bits(l1)).all()), (float(le), float(l1))
+    assert bool((bits(tr_e.grads) == bits(g1)).all()), "replayed graph and eager composition give different gradients"
+    for a, b in zip(tr_e.final, f1):
+        assert bool((bits(a) == bits(b)).all())
+    del tr_e, net_e
+    # (3) directional derivative, with the replayed graph (the weights are read from net.params at every replay)
+    g = g1.double()
+    u = torch.zeros(net_g.n_params, dtype=torch.float64)
+    for k in range(len(net_g.shapes)):
+        sl = slice(int(net_g.offsets[k]), int(net_g.offsets[k + 1]))
+        wk = net_g.params.detach()[sl].double().cpu()
+        u[sl] = torch.randn(wk.numel(), generator=gen, dtype=torch.float64) * (float(wk.abs().mean()) + 1e-3)
+    u = u.to(DEV)
+    rhs = float((g * u).sum())
+    p0 = net_g.params.detach().clone()
+    res = {}
+    for eps in (1e-3, 3e-4, 1e-4):                      # (16 unrolled steps: the loss leaves its linear range beyond ~1e-3 of the weights' scale)
+        vals = []
+        for sgn in (1.0, -1.0):
+            with torch.no_grad():
+                net_g.params.copy_((p0.double() + sgn * eps * u).float())
+            vals.append(float(tr_g.fwd_bwd(*st, re, gts)))
+        res[eps] = (vals[0] - vals[1]) / (2 * eps)
+    with torch.no_grad():
+        net_g.params.copy_(p0)
+    print("3-D SOL-16 full size: loss %.6e, <grad, u> = %.6e, central differences %s" % (float(l1), rhs, res))
+    assert min(abs(v - rhs) for v in res.values()) < 1e-2 * abs(rhs), (rhs, res)
+    # the graph is still the function it was: the original weights reproduce the first replay bit for bit after eight replays on
+    # other weights.  (Regression: with the loss as a torch reduction the captured graph held memset nodes -- the reduction's
+    # semaphores -- and after a few replays reported 0.5x / 2x the true per-step losses, DESIGN.md section 2.)
+    l4 = tr_g.fwd_bwd(*st, re, gts).clone()
+    assert bool((bits(l4) == bits(l1)).all()) and bool((bits(tr_g.grads) == bits(g1)).all()), (float(l4), float(l1))
+    # (4) one optimizer step
+    tr_g.fwd_bwd(*st, re, gts)
+    before = [t.clone() for t in net_g.tensors()]
+    tr_g.apply_gradients(1e-6)
+    assert all(float((a - b).abs().max()) > 0 for a, b in zip(net_g.tensors(), before) if a.dim() > 1)
+    l3 = float(tr_g.fwd_bwd(*st, re, gts))
+    assert np.isfinite(l3) and l3 < float(l1), (l3, float(l1))
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_karman3d_trainer_sol2_against_oracle(use_graph):
     """SOL-2 at 32 x 16 x 16, B = 2: loss, the full 1.3 M-element gradient and one TF-Adam update against the float64 oracle
