@@ -166,8 +166,8 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(ConvArgs a, int nrows) {
     };
     auto stage_late = [&]() __attribute__((always_inline)) { if (late) stage_role(); };
     if (!late) stage_role();
-    uint4 wA0, wA1, wA2, wB0, wB1, wB2;
-    wA0 = wA1 = wA2 = wB0 = wB1 = wB2 = make_uint4(0u, 0u, 0u, 0u);
+    uint4 wB0, wB1, wB2, wC0, wC1, wC2, wD0, wD1, wD2;          // the weight sets of phases 2, 3, 4 in flight (named: arrays end up in scratch)
+    wB0 = wB1 = wB2 = wC0 = wC1 = wC2 = wD0 = wD1 = wD2 = make_uint4(0u, 0u, 0u, 0u);
     DX_STAMP(12);
     DX_BARRIER();
     DX_STAMP(3);
@@ -210,10 +210,37 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(ConvArgs a, int nrows) {
 #pragma unroll
     for (int dy = 1; dy < 5; ++dy) read_b(0, 0, dy);
 
-    auto phase = [&](const int dx, const int nxt, uint4& wi0, uint4& wi1, uint4& wi2, const uint4& wo0, const uint4& wo1, const uint4& wo2)
-                     __attribute__((always_inline)) {
+    // ---- epilogue of ONE output row: lane (li, g) holds output channels cot*16 + 4g .. + 3 of pixel pcc -----------------------------
+    // (Tried: row j's epilogue behind the MFMAs of step j + 5 of the last phase, in their shadow -- row j has its last MFMA in step
+    // j + 4.  The phase grew by what the tail shrank: 9.42 -> 9.81 us per launch in the pipeline probe.  All rows at the end.)
+    float vmax = 0.f;
+    auto epilogue_row = [&](const int j) __attribute__((always_inline)) {
+        if (G0 + j < nrows) {                                   // wave uniform
+            float4 v;
+            v.x = (acc[j][0] + acl[j][0] * (1.f / 2048.f)) * out_scale + biasv.x;
+            v.y = (acc[j][1] + acl[j][1] * (1.f / 2048.f)) * out_scale + biasv.y;
+            v.z = (acc[j][2] + acl[j][2] * (1.f / 2048.f)) * out_scale + biasv.z;
+            v.w = (acc[j][3] + acl[j][3] * (1.f / 2048.f)) * out_scale + biasv.w;
+            if (a.res) { v.x += resv[j].x; v.y += resv[j].y; v.z += resv[j].z; v.w += resv[j].w; }     // (uniform branch; without a residual the prefetched dummy is dropped)
+            if (a.epi == SOL_EPI_LRELU) {
+                v.x = v.x > 0.f ? v.x : a.slope * v.x; v.y = v.y > 0.f ? v.y : a.slope * v.y;
+                v.z = v.z > 0.f ? v.z : a.slope * v.z; v.w = v.w > 0.f ? v.w : a.slope * v.w;
+            } else if (a.epi == SOL_EPI_DLRELU) {
+                v.x *= actv[j].x > 0.f ? 1.f : a.slope; v.y *= actv[j].y > 0.f ? 1.f : a.slope;
+                v.z *= actv[j].z > 0.f ? 1.f : a.slope; v.w *= actv[j].w > 0.f ? 1.f : a.slope;
+            }
+            vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            reinterpret_cast<float4*>(a.y)[out_f4(j)] = v;
+        }
+    };
+
+    // The weight sets of phases 2, 3, 4 are ALL requested during phase 0 (three named register sets, one request group at the phase's
+    // start and one each behind steps 3 and DX_NS - 2: spread out, a burst of requests stalls every wave at issue) so that the
+    // HBM-cold epilogue operands can follow early: vmcnt retires in order, and a weight set requested AFTER them could not be waited
+    // for without them.
+    auto phase = [&](const int dx) __attribute__((always_inline)) {
         const int set = dx & 1;
-        if (nxt >= 0) load_w(nxt, wi0, wi1, wi2);              // two phases of look-ahead (named register sets)
+        if (dx == 0) load_w(2, wB0, wB1, wB2);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < DX_NS; ++s) {
@@ -227,16 +254,17 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(ConvArgs a, int nrows) {
                 for (int k = 0; k < 5; ++k)
                     if (s == (DX_NS == 7 ? 4 + k / 2 : (DX_NS == 6 ? 3 + k / 2 : 3 + k / 3))) read_b(set ^ 1, dx + 1, k);
             }
-            // Epilogue operands (residual: phase 2, activation reference: phase 3), ONE request per step 3..5 -- behind the LAST weight
-            // request (vmcnt retires in order: a weight set requested after these HBM-cold operands could not be waited for without
-            // them) and spread out: a lane's 16 bytes sit 128 bytes from its neighbour's, so each request occupies the CU's
+            if (dx == 0 && s == 3) load_w(3, wC0, wC1, wC2);
+            if (dx == 0 && s == DX_NS - 2) load_w(4, wD0, wD1, wD2);
+            // Epilogue operands (residual: phase 1, activation reference: phase 2), ONE request per step 3.. -- behind the LAST weight
+            // request and spread out: a lane's 16 bytes sit 128 bytes from its neighbour's, so each request occupies the CU's
             // vector-memory path for 16 cache lines, and six of them back to back from all eight waves stalled every wave at issue
             // (+0.8 us in that phase).  UNCONDITIONAL requests -- a launch without a residual / activation reference reads the same
             // positions of x and drops the values: requests inside `if (a.res)` blocks make the compiler's next vmcnt wait a wait
-            // for everything in flight.
-            if ((dx == 2 || dx == 3) && s >= 3 && s - 3 < R) {
+            // for everything in flight.  They are HBM-cold in the training pipeline (written hundreds of launches ago): ~3 us.
+            if ((dx == 1 || dx == 2) && s >= 3 && s - 3 < R) {
                 const int j = s - 3, jj = G0 + j < nrows ? j : 0;       // (scalar) rows beyond the tensor: any valid position
-                if (dx == 2) resv[j] = reinterpret_cast<const float4*>(a.res ? a.res : a.x)[out_f4(jj)];
+                if (dx == 1) resv[j] = reinterpret_cast<const float4*>(a.res ? a.res : a.x)[out_f4(jj)];
                 else actv[j] = reinterpret_cast<const float4*>(a.epi == SOL_EPI_DLRELU ? a.act : a.x)[out_f4(jj)];
             }
             __builtin_amdgcn_sched_barrier(0);                  // keep the prefetch reads above this step's MFMAs
@@ -272,7 +300,9 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(ConvArgs a, int nrows) {
                 // next phase's weights: their buffer was last read (as the set of phase dx - 1) before the previous phase's barrier;
                 // in the first phase also the input rows 3..6 (steps 3..6 read them)
                 if (dx == 0) stage_late();                        // rows 3..6 AND the weight set of phase 1 (late role)
-                else store_w((dx + 1) & 1, wo0, wo1, wo2);
+                else if (dx == 1) store_w(0, wB0, wB1, wB2);
+                else if (dx == 2) store_w(1, wC0, wC1, wC2);
+                else store_w(0, wD0, wD1, wD2);
                 DX_BARRIER();
                 if (late_a) read_a(aslot ^ 1, dx, s + 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -280,34 +310,14 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(ConvArgs a, int nrows) {
         }
         DX_STAMP(4 + dx);
     };
-    phase(0, 2, wB0, wB1, wB2, wA0, wA1, wA2);
-    phase(1, 3, wA0, wA1, wA2, wB0, wB1, wB2);
-    phase(2, 4, wB0, wB1, wB2, wA0, wA1, wA2);
-    phase(3, -1, wA0, wA1, wA2, wB0, wB1, wB2);
-    phase(4, -1, wA0, wA1, wA2, wA0, wA1, wA2);
+    phase(0);
+    phase(1);
+    phase(2);
+    phase(3);
+    phase(4);
 
-    // ---- epilogue: lane (li, g) holds output channels cot*16 + 4g .. + 3 of pixel pcc of the three rows -----------------------
-    float vmax = 0.f;
 #pragma unroll
-    for (int j = 0; j < R; ++j) {
-        if (G0 + j < nrows) {                                   // wave uniform
-            float4 v;
-            v.x = (acc[j][0] + acl[j][0] * (1.f / 2048.f)) * out_scale + biasv.x;
-            v.y = (acc[j][1] + acl[j][1] * (1.f / 2048.f)) * out_scale + biasv.y;
-            v.z = (acc[j][2] + acl[j][2] * (1.f / 2048.f)) * out_scale + biasv.z;
-            v.w = (acc[j][3] + acl[j][3] * (1.f / 2048.f)) * out_scale + biasv.w;
-            if (a.res) { v.x += resv[j].x; v.y += resv[j].y; v.z += resv[j].z; v.w += resv[j].w; }     // (uniform branch; without a residual the prefetched dummy is dropped)
-            if (a.epi == SOL_EPI_LRELU) {
-                v.x = v.x > 0.f ? v.x : a.slope * v.x; v.y = v.y > 0.f ? v.y : a.slope * v.y;
-                v.z = v.z > 0.f ? v.z : a.slope * v.z; v.w = v.w > 0.f ? v.w : a.slope * v.w;
-            } else if (a.epi == SOL_EPI_DLRELU) {
-                v.x *= actv[j].x > 0.f ? 1.f : a.slope; v.y *= actv[j].y > 0.f ? 1.f : a.slope;
-                v.z *= actv[j].z > 0.f ? 1.f : a.slope; v.w *= actv[j].w > 0.f ? 1.f : a.slope;
-            }
-            vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-            reinterpret_cast<float4*>(a.y)[out_f4(j)] = v;
-        }
-    }
+    for (int j = 0; j < R; ++j) epilogue_row(j);
     DX_STAMP(9);
     if (a.ymax) amax_publish_last(vmax, a.ymax, amax_lds);
     DX_STAMP(10);

@@ -118,13 +118,15 @@ if "--no-step" not in sys.argv:
         wls[dx] = bench.Workload(sol_amd, dev, 6, 128, 64, 32, 0)
         wls[dx].step(1e-6)
     res_ms = {0: [], 1: []}
-    for rep in range(3):
-        for dx in (0, 1):
+    for rep in range(8):
+        for dx in ((0, 1) if rep % 2 == 0 else (1, 0)):
             _lib.set_option("conv_dx", dx)
-            sec, loss, _ = bench.timed_steps(wls[dx], 1e-6, 10, 2, torch.cuda.synchronize)
-            res_ms[dx].append(sec / 10 * 1e3)
-            print("rep %d conv_dx=%d: %.3f ms per SOL-32 step (loss %.4f)" % (rep, dx, sec / 10 * 1e3, loss), flush=True)
+            sec, loss, _ = bench.timed_steps(wls[dx], 1e-6, 20, 2, torch.cuda.synchronize)
+            res_ms[dx].append(sec / 20 * 1e3)
+            print("rep %d conv_dx=%d: %.3f ms per SOL-32 step (loss %.4f)" % (rep, dx, sec / 20 * 1e3, loss), flush=True)
     out["ms_per_step"] = res_ms
+    import statistics
+    print("medians: sb %.3f ms  dx %.3f ms" % (statistics.median(res_ms[0]), statistics.median(res_ms[1])), flush=True)
     for name, (Bq, Yq, Xq) in {"recipe_64x32_b3": (3, 64, 32)}.items():
         r2 = {}
         for dx in (0, 1):
