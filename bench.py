@@ -49,6 +49,9 @@ def parse():
     p.add_argument("--precision", default="split", choices=["split", "bf16x6", "fp32"], help="conv arithmetic of the timed steps")
     p.add_argument("--cpu-msteps", type=int, default=2, help="msteps of the bounded CPU-baseline sample")
     p.add_argument("--no-cpu-sol32", action="store_true", help="skip the ONE CPU training step at the full SOL-<msteps> depth that calibrates the bounded sample")
+    p.add_argument("--prewarm", type=int, default=0,
+                   help="untimed training steps BEFORE the W warm-up steps (clock / power-state ramp of a freshly leased GPU: the first seconds "
+                        "of a process; measured: no effect on this pool, default 0); reported in the line as pre_warmup_steps")
     p.add_argument("--comm", default="torch", choices=["torch", "lib"],
                    help="N > 1: the gradient all-reduce through torch.distributed.all_reduce (RCCL via PyTorch) or through the library's own "
                         "RCCL communicator (sol_allreduce_grads, csrc/comm.hip; needs one device per rank)")
@@ -372,6 +375,8 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(max(0, args.prewarm)):
+        wl.step(args.lr)
     sec, loss, trace = timed_steps(wl, args.lr, args.steps, args.warmup, barrier)
     tsec = torch.tensor([sec], dtype=torch.float64, device=dev)
     rank_ms = [sec / args.steps * 1e3]
@@ -512,7 +517,7 @@ def main():
             # the same step with every convolution on v_mfma_f32_*_f32 (no operand splits), that kernel's fraction of the fp32 matrix
             # peak, and the fused advect + pressure launch's fraction of the HBM peak at this batch size (measured k)
             "strict_fp32_ms_per_step": None, "strict_fp32_frac": None, "solver_step_frac": roof_solver["frac"] if roof_solver else None,
-            "valid": bool(valid), "rank_skew": rank_skew,
+            "valid": bool(valid), "rank_skew": rank_skew, "pre_warmup_steps": max(0, args.prewarm),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"split": "f32 (fp16x3 split MFMA in 32-ch convs)", "bf16x6": "f32 (bf16x6 split MFMA in 32-ch convs)", "fp32": "f32"}[args.precision],
             "data": "synthetic",
