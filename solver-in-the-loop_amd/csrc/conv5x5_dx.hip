@@ -51,6 +51,10 @@ __device__ unsigned g_dx_prof_ctl[2] = {0u, 1u};
 
 template <int R>
 __global__ void __launch_bounds__(512) k_conv5x5_dx(ConvArgs a, int nrows) {
+    // (Tried: all kernel arguments fetched in ONE batch of scalar loads pinned at the entry instead of the compiler's three dependent
+    // batches.  The timeline behind the first stamp improved by 0.1 us -- and every launch became 0.5 us LONGER (rocprof 11.2 ->
+    // 11.7 us in the step): the one big batch is waited for before anything is issued, while the lazy batches overlap with the
+    // first vector requests.  Reverted.)
     constexpr int DX_NS = R + 4;                                // input rows (LDS slots) of R output rows
     static_assert(R >= 1 && R <= 3, "one to three output rows per workgroup");
     extern __shared__ __align__(16) unsigned char smem_dx[];

@@ -105,6 +105,41 @@ for dx in (0, 1, 0, 1):
     print("conv_dx=%d: %.2f us per launch (graph replay, 50 launches, res + lrelu + absmax)" % (dx, us), flush=True)
 out["us_per_launch"] = times
 
+# ---- the same chain as the training step sees it: ten different layers' weights in turn and a residual operand that is HBM-cold
+#      (50 different tensors = 315 MB, more than the 256 MB memory-side cache) ----
+packs = [ops._pack(torch.randn(5, 5, 32, 32, device=DEV) * 0.02, 32, 32, ops.CONV_FWD) for _ in range(10)]
+ress = [torch.randn(B, H, W, 32, device=DEV) for _ in range(50)]
+times_cold = {}
+for dx in (0, 1, 0, 1):
+    _lib.set_option("conv_dx", dx)
+    bufs = [x, y]
+
+    def chain2():
+        for k in range(50):
+            src, dst = bufs[k & 1], bufs[(k + 1) & 1]
+            _lib.check(lib.sol_conv5x5_scaled(_lib.stream(), _lib.ptr(src), _lib.ptr(packs[k % 10]), _lib.ptr(b), _lib.ptr(ress[k]), None, _lib.ptr(dst),
+                                              B, H, W, 32, 32, ops.EPI_LRELU, 0.3, _lib.ptr(xm), _lib.ptr(ym)))
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        chain2()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with _lib.no_gc_during_capture(), torch.cuda.graph(g):
+        chain2()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 / 50 * 1e3
+    times_cold.setdefault(dx, []).append(us)
+    print("conv_dx=%d: %.2f us per launch (graph replay, 50 launches, TEN layers' weights in turn, 50 different residual tensors)" % (dx, us), flush=True)
+out["us_per_launch_cold_operands"] = times_cold
+del ress
+
 if "--no-step" not in sys.argv:
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
