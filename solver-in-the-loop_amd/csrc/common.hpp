@@ -156,6 +156,7 @@ struct SolOptions {
     int k3d_fused_tf;     // 1 (default): the sine transforms of the karman-3d pressure solve as LDS-resident plane / column-slab kernels; 0: batched GEMMs
     int k3d_conv_rows;    // rows per workgroup of the one-launch Conv3D kernel: 8 (k_conv3d_sb8, 64 x 32 wave tiles), 6 (k_conv3d_sb6, 32 x 32), 3 (k_conv3d_sb, 16 x 32)
     int k3d_conv_fused;   // 1 (default): 32 -> 32 Conv3D layers with W == 64 and a known operand absmax as ONE launch (conv3d_sb.hip); 0: five passes of the 2-D kernel
+    int k3d_mfma_tf;      // 1 (default): the LDS-resident sine transforms of the karman-3d pressure solve on the fp32 matrix cores (k3_ty_mfma, k3_tzx_mfma)
     int conv_dx;          // 1 (default): the 32 -> 32 fp16 three-product convolutions run the dx-major kernel (conv5x5_dx.hip: a wave owns a pixel segment of all
                           //    three output rows, 0.53 LDS operand reads per MFMA); 0: k_conv5x5_sb (one output row per wave, 1.0 reads per MFMA)
     int k3d_tile;         // 1: karman-3d advection from LDS tiles holding the full z column + halo; 0 (default, measured faster at B <= 2): wave-per-column gathers from global memory

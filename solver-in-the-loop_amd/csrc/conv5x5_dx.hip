@@ -267,9 +267,12 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(ConvArgs a, int nrows) {
             // positions of x and drops the values: requests inside `if (a.res)` blocks make the compiler's next vmcnt wait a wait
             // for everything in flight.  They are HBM-cold in the training pipeline (written hundreds of launches ago): ~3 us.
             if ((dx == 1 || dx == 2) && s >= 3 && s - 3 < R) {
-                const int j = s - 3, jj = G0 + j < nrows ? j : 0;       // (scalar) rows beyond the tensor: any valid position
-                if (dx == 1) resv[j] = reinterpret_cast<const float4*>(a.res ? a.res : a.x)[out_f4(jj)];
-                else actv[j] = reinterpret_cast<const float4*>(a.epi == SOL_EPI_DLRELU ? a.act : a.x)[out_f4(jj)];
+                const int j = s - 3;
+                // (scalar clamp) rows beyond the tensor -- the last workgroup's tail and the padding workgroups that own no rows at
+                // all (grid rounded up to a multiple of 8) -- read the tensor's last row: any valid position
+                const size_t o4 = ((size_t)min(G0 + j, nrows - 1) * W + x0 + pcc) * 8 + cot * 4 + g;
+                if (dx == 1) resv[j] = reinterpret_cast<const float4*>(a.res ? a.res : a.x)[o4];
+                else actv[j] = reinterpret_cast<const float4*>(a.epi == SOL_EPI_DLRELU ? a.act : a.x)[o4];
             }
             __builtin_amdgcn_sched_barrier(0);                  // keep the prefetch reads above this step's MFMAs
             const f16x8 x1 = __builtin_bit_cast(f16x8, ao[aslot][0]), x2 = __builtin_bit_cast(f16x8, ao[aslot][1]);

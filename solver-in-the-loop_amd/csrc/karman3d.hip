@@ -491,6 +491,107 @@ __global__ void __launch_bounds__(256) k3_ty(const float* __restrict__ in, float
     }
 }
 
+
+// ---- the same transforms on the fp32 matrix cores (option k3d_mfma_tf, default) ------------------------------------------------
+// k3_ty / k3_tzx above feed every FMA from LDS (10 reads per 16 FMAs): 35.5 / 10.6 us per launch, a tenth of a CU's fp32 rate, and
+// six of them are 113 of the 174 us of a 3-D solver step.  v_mfma_f32_32x32x2_f32 has the same peak as the VALU but takes its
+// operands as ONE ds_read_b32 each per 4096 FLOP: A[i][k] in lane (i, k) = (lane & 31, lane >> 5), B[k][j] in lane (j, k), D rows
+// (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31 (the layout k_conv5x5_bww32 uses).  LDS strides: arrays read with the lane
+// along a ROW index (A operands) have stride = 2 (mod 64) words, arrays read with the lane along the column (B operands) stride = 32
+// (mod 64): the two k of a step then hit disjoint bank halves -- conflict free.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+// The transform matrices never go through LDS: they are the same for every workgroup (L2 resident), symmetric, and a wave needs the
+// same 32 rows (ty) / one 32 x K block (tzx) of them for all its MFMAs -- one coalesced dword per lane and K step, held in registers
+// (staging the 64 KB Q_y into LDS was more than half of the first MFMA version of k3_ty: 18.4 us).
+
+// one workgroup = a slab of 32 columns x all Y rows: out = Qy diag(il) Qy f (Y % 32 == 0, Y <= 128; wave w owns row tile w)
+template <int YK>                              // YK = Y / 2 K steps (64 at Y = 128)
+__global__ void __launch_bounds__(256) k3_ty_mfma(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ Qy,
+                                                   const float* __restrict__ il, int XZ) {
+    constexpr int Y = 2 * YK;
+    __shared__ __align__(16) float Fm[Y * 32], Tm[Y * 32];
+    const int b = blockIdx.y, c0 = blockIdx.x * 32;
+    const size_t base = (size_t)b * Y * XZ + c0;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 31, kp = lane >> 5;
+    const int m0 = wave * 32;
+    // A[m][k] = Qy[k][m] (symmetric): lane (m = m0 + c, k = 2 ks + kp) -- a coalesced row segment per k
+    float qa[YK];
+    if (m0 < Y) {
+#pragma unroll
+        for (int ks = 0; ks < YK; ++ks) qa[ks] = Qy[(size_t)(2 * ks + kp) * Y + m0 + c];
+    }
+    for (int e = t; e < Y * 8; e += 256) *reinterpret_cast<float4*>(&Fm[(e >> 3) * 32 + (e & 7) * 4]) = *reinterpret_cast<const float4*>(&in[base + (size_t)(e >> 3) * XZ + (e & 7) * 4]);
+    float ilv[16];
+    if (m0 < Y) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ilv[r] = il[(size_t)(m0 + (r & 3) + 8 * (r >> 2) + 4 * kp) * XZ + c0 + c];
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* Bm = pass == 0 ? Fm : Tm;
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (m0 < Y) {
+            const float* bp = Bm + kp * 32 + c;
+#pragma unroll
+            for (int ks = 0; ks < YK; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[ks], bp[ks * 64], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * kp;
+                if (pass == 0) Tm[m * 32 + c] = acc[r] * ilv[r];
+                else out[base + (size_t)m * XZ + c] = acc[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// one workgroup = one (x, z) plane: out = Qx (F Qz)  (X, Z in {32, 64}); wave = (row tile, column tile)
+template <int XK, int ZK>                      // K steps of the two products: X / 2, Z / 2
+__global__ void __launch_bounds__(256) k3_tzx_mfma(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ Qx,
+                                                    const float* __restrict__ Qz) {
+    constexpr int X = 2 * XK, Z = 2 * ZK, SA = 66, SB = 96;      // A-type / B-type LDS strides (words)
+    __shared__ __align__(16) float Fa[X * SA], Tb[X * SB];
+    const size_t plane = (size_t)blockIdx.x * X * Z;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 31, kp = lane >> 5;
+    const int mt = wave & 1, nt = wave >> 1;   // tile (rows 32 mt.., columns 32 nt..)
+    const bool have = mt * 32 < X && nt * 32 < Z;
+    float qz[ZK], qx[XK];                      // B[k][z] = Qz[k][32 nt + c];  A[m][k] = Qx[k][32 mt + c] (symmetric): coalesced rows
+    if (have) {
+#pragma unroll
+        for (int ks = 0; ks < ZK; ++ks) qz[ks] = Qz[(2 * ks + kp) * Z + nt * 32 + c];
+#pragma unroll
+        for (int ks = 0; ks < XK; ++ks) qx[ks] = Qx[(2 * ks + kp) * X + mt * 32 + c];
+    }
+    for (int e = t; e < X * Z / 2; e += 256) {       // 8-byte pieces (rows of SA words are 8-byte aligned)
+        const int row = e / (Z / 2), col = (e % (Z / 2)) * 2;
+        *reinterpret_cast<float2*>(&Fa[row * SA + col]) = *reinterpret_cast<const float2*>(&in[plane + (size_t)row * Z + col]);
+    }
+    __syncthreads();
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (have) {                                // T = F Qz: A = F[x][k] (LDS), B = Qz (registers)
+        const float* ap = Fa + (mt * 32 + c) * SA + kp;
+#pragma unroll
+        for (int ks = 0; ks < ZK; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[ks * 2], qz[ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Tb[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kp) * SB + nt * 32 + c] = acc[r];
+    }
+    __syncthreads();
+    if (have) {                                // out = Qx T: A = Qx (registers), B = T[k][z] (LDS)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* bp = Tb + kp * SB + nt * 32 + c;
+#pragma unroll
+        for (int ks = 0; ks < XK; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qx[ks], bp[ks * 2 * SB], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[plane + (size_t)(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kp) * Z + nt * 32 + c] = acc[r];
+    }
+}
+
 // velocity += scale_c * correction[..., c]  (to_staggered + add, karman_train.py:88-90, 424-426, three components): the
 // correction has no value on the last face of each component's own axis
 __global__ void __launch_bounds__(256) k3_correct(const float* __restrict__ out, int CO, float s0, float s1, float s2, float* __restrict__ vy,
@@ -543,12 +644,28 @@ int pressure_solve3d(hipStream_t s, const sol_karman3d_cfg* c, const int32_t* hd
     // inverse y transform, plane-wise inverse) instead of six batched GEMMs + a scaling pass
     const bool fused_tf = sol_opt().k3d_fused_tf && X <= 64 && Z <= 64 && Y <= 128 && X % 4 == 0 && Z % 4 == 0 && Y % 16 == 0 && (X * Z) % 32 == 0;
     const size_t ty_lds = ((size_t)Y * (Y + 4) + (size_t)Y * 36) * sizeof(float);
+    // the matrix-core kernels are instantiated for the shapes that occur: Y in {128, 64, 32}, X, Z in {64, 32}
+    const bool mfma_tf = sol_opt().k3d_mfma_tf && fused_tf && (X == 64 || X == 32) && (Z == 64 || Z == 32) && (Y == 128 || Y == 64 || Y == 32);
     auto Gf = [&](float* src, float* t1, float* t2) -> int {
         static std::atomic<unsigned long long> optin{0};
         if (int e = sol_lds_optin(optin, {SOL_K(k3_ty)}, "k3_ty")) return e;
-        SOL_LAUNCH(k3_tzx, dim3(B * Y), dim3(256), 0, s, src, t1, Qx, Qz, X, Z);
-        SOL_LAUNCH(k3_ty, dim3(X * Z / 32, B), dim3(256), ty_lds, s, t1, t2, Qy, il, Y, X * Z);
-        SOL_LAUNCH(k3_tzx, dim3(B * Y), dim3(256), 0, s, t2, t1, Qx, Qz, X, Z);
+        if (mfma_tf) {
+            auto tzx = [&](const float* in, float* out) {
+                if (X == 64 && Z == 64) SOL_LAUNCH((k3_tzx_mfma<32, 32>), dim3(B * Y), dim3(256), 0, s, in, out, Qx, Qz);
+                else if (X == 64) SOL_LAUNCH((k3_tzx_mfma<32, 16>), dim3(B * Y), dim3(256), 0, s, in, out, Qx, Qz);
+                else if (Z == 64) SOL_LAUNCH((k3_tzx_mfma<16, 32>), dim3(B * Y), dim3(256), 0, s, in, out, Qx, Qz);
+                else SOL_LAUNCH((k3_tzx_mfma<16, 16>), dim3(B * Y), dim3(256), 0, s, in, out, Qx, Qz);
+            };
+            tzx(src, t1);
+            if (Y == 128) SOL_LAUNCH(k3_ty_mfma<64>, dim3(X * Z / 32, B), dim3(256), 0, s, (const float*)t1, t2, Qy, il, X * Z);
+            else if (Y == 64) SOL_LAUNCH(k3_ty_mfma<32>, dim3(X * Z / 32, B), dim3(256), 0, s, (const float*)t1, t2, Qy, il, X * Z);
+            else SOL_LAUNCH(k3_ty_mfma<16>, dim3(X * Z / 32, B), dim3(256), 0, s, (const float*)t1, t2, Qy, il, X * Z);
+            tzx(t2, t1);
+        } else {
+            SOL_LAUNCH(k3_tzx, dim3(B * Y), dim3(256), 0, s, src, t1, Qx, Qz, X, Z);
+            SOL_LAUNCH(k3_ty, dim3(X * Z / 32, B), dim3(256), ty_lds, s, t1, t2, Qy, il, Y, X * Z);
+            SOL_LAUNCH(k3_tzx, dim3(B * Y), dim3(256), 0, s, t2, t1, Qx, Qz, X, Z);
+        }
         SOL_LAUNCH_CHECK();
         return SOL_OK;
     };
@@ -678,7 +795,12 @@ __global__ void __launch_bounds__(256) k3b_gva(K3BArgs a) {
     if (threadIdx.x == 0) {
         float m = 0.f;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
-        atomicMax(&a.gmax[b * K3B_SLOTS + (blockIdx.x & (K3B_SLOTS - 1))], __float_as_uint(m));
+        // (thousands of workgroups share the 64 slots of a simulation and same-address atomics serialise in the L2, ~0.3 us apiece:
+        //  33 us for this kernel.  A workgroup whose maximum does not exceed what the slot already holds has nothing to publish;
+        //  the maximum is order independent, so the filter changes nothing but the number of atomics.)
+        unsigned* slot = &a.gmax[b * K3B_SLOTS + (blockIdx.x & (K3B_SLOTS - 1))];
+        const unsigned mb = __float_as_uint(m);
+        if (mb > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, mb);
     }
 }
 
