@@ -23,7 +23,9 @@ _NOSLP = ["-fno-slp-vectorize"]
 _ITILP = ["-mllvm", "--amdgpu-sched-strategy=iterative-ilp"]
 EXTRA = {"karman_step.hip": _NOSLP + _ITILP, "conv3d_sb.hip": _NOSLP, "conv5x5_sb.hip": _NOSLP + _ITILP, "conv5x5.hip": _NOSLP + _ITILP,
          "train.hip": _NOSLP, "cnn_chain.hip": _NOSLP,
-         "conv5x5_dx.hip": _NOSLP}                # hand-scheduled with sched_barrier like conv3d_sb.hip: no iterative-ILP strategy
+         # hand-scheduled with sched_barrier like conv3d_sb.hip: no iterative-ILP strategy; the leading scalar kernel arguments
+         # (pointers + tile geometry, 11 dwords) are preloaded into SGPRs by the command processor
+         "conv5x5_dx.hip": _NOSLP + ["-mllvm", "-amdgpu-kernarg-preload-count=11"]}
 
 
 def _hipcc():

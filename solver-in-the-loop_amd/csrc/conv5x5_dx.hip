@@ -50,7 +50,13 @@ __device__ unsigned g_dx_prof_ctl[2] = {0u, 1u};
 #endif
 
 template <int R>
-__global__ void __launch_bounds__(512) k_conv5x5_dx(ConvArgs a, int nrows) {
+__global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ arg_x, const void* __restrict__ arg_wsh, const unsigned* __restrict__ arg_xmax,
+                                                      int nrows, int arg_H, int arg_W, int arg_tiles_x, int arg_hshift, ConvArgs a) {
+    // What the prologue needs before its first request -- the three operand pointers and the tile geometry -- are LEADING scalar
+    // kernel arguments: the file is compiled with -amdgpu-kernarg-preload-count=13, so the command processor delivers them in SGPRs
+    // with the wave (gfx950 kernel-argument preload) and no scalar-memory round trip stands in front of the requests; the rest
+    // of ConvArgs (epilogue operands) is fetched lazily in their shadow.
+    a.x = arg_x; a.wsh = arg_wsh; a.xmax = arg_xmax; a.H = arg_H; a.W = arg_W; a.tiles_x = arg_tiles_x; a.RPW = arg_hshift;
     // (Tried: all kernel arguments fetched in ONE batch of scalar loads pinned at the entry instead of the compiler's three dependent
     // batches.  The timeline behind the first stamp improved by 0.1 us -- and every launch became 0.5 us LONGER (rocprof 11.2 ->
     // 11.7 us in the step): the one big batch is waited for before anything is issued, while the lazy batches overlap with the
@@ -360,8 +366,8 @@ int sol_conv_dx_launch(hipStream_t s, const ConvArgs& a_in, int ntiles) {
     const int R = ((nrows + 2) / 3) * a.tiles_x >= 128 ? 3 : 1;
     int grid = ((nrows + R - 1) / R) * a.tiles_x;
     if (grid > 64) grid = (grid + 7) / 8 * 8;             // XCD-aware tile order needs a multiple of 8 (xcd_tile); padding tiles own no rows
-    if (R == 3) SOL_LAUNCH(k_conv5x5_dx<3>, dim3(grid), dim3(512), dx_lds(3), s, a, nrows);
-    else SOL_LAUNCH(k_conv5x5_dx<1>, dim3(grid), dim3(512), dx_lds(1), s, a, nrows);
+    if (R == 3) SOL_LAUNCH(k_conv5x5_dx<3>, dim3(grid), dim3(512), dx_lds(3), s, a.x, a.wsh, a.xmax, nrows, a.H, a.W, a.tiles_x, a.RPW, a);
+    else SOL_LAUNCH(k_conv5x5_dx<1>, dim3(grid), dim3(512), dx_lds(1), s, a.x, a.wsh, a.xmax, nrows, a.H, a.W, a.tiles_x, a.RPW, a);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }
