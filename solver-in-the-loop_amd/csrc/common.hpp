@@ -17,10 +17,10 @@ int sol_density_chain(const sol_karman_cfg* c, void* stream, int ms, const float
                       long st_vy, long st_vx, const float* inflow, float* d_steps, long st_d, float* d_final);
 // internal (train.hip): last CNN layer (32 -> 2, no activation) fused with `velocity += std * to_staggered(output)` and the
 // l2 loss of the step (karman_train.py:413-447); needs the split-precision kernels (sol_conv_correct_fusable)
-bool sol_conv_correct_fusable(int W);
+bool sol_conv_correct_fusable(int W, int rows);      // rows = B * H of the CNN's images
 int sol_conv5x5_correct(void* stream, const float* x, const float* packed, const float* bias, int B, int H, int W,
                         const unsigned* x_absmax, float* vy, float* vx, const float* gt_vy, const float* gt_vx,
-                        float s0, float s1, float l0, float l1, float* loss);
+                        float s0, float s1, float l0, float l1, float* loss, float* loss_part);
 size_t sol_bww_batched_ws_floats(int nseg, int B, int H, int cin, int cout);
 int sol_bww_batched(void* stream, const float* x, const float* dz, float* partial, int nseg, int nseg_layout, int overwrite,
                     long x_seg, long dz_seg, int B, int H, int W, int cin, int cout,
@@ -50,7 +50,10 @@ struct ConvArgs {
     float cs0, cs1;                 // correction scale (out.std, = std_v unless --pretf)
     float ls0, ls1;                 // loss scale (std_v)
     float* closs;                   // += 0.5 * sum(((gt - v) / std)^2) over ALL faces, or NULL
+    float* closs_part;              // [SOL_LOSS_PART_FLOATS] scratch of the deterministic fold (loss_fold_wg), required with closs
 };
+// deterministic loss of a launch: one partial per workgroup + the launch's ticket word (at index SOL_LOSS_PART_MAX, zero between launches)
+constexpr int SOL_LOSS_PART_MAX = 2048, SOL_LOSS_PART_FLOATS = SOL_LOSS_PART_MAX + 64;
 constexpr int SOL_AMAX_SLOTS = 256;   // one per workgroup of a 256-WG launch: same-address atomics serialise in L2 (~0.3 us each)
 // backward-weight arguments
 struct BwArgs {
@@ -123,7 +126,7 @@ int sol_conv_sh_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int 
 int sol_conv_sb_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int mode, void* out);
 int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles);
 // dx-major form of the 32 -> 32 fp16 three-product kernel (conv5x5_dx.hip; option conv_dx)
-bool sol_conv_dx_usable(const ConvArgs& a, int NT);
+bool sol_conv_dx_usable(const ConvArgs& a, int NT, int ntiles);
 int sol_conv_dx_launch(hipStream_t s, const ConvArgs& a, int ntiles);
 
 // fused 5x5x5 convolution, 32 -> 32 or 32 -> (<= 16) channels, W == 64 (conv3d_sb.hip)
@@ -157,8 +160,10 @@ struct SolOptions {
     int k3d_conv_rows;    // rows per workgroup of the one-launch Conv3D kernel: 8 (k_conv3d_sb8, 64 x 32 wave tiles), 6 (k_conv3d_sb6, 32 x 32), 3 (k_conv3d_sb, 16 x 32)
     int k3d_conv_fused;   // 1 (default): 32 -> 32 Conv3D layers with W == 64 and a known operand absmax as ONE launch (conv3d_sb.hip); 0: five passes of the 2-D kernel
     int k3d_mfma_tf;      // 1 (default): the LDS-resident sine transforms of the karman-3d pressure solve on the fp32 matrix cores (k3_ty_mfma, k3_tzx_mfma)
-    int conv_dx;          // 1 (default): the 32 -> 32 fp16 three-product convolutions run the dx-major kernel (conv5x5_dx.hip: a wave owns a pixel segment of all
-                          //    three output rows, 0.53 LDS operand reads per MFMA); 0: k_conv5x5_sb (one output row per wave, 1.0 reads per MFMA)
+    int conv_dx;          // bit 0: the 32 -> 32 fp16 three-product convolutions run the dx-major kernel (conv5x5_dx.hip: a wave owns a pixel segment of all
+                          //    three output rows, 0.53 LDS operand reads per MFMA); 0: k_conv5x5_sb (one output row per wave, 1.0 reads per MFMA).
+                          //    bit 1: also the thin 32 -> (<= 16) layers where a workgroup owns one row (small launches); bit 2: those layers in every
+                          //    launch (measured slower where the launch fills the chip).  Default 3.
     int k3d_tile;         // 1: karman-3d advection from LDS tiles holding the full z column + halo; 0 (default, measured faster at B <= 2): wave-per-column gathers from global memory
 };
 SolOptions& sol_opt();
@@ -223,6 +228,49 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
+}
+
+// Bit-reproducible sum over a launch (the per-step l2 loss).  Called by ONE full wave of every workgroup with the workgroup's
+// sum `wg_sum` (wave uniform; itself formed in a fixed order): the partial goes to part[blockIdx.x] and the workgroup draws a
+// ticket; the LAST workgroup adds all partials in workgroup order (64 strided chains, then the fixed butterfly of wave_sum)
+// and adds the total to *loss.  No floating-point atomics between workgroups -- with those the sum depended on the order the
+// workgroups happened to finish in (equal to round-off only; the training step is otherwise bit for bit reproducible).
+// The final add IS an atomic: with the option `streams` > 1 several launches (sub-batches) add to the same word.
+__device__ __forceinline__ void loss_fold_wg(float wg_sum, float* __restrict__ loss, float* __restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    unsigned* ctr = reinterpret_cast<unsigned*>(part + SOL_LOSS_PART_MAX);
+    unsigned last = 0u;
+    if (lane == 0) {
+        __hip_atomic_store(&part[blockIdx.x], wg_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    }
+    last = (unsigned)__shfl((int)last, 0, 64);
+    if (!last) return;
+    float t = 0.f;
+    for (int i = lane; i < (int)gridDim.x; i += 64) t += __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = wave_sum(t);
+    if (lane == 0) {
+        atomicAdd(loss, t);
+        __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
+    }
+}
+// Barrier-free workgroup stage in front of it: every wave (all lanes) calls this with its lanes' sums; `lds` = {wave ticket (zeroed before
+// the kernel's first barrier), pad, pad, pad, one slot per wave}.  The wave that draws the last ticket adds the slots in wave order.
+__device__ __forceinline__ void loss_publish_last(float lsum, float* __restrict__ loss, float* __restrict__ part, unsigned* lds) {
+    lsum = wave_sum(lsum);
+    const int nw = blockDim.x >> 6;
+    unsigned last = 0u;
+    if ((threadIdx.x & 63) == 0) {
+        reinterpret_cast<float*>(lds)[4 + (threadIdx.x >> 6)] = lsum;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        last = atomicAdd(&lds[0], 1u) == (unsigned)(nw - 1) ? 1u : 0u;       // the LDS unit executes in arrival order: the slot is written before the ticket is drawn
+    }
+    last = (unsigned)__shfl((int)last, 0, 64);
+    if (!last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float s = 0.f;
+    for (int w = 0; w < nw; ++w) s += reinterpret_cast<volatile float*>(lds)[4 + w];
+    loss_fold_wg(s, loss, part);
 }
 
 // XCD-aware tile order: the hardware deals consecutive workgroup ids round robin to the 8 XCDs (each with its own L2), so

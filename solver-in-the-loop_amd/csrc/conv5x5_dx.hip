@@ -32,9 +32,9 @@ constexpr int DX_SLOT = 2 * DX_PLANE;              // hi + lo plane
 // serves launches with few image rows (the reference's 64x32 x 3 recipe: 96 rows = 32 workgroups of three rows on 256 CUs, every
 // launch pure latency): three times the workgroups, a third of the loop each -- the rows no longer share pixel operands, which does
 // not matter where the loop is a fraction of the launch.
-constexpr int DX_WPL = 32 * 64;                    // bytes per (tap, plane) weight block: 32 co x 32 ci fp16
-constexpr int DX_WPH = 5 * 2 * DX_WPL;             // bytes per dx phase: five dy x two planes
-constexpr int dx_lds(int R) { return (R + 4) * DX_SLOT + 2 * DX_WPH + 16; }
+constexpr int dx_wpl(int COT) { return COT * 16 * 64; }        // bytes per (tap, plane) weight block: 16 COT co x 32 ci fp16
+constexpr int dx_wph(int COT) { return 5 * 2 * dx_wpl(COT); }  // bytes per dx phase: five dy x two planes
+constexpr int dx_lds(int R, int COT) { return (R + 4) * DX_SLOT + 2 * dx_wph(COT) + 16 + 64; }    // + absmax words, loss_publish_last's 4 + 12
 
 #define DX_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -49,7 +49,10 @@ __device__ unsigned g_dx_prof_ctl[2] = {0u, 1u};
 #define DX_STAMP(k) do { } while (0)
 #endif
 
-template <int R>
+// COT: 16-channel output tiles.  2: the 32 -> 32 layers (waves = 4 pixel segments x 2 tiles).  1: the thin layers (<= 16 output channels:
+// the 32 -> 2 output layer in correction mode and its data gradient's counterpart) -- waves 0..3 own the four pixel segments and all the
+// MFMAs, waves 4..7 are the "late" staging role only.
+template <int R, int COT>
 __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ arg_x, const void* __restrict__ arg_wsh, const unsigned* __restrict__ arg_xmax,
                                                       int nrows, int arg_H, int arg_W, int arg_tiles_x, int arg_hshift, ConvArgs a) {
     // What the prologue needs before its first request -- the three operand pointers and the tile geometry -- are LEADING scalar
@@ -62,6 +65,9 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
     // 11.7 us in the step): the one big batch is waited for before anything is issued, while the lazy batches overlap with the
     // first vector requests.  Reverted.)
     constexpr int DX_NS = R + 4;                                // input rows (LDS slots) of R output rows
+    constexpr int DX_WPL = dx_wpl(COT), DX_WPH = dx_wph(COT);
+    constexpr int NBLK = COT * 128;                             // uint4 per tap of the packed weights: 2 planes x 16 COT co x 4
+    static_assert(COT == 1 || COT == 2, "one or two 16-channel output tiles");
     static_assert(R >= 1 && R <= 3, "one to three output rows per workgroup");
     extern __shared__ __align__(16) unsigned char smem_dx[];
     unsigned char* const ring = smem_dx;                        // [7 slots][2 planes][68 px][64 B]
@@ -76,7 +82,7 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
     if (dx_prof) dx_prof += ((size_t)(g_dx_prof_ctl[0] % g_dx_prof_ctl[1]) * gridDim.x + blockIdx.x) * 16;
 #endif
     DX_STAMP(0);
-    if (tid == 0) *reinterpret_cast<uint2*>(amax_lds) = make_uint2(0u, 0u);
+    if (tid == 0) *reinterpret_cast<uint4*>(amax_lds) = make_uint4(0u, 0u, 0u, 0u);      // absmax word + ticket, loss sum + ticket
     // What needs no tile coordinates is requested first, in the shadow of the scalar preamble: the absmax slots and the role's weight set
     // (phase 0 / phase 1: piece k = dy block k, position t).  NAMED registers: an array captured by the staging lambda was put into
     // scratch memory (a store behind every load: the requests serialised, first MFMA at 5.4 us).
@@ -84,8 +90,14 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
     const int t = tid & 255;
     const uint4 am = amax_load(a.xmax);
     const uint4* gw = reinterpret_cast<const uint4*>(a.wsh) + 1;          // behind the header {2^shift_w, 2^-shift_w, 0, 0}
-    const uint4* wsrc = gw + (size_t)(late ? 1 : 0) * 256 + t;
-    const uint4 wq0 = wsrc[0 * 5 * 256], wq1 = wsrc[1 * 5 * 256], wq2 = wsrc[2 * 5 * 256], wq3 = wsrc[3 * 5 * 256], wq4 = wsrc[4 * 5 * 256];
+    // item i = t + 256 k of the role's phase (5 NBLK items: tap (i / NBLK, dxr), position i % NBLK); COT == 1 has 640: k = 3, 4 and the
+    // upper half of k = 2 repeat item 0 and are dropped
+    auto wsrc_of = [&](int k) {
+        int i = t + 256 * k;
+        if (i >= 5 * NBLK) i = 0;
+        return gw + (size_t)((i / NBLK) * 5 + (late ? 1 : 0)) * NBLK + (i % NBLK);
+    };
+    const uint4 wq0 = *wsrc_of(0), wq1 = *wsrc_of(1), wq2 = *wsrc_of(2), wq3 = *wsrc_of(COT == 2 ? 3 : 0), wq4 = *wsrc_of(COT == 2 ? 4 : 0);
     const float winv = reinterpret_cast<const float*>(a.wsh)[1];
     // Scalar preamble, kept short: it runs before the first request can go out (its first form -- four integer divisions on the
     // VALU with read-first-lane round trips and a compare chain per (s, j) pair, 330 instructions -- cost 1.2 us of every launch).
@@ -128,16 +140,16 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
     const bool hok = hxx >= 0 && hxx < W;
     // weight set of phase dx as three 16-byte pieces of every thread (later phases): 1280 uint4 = five (dy) blocks of 256
     auto load_w = [&](int dx, uint4& p0, uint4& p1, uint4& p2) {
-        const int i0 = tid, i1 = tid + 512, i2 = (tid & 255) + 1024;
-        p0 = gw[(size_t)((i0 >> 8) * 5 + dx) * 256 + (i0 & 255)];
-        p1 = gw[(size_t)((i1 >> 8) * 5 + dx) * 256 + (i1 & 255)];
-        p2 = gw[(size_t)((i2 >> 8) * 5 + dx) * 256 + (i2 & 255)];
+        const int i0 = tid, i1 = tid + 512 < 5 * NBLK ? tid + 512 : 0, i2 = (tid & 255) + 1024;
+        p0 = gw[(size_t)((i0 / NBLK) * 5 + dx) * NBLK + (i0 % NBLK)];
+        p1 = gw[(size_t)((i1 / NBLK) * 5 + dx) * NBLK + (i1 % NBLK)];
+        if (COT == 2) p2 = gw[(size_t)((i2 / NBLK) * 5 + dx) * NBLK + (i2 % NBLK)];
     };
     auto store_w = [&](int buf, const uint4& p0, const uint4& p1, const uint4& p2) {
         uint4* dst = reinterpret_cast<uint4*>(Wt + buf * DX_WPH);
         dst[tid] = p0;
-        dst[tid + 512] = p1;
-        if (tid < 256) dst[tid + 1024] = p2;
+        if (tid + 512 < 5 * NBLK) dst[tid + 512] = p1;
+        if (COT == 2 && tid < 256) dst[tid + 1024] = p2;
     };
     auto row_of = [&](int s_) { const int gr = G0 - 2 + s_; return gr < 0 ? 0 : (gr >= nrows ? nrows - 1 : gr); };    // scalar clamp
     float4 hv[8], hh;                                            // item n: row s_base + (n >> 1), pixel p + 32 (n & 1); the early role has six
@@ -172,7 +184,9 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
         if (!hok) hh = make_float4(0.f, 0.f, 0.f, 0.f);
         if (hrow < n_rows) put(q0 + hrow * DX_SLOT + hc_h * 64 + ((((c4 >> 1) ^ swzb(hc_h)) << 4) | ((c4 & 1) << 3)), hh);
         uint4* dst = reinterpret_cast<uint4*>(Wt + (late ? 1 : 0) * DX_WPH) + t;
-        dst[0] = wq0; dst[256] = wq1; dst[512] = wq2; dst[768] = wq3; dst[1024] = wq4;
+        dst[0] = wq0; dst[256] = wq1;
+        if (COT == 2) { dst[512] = wq2; dst[768] = wq3; dst[1024] = wq4; }
+        else if (t < 128) dst[512] = wq2;
     };
     auto stage_late = [&]() __attribute__((always_inline)) { if (late) stage_role(); };
     if (!late) stage_role();
@@ -182,9 +196,11 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
     DX_BARRIER();
     DX_STAMP(3);
     float4 biasv = make_float4(0.f, 0.f, 0.f, 0.f);           // output channels cot * 16 + 4 g .. + 3 (epilogue): requested behind the barrier,
-    if (a.bias) {                                                // off the critical path (four dword loads: a caller's bias slice need not be 16-byte aligned)
+    const bool mma = COT == 2 || !late;                         // wave uniform: this wave owns an output tile
+    if (a.bias && mma) {                                         // off the critical path (four dword loads: a caller's bias slice need not be 16-byte aligned)
         const float* bp = a.bias + cot * 16 + 4 * g;
-        biasv = make_float4(bp[0], bp[1], bp[2], bp[3]);
+        if (COT == 2) biasv = make_float4(bp[0], bp[1], bp[2], bp[3]);
+        else biasv = make_float4(4 * g < a.CO ? bp[0] : 0.f, 4 * g + 1 < a.CO ? bp[1] : 0.f, 4 * g + 2 < a.CO ? bp[2] : 0.f, 4 * g + 3 < a.CO ? bp[3] : 0.f);
     }
 
     f32x4 acc[R], acl[R];                                       // acl: the 2^-11 weighted cross terms
@@ -215,10 +231,12 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
         ao[slot][0] = *reinterpret_cast<const uint4*>(ab + s_ * DX_SLOT);
         ao[slot][1] = *reinterpret_cast<const uint4*>(ab + s_ * DX_SLOT + DX_PLANE);
     };
-    read_b(0, 0, 0);
-    read_a(0, 0, 0);
+    if (mma) {
+        read_b(0, 0, 0);
+        read_a(0, 0, 0);
 #pragma unroll
-    for (int dy = 1; dy < 5; ++dy) read_b(0, 0, dy);
+        for (int dy = 1; dy < 5; ++dy) read_b(0, 0, dy);
+    }
 
     // ---- epilogue of ONE output row: lane (li, g) holds output channels cot*16 + 4g .. + 3 of pixel pcc -----------------------------
     // (Tried: row j's epilogue behind the MFMAs of step j + 5 of the last phase, in their shadow -- row j has its last MFMA in step
@@ -244,6 +262,59 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
         }
     };
 
+    // ---- thin layers (COT == 1): lane (li, g) holds output channels 4g .. 4g+3 of pixel pcc --------------------------------------
+    // correction mode (a.cvy: the 32 -> 2 output layer of the trainer, lanes g == 0): the output is applied to the staggered velocity and
+    // never stored; the faces without a correction (v_y row H, v_x column W) only enter the loss: the owner of the image's last row / of
+    // column W - 1 adds them.  Otherwise a strided store of the a.CO <= 16 channels.
+    float lsum = 0.f;
+    auto epilogue_thin = [&](const int j) __attribute__((always_inline)) {
+        const int gy = G0 + j;
+        if (gy >= nrows) return;                                // wave uniform
+        float o4[4];
+        o4[0] = (acc[j][0] + acl[j][0] * (1.f / 2048.f)) * out_scale + biasv.x;
+        o4[1] = (acc[j][1] + acl[j][1] * (1.f / 2048.f)) * out_scale + biasv.y;
+        o4[2] = (acc[j][2] + acl[j][2] * (1.f / 2048.f)) * out_scale + biasv.z;
+        o4[3] = (acc[j][3] + acl[j][3] * (1.f / 2048.f)) * out_scale + biasv.w;
+        const int i = x0 + pcc;
+        if (a.cvy) {
+            if (g == 0) {
+                const int b = a.RPW >= 0 ? (gy >> a.RPW) : gy / H;
+                const int jj = gy - b * H, nVy = (H + 1) * W, nVx = H * (W + 1);
+                float* vy = a.cvy + (size_t)b * nVy + (size_t)jj * W;
+                float* vx = a.cvx + (size_t)b * nVx + (size_t)jj * (W + 1);
+                const float v0 = vy[i] + a.cs0 * o4[0], v1 = vx[i] + a.cs1 * o4[1];
+                vy[i] = v0;
+                vx[i] = v1;
+                if (a.gty) {
+                    const float* gt = a.gty + (size_t)b * nVy + (size_t)jj * W;
+                    const float d = (gt[i] - v0) / a.ls0;
+                    lsum += 0.5f * d * d;
+                    if (jj == H - 1) { const float d2 = (gt[W + i] - vy[W + i]) / a.ls0; lsum += 0.5f * d2 * d2; }     // v_y row H
+                }
+                if (a.gtx) {
+                    const float* gt = a.gtx + (size_t)b * nVx + (size_t)jj * (W + 1);
+                    const float d = (gt[i] - v1) / a.ls1;
+                    lsum += 0.5f * d * d;
+                    if (i == W - 1) { const float d2 = (gt[W] - vx[W]) / a.ls1; lsum += 0.5f * d2 * d2; }             // v_x column W
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 4 * g + r;
+                if (co < a.CO) {
+                    const size_t o = ((size_t)gy * W + i) * a.CO + co;
+                    float v = o4[r];
+                    if (a.res) v += a.res[o];
+                    if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
+                    else if (a.epi == SOL_EPI_DLRELU) v *= (a.act[o] > 0.f ? 1.f : a.slope);
+                    vmax = fmaxf(vmax, fabsf(v));
+                    a.y[o] = v;
+                }
+            }
+        }
+    };
+
     // The weight sets of phases 2, 3, 4 are ALL requested during phase 0 (three named register sets, one request group at the phase's
     // start and one each behind steps 3 and DX_NS - 2: spread out, a burst of requests stalls every wave at issue) so that the
     // HBM-cold epilogue operands can follow early: vmcnt retires in order, and a weight set requested AFTER them could not be waited
@@ -257,12 +328,14 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
             // operands of the next step: A(s + 1) of this phase, or A(0) of the next one; behind the barrier also the next weight set
             const int aslot = (dx * DX_NS + s) & 1;             // (7 steps per phase: the slot parity runs on across phases)
             const bool late_a = dx == 0 && s == 2;              // row 3 is only staged behind this step (first phase)
-            if (s + 1 < DX_NS && !late_a) read_a(aslot ^ 1, dx, s + 1);
-            else if (dx < 4) read_a(aslot ^ 1, dx + 1, 0);
-            if (dx < 4) {                                       // the next weight set, over the steps behind the barrier
+            if (mma) {
+                if (s + 1 < DX_NS && !late_a) read_a(aslot ^ 1, dx, s + 1);
+                else if (dx < 4) read_a(aslot ^ 1, dx + 1, 0);
+                if (dx < 4) {                                   // the next weight set, over the steps behind the barrier
 #pragma unroll
-                for (int k = 0; k < 5; ++k)
-                    if (s == (DX_NS == 7 ? 4 + k / 2 : (DX_NS == 6 ? 3 + k / 2 : 3 + k / 3))) read_b(set ^ 1, dx + 1, k);
+                    for (int k = 0; k < 5; ++k)
+                        if (s == (DX_NS == 7 ? 4 + k / 2 : (DX_NS == 6 ? 3 + k / 2 : 3 + k / 3))) read_b(set ^ 1, dx + 1, k);
+                }
             }
             if (dx == 0 && s == 3) load_w(3, wC0, wC1, wC2);
             if (dx == 0 && s == DX_NS - 2) load_w(4, wD0, wD1, wD2);
@@ -272,7 +345,7 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
             // (+0.8 us in that phase).  UNCONDITIONAL requests -- a launch without a residual / activation reference reads the same
             // positions of x and drops the values: requests inside `if (a.res)` blocks make the compiler's next vmcnt wait a wait
             // for everything in flight.  They are HBM-cold in the training pipeline (written hundreds of launches ago): ~3 us.
-            if ((dx == 1 || dx == 2) && s >= 3 && s - 3 < R) {
+            if (COT == 2 && (dx == 1 || dx == 2) && s >= 3 && s - 3 < R) {
                 const int j = s - 3;
                 // (scalar clamp) rows beyond the tensor -- the last workgroup's tail and the padding workgroups that own no rows at
                 // all (grid rounded up to a multiple of 8) -- read the tensor's last row: any valid position
@@ -286,7 +359,9 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
             unsigned need = 0u;
 #pragma unroll
             for (int j = jlo; j <= jhi; ++j) need |= 1u << (j * 8 + s);
-            if ((vmask & need) == need) {
+            if (!mma) {
+                // (COT == 1: a staging-only wave)
+            } else if ((vmask & need) == need) {
                 // the common case (every pair of this step valid): one straight block, the three rows' chains interleaved
 #pragma unroll
                 for (int j = jlo; j <= jhi; ++j)
@@ -317,7 +392,7 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
                 else if (dx == 2) store_w(1, wC0, wC1, wC2);
                 else store_w(0, wD0, wD1, wD2);
                 DX_BARRIER();
-                if (late_a) read_a(aslot ^ 1, dx, s + 1);
+                if (late_a && mma) read_a(aslot ^ 1, dx, s + 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -329,8 +404,17 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
     phase(3);
     phase(4);
 
+    if (COT == 2) {
 #pragma unroll
-    for (int j = 0; j < R; ++j) epilogue_row(j);
+        for (int j = 0; j < R; ++j) epilogue_row(j);
+    } else {
+        if (mma) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) epilogue_thin(j);
+        }
+        // workgroup uniform: wave sums -> LDS slots -> the last wave's fixed-order sum -> the launch's fixed-order fold (bit reproducible)
+        if (a.cvy && a.closs) loss_publish_last(lsum, a.closs, a.closs_part, amax_lds + 2);
+    }
     DX_STAMP(9);
     if (a.ymax) amax_publish_last(vmax, a.ymax, amax_lds);
     DX_STAMP(10);
@@ -351,8 +435,18 @@ extern "C" int sol_conv_dx_prof_set(long long* buf, unsigned cap) {
 }
 #endif
 
-bool sol_conv_dx_usable(const ConvArgs& a, int NT) {
-    return sol_opt().conv_dx && NT == 2 && a.CO == 32 && a.xmax && a.wsh && !a.cvy && a.W % 64 == 0;
+// three rows per workgroup where that fills the chip; one row where the launch is small (< 128 three-row workgroups)
+static int dx_rows_per_wg(int nrows, int tiles_x) { return ((nrows + 2) / 3) * tiles_x >= 128 ? 3 : 1; }
+
+bool sol_conv_dx_usable(const ConvArgs& a, int NT, int ntiles) {
+    if (!sol_opt().conv_dx || !a.xmax || !a.wsh || a.W % 64 != 0) return false;
+    if (NT == 2) return a.CO == 32 && !a.cvy;
+    // Thin layers (<= 16 output channels; option bit 1, bit 2 = also in big launches): half the waves of the COT = 1 form only stage, and
+    // where the launch fills the chip with three-row workgroups k_conv5x5_sb<1, 2> (twelve waves, a row each) is the faster kernel
+    // (SOL-32 step at 128x64, B = 6: 13.26 ms against 13.43); in the small launches (one row per workgroup: the 64x32 recipe, roll-outs)
+    // the dx form wins (8.94 against 9.04 ms per recipe step; tools/conv_thin_ab.py).
+    if (NT != 1 || a.CO > 16 || !(sol_opt().conv_dx & 2)) return false;
+    return (sol_opt().conv_dx & 4) != 0 || dx_rows_per_wg(ntiles / a.tiles_x, a.tiles_x) == 1;
 }
 
 int sol_conv_dx_launch(hipStream_t s, const ConvArgs& a_in, int ntiles) {
@@ -360,14 +454,17 @@ int sol_conv_dx_launch(hipStream_t s, const ConvArgs& a_in, int ntiles) {
     a.RPW = -1;                                           // (field unused by this kernel otherwise) log2 H, or -1
     for (int k = 0; k < 20; ++k) if ((1 << k) == a.H) a.RPW = k;
     static std::atomic<unsigned long long> optin{0};
-    if (int e = sol_lds_optin(optin, {SOL_K(k_conv5x5_dx<1>), SOL_K(k_conv5x5_dx<3>)}, "k_conv5x5_dx")) return e;
+    if (int e = sol_lds_optin(optin, {SOL_K((k_conv5x5_dx<1, 2>)), SOL_K((k_conv5x5_dx<3, 2>)), SOL_K((k_conv5x5_dx<1, 1>)), SOL_K((k_conv5x5_dx<3, 1>))}, "k_conv5x5_dx")) return e;
+    const bool thin = a.CO <= 16;
     const int nrows = ntiles / a.tiles_x;                 // global image rows B*H
-    // three rows per workgroup where that fills the chip; one row where the launch is small (< 128 three-row workgroups)
-    const int R = ((nrows + 2) / 3) * a.tiles_x >= 128 ? 3 : 1;
+    const int R = dx_rows_per_wg(nrows, a.tiles_x);
     int grid = ((nrows + R - 1) / R) * a.tiles_x;
     if (grid > 64) grid = (grid + 7) / 8 * 8;             // XCD-aware tile order needs a multiple of 8 (xcd_tile); padding tiles own no rows
-    if (R == 3) SOL_LAUNCH(k_conv5x5_dx<3>, dim3(grid), dim3(512), dx_lds(3), s, a.x, a.wsh, a.xmax, nrows, a.H, a.W, a.tiles_x, a.RPW, a);
-    else SOL_LAUNCH(k_conv5x5_dx<1>, dim3(grid), dim3(512), dx_lds(1), s, a.x, a.wsh, a.xmax, nrows, a.H, a.W, a.tiles_x, a.RPW, a);
+    if (thin) {
+        if (R == 3) SOL_LAUNCH((k_conv5x5_dx<3, 1>), dim3(grid), dim3(512), dx_lds(3, 1), s, a.x, a.wsh, a.xmax, nrows, a.H, a.W, a.tiles_x, a.RPW, a);
+        else SOL_LAUNCH((k_conv5x5_dx<1, 1>), dim3(grid), dim3(512), dx_lds(1, 1), s, a.x, a.wsh, a.xmax, nrows, a.H, a.W, a.tiles_x, a.RPW, a);
+    } else if (R == 3) SOL_LAUNCH((k_conv5x5_dx<3, 2>), dim3(grid), dim3(512), dx_lds(3, 2), s, a.x, a.wsh, a.xmax, nrows, a.H, a.W, a.tiles_x, a.RPW, a);
+    else SOL_LAUNCH((k_conv5x5_dx<1, 2>), dim3(grid), dim3(512), dx_lds(1, 2), s, a.x, a.wsh, a.xmax, nrows, a.H, a.W, a.tiles_x, a.RPW, a);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }

@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     constexpr int SLOT = NPL * PLANE;             // bytes per halo row
     constexpr int WPL = OP * 64;                  // bytes per (dx, plane) weight block
     constexpr int WBUF = 5 * NPL * WPL;           // bytes per tap-row weight phase
-    constexpr int AMAX_LDS = 4 * SLOT + 2 * WBUF;  // two words behind the ring and the weight buffers: workgroup max|y|, wave counter
+    constexpr int AMAX_LDS = 4 * SLOT + 2 * WBUF;  // behind the ring and the weight buffers: workgroup max|y|, wave counter; loss_publish_last's 4 + 12 words
     extern __shared__ __align__(16) unsigned char smem_sb[];
     if (SOL_CONV_TRUNC == 0) return;
 #ifdef SOL_CONV_PROF
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
     if (cv_prof) cv_prof += ((size_t)(g_conv_prof_ctl[0] % g_conv_prof_ctl[1]) * gridDim.x + blockIdx.x) * 16;
 #endif
     SOL_CSTAMP(0);
-    if (threadIdx.x == 0) *reinterpret_cast<uint2*>(smem_sb + AMAX_LDS) = make_uint2(0u, 0u);      // see amax_publish_last
+    if (threadIdx.x == 0) *reinterpret_cast<uint4*>(smem_sb + AMAX_LDS) = make_uint4(0u, 0u, 0u, 0u);      // see amax_publish_last, loss_publish_last
     // the wave index is read into an SGPR: everything derived from it (tile row, image bounds, "does this wave have taps in
     // this tap row") is then provably wave uniform -- scalar branches instead of exec-masked regions that the compiler
     // executes back to back with conservative waits at the joins
@@ -454,15 +454,8 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
                 if (gt && li == 1 && i == W - 1) { const float d = (gt[W] - vf[W]) / ls; lsum += 0.5f * d * d; }            // v_x column W
             }
         }
-        if (a.closs) {                                // workgroup uniform: wave sums -> LDS -> the last wave adds to the step's loss
-            lsum = wave_sum(lsum);
-            float* acc2 = reinterpret_cast<float*>(smem_sb + AMAX_LDS);
-            if (lane == 0) {
-                atomicAdd(&acc2[0], lsum);
-                const unsigned ticket = atomicAdd(reinterpret_cast<unsigned*>(acc2) + 1, 1u);
-                if (ticket == (blockDim.x >> 6) - 1) atomicAdd(a.closs, atomicAdd(&acc2[0], 0.f));
-            }
-        }
+        // workgroup uniform: wave sums -> LDS slots -> the last wave's fixed-order sum -> the launch's fixed-order fold (bit reproducible)
+        if (a.closs) loss_publish_last(lsum, a.closs, a.closs_part, reinterpret_cast<unsigned*>(smem_sb + AMAX_LDS) + 2);
     } else if (tvalid) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -562,7 +555,7 @@ __global__ void __launch_bounds__(256) k_pack_jobs(PackJobs jobs) {
 }
 
 // dynamic part: ring + two weight buffers (three planes: the bf16 kinds) + absmax words (the kernels add 24 x OP/16 KB static)
-constexpr size_t sb_lds(int OP) { return (size_t)4 * 3 * 68 * 64 + 2 * (size_t)5 * 3 * OP * 64 + 16; }
+constexpr size_t sb_lds(int OP) { return (size_t)4 * 3 * 68 * 64 + 2 * (size_t)5 * 3 * OP * 64 + 16 + 64; }
 
 int init_sb_kernels() {
     // static LDS (the conv kernels' epilogue-prefetch regions) counts against the same 160 KB
@@ -618,7 +611,7 @@ int sol_conv_sh_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int 
 // SOL_CONV_SPLIT=3 runs the three leading products only (~2^-17 relative error per product): an
 // experiment knob, NOT the default and not what bench.py or the parity tests use.
 int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles) {
-    if (sol_conv_dx_usable(a, NT)) return sol_conv_dx_launch(s, a, ntiles);
+    if (sol_conv_dx_usable(a, NT, ntiles)) return sol_conv_dx_launch(s, a, ntiles);
     if (int e = init_sb_kernels()) return e;
     const int nprod = sol_opt().conv_split3 ? 3 : 6;
     const int nrows = ntiles / a.tiles_x;             // global image rows B*H

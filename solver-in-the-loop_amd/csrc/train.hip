@@ -35,7 +35,7 @@ SolOptions& sol_opt() {
         SolOptions d{};
         d.conv_precision = 0; d.conv_split3 = 0; d.conv_r3 = 1; d.conv_thin = 1; d.conv_bww32 = 1;
         d.correct_fuse = 1; d.bww_fuse = 1; d.bww_chunk = 0; d.bww_side = 1; d.streams = 1;
-        d.density_mode = 0; d.cpt = 0; d.dbg_skip = 0; d.step_prof = 0; d.cnn_persistent = 0; d.graph_stream = 0; d.k3d_tile = 0; d.k3d_fused_tf = 1; d.k3d_conv_fused = 1; d.k3d_conv_rows = 8; d.conv_dx = 1; d.k3d_mfma_tf = 1;
+        d.density_mode = 0; d.cpt = 0; d.dbg_skip = 0; d.step_prof = 0; d.cnn_persistent = 0; d.graph_stream = 0; d.k3d_tile = 0; d.k3d_fused_tf = 1; d.k3d_conv_fused = 1; d.k3d_conv_rows = 8; d.conv_dx = 3; d.k3d_mfma_tf = 1;
         return d;
     }();
     return o;
@@ -51,7 +51,7 @@ const OptName OPT_NAMES[] = {
     {"density_mode", &SolOptions::density_mode, 0, 2}, {"cpt", &SolOptions::cpt, 0, 16}, {"dbg_skip", &SolOptions::dbg_skip, 0, 1 << 30},
     {"step_prof", &SolOptions::step_prof, 0, 1}, {"cnn_persistent", &SolOptions::cnn_persistent, 0, 1},
     {"graph_stream", &SolOptions::graph_stream, 0, 1}, {"k3d_tile", &SolOptions::k3d_tile, 0, 1}, {"k3d_fused_tf", &SolOptions::k3d_fused_tf, 0, 1}, {"k3d_conv_fused", &SolOptions::k3d_conv_fused, 0, 1}, {"k3d_conv_rows", &SolOptions::k3d_conv_rows, 3, 8},
-    {"conv_dx", &SolOptions::conv_dx, 0, 1}, {"k3d_mfma_tf", &SolOptions::k3d_mfma_tf, 0, 1},
+    {"conv_dx", &SolOptions::conv_dx, 0, 7}, {"k3d_mfma_tf", &SolOptions::k3d_mfma_tf, 0, 1},
 };
 }  // namespace
 
@@ -143,7 +143,7 @@ inline int64_t layer_koff(int l) {
 // ---- velocity += CNN correction (to_staggered pad, karman_train.py:88-90,413-426) + l2 loss ----
 __global__ void k_correct_loss(float* __restrict__ vy, float* __restrict__ vx, const float* __restrict__ O,
                                const float* __restrict__ gt_vy, const float* __restrict__ gt_vx,
-                               float s0, float s1, float l0, float l1, float* __restrict__ loss, int B, int Y, int X, int tr) {
+                               float s0, float s1, float l0, float l1, float* __restrict__ loss, float* __restrict__ loss_part, int B, int Y, int X, int tr) {
     __shared__ float red[64];
     const int N = Y * X, nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
     auto cell = [&](int j, int i) { return tr ? i * Y + j : j * X + i; };      // O is [B][X][Y][2] in transposed CNN mode
@@ -166,9 +166,9 @@ __global__ void k_correct_loss(float* __restrict__ vy, float* __restrict__ vx, c
             if (gt_vx) { const float d = (gt_vx[e2] - v) / l1; l += 0.5f * d * d; }
         }
     }
-    if (loss) {
+    if (loss) {                                    // fixed-order fold over the launch's workgroups (bit reproducible; loss_fold_wg)
         const float s = block_sum(l, red, 0);
-        if (threadIdx.x == 0) atomicAdd(loss, s);
+        if (threadIdx.x < 64) loss_fold_wg(s, loss, loss_part);
     }
 }
 
@@ -344,6 +344,7 @@ struct Ws {
     float *part[NL];
     size_t part_floats[NL];
     float *adam_scale;
+    float *loss_part;              // [SOL_LOSS_PART_FLOATS] scratch of the per-step loss fold
     size_t total_floats;
 };
 
@@ -389,6 +390,7 @@ size_t carve_ws(const sol_train_cfg* c, float* base, Ws& w, bool training) {
         w.part[l] = take(w.part_floats[l]);
     }
     w.adam_scale = take(64);
+    w.loss_part = take(SOL_LOSS_PART_FLOATS);          // per-workgroup partials + ticket of the step loss (loss_fold_wg)
     w.total_floats = off;
     return off * sizeof(float);
 }
@@ -417,7 +419,7 @@ inline float out_s1(const sol_train_cfg* c) { return c->out_std_v1 > 0.f ? c->ou
 // amax: [11][SOL_AMAX_SLOTS] absmax slots of act[0..10] (zeroed by the caller): every producer publishes max|y| and every
 // 32-channel consumer derives its fp16 operand scale from it (sol_conv5x5_scaled).
 // corr != nullptr: the last layer applies its output to the velocity and accumulates the loss (sol_conv5x5_correct) instead of storing O
-struct Correct { float *vy, *vx; const float *gt_vy, *gt_vx; float* loss; };
+struct Correct { float *vy, *vx; const float *gt_vy, *gt_vx; float *loss, *loss_part; };
 int net_forward(const sol_train_cfg* c, void* s, const Ws& w, const float* feat, float* const* act, float* O, uint32_t* amax, const Correct* corr = nullptr,
                 uint32_t* chain_flags = nullptr) {
     const bool tr = cnn_transposed(c->karman.Y, c->karman.X);      // then `feat` and every CNN tensor are [B][X][Y][C]
@@ -443,7 +445,7 @@ int net_forward(const sol_train_cfg* c, void* s, const Ws& w, const float* feat,
     }
     if (corr)
         return sol_conv5x5_correct(s, act[10], w.wf[11], w.bias[11], B, Y, X, am(10), corr->vy, corr->vx, corr->gt_vy, corr->gt_vx,
-                                   out_s0(c), out_s1(c), c->std_v0, c->std_v1, corr->loss);
+                                   out_s0(c), out_s1(c), c->std_v0, c->std_v1, corr->loss, corr->loss_part);
     return sol_conv5x5_scaled(s, act[10], w.wf[11], w.bias[11], nullptr, nullptr, O, B, Y, X, 32, 2, SOL_EPI_NONE, sl, am(10), nullptr);
 }
 
@@ -589,14 +591,14 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         }
         float* act[11];
         for (int k = 0; k < 11; ++k) act[k] = w.acts + ((size_t)i * 11 + k) * w.cells * 32;
-        if (sol_conv_correct_fusable(X)) {            // correction + loss ride in the epilogue of the last CNN layer
-            const Correct corr{vycur, vxcur, gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx, io.loss_steps + i};
+        if (sol_conv_correct_fusable(X, B * Y)) {            // correction + loss ride in the epilogue of the last CNN layer
+            const Correct corr{vycur, vxcur, gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx, io.loss_steps + i, w.loss_part};
             if (int e = net_forward(c, stream, wn, feat_cnn, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS, &corr, w.chain_flags + (size_t)(2 * i) * w.chain_words)) return e;
         } else {
             if (int e = net_forward(c, stream, wn, feat_cnn, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS, nullptr, w.chain_flags + (size_t)(2 * i) * w.chain_words)) return e;
-            SOL_LAUNCH(k_correct_loss, dim3(egrid), dim3(256), 0, hs, vycur, vxcur, w.O,
+            SOL_LAUNCH(k_correct_loss, dim3(std::min(egrid, SOL_LOSS_PART_MAX)), dim3(256), 0, hs, vycur, vxcur, w.O,
                                gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx,
-                               out_s0(c), out_s1(c), c->std_v0, c->std_v1, io.loss_steps + i, B, Y, X, tr ? 1 : 0);
+                               out_s0(c), out_s1(c), c->std_v0, c->std_v1, io.loss_steps + i, w.loss_part, B, Y, X, tr ? 1 : 0);
             SOL_LAUNCH_CHECK();
         }
     }
@@ -745,6 +747,7 @@ int train_fwd_bwd_impl(const sol_train_cfg* cfg, hipStream_t hs, const TrainIO& 
             z.zero(io.iters_bwd, B * sizeof(int32_t));                                 // step 0 needs no adjoint
         }
         z.zero(w[k].dO4, w[k].cells * 4 * sizeof(float));
+        z.zero(w[k].loss_part + SOL_LOSS_PART_MAX, 64 * sizeof(float));               // the loss fold's ticket word
         z.zero(w[k].amax_act, 2 * w[k].amax_words * sizeof(uint32_t));                 // activation + gradient absmax slots
         const bool chain = sol_cnn_chain_usable(sub.karman.B, cnn_transposed(Y, X) ? X : Y, cnn_transposed(Y, X) ? Y : X);
         // hand-off regions of the persistent CNN launches: zero ONCE (tag 0 = "never written"); afterwards the tags do the work
@@ -928,13 +931,13 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
             }
         }
         uint32_t* amax = w.amax_act + (size_t)(i % ROLLOUT_AMAX_SETS) * 11 * SOL_AMAX_SLOTS;
-        if (sol_conv_correct_fusable(X)) {
-            const Correct corr{tvy, tvx, nullptr, nullptr, nullptr};
+        if (sol_conv_correct_fusable(X, B * Y)) {
+            const Correct corr{tvy, tvx, nullptr, nullptr, nullptr, nullptr};
             if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, amax, &corr, w.chain_flags + (size_t)(i % ROLLOUT_AMAX_SETS) * w.chain_words)) return e;
         } else {
             if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, amax, nullptr, w.chain_flags + (size_t)(i % ROLLOUT_AMAX_SETS) * w.chain_words)) return e;
             SOL_LAUNCH(k_correct_loss, dim3(egrid), dim3(256), 0, hs, tvy, tvx, w.O,
-                               (const float*)nullptr, (const float*)nullptr, out_s0(cfg), out_s1(cfg), cfg->std_v0, cfg->std_v1, (float*)nullptr, B, Y, X, tr ? 1 : 0);
+                               (const float*)nullptr, (const float*)nullptr, out_s0(cfg), out_s1(cfg), cfg->std_v0, cfg->std_v1, (float*)nullptr, (float*)nullptr, B, Y, X, tr ? 1 : 0);
             SOL_LAUNCH_CHECK();
         }
     }

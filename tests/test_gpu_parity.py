@@ -415,6 +415,44 @@ def test_conv5x5_dx_kernel_every_epilogue_against_float64_and_the_row_per_wave_k
         _lib.set_option("conv_dx", saved)
 
 
+@pytest.mark.parametrize("B,H,W", [(6, 128, 64), (2, 5, 64), (1, 7, 128), (1, 1, 64)])
+@pytest.mark.parametrize("cout", [2, 3, 16])
+def test_conv5x5_dx_thin_layers_against_float64_and_the_row_per_wave_kernel(B, H, W, cout):
+    """The thin-layer form of the dx-major kernel (k_conv5x5_dx<R, 1>: <= 16 output channels, waves 4..7 stage only; option conv_dx
+    bit 1 = in one-row-per-workgroup launches (default), bit 2 = everywhere) against a float64 convolution and k_conv5x5_sb<1, 2>
+    for the strided-store epilogues (the correction-mode epilogue is covered by the trainer and roll-out tests at B = 1)."""
+    from sol_amd import _lib
+    gen = torch.Generator().manual_seed(B * 100 + H + cout)
+    x = torch.randn(B, H, W, 32, generator=gen, dtype=torch.float32).to(DEV)
+    w = (torch.randn(5, 5, 32, cout, generator=gen, dtype=torch.float32) * 0.05).to(DEV)
+    b = torch.randn(cout, generator=gen, dtype=torch.float32).to(DEV)
+    res = torch.randn(B, H, W, cout, generator=gen, dtype=torch.float32).to(DEV)
+    act = torch.randn(B, H, W, cout, generator=gen, dtype=torch.float32).to(DEV)
+    packed = ops._pack(w, 32, cout, ops.CONV_FWD)
+    xm = ops.absmax_slots(x)
+    conv = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), None, padding=2).permute(0, 2, 3, 1)
+    saved = _lib.get_option("conv_dx")
+    try:
+        for name, (bb, rr, aa, epi) in {"bias+lrelu": (b, None, None, ops.EPI_LRELU), "res+dlrelu": (None, res, act, ops.EPI_DLRELU),
+                                        "plain": (None, None, None, ops.EPI_NONE)}.items():
+            ref = conv + (bb.double() if bb is not None else 0.0) + (rr.double() if rr is not None else 0.0)
+            if epi == ops.EPI_LRELU:
+                ref = torch.where(ref > 0, ref, 0.3 * ref)
+            elif epi == ops.EPI_DLRELU:
+                ref = ref * torch.where(aa.double() > 0, 1.0, 0.3)
+            ys = {}
+            for dx in (7, 1):
+                _lib.set_option("conv_dx", dx)
+                ym = torch.zeros(ops.AMAX_SLOTS, dtype=torch.int32, device=DEV)
+                with _lib.profile() as p:
+                    ys[dx] = ops.conv5x5_scaled_raw(x, packed, bb, rr, aa, cout, epi, 0.3, xm, ym)
+                assert float(ym.max().view(torch.float32).item()) == float(ys[dx].abs().max()), (name, dx)
+                assert any(("k_conv5x5_dx" in k) == (dx == 7) for k in p.kernels), (dx, p.kernels)
+            assert rel(ys[7], ref) < 6e-7 and rel(ys[7], ref) < 1.5 * rel(ys[1], ref) + 1e-8, (name, rel(ys[7], ref), rel(ys[1], ref))
+    finally:
+        _lib.set_option("conv_dx", saved)
+
+
 def test_mars_moon_network_full_size_against_torch_float64_autograd():
     """model_mars_moon at the bench shape (B = 6, 128 x 64): forward, input gradient and all 24 parameter gradients of the HIP
     convolution path (per-op autograd surface: the same forward / backward-data / weight-gradient kernels the fused trainer
