@@ -12,6 +12,7 @@
 
 int sol_set_error(int code, const char* fmt, ...);
 int sol_init_karman_kernels();
+int sol_karman_feat_transposed(int on);      // internal: feature I/O of the step kernels in the CNN's transposed cell order (karman_step.hip)
 int sol_init_conv_kernels();
 int sol_density_chain(const sol_karman_cfg* c, void* stream, int ms, const float* d0, const float* svy, const float* svx,
                       long st_vy, long st_vx, const float* inflow, float* d_steps, long st_d, float* d_final);
@@ -163,7 +164,8 @@ struct SolOptions {
     int conv_dx;          // bit 0: the 32 -> 32 fp16 three-product convolutions run the dx-major kernel (conv5x5_dx.hip: a wave owns a pixel segment of all
                           //    three output rows, 0.53 LDS operand reads per MFMA); 0: k_conv5x5_sb (one output row per wave, 1.0 reads per MFMA).
                           //    bit 1: also the thin 32 -> (<= 16) layers where a workgroup owns one row (small launches); bit 2: those layers in every
-                          //    launch (measured slower where the launch fills the chip).  Default 3.
+                          //    launch (measured slower where the launch fills the chip); bit 3: the 32 -> 32 layers of one-row-per-workgroup launches as two
+                          //    half-channel workgroups per tile (k_conv5x5_dx<1, 1, true>).  Default 11.
     int k3d_tile;         // 1: karman-3d advection from LDS tiles holding the full z column + halo; 0 (default, measured faster at B <= 2): wave-per-column gathers from global memory
 };
 SolOptions& sol_opt();

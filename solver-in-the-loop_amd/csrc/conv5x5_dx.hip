@@ -34,7 +34,8 @@ constexpr int DX_SLOT = 2 * DX_PLANE;              // hi + lo plane
 // not matter where the loop is a fraction of the launch.
 constexpr int dx_wpl(int COT) { return COT * 16 * 64; }        // bytes per (tap, plane) weight block: 16 COT co x 32 ci fp16
 constexpr int dx_wph(int COT) { return 5 * 2 * dx_wpl(COT); }  // bytes per dx phase: five dy x two planes
-constexpr int dx_lds(int R, int COT) { return (R + 4) * DX_SLOT + 2 * dx_wph(COT) + 16 + 64; }    // + absmax words, loss_publish_last's 4 + 12
+constexpr int dx_wbufs(int R) { return R == 1 ? 5 : 2; }       // one row per workgroup: all five weight sets stay resident (see RW in the kernel)
+constexpr int dx_lds(int R, int COT) { return (R + 4) * DX_SLOT + dx_wbufs(R) * dx_wph(COT) + 16 + 64; }    // + absmax words, loss_publish_last's 4 + 12
 
 #define DX_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -52,7 +53,10 @@ __device__ unsigned g_dx_prof_ctl[2] = {0u, 1u};
 // COT: 16-channel output tiles.  2: the 32 -> 32 layers (waves = 4 pixel segments x 2 tiles).  1: the thin layers (<= 16 output channels:
 // the 32 -> 2 output layer in correction mode and its data gradient's counterpart) -- waves 0..3 own the four pixel segments and all the
 // MFMAs, waves 4..7 are the "late" staging role only.
-template <int R, int COT>
+// SPLIT (COT = 1 only): a 32 -> 32 layer as TWO workgroups per tile, each with one 16-channel half of the output -- for the small launches
+// (one row per workgroup, 96..128 tiles on 256 CUs): a workgroup then stages half the weights (50 instead of 100 KB; the weights are
+// 70 % of what a one-row workgroup pulls through its CU's 64 B/clock vector-memory path) and the launch uses twice the CUs.
+template <int R, int COT, bool SPLIT = false>
 __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ arg_x, const void* __restrict__ arg_wsh, const unsigned* __restrict__ arg_xmax,
                                                       int nrows, int arg_H, int arg_W, int arg_tiles_x, int arg_hshift, ConvArgs a) {
     // What the prologue needs before its first request -- the three operand pointers and the tile geometry -- are LEADING scalar
@@ -67,14 +71,28 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
     constexpr int DX_NS = R + 4;                                // input rows (LDS slots) of R output rows
     constexpr int DX_WPL = dx_wpl(COT), DX_WPH = dx_wph(COT);
     constexpr int NBLK = COT * 128;                             // uint4 per tap of the packed weights: 2 planes x 16 COT co x 4
+    constexpr int TAPQ = (COT == 2 || SPLIT) ? 256 : 128;       // uint4 per tap of the packed SOURCE (32 or 16 padded output channels)
     static_assert(COT == 1 || COT == 2, "one or two 16-channel output tiles");
+    static_assert(!SPLIT || COT == 1, "SPLIT: one output tile per workgroup");
     static_assert(R >= 1 && R <= 3, "one to three output rows per workgroup");
     extern __shared__ __align__(16) unsigned char smem_dx[];
     unsigned char* const ring = smem_dx;                        // [7 slots][2 planes][68 px][64 B]
-    unsigned char* const Wt = smem_dx + DX_NS * DX_SLOT;        // [2 buffers][5 dy][2 planes][32 co][64 B]
-    unsigned* const amax_lds = reinterpret_cast<unsigned*>(smem_dx + DX_NS * DX_SLOT + 2 * DX_WPH);
+    unsigned char* const Wt = smem_dx + DX_NS * DX_SLOT;        // [2 (RW: 5) buffers][5 dy][2 planes][16 COT co][64 B]
+    // RW ("resident weights", one-row workgroups): the five-slot ring leaves room for ALL five weight sets (43.5 + 100 KB), so the sets of
+    // phases 2..4 get their own buffers, are written once (phase 1) and the phases 2, 3 run without a barrier and read their next set
+    // a whole phase ahead.  In those launches (96..128 workgroups: the 64x32 recipe, roll-outs at B = 1) a phase is five steps of three
+    // MFMAs and the barrier + store + exposed operand read of a double-buffered phase cost as much as its MFMAs (phase timeline,
+    // tools/conv_dx_probe.py 3 32 64: phases 1..3 0.6-0.7 us each, phase 4 -- no barrier -- 0.26 us).
+    constexpr bool RW = dx_wbufs(R) == 5;
+    unsigned* const amax_lds = reinterpret_cast<unsigned*>(smem_dx + DX_NS * DX_SLOT + dx_wbufs(R) * DX_WPH);
     const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int seg = wid & 3, cot = wid >> 2;                    // 16-pixel segment, 16-channel output tile (wave uniform)
+    int bid = blockIdx.x, ngrid = gridDim.x, half = 0;          // SPLIT: workgroups [0, n) own output channels 0..15 of tile bid, [n, 2n) channels 16..31
+    if (SPLIT) { ngrid >>= 1; half = bid >= ngrid ? 1 : 0; bid -= half * ngrid; }
+    const int seg = wid & 3;                                    // 16-pixel segment (wave uniform)
+    const int wt = COT == 2 ? wid >> 2 : 0;                     // the wave's 16-channel tile inside the workgroup's staged weights
+    const int cot = SPLIT ? half : wid >> 2;                    // ... and among the layer's output channels
+    // position r of a staged tap block [2 planes][16 COT co][4] inside the source's tap block [2 planes][32 or 16 co][4]
+    auto wpos = [&](int r) { return SPLIT ? ((r >> 6) * 128 + half * 64 + (r & 63)) : r; };
     const int g = lane >> 4, li = lane & 15;
     const int H = a.H, W = a.W;
 #ifdef SOL_CONV_PROF
@@ -95,13 +113,13 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
     auto wsrc_of = [&](int k) {
         int i = t + 256 * k;
         if (i >= 5 * NBLK) i = 0;
-        return gw + (size_t)((i / NBLK) * 5 + (late ? 1 : 0)) * NBLK + (i % NBLK);
+        return gw + (size_t)((i / NBLK) * 5 + (late ? 1 : 0)) * TAPQ + wpos(i % NBLK);
     };
     const uint4 wq0 = *wsrc_of(0), wq1 = *wsrc_of(1), wq2 = *wsrc_of(2), wq3 = *wsrc_of(COT == 2 ? 3 : 0), wq4 = *wsrc_of(COT == 2 ? 4 : 0);
     const float winv = reinterpret_cast<const float*>(a.wsh)[1];
     // Scalar preamble, kept short: it runs before the first request can go out (its first form -- four integer divisions on the
     // VALU with read-first-lane round trips and a compare chain per (s, j) pair, 330 instructions -- cost 1.2 us of every launch).
-    const int bx = xcd_tile(blockIdx.x, gridDim.x);
+    const int bx = xcd_tile(bid, ngrid);
     int tx = 0, ty = bx;
     if (a.tiles_x != 1) { tx = bx % a.tiles_x; ty = bx / a.tiles_x; }      // (W == 64: one column block, no division)
     const int G0 = ty * R, x0 = tx * 64;
@@ -141,9 +159,9 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
     // weight set of phase dx as three 16-byte pieces of every thread (later phases): 1280 uint4 = five (dy) blocks of 256
     auto load_w = [&](int dx, uint4& p0, uint4& p1, uint4& p2) {
         const int i0 = tid, i1 = tid + 512 < 5 * NBLK ? tid + 512 : 0, i2 = (tid & 255) + 1024;
-        p0 = gw[(size_t)((i0 / NBLK) * 5 + dx) * NBLK + (i0 % NBLK)];
-        p1 = gw[(size_t)((i1 / NBLK) * 5 + dx) * NBLK + (i1 % NBLK)];
-        if (COT == 2) p2 = gw[(size_t)((i2 / NBLK) * 5 + dx) * NBLK + (i2 % NBLK)];
+        p0 = gw[(size_t)((i0 / NBLK) * 5 + dx) * TAPQ + wpos(i0 % NBLK)];
+        p1 = gw[(size_t)((i1 / NBLK) * 5 + dx) * TAPQ + wpos(i1 % NBLK)];
+        if (COT == 2) p2 = gw[(size_t)((i2 / NBLK) * 5 + dx) * TAPQ + wpos(i2 % NBLK)];
     };
     auto store_w = [&](int buf, const uint4& p0, const uint4& p1, const uint4& p2) {
         uint4* dst = reinterpret_cast<uint4*>(Wt + buf * DX_WPH);
@@ -160,6 +178,13 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
         hv[n] = src[(size_t)row_of(s_) * W * 8 + (n & 1) * 32 * 8];
     }
     hh = gx[((size_t)row_of(s_base + (hrow < n_rows ? hrow : n_rows - 1)) * W + (hok ? hxx : 0)) * 8 + c4];
+    uint4 wB0, wB1, wB2, wC0, wC1, wC2, wD0, wD1, wD2;          // the weight sets of phases 2, 3, 4 in flight (named: arrays end up in scratch)
+    wB0 = wB1 = wB2 = wC0 = wC1 = wC2 = wD0 = wD1 = wD2 = make_uint4(0u, 0u, 0u, 0u);
+    if (RW) {                                                    // one-row workgroups: all of it is wanted within ~1.5 us -- requested here, behind the role's own
+        load_w(2, wB0, wB1, wB2);
+        load_w(3, wC0, wC1, wC2);
+        load_w(4, wD0, wD1, wD2);
+    }
     __builtin_amdgcn_sched_barrier(0);
     DX_STAMP(1);
     float sa, sai;
@@ -190,8 +215,6 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
     };
     auto stage_late = [&]() __attribute__((always_inline)) { if (late) stage_role(); };
     if (!late) stage_role();
-    uint4 wB0, wB1, wB2, wC0, wC1, wC2, wD0, wD1, wD2;          // the weight sets of phases 2, 3, 4 in flight (named: arrays end up in scratch)
-    wB0 = wB1 = wB2 = wC0 = wC1 = wC2 = wD0 = wD1 = wD2 = make_uint4(0u, 0u, 0u, 0u);
     DX_STAMP(12);
     DX_BARRIER();
     DX_STAMP(3);
@@ -199,7 +222,7 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
     const bool mma = COT == 2 || !late;                         // wave uniform: this wave owns an output tile
     if (a.bias && mma) {                                         // off the critical path (four dword loads: a caller's bias slice need not be 16-byte aligned)
         const float* bp = a.bias + cot * 16 + 4 * g;
-        if (COT == 2) biasv = make_float4(bp[0], bp[1], bp[2], bp[3]);
+        if (COT == 2 || SPLIT) biasv = make_float4(bp[0], bp[1], bp[2], bp[3]);
         else biasv = make_float4(4 * g < a.CO ? bp[0] : 0.f, 4 * g + 1 < a.CO ? bp[1] : 0.f, 4 * g + 2 < a.CO ? bp[2] : 0.f, 4 * g + 3 < a.CO ? bp[3] : 0.f);
     }
 
@@ -212,7 +235,7 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
 #pragma unroll
     for (int j = 0; j < R; ++j) { resv[j] = make_float4(0.f, 0.f, 0.f, 0.f); actv[j] = make_float4(1.f, 1.f, 1.f, 1.f); }
     const int pcc = seg * 16 + li;                              // this lane's pixel inside the 64-pixel row
-    const int co_l = cot * 16 + li;                             // this lane's weight row (output channel) of the A operand
+    const int co_l = wt * 16 + li;                              // this lane's weight row (output channel) of the A operand
     auto out_f4 = [&](int j) { return ((size_t)(G0 + j) * W + x0 + pcc) * 8 + cot * 4 + g; };   // float4 index of (row j, this pixel, co 4g..)
     const unsigned char* const wlane = Wt + co_l * 64 + ((g ^ swzb(co_l)) << 4);
     auto a_base = [&](int dx) { const int hc = pcc + dx; return ring + hc * 64 + ((g ^ swzb(hc)) << 4); };
@@ -223,8 +246,8 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
     // written), when every wave is deep inside a run of MFMAs.
     uint4 bw[2][5][2], ao[2][2];
     auto read_b = [&](int set, int dx, int dy) __attribute__((always_inline)) {
-        bw[set][dy][0] = *reinterpret_cast<const uint4*>(wlane + (dx & 1) * DX_WPH + dy * 2 * DX_WPL);
-        bw[set][dy][1] = *reinterpret_cast<const uint4*>(wlane + (dx & 1) * DX_WPH + dy * 2 * DX_WPL + DX_WPL);
+        bw[set][dy][0] = *reinterpret_cast<const uint4*>(wlane + (RW ? dx : (dx & 1)) * DX_WPH + dy * 2 * DX_WPL);
+        bw[set][dy][1] = *reinterpret_cast<const uint4*>(wlane + (RW ? dx : (dx & 1)) * DX_WPH + dy * 2 * DX_WPL + DX_WPL);
     };
     auto read_a = [&](int slot, int dx, int s_) __attribute__((always_inline)) {
         const unsigned char* ab = a_base(dx);
@@ -321,7 +344,7 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
     // for without them.
     auto phase = [&](const int dx) __attribute__((always_inline)) {
         const int set = dx & 1;
-        if (dx == 0) load_w(2, wB0, wB1, wB2);
+        if (dx == 0 && !RW) load_w(2, wB0, wB1, wB2);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < DX_NS; ++s) {
@@ -334,18 +357,18 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
                 if (dx < 4) {                                   // the next weight set, over the steps behind the barrier
 #pragma unroll
                     for (int k = 0; k < 5; ++k)
-                        if (s == (DX_NS == 7 ? 4 + k / 2 : (DX_NS == 6 ? 3 + k / 2 : 3 + k / 3))) read_b(set ^ 1, dx + 1, k);
+                        if (s == (RW && dx >= 1 ? k : (DX_NS == 7 ? 4 + k / 2 : (DX_NS == 6 ? 3 + k / 2 : 3 + k / 3)))) read_b(set ^ 1, dx + 1, k);
                 }
             }
-            if (dx == 0 && s == 3) load_w(3, wC0, wC1, wC2);
-            if (dx == 0 && s == DX_NS - 2) load_w(4, wD0, wD1, wD2);
+            if (dx == 0 && s == 3 && !RW) load_w(3, wC0, wC1, wC2);
+            if (dx == 0 && s == DX_NS - 2 && !RW) load_w(4, wD0, wD1, wD2);
             // Epilogue operands (residual: phase 1, activation reference: phase 2), ONE request per step 3.. -- behind the LAST weight
             // request and spread out: a lane's 16 bytes sit 128 bytes from its neighbour's, so each request occupies the CU's
             // vector-memory path for 16 cache lines, and six of them back to back from all eight waves stalled every wave at issue
             // (+0.8 us in that phase).  UNCONDITIONAL requests -- a launch without a residual / activation reference reads the same
             // positions of x and drops the values: requests inside `if (a.res)` blocks make the compiler's next vmcnt wait a wait
             // for everything in flight.  They are HBM-cold in the training pipeline (written hundreds of launches ago): ~3 us.
-            if (COT == 2 && (dx == 1 || dx == 2) && s >= 3 && s - 3 < R) {
+            if ((COT == 2 || SPLIT) && (dx == 1 || dx == 2) && s >= 3 && s - 3 < R) {
                 const int j = s - 3;
                 // (scalar clamp) rows beyond the tensor -- the last workgroup's tail and the padding workgroups that own no rows at
                 // all (grid rounded up to a multiple of 8) -- read the tensor's last row: any valid position
@@ -384,10 +407,13 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
                     }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (s == 2 && dx < 4) {
+            if (s == 2 && dx < (RW ? 1 : 4)) {
                 // next phase's weights: their buffer was last read (as the set of phase dx - 1) before the previous phase's barrier;
                 // in the first phase also the input rows 3..6 (steps 3..6 read them)
-                if (dx == 0) stage_late();                        // rows 3..6 AND the weight set of phase 1 (late role)
+                if (dx == 0) {
+                    stage_late();                                 // rows 3..6 AND the weight set of phase 1 (late role)
+                    if (RW) { store_w(2, wB0, wB1, wB2); store_w(3, wC0, wC1, wC2); store_w(4, wD0, wD1, wD2); }      // (the last barrier of the launch)
+                }
                 else if (dx == 1) store_w(0, wB0, wB1, wB2);
                 else if (dx == 2) store_w(1, wC0, wC1, wC2);
                 else store_w(0, wD0, wD1, wD2);
@@ -404,9 +430,11 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
     phase(3);
     phase(4);
 
-    if (COT == 2) {
+    if (COT == 2 || SPLIT) {
+        if (mma) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) epilogue_row(j);
+            for (int j = 0; j < R; ++j) epilogue_row(j);
+        }
     } else {
         if (mma) {
 #pragma unroll
@@ -440,7 +468,7 @@ static int dx_rows_per_wg(int nrows, int tiles_x) { return ((nrows + 2) / 3) * t
 
 bool sol_conv_dx_usable(const ConvArgs& a, int NT, int ntiles) {
     if (!sol_opt().conv_dx || !a.xmax || !a.wsh || a.W % 64 != 0) return false;
-    if (NT == 2) return a.CO == 32 && !a.cvy;
+    if (NT == 2) return a.CO == 32 && !a.cvy;                  // (one-row launches: as two half-channel workgroups per tile, option bit 3)
     // Thin layers (<= 16 output channels; option bit 1, bit 2 = also in big launches): half the waves of the COT = 1 form only stage, and
     // where the launch fills the chip with three-row workgroups k_conv5x5_sb<1, 2> (twelve waves, a row each) is the faster kernel
     // (SOL-32 step at 128x64, B = 6: 13.26 ms against 13.43); in the small launches (one row per workgroup: the 64x32 recipe, roll-outs)
@@ -454,13 +482,16 @@ int sol_conv_dx_launch(hipStream_t s, const ConvArgs& a_in, int ntiles) {
     a.RPW = -1;                                           // (field unused by this kernel otherwise) log2 H, or -1
     for (int k = 0; k < 20; ++k) if ((1 << k) == a.H) a.RPW = k;
     static std::atomic<unsigned long long> optin{0};
-    if (int e = sol_lds_optin(optin, {SOL_K((k_conv5x5_dx<1, 2>)), SOL_K((k_conv5x5_dx<3, 2>)), SOL_K((k_conv5x5_dx<1, 1>)), SOL_K((k_conv5x5_dx<3, 1>))}, "k_conv5x5_dx")) return e;
+    if (int e = sol_lds_optin(optin, {SOL_K((k_conv5x5_dx<1, 2>)), SOL_K((k_conv5x5_dx<3, 2>)), SOL_K((k_conv5x5_dx<1, 1>)), SOL_K((k_conv5x5_dx<3, 1>)),
+                                         SOL_K((k_conv5x5_dx<1, 1, true>))}, "k_conv5x5_dx")) return e;
     const bool thin = a.CO <= 16;
     const int nrows = ntiles / a.tiles_x;                 // global image rows B*H
     const int R = dx_rows_per_wg(nrows, a.tiles_x);
     int grid = ((nrows + R - 1) / R) * a.tiles_x;
     if (grid > 64) grid = (grid + 7) / 8 * 8;             // XCD-aware tile order needs a multiple of 8 (xcd_tile); padding tiles own no rows
-    if (thin) {
+    if (!thin && R == 1 && (sol_opt().conv_dx & 8))
+        SOL_LAUNCH((k_conv5x5_dx<1, 1, true>), dim3(2 * grid), dim3(512), dx_lds(1, 1), s, a.x, a.wsh, a.xmax, nrows, a.H, a.W, a.tiles_x, a.RPW, a);
+    else if (thin) {
         if (R == 3) SOL_LAUNCH((k_conv5x5_dx<3, 1>), dim3(grid), dim3(512), dx_lds(3, 1), s, a.x, a.wsh, a.xmax, nrows, a.H, a.W, a.tiles_x, a.RPW, a);
         else SOL_LAUNCH((k_conv5x5_dx<1, 1>), dim3(grid), dim3(512), dx_lds(1, 1), s, a.x, a.wsh, a.xmax, nrows, a.H, a.W, a.tiles_x, a.RPW, a);
     } else if (R == 3) SOL_LAUNCH((k_conv5x5_dx<3, 2>), dim3(grid), dim3(512), dx_lds(3, 2), s, a.x, a.wsh, a.xmax, nrows, a.H, a.W, a.tiles_x, a.RPW, a);

@@ -33,6 +33,7 @@ struct StepArgs {
     long bc_stride;
     float *d_out, *vy_out, *vx_out, *saved_vy, *saved_vx, *feat;
     float fs0, fs1, fs2;
+    int feat_tr;   // features / feature gradients in the transposed cell order [B][X][Y][C] (the CNN's image order when the CNN runs on the transposed grid)
     int* iters;
     // backward only
     const float *g_vy_out, *g_vx_out, *dfeat;
@@ -1146,10 +1147,18 @@ __device__ __forceinline__ void karman_fwd_body(const StepArgs& a, float* smem) 
         __syncthreads();
         float4* gf = reinterpret_cast<float4*>(a.feat) + (size_t)b * N;
         const float rech = a.re[b] * a.fs2;
-        #pragma unroll 4
-        for (int k = tid; k < N; k += nthr) {
-            const int j = k >> lx, i = k & (X - 1);
-            gf[k] = make_float4(L.Avy[k] * a.fs0, L.Avx[j * XP + i] * a.fs1, rech, 0.f);
+        if (a.feat_tr) {        // cell (j, i) -> position i * Y + j: coalesced stores, column reads of the LDS fields (a few bank-conflicted reads per thread)
+            #pragma unroll 4
+            for (int k = tid; k < N; k += nthr) {
+                const int i = k / Y, j = k - i * Y;
+                gf[k] = make_float4(L.Avy[j * X + i] * a.fs0, L.Avx[j * XP + i] * a.fs1, rech, 0.f);
+            }
+        } else {
+            #pragma unroll 4
+            for (int k = tid; k < N; k += nthr) {
+                const int j = k >> lx, i = k & (X - 1);
+                gf[k] = make_float4(L.Avy[k] * a.fs0, L.Avx[j * XP + i] * a.fs1, rech, 0.f);
+            }
         }
     }
     SOL_STAMP(8);
@@ -1250,20 +1259,39 @@ __device__ __forceinline__ void karman_bwd_body(const StepArgs& a, float* smem) 
         const float4* dq4 = df ? df4 : gy4;
         const float* dq = df ? df : gy;
         const float w0 = df ? a.fs0 : 0.f, w1 = df ? a.fs1 : 0.f;
+        if (a.feat_tr && df) {      // feature gradient in the transposed cell order: cell (j, i) at i * Y + j (uniform branch around the whole request group)
 #pragma unroll
-        for (int n = 0; n < NV; ++n) {
-            const int q = min(tid + n * nthr, nQy - 1);
-            const int qd = df ? min(q, (N >> 2) - 1) : 0;
-            ty[n] = gy4[q];
-            f0[n] = dq4[2 * qd];
-            f1[n] = dq4[2 * qd + 1];
-        }
+            for (int n = 0; n < NV; ++n) {
+                const int q = min(tid + n * nthr, nQy - 1);
+                const int k0 = 4 * min(q, (N >> 2) - 1), j = k0 >> lx, i0 = k0 & (X - 1);       // four cells of one row (X % 4 == 0)
+                const float* p = dq + 2 * ((size_t)i0 * Y + j);
+                ty[n] = gy4[q];
+                f0[n].x = p[0]; f0[n].z = p[2 * Y]; f1[n].x = p[4 * Y]; f1[n].z = p[6 * Y];
+                f0[n].y = f0[n].w = f1[n].y = f1[n].w = 0.f;
+            }
 #pragma unroll
-        for (int n = 0; n < MAXT; ++n) {
-            const int kx = min(tid + n * nthr, nVx - 1);
-            const int j = (int)(((float)kx + 0.5f) * invXP), i = kx - j * XP;
-            tx[n] = gx[kx];
-            fxv[n] = dq[df ? 2 * (j * X + min(i, X - 1)) + 1 : 0];
+            for (int n = 0; n < MAXT; ++n) {
+                const int kx = min(tid + n * nthr, nVx - 1);
+                const int j = (int)(((float)kx + 0.5f) * invXP), i = kx - j * XP;
+                tx[n] = gx[kx];
+                fxv[n] = dq[2 * (min(i, X - 1) * Y + j) + 1];
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const int q = min(tid + n * nthr, nQy - 1);
+                const int qd = df ? min(q, (N >> 2) - 1) : 0;
+                ty[n] = gy4[q];
+                f0[n] = dq4[2 * qd];
+                f1[n] = dq4[2 * qd + 1];
+            }
+#pragma unroll
+            for (int n = 0; n < MAXT; ++n) {
+                const int kx = min(tid + n * nthr, nVx - 1);
+                const int j = (int)(((float)kx + 0.5f) * invXP), i = kx - j * XP;
+                tx[n] = gx[kx];
+                fxv[n] = dq[df ? 2 * (j * X + min(i, X - 1)) + 1 : 0];
+            }
         }
 #pragma unroll
         for (int n = 0; n < CPT / 4; ++n) ta[n] = gact[min(tid + n * nthr, (N >> 2) - 1)];
@@ -1667,6 +1695,8 @@ int check_cfg(const sol_karman_cfg* c) {
     return SOL_OK;
 }
 
+thread_local int g_feat_transposed = 0;        // see sol_karman_feat_transposed
+
 void fill_common(StepArgs& a, const sol_karman_cfg* c) {
     a.B = c->B; a.Y = c->Y; a.X = c->X;
     a.dtdx = c->dt / c->dx;
@@ -1681,9 +1711,19 @@ void fill_common(StepArgs& a, const sol_karman_cfg* c) {
     a.fd = c->direct;
     a.fd_n = c->direct_n;
     a.dbg = sol_opt().dbg_skip;   // timing experiments only
+    a.feat_tr = g_feat_transposed;
 }
 
 }  // namespace
+
+// internal (train.hip): while set, the step launches of THIS host thread write `feat_out` and read `dfeat` in the transposed cell
+// order [B][X][Y][C] -- the image order of the CNN when it runs on the transposed grid (cnn_transposed: 64x32) --, which folds the
+// two k_transpose_cells launches of every unrolled step into the solver kernels.  Returns the previous value.
+int sol_karman_feat_transposed(int on) {
+    const int old = g_feat_transposed;
+    g_feat_transposed = on ? 1 : 0;
+    return old;
+}
 
 // one-time: allow the full 160 KiB of dynamic LDS (not a stream operation -> done outside graph capture)
 int sol_init_karman_kernels() {

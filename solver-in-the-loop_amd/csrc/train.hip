@@ -35,7 +35,7 @@ SolOptions& sol_opt() {
         SolOptions d{};
         d.conv_precision = 0; d.conv_split3 = 0; d.conv_r3 = 1; d.conv_thin = 1; d.conv_bww32 = 1;
         d.correct_fuse = 1; d.bww_fuse = 1; d.bww_chunk = 0; d.bww_side = 1; d.streams = 1;
-        d.density_mode = 0; d.cpt = 0; d.dbg_skip = 0; d.step_prof = 0; d.cnn_persistent = 0; d.graph_stream = 0; d.k3d_tile = 0; d.k3d_fused_tf = 1; d.k3d_conv_fused = 1; d.k3d_conv_rows = 8; d.conv_dx = 3; d.k3d_mfma_tf = 1;
+        d.density_mode = 0; d.cpt = 0; d.dbg_skip = 0; d.step_prof = 0; d.cnn_persistent = 0; d.graph_stream = 0; d.k3d_tile = 0; d.k3d_fused_tf = 1; d.k3d_conv_fused = 1; d.k3d_conv_rows = 8; d.conv_dx = 11; d.k3d_mfma_tf = 1;
         return d;
     }();
     return o;
@@ -51,7 +51,7 @@ const OptName OPT_NAMES[] = {
     {"density_mode", &SolOptions::density_mode, 0, 2}, {"cpt", &SolOptions::cpt, 0, 16}, {"dbg_skip", &SolOptions::dbg_skip, 0, 1 << 30},
     {"step_prof", &SolOptions::step_prof, 0, 1}, {"cnn_persistent", &SolOptions::cnn_persistent, 0, 1},
     {"graph_stream", &SolOptions::graph_stream, 0, 1}, {"k3d_tile", &SolOptions::k3d_tile, 0, 1}, {"k3d_fused_tf", &SolOptions::k3d_fused_tf, 0, 1}, {"k3d_conv_fused", &SolOptions::k3d_conv_fused, 0, 1}, {"k3d_conv_rows", &SolOptions::k3d_conv_rows, 3, 8},
-    {"conv_dx", &SolOptions::conv_dx, 0, 7}, {"k3d_mfma_tf", &SolOptions::k3d_mfma_tf, 0, 1},
+    {"conv_dx", &SolOptions::conv_dx, 0, 15}, {"k3d_mfma_tf", &SolOptions::k3d_mfma_tf, 0, 1},
 };
 }  // namespace
 
@@ -263,22 +263,10 @@ struct MemList {
 // The split-precision convolution / weight-gradient kernels want image rows of 64 pixels.  A 64 x 32 grid (the reference's own
 // training recipe, karman-2d/Makefile:78-80) has rows of 32 -- but columns of 64, and conv(x^T, w^T) = conv(x, w)^T: the
 // whole CNN runs on TRANSPOSED images [B][X][Y][C] with tap-transposed packed weights (sol_pack_jobs), the weight gradients
-// are transposed back in their reduction.  Only the two ends touch the solver's layout: the features are transposed after
-// the solver step, the feature gradient before its adjoint (two tiny launches per unrolled step), and the correction /
-// loss / seed kernels index the transposed cell order.
+// are transposed back in their reduction.  Only the two ends touch the solver's layout: the solver kernels write the features
+// and read the feature gradient in the transposed cell order (sol_karman_feat_transposed; two k_transpose_cells launches per
+// unrolled step until round 4), and the correction / loss / seed kernels index the transposed cell order.
 __host__ __device__ inline bool cnn_transposed(int Y, int X) { return X % 64 != 0 && Y % 64 == 0; }
-// dst[b][i][j][c] = src[b][j][i][c]  (C floats per cell)
-template <int C>
-__global__ void k_transpose_cells(const float* __restrict__ src, float* __restrict__ dst, int B, int Y, int X) {
-    const int total = B * Y * X;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const int b = e / (Y * X), r = e - b * (Y * X), i = r / Y, j = r - i * Y;       // e = destination cell (b, i, j)
-        const float* sp = src + ((size_t)(b * Y + j) * X + i) * C;
-        float* dp = dst + (size_t)e * C;
-        if (C == 4) *reinterpret_cast<float4*>(dp) = *reinterpret_cast<const float4*>(sp);
-        else *reinterpret_cast<float2*>(dp) = *reinterpret_cast<const float2*>(sp);
-    }
-}
 
 __global__ void k_pad_bias(const float* __restrict__ params, float* __restrict__ biasp, int64_t boff, int cout) {
     const int t = threadIdx.x;
@@ -327,7 +315,6 @@ struct Ws {
     float *vy, *vx, *d;            // [msteps][B][...] states after step i (index i = state i+1)
     float *svy, *svx;              // [msteps] saved post-diffusion velocity
     float *feat;                   // [msteps][cells][4]  (cell order of the CNN: transposed in transposed CNN mode)
-    float *feat_raw, *dF_n;        // transposed CNN mode: the solver's feature output / the feature gradient in the solver's cell order
     float *acts;                   // [msteps][11][cells][32]
     float *O;                      // [cells][2]
     float *gA, *gB;                // [cells][32]
@@ -363,8 +350,6 @@ size_t carve_ws(const sol_train_cfg* c, float* base, Ws& w, bool training) {
     w.vy = take(ms * w.st_vy); w.vx = take(ms * w.st_vx); w.d = take(ms * w.st_d);
     w.svy = take(ms * w.st_vy); w.svx = take(ms * w.st_vx);
     w.feat = take(ms * w.cells * 4);
-    w.feat_raw = take(w.cells * 4);
-    w.dF_n = take(w.cells * 2);
     w.acts = take((size_t)ms * 11 * w.cells * 32);
     w.O = take(w.cells * 2);
     w.gA = take(w.cells * 32); w.gB = take(w.cells * 32);
@@ -418,6 +403,14 @@ inline float out_s1(const sol_train_cfg* c) { return c->out_std_v1 > 0.f ? c->ou
 // CNN forward (model_mars_moon, karman_train.py:101-138).  acts: 11 buffers [cells][32].
 // amax: [11][SOL_AMAX_SLOTS] absmax slots of act[0..10] (zeroed by the caller): every producer publishes max|y| and every
 // 32-channel consumer derives its fp16 operand scale from it (sol_conv5x5_scaled).
+// scope guard: feature I/O of the solver launches issued inside the scope in the CNN's transposed cell order
+struct FeatOrder {
+    int old; bool active;
+    explicit FeatOrder(bool tr) : old(sol_karman_feat_transposed(tr ? 1 : 0)), active(true) {}
+    void restore() { if (active) { sol_karman_feat_transposed(old); active = false; } }
+    ~FeatOrder() { restore(); }
+};
+
 // corr != nullptr: the last layer applies its output to the velocity and accumulates the loss (sol_conv5x5_correct) instead of storing O
 struct Correct { float *vy, *vx; const float *gt_vy, *gt_vx; float *loss, *loss_part; };
 int net_forward(const sol_train_cfg* c, void* s, const Ws& w, const float* feat, float* const* act, float* O, uint32_t* amax, const Correct* corr = nullptr,
@@ -544,7 +537,6 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
     const int B = kc->B, Y = kc->Y, X = kc->X, ms = c->msteps;
     const bool tr = cnn_transposed(Y, X);              // CNN tensors are [B][X][Y][C]; cY x cX = image shape the CNN kernels see
     const int cY = tr ? X : Y, cX = tr ? Y : X;
-    const int tgrid = (int)((w.cells + 255) / 256);
     const float fscale[3] = {1.f / in_s0(c), 1.f / in_s1(c), 1.f / c->std_re};
     const int egrid = (int)((w.st_vy + w.st_vx + 255) / 256);
     const size_t gVy = (size_t)Btot * w.nVy, gVx = (size_t)Btot * w.nVx;       // per-step stride of the gt frames
@@ -571,7 +563,10 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         float* vycur = w.vy + (size_t)i * w.st_vy;
         float* vxcur = w.vx + (size_t)i * w.st_vx;
         float* feat_cnn = w.feat + (size_t)i * w.cells * 4;
-        float* feat = tr ? w.feat_raw : feat_cnn;       // what the solver step writes
+        // Transposed CNN mode: the solver kernels write the features (and read the feature gradient) in the CNN's cell order themselves
+        // (sol_karman_feat_transposed) -- it was a k_transpose_cells launch each way per unrolled step: 63 launches of 4.3 us in the 64x32 recipe.
+        float* feat = feat_cnn;
+        FeatOrder feat_order(tr);
         // The passive density leaves the critical path.  With the direct-solver kernels the density advection of step
         // i-1 (it only needs that step's saved velocity) rides in the solver launch of step i as B extra workgroups;
         // otherwise the whole chain is one launch after the unroll (sol_density_chain below).
@@ -585,10 +580,7 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
                                                  w.d + (size_t)(i - 1) * w.st_d)) return e;
         } else if (int e = sol_karman_step_fwd(kc, stream, din, vyin, vxin, re, io.active, io.inflow, bcv, bcm, io.bc_stride,
                                                dens_inline ? dcur : nullptr, vycur, vxcur, svy_i, svx_i, feat, fscale, it_i)) return e;
-        if (tr) {
-            SOL_LAUNCH(k_transpose_cells<4>, dim3(tgrid), dim3(256), 0, hs, (const float*)w.feat_raw, feat_cnn, B, Y, X);
-            SOL_LAUNCH_CHECK();
-        }
+        feat_order.restore();
         float* act[11];
         for (int k = 0; k < 11; ++k) act[k] = w.acts + ((size_t)i * 11 + k) * w.cells * 32;
         if (sol_conv_correct_fusable(X, B * Y)) {            // correction + loss ride in the epilogue of the last CNN layer
@@ -703,11 +695,7 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         if (i > 0) {
             if (int e = sol_conv5x5_scaled(stream, D[0], wn.wb[0], nullptr, nullptr, nullptr, w.dF, B, cY, cX, 32, 2, SOL_EPI_NONE, sl, am(0), nullptr)) return e;
             const float* dF = w.dF;
-            if (tr) {       // feature gradient back into the solver's cell order ([B][X][Y][2] -> [B][Y][X][2]: the same kernel with the axes swapped)
-                SOL_LAUNCH(k_transpose_cells<2>, dim3(tgrid), dim3(256), 0, hs, (const float*)w.dF, w.dF_n, B, X, Y);
-                SOL_LAUNCH_CHECK();
-                dF = w.dF_n;
-            }
+            FeatOrder feat_order(tr);       // the adjoint reads the feature gradient in the CNN's (transposed) cell order
             if (int e = sol_karman_step_bwd_fused(kc, stream, w.svy + (size_t)i * w.st_vy, w.svx + (size_t)i * w.st_vx, re, io.active,
                                                   bcm, io.bc_stride, gvy, gvx, dF, fscale, w.gvy[cur ^ 1], w.gvx[cur ^ 1],
                                                   io.iters_bwd ? io.iters_bwd + (size_t)i * Btot + b0 : nullptr,
@@ -912,12 +900,11 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
         float* sd = (i & 1) ? w.d : d;   float* svy = (i & 1) ? w.vy : vy;   float* svx = (i & 1) ? w.vx : vx;
         float* td = (i & 1) ? d : w.d;   float* tvy = (i & 1) ? vy : w.vy;   float* tvx = (i & 1) ? vx : w.vx;
         const bool tr = cnn_transposed(Y, X);
-        if (int e = sol_karman_step_fwd(kc, stream, sd, svy, svx, re, active, inflow, velBCy, velBCyMask, bc_batch_stride,
-                                        td, tvy, tvx, nullptr, nullptr, tr ? w.feat_raw : w.feat, fscale,
-                                        iters ? iters + (size_t)i * B : nullptr)) return e;
-        if (tr) {
-            SOL_LAUNCH(k_transpose_cells<4>, dim3((int)((w.cells + 255) / 256)), dim3(256), 0, hs, (const float*)w.feat_raw, w.feat, B, Y, X);
-            SOL_LAUNCH_CHECK();
+        {
+            FeatOrder feat_order(tr);       // transposed CNN mode: features straight in the CNN's cell order
+            if (int e = sol_karman_step_fwd(kc, stream, sd, svy, svx, re, active, inflow, velBCy, velBCyMask, bc_batch_stride,
+                                            td, tvy, tvx, nullptr, nullptr, w.feat, fscale,
+                                            iters ? iters + (size_t)i * B : nullptr)) return e;
         }
         if (i % ROLLOUT_AMAX_SETS == 0) {
             MemList z;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Phase timeline of the dx-major 32 -> 32 convolution launch (csrc/conv5x5_dx.hip) next to k_conv5x5_sb<2, 2>, C3 shape.
     python tools/ab_lib.py --build dxprof conv5x5_dx.hip:-DSOL_CONV_PROF conv5x5_sb.hip:-DSOL_CONV_PROF     (needs hipcc; no GPU)
-    python tools/conv_dx_probe.py                                                                              (on the GPU box)
+    python tools/conv_dx_probe.py [B H W]                                                                      (on the GPU box)
 The stamps perturb the kernels (a scalar load, s_memrealtime and a store by thread 0 each): read DIFFERENCES between phases."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +17,7 @@ from sol_amd._lib import ptr, stream, check
 lib = _lib.load()
 for f in (lib.sol_conv_dx_prof_set, lib.sol_conv_prof_set):
     f.argtypes = [C.c_void_p, C.c_uint]
-B, Y, X = 6, 128, 64
+B, Y, X = [int(a) for a in sys.argv[1:4]] if len(sys.argv) >= 4 else (6, 128, 64)      # e.g. 3 32 64: the 64x32 recipe's CNN shape (one row per workgroup)
 dev = "cuda"
 x = torch.randn(B, Y, X, 32, device=dev)
 res = torch.randn(B, Y, X, 32, device=dev)
@@ -27,7 +27,9 @@ bias = torch.randn(32, device=dev)
 y = torch.empty_like(x)
 xam = ops.absmax_slots(x)
 yam = torch.zeros(ops.AMAX_SLOTS, dtype=torch.int32, device=dev)
-nwg = B * Y // 3
+rows = B * Y
+nwg = (rows + 2) // 3 if (rows + 2) // 3 >= 128 else rows      # rows per workgroup as the launchers choose them
+nwg = (nwg + 7) // 8 * 8 if nwg > 64 else nwg
 st = torch.zeros(nwg * 16, dtype=torch.int64, device=dev)
 junk = torch.empty(64 << 20, dtype=torch.float32, device=dev)      # 256 MB: flushes L2 / MALL between launches ("cold" = the training pipeline's state)
 call = lambda: check(lib.sol_conv5x5_scaled(stream(), ptr(x), ptr(packed), ptr(bias), ptr(res), None, ptr(y), B, Y, X, 32, 32,

@@ -72,7 +72,7 @@ if "--no-step" not in sys.argv:
                 losses[dx] = loss
         out[name] = res_ms
         print("%s medians: thin layers on sb %.3f ms, on dx %.3f ms   (losses %r)" % (name, statistics.median(res_ms[1]), statistics.median(res_ms[7]), losses), flush=True)
-_lib.set_option("conv_dx", 3)
+_lib.set_option("conv_dx", 11)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 with open(os.path.join(ROOT, "gpurun_out", "conv_thin_ab.json"), "w") as f:
     json.dump(out, f, indent=1)
