@@ -510,6 +510,10 @@ struct FdView {
 };
 constexpr int FD_Y = 128, FD_X = 64, FD_LD = 65, FD_WIN = 16, FD_ULD = 17;
 constexpr int FD_BUF = FD_Y * FD_LD;   // floats per transform buffer
+#ifndef SOL_FD_MFMA
+#define SOL_FD_MFMA 1                  // the sine transforms of fd_solve on the fp32 matrix cores (0: the packed-VALU forms, for A/B builds)
+#endif
+constexpr int FD_QYS = SOL_FD_MFMA ? 32 : FD_Y / 16;   // VGPRs of the wave's Qy coefficient slice, loaded at kernel start
 
 __device__ __forceinline__ FdView fd_view(const float* __restrict__ blob) {
     const int* h = reinterpret_cast<const int*>(blob);
@@ -582,6 +586,67 @@ __device__ __forceinline__ void fd_trans_rl(const float (&sl)[NK / 16], const fl
     }
 }
 
+// ---- the four sine transforms of a solve on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) ----------------------------------
+// Same peak as the packed VALU, but the operands arrive as plain vector registers: no wave-uniform coefficient stream (v_readlane /
+// s_load per packed FMA), which is what the VALU forms above are bound by (8.0 us for the two forward transforms of a solve against
+// 2.6 us of multiply-adds).  Eight waves = eight 32 x 32 output tiles:
+//   y transform (128 rows, symmetry as above): four products [32 j' x 64 k] . [64 k x 64 c], wave = (product p, column half):
+//       p = 0: rows j = 2j'      = sum_k Q[k][j] s_k          p = 2: rows 127 - 2j'       = sum_k (-1)^k Q[k][2j'] d_k
+//       p = 1: rows j = 2j' + 1  = sum_k Q[k][j] d_k          p = 3: rows 127 - (2j' + 1) = sum_k (-1)^k Q[k][2j'+1] s_k
+//     A operand = the wave's coefficient slice, 32 VGPRs loaded once per kernel (fd_load_ay: register t, lane (i, kk) = coefficient
+//     (k = 2t + kk, row j'(i))); B operand = s_k / d_k formed from two ds_read_b32 of the column (rows k and 127 - k).
+//   x transform (64 columns, no symmetry: its parity split would halve the tile width): [128 m x 64 c] . [64 c x 64 c'],
+//     wave = (32-row tile, column half); A operand = one ds_read_b32 of the row, B operand = Qx[c][32 half + j] in 32 VGPRs (fd_load_bx).
+// Accumulator tile D[r], lane: row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31.
+typedef float fd_f16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void fd_load_ay(const float* __restrict__ Qy, int w, float (&ay)[32]) {
+    const int lane = threadIdx.x & 63, i = lane & 31, kk = lane >> 5, p = w >> 1;
+    const float sgn = (p >= 2 && kk) ? -1.f : 1.f;               // (-1)^k, k = 2t + kk
+#pragma unroll
+    for (int t = 0; t < 32; ++t) ay[t] = sgn * Qy[(size_t)(2 * t + kk) * FD_Y + 2 * i + (p & 1)];
+}
+__device__ __forceinline__ void fd_load_bx(const float* __restrict__ Qx, int w, float (&bx)[32]) {
+    const int lane = threadIdx.x & 63, j = lane & 31, kk = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) bx[t] = Qx[(size_t)(2 * t + kk) * FD_X + 32 * (w & 1) + j];
+}
+// y transform of src ([128][FD_LD]) -> dst ([128][LDD])
+template <int LDD>
+__device__ __forceinline__ void fd_mfma_y(const float (&ay)[32], const float* src, float* dst, int w) {
+    const int lane = threadIdx.x & 63, kk = lane >> 5, p = w >> 1;
+    const float* lo = src + 32 * (w & 1) + (lane & 31) + kk * FD_LD;                  // rows k = 2t + kk
+    const float* hi = src + 32 * (w & 1) + (lane & 31) + (FD_Y - 1 - kk) * FD_LD;      // rows 127 - k
+    const float dsg = (p == 0 || p == 3) ? 1.f : -1.f;                                  // s_k (p = 0, 3) or d_k (p = 1, 2)   (wave uniform)
+    fd_f16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        const float v = lo[2 * t * FD_LD] + dsg * hi[-2 * t * FD_LD];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[t], v, acc, 0, 0, 0);
+    }
+    float* d = dst + 32 * (w & 1) + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * kk;
+        const int row = p < 2 ? 2 * i + p : FD_Y - 1 - 2 * i - (p - 2);
+        d[row * LDD] = acc[r];
+    }
+}
+// x transform of src ([128][FD_LD]) -> dst ([128][FD_LD]); src and dst must be different buffers
+__device__ __forceinline__ void fd_mfma_x(const float (&bx)[32], const float* src, float* dst, int w) {
+    const int lane = threadIdx.x & 63, kk = lane >> 5;
+    const float* ap = src + (32 * (w >> 1) + (lane & 31)) * FD_LD + kk;                 // row m, columns c = 2t + kk
+    fd_f16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * t], bx[t], acc, 0, 0, 0);
+    float* d = dst + (32 * (w >> 1)) * FD_LD + 32 * (w & 1) + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[((r & 3) + 8 * (r >> 2) + 4 * kk) * FD_LD] = acc[r];
+}
+
 // Touch every 128-byte line of the blob once at kernel start (one dword per line, summed into a value the caller
 // keeps alive): the solver kernels run between convolution launches that stream hundreds of MB through the L2,
 // so the 263 KB of coefficients would otherwise come from HBM inside the latency-bound scalar-load loops.
@@ -596,9 +661,17 @@ __device__ __forceinline__ float fd_prefetch(const float* __restrict__ blob, int
     return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
 }
 
+__device__ __forceinline__ void fd_load_qys(const float* __restrict__ Qy, int w, float (&qys)[FD_QYS]) {
+#if SOL_FD_MFMA
+    fd_load_ay(Qy, w, qys);
+#else
+    fd_load_slice<FD_Y>(Qy, w, qys);
+#endif
+}
+
 // rhs in rf[] (strip layout: rows 16*wave + k, column lane); returns the solution as a [128][64] LDS array (inside buf,
 // complete for every thread).  buf = 2*FD_BUF floats of LDS.
-__device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const float (&qys)[FD_Y / 16], float* buf, const float (&rf)[16], long long* prof) {
+__device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const float (&qys)[FD_QYS], float* buf, const float (&rf)[16], long long* prof) {
 #define FD_STAMP(i) do { if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[i] = wall_clock64(); } while (0)
     const FdView F = fd_view(blob);
     float* B0 = buf;
@@ -612,10 +685,35 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = tid & 127, cb = __builtin_amdgcn_readfirstlane(tid >> 7);
     f2 lo[4], hi[4];
+    // this thread's 16 spectral coefficients: index 2q+e -> column 8cb+2q+e, 8+2q+e -> column 63-(8cb+2q+e)
+    float t2[16], il[16];
+    int col[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        col[2 * q] = 8 * cb + 2 * q; col[2 * q + 1] = col[2 * q] + 1;
+        col[8 + 2 * q] = FD_X - 1 - col[2 * q]; col[8 + 2 * q + 1] = FD_X - 2 - col[2 * q];
+    }
 
     // ---- forward transform: T2 = (Qy b Qx) / lam ---------------------------------------
 #pragma unroll
     for (int k = 0; k < 16; ++k) B0[(16 * w + k) * FD_LD + lane] = rf[k];
+#if SOL_FD_MFMA
+    float bx[32];
+    fd_load_bx(F.Qx, w, bx);             // x-transform operand + the eigenvalue reciprocals: in flight behind the y transform
+#pragma unroll
+    for (int e = 0; e < 16; ++e) il[e] = F.ilT[col[e] * FD_Y + m];
+    __syncthreads();
+    fd_mfma_y<FD_LD>(qys, B0, B1, w);    // B1 = Qy b
+    __syncthreads();
+    fd_mfma_x(bx, B1, B0, w);            // B0 = Qy b Qx
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        t2[e] = B0[m * FD_LD + col[e]] * il[e];
+        B1[m * FD_LD + col[e]] = t2[e];
+    }
+    __syncthreads();                     // B1 = T2, B0 free
+#else
     __syncthreads();
     fd_trans_rl<FD_Y, FD_LD>(qys, B0 + lane, lo, hi);          // rows 8w+r and 127-(8w+r), column lane
     __syncthreads();
@@ -627,15 +725,8 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
     }
     __syncthreads();
     fd_trans<FD_X, 1>(F.Qx, B0 + m * FD_LD, cb, lo, hi);       // row m, columns 8cb+r and 63-(8cb+r)
-    // this thread's 16 spectral coefficients: index 2q+e -> column 8cb+2q+e, 8+2q+e -> column 63-(8cb+2q+e)
-    float t2[16], il[16];
-    int col[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        col[2 * q] = 8 * cb + 2 * q; col[2 * q + 1] = col[2 * q] + 1;
-        col[8 + 2 * q] = FD_X - 1 - col[2 * q]; col[8 + 2 * q + 1] = FD_X - 2 - col[2 * q];
-        t2[2 * q] = lo[q].x; t2[2 * q + 1] = lo[q].y; t2[8 + 2 * q] = hi[q].x; t2[8 + 2 * q + 1] = hi[q].y;
-    }
+    for (int q = 0; q < 4; ++q) { t2[2 * q] = lo[q].x; t2[2 * q + 1] = lo[q].y; t2[8 + 2 * q] = hi[q].x; t2[8 + 2 * q + 1] = hi[q].y; }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         il[e] = F.ilT[col[e] * FD_Y + m];
@@ -643,6 +734,7 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
         B1[m * FD_LD + col[e]] = t2[e];
     }
     __syncthreads();                     // B1 = T2, B0 free
+#endif
     FD_STAMP(9);
 
     // ---- window values of G b:  u = T2 Qx[:, win] ;  x0w = Qy[win, :] u ----------------------
@@ -748,6 +840,14 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
     __syncthreads();
     FD_STAMP(14);
     // ---- inverse transform: x = Qy (T2 Qx), written to B1 as [128][64] for the caller ---------------
+#if SOL_FD_MFMA
+    fd_mfma_x(bx, B1, B0, w);
+    __syncthreads();                     // B0 = T3; every read of B1 (T2) is done
+    FD_STAMP(15);
+    fd_mfma_y<FD_X>(qys, B0, B1, w);
+    __syncthreads();                     // solution complete in LDS
+    return B1;
+#else
     fd_trans<FD_X, 1>(F.Qx, B1 + m * FD_LD, cb, lo, hi);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -766,6 +866,7 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
     }
     __syncthreads();                     // solution complete in LDS
     return B1;
+#endif
 }
 
 // ---- the same direct solve for small grids (Y*X <= 2048, e.g. the reference's 64x32 training recipe,
@@ -1068,10 +1169,10 @@ __device__ __forceinline__ void karman_fwd_body(const StepArgs& a, float* smem) 
     SOL_STAMP(4);
 
     // ---- phase 4/5: divergence + CG pressure solve ----------------------------------
-    float qys[FD_Y / 16];           // direct solver: this wave's slice of Qy (L2-warm: fd_prefetch), in flight behind the setup
+    float qys[FD_QYS];              // direct solver: this wave's slice of Qy (L2-warm: fd_prefetch), in flight behind the setup
 #pragma unroll
-    for (int j = 0; j < FD_Y / 16; ++j) qys[j] = 0.f;
-    if constexpr (SOLVER == 2 && CPT == 16) { if (Y == FD_Y) fd_load_slice<FD_Y>(a.fd + 16, __builtin_amdgcn_readfirstlane(tid >> 6), qys); }
+    for (int j = 0; j < FD_QYS; ++j) qys[j] = 0.f;
+    if constexpr (SOLVER == 2 && CPT == 16) { if (Y == FD_Y) fd_load_qys(a.fd + 16, __builtin_amdgcn_readfirstlane(tid >> 6), qys); }
     const Own o = ownership<CPT>(Y, X);
     float dg[CPT], ac[CPT], r[CPT], x[CPT];
     cell_coeffs<CPT>(o, L.act, Y, X, dg, ac);
@@ -1322,10 +1423,10 @@ __device__ __forceinline__ void karman_bwd_body(const StepArgs& a, float* smem) 
     SOL_STAMP(1);
 
     // ---- 2: projection adjoint:  M z = G^T (m * g) -----------------------------------
-    float qys[FD_Y / 16];
+    float qys[FD_QYS];
 #pragma unroll
-    for (int j = 0; j < FD_Y / 16; ++j) qys[j] = 0.f;
-    if constexpr (SOLVER == 2 && CPT == 16) { if (Y == FD_Y) fd_load_slice<FD_Y>(a.fd + 16, __builtin_amdgcn_readfirstlane(tid >> 6), qys); }
+    for (int j = 0; j < FD_QYS; ++j) qys[j] = 0.f;
+    if constexpr (SOLVER == 2 && CPT == 16) { if (Y == FD_Y) fd_load_qys(a.fd + 16, __builtin_amdgcn_readfirstlane(tid >> 6), qys); }
     const Own o = ownership<CPT>(Y, X);
     float dg[CPT], ac[CPT], r[CPT], z[CPT];
     cell_coeffs<CPT>(o, L.act, Y, X, dg, ac);
