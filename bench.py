@@ -467,10 +467,10 @@ def main():
             return None, None
 
         # (1) dominant kernel: the 32->32 conv (forward and backward-data launches share one kernel)
-        conv_names = {"split": ("k_conv5x5_dx<3>", "k_conv5x5_dx<1>", "k_conv5x5_sb<2, 2>", "k_conv5x5_sb<2, 0>"), "bf16x6": ("k_conv5x5_sb<2, 0>",), "fp32": ("k_conv5x5_r3<2>",)}[args.precision]
+        conv_names = {"split": ("k_conv5x5_dx<3, 2>", "k_conv5x5_dx<1, 1, true>", "k_conv5x5_dx<1, 2>", "k_conv5x5_sb<2, 2>", "k_conv5x5_sb<2, 0>"), "bf16x6": ("k_conv5x5_sb<2, 0>",), "fp32": ("k_conv5x5_r3<2>",)}[args.precision]
         cname, cst = pick(*conv_names)
         flop_conv = 2.0 * 25 * 32 * 32 * B * N
-        nprod = {"k_conv5x5_dx<3>": 3, "k_conv5x5_dx<1>": 3, "k_conv5x5_sb<2, 2>": 3, "k_conv5x5_sb<2, 0>": 6}.get(cname, 1)
+        nprod = 3 if cname.startswith("k_conv5x5_dx") else {"k_conv5x5_sb<2, 2>": 3, "k_conv5x5_sb<2, 0>": 6}.get(cname, 1)
         roof_conv = None
         if cst:
             t_conv = cst["avg_us"] * 1e-6

@@ -103,6 +103,7 @@ int sol_karman_step_bwd_fused(const sol_karman_cfg* cfg, void* stream,
                               const float* g_vy_out, const float* g_vx_out, const float* dfeat, const float* feat_scale,
                               float* g_vy_in, float* g_vx_in, int32_t* iters, const BwArgs* bw, int nbw, int wg_per);
 int sol_karman_bwd_fusable(const sol_karman_cfg* cfg);
+int sol_karman_bwd_fusable_small(const sol_karman_cfg* cfg);     // the same for the 64 x 32 grid (k_karman_bwd_bww_small: 16 rows per gradient workgroup)
 int sol_karman_step_fwd_dens(const sol_karman_cfg* cfg, void* stream,
                              const float* vy_in, const float* vx_in, const float* re, const float* active, const float* inflow,
                              const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,

@@ -274,23 +274,25 @@ __device__ __forceinline__ void cg_block_sum2(float& v0, float& v1, float* slot)
     v1 = row_allsum(slot[16 + (threadIdx.x & 15)]);
 }
 // workgroup max of a non-negative value (one barrier; `slot` = 16 floats, stale entries must be >= 0 and <= result)
+template <int NT = 0>
 __device__ __forceinline__ float block_max(float v, float* slot) {
     v = __uint_as_float(amax_wave_max(__float_as_uint(v)));      // DPP row operations (non-negative floats order like their bit patterns)
     if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
     __syncthreads();
     float m = 0.f;
-    const int nw = (blockDim.x + 63) >> 6;
+    const int nw = ((NT ? NT : (int)blockDim.x) + 63) >> 6;
     for (int w = 0; w < nw; ++w) m = fmaxf(m, slot[w]);
     return m;
 }
 // two workgroup maxima with ONE barrier (`slot`: 32 floats)
+template <int NT = 0>
 __device__ __forceinline__ void block_max2(float& a, float& b, float* slot) {
     a = __uint_as_float(amax_wave_max(__float_as_uint(a)));
     b = __uint_as_float(amax_wave_max(__float_as_uint(b)));
     if ((threadIdx.x & 63) == 0) { slot[threadIdx.x >> 6] = a; slot[16 + (threadIdx.x >> 6)] = b; }
     __syncthreads();
     float ma = 0.f, mb = 0.f;
-    const int nw = (blockDim.x + 63) >> 6;
+    const int nw = ((NT ? NT : (int)blockDim.x) + 63) >> 6;
     for (int w = 0; w < nw; ++w) { ma = fmaxf(ma, slot[w]); mb = fmaxf(mb, slot[16 + w]); }
     a = ma; b = mb;
 }
@@ -878,10 +880,11 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
 // is the matrix itself; intermediate results are stored in the orientation their consumer needs).
 // stage the matrices of the blob into the solver's LDS region; called at kernel start so that the copies travel behind the
 // diffusion / advection phases (nothing else touches `ext`); the solve begins with a barrier
+template <int NT = 0>     // NT: threads of the workgroup that run the solver (0: all of it)
 __device__ __forceinline__ void fd_small_stage(const float* __restrict__ blob, int Y, int X, float* ext) {
     const int* h = reinterpret_cast<const int*>(blob);
     const int SP = h[6];
-    const int tid = threadIdx.x, T = blockDim.x;
+    const int tid = threadIdx.x, T = NT ? NT : (int)blockDim.x;
     const int n4 = (Y * Y + X * X + X * Y) / 4;              // Qy, Qx, 1/lam: contiguous in the blob and in LDS
     const float4* src = reinterpret_cast<const float4*>(blob + 16);
     float4* dst = reinterpret_cast<float4*>(ext);
@@ -906,7 +909,7 @@ __device__ __forceinline__ void fd_small_stage(const float* __restrict__ blob, i
 #pragma unroll 4
     for (int e = tid; e < Y * 16; e += T) QyW[e] = gQy[(size_t)(wy0 + (e & 15)) * Y + (e >> 4)];
 }
-template <int CPT>
+template <int CPT, int NT = 0>
 __device__ __forceinline__ float* fd_solve_small(const float* __restrict__ blob, int Y, int X, const Own& o, float* ext, const float (&rf)[CPT]) {
     const int* h = reinterpret_cast<const int*>(blob);
     const int wy0 = h[3], wx0 = h[4], SP = h[6];
@@ -929,7 +932,7 @@ __device__ __forceinline__ float* fd_solve_small(const float* __restrict__ blob,
     float* CP = XS + 256;
     float* KP = CP + 256;              // K'^T [SP][SP] when SP <= 64 (fd_small_stage)
     float* QyW = KP + 4096;            // [Y][16] window rows of Qy
-    const int tid = threadIdx.x, T = blockDim.x;
+    const int tid = threadIdx.x, T = NT ? NT : (int)blockDim.x;
     (void)gQy; (void)gQW;
     if (o.owner) {
 #pragma unroll
@@ -1323,10 +1326,11 @@ __global__ void __launch_bounds__(512) k_density_step(DensStep q) { density_step
 // ------------------------------------------------------------------------------------
 // backward (adjoint w.r.t. the input velocity)
 // ------------------------------------------------------------------------------------
-template <int CPT, int SOLVER>
+// NT != 0: the body runs on the first NT threads of a larger workgroup whose other waves have ended (k_karman_bwd_bww_small)
+template <int CPT, int SOLVER, int NT = 0>
 __device__ __forceinline__ void karman_bwd_body(const StepArgs& a, float* smem) {
     constexpr int MAXT = CPT + 1;   // face targets per thread: (Y+1)*X / (Y*X/CPT) <= CPT+1 for Y >= CPT
-    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = NT ? NT : (int)blockDim.x;
     const int Y = a.Y, X = a.X, N = Y * X, nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
     const int lx = __ffs(X) - 1;                 // X is a power of two: k / X == k >> lx
     const float invXP = 1.f / (float)XP;         // k / XP == (int)((k + 0.5) * invXP), exact for k < 2^22
@@ -1337,7 +1341,7 @@ __device__ __forceinline__ void karman_bwd_body(const StepArgs& a, float* smem) 
     float fdp = 0.f;
     if constexpr (SOLVER == 2) {
         if (Y == FD_Y) fdp = fd_prefetch(a.fd, a.fd_n);
-        else fd_small_stage(a.fd, Y, X, L.fdx);
+        else fd_small_stage<NT>(a.fd, Y, X, L.fdx);
     }
     // ---- 1: load incoming gradient (+ feature gradient): all global loads in flight first --------
     {
@@ -1447,8 +1451,8 @@ __device__ __forceinline__ void karman_bwd_body(const StepArgs& a, float* smem) 
     float* Pfd = nullptr;
     SOL_STAMP(2);
     if constexpr (SOLVER == 2) {
-        if constexpr (CPT == 16) Pfd = Y == FD_Y ? fd_solve(a.fd, qys, L.Bvy, r, a.prof) : fd_solve_small<CPT>(a.fd, Y, X, o, L.fdx, r);
-        else Pfd = fd_solve_small<CPT>(a.fd, Y, X, o, L.fdx, r);
+        if constexpr (CPT == 16) Pfd = Y == FD_Y ? fd_solve(a.fd, qys, L.Bvy, r, a.prof) : fd_solve_small<CPT, NT>(a.fd, Y, X, o, L.fdx, r);
+        else Pfd = fd_solve_small<CPT, NT>(a.fd, Y, X, o, L.fdx, r);
     } else if constexpr (SOLVER == 1) {
         it = X == 64 ? pcg_solve<CPT, true, 32>(o, Y, X, L.act, dg, ac, r, z, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter)
                      : pcg_solve<CPT, false, 8>(o, Y, X, L.act, dg, ac, r, z, L.E, L.red, L.cs, a.cinv, a.rtol2, a.atol2, a.max_iter);
@@ -1523,7 +1527,7 @@ __device__ __forceinline__ void karman_bwd_body(const StepArgs& a, float* smem) 
 #pragma unroll
         for (int n = 0; n < MAXT; ++n) gmax = fmaxf(gmax, fmaxf(fabsf(gy[n]), fabsf(gx[n])));
     }
-    block_max2(smax, gmax, L.red);          // barrier: S staged, accumulators cleared
+    block_max2<NT>(smax, gmax, L.red);          // barrier: S staged, accumulators cleared
     const float bound = 16.f * gmax * fmaxf(1.f, 2.f * a.dtdx * smax);
     const float qs = bound > 0.f ? 2147483648.f / bound : 0.f;      // fixed-point scale
     const float qi = bound > 0.f ? bound / 2147483648.f : 0.f;
@@ -1668,6 +1672,21 @@ __global__ void __launch_bounds__(512) k_karman_bwd_bww(StepArgs a, BwPack bw) {
         if (stamp) a.prof[idx == 0 ? 16 : 18] = wall_clock64();
         sbk::bww_sb_body<2>(bw.a[job], sub, reinterpret_cast<unsigned char*>(smem));
         if (stamp) a.prof[idx == 0 ? 17 : 19] = wall_clock64();
+    }
+}
+
+// The same fusion for the 64 x 32 grid (the reference's own training recipe): its adjoint runs on 256 threads (eight-cell strips,
+// LDS-resident direct solver), the weight-gradient body on 512.  The launch has 512-thread workgroups; in a solver workgroup waves
+// 4..7 end at once (ended waves do not take part in s_barrier) and the adjoint body runs on the first 256 threads
+// (karman_bwd_body<8, 2, 256>: every stride it derives from the workgroup size is the template argument).
+__global__ void __launch_bounds__(512) k_karman_bwd_bww_small(StepArgs a, BwPack bw) {
+    extern __shared__ __align__(16) float smem[];
+    if ((int)blockIdx.x < a.B) {
+        if (threadIdx.x >= 256) return;
+        karman_bwd_body<8, 2, 256>(a, smem);
+    } else {
+        const int idx = (int)blockIdx.x - a.B;
+        sbk::bww_sb_body<2>(bw.a[idx / bw.wg_per], idx % bw.wg_per, reinterpret_cast<unsigned char*>(smem));
     }
 }
 
@@ -1831,7 +1850,7 @@ int sol_init_karman_kernels() {
     static std::atomic<unsigned long long> optin{0};
     return sol_lds_optin(optin, {SOL_K(k_karman_fwd<8, 0>), SOL_K(k_karman_bwd<8, 0>), SOL_K(k_karman_fwd<8, 2>), SOL_K(k_karman_bwd<8, 2>),
                                  SOL_K(k_karman_fwd<16, 0>), SOL_K(k_karman_bwd<16, 0>), SOL_K(k_karman_fwd<16, 1>), SOL_K(k_karman_bwd<16, 1>),
-                                 SOL_K(k_karman_fwd<16, 2>), SOL_K(k_karman_bwd<16, 2>), SOL_K(k_karman_bwd_bww), SOL_K(k_karman_fwd_dens)},
+                                 SOL_K(k_karman_fwd<16, 2>), SOL_K(k_karman_bwd<16, 2>), SOL_K(k_karman_bwd_bww), SOL_K(k_karman_fwd_dens), SOL_K(k_karman_bwd_bww_small)},
                          "karman kernels");
 }
 
@@ -1993,15 +2012,20 @@ static int step_bwd_impl(const sol_karman_cfg* cfg, void* stream,
     if (feat_scale) { a.fs0 = feat_scale[0]; a.fs1 = feat_scale[1]; a.fs2 = feat_scale[2]; }
     a.g_vy_in = g_vy_in; a.g_vx_in = g_vx_in; a.iters = iters;
     const int cpt = pick_cpt(cfg);
-    if (nbw > 0) {      // weight-gradient workgroups ride in the adjoint's launch (direct-solver kernels, 16-cell strips)
-        SOL_REQUIRE(cpt == 16 && a.fd && nbw <= 12 && wg_per >= 1, "fused adjoint + weight-gradient launch: unsupported configuration");
+    if (nbw > 0) {      // weight-gradient workgroups ride in the adjoint's launch (direct-solver kernels: 128x64 with 16-cell strips, 64x32 with 8-cell strips)
+        SOL_REQUIRE((sol_karman_bwd_fusable(cfg) || sol_karman_bwd_fusable_small(cfg)) && nbw <= 12 && wg_per >= 1, "fused adjoint + weight-gradient launch: unsupported configuration");
         if (int e = sol_init_karman_kernels()) return e;
         BwPack pk{};
         for (int k = 0; k < nbw; ++k) pk.a[k] = bw[k];
         pk.n = nbw; pk.wg_per = wg_per;
-        size_t lds = lds_bytes(cfg->Y, cfg->X, 16);
+        size_t lds = lds_bytes(cfg->Y, cfg->X, cpt);
         if (lds < (size_t)sbk::BW_LDS) lds = sbk::BW_LDS;
         if (sol_opt().step_prof) a.prof = prof_buffer();
+        if (cpt == 8) {
+            SOL_LAUNCH(k_karman_bwd_bww_small, dim3(cfg->B + nbw * wg_per), dim3(512), lds, (hipStream_t)stream, a, pk);
+            SOL_LAUNCH_CHECK();
+            return SOL_OK;
+        }
         SOL_LAUNCH(k_karman_bwd_bww, dim3(cfg->B + nbw * wg_per), dim3(512), lds, (hipStream_t)stream, a, pk);
         SOL_LAUNCH_CHECK();
         if (a.prof) return prof_print((hipStream_t)stream, a, true);
@@ -2049,4 +2073,8 @@ int sol_bww_jobs_launch(void* stream, const BwArgs* bw, int nbw, int wg_per) {
 // 1 if the fused adjoint + weight-gradient launch exists for this configuration
 int sol_karman_bwd_fusable(const sol_karman_cfg* cfg) {
     return cfg && cfg->direct && cfg->Y == FD_Y && cfg->X == FD_X && pick_cpt(cfg) == 16;
+}
+// ... and for the 64 x 32 grid (256 solver threads inside 512-thread workgroups: k_karman_bwd_bww_small)
+int sol_karman_bwd_fusable_small(const sol_karman_cfg* cfg) {
+    return cfg && cfg->direct && cfg->Y == 64 && cfg->X == 32 && pick_cpt(cfg) == 8;
 }

@@ -523,11 +523,18 @@ struct TrainIO {
     int32_t *iters_fwd, *iters_bwd;
 };
 
-// same predicate as `fuse` in run_chain (the reduce at the end must know the partial layout)
-bool train_fused(const sol_train_cfg* c, const Ws& w, int ms) {
+// The weight gradients of the 32 -> 32 layers of unrolled step i ride in the solver-adjoint launch of step i (k_karman_bwd_bww at 128x64,
+// k_karman_bwd_bww_small at 64x32 -- there the CNN runs on the transposed images, rows = B * X).  Returns the image rows per gradient
+// workgroup (32 / 16: sized to last about as long as the adjoint), or 0 where the per-layer launches after the sweep are used.
+// run_chain and the reduce at the end (which must know the partial layout) both ask here.
+int train_fused_rb(const sol_train_cfg* c, const Ws& w, int ms) {
     const sol_karman_cfg* kc = &c->karman;
-    return pick_bww_chunk(ms) == ms && kc->X == 64 && (kc->B * kc->Y) % 32 == 0 && sol_karman_bwd_fusable(kc) && sol_opt().bww_fuse &&
-           sol_opt().conv_precision == 0 && sol_bww_step_ws_floats(kc->B, kc->Y, 32) <= w.part_floats[1];
+    const bool tr = cnn_transposed(kc->Y, kc->X);
+    const int cY = tr ? kc->X : kc->Y, cX = tr ? kc->Y : kc->X;
+    if (pick_bww_chunk(ms) != ms || cX != 64 || !sol_opt().bww_fuse || sol_opt().conv_precision != 0) return 0;
+    const int rb = sol_karman_bwd_fusable(kc) ? 32 : (sol_karman_bwd_fusable_small(kc) ? 16 : 0);
+    if (!rb || (kc->B * cY) % rb != 0 || sol_bww_step_ws_floats(kc->B, cY, rb) > w.part_floats[1]) return 0;
+    return rb;
 }
 
 // forward unroll + reverse sweep of the simulations [b0, b0 + c.karman.B) on stream hs
@@ -621,11 +628,9 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
     const long seg32 = (long)(11 * cl32);
     const int CH = pick_bww_chunk(ms);
     // weight gradients of the 32 -> 32 layers ride in the solver-adjoint launches (see k_karman_bwd_bww): 32 rows per workgroup
-    constexpr int FRB = 32;
-    const bool fuse = CH == ms && X == 64 && (B * Y) % FRB == 0 && sol_karman_bwd_fusable(kc) && sol_opt().bww_fuse &&
-                      sol_opt().conv_precision == 0 &&
-                      sol_bww_step_ws_floats(B, Y, FRB) <= w.part_floats[1];
-    const int wg_per = (B * Y) / FRB;
+    const int FRB = train_fused_rb(c, w, ms);
+    const bool fuse = FRB != 0;
+    const int wg_per = fuse ? (B * cY) / FRB : 1;
     const bool use_side = CH < ms && pool()->ok && sol_opt().bww_side;
     hipStream_t side = pool()->s[7];
     bool side_used = false;
@@ -689,7 +694,7 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         BwArgs jobs[10];
         if (fuse) {       // this step's dz tensors are complete: one job per 32 -> 32 layer
             for (int l = 1; l <= 10; ++l)
-                if (int e = sol_bww_step_job(&jobs[l - 1], act[l - 1], D[l], w.part[l], i == ms - 1 ? 1 : 0, B, Y, X, FRB,
+                if (int e = sol_bww_step_job(&jobs[l - 1], act[l - 1], D[l], w.part[l], i == ms - 1 ? 1 : 0, B, cY, cX, FRB,
                                              w.amax_act + ((size_t)i * 11 + (l - 1)) * SOL_AMAX_SLOTS, am(l))) return e;
         }
         if (i > 0) {
@@ -759,17 +764,17 @@ int train_fwd_bwd_impl(const sol_train_cfg* cfg, hipStream_t hs, const TrainIO& 
     }
     // all twelve layers of a chain in two launches (chain k > 0 accumulates onto chain k-1: one pair of launches per chain)
     const bool trn = cnn_transposed(Y, X);
-    const bool fused_all = train_fused(&sub, w[0], ms);
+    const int fused_rb = train_fused_rb(&sub, w[0], ms);
     for (int k = 0; k < S; ++k) {
         float *part[NL], *dw[NL], *db[NL];
         int rows[NL], rbs[NL], cins[NL], couts[NL];
         for (int l = 0; l < NL; ++l) {
             const int cin = layer_cin(l), cout = layer_cout(l);
             const int64_t koff = layer_koff(l), boff = koff + 25 * cin * cout;
-            const bool fused = l >= 1 && l <= 10 && fused_all;
+            const bool fused = l >= 1 && l <= 10 && fused_rb != 0;
             part[l] = w[k].part[l]; dw[l] = grads + koff; db[l] = grads + boff; cins[l] = cin; couts[l] = cout;
-            rows[l] = fused ? (B / S) * Y : pick_bww_chunk(ms) * (B / S) * (trn ? X : Y);
-            rbs[l] = fused ? 32 : 0;
+            rows[l] = (fused ? 1 : pick_bww_chunk(ms)) * (B / S) * (trn ? X : Y);
+            rbs[l] = fused ? fused_rb : 0;
         }
         if (int e = sol_bww_reduce_layers(hs, NL, part, dw, db, rows, rbs, cins, couts, k > 0 ? 1 : 0, trn ? 1 : 0)) return e;
     }
