@@ -101,7 +101,11 @@ int sol_karman_step_bwd_fused(const sol_karman_cfg* cfg, void* stream,
                               const float* saved_vy, const float* saved_vx, const float* re, const float* active,
                               const float* velBCyMask, int64_t bc_batch_stride,
                               const float* g_vy_out, const float* g_vx_out, const float* dfeat, const float* feat_scale,
-                              float* g_vy_in, float* g_vx_in, int32_t* iters, const BwArgs* bw, int nbw, int wg_per);
+                              float* g_vy_in, float* g_vx_in, int32_t* iters, const BwArgs* bw, int nbw, int wg_per,
+                              const struct SolDensRide* dens = nullptr);
+// one passive-density advection (post-diffusion velocity svy / svx of its step) as B extra workgroups of a fused adjoint launch
+// (k_karman_bwd_bww_small only: the 64x32 training path, where no forward launch can carry it)
+struct SolDensRide { const float *d_in, *svy, *svx, *inflow; float* d_out; };
 int sol_karman_bwd_fusable(const sol_karman_cfg* cfg);
 int sol_karman_bwd_fusable_small(const sol_karman_cfg* cfg);     // the same for the 64 x 32 grid (k_karman_bwd_bww_small: 16 rows per gradient workgroup)
 int sol_karman_step_fwd_dens(const sol_karman_cfg* cfg, void* stream,
@@ -111,7 +115,7 @@ int sol_karman_step_fwd_dens(const sol_karman_cfg* cfg, void* stream,
                              float* feat_out, const float* feat_scale, int32_t* iters,
                              const float* dens_d_in, const float* dens_svy, const float* dens_svx, float* dens_d_out);
 int sol_density_step(const sol_karman_cfg* c, void* stream, const float* d_in, const float* svy, const float* svx, const float* inflow, float* d_out);
-int sol_bww_jobs_launch(void* stream, const BwArgs* bw, int nbw, int wg_per);
+int sol_bww_jobs_launch(void* stream, const BwArgs* bw, int nbw, int wg_per, const sol_karman_cfg* cfg = nullptr, const SolDensRide* dens = nullptr);
 // weight-gradient job description for one layer of ONE unrolled step with `rb` rows per workgroup (train.hip -> fused launch)
 int sol_bww_step_job(BwArgs* out, const float* x, const float* dz, float* partial, int overwrite, int B, int H, int W, int rb,
                      const unsigned* xmax, const unsigned* zmax);

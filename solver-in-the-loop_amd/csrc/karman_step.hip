@@ -1679,15 +1679,19 @@ __global__ void __launch_bounds__(512) k_karman_bwd_bww(StepArgs a, BwPack bw) {
 // LDS-resident direct solver), the weight-gradient body on 512.  The launch has 512-thread workgroups; in a solver workgroup waves
 // 4..7 end at once (ended waves do not take part in s_barrier) and the adjoint body runs on the first 256 threads
 // (karman_bwd_body<8, 2, 256>: every stride it derives from the workgroup size is the template argument).
-__global__ void __launch_bounds__(512) k_karman_bwd_bww_small(StepArgs a, BwPack bw) {
+// The passive density has no forward launch to ride with at this size (the forward kernel is the 256-thread form): ONE of its msteps
+// advections rides in each launch of the REVERSE sweep as q.B more workgroups (all saved velocities exist by then; it was a chain of
+// msteps dependent advections in one launch behind the forward unroll: 162 us of the 64x32 recipe's step).
+__global__ void __launch_bounds__(512) k_karman_bwd_bww_small(StepArgs a, BwPack bw, DensStep q) {
     extern __shared__ __align__(16) float smem[];
+    const int ng = bw.n * bw.wg_per;
     if ((int)blockIdx.x < a.B) {
         if (threadIdx.x >= 256) return;
         karman_bwd_body<8, 2, 256>(a, smem);
-    } else {
+    } else if ((int)blockIdx.x < a.B + ng) {
         const int idx = (int)blockIdx.x - a.B;
         sbk::bww_sb_body<2>(bw.a[idx / bw.wg_per], idx % bw.wg_per, reinterpret_cast<unsigned char*>(smem));
-    }
+    } else density_step_body(q, (int)blockIdx.x - a.B - ng);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1999,7 +2003,7 @@ static int step_bwd_impl(const sol_karman_cfg* cfg, void* stream,
                          const float* g_vy_out, const float* g_vx_out,
                          const float* dfeat, const float* feat_scale,
                          float* g_vy_in, float* g_vx_in, int32_t* iters,
-                         const BwArgs* bw, int nbw, int wg_per) {
+                         const BwArgs* bw, int nbw, int wg_per, const SolDensRide* dens = nullptr) {
     if (int e = check_cfg(cfg)) return e;
     SOL_REQUIRE(saved_vy && saved_vx && re && active && velBCyMask && g_vy_out && g_vx_out && g_vy_in && g_vx_in,
                 "sol_karman_step_bwd: NULL pointer argument");
@@ -2021,8 +2025,11 @@ static int step_bwd_impl(const sol_karman_cfg* cfg, void* stream,
         size_t lds = lds_bytes(cfg->Y, cfg->X, cpt);
         if (lds < (size_t)sbk::BW_LDS) lds = sbk::BW_LDS;
         if (sol_opt().step_prof) a.prof = prof_buffer();
+        SOL_REQUIRE(!dens || cpt == 8, "a density advection rides only in the 64x32 fused launch");
         if (cpt == 8) {
-            SOL_LAUNCH(k_karman_bwd_bww_small, dim3(cfg->B + nbw * wg_per), dim3(512), lds, (hipStream_t)stream, a, pk);
+            DensStep q{};
+            if (dens) q = DensStep{cfg->B, cfg->Y, cfg->X, cfg->inflow_before, cfg->dt / cfg->dx, cfg->dt, dens->d_in, dens->svy, dens->svx, dens->inflow, dens->d_out};
+            SOL_LAUNCH(k_karman_bwd_bww_small, dim3(cfg->B + nbw * wg_per + (dens ? cfg->B : 0)), dim3(512), lds, (hipStream_t)stream, a, pk, q);
             SOL_LAUNCH_CHECK();
             return SOL_OK;
         }
@@ -2053,19 +2060,25 @@ int sol_karman_step_bwd_fused(const sol_karman_cfg* cfg, void* stream,
                               const float* saved_vy, const float* saved_vx, const float* re, const float* active,
                               const float* velBCyMask, int64_t bc_batch_stride,
                               const float* g_vy_out, const float* g_vx_out, const float* dfeat, const float* feat_scale,
-                              float* g_vy_in, float* g_vx_in, int32_t* iters, const BwArgs* bw, int nbw, int wg_per) {
+                              float* g_vy_in, float* g_vx_in, int32_t* iters, const BwArgs* bw, int nbw, int wg_per, const SolDensRide* dens) {
     return step_bwd_impl(cfg, stream, saved_vy, saved_vx, re, active, velBCyMask, bc_batch_stride, g_vy_out, g_vx_out, dfeat, feat_scale,
-                         g_vy_in, g_vx_in, iters, bw, nbw, wg_per);
+                         g_vy_in, g_vx_in, iters, bw, nbw, wg_per, dens);
 }
 // weight-gradient jobs alone (the first step of the unroll has no solver adjoint): same kernel, no solver workgroups
-int sol_bww_jobs_launch(void* stream, const BwArgs* bw, int nbw, int wg_per) {
-    SOL_REQUIRE(bw && nbw >= 1 && nbw <= 12 && wg_per >= 1, "sol_bww_jobs_launch: bad arguments");
+int sol_bww_jobs_launch(void* stream, const BwArgs* bw, int nbw, int wg_per, const sol_karman_cfg* cfg, const SolDensRide* dens) {
+    SOL_REQUIRE(bw && nbw >= 1 && nbw <= 12 && wg_per >= 1 && (!dens || cfg), "sol_bww_jobs_launch: bad arguments");
     if (int e = sol_init_karman_kernels()) return e;
     StepArgs a{};
     a.B = 0;
     BwPack pk{};
     for (int k = 0; k < nbw; ++k) pk.a[k] = bw[k];
     pk.n = nbw; pk.wg_per = wg_per;
+    if (dens) {         // with a density advection riding along (64x32 training path)
+        const DensStep q{cfg->B, cfg->Y, cfg->X, cfg->inflow_before, cfg->dt / cfg->dx, cfg->dt, dens->d_in, dens->svy, dens->svx, dens->inflow, dens->d_out};
+        SOL_LAUNCH(k_karman_bwd_bww_small, dim3(nbw * wg_per + cfg->B), dim3(512), (size_t)sbk::BW_LDS, (hipStream_t)stream, a, pk, q);
+        SOL_LAUNCH_CHECK();
+        return SOL_OK;
+    }
     SOL_LAUNCH(k_karman_bwd_bww, dim3(nbw * wg_per), dim3(512), (size_t)sbk::BW_LDS, (hipStream_t)stream, a, pk);
     SOL_LAUNCH_CHECK();
     return SOL_OK;

@@ -562,6 +562,9 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
     // ---------------- forward unroll ----------------
     const bool dens_inline = sol_opt().density_mode == 1;
     const bool dens_fused = !dens_inline && io.d_final && sol_karman_bwd_fusable(kc) && sol_opt().density_mode == 0;
+    // 64x32: one density advection per launch of the REVERSE sweep (k_karman_bwd_bww_small), msteps launches for msteps advections
+    const bool dens_ride_bwd = !dens_inline && !dens_fused && io.d_final && sol_opt().density_mode == 0 && sol_karman_bwd_fusable_small(kc) &&
+                               train_fused_rb(c, w, ms) != 0;
     for (int i = 0; i < ms; ++i) {
         const float* din = i == 0 ? d0 : w.d + (size_t)(i - 1) * w.st_d;
         const float* vyin = i == 0 ? vy0 : w.vy + (size_t)(i - 1) * w.st_vy;
@@ -609,7 +612,7 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         const float* dprev = ms == 1 ? d0 : w.d + (size_t)(ms - 2) * w.st_d;
         if (int e = sol_density_step(kc, stream, dprev, w.svy + (size_t)(ms - 1) * w.st_vy, w.svx + (size_t)(ms - 1) * w.st_vx, io.inflow,
                                      io.d_final + (size_t)b0 * w.N)) return e;
-    } else if (io.d_final) {
+    } else if (io.d_final && !dens_ride_bwd) {
         // all saved velocities exist now: the whole density chain is ONE launch (one workgroup per simulation, ~0.3 ms)
         // on the main stream (as a concurrent graph branch it takes 6 CUs away from the 256-workgroup conv launches)
         if (int e = sol_density_chain(kc, stream, ms, d0, w.svy, w.svx, (long)w.st_vy, (long)w.st_vx, io.inflow, nullptr, (long)w.st_d,
@@ -697,6 +700,12 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
                 if (int e = sol_bww_step_job(&jobs[l - 1], act[l - 1], D[l], w.part[l], i == ms - 1 ? 1 : 0, B, cY, cX, FRB,
                                              w.amax_act + ((size_t)i * 11 + (l - 1)) * SOL_AMAX_SLOTS, am(l))) return e;
         }
+        SolDensRide ride{};
+        if (dens_ride_bwd) {          // density advection s = ms - 1 - i (forward order) rides in this step's launch
+            const int sd = ms - 1 - i;
+            ride = SolDensRide{sd == 0 ? d0 : w.d + (size_t)(sd - 1) * w.st_d, w.svy + (size_t)sd * w.st_vy, w.svx + (size_t)sd * w.st_vx, io.inflow,
+                               sd == ms - 1 ? io.d_final + (size_t)b0 * w.N : w.d + (size_t)sd * w.st_d};
+        }
         if (i > 0) {
             if (int e = sol_conv5x5_scaled(stream, D[0], wn.wb[0], nullptr, nullptr, nullptr, w.dF, B, cY, cX, 32, 2, SOL_EPI_NONE, sl, am(0), nullptr)) return e;
             const float* dF = w.dF;
@@ -704,10 +713,10 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
             if (int e = sol_karman_step_bwd_fused(kc, stream, w.svy + (size_t)i * w.st_vy, w.svx + (size_t)i * w.st_vx, re, io.active,
                                                   bcm, io.bc_stride, gvy, gvx, dF, fscale, w.gvy[cur ^ 1], w.gvx[cur ^ 1],
                                                   io.iters_bwd ? io.iters_bwd + (size_t)i * Btot + b0 : nullptr,
-                                                  jobs, fuse ? 10 : 0, wg_per)) return e;
+                                                  jobs, fuse ? 10 : 0, wg_per, dens_ride_bwd ? &ride : nullptr)) return e;
             cur ^= 1;
         } else if (fuse) {
-            if (int e = sol_bww_jobs_launch(stream, jobs, 10, wg_per)) return e;     // step 0 has no adjoint to ride with
+            if (int e = sol_bww_jobs_launch(stream, jobs, 10, wg_per, kc, dens_ride_bwd ? &ride : nullptr)) return e;     // step 0 has no adjoint to ride with
         }
     }
     if (side_used) {      // join the side stream
