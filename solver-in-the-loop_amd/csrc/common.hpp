@@ -18,10 +18,10 @@ int sol_density_chain(const sol_karman_cfg* c, void* stream, int ms, const float
                       long st_vy, long st_vx, const float* inflow, float* d_steps, long st_d, float* d_final);
 // internal (train.hip): last CNN layer (32 -> 2, no activation) fused with `velocity += std * to_staggered(output)` and the
 // l2 loss of the step (karman_train.py:413-447); needs the split-precision kernels (sol_conv_correct_fusable)
-bool sol_conv_correct_fusable(int W, int rows);      // rows = B * H of the CNN's images
+bool sol_conv_correct_fusable(int W, int rows);      // W, rows = B * H of the CNN's images (the transposed ones in transposed CNN mode)
 int sol_conv5x5_correct(void* stream, const float* x, const float* packed, const float* bias, int B, int H, int W,
                         const unsigned* x_absmax, float* vy, float* vx, const float* gt_vy, const float* gt_vx,
-                        float s0, float s1, float l0, float l1, float* loss, float* loss_part);
+                        float s0, float s1, float l0, float l1, float* loss, float* loss_part, int transposed);
 size_t sol_bww_batched_ws_floats(int nseg, int B, int H, int cin, int cout);
 int sol_bww_batched(void* stream, const float* x, const float* dz, float* partial, int nseg, int nseg_layout, int overwrite,
                     long x_seg, long dz_seg, int B, int H, int W, int cin, int cout,
@@ -52,7 +52,24 @@ struct ConvArgs {
     float ls0, ls1;                 // loss scale (std_v)
     float* closs;                   // += 0.5 * sum(((gt - v) / std)^2) over ALL faces, or NULL
     float* closs_part;              // [SOL_LOSS_PART_FLOATS] scratch of the deterministic fold (loss_fold_wg), required with closs
+    int ctr;                        // 1: the CNN runs on the transposed grid -- image row = the solver's x index, pixel = its y index (velocity [B,W+1,H] / [B,W,H+1])
 };
+// correction mode: offsets of the faces of CNN pixel (image row jj, pixel px) inside a simulation's v_y / v_x, and of the face without
+// a correction that this pixel also owns for the loss (v_y row Y, v_x column X of the SOLVER grid), or -1
+struct CorrFaces { int oy, ox, ey, ex; };
+__device__ __forceinline__ CorrFaces corr_faces(int tr, int H, int W, int jj, int px) {
+    CorrFaces f;
+    if (!tr) {          // solver grid Y = H, X = W
+        f.oy = jj * W + px; f.ox = jj * (W + 1) + px;
+        f.ey = jj == H - 1 ? f.oy + W : -1;
+        f.ex = px == W - 1 ? f.ox + 1 : -1;
+    } else {            // solver grid Y = W, X = H: cell (j = px, i = jj)
+        f.oy = px * H + jj; f.ox = px * (H + 1) + jj;
+        f.ey = px == W - 1 ? f.oy + H : -1;
+        f.ex = jj == H - 1 ? f.ox + 1 : -1;
+    }
+    return f;
+}
 // deterministic loss of a launch: one partial per workgroup + the launch's ticket word (at index SOL_LOSS_PART_MAX, zero between launches)
 constexpr int SOL_LOSS_PART_MAX = 2048, SOL_LOSS_PART_FLOATS = SOL_LOSS_PART_MAX + 64;
 constexpr int SOL_AMAX_SLOTS = 256;   // one per workgroup of a 256-WG launch: same-address atomics serialise in L2 (~0.3 us each)

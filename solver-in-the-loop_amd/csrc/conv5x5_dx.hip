@@ -302,23 +302,25 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
         if (a.cvy) {
             if (g == 0) {
                 const int b = a.RPW >= 0 ? (gy >> a.RPW) : gy / H;
-                const int jj = gy - b * H, nVy = (H + 1) * W, nVx = H * (W + 1);
-                float* vy = a.cvy + (size_t)b * nVy + (size_t)jj * W;
-                float* vx = a.cvx + (size_t)b * nVx + (size_t)jj * (W + 1);
-                const float v0 = vy[i] + a.cs0 * o4[0], v1 = vx[i] + a.cs1 * o4[1];
-                vy[i] = v0;
-                vx[i] = v1;
+                const int jj = gy - b * H;
+                const int nVy = a.ctr ? (W + 1) * H : (H + 1) * W, nVx = a.ctr ? W * (H + 1) : H * (W + 1);
+                const CorrFaces f = corr_faces(a.ctr, H, W, jj, i);
+                float* vy = a.cvy + (size_t)b * nVy;
+                float* vx = a.cvx + (size_t)b * nVx;
+                const float v0 = vy[f.oy] + a.cs0 * o4[0], v1 = vx[f.ox] + a.cs1 * o4[1];
+                vy[f.oy] = v0;
+                vx[f.ox] = v1;
                 if (a.gty) {
-                    const float* gt = a.gty + (size_t)b * nVy + (size_t)jj * W;
-                    const float d = (gt[i] - v0) / a.ls0;
+                    const float* gt = a.gty + (size_t)b * nVy;
+                    const float d = (gt[f.oy] - v0) / a.ls0;
                     lsum += 0.5f * d * d;
-                    if (jj == H - 1) { const float d2 = (gt[W + i] - vy[W + i]) / a.ls0; lsum += 0.5f * d2 * d2; }     // v_y row H
+                    if (f.ey >= 0) { const float d2 = (gt[f.ey] - vy[f.ey]) / a.ls0; lsum += 0.5f * d2 * d2; }       // v_y row Y of the solver grid
                 }
                 if (a.gtx) {
-                    const float* gt = a.gtx + (size_t)b * nVx + (size_t)jj * (W + 1);
-                    const float d = (gt[i] - v1) / a.ls1;
+                    const float* gt = a.gtx + (size_t)b * nVx;
+                    const float d = (gt[f.ox] - v1) / a.ls1;
                     lsum += 0.5f * d * d;
-                    if (i == W - 1) { const float d2 = (gt[W] - vx[W]) / a.ls1; lsum += 0.5f * d2 * d2; }             // v_x column W
+                    if (f.ex >= 0) { const float d2 = (gt[f.ex] - vx[f.ex]) / a.ls1; lsum += 0.5f * d2 * d2; }       // v_x column X
                 }
             }
         } else {

@@ -438,20 +438,21 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
         // correction (v_y row H, v_x column W) only enter the loss: the owner of the image's last row / of column W-1 adds them.
         float lsum = 0.f;
         if (tvalid && li < 2) {
-            const int jj = gy - b * H, nVy = (H + 1) * W, nVx = H * (W + 1);
+            const int jj = gy - b * H;
+            const int nV = li == 0 ? (a.ctr ? (W + 1) * H : (H + 1) * W) : (a.ctr ? W * (H + 1) : H * (W + 1));      // faces per simulation
             const float bias = a.bias ? biasv[0] : 0.f;
             const float s = li == 0 ? a.cs0 : a.cs1, ls = li == 0 ? a.ls0 : a.ls1;
-            float* vf = li == 0 ? a.cvy + (size_t)b * nVy + (size_t)jj * W : a.cvx + (size_t)b * nVx + (size_t)jj * (W + 1);
-            const float* gt = li == 0 ? (a.gty ? a.gty + (size_t)b * nVy + (size_t)jj * W : nullptr)
-                                      : (a.gtx ? a.gtx + (size_t)b * nVx + (size_t)jj * (W + 1) : nullptr);
+            float* vf = (li == 0 ? a.cvy : a.cvx) + (size_t)b * nV;
+            const float* gt = li == 0 ? a.gty : a.gtx;
+            if (gt) gt += (size_t)b * nV;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = x0 + wave * 16 + 4 * g + r;
-                const float v = vf[i] + s * (acc[0][r] + bias);
-                vf[i] = v;
-                if (gt) { const float d = (gt[i] - v) / ls; lsum += 0.5f * d * d; }
-                if (gt && li == 0 && jj == H - 1) { const float d = (gt[W + i] - vf[W + i]) / ls; lsum += 0.5f * d * d; }   // v_y row H
-                if (gt && li == 1 && i == W - 1) { const float d = (gt[W] - vf[W]) / ls; lsum += 0.5f * d * d; }            // v_x column W
+                const CorrFaces f = corr_faces(a.ctr, H, W, jj, x0 + wave * 16 + 4 * g + r);
+                const int o = li == 0 ? f.oy : f.ox, e = li == 0 ? f.ey : f.ex;
+                const float v = vf[o] + s * (acc[0][r] + bias);
+                vf[o] = v;
+                if (gt) { const float d = (gt[o] - v) / ls; lsum += 0.5f * d * d; }
+                if (gt && e >= 0) { const float d = (gt[e] - vf[e]) / ls; lsum += 0.5f * d * d; }        // the face without a correction (v_y row Y / v_x column X)
             }
         }
         // workgroup uniform: wave sums -> LDS slots -> the last wave's fixed-order sum -> the launch's fixed-order fold (bit reproducible)

@@ -438,7 +438,7 @@ int net_forward(const sol_train_cfg* c, void* s, const Ws& w, const float* feat,
     }
     if (corr)
         return sol_conv5x5_correct(s, act[10], w.wf[11], w.bias[11], B, Y, X, am(10), corr->vy, corr->vx, corr->gt_vy, corr->gt_vx,
-                                   out_s0(c), out_s1(c), c->std_v0, c->std_v1, corr->loss, corr->loss_part);
+                                   out_s0(c), out_s1(c), c->std_v0, c->std_v1, corr->loss, corr->loss_part, tr ? 1 : 0);
     return sol_conv5x5_scaled(s, act[10], w.wf[11], w.bias[11], nullptr, nullptr, O, B, Y, X, 32, 2, SOL_EPI_NONE, sl, am(10), nullptr);
 }
 
@@ -593,7 +593,7 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         feat_order.restore();
         float* act[11];
         for (int k = 0; k < 11; ++k) act[k] = w.acts + ((size_t)i * 11 + k) * w.cells * 32;
-        if (sol_conv_correct_fusable(X, B * Y)) {            // correction + loss ride in the epilogue of the last CNN layer
+        if (sol_conv_correct_fusable(cX, B * cY)) {            // correction + loss ride in the epilogue of the last CNN layer
             const Correct corr{vycur, vxcur, gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx, io.loss_steps + i, w.loss_part};
             if (int e = net_forward(c, stream, wn, feat_cnn, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS, &corr, w.chain_flags + (size_t)(2 * i) * w.chain_words)) return e;
         } else {
@@ -932,7 +932,7 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
             }
         }
         uint32_t* amax = w.amax_act + (size_t)(i % ROLLOUT_AMAX_SETS) * 11 * SOL_AMAX_SLOTS;
-        if (sol_conv_correct_fusable(X, B * Y)) {
+        if (sol_conv_correct_fusable(tr ? Y : X, tr ? B * X : B * Y)) {
             const Correct corr{tvy, tvx, nullptr, nullptr, nullptr, nullptr};
             if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, amax, &corr, w.chain_flags + (size_t)(i % ROLLOUT_AMAX_SETS) * w.chain_words)) return e;
         } else {
