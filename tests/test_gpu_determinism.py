@@ -224,7 +224,7 @@ def test_l2_loss_against_the_reference_formula(B, Y, X):
     ta, tb = f32(a).requires_grad_(True), f32(b).requires_grad_(True)
     tl = torch.ops.sol.l2_loss(ta, tb, f32(gy), f32(gx), std[0], std[1])
     (3.0 * tl).backward()
-    assert abs(float(tl) - float(ref)) < 2e-6 * float(ref) and rel(ta.grad, 3.0 * a.grad) < 1e-6 and rel(tb.grad, 3.0 * b.grad) < 1e-6
+    assert abs(float(tl.detach()) - float(ref)) < 2e-6 * float(ref) and rel(ta.grad, 3.0 * a.grad) < 1e-6 and rel(tb.grad, 3.0 * b.grad) < 1e-6
 
 
 def test_l2_loss_three_components_and_bad_arguments():

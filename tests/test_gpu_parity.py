@@ -1079,7 +1079,10 @@ def test_options_and_launch_profiler():
     assert abs(float(hl) - float(loss)) < 1e-5 * abs(float(loss))
     names = {k.strip("()"): v for k, v in p.kernels.items()}
     # ten 32->32 layers, forward + backward-data, per unrolled step (B * Y = 256 rows: the one-row-per-workgroup form of the dx kernel)
-    assert sum(v[0] for k, v in names.items() if k.startswith("k_conv5x5_dx")) == ms * (10 + 10)
+    thin = ("k_conv5x5_dx<1, 1>", "k_conv5x5_dx<3, 1>")
+    assert sum(v[0] for k, v in names.items() if k.startswith("k_conv5x5_dx") and k not in thin) == ms * (10 + 10)
+    # ... and its thin-layer form for the 32 -> 2 output layer (correction mode) and the 32 -> 3 data gradient of the first layer
+    assert sum(v[0] for k, v in names.items() if k in thin) == ms + (ms - 1), names
     assert all(c > 0 and t > 0 for c, t in names.values())
     assert lib.sol_version() == _lib.ABI_VERSION
 
@@ -1103,7 +1106,8 @@ def test_persistent_cnn_chain_equals_per_layer_launches():
             with _lib.profile() as p:
                 tr.fwd_bwd(*args, want_final=True, eager=True)
             names = {k.strip("()") for k in p.kernels}
-            assert ("k_cnn_chain" in names) == (mode == 1) and any(n.startswith("k_conv5x5_dx") for n in names) == (mode == 0)
+            thin = ("k_conv5x5_dx<1, 1>", "k_conv5x5_dx<3, 1>")         # the 32 -> 2 / 32 -> 3 layers are per-layer launches in both modes
+            assert ("k_cnn_chain" in names) == (mode == 1) and any(n.startswith("k_conv5x5_dx") and n not in thin for n in names) == (mode == 0)
             assert abs(float(hl) - float(loss)) < 1e-5 * abs(float(loss))
             assert rel(tr.grads, gref) < TOL_GRAD
             ro = sol_amd.SolRollout(net, tr.masks, B, Y, X, g.dx, std_v, o.STD_RE)
