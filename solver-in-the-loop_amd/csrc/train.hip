@@ -910,15 +910,31 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
     for (int k = 0; k < 11; ++k) act[k] = w.acts + (size_t)(k % 3) * w.cells * 32;
     // the state ping-pongs between the caller's buffers and the workspace (no copy-back per step); an odd step count ends
     // with one copy into the caller's buffers
+    // The passive density leaves the solver kernel's critical path as in the training unroll (12 us of a 48 us launch at B = 1): the
+    // advection of step i-1 -- it only needs that step's post-diffusion velocity, kept in two slots (the gradient buffers of the
+    // training workspace are free here) -- rides in the solver launch of step i as B extra workgroups (k_karman_fwd_dens), the last
+    // one is its own small launch behind the loop.  Same buffers, same values.
+    const bool dens_ride = sol_karman_bwd_fusable(kc) && sol_opt().density_mode == 0;
     for (int i = 0; i < nsteps; ++i) {
         float* sd = (i & 1) ? w.d : d;   float* svy = (i & 1) ? w.vy : vy;   float* svx = (i & 1) ? w.vx : vx;
         float* td = (i & 1) ? d : w.d;   float* tvy = (i & 1) ? vy : w.vy;   float* tvx = (i & 1) ? vx : w.vx;
         const bool tr = cnn_transposed(Y, X);
         {
             FeatOrder feat_order(tr);       // transposed CNN mode: features straight in the CNN's cell order
-            if (int e = sol_karman_step_fwd(kc, stream, sd, svy, svx, re, active, inflow, velBCy, velBCyMask, bc_batch_stride,
-                                            td, tvy, tvx, nullptr, nullptr, w.feat, fscale,
-                                            iters ? iters + (size_t)i * B : nullptr)) return e;
+            int32_t* it_i = iters ? iters + (size_t)i * B : nullptr;
+            if (!dens_ride) {
+                if (int e = sol_karman_step_fwd(kc, stream, sd, svy, svx, re, active, inflow, velBCy, velBCyMask, bc_batch_stride,
+                                                td, tvy, tvx, nullptr, nullptr, w.feat, fscale, it_i)) return e;
+            } else if (i == 0) {
+                if (int e = sol_karman_step_fwd(kc, stream, sd, svy, svx, re, active, inflow, velBCy, velBCyMask, bc_batch_stride,
+                                                nullptr, tvy, tvx, w.gvy[0], w.gvx[0], w.feat, fscale, it_i)) return e;
+            } else {
+                float* psd = ((i - 1) & 1) ? w.d : d;           // density in / out of step i-1 (the buffers it would have used itself)
+                float* ptd = ((i - 1) & 1) ? d : w.d;
+                if (int e = sol_karman_step_fwd_dens(kc, stream, svy, svx, re, active, inflow, velBCy, velBCyMask, bc_batch_stride, tvy, tvx,
+                                                     w.gvy[i & 1], w.gvx[i & 1], w.feat, fscale, it_i,
+                                                     psd, w.gvy[(i - 1) & 1], w.gvx[(i - 1) & 1], ptd)) return e;
+            }
         }
         if (i % ROLLOUT_AMAX_SETS == 0) {
             MemList z;
@@ -941,6 +957,10 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
                                (const float*)nullptr, (const float*)nullptr, out_s0(cfg), out_s1(cfg), cfg->std_v0, cfg->std_v1, (float*)nullptr, (float*)nullptr, B, Y, X, tr ? 1 : 0);
             SOL_LAUNCH_CHECK();
         }
+    }
+    if (dens_ride && nsteps > 0) {      // the density of the last step
+        const int k = nsteps - 1;
+        if (int e = sol_density_step(kc, stream, (k & 1) ? w.d : d, w.gvy[k & 1], w.gvx[k & 1], inflow, (k & 1) ? d : w.d)) return e;
     }
     if (nsteps & 1) {
         MemList c;
