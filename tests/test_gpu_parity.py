@@ -287,6 +287,38 @@ def test_train_step_c2_config_and_adam(clip):
     assert rel(upd, upd_ref) < 1e-3
 
 
+@pytest.mark.parametrize("B", [3, 12])
+def test_transposed_cnn_recipe_paths_against_oracle(B):
+    """64x32 (the reference's own recipe: the CNN runs on the transposed images) through everything round 4 folded into its launches:
+    features / feature gradients in the CNN's cell order straight from the solver kernels, the correction + loss epilogue in transposed
+    cell order (B = 3: the one-row thin form of the dx kernel; B = 12: a chip-filling launch, k_conv5x5_sb<1, 2>), weight gradients and
+    the passive density riding in the solver-adjoint launches (k_karman_bwd_bww_small) -- loss, per-step losses, gradient and the final
+    state (density included) against the float64 oracle, and the kernel set that ran."""
+    from sol_amd import _lib
+    Y, X, ms = 64, 32, 2
+    g, d, vy, vx, re, gts, params, std_v, loss = _oracle_problem(B, Y, X, ms)
+    net, tr = _trainer_from(params, g, B, Y, X, ms, std_v)
+    args = (f32(d), f32(vy), f32(vx), f32(re), f32(torch.stack([s[1] for s in gts])), f32(torch.stack([s[2] for s in gts])))
+    hl = tr.fwd_bwd(*args, want_final=True)
+    gref = torch.cat([p.grad.reshape(-1) for p in params])
+    assert abs(float(hl) - float(loss)) < 1e-5 * abs(float(loss))
+    assert rel(tr.grads, gref) < TOL_GRAD
+    with torch.no_grad():
+        rd, ry, rx = d, vy, vx
+        for _ in range(ms):
+            rd, ry, rx = o.karman_step(rd, ry, rx, re, g)
+            cy, cx = o.correction([p.detach() for p in params], ry, rx, re, std_v, o.STD_RE)
+            ry, rx = ry + cy, rx + cx
+    assert rel(tr.final[1], ry) < TOL_FIELD and rel(tr.final[2], rx) < TOL_FIELD and rel(tr.final[0], rd) < TOL_FIELD
+    with _lib.profile() as p:
+        tr.fwd_bwd(*args, want_final=True, eager=True)
+    names = {k.strip("()"): v[0] for k, v in p.kernels.items()}
+    assert names.get("k_karman_bwd_bww_small") == ms and "k_density_chain" not in names and "k_correct_loss" not in names, names
+    assert not any(k.startswith("k_transpose_cells") for k in names), names
+    thin_fwd = "k_conv5x5_dx<1, 1>" if B == 3 else "k_conv5x5_sb<1, 2>"
+    assert names.get(thin_fwd) == ms + (ms - 1), names              # correction-mode output layer + the 32 -> 3 data gradient
+
+
 _ORACLE_CACHE = {}
 
 
