@@ -17,8 +17,16 @@
 // of one pixel: the epilogue stores 16-byte pieces straight from registers -- no LDS transposition, no epilogue barrier, and the
 // residual / activation-reference operands are prefetched into registers in the same layout.
 //
+// Forms (template arguments R, COT, SPLIT; chosen by sol_conv_dx_launch, option conv_dx):
+//   <3, 2>        the form above: launches that fill the chip with three-row workgroups (128x64, B = 6: 256 workgroups);
+//   <1, 2>        one row per workgroup for small launches; five LDS rows leave room for ALL five weight sets (resident weights: one
+//                 barrier behind the prologue's, phases 1..4 barrier free);
+//   <1, 1, true>  ... as two half-channel workgroups per tile (each stages 50 of the 100 KB of weights; waves 4..7 stage only);
+//   <R, 1>        thin layers (<= 16 output channels: the 32 -> 2 output layer in correction mode -- velocity update + l2 loss in the
+//                 epilogue --, the 32 -> 3 data gradient); used in one-row launches, k_conv5x5_sb<1, 2> is faster in chip-filling ones.
+//
 // Replaces keras.layers.Conv2D(32, 5, padding='same') (+ bias, LeakyReLU, residual add) of model_mars_moon
-// (/root/reference/karman-2d/karman_train.py:101-138) for the ten 32 -> 32 layers, forward and backward-data.
+// (/root/reference/karman-2d/karman_train.py:101-138) for the ten 32 -> 32 layers and the output layer, forward and backward-data.
 #include "split_kernels.hpp"
 
 namespace {
@@ -60,7 +68,7 @@ template <int R, int COT, bool SPLIT = false>
 __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ arg_x, const void* __restrict__ arg_wsh, const unsigned* __restrict__ arg_xmax,
                                                       int nrows, int arg_H, int arg_W, int arg_tiles_x, int arg_hshift, ConvArgs a) {
     // What the prologue needs before its first request -- the three operand pointers and the tile geometry -- are LEADING scalar
-    // kernel arguments: the file is compiled with -amdgpu-kernarg-preload-count=13, so the command processor delivers them in SGPRs
+    // kernel arguments: the file is compiled with -amdgpu-kernarg-preload-count=11, so the command processor delivers them in SGPRs
     // with the wave (gfx950 kernel-argument preload) and no scalar-memory round trip stands in front of the requests; the rest
     // of ConvArgs (epilogue operands) is fetched lazily in their shadow.
     a.x = arg_x; a.wsh = arg_wsh; a.xmax = arg_xmax; a.H = arg_H; a.W = arg_W; a.tiles_x = arg_tiles_x; a.RPW = arg_hshift;
