@@ -735,10 +735,11 @@ def test_shard_gradients_sum_to_the_large_batch_gradient():
     assert rel(acc, full.grads) < 1e-5
 
 
-@pytest.mark.parametrize("Y,X,n", [(64, 32, 3), (64, 32, 10), (128, 64, 2)])
+@pytest.mark.parametrize("Y,X,n", [(64, 32, 3), (64, 32, 10), (128, 64, 2), (128, 64, 3), (128, 64, 1)])
 def test_rollout_against_oracle(Y, X, n):
     """odd / even step counts (the state ping-pongs between the caller's buffers and the workspace), more steps than absmax
-    slot sets, and the 128x64 path whose last CNN layer applies the correction itself"""
+    slot sets, and the 128x64 path whose last CNN layer applies the correction itself and whose passive density rides one step
+    behind in the solver launches (even, odd and a single step: the last advection is its own launch)"""
     B = 1
     g = o.geometry(Y, X)
     d, vy, vx = o.synthetic_state(B, Y, X, 21)
