@@ -519,6 +519,9 @@ def main():
             # the same step with every convolution on v_mfma_f32_*_f32 (no operand splits), that kernel's fraction of the fp32 matrix
             # peak, and the fused advect + pressure launch's fraction of the HBM peak at this batch size (measured k)
             "strict_fp32_ms_per_step": None, "strict_fp32_frac": None, "solver_step_frac": roof_solver["frac"] if roof_solver else None,
+            # ... and the other shapes of the same path that the extras time (filled in below): the reference's own recipe (64x32, B = 3,
+            # SOL-32), the no-grad roll-out at B = 1 and at the bench batch, one karman-3d SOL-16 step
+            "recipe_64x32_b3_ms_per_step": None, "rollout_b1_us_per_step": None, "rollout_b6_us_per_step": None, "karman3d_sol16_ms_per_step": None,
             "valid": bool(valid), "rank_skew": rank_skew, "pre_warmup_steps": max(0, args.prewarm),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"split": "f32 (fp16x3 split MFMA in 32-ch convs)", "bf16x6": "f32 (bf16x6 split MFMA in 32-ch convs)", "fp32": "f32"}[args.precision],
@@ -644,11 +647,15 @@ def main():
                     sol_amd._lib.set_option("cnn_persistent", 0)
             if "b1" in out["rollout"] and "us_per_step" in out["rollout"]["b1"]:
                 out["rollout"].update({k: out["rollout"]["b1"][k] for k in ("sim_steps_per_s", "batch", "steps", "us_per_step")})
+            out["recipe_64x32_b3_ms_per_step"] = out.get("reference_recipe_64x32_b3", {}).get("ms_per_step")
+            out["rollout_b1_us_per_step"] = out["rollout"].get("b1", {}).get("us_per_step")
+            out["rollout_b6_us_per_step"] = out["rollout"].get("b6", {}).get("us_per_step")
         if not args.no_extras and world == 1:
             try:
                 out["karman3d"] = karman3d_leg(sol_amd, dev)
             except Exception as e:
                 out["karman3d"] = {"error": str(e)}
+            out["karman3d_sol16_ms_per_step"] = (out["karman3d"].get("train_sol16") or {}).get("ms_per_step")
         if k3d_dp is not None:
             out["karman3d_data_parallel"] = k3d_dp
         if world == 1 and not args.no_cpu_baseline:
