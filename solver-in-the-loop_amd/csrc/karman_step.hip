@@ -702,6 +702,14 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
 #if SOL_FD_MFMA
     float bx[32];
     fd_load_bx(F.Qx, w, bx);             // x-transform operand + the eigenvalue reciprocals: in flight behind the y transform
+    float* XP8 = B0 + 4096;              // [8 waves][256] partial window values (MFMA form)
+    // window products on v_mfma_f32_16x16x4_f32 (wave = 16 rows m; B operand lane: column lane & 15, k = lane >> 4).  Two request groups, so
+    // that no more than 20 extra registers are live across the transforms: what the first two window phases need here, the rest behind them.
+    float qxw[16], qyk[4];               // QxW[c][i'] (u = T2 QxW);  window rows of Qy as A operand [16 jw x 4 m] of x0w = Qy[win, :] u (this wave's K slice)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) qxw[t] = F.QxW[(4 * t + (lane >> 4)) * FD_WIN + (lane & 15)];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qyk[t] = F.Qy[(size_t)(F.wy0 + (lane & 15)) * FD_Y + 16 * w + 4 * t + (lane >> 4)];
 #pragma unroll
     for (int e = 0; e < 16; ++e) il[e] = F.ilT[col[e] * FD_Y + m];
     __syncthreads();
@@ -740,6 +748,18 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
     FD_STAMP(9);
 
     // ---- window values of G b:  u = T2 Qx[:, win] ;  x0w = Qy[win, :] u ----------------------
+#if SOL_FD_MFMA
+    {
+        typedef float fd_f4 __attribute__((ext_vector_type(4)));
+        fd_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* ap = B1 + (16 * w + (lane & 15)) * FD_LD + (lane >> 4);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * t], qxw[t], acc, 0, 0, 0);
+        float* up = U + (16 * w + 4 * (lane >> 4)) * FD_ULD + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) up[r * FD_ULD] = acc[r];
+    }
+#else
     {
         f2 u0 = {0.f, 0.f}, u1 = {0.f, 0.f};
         fd_cfp Qc = (fd_cfp)(F.QxW + 4 * cb);           // QxW[c][i'] = Qx[c][wx0 + i']: 64 B per c
@@ -755,8 +775,41 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
         float* up = U + m * FD_ULD + 4 * cb;
         up[0] = u0.x; up[1] = u0.y; up[2] = u1.x; up[3] = u1.y;
     }
+#endif
     __syncthreads();
     FD_STAMP(10);
+#if SOL_FD_MFMA
+    {
+        typedef float fd_f4 __attribute__((ext_vector_type(4)));
+        fd_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* bp = U + (16 * w + (lane >> 4)) * FD_ULD + (lane & 15);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qyk[t], bp[4 * t * FD_ULD], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) XP8[w * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
+        if (tid < 256) W2[tid] = 0.f;
+    }
+    // second request group: Qx[wx0 + i'][c] (spectral coefficients of the correction) and the window rows of Qy as A operand [16 m x 4 jw]
+    // of t2w = Qy[:, win] W2 -- in flight behind the gather and the K' product
+    float qxr[4][4], qym[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) qxr[ct][t] = F.Qx[(size_t)(F.wx0 + 4 * t + (lane >> 4)) * FD_X + 16 * ct + (lane & 15)];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qym[t] = F.Qy[(size_t)(F.wy0 + 4 * t + (lane >> 4)) * FD_Y + 16 * w + (lane & 15)];
+    __syncthreads();
+    FD_STAMP(11);
+    if (tid < F.SP) {
+        const int si = F.sidx[tid];
+        float v = 0.f;
+        if (si >= 0) {
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) v += XP8[ww * 256 + si];
+        }
+        XS[tid] = v;
+    }
+#else
     {
         const int h = tid >> 8, t = tid & 255, jw = t >> 4, iw = t & 15;
         const float* qrow = F.Qy + (size_t)(F.wy0 + jw) * FD_Y + 64 * h;
@@ -773,6 +826,7 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
         const int si = F.sidx[tid];
         XS[tid] = si >= 0 ? XP[si] + XP[256 + si] : 0.f;
     }
+#endif
     __syncthreads();
     // ---- c = K' x0_S  (two halves of the sum), scattered with a minus sign into the window -----
     if (tid < 2 * F.SP) {
@@ -792,6 +846,18 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
     }
     __syncthreads();
     // ---- spectral coefficients of the correction: t2w = Qy[:, win] W2 ; T2 += (t2w Qx[win, :]) / lam
+#if SOL_FD_MFMA
+    {
+        typedef float fd_f4 __attribute__((ext_vector_type(4)));
+        fd_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* bp = W2 + (lane >> 4) * FD_WIN + (lane & 15);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qym[t], bp[4 * t * FD_WIN], acc, 0, 0, 0);
+        float* up = U + (16 * w + 4 * (lane >> 4)) * FD_ULD + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) up[r * FD_ULD] = acc[r];
+    }
+#else
     {
         f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
         float qw[FD_WIN];
@@ -809,8 +875,37 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
         float* up = U + m * FD_ULD + 4 * cb;
         up[0] = a0.x; up[1] = a0.y; up[2] = a1.x; up[3] = a1.y;
     }
+#endif
     __syncthreads();
     FD_STAMP(13);
+#if SOL_FD_MFMA
+    {
+        // S[m][c] = sum_i' t2w[m][i'] Qx[wx0+i'][c] on the matrix cores (wave = rows 16w .. 16w+15, four 16-column tiles) -> XS2 (= B0 behind
+        // the small scratch arrays ... B0 is free but U / W2 live in its head: the products go to B1's free twin rows, see below)
+        typedef float fd_f4 __attribute__((ext_vector_type(4)));
+        fd_f4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = (fd_f4){0.f, 0.f, 0.f, 0.f};
+        const float* ap = U + (16 * w + (lane & 15)) * FD_ULD + (lane >> 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float av = ap[4 * t];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, qxr[ct][t], acc[ct], 0, 0, 0);
+        }
+        __syncthreads();                 // every read of U (t2w) is done: S may overwrite B0
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) B0[(16 * w + 4 * (lane >> 4) + r) * FD_LD + 16 * ct + (lane & 15)] = acc[ct][r];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            t2[e] += il[e] * B0[m * FD_LD + col[e]];
+            B1[m * FD_LD + col[e]] = t2[e];
+        }
+    }
+#else
     {
         // T2[m][c] += il * sum_i' t2w[m][i'] Qx[wx0+i'][c] for this thread's 16 columns (8 contiguous + their 8 mirrors)
         f2 al[4], ah[4];
@@ -839,6 +934,7 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
 #pragma unroll
         for (int e = 0; e < 16; ++e) B1[m * FD_LD + col[e]] = t2[e];
     }
+#endif
     __syncthreads();
     FD_STAMP(14);
     // ---- inverse transform: x = Qy (T2 Qx), written to B1 as [128][64] for the caller ---------------

@@ -321,14 +321,32 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
             }
     }
     __syncthreads();
-    {   // all 512 threads move 16-byte pieces (4 consecutive co of one ci) into the block's partial slice
+    {   // all 512 threads move 16-byte pieces (4 consecutive co of one ci) into the block's partial slice.  Accumulating launches first
+        // request ALL of the thread's thirteen old pieces (the slice was written an unrolled step ago: HBM-cold), then add and store --
+        // as a load-add-store loop the compiler kept one or two requests in flight (the accumulator registers are free by now)
         float* pw = a.partial + (size_t)blk * (25 * 1024);
-        for (int e = tid; e < 4 * 25 * 64; e += 512) {
+        constexpr int NP = (4 * 25 * 64 + 511) / 512;       // 13 (the last one for threads < 256)
+        auto dst_of = [&](int e) {
             const int c4 = e & 3, row = (e >> 2) & 15, tp = (e >> 6) % 25, wt = e / (25 * 64);      // wt = (mt, nt) tile
-            const float4 v = *reinterpret_cast<const float4*>(&red[(wt * 25 + tp) * 256 + row * 16 + c4 * 4]);
-            float4* dst = reinterpret_cast<float4*>(&pw[(tp * 32 + 16 * (wt & 1) + row) * 32 + 16 * (wt >> 1) + c4 * 4]);
-            if (a.overwrite) *dst = v;
-            else { const float4 o = *dst; *dst = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w); }
+            return reinterpret_cast<float4*>(&pw[(tp * 32 + 16 * (wt & 1) + row) * 32 + 16 * (wt >> 1) + c4 * 4]);
+        };
+        float4 old[NP];
+        if (!a.overwrite) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) old[k] = *dst_of(min(tid + k * 512, 4 * 25 * 64 - 1));
+        } else {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) old[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int e = tid + k * 512;
+            if (e < 4 * 25 * 64) {
+                const int c4 = e & 3, row = (e >> 2) & 15, tp = (e >> 6) % 25, wt = e / (25 * 64);
+                const float4 v = *reinterpret_cast<const float4*>(&red[(wt * 25 + tp) * 256 + row * 16 + c4 * 4]);
+                *dst_of(e) = make_float4(old[k].x + v.x, old[k].y + v.y, old[k].z + v.z, old[k].w + v.w);
+            }
         }
     }
     __syncthreads();
