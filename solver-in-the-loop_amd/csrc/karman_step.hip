@@ -1036,7 +1036,35 @@ __device__ __forceinline__ float* fd_solve_small(const float* __restrict__ blob,
     }
     __syncthreads();
     // C tile loop: MODE 0: C[m][n] = v;  1: Ct[n][m] = v;  2: Ct[n][m] = v * S[n][m];  3: Ct[n][m] += v * S[n][m]
+    // Grids whose sides are multiples of 16 (64x32, 32x16): the products run as 16 x 16 tiles of v_mfma_f32_16x16x4_f32, one tile per wave
+    // and trip -- A operand lane (m = lane & 15, k = lane >> 4) = At[k][m0 + m], B operand = Bm[k][n0 + n], both contiguous LDS reads; tile
+    // element r of a lane: row m0 + 4 (lane >> 4) + r, column n0 + (lane & 15).  The 4 x 4 register-tile form below kept half of the 256
+    // threads busy in the large products and spent two LDS reads per 16 multiply-adds.
+    const bool mfma_ok = SOL_FD_MFMA && (Y & 15) == 0 && (X & 15) == 0;
     auto mm = [&](const float* At, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K, int mode, const float* S) {
+        if (mfma_ok) {
+            typedef float fd_f4 __attribute__((ext_vector_type(4)));
+            const int lane = tid & 63, wv = tid >> 6, nw = T >> 6, tn16 = N >> 4, tiles16 = (M >> 4) * tn16;
+            for (int t = wv; t < tiles16; t += nw) {
+                const int m0 = (t / tn16) << 4, n0 = (t % tn16) << 4;
+                const float* ap = At + (lane >> 4) * lda + m0 + (lane & 15);
+                const float* bp = Bm + (lane >> 4) * ldb + n0 + (lane & 15);
+                fd_f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+                for (int k = 0; k < K; k += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[k * lda], bp[k * ldb], acc, 0, 0, 0);
+                const int n = n0 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + 4 * (lane >> 4) + r;
+                    if (mode == 0) C[m * ldc + n] = acc[r];
+                    else if (mode == 1) C[n * ldc + m] = acc[r];
+                    else if (mode == 2) C[n * ldc + m] = acc[r] * S[n * ldc + m];
+                    else if (mode == 3) C[n * ldc + m] += acc[r] * S[n * ldc + m];
+                    else C[m * ldc + n] += acc[r] * S[m * ldc + n];
+                }
+            }
+            return;
+        }
         const int tn = N >> 2, tiles = (M >> 2) * tn;
         for (int t = tid; t < tiles; t += T) {
             const int m0 = (t / tn) << 2, n0 = (t % tn) << 2;
