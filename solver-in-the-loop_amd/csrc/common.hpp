@@ -21,7 +21,7 @@ int sol_density_chain(const sol_karman_cfg* c, void* stream, int ms, const float
 bool sol_conv_correct_fusable(int W, int rows);      // W, rows = B * H of the CNN's images (the transposed ones in transposed CNN mode)
 int sol_conv5x5_correct(void* stream, const float* x, const float* packed, const float* bias, int B, int H, int W,
                         const unsigned* x_absmax, float* vy, float* vx, const float* gt_vy, const float* gt_vx,
-                        float s0, float s1, float l0, float l1, float* loss, float* loss_part, int transposed);
+                        float s0, float s1, float l0, float l1, unsigned long long* loss_acc, int transposed);
 size_t sol_bww_batched_ws_floats(int nseg, int B, int H, int cin, int cout);
 int sol_bww_batched(void* stream, const float* x, const float* dz, float* partial, int nseg, int nseg_layout, int overwrite,
                     long x_seg, long dz_seg, int B, int H, int W, int cin, int cout,
@@ -50,8 +50,7 @@ struct ConvArgs {
     const float *gty, *gtx;         // ground-truth frames for the l2 loss, or NULL
     float cs0, cs1;                 // correction scale (out.std, = std_v unless --pretf)
     float ls0, ls1;                 // loss scale (std_v)
-    float* closs;                   // += 0.5 * sum(((gt - v) / std)^2) over ALL faces, or NULL
-    float* closs_part;              // [SOL_LOSS_PART_FLOATS] scratch of the deterministic fold (loss_fold_wg), required with closs
+    unsigned long long* closs;      // exact accumulator ([SOL_LOSS_ACC_WORDS], loss_add_exact) of 0.5 * sum(((gt - v) / std)^2) over ALL faces, or NULL
     int ctr;                        // 1: the CNN runs on the transposed grid -- image row = the solver's x index, pixel = its y index (velocity [B,W+1,H] / [B,W,H+1])
 };
 // correction mode: offsets of the faces of CNN pixel (image row jj, pixel px) inside a simulation's v_y / v_x, and of the face without
@@ -70,8 +69,6 @@ __device__ __forceinline__ CorrFaces corr_faces(int tr, int H, int W, int jj, in
     }
     return f;
 }
-// deterministic loss of a launch: one partial per workgroup + the launch's ticket word (at index SOL_LOSS_PART_MAX, zero between launches)
-constexpr int SOL_LOSS_PART_MAX = 2048, SOL_LOSS_PART_FLOATS = SOL_LOSS_PART_MAX + 64;
 constexpr int SOL_AMAX_SLOTS = 256;   // one per workgroup of a 256-WG launch: same-address atomics serialise in L2 (~0.3 us each)
 // backward-weight arguments
 struct BwArgs {
@@ -254,33 +251,31 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// Bit-reproducible sum over a launch (the per-step l2 loss).  Called by ONE full wave of every workgroup with the workgroup's
-// sum `wg_sum` (wave uniform; itself formed in a fixed order): the partial goes to part[blockIdx.x] and the workgroup draws a
-// ticket; the LAST workgroup adds all partials in workgroup order (64 strided chains, then the fixed butterfly of wave_sum)
-// and adds the total to *loss.  No floating-point atomics between workgroups -- with those the sum depended on the order the
-// workgroups happened to finish in (equal to round-off only; the training step is otherwise bit for bit reproducible).
-// The final add IS an atomic: with the option `streams` > 1 several launches (sub-batches) add to the same word.
-__device__ __forceinline__ void loss_fold_wg(float wg_sum, float* __restrict__ loss, float* __restrict__ part) {
-    const int lane = threadIdx.x & 63;
-    unsigned* ctr = reinterpret_cast<unsigned*>(part + SOL_LOSS_PART_MAX);
-    unsigned last = 0u;
-    if (lane == 0) {
-        __hip_atomic_store(&part[blockIdx.x], wg_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
-    }
-    last = (unsigned)__shfl((int)last, 0, 64);
-    if (!last) return;
-    float t = 0.f;
-    for (int i = lane; i < (int)gridDim.x; i += 64) t += __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    t = wave_sum(t);
-    if (lane == 0) {
-        atomicAdd(loss, t);
-        __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
-    }
+// Bit-reproducible sum over launches (the per-step l2 loss): an EXACT accumulator.  A workgroup's sum s >= 0 (itself formed in a fixed
+// order) is the integer m * 2^(e - 150) (24-bit mantissa m, biased exponent e); it is added as m << (e & 7) to the 64-bit integer
+// acc[e >> 3] (32 buckets of eight binades, units 2^(8 b - 150)): integer addition is exact and associative, so the result does not
+// depend on the order in which workgroups -- or launches, or sub-batch streams -- arrive, and nothing is rounded before the final
+// conversion (k_loss_finish: the buckets in ascending order, in double).  One fire-and-forget atomic per workgroup: no ticket, no
+// fence, nobody waits.  (First form of the round: per-workgroup partials + a release/acquire ticket, the last workgroup folding them
+// in order -- also reproducible, but every workgroup's tail carried an agent-scope release (L2 write-back) and an atomic round trip.)
+// Capacity: m << 7 < 2^31 per addition, 2^32 additions per bucket.
+constexpr int SOL_LOSS_ACC_WORDS = 32;                           // unsigned long long per loss value
+__device__ __forceinline__ void loss_add_exact(float wg_sum, unsigned long long* __restrict__ acc) {
+    const unsigned bits = __float_as_uint(wg_sum);
+    const unsigned e = (bits >> 23) & 0xffu;
+    if ((bits << 1) == 0u || e == 0xffu || (bits >> 31)) return;          // zero (nothing to add); inf / nan / negative: not a loss partial
+    const unsigned long long m = (bits & 0x7fffffu) | (e ? 0x800000u : 0u);
+    const unsigned ee = e ? e : 1u;                              // denormals share the exponent of the smallest normal
+    atomicAdd(&acc[ee >> 3], m << (ee & 7u));
+}
+__device__ __forceinline__ float loss_acc_value(const unsigned long long* __restrict__ acc) {
+    double v = 0.0;
+    for (int b = 0; b < SOL_LOSS_ACC_WORDS; ++b) v += ldexp((double)acc[b], 8 * b - 150);
+    return (float)v;
 }
 // Barrier-free workgroup stage in front of it: every wave (all lanes) calls this with its lanes' sums; `lds` = {wave ticket (zeroed before
 // the kernel's first barrier), pad, pad, pad, one slot per wave}.  The wave that draws the last ticket adds the slots in wave order.
-__device__ __forceinline__ void loss_publish_last(float lsum, float* __restrict__ loss, float* __restrict__ part, unsigned* lds) {
+__device__ __forceinline__ void loss_publish_last(float lsum, unsigned long long* __restrict__ acc, unsigned* lds) {
     lsum = wave_sum(lsum);
     const int nw = blockDim.x >> 6;
     unsigned last = 0u;
@@ -294,7 +289,7 @@ __device__ __forceinline__ void loss_publish_last(float lsum, float* __restrict_
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     float s = 0.f;
     for (int w = 0; w < nw; ++w) s += reinterpret_cast<volatile float*>(lds)[4 + w];
-    loss_fold_wg(s, loss, part);
+    if ((threadIdx.x & 63) == 0) loss_add_exact(s, acc);
 }
 
 // XCD-aware tile order: the hardware deals consecutive workgroup ids round robin to the 8 XCDs (each with its own L2), so

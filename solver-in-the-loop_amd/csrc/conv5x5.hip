@@ -1100,15 +1100,15 @@ const void* sol_conv_packed_wsh(const float* packed, int cout) {
 }
 
 bool sol_conv_correct_fusable(int W, int rows) {
-    // (the loss fold holds one partial per workgroup: at most SOL_LOSS_PART_MAX workgroups of three rows, rounded up to a multiple of 8)
-    return sol_opt().conv_precision == 0 && sol_opt().correct_fuse && W % 64 == 0 && ((rows + 2) / 3) * (W / 64) + 8 <= SOL_LOSS_PART_MAX;
+    (void)rows;
+    return sol_opt().conv_precision == 0 && sol_opt().correct_fuse && W % 64 == 0;
 }
 
 int sol_conv5x5_correct(void* stream, const float* x, const float* packed, const float* bias, int B, int H, int W,
                         const unsigned* x_absmax, float* vy, float* vx, const float* gt_vy, const float* gt_vx,
-                        float s0, float s1, float l0, float l1, float* loss, float* loss_part, int transposed) {
+                        float s0, float s1, float l0, float l1, unsigned long long* loss_acc, int transposed) {
     if (int e = check_shape(B, H, W, 32, 2)) return e;
-    SOL_REQUIRE(x && packed && x_absmax && vy && vx && (!loss || loss_part) && sol_conv_correct_fusable(W, B * H), "sol_conv5x5_correct: bad arguments");
+    SOL_REQUIRE(x && packed && x_absmax && vy && vx && sol_conv_correct_fusable(W, B * H), "sol_conv5x5_correct: bad arguments");
     if (int e = sol_init_conv_kernels()) return e;
     ConvArgs a{};
     a.x = x; a.wp = packed; a.bias = bias; a.B = B; a.H = H; a.W = W; a.CO = 2; a.epi = SOL_EPI_NONE;
@@ -1116,7 +1116,7 @@ int sol_conv5x5_correct(void* stream, const float* x, const float* packed, const
     a.wsb = packed + (size_t)25 * 32 * pad_out(2);
     a.wsh = packed + (size_t)25 * 32 * pad_out(2) + sol_conv_sb_packed_floats(pad_out(2));
     a.xmax = x_absmax;
-    a.cvy = vy; a.cvx = vx; a.gty = gt_vy; a.gtx = gt_vx; a.cs0 = s0; a.cs1 = s1; a.ls0 = l0; a.ls1 = l1; a.closs = loss; a.closs_part = loss_part; a.ctr = transposed ? 1 : 0;
+    a.cvy = vy; a.cvx = vx; a.gty = gt_vy; a.gtx = gt_vx; a.cs0 = s0; a.cs1 = s1; a.ls0 = l0; a.ls1 = l1; a.closs = loss_acc; a.ctr = transposed ? 1 : 0;
     return sol_conv_sb_launch((hipStream_t)stream, a, 1, B * H * (W / 64));
 }
 

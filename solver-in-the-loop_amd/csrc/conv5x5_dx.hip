@@ -477,8 +477,8 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
 #pragma unroll
             for (int j = 0; j < R; ++j) epilogue_thin(j);
         }
-        // workgroup uniform: wave sums -> LDS slots -> the last wave's fixed-order sum -> the launch's fixed-order fold (bit reproducible)
-        if (a.cvy && a.closs) loss_publish_last(lsum, a.closs, a.closs_part, amax_lds + 2);
+        // workgroup uniform: wave sums -> LDS slots -> the last wave's fixed-order sum -> ONE exact integer add per workgroup (loss_add_exact: bit reproducible)
+        if (a.cvy && a.closs) loss_publish_last(lsum, a.closs, amax_lds + 2);
     }
     DX_STAMP(9);
     if (a.ymax) amax_publish_last(vmax, a.ymax, amax_lds);

@@ -455,8 +455,8 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
                 if (gt && e >= 0) { const float d = (gt[e] - vf[e]) / ls; lsum += 0.5f * d * d; }        // the face without a correction (v_y row Y / v_x column X)
             }
         }
-        // workgroup uniform: wave sums -> LDS slots -> the last wave's fixed-order sum -> the launch's fixed-order fold (bit reproducible)
-        if (a.closs) loss_publish_last(lsum, a.closs, a.closs_part, reinterpret_cast<unsigned*>(smem_sb + AMAX_LDS) + 2);
+        // workgroup uniform: wave sums -> LDS slots -> the last wave's fixed-order sum -> ONE exact integer add per workgroup (loss_add_exact: bit reproducible)
+        if (a.closs) loss_publish_last(lsum, a.closs, reinterpret_cast<unsigned*>(smem_sb + AMAX_LDS) + 2);
     } else if (tvalid) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {

@@ -143,7 +143,7 @@ inline int64_t layer_koff(int l) {
 // ---- velocity += CNN correction (to_staggered pad, karman_train.py:88-90,413-426) + l2 loss ----
 __global__ void k_correct_loss(float* __restrict__ vy, float* __restrict__ vx, const float* __restrict__ O,
                                const float* __restrict__ gt_vy, const float* __restrict__ gt_vx,
-                               float s0, float s1, float l0, float l1, float* __restrict__ loss, float* __restrict__ loss_part, int B, int Y, int X, int tr) {
+                               float s0, float s1, float l0, float l1, unsigned long long* __restrict__ loss, int B, int Y, int X, int tr) {
     __shared__ float red[64];
     const int N = Y * X, nVy = (Y + 1) * X, nVx = Y * (X + 1), XP = X + 1;
     auto cell = [&](int j, int i) { return tr ? i * Y + j : j * X + i; };      // O is [B][X][Y][2] in transposed CNN mode
@@ -166,10 +166,16 @@ __global__ void k_correct_loss(float* __restrict__ vy, float* __restrict__ vx, c
             if (gt_vx) { const float d = (gt_vx[e2] - v) / l1; l += 0.5f * d * d; }
         }
     }
-    if (loss) {                                    // fixed-order fold over the launch's workgroups (bit reproducible; loss_fold_wg)
+    if (loss) {                                    // one exact integer add per workgroup (bit reproducible; loss_add_exact)
         const float s = block_sum(l, red, 0);
-        if (threadIdx.x < 64) loss_fold_wg(s, loss, loss_part);
+        if (threadIdx.x == 0) loss_add_exact(s, loss);
     }
+}
+
+// the per-step losses out of their exact accumulators (one thread per unrolled step)
+__global__ void k_loss_finish(const unsigned long long* __restrict__ acc, float* __restrict__ loss_steps, int ms) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ms) loss_steps[i] = loss_acc_value(acc + (size_t)i * SOL_LOSS_ACC_WORDS);
 }
 
 // ---- backward seed: g_prd = g_next + (prd - gt)/(std^2 msteps);  dO = std * g_prd on cells ----
@@ -331,7 +337,7 @@ struct Ws {
     float *part[NL];
     size_t part_floats[NL];
     float *adam_scale;
-    float *loss_part;              // [SOL_LOSS_PART_FLOATS] scratch of the per-step loss fold
+    unsigned long long* loss_acc;  // [msteps][SOL_LOSS_ACC_WORDS] exact accumulators of the per-step losses (loss_add_exact)
     size_t total_floats;
 };
 
@@ -375,7 +381,7 @@ size_t carve_ws(const sol_train_cfg* c, float* base, Ws& w, bool training) {
         w.part[l] = take(w.part_floats[l]);
     }
     w.adam_scale = take(64);
-    w.loss_part = take(SOL_LOSS_PART_FLOATS);          // per-workgroup partials + ticket of the step loss (loss_fold_wg)
+    w.loss_acc = reinterpret_cast<unsigned long long*>(take((size_t)ms * SOL_LOSS_ACC_WORDS * 2));   // 64-bit words
     w.total_floats = off;
     return off * sizeof(float);
 }
@@ -412,7 +418,7 @@ struct FeatOrder {
 };
 
 // corr != nullptr: the last layer applies its output to the velocity and accumulates the loss (sol_conv5x5_correct) instead of storing O
-struct Correct { float *vy, *vx; const float *gt_vy, *gt_vx; float *loss, *loss_part; };
+struct Correct { float *vy, *vx; const float *gt_vy, *gt_vx; unsigned long long* loss; };
 int net_forward(const sol_train_cfg* c, void* s, const Ws& w, const float* feat, float* const* act, float* O, uint32_t* amax, const Correct* corr = nullptr,
                 uint32_t* chain_flags = nullptr) {
     const bool tr = cnn_transposed(c->karman.Y, c->karman.X);      // then `feat` and every CNN tensor are [B][X][Y][C]
@@ -438,7 +444,7 @@ int net_forward(const sol_train_cfg* c, void* s, const Ws& w, const float* feat,
     }
     if (corr)
         return sol_conv5x5_correct(s, act[10], w.wf[11], w.bias[11], B, Y, X, am(10), corr->vy, corr->vx, corr->gt_vy, corr->gt_vx,
-                                   out_s0(c), out_s1(c), c->std_v0, c->std_v1, corr->loss, corr->loss_part, tr ? 1 : 0);
+                                   out_s0(c), out_s1(c), c->std_v0, c->std_v1, corr->loss, tr ? 1 : 0);
     return sol_conv5x5_scaled(s, act[10], w.wf[11], w.bias[11], nullptr, nullptr, O, B, Y, X, 32, 2, SOL_EPI_NONE, sl, am(10), nullptr);
 }
 
@@ -594,13 +600,13 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         float* act[11];
         for (int k = 0; k < 11; ++k) act[k] = w.acts + ((size_t)i * 11 + k) * w.cells * 32;
         if (sol_conv_correct_fusable(cX, B * cY)) {            // correction + loss ride in the epilogue of the last CNN layer
-            const Correct corr{vycur, vxcur, gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx, io.loss_steps + i, w.loss_part};
+            const Correct corr{vycur, vxcur, gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx, shared.loss_acc + (size_t)i * SOL_LOSS_ACC_WORDS};
             if (int e = net_forward(c, stream, wn, feat_cnn, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS, &corr, w.chain_flags + (size_t)(2 * i) * w.chain_words)) return e;
         } else {
             if (int e = net_forward(c, stream, wn, feat_cnn, act, w.O, w.amax_act + (size_t)i * 11 * SOL_AMAX_SLOTS, nullptr, w.chain_flags + (size_t)(2 * i) * w.chain_words)) return e;
-            SOL_LAUNCH(k_correct_loss, dim3(std::min(egrid, SOL_LOSS_PART_MAX)), dim3(256), 0, hs, vycur, vxcur, w.O,
+            SOL_LAUNCH(k_correct_loss, dim3(egrid), dim3(256), 0, hs, vycur, vxcur, w.O,
                                gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx,
-                               out_s0(c), out_s1(c), c->std_v0, c->std_v1, io.loss_steps + i, w.loss_part, B, Y, X, tr ? 1 : 0);
+                               out_s0(c), out_s1(c), c->std_v0, c->std_v1, shared.loss_acc + (size_t)i * SOL_LOSS_ACC_WORDS, B, Y, X, tr ? 1 : 0);
             SOL_LAUNCH_CHECK();
         }
     }
@@ -749,7 +755,7 @@ int train_fwd_bwd_impl(const sol_train_cfg* cfg, hipStream_t hs, const TrainIO& 
             z.zero(io.iters_bwd, B * sizeof(int32_t));                                 // step 0 needs no adjoint
         }
         z.zero(w[k].dO4, w[k].cells * 4 * sizeof(float));
-        z.zero(w[k].loss_part + SOL_LOSS_PART_MAX, 64 * sizeof(float));               // the loss fold's ticket word
+        if (k == 0) z.zero(w[0].loss_acc, (size_t)ms * SOL_LOSS_ACC_WORDS * sizeof(unsigned long long));   // every chain adds into chain 0's accumulators
         z.zero(w[k].amax_act, 2 * w[k].amax_words * sizeof(uint32_t));                 // activation + gradient absmax slots
         const bool chain = sol_cnn_chain_usable(sub.karman.B, cnn_transposed(Y, X) ? X : Y, cnn_transposed(Y, X) ? Y : X);
         // hand-off regions of the persistent CNN launches: zero ONCE (tag 0 = "never written"); afterwards the tags do the work
@@ -771,6 +777,8 @@ int train_fwd_bwd_impl(const sol_train_cfg* cfg, hipStream_t hs, const TrainIO& 
             SOL_HIP_CHECK(hipStreamWaitEvent(hs, sp->join[k], 0));
         }
     }
+    SOL_LAUNCH(k_loss_finish, dim3((ms + 63) / 64), dim3(64), 0, hs, (const unsigned long long*)w[0].loss_acc, io.loss_steps, ms);
+    SOL_LAUNCH_CHECK();
     // all twelve layers of a chain in two launches (chain k > 0 accumulates onto chain k-1: one pair of launches per chain)
     const bool trn = cnn_transposed(Y, X);
     const int fused_rb = train_fused_rb(&sub, w[0], ms);
@@ -949,12 +957,12 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
         }
         uint32_t* amax = w.amax_act + (size_t)(i % ROLLOUT_AMAX_SETS) * 11 * SOL_AMAX_SLOTS;
         if (sol_conv_correct_fusable(tr ? Y : X, tr ? B * X : B * Y)) {
-            const Correct corr{tvy, tvx, nullptr, nullptr, nullptr, nullptr};
+            const Correct corr{tvy, tvx, nullptr, nullptr, nullptr};
             if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, amax, &corr, w.chain_flags + (size_t)(i % ROLLOUT_AMAX_SETS) * w.chain_words)) return e;
         } else {
             if (int e = net_forward(cfg, stream, w, w.feat, act, w.O, amax, nullptr, w.chain_flags + (size_t)(i % ROLLOUT_AMAX_SETS) * w.chain_words)) return e;
             SOL_LAUNCH(k_correct_loss, dim3(egrid), dim3(256), 0, hs, tvy, tvx, w.O,
-                               (const float*)nullptr, (const float*)nullptr, out_s0(cfg), out_s1(cfg), cfg->std_v0, cfg->std_v1, (float*)nullptr, (float*)nullptr, B, Y, X, tr ? 1 : 0);
+                               (const float*)nullptr, (const float*)nullptr, out_s0(cfg), out_s1(cfg), cfg->std_v0, cfg->std_v1, (unsigned long long*)nullptr, B, Y, X, tr ? 1 : 0);
             SOL_LAUNCH_CHECK();
         }
     }
