@@ -686,7 +686,9 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = tid & 127, cb = __builtin_amdgcn_readfirstlane(tid >> 7);
+#if !SOL_FD_MFMA
     f2 lo[4], hi[4];
+#endif
     // this thread's 16 spectral coefficients: index 2q+e -> column 8cb+2q+e, 8+2q+e -> column 63-(8cb+2q+e)
     float t2[16], il[16];
     int col[16];

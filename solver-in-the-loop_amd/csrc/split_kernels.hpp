@@ -115,10 +115,6 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
         out_scale = ix * iz;
     }
 
-    auto row_ptr = [&](const float* base, long seg_stride, int gr) {
-        const int seg = gr / RPS, grs = gr - seg * RPS;
-        return reinterpret_cast<const float4*>(base + (size_t)seg * seg_stride) + (size_t)grs * W * 8;
-    };
     // this thread's item of x row gx_row (x role) or dz row gz_row (dz role); rows outside [0, R) are replaced by row r0 (their
     // item is requested and dropped)
     // the role's tensor and segment stride, selected ONCE and made opaque (left as `xrole ? a.x : a.dz` at the point of use the

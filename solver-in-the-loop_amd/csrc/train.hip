@@ -274,11 +274,6 @@ struct MemList {
 // unrolled step until round 4), and the correction / loss / seed kernels index the transposed cell order.
 __host__ __device__ inline bool cnn_transposed(int Y, int X) { return X % 64 != 0 && Y % 64 == 0; }
 
-__global__ void k_pad_bias(const float* __restrict__ params, float* __restrict__ biasp, int64_t boff, int cout) {
-    const int t = threadIdx.x;
-    if (t < 32) biasp[t] = t < cout ? params[boff + t] : 0.f;
-}
-
 // ---- TF1 AdamOptimizer ------------------------------------------------------------------
 __global__ void k_tensor_scale(const float* __restrict__ g, float* __restrict__ scale, int64_t off, int64_t n,
                                float clip_norm) {
