@@ -35,6 +35,7 @@ extern "C" {
 #define SOL_ERR_ARG (-1)      /* invalid argument / unsupported shape */
 #define SOL_ERR_HIP (-2)      /* HIP runtime error (text in sol_last_error) */
 #define SOL_ERR_WORKSPACE (-3)
+#define SOL_ERR_GRAPH (-4)    /* a captured graph holds a node type that is refused (sol_graph_check) */
 
 #define SOL_MARS_MOON_PARAMS 260354   /* model_mars_moon, karman_train.py:101-138 */
 
@@ -299,6 +300,21 @@ int sol_train_graph_create(const sol_train_cfg* cfg, const float* params,
                            int32_t* iters_fwd, int32_t* iters_bwd, sol_train_graph** out);
 int sol_train_graph_launch(sol_train_graph* graph, void* stream);
 int sol_train_graph_destroy(sol_train_graph* graph);
+
+/* Graph-capture guard.  The reference builds its TF graph once and runs it many times (karman_train.py:385-391, 502); here that shape is a
+ * captured hipGraph, and a graph on this path may hold KERNEL nodes only (plus empty / event / child-graph nodes): memset nodes replay
+ * unreliably on ROCm 7.2 (a torch reduction's semaphore clear inside a captured trainer made the reported losses 0.5x / 2x the true values
+ * after a few replays), memcpy / host / alloc nodes mean work that is not a kernel of this path sits in the replayed region.
+ *   sol_graph_census  counts[t] = number of nodes of hipGraphNodeType t in `graph` (a hipGraph_t; child graphs are entered), t < ncounts <= 64
+ *   sol_graph_check   SOL_ERR_GRAPH (and a message naming the node types and `what`) when the graph holds a memset, memcpy, memcpy-to/from-
+ *                     symbol, host, mem-alloc or mem-free node; SOL_OK otherwise.  sol_train_graph_create applies it to its own capture; a
+ *                     host that captures the per-op entry points itself calls it between hipStreamEndCapture and hipGraphInstantiate.    */
+/*   sol_copy_words    dst[0..nwords) = src[0..nwords) (32-bit words; src NULL: zero fill) as ONE KERNEL launch: the copy a host uses inside
+ *                     a stream capture instead of hipMemcpyAsync / hipMemsetAsync (torch: tensor.copy_ / clone() of a contiguous tensor).   */
+int sol_copy_words(void* stream, void* dst, const void* src, int64_t nwords);
+int sol_graph_census(void* graph, int32_t* counts, int32_t ncounts);
+int sol_graph_check(void* graph, const char* what);
+const char* sol_graph_node_type_name(int32_t type);
 
 /* Forward only (karman_apply.py:138-158 roll-out without the frame dump): runs `nsteps`
  * solver+CNN steps in place of d/vy/vx.  workspace: sol_rollout_workspace_bytes().       */

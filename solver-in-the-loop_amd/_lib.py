@@ -84,6 +84,10 @@ _SIGS = {
     "sol_train_graph_create": (C.c_int, [C.POINTER(TrainCfg)] + [_P] * 9 + [C.c_int64] + [_P] * 3 + [C.c_size_t] + [_P] * 7 + [C.POINTER(C.c_void_p)]),
     "sol_train_graph_launch": (C.c_int, [_P, _P]),
     "sol_train_graph_destroy": (C.c_int, [_P]),
+    "sol_copy_words": (C.c_int, [_P, _P, _P, C.c_int64]),
+    "sol_graph_census": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32]),
+    "sol_graph_check": (C.c_int, [_P, C.c_char_p]),
+    "sol_graph_node_type_name": (C.c_char_p, [C.c_int32]),
     "sol_rollout_workspace_bytes": (C.c_size_t, [C.POINTER(TrainCfg)]),
     "sol_rollout": (C.c_int, [C.POINTER(TrainCfg), _P] + [_P] * 9 + [C.c_int64, C.c_int32, _P, C.c_size_t, _P]),
     "sol_l2_loss_scratch_floats": (C.c_int32, []),
@@ -231,6 +235,68 @@ class no_gc_during_capture:
         if self._was:
             gc.enable()
         return False
+
+
+def dcopy_(dst, src):
+    """dst.copy_(src) for contiguous 32-bit device tensors of equal size AS A KERNEL (sol_copy_words): torch's copy_ / clone() of a
+    contiguous tensor is a hipMemcpyAsync, i.e. a MEMCPY NODE in a captured graph, which sol_graph_check refuses.  Returns dst."""
+    if dst.numel() != src.numel() or dst.dtype != src.dtype:
+        raise SolError("dcopy_: %s %s <- %s %s" % (tuple(dst.shape), dst.dtype, tuple(src.shape), src.dtype))
+    src = src.detach()
+    if not (dst.is_contiguous() and src.is_contiguous()):
+        dst.copy_(src)                       # a strided copy is an elementwise kernel already
+        return dst
+    check(load().sol_copy_words(stream(), ptr(dst), ptr(src), dst.numel()))
+    return dst
+
+
+def dclone(t):
+    """t.detach().clone() without a memcpy node (see dcopy_)."""
+    return dcopy_(torch.empty_like(t, memory_format=torch.contiguous_format), t.detach().contiguous())
+
+
+def pad_high(t, *dims):
+    """Zero padding by ONE element at the high end of each of `dims` -- torch.nn.functional.pad(t, ...) written as concatenation with
+    zeros.  Same values; the difference is what a captured graph holds: constant_pad_nd copies `t` into a narrow of the result, and its
+    backward clone()s a narrow of the gradient -- with batch size 1 (or padding along dim 0) those narrows are CONTIGUOUS, the copies are
+    hipMemcpyAsync, and the captured trainer holds memcpy nodes (refused by sol_graph_check).  cat / its backward are kernels / views."""
+    for d in dims:
+        shape = list(t.shape)
+        shape[d] = 1
+        t = torch.cat([t, t.new_zeros(shape)], dim=d)
+    return t
+
+
+def stack0(ts):
+    """torch.stack(ts) of 0-d tensors; a stack of ONE tensor is a plain contiguous copy (a memcpy node under capture): reshape instead."""
+    return ts[0].reshape(1) if len(ts) == 1 else torch.stack(ts)
+
+
+def graph_census(raw_graph):
+    """{node type name: count} of a hipGraph_t (child graphs entered) -- sol_graph_census."""
+    lib = load()
+    counts = (C.c_int32 * 32)()
+    check(lib.sol_graph_census(C.c_void_p(int(raw_graph)), counts, 32))
+    return {lib.sol_graph_node_type_name(t).decode(): int(counts[t]) for t in range(32) if counts[t]}
+
+
+def capture_graph(fn, what):
+    """Capture `fn()` (launches on torch's current stream) into a torch CUDAGraph and return it, instantiated -- THE way this package
+    captures torch-composed work (GraphTrainer, BurgersTrainer, BurgersRollout, Karman3DTrainer).  The captured graph is passed through
+    sol_graph_check BEFORE it is instantiated: anything but kernel nodes (a memset node = a multi-workgroup torch reduction's semaphore
+    clear or a torch.zeros() inside the capture; a memcpy node = data staged inside the replayed region) raises SolError naming the node
+    types.  Memset nodes replay unreliably on ROCm 7.2 (per-step losses 0.5x / 2x the true values after a few
+    replays); with this guard that defect class is refused at capture time instead of being tested for after the fact."""
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with no_gc_during_capture(), torch.cuda.graph(g):
+        fn()
+    try:
+        check(load().sol_graph_check(C.c_void_p(int(g.raw_cuda_graph())), what.encode()))
+    except SolError:
+        g.reset()
+        raise
+    g.instantiate()
+    return g
 
 
 def check(code):

@@ -180,13 +180,13 @@ class BurgersTrainer:
             # reduction (a multi-workgroup torch .sum() puts a memset node into the captured graph: ops.L2LossFn)
             vt, gt_t = st.velocity.staggered_tensor(), self.velo[k + 1]
             losses.append(ops.l2_loss((vt[..., 0].contiguous(), vt[..., 1].contiguous()), (gt_t[..., 0].contiguous(), gt_t[..., 1].contiguous()), self._std_v_host))
-        return torch.stack(losses).sum() / self.ms
+        return _lib.stack0(losses).sum() / self.ms
 
     def _eager(self):
         self.net.params.grad = None
         loss = self._unrolled_loss()
         loss.backward()
-        self.loss.copy_(loss.detach())
+        _lib.dcopy_(self.loss, loss)
 
     def _capture(self):
         side = torch.cuda.Stream()
@@ -197,12 +197,11 @@ class BurgersTrainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.net.params.grad = None             # the captured backward allocates .grad from the graph's pool and rewrites it per replay
-        g = torch.cuda.CUDAGraph()
-        with _lib.no_gc_during_capture(), torch.cuda.graph(g):
+        def body():
             loss = self._unrolled_loss()
             loss.backward()
-            self.loss.copy_(loss.detach())
-        self._graph = g
+            _lib.dcopy_(self.loss, loss)          # (a kernel: a contiguous copy_ would be a memcpy node, refused by the capture guard)
+        self._graph = _lib.capture_graph(body, "BurgersTrainer")      # kernel nodes only (sol_graph_check), then instantiated
 
     def fwd_bwd(self, velo, forc=None, eager=False):
         """Copies the batch into the static buffers, runs forward + backward; returns the loss tensor (device scalar); the
@@ -260,8 +259,8 @@ class BurgersRollout:
                 st = self.sim.step_with_f(st, F.BurgersVelocitySMAC(self.dom, velocity=self.f_step, batch_size=self.B), dt=self.dt)
                 feat = to_feature([st], [F.BurgersVelocitySMAC(self.dom, velocity=self.f_feat, batch_size=self.B)])
             cv = to_staggered(self.net.predict(feat / self.std_in) * self.std_v, self.dom.box)
-            self.corr.copy_(cv.staggered_tensor())
-            self.vel.copy_((st.velocity + cv).staggered_tensor())
+            _lib.dcopy_(self.corr, cv.staggered_tensor())      # (kernel copies: no memcpy nodes in the captured graph)
+            _lib.dcopy_(self.vel, (st.velocity + cv).staggered_tensor())
 
     def reset(self, velocity):
         self.vel.copy_(torch.as_tensor(velocity, dtype=torch.float32).reshape(self.vel.shape))
@@ -285,10 +284,7 @@ class BurgersRollout:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.vel.copy_(keep)
-            g = torch.cuda.CUDAGraph()
-            with _lib.no_gc_during_capture(), torch.cuda.graph(g):
-                self._one()
-            self._graph = g
+            self._graph = _lib.capture_graph(self._one, "BurgersRollout")
             self.vel.copy_(keep)
         self._graph.replay()
         return self.vel

@@ -259,16 +259,22 @@ __device__ __forceinline__ float wave_sum(float v) {
 // fence, nobody waits.  (First form of the round: per-workgroup partials + a release/acquire ticket, the last workgroup folding them
 // in order -- also reproducible, but every workgroup's tail carried an agent-scope release (L2 write-back) and an atomic round trip.)
 // Capacity: m << 7 < 2^31 per addition, 2^32 additions per bucket.
+// Non-finite sums are NOT dropped: a workgroup sum that is inf / nan (a diverged run) -- or negative, which no sum of squares can be --
+// sets the POISON bit (bit 63 of the last bucket, out of reach of 2^32 finite additions) and loss_acc_value() then returns NaN, like the
+// float atomics this replaced and like the reference's tf.nn.l2_loss (karman_train.py:430-436): monitoring keyed on a non-finite loss fires.
 constexpr int SOL_LOSS_ACC_WORDS = 32;                           // unsigned long long per loss value
+constexpr unsigned long long SOL_LOSS_POISON = 1ull << 63;       // in acc[SOL_LOSS_ACC_WORDS - 1]
 __device__ __forceinline__ void loss_add_exact(float wg_sum, unsigned long long* __restrict__ acc) {
     const unsigned bits = __float_as_uint(wg_sum);
     const unsigned e = (bits >> 23) & 0xffu;
-    if ((bits << 1) == 0u || e == 0xffu || (bits >> 31)) return;          // zero (nothing to add); inf / nan / negative: not a loss partial
+    if ((bits << 1) == 0u) return;                               // +-0: nothing to add
+    if (e == 0xffu || (bits >> 31)) { atomicOr(&acc[SOL_LOSS_ACC_WORDS - 1], SOL_LOSS_POISON); return; }
     const unsigned long long m = (bits & 0x7fffffu) | (e ? 0x800000u : 0u);
     const unsigned ee = e ? e : 1u;                              // denormals share the exponent of the smallest normal
     atomicAdd(&acc[ee >> 3], m << (ee & 7u));
 }
 __device__ __forceinline__ float loss_acc_value(const unsigned long long* __restrict__ acc) {
+    if (acc[SOL_LOSS_ACC_WORDS - 1] & SOL_LOSS_POISON) return __uint_as_float(0x7fc00000u);
     double v = 0.0;
     for (int b = 0; b < SOL_LOSS_ACC_WORDS; ++b) v += ldexp((double)acc[b], 8 * b - 150);
     return (float)v;

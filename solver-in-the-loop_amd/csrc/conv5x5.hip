@@ -1109,6 +1109,9 @@ int sol_conv5x5_correct(void* stream, const float* x, const float* packed, const
                         float s0, float s1, float l0, float l1, unsigned long long* loss_acc, int transposed) {
     if (int e = check_shape(B, H, W, 32, 2)) return e;
     SOL_REQUIRE(x && packed && x_absmax && vy && vx && sol_conv_correct_fusable(W, B * H), "sol_conv5x5_correct: bad arguments");
+    // (the thin dx kernel's prefetch keys both ground-truth reads on gt_vy: one frame without the other would be a NULL-based device read)
+    SOL_REQUIRE(!gt_vy == !gt_vx, "sol_conv5x5_correct: gt_vy and gt_vx must be given together (or both NULL: no loss)");
+    SOL_REQUIRE(!loss_acc || gt_vy, "sol_conv5x5_correct: a loss accumulator needs the ground-truth frames");
     if (int e = sol_init_conv_kernels()) return e;
     ConvArgs a{};
     a.x = x; a.wp = packed; a.bias = bias; a.B = B; a.H = H; a.W = W; a.CO = 2; a.epi = SOL_EPI_NONE;

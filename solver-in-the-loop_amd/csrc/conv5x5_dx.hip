@@ -505,7 +505,7 @@ static int dx_rows_per_wg(int nrows, int tiles_x) { return ((nrows + 2) / 3) * t
 
 bool sol_conv_dx_usable(const ConvArgs& a, int NT, int ntiles) {
     if (!sol_opt().conv_dx || !a.xmax || !a.wsh || a.W % 64 != 0) return false;
-    if (NT == 2) return a.CO == 32 && !a.cvy;                  // (one-row launches: as two half-channel workgroups per tile, option bit 3)
+    if (NT == 2) return (sol_opt().conv_dx & 1) && a.CO == 32 && !a.cvy;      // option bit 0 (one-row launches: as two half-channel workgroups per tile, bit 3)
     // Thin layers (<= 16 output channels; option bit 1, bit 2 = also in big launches): half the waves of the COT = 1 form only stage, and
     // where the launch fills the chip with three-row workgroups k_conv5x5_sb<1, 2> (twelve waves, a row each) is the faster kernel
     // (SOL-32 step at 128x64, B = 6: 13.26 ms against 13.43); in the small launches (one row per workgroup: the 64x32 recipe, roll-outs)

@@ -600,7 +600,7 @@ int sol_conv_sh_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int 
     const int OP = cout <= 16 ? 16 : 32;
     float* hdr = reinterpret_cast<float*>(out);
     unsigned* slots = reinterpret_cast<unsigned*>(hdr + 4 + (size_t)25 * 2 * OP * 16);
-    SOL_HIP_CHECK(hipMemsetAsync(slots, 0, SOL_AMAX_SLOTS * sizeof(unsigned), s));
+    SOL_LAUNCH(k_zero_slots, dim3(1), dim3(SOL_AMAX_SLOTS), 0, s, slots);       // (a kernel, not hipMemsetAsync: memset nodes are refused in captured graphs, sol_graph_check)
     SOL_LAUNCH(k_absmax, dim3(8), dim3(256), 0, s, w_hwio, (size_t)25 * cin * cout, slots);
     SOL_LAUNCH_CHECK();
     const int total = 25 * OP * 16;

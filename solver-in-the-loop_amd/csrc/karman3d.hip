@@ -708,7 +708,10 @@ int check_blob3d(const sol_karman3d_cfg* c, const int32_t* hdr) {
 //                  int64 accumulators, scale = a power of two with max|g_a| * scale in [2^37, 2^38): integer addition is
 //                  order independent, so the adjoint is reproducible BIT FOR BIT (run twice, compare) --
 //                  the scheme of the 2-D kernels (int32 into LDS) with the headroom global memory affords:
-//                  2^25 single-contribution range above max|g_a|, resolution 2^-37 max|g_a|.
+//                  2^25 single-contribution range above max|g_a|, resolution 2^-37 max|g_a|.  Bounds, stated: a FINITE contribution
+//                  beyond 2^25 max|g_a| saturates in __float2ll_rn (the back-trace term is g_a times a velocity DIFFERENCE of the
+//                  saved field times dt/dx: it would take |dv| dt/dx > 3e7, i.e. a simulation that has already blown up); a
+//                  NON-FINITE g_a poisons the whole simulation's input gradient (k3b_gva publishes a NaN maximum, k3b_scale).
 //   k3b_diffuse_adj g_in = (I + alpha L^T)(g_c . (1 - bcm))  (gather form of the transposed replicate-padded Laplacian; converts
 //                  the fixed-point g_c back to fp32 as it reads it)
 // ========================================================================================================================
@@ -733,6 +736,11 @@ constexpr int K3B_FIXBITS = 37;           // max|g_a| * 2^shift lies in [2^37, 2
 // power-of-two fixed-point scale of simulation b's scatter and its inverse, from the published max|g_a| (wave-uniform result)
 __device__ __forceinline__ void k3b_scale(const unsigned* gmax_b, float& qs, float& qi) {
     const unsigned m = amax_wave_max(gmax_b[threadIdx.x & (K3B_SLOTS - 1)]);
+    if (m >= 0x7f800000u) {                   // k3b_gva met an inf / nan gradient in this simulation: nothing is scattered (qs = 0) and the
+        qs = 0.f;                             // conversion back (k3b_diffuse_adj: value * qi) makes EVERY input gradient of the simulation NaN --
+        qi = __uint_as_float(0x7fc00000u);    // as the fp32 atomics this scheme replaced did, instead of laundering it into finite numbers
+        return;
+    }
     int e = (int)(m >> 23) - 127;
     e = m == 0u ? 0 : min(max(e, -80), 120);
     qs = __uint_as_float((unsigned)(K3B_FIXBITS - e + 127) << 23);
@@ -772,6 +780,7 @@ __global__ void __launch_bounds__(256) k3b_gva(K3BArgs a) {
     const float* P = a.gdiv + (size_t)b * N;
     auto cell = [&](int j, int i, int k) { return ((unsigned)j < (unsigned)Y && (unsigned)i < (unsigned)X && (unsigned)k < (unsigned)Z) ? P[((size_t)j * X + i) * Z + k] : 0.f; };
     float vmax = 0.f;
+    bool bad = false;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nVy + nVx + nVz; e += gridDim.x * blockDim.x) {
         float v;
         if (e < nVy) {
@@ -785,21 +794,22 @@ __global__ void __launch_bounds__(256) k3b_gva(K3BArgs a) {
             a.gaz[(size_t)b * nVz + q] = v = face_mask<2>(a.active, Y, X, Z, j, i, k) * (a.goz[(size_t)b * nVz + q] + cell(j, i, k - 1) - cell(j, i, k));
         }
         vmax = fmaxf(vmax, fabsf(v));
+        bad |= !(fabsf(v) <= 3.402823466e38f);                   // inf or nan (fmaxf drops a NaN)
     }
-    // max|g_a| of this simulation -> the scale of the fixed-point scatter (one atomic per workgroup; a NaN gradient publishes
-    // nothing and scatters nothing: the consumer then sees zeros instead of undefined integer conversions)
-    __shared__ float red[16];
-    vmax = __uint_as_float(amax_wave_max(__float_as_uint(vmax)));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vmax;
+    // max|g_a| of this simulation -> the scale of the fixed-point scatter (one atomic per workgroup).  A non-finite g_a publishes
+    // the bits of a NaN -- the largest value the integer maximum can see -- and k3b_scale turns that into "scatter nothing, convert
+    // back to NaN": the simulation's input gradient is NaN, not a finite number made of saturated integer conversions.
+    __shared__ unsigned red[16];
+    const unsigned wmax = amax_wave_max(bad ? 0x7fc00000u : __float_as_uint(vmax));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = wmax;
     __syncthreads();
     if (threadIdx.x == 0) {
-        float m = 0.f;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
+        unsigned mb = 0u;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) mb = max(mb, red[w]);
         // (thousands of workgroups share the 64 slots of a simulation and same-address atomics serialise in the L2, ~0.3 us apiece:
         //  33 us for this kernel.  A workgroup whose maximum does not exceed what the slot already holds has nothing to publish;
         //  the maximum is order independent, so the filter changes nothing but the number of atomics.)
         unsigned* slot = &a.gmax[b * K3B_SLOTS + (blockIdx.x & (K3B_SLOTS - 1))];
-        const unsigned mb = __float_as_uint(m);
         if (mb > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, mb);
     }
 }

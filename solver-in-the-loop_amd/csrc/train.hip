@@ -265,6 +265,18 @@ struct MemList {
     }
 };
 
+}  // namespace
+// Device-to-device copy / zero fill of 32-bit words AS A KERNEL (k_mem_jobs): what a host uses inside a stream capture instead of
+// hipMemcpyAsync / hipMemsetAsync (torch: tensor.copy_, clone, multi-block reductions), whose graph nodes sol_graph_check refuses.
+extern "C" int sol_copy_words(void* stream, void* dst, const void* src, int64_t nwords) {
+    SOL_REQUIRE(dst && nwords >= 0 && (((uintptr_t)dst | (uintptr_t)src) & 3) == 0, "sol_copy_words: dst (4-byte aligned), nwords >= 0; src NULL = zero fill");
+    if (nwords == 0 || dst == src) return SOL_OK;
+    MemList m;
+    m.copy(dst, src, (size_t)nwords * 4);
+    return m.launch((hipStream_t)stream);
+}
+namespace {
+
 // ---- transposed CNN mode ------------------------------------------------------------------------
 // The split-precision convolution / weight-gradient kernels want image rows of 64 pixels.  A 64 x 32 grid (the reference's own
 // training recipe, karman-2d/Makefile:78-80) has rows of 32 -- but columns of 64, and conv(x^T, w^T) = conv(x, w)^T: the
@@ -745,10 +757,7 @@ int train_fwd_bwd_impl(const sol_train_cfg* cfg, hipStream_t hs, const TrainIO& 
     if (int e = pack_all(cfg, hs, io.params, w[0], true)) return e;
     for (int k = 0; k < S; ++k) {
         MemList z;
-        if (k == 0) {
-            z.zero(io.loss_steps, ms * sizeof(float));
-            z.zero(io.iters_bwd, B * sizeof(int32_t));                                 // step 0 needs no adjoint
-        }
+        if (k == 0) z.zero(io.iters_bwd, B * sizeof(int32_t));                       // step 0 needs no adjoint  (io.loss_steps: every entry is written by k_loss_finish)
         z.zero(w[k].dO4, w[k].cells * 4 * sizeof(float));
         if (k == 0) z.zero(w[0].loss_acc, (size_t)ms * SOL_LOSS_ACC_WORDS * sizeof(unsigned long long));   // every chain adds into chain 0's accumulators
         z.zero(w[k].amax_act, 2 * w[k].amax_words * sizeof(uint32_t));                 // activation + gradient absmax slots
@@ -821,6 +830,137 @@ extern "C" int sol_train_fwd_bwd(const sol_train_cfg* cfg, void* stream, const f
     return train_fwd_bwd_impl(cfg, (hipStream_t)stream, io, workspace, workspace_bytes, grads);
 }
 
+// ---- graph-capture guard ---------------------------------------------------------------------------
+// A replayed hipGraph on this path may contain KERNEL nodes (and empty / event / child-graph nodes) only.  Memset and memcpy nodes
+// are refused: on ROCm 7.2 a captured memset node is unreliable under replay -- round 4: a torch reduction's semaphore memset inside a
+// captured trainer made the reported per-step losses 0.5x / 2x the true values after a few replays while state and gradient stayed
+// right -- and a memcpy node means somebody staged data inside the timed region.  Every capture site of the
+// package (sol_train_graph_create here; the torch captures of GraphTrainer, BurgersTrainer, BurgersRollout, Karman3DTrainer through
+// _lib.capture_graph) passes its graph through this check BEFORE instantiating it, so the defect class is refused, not tested for.
+// Reference shape it protects: "build the graph once, sess.run many" (karman_train.py:385-391, 502).
+static const char* graph_node_type_name(hipGraphNodeType t) {
+    switch (t) {
+        case hipGraphNodeTypeKernel: return "kernel";
+        case hipGraphNodeTypeMemcpy: return "memcpy";
+        case hipGraphNodeTypeMemset: return "memset";
+        case hipGraphNodeTypeHost: return "host";
+        case hipGraphNodeTypeGraph: return "child-graph";
+        case hipGraphNodeTypeEmpty: return "empty";
+        case hipGraphNodeTypeWaitEvent: return "wait-event";
+        case hipGraphNodeTypeEventRecord: return "event-record";
+        case hipGraphNodeTypeExtSemaphoreSignal: return "ext-semaphore-signal";
+        case hipGraphNodeTypeExtSemaphoreWait: return "ext-semaphore-wait";
+        case hipGraphNodeTypeMemAlloc: return "mem-alloc";
+        case hipGraphNodeTypeMemFree: return "mem-free";
+        case hipGraphNodeTypeMemcpyFromSymbol: return "memcpy-from-symbol";
+        case hipGraphNodeTypeMemcpyToSymbol: return "memcpy-to-symbol";
+        default: return "other";
+    }
+}
+
+// counts[hipGraphNodeType] += nodes of `graph` (child graphs are entered); returns SOL_OK or a HIP error
+static int graph_census(hipGraph_t graph, int32_t* counts, int ncounts, int depth) {
+    size_t n = 0;
+    SOL_HIP_CHECK(hipGraphGetNodes(graph, nullptr, &n));
+    if (n == 0) return SOL_OK;
+    hipGraphNode_t* nodes = new hipGraphNode_t[n];
+    hipError_t e = hipGraphGetNodes(graph, nodes, &n);
+    int rc = SOL_OK;
+    for (size_t i = 0; i < n && e == hipSuccess && rc == SOL_OK; ++i) {
+        hipGraphNodeType t;
+        e = hipGraphNodeGetType(nodes[i], &t);
+        if (e != hipSuccess) break;
+        if ((int)t >= 0 && (int)t < ncounts) counts[(int)t]++;
+        if (t == hipGraphNodeTypeGraph && depth < 8) {
+            hipGraph_t child = nullptr;
+            e = hipGraphChildGraphNodeGetGraph(nodes[i], &child);
+            if (e == hipSuccess && child) rc = graph_census(child, counts, ncounts, depth + 1);
+        }
+    }
+    delete[] nodes;
+    if (e != hipSuccess) return sol_set_error(SOL_ERR_HIP, "graph node enumeration failed: %s", hipGetErrorString(e));
+    return rc;
+}
+
+extern "C" int sol_graph_census(void* graph, int32_t* counts, int32_t ncounts) {
+    SOL_REQUIRE(graph && counts && ncounts >= 1 && ncounts <= 64, "sol_graph_census: graph, counts[1..64]");
+    for (int i = 0; i < ncounts; ++i) counts[i] = 0;
+    return graph_census((hipGraph_t)graph, counts, ncounts, 0);
+}
+
+extern "C" const char* sol_graph_node_type_name(int32_t type) { return graph_node_type_name((hipGraphNodeType)type); }
+
+extern "C" int sol_graph_check(void* graph, const char* what) {
+    SOL_REQUIRE(graph != nullptr, "sol_graph_check: NULL graph");
+    int32_t counts[32];
+    if (int e = sol_graph_census(graph, counts, 32)) return e;
+    // refused: everything that moves or clears memory without being one of this library's (or the caller's) kernels
+    const hipGraphNodeType refused[] = {hipGraphNodeTypeMemset, hipGraphNodeTypeMemcpy, hipGraphNodeTypeMemcpyFromSymbol, hipGraphNodeTypeMemcpyToSymbol,
+                                        hipGraphNodeTypeHost, hipGraphNodeTypeMemAlloc, hipGraphNodeTypeMemFree};
+    char found[256];
+    size_t len = 0;
+    int bad = 0;
+    found[0] = 0;
+    for (hipGraphNodeType t : refused)
+        if ((int)t < 32 && counts[(int)t] > 0) {
+            bad += counts[(int)t];
+            len += (size_t)snprintf(found + len, len < sizeof(found) ? sizeof(found) - len : 0, "%s%d %s", len ? ", " : "", counts[(int)t], graph_node_type_name(t));
+            if (len >= sizeof(found)) len = sizeof(found) - 1;
+        }
+    if (bad) {
+        // the first few offenders with their neighbours in the graph ("memcpy after <kernel> before <kernel>"): that is what locates
+        // the host line -- the copy follows the kernel that produced its source and precedes the first consumer of its destination
+        size_t n = 0;
+        char det[600];
+        size_t dl = 0;
+        det[0] = 0;
+        auto kname = [](hipGraphNode_t nd, char* out, size_t cap) {
+            hipGraphNodeType t;
+            out[0] = 0;
+            if (hipGraphNodeGetType(nd, &t) != hipSuccess) return;
+            if (t == hipGraphNodeTypeKernel) {
+                hipKernelNodeParams kp;
+                const char* nm = nullptr;
+                if (hipGraphKernelNodeGetParams(nd, &kp) == hipSuccess && kp.func) nm = hipKernelNameRefByPtr(kp.func, nullptr);
+                snprintf(out, cap, "%.60s", nm ? nm : "kernel");
+            } else snprintf(out, cap, "%s", graph_node_type_name(t));
+        };
+        if (hipGraphGetNodes((hipGraph_t)graph, nullptr, &n) == hipSuccess && n) {
+            hipGraphNode_t* nodes = new hipGraphNode_t[n];
+            if (hipGraphGetNodes((hipGraph_t)graph, nodes, &n) == hipSuccess) {
+                int shown = 0;
+                for (size_t i = 0; i < n && shown < 4 && dl + 160 < sizeof(det); ++i) {
+                    hipGraphNodeType t;
+                    if (hipGraphNodeGetType(nodes[i], &t) != hipSuccess) break;
+                    bool off = false;
+                    for (hipGraphNodeType r : refused) off = off || r == t;
+                    if (!off) continue;
+                    char before[64] = "", after[64] = "";
+                    hipGraphNode_t nb[4];
+                    size_t k = 4;
+                    if (hipGraphNodeGetDependencies(nodes[i], nb, &k) == hipSuccess && k) kname(nb[0], before, sizeof(before));
+                    k = 4;
+                    if (hipGraphNodeGetDependentNodes(nodes[i], nb, &k) == hipSuccess && k) kname(nb[0], after, sizeof(after));
+                    size_t bytes = 0;
+                    if (t == hipGraphNodeTypeMemset) {
+                        hipMemsetParams mp;
+                        if (hipGraphMemsetNodeGetParams(nodes[i], &mp) == hipSuccess) bytes = mp.width * (mp.height ? mp.height : 1) * mp.elementSize;
+                    }
+                    dl += (size_t)snprintf(det + dl, sizeof(det) - dl, "%s%s", shown++ ? "; " : "", graph_node_type_name(t));
+                    if (bytes) dl += (size_t)snprintf(det + dl, sizeof(det) - dl, " of %zu B", bytes);
+                    dl += (size_t)snprintf(det + dl, sizeof(det) - dl, " after '%s' before '%s'", before[0] ? before : "-", after[0] ? after : "-");
+                }
+            }
+            delete[] nodes;
+        }
+        return sol_set_error(SOL_ERR_GRAPH, "%s: the captured graph holds %s node(s) among %d kernel nodes [first: %s] -- only kernel nodes replay reliably on this "
+                             "path (a memset node is what a multi-workgroup torch reduction or torch.zeros() inside the capture leaves behind: use the "
+                             "library's kernels -- ops.L2LossFn for the loss, _lib.dcopy_ / _lib.dclone for copies -- or allocate and clear before the capture)",
+                             what ? what : "graph", found, counts[(int)hipGraphNodeTypeKernel], det);
+    }
+    return SOL_OK;
+}
+
 // ---- the same step as a replayable hipGraph (removes ~1000 host launches per step) --------------
 struct sol_train_graph {
     hipGraph_t graph;
@@ -856,6 +996,7 @@ extern "C" int sol_train_graph_create(const sol_train_cfg* cfg, const float* par
     (void)hipStreamDestroy(cs);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (ee != hipSuccess || !graph) return sol_set_error(SOL_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ee));
+    if (int e = sol_graph_check(graph, "sol_train_graph_create")) { (void)hipGraphDestroy(graph); return e; }      // kernel nodes only
     hipGraphExec_t exec = nullptr;
     const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     if (ei != hipSuccess) { (void)hipGraphDestroy(graph); return sol_set_error(SOL_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei)); }

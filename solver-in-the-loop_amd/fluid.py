@@ -11,6 +11,8 @@ density [B,Y,X,1], v_y [B,Y+1,X,1], v_x [B,Y,X+1,1], staggered tensor [B,Y+1,X+1
 import numpy as np
 import torch
 
+from . import _lib
+
 OPEN = "open"
 PERIODIC = "periodic"
 
@@ -130,8 +132,8 @@ class StaggeredGrid:
 
     def staggered_tensor(self):
         vy, vx = self.data[0].data, self.data[1].data
-        vy = torch.nn.functional.pad(vy, (0, 0, 0, 1))            # pad x at the high end
-        vx = torch.nn.functional.pad(vx, (0, 0, 0, 0, 0, 1))      # pad y at the high end
+        vy = _lib.pad_high(vy, 2)                                 # pad x at the high end  (cat with zeros: no memcpy node under capture)
+        vx = _lib.pad_high(vx, 1)                                 # pad y at the high end
         return torch.cat([vy, vx], dim=-1)
 
     def __add__(self, other):

@@ -152,17 +152,31 @@ class _Karman3DStepFn(torch.autograd.Function):
         return None, None, gi[0], gi[1], gi[2], None
 
 
+class _ToFeature3DFn(torch.autograd.Function):
+    """to_feature3d as one node with a backward made of kernels only: the autograd backward of `vy[:, :Y]` is zeros + a copy into a
+    narrow, and with B = 1 that narrow is contiguous -- a hipMemcpyAsync, i.e. a memcpy node per unrolled step in the captured trainer
+    (refused by sol_graph_check).  Here: zero-padding of the strided channel slices (fill + strided copy kernels)."""
+
+    @staticmethod
+    def forward(ctx, vy, vx, vz, re):
+        Y, X, Z = vx.shape[1], vy.shape[2], vy.shape[3]
+        st = torch.stack([vy[:, :Y], vx[:, :, :X], vz[..., :Z]], dim=-1)
+        return torch.cat([st, re.reshape(-1, 1, 1, 1, 1).expand(-1, Y, X, Z, 1).to(st.dtype)], dim=-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _lib.pad_high(g[..., 0], 1), _lib.pad_high(g[..., 1], 2), _lib.pad_high(g[..., 2], 3), None
+
+
 def to_feature3d(vy, vx, vz, re):
     """karman_train.py:77-86 with three components: [B,Y,X,Z,4] = the components at the low faces of every cell + Re."""
-    Y, X, Z = vx.shape[1], vy.shape[2], vy.shape[3]
-    st = torch.stack([vy[:, :Y], vx[:, :, :X], vz[..., :Z]], dim=-1)
-    return torch.cat([st, re.reshape(-1, 1, 1, 1, 1).expand(-1, Y, X, Z, 1).to(st.dtype)], dim=-1)
+    return _ToFeature3DFn.apply(vy, vx, vz, re)
 
 
 def to_staggered3d(t):
     """karman_train.py:88-90 with three components: zero padding at the high end of each component's own axis."""
-    pad = torch.nn.functional.pad
-    return pad(t[..., 0], (0, 0, 0, 0, 0, 1)), pad(t[..., 1], (0, 0, 0, 1)), pad(t[..., 2], (0, 1))
+    # (cat with zeros, not F.pad: its backward clone()s a narrow of the gradient -- contiguous at B = 1, i.e. a memcpy node: _lib.pad_high)
+    return _lib.pad_high(t[..., 0], 1), _lib.pad_high(t[..., 1], 2), _lib.pad_high(t[..., 2], 3)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -215,6 +229,14 @@ class MarsMoon3D:
         torch bumps `_version`; the library's own Adam (ctypes) does not -- Karman3DTrainer.apply_gradients resets the caches itself."""
         return (self.params.data_ptr(), self.params._version)
 
+    def invalidate(self):
+        """Drop the packed-weight caches.  MUST be called by whoever changes the CONTENT of `params` in a way torch's version counter does
+        not see: writes through `params.data` (`p.data.add_()`, `load_state_dict`-style `.data.copy_`), ctypes / HIP writes into the
+        buffer (the library's own Adam: Karman3DTrainer.apply_gradients calls this), external kernels.  `set_weights` calls it itself;
+        in-place torch ops on `params` bump `_version` and need nothing."""
+        self._packed = None
+        self._tpacks = None
+
     fused_backward = True      # one autograd node with a hand-written reverse sweep (False: one node per layer, torch glue)
 
     def __call__(self, x):
@@ -242,7 +264,8 @@ class MarsMoon3D:
         return int(self.offsets[-1])
 
     def tensors(self):
-        return [self.params[self.offsets[k]:self.offsets[k + 1]].reshape(self.shapes[k]) for k in range(len(self.shapes))]
+        from .ops import split_flat
+        return [t.reshape(s) for t, s in zip(split_flat(self.params, self.offsets), self.shapes)]
 
     def get_weights(self):
         return [t.detach().cpu().numpy() for t in self.tensors()]
@@ -252,8 +275,7 @@ class MarsMoon3D:
         assert flat.size == self.n_params, "weight list does not match %s" % self.name
         with torch.no_grad():
             self.params.copy_(torch.as_tensor(flat, device=self.params.device))
-        self._packed = None
-        self._tpacks = None
+        self.invalidate()
 
     def pack(self):
         """(packed weights, padded biases) per layer in the layout the conv kernels consume; cached until set_weights."""
@@ -327,7 +349,7 @@ def conv3d_bwd_weight(xk, dz, cin, cout, xmax=None, zmax=None):
     zmax = (zmax if zmax is not None and dzk is dz else _absmax(dzk)) if both32 else None
     check(lib.sol_conv3d_bwd_weight(stream(), ptr(xk), ptr(dzk), ptr(xmax), ptr(zmax),
                                     ptr(part), ptr(dW), ptr(db), ptr(scratch), B, D, H, W, cin_k, co_k, cin, co_k))
-    return dW[..., :cout].contiguous(), db[:cout].clone()
+    return (dW if co_k == cout else dW[..., :cout].contiguous()), (db if co_k == cout else _lib.dclone(db[:cout]))
 
 
 class _Conv3DFn(torch.autograd.Function):
@@ -481,7 +503,7 @@ class Karman3DTrainer:
         d, vy, vx, vz, re = self._in
         self.net.params.grad = None
         self.net._tpacks = None                     # the weights moved since the last step: re-pack once (inside the graph when captured)
-        v = (vy.detach().clone().requires_grad_(True), vx, vz)     # the state enters the graph (the step's autograd Function needs a grad-requiring input)
+        v = (_lib.dclone(vy).requires_grad_(True), vx, vz)     # the state enters the graph (the step's autograd Function needs a grad-requiring input)
         losses = []
         for i in range(self.ms):
             d, *v = self.sim.step(d, v[0], v[1], v[2], re)
@@ -489,14 +511,15 @@ class Karman3DTrainer:
             v = tuple(a + c for a, c in zip(v, to_staggered3d(out)))
             # (one kernel, no torch reduction: a multi-workgroup torch .sum() puts a memset node into the captured graph, ops.L2LossFn)
             losses.append(ops_l2_loss(v, tuple(g[i] for g in self._gt), self._std_v_host))
-        losses = torch.stack(losses)
+        losses = _lib.stack0(losses)
         loss = losses.sum() / self.ms
         loss.backward()
-        self.loss_steps.copy_(losses.detach())
-        self._loss.copy_(loss.detach())
-        self._grads.copy_(self.net.params.grad)
+        # (kernel copies: a contiguous tensor.copy_ is a hipMemcpyAsync = a memcpy node, refused by the capture guard -- _lib.dcopy_)
+        _lib.dcopy_(self.loss_steps, losses)
+        _lib.dcopy_(self._loss, loss)
+        _lib.dcopy_(self._grads, self.net.params.grad)
         for dst, src in zip(self._fin, (d,) + tuple(v)):
-            dst.copy_(src.detach())
+            _lib.dcopy_(dst, src)
 
     def fwd_bwd(self, d, vy, vx, vz, re, gts):
         """gts: [msteps] of (vy, vx, vz) frames, or the three stacked tensors [msteps, B, ...]."""
@@ -522,10 +545,7 @@ class Karman3DTrainer:
                     torch.cuda.current_stream().wait_stream(side)
                     torch.cuda.synchronize()
                     self.net.params.grad = None
-                    g = torch.cuda.CUDAGraph()
-                    with _lib.no_gc_during_capture(), torch.cuda.graph(g):
-                        self._unrolled()
-                    self._graph = g
+                    self._graph = _lib.capture_graph(self._unrolled, "Karman3DTrainer")      # kernel nodes only (sol_graph_check), then instantiated
                 self._graph.replay()
         self.final = tuple(self._fin)
         return self._loss
@@ -539,8 +559,7 @@ class Karman3DTrainer:
         p = self.net.params.detach()
         check(self.lib.sol_adam_tf_step(stream(), ptr(p), ptr(self._grads), ptr(self.m), ptr(self.v),
                                         self.net.n_params, self.t, float(lr), self.beta1, self.beta2, self.eps, 0.0, None, 0, None))
-        self.net._packed = None                     # both pack caches are stale now (the forward packs AND the training packs)
-        self.net._tpacks = None
+        self.net.invalidate()                       # both pack caches are stale now (the forward packs AND the training packs)
 
     def train_step(self, d, vy, vx, vz, re, gts, lr):
         """One training step on this rank's simulations; returns the GLOBAL loss tensor (the sum over all ranks' simulations)."""

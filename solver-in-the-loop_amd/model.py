@@ -48,7 +48,9 @@ class ConvNet:
 
     def tensors(self, flat=None):
         flat = self.params if flat is None else flat
-        return [flat[self.offsets[k]:self.offsets[k + 1]].reshape(self.shapes[k]) for k in range(len(self.shapes))]
+        # (ops.split_flat: ONE autograd node whose backward assembles the flat gradient with kernel copies -- plain slices cost a
+        #  memcpy node, a zero fill and an add of the whole buffer per tensor and unrolled step in a captured trainer)
+        return [t.reshape(s) for t, s in zip(ops.split_flat(flat, self.offsets), self.shapes)]
 
     # Keras-style API used by the reference scripts
     def get_weights(self):
@@ -131,8 +133,9 @@ class Mercury(ConvNet):
     def __call__(self, x, flat=None):
         p = self.tensors(flat)
         h = ops.conv5x5(x, p[0], p[1], None, True, 0.0)
-        ha = ops.conv5x5(h, p[2][..., :32].contiguous(), p[3][:32].contiguous(), None, True, 0.0)
-        hb = ops.conv5x5(h, p[2][..., 32:].contiguous(), p[3][32:].contiguous(), None, True, 0.0)
+        b3a, b3b = ops.split_flat(p[3], (0, 32, 64))           # (1-D halves: not plain slices, see ConvNet.tensors)
+        ha = ops.conv5x5(h, p[2][..., :32].contiguous(), b3a, None, True, 0.0)
+        hb = ops.conv5x5(h, p[2][..., 32:].contiguous(), b3b, None, True, 0.0)
         oa = ops.conv5x5(ha, p[4][:, :, :32].contiguous(), p[5], None, False, 0.0)
         return ops.conv5x5(hb, p[4][:, :, 32:].contiguous(), torch.zeros_like(p[5]), oa, False, 0.0)
 

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import KarmanCfg, check, ptr, stream
+from ._lib import KarmanCfg, SolError, check, ptr, stream
 
 EPI_NONE, EPI_LRELU, EPI_DLRELU = 0, 1, 2
 CONV_FWD, CONV_BWD_DATA = 0, 1
@@ -312,6 +312,46 @@ def burgers_step_large(vy, vx, fy, fx, cfg, circ, workspace=None):
     return oy, ox
 
 
+class SplitFlatFn(torch.autograd.Function):
+    """1-D tensor -> its consecutive pieces flat[b[k]:b[k+1]] (views) as ONE autograd node whose backward assembles the gradient with
+    KERNEL copies (_lib.dcopy_).  Why not plain slicing: the backward of a 1-D slice is zeros(n) + narrow.copy_(g), and a copy into a
+    contiguous narrow is a hipMemcpyAsync -- one MEMCPY NODE per parameter tensor and unrolled step in a captured trainer (refused by
+    sol_graph_check), next to an n-sized zero fill and an n-sized add each.  Used for the flat parameter buffer of the networks
+    (ConvNet.tensors, MarsMoon3D.tensors) and for the 1-D halves model_mercury takes of a bias."""
+
+    @staticmethod
+    def forward(ctx, flat, bounds):
+        ctx.bounds = tuple(int(b) for b in bounds)
+        ctx.n = flat.numel()
+        return tuple(flat[ctx.bounds[k]:ctx.bounds[k + 1]] for k in range(len(ctx.bounds) - 1))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        b = ctx.bounds
+        ref = next(g for g in gs if g is not None)
+        out = torch.empty(ctx.n, dtype=ref.dtype, device=ref.device)
+        if b[0] > 0:
+            out[:b[0]].zero_()
+        if b[-1] < ctx.n:
+            out[b[-1]:].zero_()
+        for k, g in enumerate(gs):
+            seg = out[b[k]:b[k + 1]]
+            if g is None:
+                seg.zero_()
+            elif g.is_cuda and g.dtype in (torch.float32, torch.int32):
+                _lib.dcopy_(seg, g.contiguous().reshape(-1))
+            else:
+                seg.copy_(g.reshape(-1))
+        return out, None
+
+
+def split_flat(flat, bounds):
+    """pieces flat[bounds[k]:bounds[k+1]] of a 1-D tensor; differentiable through SplitFlatFn when `flat` requires grad"""
+    if torch.is_grad_enabled() and flat.requires_grad:
+        return SplitFlatFn.apply(flat, tuple(int(b) for b in bounds))
+    return tuple(flat[int(bounds[k]):int(bounds[k + 1])] for k in range(len(bounds) - 1))
+
+
 def l2_loss_fwd_bwd(pred, gt, std, gscale=1.0, want_grad=True, loss=None, grads=None):
     """sol_l2_loss_fwd_bwd: the loss of ONE unrolled step, karman_train.py:428-436 -- 0.5 * sum(((gt - pred) / std)^2) over the
     staggered components `pred` / `gt` (tuples of 1..3 device tensors, e.g. (v_y [B,Y+1,X], v_x [B,Y,X+1])), `std` one scale per
@@ -321,6 +361,12 @@ def l2_loss_fwd_bwd(pred, gt, std, gscale=1.0, want_grad=True, loss=None, grads=
     assert 1 <= nc <= 3 and len(gt) == nc and len(std) == nc
     pred = [_lib.f32(t) for t in pred]
     gt = [_lib.f32(t) for t in gt]
+    for c in range(nc):     # the kernel reads n[c] = pred[c].numel() elements of BOTH: a mismatch would be an out-of-bounds device read
+        if gt[c].shape != pred[c].shape or gt[c].device != pred[c].device:
+            raise SolError("l2_loss_fwd_bwd: component %d: gt %s on %s does not match pred %s on %s" % (
+                c, tuple(gt[c].shape), gt[c].device, tuple(pred[c].shape), pred[c].device))
+        if grads is not None and (grads[c].shape != pred[c].shape or grads[c].device != pred[c].device):
+            raise SolError("l2_loss_fwd_bwd: component %d: grads %s does not match pred %s" % (c, tuple(grads[c].shape), tuple(pred[c].shape)))
     acc_g = grads is not None
     g = list(grads) if acc_g else ([torch.empty_like(t) for t in pred] if want_grad else None)
     acc_l = loss is not None

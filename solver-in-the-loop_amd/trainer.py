@@ -304,8 +304,7 @@ class GraphTrainer:
         from . import fluid, karman
         d0, vy0, vx0, re, gt_vy, gt_vx = self._in
         B, Y, X = self.B, self.Y, self.X
-        pad = torch.nn.functional.pad
-        stag = lambda vy, vx: torch.stack([pad(vy, (0, 1)), pad(vx, (0, 0, 0, 1))], dim=-1)     # [B,Y+1,X+1,2]
+        stag = lambda vy, vx: torch.stack([_lib.pad_high(vy, 2), _lib.pad_high(vx, 1)], dim=-1)     # [B,Y+1,X+1,2]
         st = fluid.Fluid(self.dom, density=d0.reshape(B, Y, X, 1), velocity=stag(vy0, vx0), batch_size=B)
         losses = []
         for i in range(self.msteps):
@@ -316,13 +315,14 @@ class GraphTrainer:
             # One kernel per step, no torch reduction (a multi-workgroup torch .sum() puts a memset node into the captured graph: ops.L2LossFn)
             vt, gt_t = st.velocity.staggered_tensor(), stag(gt_vy[i], gt_vx[i])
             losses.append(ops.l2_loss((vt[..., 0].contiguous(), vt[..., 1].contiguous()), (gt_t[..., 0].contiguous(), gt_t[..., 1].contiguous()), self._std_loss_host))
-        losses = torch.stack(losses)
+        losses = _lib.stack0(losses)
         self.net.params.grad = None
         (losses.sum() / self.msteps).backward()
-        self.loss_steps.copy_(losses.detach())
-        self.grads.copy_(self.net.params.grad)
+        # (kernel copies: a contiguous tensor.copy_ is a hipMemcpyAsync = a memcpy node, refused by the capture guard -- _lib.dcopy_)
+        _lib.dcopy_(self.loss_steps, losses)
+        _lib.dcopy_(self.grads, self.net.params.grad)
         vt = st.velocity.staggered_tensor().detach()
-        self._fin[0].copy_(st.density.data.detach().reshape(B, Y, X))
+        _lib.dcopy_(self._fin[0], st.density.data.detach().reshape(B, Y, X))
         self._fin[1].copy_(vt[:, :, :X, 0])
         self._fin[2].copy_(vt[:, :Y, :, 1])
 
@@ -345,10 +345,7 @@ class GraphTrainer:
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
                 self.net.params.grad = None
-                g = torch.cuda.CUDAGraph()
-                with _lib.no_gc_during_capture(), torch.cuda.graph(g):
-                    self._unrolled()
-                self._graph = g
+                self._graph = _lib.capture_graph(self._unrolled, "GraphTrainer")      # kernel nodes only (sol_graph_check), then instantiated
             self._graph.replay()
         self.final = self._fin if want_final else None
         return self.loss_steps.sum() / self.msteps

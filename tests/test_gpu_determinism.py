@@ -276,3 +276,140 @@ def test_reference_loss_composed_from_the_per_op_abi_equals_the_fused_trainer():
     loss.backward()
     assert abs(float(loss) - float(hl)) < 1e-5 * abs(float(hl)), (float(loss), float(hl))
     assert rel(params.grad, tr.grads) < 1e-4, rel(params.grad, tr.grads)
+
+
+# ---------------------------------------------------------------------------------------------
+# non-finite values are REPORTED, not laundered (round-4 advisor findings)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,Y,X,use_graph", [(6, 128, 64, True), (3, 64, 32, False), (2, 16, 8, False)])
+def test_non_finite_ground_truth_gives_a_non_finite_step_loss(B, Y, X, use_graph):
+    """tf.nn.l2_loss propagates NaN (karman_train.py:430-436): monitoring keyed on a non-finite loss must fire.  The exact integer
+    accumulator of the per-step losses (loss_add_exact) carries a poison bit for workgroup sums that are inf / nan; the other steps'
+    losses stay finite and equal to a clean run's."""
+    ms = 3
+    tr, (d, vy, vx, re, gy, gx) = _trainer2d(B, Y, X, ms, use_graph)
+    tr.fwd_bwd(d, vy, vx, re, gy, gx)
+    torch.cuda.synchronize()
+    clean = tr.loss_steps.clone()
+    assert bool(torch.isfinite(clean).all())
+    for bad in (float("nan"), float("inf")):
+        gy2 = gy.clone()
+        gy2[1, B - 1, Y // 2, X // 3] = bad                  # one face of one simulation in the SECOND unrolled step's frame
+        tr.grads.zero_()
+        tr.fwd_bwd(d, vy, vx, re, gy2, gx)
+        torch.cuda.synchronize()
+        ls = tr.loss_steps.clone()
+        assert not bool(torch.isfinite(ls[1])), "a %s ground-truth value left a finite step loss %r" % (bad, float(ls[1]))
+        assert same_bits(ls[0:1], clean[0:1]) and bool(torch.isfinite(ls[2]))
+    # and the accumulators are clean again afterwards
+    tr.grads.zero_()
+    tr.fwd_bwd(d, vy, vx, re, gy, gx)
+    torch.cuda.synchronize()
+    assert same_bits(tr.loss_steps, clean)
+
+
+def test_karman3d_adjoint_propagates_a_non_finite_gradient():
+    """The int64 fixed-point scatter of the 3-D advection adjoint must not turn an inf / nan upstream gradient into finite numbers:
+    the affected simulation's input gradient is NaN, the other simulation of the batch is untouched (bit for bit)."""
+    B, Y, X, Z = 2, 32, 16, 16
+    sc = k3.Scene3D(Y, X, Z, device=DEV)
+    sim = k3.Karman3DFlow(sc, B)
+    gen = torch.Generator().manual_seed(12)
+    r = lambda *s: torch.randn(*s, generator=gen)
+    d = f32(torch.rand(B, Y, X, Z, generator=gen))
+    v = [f32(1.0 + 0.3 * r(B, Y + 1, X, Z)), f32(0.3 * r(B, Y, X + 1, Z)), f32(0.3 * r(B, Y, X, Z + 1))]
+    w = [f32(r(*c.shape)) for c in v]
+    re = f32(torch.tensor(o3.RE_TRAIN[:B]))
+
+    def grads(ws):
+        hv = [c.clone().requires_grad_(True) for c in v]
+        out = sim.step(d, hv[0], hv[1], hv[2], re)
+        sum((a * b).sum() for a, b in zip(out[1:], ws)).backward()
+        return [c.grad for c in hv]
+    clean = grads(w)
+    for bad in (float("nan"), float("inf")):
+        w2 = [t.clone() for t in w]
+        w2[1][1, Y // 2, X // 2, Z // 2] = bad                # simulation 1, an interior v_x face
+        g = grads(w2)
+        for c, c0 in zip(g, clean):
+            assert bool(torch.isnan(c[1]).all()), "a %s gradient was laundered into finite numbers" % bad
+            assert same_bits(c[0], c0[0])
+
+
+def test_l2_loss_rejects_mismatched_shapes():
+    a, b = torch.zeros(2, 9, 8, device=DEV), torch.zeros(2, 8, 9, device=DEV)
+    with pytest.raises(sol_amd.SolError):
+        ops.l2_loss_fwd_bwd((a, b), (a, torch.zeros(2, 8, 8, device=DEV)), (0.2, 0.2))
+    with pytest.raises(sol_amd.SolError):
+        ops.l2_loss_fwd_bwd((a, b), (a, b), (0.2, 0.2), grads=[torch.zeros_like(a), torch.zeros(3, device=DEV)])
+
+
+# ---------------------------------------------------------------------------------------------
+# graph-capture guard (sol_graph_check): kernel nodes only
+# ---------------------------------------------------------------------------------------------
+def test_captured_graphs_hold_kernel_nodes_only_and_the_guard_refuses_a_planted_reduction():
+    """Every capture site passes its graph through sol_graph_check before instantiating it.  (1) The census of a clean capture of the
+    library's kernels shows kernel nodes only.  (2) A multi-workgroup torch reduction planted inside a captured trainer -- the round-4
+    defect: its semaphore clear becomes a MEMSET node, unreliable under replay on ROCm 7.2 -- is REFUSED at capture time with a message
+    naming the node type.  (3) So is a device-to-device copy_ (memcpy node).  (4) The C++ capture (sol_train_graph_create) is checked
+    by the same function; its graph is clean."""
+    from sol_amd import _lib
+    x = torch.randn(1 << 20, device=DEV)
+    y = torch.empty_like(x)
+    out = torch.zeros(1, device=DEV)
+
+    def clean():
+        torch.mul(x, 2.0, out=y)
+    torch.cuda.synchronize()
+    g = _lib.capture_graph(clean, "clean probe")
+    g.replay()
+    torch.cuda.synchronize()
+    assert rel(y, 2.0 * x) == 0.0
+    raw = torch.cuda.CUDAGraph(keep_graph=True)
+    with _lib.no_gc_during_capture(), torch.cuda.graph(raw):
+        clean()
+    cen = _lib.graph_census(raw.raw_cuda_graph())
+    assert cen.get("kernel", 0) >= 1 and set(cen) <= {"kernel", "empty"}, cen
+
+    def planted_sum():
+        torch.mul(x, 2.0, out=y)
+        out.copy_(y.sum().reshape(1))          # 2^20 elements: a multi-workgroup reduction (semaphores cleared by a memset)
+    x.sum().item()                             # (warm the reduction's workspace allocation outside the capture)
+    with pytest.raises(sol_amd.SolError, match="memset|memcpy"):
+        _lib.capture_graph(planted_sum, "planted reduction")
+
+    def planted_copy():
+        y.copy_(x)                             # same dtype, contiguous: hipMemcpyAsync -> a memcpy node
+    with pytest.raises(sol_amd.SolError, match="memcpy"):
+        _lib.capture_graph(planted_copy, "planted copy")
+
+    # a trainer with the planted reduction: GraphTrainer computing its loss with torch instead of ops.L2LossFn
+    B, Y, X, ms = 6, 128, 64, 2
+    g_ = o.geometry(Y, X)
+    mk = ops.SceneMasks(g_.active, g_.inflow, g_.bc_mask, g_.bc_mask)
+    net = sol_amd.model_mercury(seed=0, device=DEV)
+    tr = sol_amd.GraphTrainer(net, B, Y, X, ms, (0.2, 0.25), o.STD_RE, dx=g_.dx, masks=mk)
+    d, vy, vx = (f32(t) for t in o.synthetic_state(B, Y, X, 31, project_it=False))
+    re = f32(torch.tensor(o.RE_TRAIN[:B]))
+    gts = [o.synthetic_state(B, Y, X, 600 + i, project_it=False) for i in range(ms)]
+    gy, gx = f32(torch.stack([s[1] for s in gts])), f32(torch.stack([s[2] for s in gts]))
+    orig = tr._unrolled
+    probe = torch.zeros(1, device=DEV)
+
+    def bad_unrolled():
+        orig()
+        probe.add_(x.sum())                    # 2^20 elements: a multi-workgroup reduction
+    tr._unrolled = bad_unrolled
+    with pytest.raises(sol_amd.SolError, match="memset"):
+        tr.fwd_bwd(d, vy, vx, re, gy, gx)
+    assert tr._graph is None
+    tr._unrolled = orig                        # the honest trainer captures, replays and matches its eager self
+    l1 = float(tr.fwd_bwd(d, vy, vx, re, gy, gx))
+    l2 = float(tr.fwd_bwd(d, vy, vx, re, gy, gx))
+    assert tr._graph is not None and l1 == l2 and np.isfinite(l1)
+
+    # the C++ schedule's graph
+    tr2, batch = _trainer2d(3, 64, 32, 2, True)
+    tr2.fwd_bwd(*batch)
+    torch.cuda.synchronize()
+    assert len(tr2._graphs) == 1
