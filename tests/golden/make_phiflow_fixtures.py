@@ -14,8 +14,12 @@ it loads the inputs of three committed oracle fixtures, runs the reference's OWN
 with the same array names as the oracle fixtures.  tests/test_phiflow_pin.py then compares the oracle with them (it skips while
 they are absent) and reports which setting of the recalled choices Q2-Q7 reproduces PhiFlow.
 
-    pip install phiflow==1.5.1 tensorflow==1.15      # python 3.6 / 3.7
+    pip install phiflow==1.5.1 tensorflow==1.15      # python 3.6 / 3.7      (the whole recipe, expected sizes and what to commit: PIN.md)
     python tests/golden/make_phiflow_fixtures.py --reference /path/to/Solver-in-the-Loop
+
+Every file carries a provenance record (pin_provenance.py: sha256 of the committed inputs it was made from, `git rev-parse HEAD` and a
+hash of the reference scripts, a hash of this generator, the package versions); tests/test_phiflow_pin.py verifies it, so a stale or
+hand-made fixture cannot pin anything.
 
 The reference's classes and functions are NOT restated here: `reference_defs` parses the reference's scripts and executes
 exactly the `def` / `class` statements named (KarmanFlow, to_feature, to_staggered, model_mars_moon, BurgersTest,
@@ -34,6 +38,30 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import pin_provenance as prov  # noqa: E402
+
+
+def provenance(ref, input_fixture, scripts, versions):
+    """The record tests/test_phiflow_pin.py verifies (tests/golden/pin_provenance.py): which inputs, which reference, which generator."""
+    import datetime
+    import hashlib
+    import subprocess
+    try:
+        commit = subprocess.run(["git", "-C", ref, "rev-parse", "HEAD"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                universal_newlines=True).stdout.strip() or "unknown"
+    except OSError:
+        commit = "unknown"
+    h = hashlib.sha256()
+    for rel_path in scripts:                       # a HASH of the reference scripts the definitions were lifted from; no text is stored
+        h.update(rel_path.encode())
+        h.update(prov.file_sha256(os.path.join(ref, rel_path)).encode())
+    z = np.load(os.path.join(HERE, input_fixture))
+    return {"input_fixture": input_fixture, "input_sha256": prov.input_sha256(z, prov.INPUT_KEYS[prov.kind_of(input_fixture)]),
+            "reference_commit": commit if len(commit) >= 7 else "unknown", "reference_scripts_sha256": h.hexdigest(),
+            "generator_sha256": prov.file_sha256(os.path.abspath(__file__)),
+            "phiflow_version": versions[0], "tensorflow_version": versions[1], "python_version": sys.version.split()[0],
+            "created_utc": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%M:%SZ")}
 
 
 def need_reference_stack():
@@ -203,14 +231,16 @@ def main():
     versions = need_reference_stack()
     if not os.path.exists(os.path.join(args.reference, "karman-2d", "karman_train.py")):
         raise SystemExit("--reference %s: karman-2d/karman_train.py not found" % args.reference)
-    jobs = {"step64": ("phiflow_karman_step_64x32.npz", lambda: karman_step_fixture(args.reference, "karman_step_64x32")),
-            "step16": ("phiflow_karman_step_16x8.npz", lambda: karman_step_fixture(args.reference, "karman_step_16x8")),
-            "burgers": ("phiflow_burgers_step_32x32.npz", lambda: burgers_step_fixture(args.reference)),
-            "train": ("phiflow_train_16x8_sol2.npz", lambda: train_fixture(args.reference))}
+    KT, BT = os.path.join("karman-2d", "karman_train.py"), os.path.join("burgers", "burgers_train.py")
+    # key -> (output file, input fixture, reference scripts the definitions come from, job)
+    jobs = {"step64": ("phiflow_karman_step_64x32.npz", "karman_step_64x32.npz", [KT], lambda: karman_step_fixture(args.reference, "karman_step_64x32")),
+            "step16": ("phiflow_karman_step_16x8.npz", "karman_step_16x8.npz", [KT], lambda: karman_step_fixture(args.reference, "karman_step_16x8")),
+            "burgers": ("phiflow_burgers_step_32x32.npz", "burgers_step_32x32.npz", [BT], lambda: burgers_step_fixture(args.reference)),
+            "train": ("phiflow_train_16x8_sol2.npz", "train_16x8_sol2.npz", [KT], lambda: train_fixture(args.reference))}
     for key in (args.only.split(",") if args.only else jobs):
-        fname, fn = jobs[key]
+        fname, infix, scripts, fn = jobs[key]
         data = fn()
-        data["phiflow_version"], data["tensorflow_version"] = versions
+        data.update(provenance(args.reference, infix, scripts, versions))       # verified by tests/test_phiflow_pin.py before the file may pin anything
         np.savez_compressed(os.path.join(args.out, fname), **data)
         print("wrote", os.path.join(args.out, fname), os.path.getsize(os.path.join(args.out, fname)) // 1024, "KB")
 

@@ -15,6 +15,8 @@ import torch
 import sol_oracle as o
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, GOLDEN)
+import pin_provenance as prov  # noqa: E402
 TOL_FIELD, TOL_GRAD, TOL_LOSS = 1e-5, 1e-4, 1e-5
 
 # candidate settings of the recalled choices: name -> (karman_step kwargs, geometry kwargs)
@@ -115,21 +117,25 @@ def verdict(res, what):
 def test_oracle_karman_step_against_phiflow(name):
     path = os.path.join(GOLDEN, name + ".npz")
     if not os.path.exists(path):
-        pytest.skip("PARITY UNPINNED: %s.npz is absent (generate it with tests/golden/make_phiflow_fixtures.py where phiflow 1.5.1 + TF 1.15 are installed)" % name)
+        pytest.skip("PARITY UNPINNED: %s.npz is absent (generate it with tests/golden/make_phiflow_fixtures.py where phiflow 1.5.1 + TF 1.15 are installed: tests/golden/PIN.md)" % name)
+    infix = name.replace("phiflow_", "") + ".npz"
+    print("pin provenance:", prov.verify(np.load(path), np.load(os.path.join(GOLDEN, infix)), infix))      # a stale / hand-made fixture pins nothing
     verdict(compare_karman_step(np.load(path)), name)
 
 
 def test_oracle_burgers_step_against_phiflow():
     path = os.path.join(GOLDEN, "phiflow_burgers_step_32x32.npz")
     if not os.path.exists(path):
-        pytest.skip("PARITY UNPINNED: phiflow_burgers_step_32x32.npz is absent (tests/golden/make_phiflow_fixtures.py)")
+        pytest.skip("PARITY UNPINNED: phiflow_burgers_step_32x32.npz is absent (tests/golden/make_phiflow_fixtures.py, tests/golden/PIN.md)")
+    print("pin provenance:", prov.verify(np.load(path), np.load(os.path.join(GOLDEN, "burgers_step_32x32.npz")), "burgers_step_32x32.npz"))
     verdict(compare_burgers_step(np.load(path)), "burgers step_with_f")
 
 
 def test_oracle_unrolled_loss_against_phiflow():
     path = os.path.join(GOLDEN, "phiflow_train_16x8_sol2.npz")
     if not os.path.exists(path):
-        pytest.skip("PARITY UNPINNED: phiflow_train_16x8_sol2.npz is absent (tests/golden/make_phiflow_fixtures.py)")
+        pytest.skip("PARITY UNPINNED: phiflow_train_16x8_sol2.npz is absent (tests/golden/make_phiflow_fixtures.py, tests/golden/PIN.md)")
+    print("pin provenance:", prov.verify(np.load(path), np.load(os.path.join(GOLDEN, "train_16x8_sol2.npz")), "train_16x8_sol2.npz"))
     verdict(compare_train(np.load(path), np.load(os.path.join(GOLDEN, "train_16x8_sol2.npz"))), "unrolled SOL-2 loss")
 
 
@@ -202,3 +208,49 @@ def test_generator_script_fails_clearly_without_the_reference_stack_and_finds_th
     mk.reference_defs(os.path.join(ref, "burgers", "burgers_train.py"), ["BurgersVelocitySMAC", "BurgersTest"], ns)
     assert all(k in ns for k in ("KarmanFlow", "to_feature", "to_staggered", "model_mars_moon", "BurgersTest", "BurgersVelocitySMAC"))
     assert mk.velocity_bc(64, 32, 1).sum() == 190 and mk.velocity_bc(128, 64, 1).sum() == 382         # the BC-cell counts of the known-answer tests
+
+
+def _stand_in_pin(name, infix, **override):
+    """a pin file as the generator would write it (outputs = the oracle fixture's own), with a provenance record"""
+    z = dict(np.load(os.path.join(GOLDEN, infix)))
+    rec = {"input_fixture": infix, "input_sha256": prov.input_sha256(z, prov.INPUT_KEYS[prov.kind_of(infix)]), "reference_commit": "0123456789abcdef",
+           "reference_scripts_sha256": "a" * 64, "generator_sha256": prov.file_sha256(os.path.join(GOLDEN, "make_phiflow_fixtures.py")),
+           "phiflow_version": "1.5.1", "tensorflow_version": "1.15.5", "python_version": "3.7.16", "created_utc": "2026-01-01T00:00:00Z"}
+    rec.update(override)
+    z.update(rec)
+    return z
+
+
+def test_pin_provenance_ties_a_fixture_to_the_committed_inputs_and_refuses_stale_or_hand_made_ones(tmp_path):
+    """tests/golden/pin_provenance.py: the record make_phiflow_fixtures.py writes and the checks a fixture must pass before it may pin."""
+    infix = "karman_step_16x8.npz"
+    committed = np.load(os.path.join(GOLDEN, infix))
+    good = _stand_in_pin("phiflow_karman_step_16x8", infix)
+    p = tmp_path / "phiflow_karman_step_16x8.npz"
+    np.savez_compressed(p, **good)                                     # through the container: strings / scalars survive the round trip
+    rec = prov.verify(np.load(p), committed, infix)
+    assert rec["input_fixture"] == infix and rec["phiflow_version"] == "1.5.1"
+    # hand-made (no record)
+    bare = {k: v for k, v in good.items() if k not in prov.FIELDS}
+    with pytest.raises(AssertionError, match="lacks provenance"):
+        prov.verify(bare, committed, infix)
+    # stale: made from inputs that have since changed (one bit of one input differs)
+    stale = dict(good)
+    stale["vy"] = good["vy"].copy()
+    stale["vy"].reshape(-1)[3] = np.nextafter(stale["vy"].reshape(-1)[3], 1e9)
+    with pytest.raises(AssertionError, match="stored copy of input 'vy' differs"):
+        prov.verify(stale, committed, infix)
+    with pytest.raises(AssertionError, match="are not the committed"):
+        prov.verify(_stand_in_pin("x", infix, input_sha256="0" * 64), committed, infix)
+    # made from another fixture, with another PhiFlow, or with a non-1.15 TensorFlow
+    with pytest.raises(AssertionError, match="was made from"):
+        prov.verify(_stand_in_pin("x", infix, input_fixture="karman_step_64x32.npz"), committed, infix)
+    with pytest.raises(AssertionError, match="phiflow 2.0"):
+        prov.verify(_stand_in_pin("x", infix, phiflow_version="2.0.3"), committed, infix)
+    with pytest.raises(AssertionError, match="tensorflow 2.4"):
+        prov.verify(_stand_in_pin("x", infix, tensorflow_version="2.4.1"), committed, infix)
+    # the hash does not depend on the container or on the order / presence of other arrays, only on the input arrays
+    assert prov.input_sha256(committed, prov.INPUT_KEYS["karman_step"]) == prov.input_sha256(dict(committed), prov.INPUT_KEYS["karman_step"])
+    for fx in ("burgers_step_32x32.npz", "train_16x8_sol2.npz", "karman_step_64x32.npz"):
+        z = np.load(os.path.join(GOLDEN, fx))
+        assert all(k in z.files for k in prov.INPUT_KEYS[prov.kind_of(fx)]), (fx, z.files)
