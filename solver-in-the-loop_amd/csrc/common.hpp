@@ -244,6 +244,48 @@ inline int sol_lds_optin(std::atomic<unsigned long long>& done, std::initializer
     return SOL_OK;
 }
 
+// ---- write-through output stores (round 5) ------------------------------------------------------------------------------------
+// gfx950 = 8 XCDs, each with its own L2 that is NOT coherent with the others: a kernel's plain stores stay dirty in the XCD's L2 and
+// the release at the END of the kernel writes them all back in one burst -- in front of the next launch of the dependency chain, which
+// is what every launch of this path is.  Measured on the 32 -> 32 convolution (6.3 MB of output per launch, 640 launches per SOL-32
+// step; tools/ab_lib.py, one box, three alternations): plain 13.128 ms per step, nontemporal (nt) 13.103, agent-scope write-through (sc1)
+// 12.775, system scope (sc0 sc1) 12.808.  With sc1 the lines leave the L2 while the other workgroups still compute and the end-of-kernel
+// write-back finds nothing to do.  Use for a kernel's BULK outputs that the NEXT launch consumes; not for read-modify-write sequences of
+// one thread on one address (the compiler does not see these stores in its vmcnt bookkeeping: extra stores only make its waits more
+// conservative, but it will not order a later load of the same address behind them; the 16-byte form carries its own wait states).
+// SOL_WT_STORES=0 (A/B builds): plain stores everywhere.
+#ifndef SOL_WT_STORES
+#define SOL_WT_STORES 1
+#endif
+typedef float sol_f32x4 __attribute__((ext_vector_type(4)));
+typedef float sol_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_wt(float4* p, const float4& v) {
+#if SOL_WT_STORES
+    const sol_f32x4 q = {v.x, v.y, v.z, v.w};
+    // s_nop 1: a VMEM store of more than 8 bytes followed by a VALU write of its data VGPRs needs 2 wait states on gfx940+; the
+    // compiler's hazard recognizer does not look inside inline asm (without it: an unrolled store loop reused the data registers
+    // at once and the weight-gradient partials came out wrong, tests/test_gpu_parity.py::test_conv5x5_against_oracle)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(q) : "memory");
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void st_wt(float2* p, const float2& v) {
+#if SOL_WT_STORES
+    const sol_f32x2 q = {v.x, v.y};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(q) : "memory");
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void st_wt(float* p, float v) {
+#if SOL_WT_STORES
+    asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
+
 // wave64 all-reduce (every lane gets the sum)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

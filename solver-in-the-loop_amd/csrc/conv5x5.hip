@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) k_conv5x5(ConvArgs a) {
                 v.z *= q.z > 0.f ? 1.f : a.slope; v.w *= q.w > 0.f ? 1.f : a.slope;
             }
             vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-            reinterpret_cast<float4*>(a.y)[o4] = v;
+            st_wt(reinterpret_cast<float4*>(a.y) + o4, v);
         }
     } else {
 #pragma unroll
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256) k_conv5x5(ConvArgs a) {
                 if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
                 else if (a.epi == SOL_EPI_DLRELU) v *= (a.act[o] > 0.f ? 1.f : a.slope);
                 vmax = fmaxf(vmax, fabsf(v));
-                a.y[o] = v;
+                st_wt(a.y + o, v);
             }
         }
     }
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256) k_conv5x5_c32(ConvArgs a) {
             if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
             else if (a.epi == SOL_EPI_DLRELU) v *= (a.act[o] > 0.f ? 1.f : a.slope);
             vmax = fmaxf(vmax, fabsf(v));
-            a.y[o] = v;
+            st_wt(a.y + o, v);
         }
     }
     if (a.ymax) {                                    // workgroup uniform
@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_r3(ConvArgs a, int ntiles) {
                     v.x *= q.x > 0.f ? 1.f : a.slope; v.y *= q.y > 0.f ? 1.f : a.slope;
                     v.z *= q.z > 0.f ? 1.f : a.slope; v.w *= q.w > 0.f ? 1.f : a.slope;
                 }
-                reinterpret_cast<float4*>(a.y)[o4] = v;
+                st_wt(reinterpret_cast<float4*>(a.y) + o4, v);
             }
         }
         return;
@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_r3(ConvArgs a, int ntiles) {
             if (a.res) v += a.res[o];
             if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
             else if (a.epi == SOL_EPI_DLRELU) v *= (a.act[o] > 0.f ? 1.f : a.slope);
-            a.y[o] = v;
+            st_wt(a.y + o, v);
         }
     }
 }

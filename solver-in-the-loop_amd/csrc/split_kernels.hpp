@@ -12,6 +12,14 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __host__ __device__ __forceinline__ int swzb(int idx) { return ((idx >> 2) & 1) << 1; }
+// chunk swizzles of the weight-gradient staging planes (bww_sb_body): see the layout comment there
+#ifdef BW_SWZ_READS_ONLY      // A/B switch (tools/ab_lib.py): the swizzles of rounds 1-4, conflict-free for the reads only
+__host__ __device__ __forceinline__ int bw_swx(int ch) { return ch & 15; }
+__host__ __device__ __forceinline__ int bw_swz(int ch) { return (ch >> 1) & 7; }
+#else
+__host__ __device__ __forceinline__ int bw_swx(int ch) { return ((ch ^ (ch >> 2)) & 3) | ((((ch >> 2) ^ (ch >> 4)) & 1) << 2) | (((ch >> 3) & 1) << 3); }
+__host__ __device__ __forceinline__ int bw_swz(int ch) { return (((ch >> 1) ^ (ch >> 4)) & 1) | (((ch >> 2) & 3) << 1); }
+#endif
 
 // two fp32 -> packed pair of bf16 (round to nearest even), low half = first element
 __device__ __forceinline__ unsigned pk_bf16(float x, float y) {
@@ -69,8 +77,17 @@ __device__ __forceinline__ void split2u(float x, float y, float scale, unsigned&
 // through LDS at the end.  The dx shift along K is done in registers: a lane reads pixels 8g..8g+11 of
 // its channel (b128 + b64) and builds the five shifted operands with v_alignbit (dx odd) or by register
 // renaming (dx even) -- no unaligned LDS access and the x operand is reused for all five tap rows.
-// LDS rows: x 16 chunks of 16 B per channel (68 px used), chunk ^= ci & 15; dz 8 chunks, chunk ^= (co >> 1) & 7
-// (both conflict-free for the CDNA4 ds_read_b128 lane groups).
+// LDS rows: x 16 chunks of 16 B per channel (68 px used), chunk ^= bw_swx(ci); dz 8 chunks, chunk ^= bw_swz(co).
+// The swizzles serve BOTH sides (round 5; until then chunk ^= ci & 15 / (co >> 1) & 7 served the reads only and the transposed
+// staging writes ran 4-way / 2-way conflicted: 3.1 M SQ_LDS_BANK_CONFLICT cycles per fused launch, profiles/r04_pmc_sq.txt):
+//   reads   ds_read_b128, lane groups of 16 on 64 banks: the 16 channels li of a wave's tile (channel bits 0..3) must spread over the
+//           16 chunk slots of a 256-byte bank row -- the map (bits 0..3) -> chunk must be a bijection;
+//   writes  ds_write_b32, lane groups of 32 on 32 banks ((a / 4) mod 32 = (chunk & 7) * 4 + pixel pair & 3): a group holds one
+//           pixel-pair quad and the eight channel QUADS c4 of a row item (channel = 4 c4 + c: bits 2..4 vary) -- the map
+//           (bits 2..4) -> chunk & 7 must be a bijection too.
+// Both are linear over GF(2) in the channel bits b0..b4:  x: (b0^b2, b1^b3, b2^b4, b3);  dz: (b1^b4, b2, b3)  [dz rows are 128 B:
+// b0 selects the half of the bank row].  A lane group's two chunk bases differ by 1 (g, g+1): the sets stay disjoint because the
+// channel pairs that differ by the pre-image of 1 (li ^ 1 for x, li ^ 2 for dz) lie in the same half of the group.
 #ifndef BWW_B_UPFRONT
 #define BWW_B_UPFRONT 1
 #endif
@@ -144,7 +161,7 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
             unsigned p[3];
             if constexpr (KIND == 2) split2u(e[c][0], e[c][1], is_x ? sx : sz, p[0], p[1]);
             else split3(e[c][0], e[c][1], p[0], p[1], p[2]);
-            const int sw = is_x ? (ch & 15) : ((ch >> 1) & 7);
+            const int sw = is_x ? bw_swx(ch) : bw_swz(ch);
             unsigned char* q = base + ch * row_bytes + ((((pg >> 2) ^ sw) << 4) | ((pg & 3) << 2));
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<unsigned*>(q + pl * plane_bytes) = p[pl];
@@ -186,7 +203,7 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
             for (int e = tid; e < 2 * NPL * 32 * 2; e += 256) {
                 const int side = e & 1, ch = (e >> 1) & 31, pl = (e >> 6) % NPL, st = e / (64 * NPL);
                 const int pg = side ? 33 : 0;
-                *reinterpret_cast<unsigned*>(XS + st * BW_XST + pl * BW_XPL + ch * 256 + ((((pg >> 2) ^ (ch & 15)) << 4) | ((pg & 3) << 2))) = 0u;
+                *reinterpret_cast<unsigned*>(XS + st * BW_XST + pl * BW_XPL + ch * 256 + ((((pg >> 2) ^ bw_swx(ch)) << 4) | ((pg & 3) << 2))) = 0u;
             }
         } else {
 #pragma unroll
@@ -203,6 +220,7 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
     constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
     const int c0 = 4 * kb + g;
+    const int swx_l = bw_swx(16 * mt + li), swz_l = bw_swz(16 * nt + li);      // this lane's channel rows of the x / dz operands
 
     // one image row: request the items of x row gr+3 / dz row gr+5 into (i0, i1), run the 25 taps of row gr, write the items
     // held in (o0, o1) -- x row gr+1 / dz row gr+3, requested two iterations ago -- to LDS
@@ -217,8 +235,8 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
             const unsigned char* xs = XS + (gr & 1) * BW_XST + (16 * mt + li) * 256;
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) {
-                const uint4 q = *reinterpret_cast<const uint4*>(xs + pl * BW_XPL + ((c0 ^ li) << 4));
-                const uint2 e = *reinterpret_cast<const uint2*>(xs + pl * BW_XPL + (((c0 + 1) ^ li) << 4));
+                const uint4 q = *reinterpret_cast<const uint4*>(xs + pl * BW_XPL + ((c0 ^ swx_l) << 4));
+                const uint2 e = *reinterpret_cast<const uint2*>(xs + pl * BW_XPL + (((c0 + 1) ^ swx_l) << 4));
                 A[pl][0] = q;
                 A[pl][2] = make_uint4(q.y, q.z, q.w, e.x);
                 A[pl][4] = make_uint4(q.z, q.w, e.x, e.y);
@@ -236,7 +254,7 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
 #pragma unroll
             for (int dy = 0; dy < 5; ++dy) {
                 const int gz = gr + 2 - dy;
-                const unsigned char* zs = ZS + ((gz + 6) % 6) * BW_ZST + (16 * nt + li) * 128 + ((c0 ^ ((li >> 1) & 7)) << 4);
+                const unsigned char* zs = ZS + ((gz + 6) % 6) * BW_ZST + (16 * nt + li) * 128 + ((c0 ^ swz_l) << 4);
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) Bv[dy][pl] = *reinterpret_cast<const uint4*>(zs + pl * BW_ZPL);
             }
@@ -259,7 +277,7 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
                 const int yz = y + 2 - dy;
                 if (yz < 0 || yz >= H) continue;            // workgroup uniform
                 const int gz = gr + 2 - dy;
-                const unsigned char* zs = ZS + ((gz + 6) % 6) * BW_ZST + (16 * nt + li) * 128 + ((c0 ^ ((li >> 1) & 7)) << 4);
+                const unsigned char* zs = ZS + ((gz + 6) % 6) * BW_ZST + (16 * nt + li) * 128 + ((c0 ^ swz_l) << 4);
                 uint4 Bv[NPL];
     #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) Bv[pl] = *reinterpret_cast<const uint4*>(zs + pl * BW_ZPL);
@@ -341,7 +359,7 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
             if (e < 4 * 25 * 64) {
                 const int c4 = e & 3, row = (e >> 2) & 15, tp = (e >> 6) % 25, wt = e / (25 * 64);
                 const float4 v = *reinterpret_cast<const float4*>(&red[(wt * 25 + tp) * 256 + row * 16 + c4 * 4]);
-                *dst_of(e) = make_float4(old[k].x + v.x, old[k].y + v.y, old[k].z + v.z, old[k].w + v.w);
+                *dst_of(e) = make_float4(old[k].x + v.x, old[k].y + v.y, old[k].z + v.z, old[k].w + v.w);      // (write-through stores measured no gain here: 12.86 vs 12.91 ms per step)
             }
         }
     }
