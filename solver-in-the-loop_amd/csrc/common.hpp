@@ -250,7 +250,8 @@ inline int sol_lds_optin(std::atomic<unsigned long long>& done, std::initializer
 // is what every launch of this path is.  Measured on the 32 -> 32 convolution (6.3 MB of output per launch, 640 launches per SOL-32
 // step; tools/ab_lib.py, one box, three alternations): plain 13.128 ms per step, nontemporal (nt) 13.103, agent-scope write-through (sc1)
 // 12.775, system scope (sc0 sc1) 12.808.  With sc1 the lines leave the L2 while the other workgroups still compute and the end-of-kernel
-// write-back finds nothing to do.  Use for a kernel's BULK outputs that the NEXT launch consumes; not for read-modify-write sequences of
+// write-back finds nothing to do.  Use for a kernel's BULK outputs that the NEXT launch consumes, in full 16-byte pieces (scattered
+// 4-byte write-through stores -- the thin layers' strided channels, the velocity correction -- measured SLOWER: 10.5 -> 11.0 us per launch); not for read-modify-write sequences of
 // one thread on one address (the compiler does not see these stores in its vmcnt bookkeeping: extra stores only make its waits more
 // conservative, but it will not order a later load of the same address behind them; the 16-byte form carries its own wait states).
 // SOL_WT_STORES=0 (A/B builds): plain stores everywhere.

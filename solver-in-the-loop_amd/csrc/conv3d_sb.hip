@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(768) k_conv3d_sb(ConvArgs a, int nrows, int D)
                 v.z *= q.z > 0.f ? 1.f : a.slope; v.w *= q.w > 0.f ? 1.f : a.slope;
             }
             vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-            reinterpret_cast<float4*>(a.y)[o4] = v;
+            st_wt(reinterpret_cast<float4*>(a.y) + o4, v);
         }
     }
     if (a.ymax) amax_publish_last(vmax, a.ymax, reinterpret_cast<unsigned*>(smem_c3 + AMAX_LDS));
@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(768) k_conv3d_sb6(ConvArgs a, int nrows, int D
                 v.z *= q.z > 0.f ? 1.f : a.slope; v.w *= q.w > 0.f ? 1.f : a.slope;
             }
             vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-            reinterpret_cast<float4*>(a.y)[o4] = v;
+            st_wt(reinterpret_cast<float4*>(a.y) + o4, v);
         }
     }
     if (a.ymax) amax_publish_last(vmax, a.ymax, reinterpret_cast<unsigned*>(smem_c6 + AMAX_LDS));
@@ -810,7 +810,7 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
                 v.z *= q.z > 0.f ? 1.f : a.slope; v.w *= q.w > 0.f ? 1.f : a.slope;
             }
             vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-            reinterpret_cast<float4*>(a.y)[o4] = v;
+            st_wt(reinterpret_cast<float4*>(a.y) + o4, v);
         }
     } else if (tvalid) {                              // CO < OP stored channels per pixel (the thin layers): the row's 64 * CO floats are contiguous
         const int n_out = 64 * a.CO;

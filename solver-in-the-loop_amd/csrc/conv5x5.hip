@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256) k_conv5x5(ConvArgs a) {
                 if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
                 else if (a.epi == SOL_EPI_DLRELU) v *= (a.act[o] > 0.f ? 1.f : a.slope);
                 vmax = fmaxf(vmax, fabsf(v));
-                st_wt(a.y + o, v);
+                a.y[o] = v;
             }
         }
     }
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256) k_conv5x5_c32(ConvArgs a) {
             if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
             else if (a.epi == SOL_EPI_DLRELU) v *= (a.act[o] > 0.f ? 1.f : a.slope);
             vmax = fmaxf(vmax, fabsf(v));
-            st_wt(a.y + o, v);
+            a.y[o] = v;
         }
     }
     if (a.ymax) {                                    // workgroup uniform
@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_r3(ConvArgs a, int ntiles) {
             if (a.res) v += a.res[o];
             if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
             else if (a.epi == SOL_EPI_DLRELU) v *= (a.act[o] > 0.f ? 1.f : a.slope);
-            st_wt(a.y + o, v);
+            a.y[o] = v;
         }
     }
 }

@@ -324,8 +324,8 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
                 float* vy = a.cvy + (size_t)b * nVy;
                 float* vx = a.cvx + (size_t)b * nVx;
                 const float v0 = cpv[j][0] + a.cs0 * o4[0], v1 = cpv[j][1] + a.cs1 * o4[1];       // (operands prefetched during the tap loop)
-                st_wt(&vy[f.oy], v0);
-                st_wt(&vx[f.ox], v1);
+                vy[f.oy] = v0;
+                vx[f.ox] = v1;
                 if (a.gty) {
                     const float d = (cpv[j][2] - v0) / a.ls0;
                     lsum += 0.5f * d * d;
@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
                     if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
                     else if (a.epi == SOL_EPI_DLRELU) v *= (a.act[o] > 0.f ? 1.f : a.slope);
                     vmax = fmaxf(vmax, fabsf(v));
-                    st_wt(a.y + o, v);
+                    a.y[o] = v;
                 }
             }
         }

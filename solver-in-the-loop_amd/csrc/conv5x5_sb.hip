@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
                 const CorrFaces f = corr_faces(a.ctr, H, W, jj, x0 + wave * 16 + 4 * g + r);
                 const int o = li == 0 ? f.oy : f.ox, e = li == 0 ? f.ey : f.ex;
                 const float v = vf[o] + s * (acc[0][r] + bias);
-                st_wt(&vf[o], v);
+                vf[o] = v;
                 if (gt) { const float d = (gt[o] - v) / ls; lsum += 0.5f * d * d; }
                 if (gt && e >= 0) { const float d = (gt[e] - vf[e]) / ls; lsum += 0.5f * d * d; }        // the face without a correction (v_y row Y / v_x column X)
             }
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_sb(ConvArgs a, int nrows) {
                 if (a.epi == SOL_EPI_LRELU) v = v > 0.f ? v : a.slope * v;
                 else if (a.epi == SOL_EPI_DLRELU) v *= (a.act[o] > 0.f ? 1.f : a.slope);
                 vmax = fmaxf(vmax, fabsf(v));
-                st_wt(a.y + o, v);
+                a.y[o] = v;
             }
         }
     }
