@@ -94,6 +94,10 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
     constexpr bool RW = dx_wbufs(R) == 5;
     unsigned* const amax_lds = reinterpret_cast<unsigned*>(smem_dx + DX_NS * DX_SLOT + dx_wbufs(R) * DX_WPH);
     const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    // (Tried, round 5: gridDim.x is one scalar load from the hidden part of the kernarg segment, and the tile coordinates -- every row request --
+    //  wait for it.  The grid size as a twelfth preloaded argument: 13.09 ms per step against 12.96 with the load; packed into the spare
+    //  bits of arg_hshift (no extra preload dword): 12.53 against 12.46.  Same-box A/Bs of four alternations each, both SLOWER without
+    //  the load, like the one-batch argument fetch below.  gridDim.x stays.)
     int bid = blockIdx.x, ngrid = gridDim.x, half = 0;          // SPLIT: workgroups [0, n) own output channels 0..15 of tile bid, [n, 2n) channels 16..31
     if (SPLIT) { ngrid >>= 1; half = bid >= ngrid ? 1 : 0; bid -= half * ngrid; }
     const int seg = wid & 3;                                    // 16-pixel segment (wave uniform)
