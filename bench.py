@@ -26,7 +26,7 @@ import torch
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_MFMA16_TF = 2500.0        # dense 16-bit MFMA peak
 PEAK_MFMA32_TF = 157.3         # fp32 matrix peak
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")   # written by tools/pmc_summary.py --json (with the library's source hash)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")   # written by tools/pmc_summary.py --json (with the library's source hash)
 RANK_SKEW_LIMIT = 0.25         # N > 1: the line is flagged "valid": false when the slowest rank's timed region is this much longer than the fastest one's
 
 
@@ -558,7 +558,7 @@ def main():
             "data": "synthetic",
             "dtype_note": "fp32 tensors and fp32 accumulation everywhere; with precision=split the 32-channel convolutions evaluate each fp32 "
                           "product as three exact fp16 MFMA products of power-of-two scaled 22-bit operand splits (error vs float64 <= the fp32-MFMA "
-                          "kernel's, tests/test_gpu_parity.py::test_split_conv_error_not_worse_than_fp32_mfma); strict_fp32 = same step on v_mfma_f32_*_f32",
+                          "kernel's, tests/test_gpu_parity.py::test_split_conv_relative_l2_not_worse_than_fp32_mfma); strict_fp32 = same step on v_mfma_f32_*_f32",
             "config": {"workload": "karman-2d %dx%d SOL-%d, batch %d Re values per GPU (BASELINE configs[2])" % (Y, X, ms, B),
                        "global_batch": world * B, "msteps": ms, "parallelism": "dp%d" % world, "lr": args.lr},
             "workload_deviations_from_survey_8d": [

@@ -1021,6 +1021,8 @@ def test_sol32_bench_workload_against_golden(golden_dir, precision):
 # ---------------------------------------------------------------------------------------------
 # precision equivalence of the split-operand convolution
 # ---------------------------------------------------------------------------------------------
+# REGRESSION ENVELOPE (test_split_conv_error_per_decile_stays_in_the_measured_envelope; the accuracy claim itself -- relative L2 ratio <= 1.0,
+# no allowance -- is test_split_conv_relative_l2_not_worse_than_fp32_mfma):
 # worst ratio over the ten |reference| deciles of (rms error of the split kernel) / (rms error of the strict fp32-MFMA kernel), and
 # of the max errors, MEASURED on MI355X with tools/split_precision_ranges.py (profiles/r03_split_precision_ranges.json); the
 # test allows these + 10 %.  Columns: rms fp16x3, rms bf16x6, max fp16x3, max bf16x6.  "mixed_r": the left half of every
@@ -1040,13 +1042,9 @@ SPLIT_RATIOS = {     # per case: worst decile of (rms fp16x3, rms bf16x6, max fp
 }
 
 
-def test_split_conv_error_not_worse_than_fp32_mfma():
-    """On the same inputs the fp16x3 split kernel and the bf16x6 one against the strict fp32-MFMA kernel, measured against a
-    float64 convolution per CLASS of output elements (deciles of |reference|), not only in relative L2 -- for a normal and a
-    heavy-tailed input and for within-tensor dynamic ranges from 1e-3 down to 2^-22 (around the fp16 lo plane's underflow
-    point, 2^-19 of the tensor maximum).  Bounds: the measured ratios + 10 % (SPLIT_RATIOS); in relative L2 both split
-    kernels must be at least as accurate as the fp32-MFMA kernel in every case."""
-    from sol_amd import _lib
+def _split_conv_cases():
+    """(name, x) inputs: normal, heavy-tailed, and within-tensor dynamic ranges from 1e-3 down to 2^-22 (the left half of every image row
+    scaled by r; 2^-19 of the tensor maximum is where the fp16 lo plane starts to underflow)"""
     gen = torch.Generator().manual_seed(5)
     B, Y, X = 2, 64, 64
     cases = {"normal": torch.randn(B, Y, X, 32, generator=gen, dtype=torch.float32),
@@ -1057,40 +1055,69 @@ def test_split_conv_error_not_worse_than_fp32_mfma():
         m[:, :, :32] *= ratio
         cases[name] = m
     w = (torch.randn(5, 5, 32, 32, generator=gen, dtype=torch.float32) * 0.05).to(DEV)
+    return cases, w
+
+
+def _split_conv_outputs(x, w):
+    """(float64 reference, fp16x3 split kernel, bf16x6 split kernel, strict fp32-MFMA kernel) on the same input"""
+    from sol_amd import _lib
     bias = torch.zeros(32, dtype=torch.float32, device=DEV)
     packed = ops._pack(w, 32, 32, ops.CONV_FWD)
     saved = _lib.get_option("conv_precision")
     try:
-        for name, x in cases.items():
-            x = x.float().to(DEV)
-            ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), None, padding=2).permute(0, 2, 3, 1)
-            _lib.set_option("conv_precision", 0)
-            y_h = ops.conv5x5_scaled_raw(x, packed, bias, None, None, 32, ops.EPI_NONE, 0.3, ops.absmax_slots(x))   # fp16 x3
-            y_b = ops.conv5x5_raw(x, packed, bias, None, None, 32, ops.EPI_NONE, 0.3)                               # bf16 x6
-            _lib.set_option("conv_precision", 2)
-            y_f = ops.conv5x5_raw(x, packed, bias, None, None, 32, ops.EPI_NONE, 0.3)                               # fp32 MFMA
-            assert not torch.equal(y_f, y_h) and not torch.equal(y_f, y_b)          # three different kernels did run
-            order = ref.abs().reshape(-1).argsort()
-            n = order.numel()
-            worst = {"rms_fp16x3": 0.0, "rms_bf16x6": 0.0, "max_fp16x3": 0.0, "max_bf16x6": 0.0}
-            for q in range(10):
-                idx = order[q * n // 10:(q + 1) * n // 10]
-                r = ref.reshape(-1)[idx]
-                e = {k: (v.double().reshape(-1)[idx] - r) for k, v in (("fp16x3", y_h), ("bf16x6", y_b), ("fp32", y_f))}
-                rms = {k: float(v.pow(2).mean().sqrt()) for k, v in e.items()}
-                mx = {k: float(v.abs().max()) for k, v in e.items()}
-                for k in ("fp16x3", "bf16x6"):
-                    worst["rms_" + k] = max(worst["rms_" + k], rms[k] / rms["fp32"])
-                    worst["max_" + k] = max(worst["max_" + k], mx[k] / mx["fp32"])
-            bound = SPLIT_RATIOS[name]
-            got = (worst["rms_fp16x3"], worst["rms_bf16x6"], worst["max_fp16x3"], worst["max_bf16x6"])
-            assert all(g <= 1.10 * b + 0.005 for g, b in zip(got, bound)), (name, got, bound)
-            # the small half alone (pixels 2..29 of a row see only scaled inputs): still fp32 quality in relative L2
-            small = (slice(None), slice(None), slice(2, 30))
-            assert rel(y_h[small], ref[small]) <= rel(y_f[small], ref[small]) and rel(y_b[small], ref[small]) <= rel(y_f[small], ref[small])
-            assert rel(y_h, ref) <= rel(y_f, ref) and rel(y_b, ref) <= rel(y_f, ref)
+        ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), None, padding=2).permute(0, 2, 3, 1)
+        _lib.set_option("conv_precision", 0)
+        y_h = ops.conv5x5_scaled_raw(x, packed, bias, None, None, 32, ops.EPI_NONE, 0.3, ops.absmax_slots(x))   # fp16 x3
+        y_b = ops.conv5x5_raw(x, packed, bias, None, None, 32, ops.EPI_NONE, 0.3)                               # bf16 x6
+        _lib.set_option("conv_precision", 2)
+        y_f = ops.conv5x5_raw(x, packed, bias, None, None, 32, ops.EPI_NONE, 0.3)                               # fp32 MFMA
     finally:
         _lib.set_option("conv_precision", saved)
+    assert not torch.equal(y_f, y_h) and not torch.equal(y_f, y_b)          # three different kernels did run
+    return ref, y_h, y_b, y_f
+
+
+def test_split_conv_relative_l2_not_worse_than_fp32_mfma():
+    """THE claim behind the bench line's dtype: in relative L2 against a float64 convolution -- the parity criterion of the north star --
+    the fp16x3 split kernel (22-bit operand splits) and the bf16x6 one (24-bit) are AT LEAST as accurate as the strict fp32-MFMA kernel, ratio
+    <= 1.0 with no allowance, in every case: normal and heavy-tailed inputs, within-tensor dynamic ranges down to 2^-22 of the tensor
+    maximum, on the whole tensor AND on the small half alone (pixels that only see the scaled-down inputs)."""
+    cases, w = _split_conv_cases()
+    for name, x in cases.items():
+        ref, y_h, y_b, y_f = _split_conv_outputs(x.float().to(DEV), w)
+        small = (slice(None), slice(None), slice(2, 30))
+        for what, sl in (("whole tensor", (slice(None),)), ("small half", small)):
+            rf = rel(y_f[sl], ref[sl])
+            assert rel(y_h[sl], ref[sl]) <= rf, (name, what, "fp16x3", rel(y_h[sl], ref[sl]) / rf)
+            assert rel(y_b[sl], ref[sl]) <= rf, (name, what, "bf16x6", rel(y_b[sl], ref[sl]) / rf)
+
+
+def test_split_conv_error_per_decile_stays_in_the_measured_envelope():
+    """A finer-grained REGRESSION envelope, not an accuracy claim: rms and max error per decile of |reference| of both split kernels divided
+    by the strict fp32-MFMA kernel's, bounded by what was measured on MI355X (SPLIT_RATIOS, + 10 %).  In one case (mixed_1e-5) one decile of
+    the split kernels carries 1.4x / 1.6x the fp32-MFMA kernel's error -- the bf16x6 kernel, whose operands are EXACT 24-bit splits, more
+    than the 22-bit fp16x3 one: that is fp32 accumulation order, not operand width (relative L2 of the same case: 0.4x / 0.8x, asserted
+    with no allowance by test_split_conv_relative_l2_not_worse_than_fp32_mfma)."""
+    cases, w = _split_conv_cases()
+    for name, x in cases.items():
+        ref, y_h, y_b, y_f = _split_conv_outputs(x.float().to(DEV), w)
+        order = ref.abs().reshape(-1).argsort()
+        n = order.numel()
+        worst = {"rms_fp16x3": 0.0, "rms_bf16x6": 0.0, "max_fp16x3": 0.0, "max_bf16x6": 0.0}
+        for q in range(10):
+            idx = order[q * n // 10:(q + 1) * n // 10]
+            r = ref.reshape(-1)[idx]
+            e = {k: (v.double().reshape(-1)[idx] - r) for k, v in (("fp16x3", y_h), ("bf16x6", y_b), ("fp32", y_f))}
+            rms = {k: float(v.pow(2).mean().sqrt()) for k, v in e.items()}
+            mx = {k: float(v.abs().max()) for k, v in e.items()}
+            for k in ("fp16x3", "bf16x6"):
+                worst["rms_" + k] = max(worst["rms_" + k], rms[k] / rms["fp32"])
+                worst["max_" + k] = max(worst["max_" + k], mx[k] / mx["fp32"])
+        bound = SPLIT_RATIOS[name]
+        got = (worst["rms_fp16x3"], worst["rms_bf16x6"], worst["max_fp16x3"], worst["max_bf16x6"])
+        assert all(g <= 1.10 * b + 0.005 for g, b in zip(got, bound)), (name, got, bound)
+        # the 22-bit kernel is never the worse of the two split kernels by more than the envelope's own spread: operand width is not what shows here
+        assert worst["rms_fp16x3"] <= max(1.0, 1.10 * worst["rms_bf16x6"] + 0.005), (name, got)
 
 
 def test_options_and_launch_profiler():

@@ -3,7 +3,7 @@
 the strict fp32-MFMA kernel, against a float64 convolution, for inputs with a prescribed WITHIN-TENSOR dynamic range:
 the left half of every image row is scaled by `ratio` (1e-3, 1e-5, 2^-18 .. 2^-22: around the documented cliff of the fp16
 lo plane, 2^-19 of the tensor maximum).  Per decile of |reference|: rms and max error ratios.
-Output: JSON (the bounds of tests/test_gpu_parity.py::test_split_conv_error_not_worse_than_fp32_mfma come from here)."""
+Output: JSON (the bounds of tests/test_gpu_parity.py::test_split_conv_error_per_decile_stays_in_the_measured_envelope come from here)."""
 import json
 import os
 import sys
