@@ -100,10 +100,12 @@ def cpu_baseline(args, Y, X, B):
         loss.backward()
 
     # n = os.cpu_count() of the host.  The 128x64 convolutions of this restatement do not scale past ~16 threads
-    # (more threads are SLOWER on most hosts), so both are tried on two steps each and the faster count is used for the sample: the
+    # (more threads are SLOWER on most hosts), so min(n, 16) and min(n, 32) are tried on two steps each and the faster count is used: the
     # baseline is the best the host does, and the line says which counts were tried and what the host has.
+    # (the trial is bounded: more than 32 threads are never tried -- on a 256-thread host ONE SOL-2 step of these small convolutions takes
+    #  166 s with 256 torch threads against 0.16 s with 16, measured on the round-5 GPU box; that trial alone ran for seven minutes)
     tried = {}
-    for n in sorted({min(host, 16), host}):
+    for n in sorted({min(host, 16), min(host, 32)}):
         torch.set_num_threads(n)
         one_step(1)                   # warm-up: LU factorisation, oneDNN primitive caches
         t0 = time.time()
