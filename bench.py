@@ -298,7 +298,7 @@ def karman3d_leg(sol_amd, dev, B=1, steps=8):
         train = {"msteps": ms3, "ms_per_step": t_tr * 1e3, "sim_steps_per_s": B * ms3 / t_tr, "loss": l1, "loss_first": l0, "finite": bool(math.isfinite(l1)),
                  "peak_memory_GB": torch.cuda.max_memory_allocated() / 2 ** 30,
                  "conv_fp32_equiv_TFLOPs_of_step": 3.0 * flop * ms3 / t_tr / 1e12,
-                 "note": "autograd composition of the HIP ops, captured once into a hipGraph and replayed: forward + reverse sweep + TF-Adam"}
+                 "note": "hand-written schedule over the C ABI (forward unroll + reverse sweep, no autograd graph), captured once into a kernel-nodes-only hipGraph and replayed + TF-Adam"}
     except Exception as e:
         train = {"error": str(e)}
     return {"train_sol16": train,"workload": "karman-3d %dx%dx%d, batch %d, forward roll-out (solver step + Conv3D(5) mars_moon correction; BASELINE configs[4] grid)" % (Y, X, Z, B),

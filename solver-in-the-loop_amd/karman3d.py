@@ -8,8 +8,9 @@ components + Re) and 3 output channels, and the roll-out loop of karman_apply.py
 Layout: density [B,Y,X,Z], v_y [B,Y+1,X,Z], v_x [B,Y,X+1,Z], v_z [B,Y,X,Z+1] (y = flow direction, z contiguous); CNN
 tensors [B,Y,X,Z,C].  Everything calls libsol_hip.so (csrc/karman3d.hip); there is no CPU implementation.
 
-Training (SOL-n, the reverse sweep of karman_train.py:397-457 in 3-D): `Karman3DFlow.step` and `conv3d` are torch.autograd
-Functions over the HIP adjoints (sol_karman3d_step_bwd; Conv3D backward-data = sol_conv3d on flipped weights, weight gradient
+Training (SOL-n, the reverse sweep of karman_train.py:397-457 in 3-D): `Karman3DTrainer` runs a hand-written schedule over the C ABI
+(forward unroll + reverse sweep, no autograd graph; `schedule="autograd"` keeps the torch composition as the cross-check).  For other hosts
+`Karman3DFlow.step` and `conv3d` are also torch.autograd Functions over the HIP adjoints (sol_karman3d_step_bwd; Conv3D backward-data = sol_conv3d on flipped weights, weight gradient
 = five passes of the 2-D weight-gradient kernels), composed by `Karman3DTrainer` exactly as the reference composes its graph.
 """
 import ctypes as C
@@ -423,9 +424,9 @@ class _MarsMoon3DFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, g_out):
-        net = ctx.net
-        xk, amax, *acts = ctx.saved_tensors
+    def run_backward(net, xk, amax, acts, g_out):
+        """(dx [B,Y,X,Z,4 (padded input channels)], flat gradient in get_weights() order) of the network for the output gradient g_out:
+        the reverse sweep written out by hand (used by the autograd node below and by Karman3DTrainer's hand-written schedule)."""
         pk = net.train_packs()
         sl, cin, cout = net.slope, net.cin, net.cout
         grads = [None] * 24
@@ -443,7 +444,14 @@ class _MarsMoon3DFn(torch.autograd.Function):
             dz = conv3d(dz1, pk[1 + 2 * k][1], None, dz, 32, False, sl, zm[2 * k + 1], zm[2 * k], act_ref=hprev)
         grads[0], grads[1] = conv3d_bwd_weight(xk, dz, cin, 32)
         dx = conv3d(dz, pk[0][1], None, None, xk.shape[-1], False, sl, zm[0], None)
-        return dx[..., :cin], torch.cat([t.reshape(-1) for t in grads]), None
+        return dx, torch.cat([t.reshape(-1) for t in grads])
+
+    @staticmethod
+    def backward(ctx, g_out):
+        net = ctx.net
+        xk, amax, *acts = ctx.saved_tensors
+        dx, flat = _MarsMoon3DFn.run_backward(net, xk, amax, acts, g_out)
+        return dx[..., :net.cin], flat, None
 
 
 def conv3d_fn(x, w, b, residual=None, lrelu=False, slope=0.3, packs=None):
@@ -463,8 +471,10 @@ class Karman3DTrainer:
     (sol_adam_tf_step).  gts: [msteps] of (vy, vx, vz) ground-truth frames."""
 
     def __init__(self, net, scene, B, msteps, std_v, std_re, dt=1.0, res=None, beta1=0.9, beta2=0.999, eps=1e-8, conv_precision="split",
-                 use_graph=False, group=None, comm=None, **solver):
-        """use_graph: capture the whole forward unroll + reverse sweep ONCE into a hipGraph over static input buffers (the
+                 use_graph=False, group=None, comm=None, schedule="manual", **solver):
+        """schedule: "manual" (default) = the hand-written forward unroll + reverse sweep over the C ABI (_unrolled_schedule), "autograd" = the
+        torch-autograd composition of the differentiable HIP ops (rounds 3-4; kept as the cross-check).
+        use_graph: capture the whole forward unroll + reverse sweep ONCE into a hipGraph over static input buffers (the
         TF1 "build the graph, sess.run many" shape, as trainer.GraphTrainer does for the 2-D mercury model): a step then
         copies the batch in and replays ~3000 launches with one host call."""
         from .trainer import _conv_precision_code
@@ -476,6 +486,7 @@ class Karman3DTrainer:
         dev = scene.active.device
         self.std_v = torch.tensor([float(v) for v in std_v], dtype=torch.float32, device=dev)
         self._std_v_host = tuple(float(v) for v in std_v)
+        self._std_in_host = tuple(float(v) for v in std_v) + (float(std_re),)
         self.std_in = torch.tensor([float(v) for v in std_v] + [float(std_re)], dtype=torch.float32, device=dev)
         self.conv_precision = _conv_precision_code(conv_precision)
         net.params.requires_grad_(True)
@@ -498,8 +509,76 @@ class Karman3DTrainer:
         self._fin = [f(B, Y, X, Z), f(B, Y + 1, X, Z), f(B, Y, X + 1, Z), f(B, Y, X, Z + 1)]
         self.final = None
         self.use_graph, self._graph = bool(use_graph), None
+        if schedule not in ("manual", "autograd"):
+            raise ValueError("schedule must be 'manual' or 'autograd'")
+        self.schedule = schedule
 
     def _unrolled(self):
+        if self.schedule == "manual":
+            with torch.no_grad():                   # nothing here is differentiated by torch: the reverse sweep is written out
+                return self._unrolled_schedule()
+        return self._unrolled_autograd()
+
+    def _unrolled_schedule(self):
+        """The SOL-n step as a HAND-WRITTEN schedule over the C ABI (karman_train.py:397-457 differentiated by hand, as train.hip does for
+        the 2-D scene): forward unroll with everything the reverse sweep needs kept per step, then the reverse sweep -- no autograd
+        graph, no torch op between the launches except a handful of elementwise kernels (slicing adds, one stack per step).
+        Per unrolled step i, forward:   solver step (saves the post-diffusion velocity, writes the SCALED features itself) -> network
+        (twelve launches, absmax handed from layer to layer) -> velocity += std * to_staggered(out) (sol_karman3d_correct) -> loss_i and
+        d loss_i / d v_i in one pass (sol_l2_loss_fwd_bwd, gradient pre-scaled by 1 / msteps).
+        Reverse, i = n-1 .. 0:   G = d loss_i / d v_i + (adjoint of step i+1 w.r.t. its input)  ->  d out = std * G at the corrected faces
+        -> network reverse sweep (weight gradients accumulated over the steps, d features) -> G += d features / std_in at the low faces
+        (to_feature's adjoint) -> solver adjoint (sol_karman3d_step_bwd)."""
+        from .ops import l2_loss_fwd_bwd
+        d, vy, vx, vz, re = self._in
+        net, sim, ms = self.net, self.sim, self.ms
+        sc = self.scene
+        B, Y, X, Z = self.B, sc.Y, sc.X, sc.Z
+        net._tpacks = None                          # the weights moved since the last step: re-pack once (inside the graph when captured)
+        fs = [1.0 / t for t in self._std_in_host]          # (host copies: a .tolist() of a device tensor is a synchronising copy -- illegal inside a capture)
+        sv = self._std_v_host
+        v = (vy, vx, vz)
+        keep = []                                   # per step: (saved velocities, network state, d loss_i / d v_i)
+        losses = []
+        for i in range(ms):
+            saved = [torch.empty_like(t) for t in v]
+            feat = torch.empty(B, Y, X, Z, 4, dtype=torch.float32, device=vy.device)
+            d, *v = sim._fwd(d, v[0], v[1], v[2], re, saved, feat, fs)
+            out, xk, amax, acts = _MarsMoon3DFn.run_forward(net, feat)
+            check(self.lib.sol_karman3d_correct(stream(), ptr(out), net.cout, sv[0], sv[1], sv[2], ptr(v[0]), ptr(v[1]), ptr(v[2]), B, Y, X, Z))
+            li, gi = l2_loss_fwd_bwd(v, tuple(g[i] for g in self._gt), sv, gscale=1.0 / ms)
+            losses.append(li.reshape(()))
+            keep.append((saved, xk, amax, acts, gi))
+        flat = None
+        gin = None
+        inv_in = fs[:3]
+        for i in range(ms - 1, -1, -1):
+            saved, xk, amax, acts, G = keep[i]
+            if gin is not None:
+                for c in range(3):
+                    G[c].add_(gin[c])
+            # adjoint of  v += std * to_staggered(out):  d out[..., c] = std_c * G_c restricted to the faces that received a correction
+            dO = torch.stack([G[0][:, :Y] * sv[0], G[1][:, :, :X] * sv[1], G[2][..., :Z] * sv[2]], dim=-1)
+            dx, gflat = _MarsMoon3DFn.run_backward(net, xk, amax, acts, dO)
+            flat = gflat if flat is None else flat.add_(gflat)
+            # adjoint of the feature map (the three components at the low faces of every cell, divided by std_in; the Re channel has no gradient)
+            G[0][:, :Y].add_(dx[..., 0], alpha=inv_in[0])
+            G[1][:, :, :X].add_(dx[..., 1], alpha=inv_in[1])
+            G[2][..., :Z].add_(dx[..., 2], alpha=inv_in[2])
+            gin = sim._bwd(saved, re, G[0], G[1], G[2])
+            keep[i] = None                          # (eager runs: the step's activations can go)
+        losses = _lib.stack0(losses)
+        loss = losses.sum() / ms
+        # (kernel copies: a contiguous tensor.copy_ is a hipMemcpyAsync = a memcpy node, refused by the capture guard -- _lib.dcopy_)
+        _lib.dcopy_(self.loss_steps, losses)
+        _lib.dcopy_(self._loss, loss)
+        _lib.dcopy_(self._grads, flat)
+        for dst, src in zip(self._fin, (d,) + tuple(v)):
+            _lib.dcopy_(dst, src)
+
+    def _unrolled_autograd(self):
+        """The same step as a torch-autograd composition of the differentiable HIP ops (schedule="autograd"): the cross-check of the
+        hand-written schedule (test_karman3d_manual_schedule_equals_autograd_composition) and the form of rounds 3-4."""
         d, vy, vx, vz, re = self._in
         self.net.params.grad = None
         self.net._tpacks = None                     # the weights moved since the last step: re-pack once (inside the graph when captured)

@@ -696,3 +696,42 @@ def test_karman3d_script(tmp_path):
     out2 = mod.main(["-r", "8", "-t", "4", "--re", "1.6e5", "-o", str(tmp_path / "run2"), "--model", out + "/model3d.pt"])
     v2 = scene.read_zipped_array(out2 + "/velo_000003.npz")
     assert np.isfinite(v2).all() and np.abs(v2 - scene.read_zipped_array(out + "/velo_000003.npz")).max() > 0       # the corrector acts
+
+
+@pytest.mark.parametrize("shape,use_graph", [((2, 32, 16, 16), False), ((1, 128, 64, 64), True)])
+def test_karman3d_manual_schedule_equals_autograd_composition(shape, use_graph):
+    """Karman3DTrainer's hand-written schedule (forward unroll + reverse sweep over the C ABI, no autograd graph: the default) against the
+    torch-autograd composition of the same differentiable ops (schedule="autograd", the form of rounds 3-4): per-step losses, the 1.3 M
+    parameter gradient and the final state.  Same kernels on the same operands except for the order of a few elementwise additions:
+    agreement to fp32 round-off.  At the BASELINE configs[4] grid through the replayed graph (captured through the kernel-nodes-only guard)."""
+    B, Y, X, Z = shape
+    ms = 3
+    sc = k3.Scene3D(Y, X, Z, device=DEV)
+    gen = torch.Generator().manual_seed(11)
+    r = lambda *s: torch.randn(*s, generator=gen)
+    st = (torch.rand(B, Y, X, Z, generator=gen), 1.0 + 0.2 * r(B, Y + 1, X, Z), 0.2 * r(B, Y, X + 1, Z), 0.2 * r(B, Y, X, Z + 1))
+    re = torch.tensor(o.RE_TRAIN[:B])
+    gts = [(1.0 + 0.2 * r(B, Y + 1, X, Z), 0.2 * r(B, Y, X + 1, Z), 0.2 * r(B, Y, X, Z + 1)) for _ in range(ms)]
+    res = {}
+    for schedule in ("manual", "autograd"):
+        net = k3.MarsMoon3D(device=DEV)
+        w = net.get_weights()
+        w[22] = w[22] * 0.05
+        net.set_weights(w)
+        tr = k3.Karman3DTrainer(net, sc, B, ms, (0.2, 0.25, 0.3), o.STD_RE, use_graph=use_graph, schedule=schedule)
+        assert tr.schedule == schedule
+        for _ in range(2 if use_graph else 1):                  # (graph: the second call is a pure replay)
+            tr._grads.zero_()
+            loss = tr.fwd_bwd(*st, re, gts)
+        torch.cuda.synchronize()
+        res[schedule] = (float(loss), tr.loss_steps.clone(), tr.grads.clone(), [t.clone() for t in tr.final])
+        del tr, net
+    lm, la = res["manual"], res["autograd"]
+    assert np.isfinite(lm[0]) and abs(lm[0] - la[0]) < 2e-6 * abs(la[0]), (lm[0], la[0])
+    assert rel(lm[1], la[1]) < 2e-6
+    assert rel(lm[2], la[2]) < 2e-5, rel(lm[2], la[2])
+    for a, b in zip(lm[3], la[3]):
+        assert rel(a, b) < 2e-6
+    assert float(lm[2].abs().max()) > 0
+    with pytest.raises(ValueError):
+        k3.Karman3DTrainer(k3.MarsMoon3D(device=DEV), sc, B, ms, (0.2, 0.25, 0.3), o.STD_RE, schedule="tf1")
