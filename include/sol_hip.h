@@ -445,6 +445,13 @@ size_t sol_conv3d_bwd_weight_ws_floats(int32_t B, int32_t D, int32_t H, int32_t 
 int sol_conv3d_bwd_weight(void* stream, const float* x, const float* dz, const uint32_t* x_absmax, const uint32_t* dz_absmax,
                           float* partial, float* dw_dhwio, float* db, float* db_scratch,
                           int32_t B, int32_t D, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t cin_real, int32_t cout_real);
+/* The same for a trainer that unrolls n steps (karman_train.py:397-457: one gradient per layer over ALL unrolled steps): called n times
+ * per layer on ONE partial buffer -- accumulate_partial = 0 on the first call, 1 afterwards -- with do_reduce = 1 on the last call only;
+ * dw / db are written when do_reduce is set and then hold the sum over the n calls. */
+int sol_conv3d_bwd_weight_acc(void* stream, const float* x, const float* dz, const uint32_t* x_absmax, const uint32_t* dz_absmax,
+                              float* partial, float* dw_dhwio, float* db, float* db_scratch,
+                              int32_t B, int32_t D, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t cin_real, int32_t cout_real,
+                              int32_t accumulate_partial, int32_t do_reduce);
 
 /* offsets (in floats) of layer l's kernel / bias inside the flat mars_moon parameter
  * vector; l in [0,12).  cin/cout may be NULL.                                            */

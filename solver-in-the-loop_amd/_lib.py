@@ -108,6 +108,7 @@ _SIGS = {
     "sol_conv3d": (C.c_int, [_P] * 7 + [C.c_int32] * 7 + [C.c_float] + [_P] * 2),
     "sol_conv3d_bwd_weight_ws_floats": (C.c_size_t, [C.c_int32] * 6),
     "sol_conv3d_bwd_weight": (C.c_int, [_P] * 9 + [C.c_int32] * 8),
+    "sol_conv3d_bwd_weight_acc": (C.c_int, [_P] * 9 + [C.c_int32] * 10),
     "sol_mars_moon_layer": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 

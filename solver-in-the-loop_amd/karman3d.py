@@ -329,27 +329,42 @@ def _pad_ch(x, c):
     return x.contiguous() if x.shape[-1] == c else torch.nn.functional.pad(x, (0, c - x.shape[-1])).contiguous()
 
 
-def conv3d_bwd_weight(xk, dz, cin, cout, xmax=None, zmax=None):
+def conv3d_bwd_weight(xk, dz, cin, cout, xmax=None, zmax=None, acc=None):
     """dW [5,5,5,cin,cout], db [cout] of y = conv3d(x, W) + b from xk [B,D,H,W,cin_k] (channels padded to 4 / 32) and dz
     [B,D,H,W,cout]: sol_conv3d_bwd_weight (five passes of the batched 2-D weight-gradient kernels over the shifted plane
-    ranges; fp16 three-product operands for the 32 -> 32 case, scaled by the absmax of x and dz)."""
+    ranges; fp16 three-product operands for the 32 -> 32 case, scaled by the absmax of x and dz).
+    acc = (state dict, first, last): the unrolled trainer's form (sol_conv3d_bwd_weight_acc) -- the partial sums of this layer live in
+    `state` across the calls of a reverse sweep, the first call overwrites them, the last one reduces; returns (None, None) before the
+    last call and the sum over all calls with it."""
     lib = _lib.load()
     B, D, H, W, cin_k = xk.shape
     co_k = cout if cout in (2, 32) else 32                 # the 2-D weight-gradient kernels take 2 or 32 output channels
     dzk = _pad_ch(dz, co_k)
     dev = xk.device
-    part = torch.empty(lib.sol_conv3d_bwd_weight_ws_floats(B, D, H, W, cin_k, co_k), dtype=torch.float32, device=dev)
-    dW = torch.empty(5, 5, 5, cin, co_k, dtype=torch.float32, device=dev)
-    db = torch.empty(co_k, dtype=torch.float32, device=dev)
-    scratch = torch.empty(5 * co_k, dtype=torch.float32, device=dev)
+    if acc is not None and "part" in acc[0]:
+        part, dW, db, scratch = (acc[0][k] for k in ("part", "dW", "db", "scratch"))
+    else:
+        part = torch.empty(lib.sol_conv3d_bwd_weight_ws_floats(B, D, H, W, cin_k, co_k), dtype=torch.float32, device=dev)
+        dW = torch.empty(5, 5, 5, cin, co_k, dtype=torch.float32, device=dev)
+        db = torch.empty(co_k, dtype=torch.float32, device=dev)
+        scratch = torch.empty(5 * co_k, dtype=torch.float32, device=dev)
+        if acc is not None:
+            acc[0].update(part=part, dW=dW, db=db, scratch=scratch)
     both32 = cin_k == 32 and co_k == 32
     # (the slot tensors must outlive the call: a temporary inside ptr(...) is freed -- and its block handed to the next
     # allocation -- before the launch is even enqueued)
     # (xmax / zmax given: the slots the producing conv launches published -- no pass over the tensors)
     xmax = (xmax if xmax is not None else _absmax(xk)) if both32 else None
     zmax = (zmax if zmax is not None and dzk is dz else _absmax(dzk)) if both32 else None
-    check(lib.sol_conv3d_bwd_weight(stream(), ptr(xk), ptr(dzk), ptr(xmax), ptr(zmax),
-                                    ptr(part), ptr(dW), ptr(db), ptr(scratch), B, D, H, W, cin_k, co_k, cin, co_k))
+    if acc is not None:
+        _, first, last = acc
+        check(lib.sol_conv3d_bwd_weight_acc(stream(), ptr(xk), ptr(dzk), ptr(xmax), ptr(zmax), ptr(part), ptr(dW), ptr(db), ptr(scratch),
+                                            B, D, H, W, cin_k, co_k, cin, co_k, 0 if first else 1, 1 if last else 0))
+        if not last:
+            return None, None
+    else:
+        check(lib.sol_conv3d_bwd_weight(stream(), ptr(xk), ptr(dzk), ptr(xmax), ptr(zmax),
+                                        ptr(part), ptr(dW), ptr(db), ptr(scratch), B, D, H, W, cin_k, co_k, cin, co_k))
     return (dW if co_k == cout else dW[..., :cout].contiguous()), (db if co_k == cout else _lib.dclone(db[:cout]))
 
 
@@ -424,27 +439,30 @@ class _MarsMoon3DFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    def run_backward(net, xk, amax, acts, g_out):
+    def run_backward(net, xk, amax, acts, g_out, acc=None):
         """(dx [B,Y,X,Z,4 (padded input channels)], flat gradient in get_weights() order) of the network for the output gradient g_out:
-        the reverse sweep written out by hand (used by the autograd node below and by Karman3DTrainer's hand-written schedule)."""
+        the reverse sweep written out by hand (used by the autograd node below and by Karman3DTrainer's hand-written schedule).
+        acc = (list of 12 per-layer state dicts, first, last): the weight gradients are ACCUMULATED over the calls of an unrolled reverse
+        sweep inside the kernels' partial buffers and reduced once, with the last call (conv3d_bwd_weight); the flat gradient is None before."""
+        A = (lambda l: None) if acc is None else (lambda l: (acc[0][l], acc[1], acc[2]))
         pk = net.train_packs()
         sl, cin, cout = net.slope, net.cin, net.cout
         grads = [None] * 24
         zm = torch.zeros(11, 256, dtype=torch.int32, device=xk.device)         # absmax slots of the eleven pre-activation gradients
         g = _lib.f32(g_out).contiguous()
-        grads[22], grads[23] = conv3d_bwd_weight(acts[10], g, 32, cout, xmax=amax[10])
+        grads[22], grads[23] = conv3d_bwd_weight(acts[10], g, 32, cout, xmax=amax[10], acc=A(11))
         # d loss / d (pre-activation of the last residual block's output) = conv3d(g, flip(w11)^T) * lrelu'(h5)
         dz = conv3d(_pad_ch(g, 4), pk[11][1], None, None, 32, False, sl, None, zm[10], act_ref=acts[10])
         for k in range(4, -1, -1):
             a, hprev = acts[1 + 2 * k], acts[2 * k]
             # block k: h_k = lrelu(conv_b(a) + h_{k-1}), a = lrelu(conv_a(h_{k-1}))
-            grads[4 + 4 * k], grads[5 + 4 * k] = conv3d_bwd_weight(a, dz, 32, 32, xmax=amax[2 * k + 1], zmax=zm[2 * k + 2])
+            grads[4 + 4 * k], grads[5 + 4 * k] = conv3d_bwd_weight(a, dz, 32, 32, xmax=amax[2 * k + 1], zmax=zm[2 * k + 2], acc=A(2 + 2 * k))
             dz1 = conv3d(dz, pk[2 + 2 * k][1], None, None, 32, False, sl, zm[2 * k + 2], zm[2 * k + 1], act_ref=a)
-            grads[2 + 4 * k], grads[3 + 4 * k] = conv3d_bwd_weight(hprev, dz1, 32, 32, xmax=amax[2 * k], zmax=zm[2 * k + 1])
+            grads[2 + 4 * k], grads[3 + 4 * k] = conv3d_bwd_weight(hprev, dz1, 32, 32, xmax=amax[2 * k], zmax=zm[2 * k + 1], acc=A(1 + 2 * k))
             dz = conv3d(dz1, pk[1 + 2 * k][1], None, dz, 32, False, sl, zm[2 * k + 1], zm[2 * k], act_ref=hprev)
-        grads[0], grads[1] = conv3d_bwd_weight(xk, dz, cin, 32)
+        grads[0], grads[1] = conv3d_bwd_weight(xk, dz, cin, 32, acc=A(0))
         dx = conv3d(dz, pk[0][1], None, None, xk.shape[-1], False, sl, zm[0], None)
-        return dx, torch.cat([t.reshape(-1) for t in grads])
+        return dx, (None if grads[0] is None else torch.cat([t.reshape(-1) for t in grads]))
 
     @staticmethod
     def backward(ctx, g_out):
@@ -551,6 +569,7 @@ class Karman3DTrainer:
             keep.append((saved, xk, amax, acts, gi))
         flat = None
         gin = None
+        wstate = [dict() for _ in range(12)]         # per layer: the weight-gradient partials of the whole reverse sweep (reduced once, at i = 0)
         inv_in = fs[:3]
         for i in range(ms - 1, -1, -1):
             saved, xk, amax, acts, G = keep[i]
@@ -559,8 +578,8 @@ class Karman3DTrainer:
                     G[c].add_(gin[c])
             # adjoint of  v += std * to_staggered(out):  d out[..., c] = std_c * G_c restricted to the faces that received a correction
             dO = torch.stack([G[0][:, :Y] * sv[0], G[1][:, :, :X] * sv[1], G[2][..., :Z] * sv[2]], dim=-1)
-            dx, gflat = _MarsMoon3DFn.run_backward(net, xk, amax, acts, dO)
-            flat = gflat if flat is None else flat.add_(gflat)
+            dx, gflat = _MarsMoon3DFn.run_backward(net, xk, amax, acts, dO, acc=(wstate, i == ms - 1, i == 0))
+            flat = gflat if gflat is not None else flat
             # adjoint of the feature map (the three components at the low faces of every cell, divided by std_in; the Re channel has no gradient)
             G[0][:, :Y].add_(dx[..., 0], alpha=inv_in[0])
             G[1][:, :, :X].add_(dx[..., 1], alpha=inv_in[1])
