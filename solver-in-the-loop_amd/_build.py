@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 DEFAULT_LIB = os.path.join(LIBDIR, "libsol_hip.so")
 LIB = os.environ.get("SOL_HIP_LIB") or DEFAULT_LIB      # SOL_HIP_LIB: an explicitly named PREBUILT variant (tools/ab_lib.py); never built, never stamped
-SOURCES = ["karman_step.hip", "karman_large.hip", "karman3d.hip", "conv3d_sb.hip", "burgers_step.hip", "conv5x5.hip", "conv5x5_sb.hip", "conv5x5_dx.hip", "train.hip", "comm.hip", "cnn_chain.hip"]
+SOURCES = ["karman_step.hip", "karman_large.hip", "karman3d.hip", "conv3d_sb.hip", "burgers_step.hip", "conv5x5.hip", "conv5x5_sb.hip", "conv5x5_dx.hip", "conv5x5_thin.hip", "train.hip", "comm.hip", "cnn_chain.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 # the CG loop packs its vector updates by hand (float2); the SLP vectoriser only adds v_mov traffic there
 # conv3d_sb.hip: packed-f32 VALU (v_pk_mul/fma_f32, what SLP makes of the fp16 split of the row staging) costs ~22 cycles each

@@ -147,6 +147,9 @@ int sol_conv_sb_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int 
 int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles);
 // dx-major form of the 32 -> 32 fp16 three-product kernel (conv5x5_dx.hip; option conv_dx)
 bool sol_conv_dx_usable(const ConvArgs& a, int NT, int ntiles);
+// exact-fp32 VALU form of the thin 32 -> (<= 4) layers (conv5x5_thin.hip; option conv_thin_valu)
+bool sol_conv_thin32_usable(const ConvArgs& a, int NT);
+int sol_conv_thin32_launch(hipStream_t s, const ConvArgs& a, int ntiles);
 int sol_conv_dx_launch(hipStream_t s, const ConvArgs& a, int ntiles);
 
 // fused 5x5x5 convolution, 32 -> 32 or 32 -> (<= 16) channels, W == 64 (conv3d_sb.hip)
@@ -185,6 +188,8 @@ struct SolOptions {
                           //    bit 1: also the thin 32 -> (<= 16) layers where a workgroup owns one row (small launches); bit 2: those layers in every
                           //    launch (measured slower where the launch fills the chip); bit 3: the 32 -> 32 layers of one-row-per-workgroup launches as two
                           //    half-channel workgroups per tile (k_conv5x5_dx<1, 1, true>).  Default 11.
+    int conv_thin_valu;   // 1 (default): the thin 32 -> (<= 4) layers of 64-pixel images (the trainer's output layer with the correction epilogue, the first
+                          //    layer's data gradient) in exact fp32 on the vector ALU (conv5x5_thin.hip: no absmax wait, no operand split); 0: k_conv5x5_sb<1, KIND>
     int k3d_tile;         // 1: karman-3d advection from LDS tiles holding the full z column + halo; 0 (default, measured faster at B <= 2): wave-per-column gathers from global memory
 };
 SolOptions& sol_opt();

@@ -612,6 +612,7 @@ int sol_conv_sh_pack(hipStream_t s, const float* w_hwio, int cin, int cout, int 
 // SOL_CONV_SPLIT=3 runs the three leading products only (~2^-17 relative error per product): an
 // experiment knob, NOT the default and not what bench.py or the parity tests use.
 int sol_conv_sb_launch(hipStream_t s, const ConvArgs& a, int NT, int ntiles) {
+    if (sol_conv_thin32_usable(a, NT)) return sol_conv_thin32_launch(s, a, ntiles);      // thin layers of 64-pixel images: exact fp32 on the VALU
     if (sol_conv_dx_usable(a, NT, ntiles)) return sol_conv_dx_launch(s, a, ntiles);
     if (int e = init_sb_kernels()) return e;
     const int nprod = sol_opt().conv_split3 ? 3 : 6;

@@ -463,7 +463,8 @@ def test_conv5x5_dx_thin_layers_against_float64_and_the_row_per_wave_kernel(B, H
     packed = ops._pack(w, 32, cout, ops.CONV_FWD)
     xm = ops.absmax_slots(x)
     conv = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), None, padding=2).permute(0, 2, 3, 1)
-    saved = _lib.get_option("conv_dx")
+    saved, saved_valu = _lib.get_option("conv_dx"), _lib.get_option("conv_thin_valu")
+    _lib.set_option("conv_thin_valu", 0)            # (the exact-fp32 VALU form of the plain thin layers has its own test below)
     try:
         for name, (bb, rr, aa, epi) in {"bias+lrelu": (b, None, None, ops.EPI_LRELU), "res+dlrelu": (None, res, act, ops.EPI_DLRELU),
                                         "plain": (None, None, None, ops.EPI_NONE)}.items():
@@ -483,6 +484,49 @@ def test_conv5x5_dx_thin_layers_against_float64_and_the_row_per_wave_kernel(B, H
             assert rel(ys[7], ref) < 6e-7 and rel(ys[7], ref) < 1.5 * rel(ys[1], ref) + 1e-8, (name, rel(ys[7], ref), rel(ys[1], ref))
     finally:
         _lib.set_option("conv_dx", saved)
+        _lib.set_option("conv_thin_valu", saved_valu)
+
+
+@pytest.mark.parametrize("B,H", [(6, 128), (2, 5), (1, 1), (3, 64), (1, 7)])
+@pytest.mark.parametrize("cout", [1, 2, 3, 4])
+def test_conv5x5_thin_valu_kernel_against_float64_and_the_split_kernel(B, H, cout):
+    """k_conv5x5_thin32 (conv5x5_thin.hip, option conv_thin_valu, default on): the thin 32 -> (<= 4) layers of 64-pixel images in EXACT
+    fp32 on the vector ALU -- no absmax dependency, no operand split.  Against a float64 convolution (with and without bias; image
+    heights that are not multiples of the three rows of a workgroup, single rows, images straddling workgroups) and against the
+    split-precision kernel it replaces; the published absmax equals the output's.  Launches it does not take (a residual, an
+    activation, 128-pixel rows, 16 output channels) must keep their kernels.  The correction-mode epilogue (velocity update + l2 loss)
+    runs in every trainer / roll-out test at 128x64 and in test_sol32_bench_workload_against_golden."""
+    from sol_amd import _lib
+    W = 64
+    gen = torch.Generator().manual_seed(B * 1000 + H * 10 + cout)
+    x = torch.randn(B, H, W, 32, generator=gen, dtype=torch.float32).to(DEV)
+    w = (torch.randn(5, 5, 32, cout, generator=gen, dtype=torch.float32) * 0.05).to(DEV)
+    b = torch.randn(cout, generator=gen, dtype=torch.float32).to(DEV)
+    packed = ops._pack(w, 32, cout, ops.CONV_FWD)
+    xm = ops.absmax_slots(x)
+    conv = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), None, padding=2).permute(0, 2, 3, 1)
+    saved = _lib.get_option("conv_thin_valu")
+    try:
+        for bb in (None, b):
+            ref = conv + (bb.double() if bb is not None else 0.0)
+            ys = {}
+            for valu in (1, 0):
+                _lib.set_option("conv_thin_valu", valu)
+                ym = torch.zeros(ops.AMAX_SLOTS, dtype=torch.int32, device=DEV)
+                with _lib.profile() as p:
+                    ys[valu] = ops.conv5x5_scaled_raw(x, packed, bb, None, None, cout, ops.EPI_NONE, 0.3, xm, ym)
+                assert float(ym.max().view(torch.float32).item()) == float(ys[valu].abs().max())
+                assert any("k_conv5x5_thin32" in k for k in p.kernels) == (valu == 1), (valu, p.kernels)
+            assert rel(ys[1], ref) < 4e-7, rel(ys[1], ref)
+            assert rel(ys[1], ref) <= 1.5 * rel(ys[0], ref) + 1e-8, (rel(ys[1], ref), rel(ys[0], ref))
+        _lib.set_option("conv_thin_valu", 1)
+        res = torch.randn(B, H, W, cout, generator=gen, dtype=torch.float32).to(DEV)
+        for kw in (dict(residual=res, epi=ops.EPI_NONE), dict(residual=None, epi=ops.EPI_LRELU)):
+            with _lib.profile() as p:
+                ops.conv5x5_scaled_raw(x, packed, None, kw["residual"], None, cout, kw["epi"], 0.3, xm, None)
+            assert not any("k_conv5x5_thin32" in k for k in p.kernels), p.kernels
+    finally:
+        _lib.set_option("conv_thin_valu", saved)
 
 
 def test_mars_moon_network_full_size_against_torch_float64_autograd():
