@@ -35,8 +35,8 @@ constexpr int TH_NROWS = 7;
 constexpr int TH_PART = 15 * 64 * 16;            // [unit][pixel][4 floats]
 constexpr int TH_LDS = TH_NROWS * TH_ROW + TH_PART + 128;    // + {absmax word, ticket, loss ticket, pad x3, 16 wave slots}
 
-template <int CON>                               // output channels computed: 2 (CO <= 2) or 4 (CO <= 4)
-__global__ void __launch_bounds__(1024) k_conv5x5_thin32(ConvArgs a, int nrows) {
+template <int CON, int NW>                       // CON: output channels computed, 2 (CO <= 2) or 4 (CO <= 4); NW: waves per workgroup, 16 or 8
+__global__ void __launch_bounds__(NW * 64) k_conv5x5_thin32(ConvArgs a, int nrows) {
     extern __shared__ __align__(16) unsigned char smem_th[];
     unsigned char* const rows = smem_th;
     float* const part = reinterpret_cast<float*>(smem_th + TH_NROWS * TH_ROW);
@@ -48,11 +48,13 @@ __global__ void __launch_bounds__(1024) k_conv5x5_thin32(ConvArgs a, int nrows) 
     if (tid < 32) slots[tid] = 0u;
 
     // ---- staging: every request goes out at once, no predicate (rows outside the tensor: a clamped row, never read) ----------------------
-    const int c4 = tid & 7, p = (tid >> 3) & 63, hb = tid >> 9;      // thread = channel quad of pixel p in rows hb, hb + 2, hb + 4 (, 6)
+    const int c4 = tid & 7, p = (tid >> 3) & 63, hb = tid >> 9;      // NW = 16: thread = channel quad of pixel p in rows hb, hb + 2, hb + 4 (, 6); NW = 8: all seven rows
     const float4* gx = reinterpret_cast<const float4*>(a.x) + (size_t)p * 8 + c4;
     // (NAMED registers: an indexed array is left in scratch memory by the compiler -- a store behind every load)
     auto grow = [&](int s) { return (size_t)min(max(G0 - 2 + s, 0), nrows - 1) * W * 8; };      // scalar clamp
-    const float4 v0 = gx[grow(hb)], v1 = gx[grow(hb + 2)], v2 = gx[grow(hb + 4)], v3 = gx[grow(6)];      // (row 6: both halves request it, the upper half drops it)
+    const float4 v0 = gx[grow(NW == 16 ? hb : 0)], v1 = gx[grow(NW == 16 ? hb + 2 : 1)], v2 = gx[grow(NW == 16 ? hb + 4 : 2)], v3 = gx[grow(NW == 16 ? 6 : 3)];      // (NW = 16, row 6: both halves request it, the upper half drops it)
+    float4 v4 = v3, v5 = v3, v6 = v3;
+    if (NW == 8) { v4 = gx[grow(4)]; v5 = gx[grow(5)]; v6 = gx[grow(6)]; }
     // epilogue operands of the thread's pixel (threads 0..191: row r = wave 0..2, pixel = lane), requested with the rows: the velocity faces
     // and the ground-truth frames are HBM cold (read once per training step)
     const int er = wave, gy = G0 + er;
@@ -76,7 +78,7 @@ __global__ void __launch_bounds__(1024) k_conv5x5_thin32(ConvArgs a, int nrows) 
     // invalid at kernel start, and the unit loop below has to wait for every scalar load together with its LDS reads (both count in
     // lgkmcnt) -- ten exposed round trips per unit, each to the MALL otherwise.  (A plain vector load: the value only keeps the request alive.)
     float wwarm = 0.f;
-    if (wave < 15 && lane < 5 * CON * 2)
+    if (wave < 15 && lane < 5 * CON * 2)         // (NW = 8: the wave's first unit; its second one is warmed by the wave that has the same tap row)
         wwarm = a.wp[(size_t)(wave / 3) * 5 * 16 * 32 + ((lane / (CON * 2)) * 16 + (lane / 2) % CON) * 32 + (lane & 1) * 16];
     __builtin_amdgcn_sched_barrier(0);
     if (tid < 224) {                                             // zero halo pixels 0, 1, 66, 67 of every row
@@ -86,15 +88,19 @@ __global__ void __launch_bounds__(1024) k_conv5x5_thin32(ConvArgs a, int nrows) 
     {
         float4* q = reinterpret_cast<float4*>(rows + (p + 2) * TH_PITCH + c4 * 16);
         constexpr int RS = TH_ROW / 16;
-        q[hb * RS] = v0; q[(hb + 2) * RS] = v1; q[(hb + 4) * RS] = v2;
-        if (hb == 0) q[6 * RS] = v3;
+        if (NW == 16) {
+            q[hb * RS] = v0; q[(hb + 2) * RS] = v1; q[(hb + 4) * RS] = v2;
+            if (hb == 0) q[6 * RS] = v3;
+        } else {
+            q[0] = v0; q[RS] = v1; q[2 * RS] = v2; q[3 * RS] = v3; q[4 * RS] = v4; q[5 * RS] = v5; q[6 * RS] = v6;
+        }
     }
     asm volatile("" :: "v"(wwarm));
     __syncthreads();
 
     // ---- the wave's units (output row r, tap row dy) ----------------------------------------------------------------------------------------
-    if (wave < 15) {
-        const int u = wave;
+#pragma unroll 1
+    for (int u = wave; u < 15; u += NW) {
         const int r = u % 3, dy = u / 3;
         const int oy = G0 + r, iy = oy + dy - 2;
         const int b = oy < nrows ? oy / H : 0;
@@ -178,12 +184,18 @@ bool sol_conv_thin32_usable(const ConvArgs& a, int NT) {
 
 int sol_conv_thin32_launch(hipStream_t s, const ConvArgs& a, int ntiles) {
     static std::atomic<unsigned long long> optin{0};
-    if (int e = sol_lds_optin(optin, {SOL_K(k_conv5x5_thin32<2>), SOL_K(k_conv5x5_thin32<4>)}, "k_conv5x5_thin32")) return e;
+    if (int e = sol_lds_optin(optin, {SOL_K((k_conv5x5_thin32<2, 16>)), SOL_K((k_conv5x5_thin32<4, 16>)), SOL_K((k_conv5x5_thin32<2, 8>)), SOL_K((k_conv5x5_thin32<4, 8>))}, "k_conv5x5_thin32")) return e;
     const int nrows = ntiles;                             // tiles_x == 1: one tile per image row
     int grid = (nrows + 2) / 3;
     if (grid > 64) grid = (grid + 7) / 8 * 8;             // XCD-aware tile order (xcd_tile); padding workgroups own no rows
-    if (a.CO <= 2) SOL_LAUNCH(k_conv5x5_thin32<2>, dim3(grid), dim3(1024), TH_LDS, s, a, nrows);
-    else SOL_LAUNCH(k_conv5x5_thin32<4>, dim3(grid), dim3(1024), TH_LDS, s, a, nrows);
+    const bool w8 = sol_opt().conv_thin_valu == 2;     // (A/B: eight waves, two units each)
+    if (a.CO <= 2) {
+        if (w8) SOL_LAUNCH((k_conv5x5_thin32<2, 8>), dim3(grid), dim3(512), TH_LDS, s, a, nrows);
+        else SOL_LAUNCH((k_conv5x5_thin32<2, 16>), dim3(grid), dim3(1024), TH_LDS, s, a, nrows);
+    } else {
+        if (w8) SOL_LAUNCH((k_conv5x5_thin32<4, 8>), dim3(grid), dim3(512), TH_LDS, s, a, nrows);
+        else SOL_LAUNCH((k_conv5x5_thin32<4, 16>), dim3(grid), dim3(1024), TH_LDS, s, a, nrows);
+    }
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }

@@ -51,7 +51,7 @@ const OptName OPT_NAMES[] = {
     {"density_mode", &SolOptions::density_mode, 0, 2}, {"cpt", &SolOptions::cpt, 0, 16}, {"dbg_skip", &SolOptions::dbg_skip, 0, 1 << 30},
     {"step_prof", &SolOptions::step_prof, 0, 1}, {"cnn_persistent", &SolOptions::cnn_persistent, 0, 1},
     {"graph_stream", &SolOptions::graph_stream, 0, 1}, {"k3d_tile", &SolOptions::k3d_tile, 0, 1}, {"k3d_fused_tf", &SolOptions::k3d_fused_tf, 0, 1}, {"k3d_conv_fused", &SolOptions::k3d_conv_fused, 0, 1}, {"k3d_conv_rows", &SolOptions::k3d_conv_rows, 3, 8},
-    {"conv_dx", &SolOptions::conv_dx, 0, 15}, {"conv_thin_valu", &SolOptions::conv_thin_valu, 0, 1}, {"k3d_mfma_tf", &SolOptions::k3d_mfma_tf, 0, 1},
+    {"conv_dx", &SolOptions::conv_dx, 0, 15}, {"conv_thin_valu", &SolOptions::conv_thin_valu, 0, 2}, {"k3d_mfma_tf", &SolOptions::k3d_mfma_tf, 0, 1},
 };
 }  // namespace
 
