@@ -315,7 +315,7 @@ def test_transposed_cnn_recipe_paths_against_oracle(B):
     names = {k.strip("()"): v[0] for k, v in p.kernels.items()}
     assert names.get("k_karman_bwd_bww_small") == ms and "k_density_chain" not in names and "k_correct_loss" not in names, names
     assert not any(k.startswith("k_transpose_cells") for k in names), names
-    thin_fwd = "k_conv5x5_dx<1, 1>" if B == 3 else "k_conv5x5_sb<1, 2>"
+    thin_fwd = "k_conv5x5_thin32<2, 16>"                            # (round 5: the exact-fp32 VALU kernel, every batch size; k_conv5x5_dx<1, 1> / k_conv5x5_sb<1, 2> before)
     assert names.get(thin_fwd) == ms + (ms - 1), names              # correction-mode output layer + the 32 -> 3 data gradient
 
 
@@ -1185,8 +1185,9 @@ def test_options_and_launch_profiler():
     # ten 32->32 layers, forward + backward-data, per unrolled step (B * Y = 256 rows: the one-row-per-workgroup form of the dx kernel)
     thin = ("k_conv5x5_dx<1, 1>", "k_conv5x5_dx<3, 1>")
     assert sum(v[0] for k, v in names.items() if k.startswith("k_conv5x5_dx") and k not in thin) == ms * (10 + 10)
-    # ... and its thin-layer form for the 32 -> 2 output layer (correction mode) and the 32 -> 3 data gradient of the first layer
-    assert sum(v[0] for k, v in names.items() if k in thin) == ms + (ms - 1), names
+    # ... and the exact-fp32 VALU kernel for the 32 -> 2 output layer (correction mode) and the 32 -> 3 data gradient of the first layer
+    assert sum(v[0] for k, v in names.items() if k.startswith("k_conv5x5_thin32")) == ms + (ms - 1), names
+    assert not any(k in thin for k in names), names
     assert all(c > 0 and t > 0 for c, t in names.values())
     assert lib.sol_version() == _lib.ABI_VERSION
 
