@@ -11,6 +11,7 @@ OUT=$R/gpurun_out/r5prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
 ARGS="--steps 20 --warmup 5"
+[ "${1:-}" = "--2d-only" ] && ARGS="--steps 10 --warmup 3 --no-cpu-baseline"
 python $R/bench.py $ARGS 2>$OUT/bench.err | tail -1 > $OUT/bench.json
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $R/bench.py $ARGS > $OUT/bench_under_rocprof.json 2>$OUT/rocprof.err
 DB=$(find $OUT/trace -name "*.db" | head -1)
@@ -22,6 +23,7 @@ done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F16 \
   --output-format csv -d $OUT/pmc_sq -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline > /dev/null 2>>$OUT/rocprof.err
 python $R/tools/pmc_summary.py $OUT/pmc_sq "k_" > $OUT/pmc_sq.txt
+if [ "${1:-}" = "--2d-only" ]; then rm -rf $OUT/trace $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq; ls -la $OUT; exit 0; fi     # (the karman-3d passes take ten minutes of box time)
 # karman-3d: kernel trace + HBM counters of the forward roll-out and one training step
 cat > /tmp/k3d_prof.py <<PY
 import sys, json, torch
