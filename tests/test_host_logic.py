@@ -180,3 +180,57 @@ def test_burgers_forcing_model_and_randfreq():
     assert r.shape == (33, 32) and abs(r.std() - 1) < 1e-12
     spec = np.abs(np.fft.fft2(r))
     assert spec[0:3, 0:3].sum() > 0.9 * spec.sum()              # power 8: essentially the lowest wave numbers
+
+
+def test_capture_safe_torch_helpers_equal_the_torch_ops_they_replace():
+    """The helpers that keep captured graphs kernel-only must be drop-in: same values AND same gradients as
+    the torch forms they replace -- `_lib.pad_high` vs `F.pad` (constant_pad_nd, whose backward clone()s a narrow of the gradient),
+    `ops.split_flat` vs 1-D slicing (SliceBackward = zeros + copy_), `_lib.stack0` vs `torch.stack`.  On the CPU: the same Python runs
+    there (the GPU-only part is the kernel copy inside SplitFlatFn.backward / dcopy_)."""
+    from sol_amd import _lib
+    F = torch.nn.functional
+    gen = torch.Generator().manual_seed(3)
+    # pad_high: every (dims) combination the package uses
+    for shape, dims, pad in (((2, 5, 4, 1), (2,), (0, 0, 0, 1)), ((2, 5, 4, 1), (1,), (0, 0, 0, 0, 0, 1)), ((3, 4, 5, 2), (1, 2), (0, 0, 0, 1, 0, 1)),
+                             ((1, 6, 3, 4), (1,), (0, 0, 0, 0, 0, 1)), ((2, 4, 3, 5), (3,), (0, 1)), ((2, 5, 4), (2,), (0, 1)), ((2, 5, 4), (1,), (0, 0, 0, 1))):
+        x = torch.randn(*shape, generator=gen, dtype=torch.float64)
+        a, b = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ya, yb = _lib.pad_high(a, *dims), F.pad(b, pad)
+        assert ya.shape == yb.shape and torch.equal(ya, yb), (shape, dims)
+        w = torch.randn(ya.shape, generator=gen, dtype=torch.float64)
+        (ya * w).sum().backward()
+        (yb * w).sum().backward()
+        assert torch.equal(a.grad, b.grad), (shape, dims)
+    # split_flat: pieces are views of the flat buffer, gradient = the pieces' gradients in place (zeros where a piece is unused)
+    flat = torch.randn(37, generator=gen, dtype=torch.float64)
+    bounds = (0, 5, 5, 17, 30, 37)                                   # (an empty piece and a full cover)
+    a, b = flat.clone().requires_grad_(True), flat.clone().requires_grad_(True)
+    pa = ops.split_flat(a, bounds)
+    pb = [b[bounds[k]:bounds[k + 1]] for k in range(len(bounds) - 1)]
+    assert all(torch.equal(u, v) for u, v in zip(pa, pb))
+    ws = [torch.randn(p.shape, generator=gen, dtype=torch.float64) for p in pb]
+    (sum((u * w).sum() for u, w in zip(pa, ws) if u.numel()) - 2.0 * pa[3].sum()).backward()
+    (sum((u * w).sum() for u, w in zip(pb, ws) if u.numel()) - 2.0 * pb[3].sum()).backward()
+    assert torch.equal(a.grad, b.grad)
+    a2 = flat.clone().requires_grad_(True)
+    pa2 = ops.split_flat(a2, (3, 10, 20))                             # partial cover, one piece without a gradient
+    (pa2[1] * 3.0).sum().backward()
+    exp = torch.zeros(37, dtype=torch.float64)
+    exp[10:20] = 3.0
+    assert torch.equal(a2.grad, exp)
+    with torch.no_grad():                                             # no-grad / non-differentiable inputs: plain views
+        v = ops.split_flat(a2, (0, 4, 37))
+    assert v[0].data_ptr() == a2.data_ptr() and v[0].grad_fn is None
+    # the networks' tensors() go through it: in-place edits under no_grad still reach the flat buffer
+    net = sol_amd.model_mercury(seed=1, device="cpu")
+    with torch.no_grad():
+        net.tensors()[1].fill_(0.25)
+    assert float(net.params[net.offsets[1]:net.offsets[2]].mean()) == 0.25
+    # stack0
+    one = [torch.tensor(2.5, dtype=torch.float64, requires_grad=True)]
+    s1 = _lib.stack0(one)
+    assert s1.shape == (1,) and torch.equal(s1.detach(), torch.stack(one).detach())
+    s1.sum().backward()
+    assert float(one[0].grad) == 1.0
+    many = [torch.tensor(float(k)) for k in range(4)]
+    assert torch.equal(_lib.stack0(many), torch.stack(many))
