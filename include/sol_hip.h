@@ -60,6 +60,11 @@ int sol_abi_sizes(int32_t* karman_cfg, int32_t* burgers_cfg, int32_t* train_cfg)
  *                       SIMD), operands prefetched one tap ahead; 6 = 32 x 32 tiles, twelve waves; 3 = 16 x 32 tiles, twelve waves
  *   k3d_tile (0)        1: karman-3d advection from LDS tiles that hold the full z column + halo; 0: wave-per-column gathers
  *                       straight from the L2-resident fields (measured 3x faster at batch 1-2: the tile form is instruction bound)
+ *   conv_dx (11)        bit set: 1 the 32 -> 32 fp16 x3 convolutions on the dx-major kernel, 2 thin layers in one-row launches, 4 thin layers
+ *                       everywhere, 8 half-channel workgroups in one-row launches
+ *   conv_thin_valu (1)  the thin 32 -> (<= 4) layers of 64-pixel images without residual / activation (the trainer's output layer with the
+ *                       correction + loss epilogue, the first layer's data gradient) in exact fp32 on the vector ALU; 2: its eight-wave
+ *                       form; 0: the split-precision MFMA kernels
  *   bww_chunk (0), bww_side (1), streams (1), cpt (0), conv_split3 (0), dbg_skip (0), step_prof (0): experiments, debugging */
 int sol_set_option(const char* name, int32_t value);
 int sol_get_option(const char* name, int32_t* value);
