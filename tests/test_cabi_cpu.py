@@ -144,3 +144,34 @@ def test_sol32_fixture_is_the_bench_workload(golden_dir):
     assert np.allclose(z["loss_traj"], [2386.489, 118279.49, 11700.69], rtol=1e-6)
     assert abs(z["loss_steps"].sum() / 32 - z["loss_traj"][0]) < 1e-9 * z["loss_traj"][0]
     assert z["grads_sub16"].shape == ((260354 + 15) // 16,) and z["grad_norms"].shape == (24,)
+
+
+def test_round5_entry_points_reject_bad_arguments_and_options_have_their_defaults(lib):
+    """sol_graph_check / sol_graph_census / sol_copy_words / sol_conv3d_bwd_weight_acc validate their arguments before they touch the HIP
+    runtime (no GPU needed), SOL_ERR_GRAPH is a code of its own, the node-type names are those of hipGraphNodeType, and the options
+    added in round 5 have their documented defaults and ranges."""
+    assert lib.sol_graph_check(None, b"x") == -1 and b"NULL graph" in lib.sol_last_error()
+    counts = (C.c_int32 * 8)()
+    assert lib.sol_graph_census(None, counts, 8) == -1
+    assert lib.sol_graph_census(C.c_void_p(1), counts, 0) == -1 and lib.sol_graph_census(C.c_void_p(1), counts, 65) == -1
+    assert lib.sol_graph_node_type_name(0) == b"kernel" and lib.sol_graph_node_type_name(1) == b"memcpy" and lib.sol_graph_node_type_name(2) == b"memset"
+    one = C.c_void_p(4)
+    assert lib.sol_copy_words(None, None, one, 4) == -1                     # no destination
+    assert lib.sol_copy_words(None, one, one, -1) == -1                     # negative count
+    assert lib.sol_copy_words(None, C.c_void_p(6), one, 4) == -1            # destination not 4-byte aligned
+    assert lib.sol_copy_words(None, one, one, 0) == 0 and lib.sol_copy_words(None, one, one, 16) == 0      # nothing to do / dst == src: no launch
+    rc = lib.sol_conv3d_bwd_weight_acc(None, None, one, None, None, one, one, one, one, 1, 8, 8, 64, 32, 32, 32, 32, 0, 1)
+    assert rc == -1 and b"NULL pointer" in lib.sol_last_error()
+    rc = lib.sol_conv3d_bwd_weight_acc(None, one, one, None, None, one, one, one, one, 1, 2, 8, 64, 32, 32, 32, 32, 1, 0)
+    assert rc == -1 and b"bad shape" in lib.sol_last_error()                # D < 3
+    assert _lib.get_option("conv_thin_valu") == 1
+    with pytest.raises(sol_amd.SolError):
+        _lib.set_option("conv_thin_valu", 3)
+    for v in (0, 2, 1):
+        _lib.set_option("conv_thin_valu", v)
+        assert _lib.get_option("conv_thin_valu") == v
+    # the header documents every option name the table knows that a host may want to flip
+    hdr = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "sol_hip.h")).read()
+    for name in ("conv_precision", "conv_dx", "conv_thin_valu", "cnn_persistent", "k3d_conv_rows"):
+        assert name in hdr, name
+    assert "SOL_ERR_GRAPH (-4)" in hdr
