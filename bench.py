@@ -26,7 +26,8 @@ import torch
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_MFMA16_TF = 2500.0        # dense 16-bit MFMA peak
 PEAK_MFMA32_TF = 157.3         # fp32 matrix peak
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")   # written by tools/pmc_summary.py --json (with the library's source hash)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")   # written by tools/pmc_summary.py --json (with the library's source hash)
+PRECISION_FILE = os.path.join(ROOT, "profiles", "r06_precision_at_c3.json")   # written by tests/test_gpu_parity.py::test_sol32_workload_error_of_each_conv_arithmetic_against_float64
 RANK_SKEW_LIMIT = 0.25         # N > 1: the line is flagged "valid": false when the slowest rank's timed region is this much longer than the fastest one's
 
 
@@ -51,9 +52,10 @@ def parse():
     p.add_argument("--precision", default="split", choices=["split", "bf16x6", "fp32"], help="conv arithmetic of the timed steps")
     p.add_argument("--cpu-msteps", type=int, default=2, help="msteps of the bounded CPU-baseline sample")
     p.add_argument("--no-cpu-sol32", action="store_true", help="skip the ONE CPU training step at the full SOL-<msteps> depth that calibrates the bounded sample")
-    p.add_argument("--prewarm", type=int, default=0,
-                   help="untimed training steps BEFORE the W warm-up steps (clock / power-state ramp of a freshly leased GPU: the first seconds "
-                        "of a process; measured: no effect on this pool, default 0); reported in the line as pre_warmup_steps")
+    p.add_argument("--prewarm", type=int, default=40,
+                   help="untimed training steps BEFORE the W warm-up steps (clock / power-state ramp of a freshly leased GPU: ~0.5 s of the "
+                        "workload itself, so that the K timed steps do not start on a cold clock); reported in the line as pre_warmup_steps")
+    p.add_argument("--no-device-state", action="store_true", help="skip the clock / power samples around the timed region (device_state_before / _after)")
     p.add_argument("--comm", default="torch", choices=["torch", "lib"],
                    help="N > 1: the gradient all-reduce through torch.distributed.all_reduce (RCCL via PyTorch) or through the library's own "
                         "RCCL communicator (sol_allreduce_grads, csrc/comm.hip; needs one device per rank)")
@@ -77,6 +79,12 @@ def cpu_baseline(args, Y, X, B):
     cores on a bounded sample: one fp32 training step (fwd + autograd bwd) of SOL-<cpu_msteps>."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import sol_oracle as o
+    try:        # the GPU process was pinned to its GPU's NUMA node (dist.bind_cpu_affinity): the host baseline gets the whole inherited mask back
+        from sol_amd import dist as _dist
+        if _dist.AFFINITY and _dist.AFFINITY.get("bound") and _dist.AFFINITY.get("inherited"):
+            os.sched_setaffinity(0, _dist.AFFINITY["inherited"])
+    except Exception:
+        pass
     host = os.cpu_count() or 1
     model = "unknown"
     try:
@@ -184,17 +192,157 @@ class Workload:
         return tr.train_step(self.d0, self.vy0, self.vx0, self.re, self.gt_vy, self.gt_vx, lr, want_final=True)   # final state incl. the passive density
 
 
-def timed_steps(wl, lr, steps, warmup, barrier, trainer=None):
+def timed_steps(wl, lr, steps, warmup, barrier, trainer=None, per_step=False):
+    """W untimed steps, then K steps between barrier + synchronize pairs (wall clock).  per_step: one HIP event on the launch stream in
+    front of every timed step and one behind the last (recorded asynchronously: no synchronisation is added to the timed region) -> the
+    K individual step durations, read after the closing barrier."""
     trace = []
     for _ in range(warmup):
         trace.append(float(wl.step(lr, trainer)))
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step else None
     barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
+        if evs:
+            evs[i].record()
         loss = wl.step(lr, trainer)
+    if evs:
+        evs[steps].record()
     barrier()
     sec = time.perf_counter() - t0
+    if per_step:
+        return sec, float(loss), trace, [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
     return sec, float(loss), trace
+
+
+def _quantile(v, q):
+    v = sorted(v)
+    if not v:
+        return None
+    x = q * (len(v) - 1)
+    lo = int(math.floor(x))
+    hi = min(lo + 1, len(v) - 1)
+    return v[lo] + (v[hi] - v[lo]) * (x - lo)
+
+
+def step_distribution(per_step_ms):
+    """median / p10 / p90 / min / max of the K per-step durations (HIP events on the launch stream): what lets a reader tell a slow
+    box (the whole distribution moves, and the device_state probe with it) from a 1 % kernel regression (the median moves, the probe does not)"""
+    if not per_step_ms:
+        return None
+    return {"median": _quantile(per_step_ms, 0.5), "p10": _quantile(per_step_ms, 0.1), "p90": _quantile(per_step_ms, 0.9),
+            "min": min(per_step_ms), "max": max(per_step_ms), "mean": sum(per_step_ms) / len(per_step_ms), "n": len(per_step_ms),
+            "all": [round(v, 4) for v in per_step_ms],
+            "note": "HIP events on the launch stream around every timed step (graph replay + all-reduce + Adam), recorded asynchronously; ms"}
+
+
+def _sysfs_gpu(dev_index):
+    """best-effort clock / power / temperature of the device from amdgpu's sysfs files (no root needed); {} when nothing is readable"""
+    import glob
+    out = {}
+    try:
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk"))]
+        pick = None
+        for c in cards:
+            if want and want in os.path.realpath(c):
+                pick = c
+        if pick is None and len(cards) == 1:
+            pick = cards[0]
+        if pick is None:
+            return out
+        for name, key in (("pp_dpm_sclk", "sclk_mhz"), ("pp_dpm_mclk", "mclk_mhz")):
+            try:
+                with open(os.path.join(pick, name)) as f:
+                    for line in f:
+                        if line.strip().endswith("*"):
+                            out[key] = float("".join(ch for ch in line.split(":")[1] if ch.isdigit() or ch == "."))
+            except (OSError, ValueError, IndexError):
+                pass
+        for hw in glob.glob(os.path.join(pick, "hwmon", "hwmon*")):
+            for name, key, scale in (("power1_average", "power_w", 1e-6), ("power1_input", "power_w", 1e-6), ("temp1_input", "temp_c", 1e-3),
+                                     ("freq1_input", "sclk_hwmon_mhz", 1e-6)):
+                try:
+                    with open(os.path.join(hw, name)) as f:
+                        out.setdefault(key, float(f.read().strip()) * scale)
+                except (OSError, ValueError):
+                    pass
+    except Exception:
+        pass
+    return out
+
+
+def device_state(sol_amd, dev, iters=4000000):
+    """Clock / power sample of the device: (a) ~90 ms of a dependent-MFMA chain on every SIMD (sol_clock_probe): ns per dependent
+    v_mfma_f32_16x16x16_f16 follows the engine clock the box holds UNDER MATRIX LOAD and nothing else, and the ratio of the two device
+    counters (s_memtime / s_memrealtime) is that clock in MHz; (b) amdgpu sysfs (sclk, power, temperature) where readable; (c) the clock
+    the runtime advertises.  Taken before and after the timed region."""
+    import ctypes as C
+    out = {"iters": iters}
+    try:
+        buf = torch.zeros(8, dtype=torch.int32, device=dev)
+        lib = sol_amd._lib.load()
+        sol_amd._lib.check(lib.sol_clock_probe(sol_amd._lib.stream(), C.c_void_p(buf.data_ptr()), 1000))      # warm: code object load
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sol_amd._lib.check(lib.sol_clock_probe(sol_amd._lib.stream(), C.c_void_p(buf.data_ptr()), iters))
+        torch.cuda.synchronize()
+        out["probe_wall_ms"] = (time.perf_counter() - t0) * 1e3
+        w = buf.cpu().numpy().view("uint64")
+        out["ns_per_dependent_mfma"] = float(w[0]) * 10.0 / float(w[2])
+        # s_memtime counts engine clocks on gfx950 (23.8 per 10 ns tick of s_memrealtime on a 2.4 GHz part): the ratio IS the shader clock held
+        # during the probe, measured by the device itself
+        out["shader_clock_mhz_measured"] = float(w[1]) / max(float(w[0]), 1.0) * 100.0
+        out["cycles_per_dependent_mfma"] = out["ns_per_dependent_mfma"] * out["shader_clock_mhz_measured"] * 1e-3
+    except Exception as e:
+        out["probe_error"] = str(e)
+    out.update(_sysfs_gpu(dev.index if dev.index is not None else 0))
+    try:
+        out["advertised_max_clock_mhz"] = torch.cuda.get_device_properties(dev).clock_rate / 1e3
+    except Exception:
+        pass
+    return out
+
+
+def burgers_leg(sol_amd, dev, steps=30):
+    """BASELINE configs[0] and the reference's two Burgers training recipes (burgers/Makefile:69-77: 32x32, `-b 5`, dt 0.1; NON = `-m 1`,
+    SOL-04 = `-m 4`): one training step = unrolled msteps x [BurgersTest.step_with_f -> model_mars_moon(4 -> 2) correction -> l2 loss], reverse
+    sweep, TF-Adam; captured once, replayed (sol_amd.BurgersTrainer).  Synthetic frames of the recipe's shape."""
+    import numpy as np
+    B, Y, X, dt = 5, 32, 32, 0.1
+    dom = sol_amd.Domain([Y, X], box=sol_amd.box([32, 32]), boundaries=sol_amd.PERIODIC)
+    rng = np.random.default_rng(0)
+    out = {"workload": "burgers 32x32, batch 5, dt 0.1, model_mars_moon(4 -> 2), lr 1e-4 (burgers/Makefile:69-77)", "data": "synthetic"}
+    for leg, ms in (("non_m1", 1), ("sol04_m4", 4)):
+        try:
+            velo = torch.as_tensor(0.3 * rng.standard_normal((ms + 1, B, Y + 1, X + 1, 2)).astype(np.float32), device=dev)
+            forc = torch.as_tensor(0.1 * rng.standard_normal((ms, B, Y + 1, X + 1, 2)).astype(np.float32), device=dev)
+            net = sol_amd.model_mars_moon(cin=4, cout=2, seed=0, device=dev)
+            tr = sol_amd.BurgersTrainer(net, dom, B, ms, dt, (0.2, 0.2), (0.1, 0.1), use_graph=True)
+            for _ in range(5):
+                tr.train_step(velo, forc, 1e-4)
+            torch.cuda.synchronize()
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+            t0 = time.perf_counter()
+            for i in range(steps):
+                evs[i].record()
+                loss = tr.train_step(velo, forc, 1e-4)
+            evs[steps].record()
+            torch.cuda.synchronize()
+            sec = time.perf_counter() - t0
+            per = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+            out[leg] = {"msteps": ms, "ms_per_step": sec / steps * 1e3, "ms_per_step_median": _quantile(per, 0.5), "sim_steps_per_s": B * ms * steps / sec,
+                        "loss": float(loss), "finite": bool(math.isfinite(float(loss))), "schedule": getattr(tr, "schedule", "autograd")}
+            del tr
+        except Exception as e:
+            out[leg] = {"error": str(e)}
+    return out
 
 
 def profile_kernels(wl, lr, trainer=None):
@@ -358,6 +506,25 @@ def load_traffic():
     return tab
 
 
+def load_precision():
+    """the committed workload-level precision record (errors of the three convolution arithmetics against the float64 fixture at C3, written
+    by the GPU test-suite); None when absent"""
+    try:
+        with open(PRECISION_FILE) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def precision_note():
+    p = load_precision()
+    if not p:
+        return "not recorded for this tree (profiles/r06_precision_at_c3.json missing)"
+    r, e = p["ratio_to_strict_fp32"]["split"], p["relative_l2_error"]["split"]
+    return "%.2fx / %.2fx the strict trainer's error (%.1e / %.1e absolute; tolerances 1e-5 / 1e-4)" % (
+        r["loss_steps"], r["gradient_every_16th"], e["loss_steps"], e["gradient_every_16th"])
+
+
 def traffic_bytes(tab, kernel, grid):
     # (rocprofv3 prints defaulted template arguments, the launch macro's name does not: k_conv5x5_dx<3, 2, false> vs <3, 2>)
     kern = {k.replace(", false>", ">"): v for k, v in tab.get("kernels", {}).items()}
@@ -382,6 +549,10 @@ def main():
     rank, world, local = sol_amd.dist.init_from_env(backend)
     if args.gpus != world:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if world > 1 and world <= ndev and torch.distributed.get_backend() != "nccl":
+        # one device per rank is available: a weak-scaling point measured over gloo (host staging) would say nothing about RCCL / xGMI
+        raise SystemExit("bench.py: %d ranks on %d devices must run the nccl (RCCL) backend, got %r -- refusing to print a scaling point over a "
+                         "fallback backend" % (world, ndev, torch.distributed.get_backend()))
     local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -404,7 +575,9 @@ def main():
 
     for _ in range(max(0, args.prewarm)):
         wl.step(args.lr)
-    sec, loss, trace = timed_steps(wl, args.lr, args.steps, args.warmup, barrier)
+    state_before = device_state(sol_amd, dev) if (rank == 0 and not args.no_device_state) else None
+    sec, loss, trace, per_step_ms = timed_steps(wl, args.lr, args.steps, args.warmup, barrier, per_step=True)
+    state_after = device_state(sol_amd, dev) if (rank == 0 and not args.no_device_state) else None
     tsec = torch.tensor([sec], dtype=torch.float64, device=dev)
     rank_ms = [sec / args.steps * 1e3]
     if world > 1:
@@ -540,6 +713,8 @@ def main():
             "metric": "sim-steps/s, SOL-32 training (karman-2d 128x64, fwd+bwd+Adam)",
             "value": value, "unit": "sim-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            # the distribution of the K timed steps (HIP events around every step, no synchronisation added) and the clock the box held
+            "ms_per_step_median": _quantile(per_step_ms, 0.5), "ms_per_step_p10": _quantile(per_step_ms, 0.1), "ms_per_step_p90": _quantile(per_step_ms, 0.9),
             # the two reference-width companions of the headline arithmetic FIRST (filled in below): the same step with true 24-bit operand
             # splits (bf16x6) and with every convolution on v_mfma_f32_*_f32 (strict fp32)
             "bf16x6_ms_per_step": None,
@@ -550,17 +725,23 @@ def main():
             # ... and the other shapes of the same path that the extras time (filled in below): the reference's own recipe (64x32, B = 3,
             # SOL-32), the no-grad roll-out at B = 1 and at the bench batch, one karman-3d SOL-16 step
             "recipe_64x32_b3_ms_per_step": None, "rollout_b1_us_per_step": None, "rollout_b6_us_per_step": None, "karman3d_sol16_ms_per_step": None,
+            "burgers_non_ms_per_step": None, "burgers_sol04_ms_per_step": None,
             "valid": bool(valid), "rank_skew": rank_skew, "pre_warmup_steps": max(0, args.prewarm),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "scaling_status": ("this line is the N = %d point of a weak-scaling series (6 simulations per GPU); the driver computes the curve from its own "
                                "N = 1, 2, 4, 8 runs.  No N > 1 run on separate GPUs had executed when this file was committed (no multi-GPU node in "
-                               "rounds 1-5): the 1 -> 8 curve is UNMEASURED, nothing is extrapolated here; tools/scale.sh runs the four points + the "
+                               "rounds 1-6): the 1 -> 8 curve is UNMEASURED, nothing is extrapolated here; tools/scale.sh runs the four points + the "
                                "DESIGN.md section 6 checklist on a node that has them" % world),
             "dtype": {"split": "f32 (fp16x3 split MFMA in 32-ch convs)", "bf16x6": "f32 (bf16x6 split MFMA in 32-ch convs)", "fp32": "f32"}[args.precision],
             "data": "synthetic",
             "dtype_note": "fp32 tensors and fp32 accumulation everywhere; with precision=split the 32-channel convolutions evaluate each fp32 "
-                          "product as three exact fp16 MFMA products of power-of-two scaled 22-bit operand splits (error vs float64 <= the fp32-MFMA "
-                          "kernel's, tests/test_gpu_parity.py::test_split_conv_relative_l2_not_worse_than_fp32_mfma); strict_fp32 = same step on v_mfma_f32_*_f32",
+                          "product as three exact fp16 MFMA products of power-of-two scaled 22-bit operand splits (single convolution: error vs float64 <= the "
+                          "fp32-MFMA kernel's, tests/test_gpu_parity.py::test_split_conv_relative_l2_not_worse_than_fp32_mfma); strict_fp32 = same step on "
+                          "v_mfma_f32_*_f32.  AT THIS WORKLOAD (C3, float64 fixture; precision_at_c3 below): final fields equal to the strict trainer's error, "
+                          "per-step losses / gradient %s -- the weights' two-fp16-plane representation (<= 2^-23 relative, a fixed perturbation of "
+                          "the network), not the arithmetic: test_sol32_split_trainer_equals_strict_fp32_on_weights_representable_in_two_fp16_planes"
+                          % precision_note(),
+            "precision_at_c3": load_precision(),
             "config": {"workload": "karman-2d %dx%d SOL-%d, batch %d Re values per GPU (BASELINE configs[2])" % (Y, X, ms, B),
                        "global_batch": world * B, "msteps": ms, "parallelism": "dp%d" % world, "lr": args.lr},
             "workload_deviations_from_survey_8d": [
@@ -570,9 +751,12 @@ def main():
                 "output layer of the Glorot-initialised corrector scaled by 0.01",
                 "lr = %g instead of 1e-4: at 1e-4 this synthetic workload diverges (loss 2386 -> 118280 -> 11701 -> ... -> NaN after ~10 steps, "
                 "float64 oracle agrees: tests/golden/train_128x64_sol32.npz)" % args.lr,
-                "time = wall clock over the K timed steps / K (barrier + synchronize on both sides), not the median of per-step events",
+                "value / ms_per_step = wall clock over the K timed steps / K (barrier + synchronize on both sides); the median and the p10 / p90 of "
+                "per-step HIP events are printed beside it (ms_per_step_median, step_time_distribution_ms)",
             ],
             "loss": loss, "loss_warmup": trace,
+            "step_time_distribution_ms": step_distribution(per_step_ms),
+            "device_state_before": state_before, "device_state_after": state_after,
             "roofline": roof_conv if roof_conv and (not roof_solver or cst["total_us"] >= sst["total_us"]) else roof_solver,
             "roofline_solver_step": roof_solver,
             "roofline_conv": dict(roof_conv) if roof_conv else None,
@@ -588,6 +772,7 @@ def main():
                                      "conv_flop_per_train_step": 3.0 * 520000.0 * N * B * ms,
                                      "conv_fp32_equiv_TFLOPs_of_step": 3.0 * 520000.0 * N * B * ms / (ms_per_step * 1e-3) / 1e12},
             "data_parallel": dp,
+            "cpu_affinity": {k: v for k, v in (sol_amd.dist.AFFINITY or {}).items() if k != "inherited"} or None,
         }
         if out["roofline"] is roof_conv and roof_solver:     # the north star's second roofline, inside the object the driver's `parsed` keeps
             out["roofline"]["solver_step"] = {"kernel": sname, "bound": "hbm", "frac": roof_solver["frac"], "achieved_GBps": roof_solver["achieved"],
@@ -685,6 +870,13 @@ def main():
             out["recipe_64x32_b3_ms_per_step"] = out.get("reference_recipe_64x32_b3", {}).get("ms_per_step")
             out["rollout_b1_us_per_step"] = out["rollout"].get("b1", {}).get("us_per_step")
             out["rollout_b6_us_per_step"] = out["rollout"].get("b6", {}).get("us_per_step")
+        if extras:
+            try:
+                out["burgers"] = burgers_leg(sol_amd, dev)
+            except Exception as e:
+                out["burgers"] = {"error": str(e)}
+            out["burgers_non_ms_per_step"] = (out["burgers"].get("non_m1") or {}).get("ms_per_step")
+            out["burgers_sol04_ms_per_step"] = (out["burgers"].get("sol04_m4") or {}).get("ms_per_step")
         if extras:
             try:
                 out["karman3d"] = karman3d_leg(sol_amd, dev)

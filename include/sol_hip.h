@@ -317,6 +317,10 @@ int sol_train_graph_destroy(sol_train_graph* graph);
 /*   sol_copy_words    dst[0..nwords) = src[0..nwords) (32-bit words; src NULL: zero fill) as ONE KERNEL launch: the copy a host uses inside
  *                     a stream capture instead of hipMemcpyAsync / hipMemsetAsync (torch: tensor.copy_ / clone() of a contiguous tensor).   */
 int sol_copy_words(void* stream, void* dst, const void* src, int64_t nwords);
+/*   sol_clock_probe   measurement aid (bench.py): every SIMD runs a chain of `iters` dependent v_mfma_f32_16x16x16_f16; out4 (device) =
+ *                     {duration in 10 ns ticks (s_memrealtime), duration in s_memtime ticks, iters, 0}.  ns per dependent MFMA follows
+ *                     the engine clock the device holds under matrix load: it tells a slow box from a slower kernel.                  */
+int sol_clock_probe(void* stream, uint64_t* out4, int32_t iters);
 int sol_graph_census(void* graph, int32_t* counts, int32_t ncounts);
 int sol_graph_check(void* graph, const char* what);
 const char* sol_graph_node_type_name(int32_t type);

@@ -85,6 +85,7 @@ _SIGS = {
     "sol_train_graph_launch": (C.c_int, [_P, _P]),
     "sol_train_graph_destroy": (C.c_int, [_P]),
     "sol_copy_words": (C.c_int, [_P, _P, _P, C.c_int64]),
+    "sol_clock_probe": (C.c_int, [_P, _P, C.c_int32]),
     "sol_graph_census": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32]),
     "sol_graph_check": (C.c_int, [_P, C.c_char_p]),
     "sol_graph_node_type_name": (C.c_char_p, [C.c_int32]),
@@ -127,7 +128,7 @@ def lib_path():
     return _build.LIB
 
 
-ABI_VERSION = 211     # sol_version() of the library these bindings were written against
+ABI_VERSION = 212     # sol_version() of the library these bindings were written against
 
 # Debugging overrides: environment variable -> (option, value).  Read ONCE here, in Python, when the library is loaded;
 # the library itself never reads the environment (options are set through sol_set_option, include/sol_hip.h).
@@ -243,9 +244,13 @@ def dcopy_(dst, src):
     contiguous tensor is a hipMemcpyAsync, i.e. a MEMCPY NODE in a captured graph, which sol_graph_check refuses.  Returns dst."""
     if dst.numel() != src.numel() or dst.dtype != src.dtype:
         raise SolError("dcopy_: %s %s <- %s %s" % (tuple(dst.shape), dst.dtype, tuple(src.shape), src.dtype))
+    if dst.dtype not in (torch.float32, torch.int32) or not (dst.is_cuda and src.is_cuda):
+        # checked HERE, not by ptr() in the middle of a stream capture
+        raise SolError("dcopy_: 32-bit (float32 / int32) CUDA tensors only (got %s on %s <- %s on %s)" % (dst.dtype, dst.device, src.dtype, src.device))
     src = src.detach()
     if not (dst.is_contiguous() and src.is_contiguous()):
-        dst.copy_(src)                       # a strided copy is an elementwise kernel already
+        # a strided copy is an elementwise kernel already; equal numel with different shapes means "the same words", as in the kernel form
+        dst.copy_(src if src.shape == dst.shape else src.reshape(dst.shape))
         return dst
     check(load().sol_copy_words(stream(), ptr(dst), ptr(src), dst.numel()))
     return dst
@@ -281,6 +286,9 @@ def graph_census(raw_graph):
     return {lib.sol_graph_node_type_name(t).decode(): int(counts[t]) for t in range(32) if counts[t]}
 
 
+MIN_TORCH_FOR_CAPTURE = "2.8"
+
+
 def capture_graph(fn, what):
     """Capture `fn()` (launches on torch's current stream) into a torch CUDAGraph and return it, instantiated -- THE way this package
     captures torch-composed work (GraphTrainer, BurgersTrainer, BurgersRollout, Karman3DTrainer).  The captured graph is passed through
@@ -288,7 +296,15 @@ def capture_graph(fn, what):
     clear or a torch.zeros() inside the capture; a memcpy node = data staged inside the replayed region) raises SolError naming the node
     types.  Memset nodes replay unreliably on ROCm 7.2 (per-step losses 0.5x / 2x the true values after a few
     replays); with this guard that defect class is refused at capture time instead of being tested for after the fact."""
-    g = torch.cuda.CUDAGraph(keep_graph=True)
+    try:
+        g = torch.cuda.CUDAGraph(keep_graph=True)
+        if not (hasattr(g, "raw_cuda_graph") and hasattr(g, "instantiate")):
+            raise TypeError("CUDAGraph lacks raw_cuda_graph() / instantiate()")
+    except TypeError as e:
+        # keep_graph / raw_cuda_graph / instantiate exist from torch 2.8 on; without them the captured graph cannot be inspected before it
+        # is instantiated, and an unchecked capture is exactly what this function exists to refuse
+        raise SolError("capturing %s needs torch >= %s (torch.cuda.CUDAGraph(keep_graph=True), raw_cuda_graph(), instantiate()); this is torch %s "
+                       "(%s).  Run the trainer with use_graph=False, or upgrade torch." % (what, MIN_TORCH_FOR_CAPTURE, torch.__version__, e))
     with no_gc_during_capture(), torch.cuda.graph(g):
         fn()
     try:

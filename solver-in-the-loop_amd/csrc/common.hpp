@@ -52,6 +52,8 @@ struct ConvArgs {
     float ls0, ls1;                 // loss scale (std_v)
     unsigned long long* closs;      // exact accumulator ([SOL_LOSS_ACC_WORDS], loss_add_exact) of 0.5 * sum(((gt - v) / std)^2) over ALL faces, or NULL
     int ctr;                        // 1: the CNN runs on the transposed grid -- image row = the solver's x index, pixel = its y index (velocity [B,W+1,H] / [B,W,H+1])
+    int CI;                         // input channels per pixel of x as the caller declared them (0: not stated).  Kernels that read a fixed number of
+                                    // channels per pixel whatever the caller meant (k_conv5x5_thin32: eight float4 = 32) check it before they are chosen
 };
 // correction mode: offsets of the faces of CNN pixel (image row jj, pixel px) inside a simulation's v_y / v_x, and of the face without
 // a correction that this pixel also owns for the loss (v_y row Y, v_x column X of the SOLVER grid), or -1

@@ -1042,7 +1042,7 @@ static int conv_impl(void* stream, const float* x, const float* packed, const fl
     if (int e = sol_init_conv_kernels()) return e;
     ConvArgs a{};
     a.x = x; a.wp = packed; a.bias = bias; a.res = residual; a.act = act_ref; a.y = y;
-    a.B = B; a.H = H; a.W = W; a.CO = cout; a.epi = epilogue; a.slope = slope;
+    a.B = B; a.H = H; a.W = W; a.CO = cout; a.CI = cin; a.epi = epilogue; a.slope = slope;
     a.TW = W < 64 ? W : 64;
     a.RPW = 64 / a.TW;
     a.tiles_x = W / a.TW;
@@ -1114,7 +1114,7 @@ int sol_conv5x5_correct(void* stream, const float* x, const float* packed, const
     SOL_REQUIRE(!loss_acc || gt_vy, "sol_conv5x5_correct: a loss accumulator needs the ground-truth frames");
     if (int e = sol_init_conv_kernels()) return e;
     ConvArgs a{};
-    a.x = x; a.wp = packed; a.bias = bias; a.B = B; a.H = H; a.W = W; a.CO = 2; a.epi = SOL_EPI_NONE;
+    a.x = x; a.wp = packed; a.bias = bias; a.B = B; a.H = H; a.W = W; a.CO = 2; a.CI = 32; a.epi = SOL_EPI_NONE;
     a.TW = 64; a.RPW = 1; a.tiles_x = W / 64;
     a.wsb = packed + (size_t)25 * 32 * pad_out(2);
     a.wsh = packed + (size_t)25 * 32 * pad_out(2) + sol_conv_sb_packed_floats(pad_out(2));

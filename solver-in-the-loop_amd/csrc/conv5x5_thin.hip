@@ -178,11 +178,14 @@ __global__ void __launch_bounds__(NW * 64) k_conv5x5_thin32(ConvArgs a, int nrow
 // activation (the two thin layers of the trainer), option conv_thin_valu (default 1).  Everything else stays on k_conv5x5_sb<1, KIND> /
 // the thin form of the dx kernel.
 bool sol_conv_thin32_usable(const ConvArgs& a, int NT) {
-    return sol_opt().conv_thin_valu && NT == 1 && a.CO >= 1 && a.CO <= 4 && a.W == 64 && a.tiles_x == 1 && !a.res && a.epi == SOL_EPI_NONE && a.wp &&
+    // a.CI == 32: the kernel reads eight float4 per pixel and a [tap][16][32] fp32 weight section unconditionally (a caller with another
+    // channel count -- none exists today: sol_conv_sb_launch is reached with 32 input channels only -- must not end up here)
+    return sol_opt().conv_thin_valu && NT == 1 && a.CI == 32 && a.CO >= 1 && a.CO <= 4 && a.W == 64 && a.tiles_x == 1 && !a.res && a.epi == SOL_EPI_NONE && a.wp &&
            (!a.cvy || a.CO == 2);
 }
 
 int sol_conv_thin32_launch(hipStream_t s, const ConvArgs& a, int ntiles) {
+    SOL_REQUIRE(a.CI == 32 && a.W == 64 && a.CO >= 1 && a.CO <= 4 && a.wp, "k_conv5x5_thin32: 32 input channels, 64-pixel rows, <= 4 output channels (got %d, %d, %d)", a.CI, a.W, a.CO);
     static std::atomic<unsigned long long> optin{0};
     if (int e = sol_lds_optin(optin, {SOL_K((k_conv5x5_thin32<2, 16>)), SOL_K((k_conv5x5_thin32<4, 16>)), SOL_K((k_conv5x5_thin32<2, 8>)), SOL_K((k_conv5x5_thin32<4, 8>))}, "k_conv5x5_thin32")) return e;
     const int nrows = ntiles;                             // tiles_x == 1: one tile per image row

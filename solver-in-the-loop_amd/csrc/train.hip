@@ -20,7 +20,7 @@ int sol_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* sol_last_error(void) { return g_sol_err; }
-extern "C" int sol_version(void) { return 211; }
+extern "C" int sol_version(void) { return 212; }
 // sizes of the ABI structs: the ctypes mirror in _lib.py checks them at load time
 extern "C" int sol_abi_sizes(int32_t* karman_cfg, int32_t* burgers_cfg, int32_t* train_cfg) {
     if (karman_cfg) *karman_cfg = (int32_t)sizeof(sol_karman_cfg);
@@ -274,6 +274,34 @@ extern "C" int sol_copy_words(void* stream, void* dst, const void* src, int64_t 
     MemList m;
     m.copy(dst, src, (size_t)nwords * 4);
     return m.launch((hipStream_t)stream);
+}
+namespace {
+// ---- clock probe (bench.py: is THIS box slow, or did the kernels get slower?) ----------------------------------------------------
+// Every SIMD of the chip runs one wave with a chain of `iters` DEPENDENT v_mfma_f32_16x16x16_f16 (a fixed number of matrix-pipe cycles
+// per instruction whatever the operands are; the operands are non-trivial so that the power state is the one a convolution sees).
+// Workgroup 0 reports the chain's duration on the constant 100 MHz clock (s_memrealtime) and on s_memtime, so that the host can quote
+// ns per dependent MFMA -- a number that moves with the engine clock the box actually holds under matrix load and with nothing else.
+typedef _Float16 probe_h4 __attribute__((ext_vector_type(4)));
+typedef float probe_f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_clock_probe(unsigned long long* out, int iters, float seed) {
+    const int lane = threadIdx.x & 63;
+    probe_h4 a = {(_Float16)(0.5f + 0.001f * lane), (_Float16)(seed), (_Float16)(-0.25f), (_Float16)(0.125f * (lane & 3))};
+    probe_h4 b = {(_Float16)(1.0f - 0.002f * lane), (_Float16)(0.75f), (_Float16)(seed * 0.5f), (_Float16)(-0.5f)};
+    probe_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const unsigned long long t0 = wall_clock64(), c0 = clock64();
+#pragma unroll 8
+    for (int i = 0; i < iters; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, acc, 0, 0, 0);
+    const unsigned long long t1 = wall_clock64(), c1 = clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = t1 - t0; out[1] = c1 - c0; out[2] = (unsigned long long)iters; }
+    if (acc[0] == 1.2345e-30f) out[3] = 1;      // never true: keeps the chain alive
+}
+}  // namespace
+extern "C" int sol_clock_probe(void* stream, uint64_t* out4, int32_t iters) {
+    SOL_REQUIRE(out4 && iters >= 1 && iters <= (1 << 24), "sol_clock_probe: out4 (device, four 64-bit words), 1 <= iters <= 2^24");
+    SOL_LAUNCH(k_clock_probe, dim3(256), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(out4), iters, 0.3f);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
 }
 namespace {
 
@@ -890,6 +918,60 @@ extern "C" int sol_graph_census(void* graph, int32_t* counts, int32_t ncounts) {
 
 extern "C" const char* sol_graph_node_type_name(int32_t type) { return graph_node_type_name((hipGraphNodeType)type); }
 
+// Text for sol_graph_check: the first few refused nodes of `g` -- child graphs entered, like the census -- each with the node before and
+// after it ("memcpy after <kernel> before <kernel>").  Edge lists are sized by a count query (NULL array) first.
+static void graph_node_label(hipGraphNode_t nd, char* out, size_t cap) {
+    hipGraphNodeType t;
+    out[0] = 0;
+    if (hipGraphNodeGetType(nd, &t) != hipSuccess) return;
+    if (t == hipGraphNodeTypeKernel) {
+        hipKernelNodeParams kp;
+        const char* nm = nullptr;
+        if (hipGraphKernelNodeGetParams(nd, &kp) == hipSuccess && kp.func) nm = hipKernelNameRefByPtr(kp.func, nullptr);
+        snprintf(out, cap, "%.60s", nm ? nm : "kernel");
+    } else snprintf(out, cap, "%s", graph_node_type_name(t));
+}
+static bool graph_node_refused(hipGraphNodeType t) {
+    return t == hipGraphNodeTypeMemset || t == hipGraphNodeTypeMemcpy || t == hipGraphNodeTypeMemcpyFromSymbol || t == hipGraphNodeTypeMemcpyToSymbol ||
+           t == hipGraphNodeTypeHost || t == hipGraphNodeTypeMemAlloc || t == hipGraphNodeTypeMemFree;
+}
+static void graph_offenders(hipGraph_t g, char* det, size_t cap, size_t& dl, int& shown, int depth) {
+    size_t n = 0;
+    if (depth > 8 || hipGraphGetNodes(g, nullptr, &n) != hipSuccess || !n) return;
+    std::vector<hipGraphNode_t> nodes(n);
+    if (hipGraphGetNodes(g, nodes.data(), &n) != hipSuccess) return;
+    for (size_t i = 0; i < n && shown < 4 && dl + 160 < cap; ++i) {
+        hipGraphNodeType t;
+        if (hipGraphNodeGetType(nodes[i], &t) != hipSuccess) return;
+        if (t == hipGraphNodeTypeGraph) {
+            hipGraph_t child = nullptr;
+            if (hipGraphChildGraphNodeGetGraph(nodes[i], &child) == hipSuccess && child) graph_offenders(child, det, cap, dl, shown, depth + 1);
+            continue;
+        }
+        if (!graph_node_refused(t)) continue;
+        char before[64] = "", after[64] = "";
+        size_t k = 0;
+        if (hipGraphNodeGetDependencies(nodes[i], nullptr, &k) == hipSuccess && k) {
+            std::vector<hipGraphNode_t> nb(k);
+            if (hipGraphNodeGetDependencies(nodes[i], nb.data(), &k) == hipSuccess && k) graph_node_label(nb[0], before, sizeof(before));
+        }
+        k = 0;
+        if (hipGraphNodeGetDependentNodes(nodes[i], nullptr, &k) == hipSuccess && k) {
+            std::vector<hipGraphNode_t> nb(k);
+            if (hipGraphNodeGetDependentNodes(nodes[i], nb.data(), &k) == hipSuccess && k) graph_node_label(nb[0], after, sizeof(after));
+        }
+        size_t bytes = 0;
+        if (t == hipGraphNodeTypeMemset) {
+            hipMemsetParams mp;
+            if (hipGraphMemsetNodeGetParams(nodes[i], &mp) == hipSuccess) bytes = mp.width * (mp.height ? mp.height : 1) * mp.elementSize;
+        }
+        dl += (size_t)snprintf(det + dl, cap - dl, "%s%s%s", shown++ ? "; " : "", graph_node_type_name(t), depth ? " (in a child graph)" : "");
+        if (bytes && dl < cap) dl += (size_t)snprintf(det + dl, cap - dl, " of %zu B", bytes);
+        if (dl < cap) dl += (size_t)snprintf(det + dl, cap - dl, " after '%s' before '%s'", before[0] ? before : "-", after[0] ? after : "-");
+        if (dl >= cap) dl = cap - 1;
+    }
+}
+
 extern "C" int sol_graph_check(void* graph, const char* what) {
     SOL_REQUIRE(graph != nullptr, "sol_graph_check: NULL graph");
     int32_t counts[32];
@@ -910,49 +992,11 @@ extern "C" int sol_graph_check(void* graph, const char* what) {
     if (bad) {
         // the first few offenders with their neighbours in the graph ("memcpy after <kernel> before <kernel>"): that is what locates
         // the host line -- the copy follows the kernel that produced its source and precedes the first consumer of its destination
-        size_t n = 0;
         char det[600];
         size_t dl = 0;
+        int shown = 0;
         det[0] = 0;
-        auto kname = [](hipGraphNode_t nd, char* out, size_t cap) {
-            hipGraphNodeType t;
-            out[0] = 0;
-            if (hipGraphNodeGetType(nd, &t) != hipSuccess) return;
-            if (t == hipGraphNodeTypeKernel) {
-                hipKernelNodeParams kp;
-                const char* nm = nullptr;
-                if (hipGraphKernelNodeGetParams(nd, &kp) == hipSuccess && kp.func) nm = hipKernelNameRefByPtr(kp.func, nullptr);
-                snprintf(out, cap, "%.60s", nm ? nm : "kernel");
-            } else snprintf(out, cap, "%s", graph_node_type_name(t));
-        };
-        if (hipGraphGetNodes((hipGraph_t)graph, nullptr, &n) == hipSuccess && n) {
-            hipGraphNode_t* nodes = new hipGraphNode_t[n];
-            if (hipGraphGetNodes((hipGraph_t)graph, nodes, &n) == hipSuccess) {
-                int shown = 0;
-                for (size_t i = 0; i < n && shown < 4 && dl + 160 < sizeof(det); ++i) {
-                    hipGraphNodeType t;
-                    if (hipGraphNodeGetType(nodes[i], &t) != hipSuccess) break;
-                    bool off = false;
-                    for (hipGraphNodeType r : refused) off = off || r == t;
-                    if (!off) continue;
-                    char before[64] = "", after[64] = "";
-                    hipGraphNode_t nb[4];
-                    size_t k = 4;
-                    if (hipGraphNodeGetDependencies(nodes[i], nb, &k) == hipSuccess && k) kname(nb[0], before, sizeof(before));
-                    k = 4;
-                    if (hipGraphNodeGetDependentNodes(nodes[i], nb, &k) == hipSuccess && k) kname(nb[0], after, sizeof(after));
-                    size_t bytes = 0;
-                    if (t == hipGraphNodeTypeMemset) {
-                        hipMemsetParams mp;
-                        if (hipGraphMemsetNodeGetParams(nodes[i], &mp) == hipSuccess) bytes = mp.width * (mp.height ? mp.height : 1) * mp.elementSize;
-                    }
-                    dl += (size_t)snprintf(det + dl, sizeof(det) - dl, "%s%s", shown++ ? "; " : "", graph_node_type_name(t));
-                    if (bytes) dl += (size_t)snprintf(det + dl, sizeof(det) - dl, " of %zu B", bytes);
-                    dl += (size_t)snprintf(det + dl, sizeof(det) - dl, " after '%s' before '%s'", before[0] ? before : "-", after[0] ? after : "-");
-                }
-            }
-            delete[] nodes;
-        }
+        graph_offenders((hipGraph_t)graph, det, sizeof(det), dl, shown, 0);
         return sol_set_error(SOL_ERR_GRAPH, "%s: the captured graph holds %s node(s) among %d kernel nodes [first: %s] -- only kernel nodes replay reliably on this "
                              "path (a memset node is what a multi-workgroup torch reduction or torch.zeros() inside the capture leaves behind: use the "
                              "library's kernels -- ops.L2LossFn for the loss, _lib.dcopy_ / _lib.dclone for copies -- or allocate and clear before the capture)",

@@ -13,12 +13,88 @@ import torch
 import torch.distributed as dist
 
 
+AFFINITY = None        # what bind_cpu_affinity did for this process (bench.py prints it)
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_node(device_index, sysfs="/sys"):
+    """NUMA node of the GPU `device_index` (torch's numbering) from /sys/class/drm/card*/device/numa_node, matched by PCI address;
+    None when sysfs has no answer (no amdgpu cards visible, node -1 = the platform does not say)."""
+    import glob
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        return None
+    for c in sorted(glob.glob(os.path.join(sysfs, "class/drm/card[0-9]*/device"))):
+        if want in os.path.realpath(c):
+            try:
+                with open(os.path.join(c, "numa_node")) as f:
+                    n = int(f.read().strip())
+                return n if n >= 0 else None
+            except (OSError, ValueError):
+                return None
+    return None
+
+
+def bind_cpu_affinity(device_index, local_rank=0, local_world=1, sysfs="/sys"):
+    """Pin this process to the CPUs of its GPU's NUMA node (os.sched_setaffinity): with a 12 ms step and a host-issued all-reduce + Adam
+    between two graph replays, a rank whose launcher thread migrates to the other socket shows up as rank skew.
+    Ranks that share a node split its CPUs evenly among themselves (local_rank / local_world).  Does nothing -- and says so -- when the
+    platform gives no NUMA node, when the intersection with the inherited mask is empty, or when SOL_NO_AFFINITY is set.
+    Returns a record {"numa_node", "cpus", "bound", "why"}; also kept in dist.AFFINITY."""
+    global AFFINITY
+    rec = {"numa_node": None, "cpus": None, "bound": False, "why": "", "inherited": None}
+    try:
+        if hasattr(os, "sched_getaffinity"):
+            rec["inherited"] = sorted(os.sched_getaffinity(0))      # (bench.py's CPU baseline puts this mask back for its host threads)
+        if os.environ.get("SOL_NO_AFFINITY"):
+            rec["why"] = "SOL_NO_AFFINITY set"
+        elif not hasattr(os, "sched_setaffinity"):
+            rec["why"] = "no sched_setaffinity on this platform"
+        else:
+            node = gpu_numa_node(device_index, sysfs)
+            rec["numa_node"] = node
+            if node is None:
+                rec["why"] = "sysfs gives no NUMA node for device %d" % device_index
+            else:
+                with open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)) as f:
+                    cpus = sorted(_parse_cpulist(f.read()) & set(os.sched_getaffinity(0)))
+                if local_world > 1 and len(cpus) >= 2 * local_world:
+                    per = len(cpus) // local_world
+                    cpus = cpus[(local_rank % local_world) * per:(local_rank % local_world + 1) * per]
+                if not cpus:
+                    rec["why"] = "the node's CPUs are outside the inherited affinity mask"
+                else:
+                    os.sched_setaffinity(0, cpus)
+                    rec.update(cpus="%d-%d (%d)" % (cpus[0], cpus[-1], len(cpus)), bound=True)
+    except Exception as e:          # never let a binding problem stop a run
+        rec["why"] = "failed: %s" % e
+    AFFINITY = rec
+    return rec
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract).
-    Returns (rank, world_size, local_rank).  No-op for single-process runs."""
+    Returns (rank, world_size, local_rank).  No-op for single-process runs (except the CPU binding of a GPU process)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available() and AFFINITY is None:
+        ndev = torch.cuda.device_count()
+        lw = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        # ranks that share a NUMA node split it; the split is by local rank among ALL local ranks (a conservative partition: at most
+        # local_world slices per node), only when there is more than one rank
+        bind_cpu_affinity(local % ndev, local, lw if world > 1 else 1)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

@@ -341,15 +341,24 @@ def conv3d_bwd_weight(xk, dz, cin, cout, xmax=None, zmax=None, acc=None):
     co_k = cout if cout in (2, 32) else 32                 # the 2-D weight-gradient kernels take 2 or 32 output channels
     dzk = _pad_ch(dz, co_k)
     dev = xk.device
+    shape_key = (B, D, H, W, cin_k, co_k, cin, str(dev))
     if acc is not None and "part" in acc[0]:
+        # the partial sums of a reverse sweep live in the caller's state dict: they belong to ONE shape and to a sequence that was opened
+        # with first=True (the C entry point cannot see the size of `partial`, so a mismatch would overrun it or add onto stale sums)
+        if acc[0].get("shape") != shape_key:
+            raise _lib.SolError("conv3d_bwd_weight: the accumulation state was allocated for %s, this call has %s" % (acc[0].get("shape"), shape_key))
+        if not acc[1] and not acc[0].get("open"):
+            raise _lib.SolError("conv3d_bwd_weight: first=False on a state whose sequence is not open (the previous sweep ended with last=True)")
         part, dW, db, scratch = (acc[0][k] for k in ("part", "dW", "db", "scratch"))
     else:
+        if acc is not None and not acc[1]:
+            raise _lib.SolError("conv3d_bwd_weight: the first call on a fresh accumulation state must have first=True (nothing to add onto yet)")
         part = torch.empty(lib.sol_conv3d_bwd_weight_ws_floats(B, D, H, W, cin_k, co_k), dtype=torch.float32, device=dev)
         dW = torch.empty(5, 5, 5, cin, co_k, dtype=torch.float32, device=dev)
         db = torch.empty(co_k, dtype=torch.float32, device=dev)
         scratch = torch.empty(5 * co_k, dtype=torch.float32, device=dev)
         if acc is not None:
-            acc[0].update(part=part, dW=dW, db=db, scratch=scratch)
+            acc[0].update(part=part, dW=dW, db=db, scratch=scratch, shape=shape_key)
     both32 = cin_k == 32 and co_k == 32
     # (the slot tensors must outlive the call: a temporary inside ptr(...) is freed -- and its block handed to the next
     # allocation -- before the launch is even enqueued)
@@ -358,6 +367,7 @@ def conv3d_bwd_weight(xk, dz, cin, cout, xmax=None, zmax=None, acc=None):
     zmax = (zmax if zmax is not None and dzk is dz else _absmax(dzk)) if both32 else None
     if acc is not None:
         _, first, last = acc
+        acc[0]["open"] = not last
         check(lib.sol_conv3d_bwd_weight_acc(stream(), ptr(xk), ptr(dzk), ptr(xmax), ptr(zmax), ptr(part), ptr(dW), ptr(db), ptr(scratch),
                                             B, D, H, W, cin_k, co_k, cin, co_k, 0 if first else 1, 1 if last else 0))
         if not last:

@@ -329,6 +329,28 @@ def test_conv3d_gradients_against_oracle(shape, cin, cout, res, lrelu):
         assert rel(hr.grad, r.grad) < 5e-6
 
 
+def test_conv3d_weight_gradient_accumulation_state_is_checked():
+    """conv3d_bwd_weight(acc=(state, first, last)) keeps a layer's partial sums in the caller's state dict across the calls of a reverse
+    sweep; the C entry point cannot see the size of `partial`, so the Python wrapper refuses a state reused with another shape, a fresh
+    state that does not start with first=True, and a continuation of a sequence that was closed -- and the legal sequence
+    (first .. last) sums exactly like two single calls."""
+    gen = torch.Generator().manual_seed(3)
+    B, D, H, W = 1, 6, 8, 64
+    x = torch.randn(B, D, H, W, 32, generator=gen, dtype=torch.float32).to(DEV)
+    dz = [(torch.randn(B, D, H, W, 32, generator=gen, dtype=torch.float32) * 1e-2).to(DEV) for _ in range(2)]
+    st = {}
+    with pytest.raises(sol_amd._lib.SolError, match="first=True"):
+        k3.conv3d_bwd_weight(x, dz[0], 32, 32, acc=(st, False, False))
+    assert k3.conv3d_bwd_weight(x, dz[0], 32, 32, acc=(st, True, False)) == (None, None)
+    with pytest.raises(sol_amd._lib.SolError, match="allocated for"):
+        k3.conv3d_bwd_weight(x[:, :4].contiguous(), dz[0][:, :4].contiguous(), 32, 32, acc=(st, False, True))
+    dW, db = k3.conv3d_bwd_weight(x, dz[1], 32, 32, acc=(st, False, True))
+    with pytest.raises(sol_amd._lib.SolError, match="not open"):
+        k3.conv3d_bwd_weight(x, dz[1], 32, 32, acc=(st, False, True))
+    ref = [k3.conv3d_bwd_weight(x, d, 32, 32) for d in dz]
+    assert rel(dW, ref[0][0].double() + ref[1][0].double()) < 2e-6 and rel(db, ref[0][1].double() + ref[1][1].double()) < 2e-6
+
+
 @pytest.mark.parametrize("cout,res,mode", [(32, True, "lrelu"), (32, True, "dlrelu"), (3, False, "none"), (4, False, "none")])
 def test_conv3d_full_size_one_launch_against_five_pass_and_shift_property(cout, res, mode):
     """BASELINE configs[4] size (128 x 64 x 64, all 1 024 workgroups and every XCD tile mapping of the one-launch kernel): (i) the

@@ -1062,6 +1062,117 @@ def test_sol32_bench_workload_against_golden(golden_dir, precision):
     assert np.allclose(traj, z["loss_traj"], rtol=5e-5), (traj, z["loss_traj"])
 
 
+C3_FIELD_ALLOWANCE = 1.25          # final velocity / density: err(split) <= 1.25 err(fp32), err(bf16x6) <= 1.25 err(fp32) (round-5 verdict, "next round" 2)
+C3_LOSS_GRAD_ENVELOPE = 3.0        # per-step losses / gradient: measured 1.86x / 2.26x (fp16x3), 1.30x / 1.53x (bf16x6) of the strict trainer's 2.7e-7 / 1.7e-7
+C3_LOSS_GRAD_ABS = 1e-6            # ... and in absolute terms 10x / 100x inside the tolerances (1e-5 fields, 1e-4 gradients)
+
+
+def round_to_two_fp16_planes(t):
+    """w -> (g1 + g2 / 2048) / 2^s with g1 = fp16(w 2^s), g2 = fp16((w 2^s - g1) 2048): what the split kernels' weight packing keeps of an fp32
+    weight (relative error <= 2^-23, i.e. at most the distance to the NEIGHBOURING fp32 number; the power-of-two scale does not change it)."""
+    t = t.detach().double()
+    s = 2.0 ** (14 - int(np.floor(np.log2(float(t.abs().max())))))
+    ws = (t * s).float()
+    g1 = ws.half().float()
+    g2 = ((ws - g1) * 2048.0).half().float()
+    return (g1.double() + g2.double() / 2048.0) / s
+
+
+def _c3_step(golden_dir, precision, round_weights=False):
+    """ONE first training step of the C3 workload (B=6, 128x64, SOL-32, replayed hipGraph) in the given convolution arithmetic: the trainer
+    (loss_steps, grads, final) and the fixture.  round_weights: the ten 32 -> 32 kernels replaced by their two-fp16-plane roundings."""
+    z = np.load(os.path.join(golden_dir, "train_128x64_sol32.npz"))
+    B, Y, X, ms = int(z["B"]), int(z["Y"]), int(z["X"]), int(z["msteps"])
+    w = _cached(("sol32", B, Y, X, ms), lambda: o.bench_workload(B, Y, X, ms))
+    params = [p.detach() for p in w["params"]]
+    if round_weights:
+        params = [round_to_two_fp16_planes(p) if (p.dim() == 4 and tuple(p.shape[2:]) == (32, 32)) else p for p in params]
+    net, tr = _trainer_from(params, w["geom"], B, Y, X, ms, w["std_v"], conv_precision=precision)
+    loss = tr.fwd_bwd(f32(w["d0"]), f32(w["vy0"]), f32(w["vx0"]), f32(w["re"]), f32(torch.stack(w["gt_vy"])), f32(torch.stack(w["gt_vx"])),
+                      want_final=True)
+    torch.cuda.synchronize()
+    return z, tr, float(loss)
+
+
+def _c3_errors(golden_dir, precision):
+    """relative-L2 errors of that step against the float64 fixture: final state, the 32 per-step losses, the gradient (every 16th element)"""
+    z, tr, loss = _c3_step(golden_dir, precision)
+    return {"vy_final": rel(tr.final[1], z["vy_final"]), "vx_final": rel(tr.final[2], z["vx_final"]), "d_final": rel(tr.final[0], z["d_final"]),
+            "loss_steps": rel(tr.loss_steps, z["loss_steps"]), "gradient_every_16th": rel(tr.grads[::16], z["grads_sub16"]),
+            "loss": abs(loss - float(z["loss_traj"][0])) / abs(float(z["loss_traj"][0]))}
+
+
+def test_sol32_workload_error_of_each_conv_arithmetic_against_float64(golden_dir):
+    """The WORKLOAD-level form of the precision claim behind the bench line's dtype (reference arithmetic: tf.float32,
+    karman-2d/karman_train.py:376-377): the error against the float64 fixture of the fp16x3 `split` trainer (the headline), the `bf16x6`
+    trainer and the strict fp32-MFMA trainer at the configuration the metric is quoted on (C3: B=6, 128x64, SOL-32, through the replayed
+    graph: 32 solver steps, 384 convolutions, the reverse sweep).  What holds, and is asserted:
+      * final velocity / density: err(split), err(bf16x6) <= 1.25 err(fp32)        (measured 0.94 .. 1.08: the solver's fp32 error dominates)
+      * per-step losses and gradient: every arithmetic <= 1e-6 (tolerances: 1e-5 / 1e-4), but NOT <= 1.25 err(fp32): measured 5.0e-7 /
+        3.8e-7 (fp16x3) and 3.5e-7 / 2.5e-7 (bf16x6) against 2.7e-7 / 1.7e-7 (fp32), i.e. 1.9x / 2.3x and 1.3x / 1.5x.  Bounded here by a
+        regression envelope (3x); WHY is the next test (the weights' two-plane representation), profiles/r06_precision_at_c3.json.
+    (The fixture's fields are stored as fp32: 3e-8 of quantisation under errors of order 1e-7.)  The triples are written to
+    gpurun_out/precision_at_c3.json -> profiles/r06_precision_at_c3.json, which bench.py quotes in its dtype_note."""
+    errs = {p: _c3_errors(golden_dir, p) for p in ("split", "bf16x6", "fp32")}
+    ratios = {p: {k: errs[p][k] / max(errs["fp32"][k], 1e-300) for k in errs[p]} for p in ("split", "bf16x6")}
+    try:
+        import json
+        root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out")
+        os.makedirs(root, exist_ok=True)
+        with open(os.path.join(root, "precision_at_c3.json"), "w") as f:
+            json.dump({"workload": "karman-2d 128x64 SOL-32, B=6, first training step through the replayed hipGraph, vs tests/golden/train_128x64_sol32.npz (float64 oracle)",
+                       "relative_l2_error": errs, "ratio_to_strict_fp32": ratios,
+                       "asserted": {"fields_ratio_max": C3_FIELD_ALLOWANCE, "loss_gradient_ratio_envelope": C3_LOSS_GRAD_ENVELOPE, "loss_gradient_abs_max": C3_LOSS_GRAD_ABS},
+                       "device": torch.cuda.get_device_name(0)}, f, indent=1)
+    except OSError:
+        pass
+    for p in ("split", "bf16x6"):
+        for k in ("vy_final", "vx_final", "d_final"):
+            assert errs[p][k] <= C3_FIELD_ALLOWANCE * errs["fp32"][k], (p, k, errs[p][k], errs["fp32"][k])
+        for k in ("loss_steps", "gradient_every_16th"):
+            assert errs[p][k] <= C3_LOSS_GRAD_ENVELOPE * errs["fp32"][k], (p, k, errs[p][k], errs["fp32"][k])
+    for p in errs:
+        assert max(errs[p]["vy_final"], errs[p]["vx_final"], errs[p]["d_final"]) < TOL_FIELD and errs[p]["gradient_every_16th"] < TOL_GRAD, (p, errs[p])
+        assert errs[p]["loss_steps"] <= C3_LOSS_GRAD_ABS and errs[p]["gradient_every_16th"] <= C3_LOSS_GRAD_ABS, (p, errs[p])
+
+
+def test_sol32_split_trainer_equals_strict_fp32_on_weights_representable_in_two_fp16_planes(golden_dir):
+    """WHY the split trainer's loss / gradient error at C3 is ~2x the strict trainer's although its single convolution is MORE accurate
+    (test_split_conv_relative_l2_not_worse_than_fp32_mfma; tools/conv_bias_probe.py: no coherent gain, |eps| < 4e-9): the split kernels keep
+    a WEIGHT as two fp16 planes, w' = g1 + g2 / 2048 -- a rounding of at most 2^-23 relative, i.e. to a neighbouring fp32 number at worst.
+    Activation roundings differ from pixel to pixel and average out; the weight rounding is ONE fixed perturbation dw of the network, the same
+    at every pixel of all 32 steps, and this workload's loss is very sensitive to the weights (|grad| = 1.06e7 at a loss of 2386; one Adam
+    step at lr 1e-4 takes it to 118279).  Measured (tools/precision_at_c3.py, profiles/r06_precision_diag.txt): rounding the ten 32 -> 32
+    kernels that way moves the STRICT fp32 trainer's per-step losses by +1.0e-7 .. +3.3e-7 -- the whole split-minus-fp32 offset (+1.9e-7 ..
+    +3.3e-7) -- and on such weights the two trainers agree to 1.4e-7 (losses) / 9.7e-8 (gradient) instead of 3.3e-7 / 3.2e-7.
+    Asserted: (a) on representable weights split == strict fp32 within 2.5e-7 per step loss and 2e-7 gradient; (b) with the original
+    weights their distance is at least 1.5x that of (a) -- the representation, not the arithmetic, is what separates them; (c) the strict
+    trainer itself moves by the same amount when only its weights are rounded."""
+    _, tr_s, _ = _c3_step(golden_dir, "split")
+    ls_s, g_s = tr_s.loss_steps.double().cpu().numpy(), tr_s.grads[::16].double().cpu()
+    _, tr_f, _ = _c3_step(golden_dir, "fp32")
+    ls_f, g_f = tr_f.loss_steps.double().cpu().numpy(), tr_f.grads[::16].double().cpu()
+    _, tr_sr, _ = _c3_step(golden_dir, "split", round_weights=True)
+    ls_sr, g_sr = tr_sr.loss_steps.double().cpu().numpy(), tr_sr.grads[::16].double().cpu()
+    _, tr_fr, _ = _c3_step(golden_dir, "fp32", round_weights=True)
+    ls_fr, g_fr = tr_fr.loss_steps.double().cpu().numpy(), tr_fr.grads[::16].double().cpu()
+    d_repr, d_orig, d_round = np.abs(ls_sr / ls_fr - 1), np.abs(ls_s / ls_f - 1), np.abs(ls_fr / ls_f - 1)
+    assert d_repr.max() <= 2.5e-7 and rel(g_sr, g_fr) <= 2e-7, (d_repr.max(), rel(g_sr, g_fr))
+    assert d_orig.mean() >= 1.5 * d_repr.mean() and rel(g_s, g_f) >= 1.5 * rel(g_sr, g_fr), (d_orig.mean(), d_repr.mean(), rel(g_s, g_f), rel(g_sr, g_fr))
+    assert d_round.mean() >= 0.5 * d_orig.mean(), (d_round.mean(), d_orig.mean())
+    try:
+        import json
+        root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out")
+        os.makedirs(root, exist_ok=True)
+        with open(os.path.join(root, "precision_at_c3_weights.json"), "w") as f:
+            json.dump({"per_step_loss_rel_distance_split_vs_strict_fp32": {"original_weights_mean": float(d_orig.mean()), "original_weights_max": float(d_orig.max()),
+                                                                          "two_plane_representable_weights_mean": float(d_repr.mean()), "two_plane_representable_weights_max": float(d_repr.max())},
+                       "strict_fp32_rounded_vs_original_weights_mean": float(d_round.mean()),
+                       "gradient_rel_l2_split_vs_strict_fp32": {"original_weights": rel(g_s, g_f), "two_plane_representable_weights": rel(g_sr, g_fr)}}, f, indent=1)
+    except OSError:
+        pass
+
+
 # ---------------------------------------------------------------------------------------------
 # precision equivalence of the split-operand convolution
 # ---------------------------------------------------------------------------------------------
@@ -1276,7 +1387,7 @@ def test_library_rccl_communicator_single_rank():
 # ---------------------------------------------------------------------------------------------
 # Burgers unrolled loss + gradient (BASELINE configs[0]); --pretf scales in the fused trainer
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("noforce,ms", [(False, 1), (False, 2), (True, 2)])
+@pytest.mark.parametrize("noforce,ms", [(False, 1), (False, 2), (True, 2), (False, 4)])       # (False, 4): the reference's SOL-04 recipe, burgers/Makefile:75-77 `-m 4 -b 5`
 def test_burgers_unrolled_loss_and_gradient_against_oracle(noforce, ms):
     """burgers/ 32x32, batch 5, dt 0.1 (karman... burgers/Makefile:71 `-l 32 --dt 0.1 -b 5 -m 1`): the unrolled graph of
     burgers_train.py:379-437 composed from the reference-shaped surface (BurgersTest.step_with_f, to_feature, model,

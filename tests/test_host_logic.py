@@ -234,3 +234,50 @@ def test_capture_safe_torch_helpers_equal_the_torch_ops_they_replace():
     assert float(one[0].grad) == 1.0
     many = [torch.tensor(float(k)) for k in range(4)]
     assert torch.equal(_lib.stack0(many), torch.stack(many))
+
+
+def test_cpu_affinity_binding_follows_the_gpus_numa_node(tmp_path, monkeypatch):
+    """dist.bind_cpu_affinity (first-run hardening for a multi-GPU node, SURVEY.md section 8e: host jitter between graph replays): the
+    process is pinned to the CPUs of its GPU's NUMA node as sysfs reports them, ranks that share a node split it, and every way the
+    platform can fail to answer leaves the process unbound WITH a reason -- on a fake sysfs tree (no GPU here)."""
+    import os
+    from sol_amd import dist as sd
+    if not hasattr(os, "sched_setaffinity"):
+        pytest.skip("no sched_setaffinity")
+    mine = sorted(os.sched_getaffinity(0))
+    node = tmp_path / "devices" / "system" / "node" / "node1"
+    node.mkdir(parents=True)
+    (node / "cpulist").write_text("%d-%d\n" % (mine[0], mine[-1]))
+    calls = []
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: calls.append(sorted(cpus)))
+    monkeypatch.setattr(sd, "gpu_numa_node", lambda idx, sysfs="/sys": 1)
+    rec = sd.bind_cpu_affinity(0, sysfs=str(tmp_path))
+    assert rec["bound"] and rec["numa_node"] == 1 and calls[-1] == mine and rec["inherited"] == mine and sd.AFFINITY is rec
+    if len(mine) >= 4:                                  # two local ranks on one node: disjoint halves
+        a = sd.bind_cpu_affinity(0, 0, 2, sysfs=str(tmp_path)); ca = calls[-1]
+        b = sd.bind_cpu_affinity(0, 1, 2, sysfs=str(tmp_path)); cb = calls[-1]
+        assert a["bound"] and b["bound"] and not set(ca) & set(cb) and len(ca) == len(cb) == len(mine) // 2
+    n = len(calls)
+    monkeypatch.setattr(sd, "gpu_numa_node", lambda idx, sysfs="/sys": None)
+    rec = sd.bind_cpu_affinity(0, sysfs=str(tmp_path))
+    assert not rec["bound"] and "NUMA" in rec["why"] and len(calls) == n
+    monkeypatch.setattr(sd, "gpu_numa_node", lambda idx, sysfs="/sys": 7)          # a node sysfs does not list
+    rec = sd.bind_cpu_affinity(0, sysfs=str(tmp_path))
+    assert not rec["bound"] and rec["why"].startswith("failed") and len(calls) == n
+    monkeypatch.setenv("SOL_NO_AFFINITY", "1")
+    assert sd.bind_cpu_affinity(0, sysfs=str(tmp_path))["why"] == "SOL_NO_AFFINITY set" and len(calls) == n
+    assert sd._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    sd.AFFINITY = None
+
+
+def test_dcopy_validates_its_operands_before_touching_the_library():
+    """_lib.dcopy_ (the kernel copy used inside stream captures) refuses what the C entry point cannot take BEFORE any library call -- a
+    dtype that is not 32-bit, host tensors, unequal sizes -- instead of failing inside ptr() in the middle of a capture."""
+    from sol_amd import _lib
+    a, b = torch.zeros(6), torch.zeros(2, 3)
+    with pytest.raises(_lib.SolError, match="CUDA"):
+        _lib.dcopy_(a, b)                                # host tensors
+    with pytest.raises(_lib.SolError):
+        _lib.dcopy_(torch.zeros(6), torch.zeros(5))      # sizes
+    with pytest.raises(_lib.SolError):
+        _lib.dcopy_(torch.zeros(4, dtype=torch.float64), torch.zeros(4, dtype=torch.float64))
