@@ -214,6 +214,12 @@ size_t sol_conv5x5_packed_floats(int32_t cin, int32_t cout, int32_t mode);
 int sol_conv5x5_pack(void* stream, const float* w_hwio, int32_t cin, int32_t cout,
                      int32_t mode, float* packed);
 
+/* n <= 24 (layer, mode) pack jobs in ONE launch -- same packed layout as n calls of sol_conv5x5_pack (cin[k], cout[k] as there: of the
+ * convolution being RUN; packed[k] of sol_conv5x5_packed_floats(cin[k], cout[k], mode[k]) floats).  For hosts that compose the unrolled
+ * step themselves (the Python schedules of model_mercury / the Burgers path): one launch per training step instead of ~100.          */
+int sol_conv5x5_pack_jobs(void* stream, int32_t n, const float* const* w_hwio, const int32_t* cin, const int32_t* cout,
+                          const int32_t* mode, float* const* packed);
+
 #define SOL_EPI_NONE 0        /* y = conv + bias (+ residual)                       */
 #define SOL_EPI_LRELU 1       /* y = lrelu(conv + bias (+ residual))                */
 #define SOL_EPI_DLRELU 2      /* y = (conv (+ residual)) * lrelu'(act_ref)  (backward) */
@@ -253,6 +259,11 @@ int sol_conv5x5_bwd_weight(void* stream, const float* x, const float* dz, float*
 int sol_conv5x5_bwd_weight_reduce(void* stream, const float* partial, float* dw_hwio, float* db,
                                   int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,
                                   int32_t accumulate);
+
+/* sol_conv5x5_bwd_weight_reduce for n <= 12 layers of one image size (B, H, W) in two launches; same summation order.  dw_hwio[k] /
+ * db[k] may point into a flat gradient buffer (Keras get_weights() order).  cin[k] = real input channels of layer k.            */
+int sol_conv5x5_bwd_weight_reduce_jobs(void* stream, int32_t n, float* const* partial, float* const* dw_hwio, float* const* db,
+                                       int32_t B, int32_t H, int32_t W, const int32_t* cin, const int32_t* cout, int32_t accumulate);
 
 /* ------------------------------------------------------------------------------------
  * Whole training step: the unrolled msteps graph of karman_train.py:397-457

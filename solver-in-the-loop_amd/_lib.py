@@ -72,6 +72,8 @@ _SIGS = {
     "sol_burgers_step_fwd_large": (C.c_int, [C.POINTER(BurgersCfg), _P] + [_P] * 10 + [_P, C.c_size_t]),
     "sol_conv5x5_packed_floats": (C.c_size_t, [C.c_int32] * 3),
     "sol_conv5x5_pack": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "sol_conv5x5_pack_jobs": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
+    "sol_conv5x5_bwd_weight_reduce_jobs": (C.c_int, [_P, C.c_int32] + [C.POINTER(C.c_void_p)] * 3 + [C.c_int32] * 3 + [C.POINTER(C.c_int32)] * 2 + [C.c_int32]),
     "sol_conv5x5": (C.c_int, [_P] * 7 + [C.c_int32] * 6 + [C.c_float]),
     "sol_absmax_slots": (C.c_int32, []),
     "sol_absmax": (C.c_int, [_P, _P, C.c_int64, _P]),
@@ -128,7 +130,7 @@ def lib_path():
     return _build.LIB
 
 
-ABI_VERSION = 212     # sol_version() of the library these bindings were written against
+ABI_VERSION = 213     # sol_version() of the library these bindings were written against
 
 # Debugging overrides: environment variable -> (option, value).  Read ONCE here, in Python, when the library is loaded;
 # the library itself never reads the environment (options are set through sol_set_option, include/sol_hip.h).

@@ -2,6 +2,8 @@
 to_feature / to_feature_noforce (l.75-92), BurgersTest.step / step_with_f (l.178-187), and the TF1
 AdamOptimizer used at l.437 as a small optimizer object over the flat parameter buffer."""
 
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -146,8 +148,14 @@ class BurgersTrainer:
     velo: [msteps+1, B, Y+1, X+1, 2] staggered frames (frame 0 = start state, frames 1.. = targets), forc: [msteps, B, Y+1, X+1, 2]
     (ignored with noforce) -- what BurgersDataset.getData(consecutive_frames=msteps) returns, stacked."""
 
-    def __init__(self, net, domain, batch_size, msteps, dt, std_v, std_f=None, noforce=False, use_graph=True, viscosity=0.1):
+    def __init__(self, net, domain, batch_size, msteps, dt, std_v, std_f=None, noforce=False, use_graph=True, viscosity=0.1, schedule="manual"):
+        """schedule: "manual" (default since round 6) = the unrolled step as a HAND-WRITTEN schedule over the C ABI (_schedule_step: forward
+        unroll keeping the step inputs and the network's activations, reverse sweep with the weight gradients accumulated over the steps;
+        no autograd graph), "autograd" = the torch-autograd composition of the differentiable HIP ops (rounds 2-5; the cross-check)."""
         from . import fluid
+        if schedule not in ("manual", "autograd"):
+            raise ValueError("schedule must be 'manual' or 'autograd'")
+        self.schedule, self._sched = schedule, None
         self.net, self.dom, self.B, self.ms, self.dt, self.noforce = net, domain, int(batch_size), int(msteps), float(dt), bool(noforce)
         dev = net.params.device
         Y, X = domain.resolution
@@ -156,8 +164,11 @@ class BurgersTrainer:
         self._std_v_host = tuple(float(v) for v in np.asarray(std_v, dtype=np.float64).reshape(2))
         if noforce:
             self.std_in = self.std_v
+            self._std_in_host = self._std_v_host
         else:
             self.std_in = torch.cat([self.std_v, torch.as_tensor(std_f, dtype=torch.float32, device=dev).reshape(2)])
+            self._std_in_host = self._std_v_host + tuple(float(v) for v in np.asarray(std_f, dtype=np.float64).reshape(2))
+        self.grads = torch.zeros(net.n_params, dtype=torch.float32, device=dev)        # manual schedule: the flat gradient (also net.params.grad)
         self.velo = torch.zeros(self.ms + 1, self.B, Y + 1, X + 1, 2, dtype=torch.float32, device=dev)
         self.forc = torch.zeros(self.ms, self.B, Y + 1, X + 1, 2, dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
@@ -182,7 +193,71 @@ class BurgersTrainer:
             losses.append(ops.l2_loss((vt[..., 0].contiguous(), vt[..., 1].contiguous()), (gt_t[..., 0].contiguous(), gt_t[..., 1].contiguous()), self._std_v_host))
         return _lib.stack0(losses).sum() / self.ms
 
+    def _schedule_step(self):
+        """burgers_train.py:379-437 differentiated by hand.  Forward, per unrolled step k: sol_burgers_step_fwd on (v, f_k) (the step's INPUT
+        velocity is what its adjoint needs) -> features = (v, f_k at the low faces) / std_in -> the network's forward launches
+        (schedule2d.NetSchedule2D) -> v += std_v * to_staggered(out) -> loss_k and d loss_k / d v_k in one pass over the padded staggered
+        tensors (sol_l2_loss_fwd_bwd; the padding only adds the constant the reference's l2_loss sees there).  Reverse, k = n-1 .. 0:
+        G = d loss_k / d v_k + (adjoint of step k+1) -> d out = std_v * G at the corrected faces -> network reverse sweep (weight gradients
+        accumulated over the steps) -> G += d features / std_in at the low faces -> sol_burgers_step_bwd.  One reduce per layer at the end."""
+        from .schedule2d import NetSchedule2D
+        lib = _lib.load()
+        Y, X = self.dom.resolution
+        B, ms, dev = self.B, self.ms, self.velo.device
+        if self._sched is None:
+            self._sched = NetSchedule2D(self.net, B, Y, X)
+            self._circ = ops.burgers_circ(Y, X, self.dt * self.sim.viscosity, dev)
+            self._bcfg = BurgersCfg(B, Y, X, float(self.dom.dx[1]), float(self.dt))
+        sch, circ, cfg = self._sched, self._circ, self._bcfg
+        sv, sin = self._std_v_host, self._std_in_host
+        sch.begin_step()
+        vy, vx = self.velo[0][:, :, :X, 0].contiguous(), self.velo[0][:, :Y, :, 1].contiguous()
+        keep, losses = [], []
+        for k in range(ms):
+            fy = fx = None
+            if not self.noforce:
+                fy, fx = self.forc[k][:, :, :X, 0].contiguous(), self.forc[k][:, :Y, :, 1].contiguous()
+            oy, ox = torch.empty_like(vy), torch.empty_like(vx)
+            check(lib.sol_burgers_step_fwd(C.byref(cfg), stream(), ptr(vy), ptr(vx), ptr(fy), ptr(fx), ptr(circ[0]), ptr(circ[1]), ptr(circ[2]), ptr(circ[3]),
+                                           ptr(oy), ptr(ox)))
+            chans = [oy[:, :Y], ox[:, :, :X]]
+            if not self.noforce:
+                chans += [fy[:, :Y], fx[:, :, :X]]
+            # (the division by the std TENSOR, as to_feature(...) / std_in of the autograd composition does it: a scalar division is a
+            #  multiplication by the reciprocal in torch -- one ulp apart, enough to flip the sign of an activation that sits at a
+            #  LeakyReLU kink and with it a gradient element: tools/dbg/burgers_sched_dbg.py)
+            out, state = sch.forward(torch.stack(chans, dim=-1) / self.std_in)
+            oy[:, :Y].add_(out[..., 0], alpha=sv[0])                 # to_staggered + add: the last row / column receives no correction
+            ox[:, :, :X].add_(out[..., 1], alpha=sv[1])
+            gt = self.velo[k + 1]
+            li, gi = ops.l2_loss_fwd_bwd((_lib.pad_high(oy, 2), _lib.pad_high(ox, 1)), (gt[..., 0].contiguous(), gt[..., 1].contiguous()), sv, gscale=1.0 / ms)
+            losses.append(li.reshape(()))
+            keep.append((vy, vx, state, (gi[0][:, :, :X].contiguous(), gi[1][:, :Y, :].contiguous())))
+            vy, vx = oy, ox
+        gin = None
+        for k in range(ms - 1, -1, -1):
+            iy, ix, state, G = keep[k]
+            if gin is not None:
+                G[0].add_(gin[0])
+                G[1].add_(gin[1])
+            dO = torch.stack([G[0][:, :Y] * sv[0], G[1][:, :, :X] * sv[1]], dim=-1)
+            dx = sch.backward(state, dO)
+            G[0][:, :Y].add_(dx[..., 0], alpha=1.0 / sin[0])
+            G[1][:, :, :X].add_(dx[..., 1], alpha=1.0 / sin[1])
+            oy, ox = torch.empty_like(iy), torch.empty_like(ix)
+            check(lib.sol_burgers_step_bwd(C.byref(cfg), stream(), ptr(iy), ptr(ix), ptr(circ[0]), ptr(circ[1]), ptr(circ[2]), ptr(circ[3]),
+                                           ptr(G[0]), ptr(G[1]), ptr(oy), ptr(ox)))
+            gin = (oy, ox)
+            keep[k] = None
+        _lib.dcopy_(self.loss, _lib.stack0(losses).sum() / ms)
+        _lib.dcopy_(self.grads, sch.end_step())
+
     def _eager(self):
+        if self.schedule == "manual":
+            with torch.no_grad():
+                self._schedule_step()
+            self.net.params.grad = self.grads
+            return
         self.net.params.grad = None
         loss = self._unrolled_loss()
         loss.backward()
@@ -196,6 +271,13 @@ class BurgersTrainer:
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self.schedule == "manual":
+            def body():
+                with torch.no_grad():
+                    self._schedule_step()
+            self._graph = _lib.capture_graph(body, "BurgersTrainer")
+            self.net.params.grad = self.grads    # static buffer, rewritten by every replay
+            return
         self.net.params.grad = None             # the captured backward allocates .grad from the graph's pool and rewrites it per replay
         def body():
             loss = self._unrolled_loss()

@@ -1027,6 +1027,23 @@ extern "C" int sol_conv5x5_pack(void* stream, const float* w_hwio, int32_t cin, 
     return SOL_OK;
 }
 
+// n <= 24 (layer, mode) pack jobs in ONE launch (k_pack_jobs: what the C++ trainer packs its step's weights with): the per-step weight
+// packing of a host-composed schedule (schedule2d.NetSchedule2D) is one launch instead of two to ten per layer and mode.
+extern "C" int sol_conv5x5_pack_jobs(void* stream, int32_t n, const float* const* w_hwio, const int32_t* cin, const int32_t* cout,
+                                     const int32_t* mode, float* const* packed) {
+    SOL_REQUIRE(n >= 1 && n <= 24 && w_hwio && cin && cout && mode && packed, "sol_conv5x5_pack_jobs: 1 <= n <= 24 jobs, no NULL array");
+    const float* bi[24];
+    float* bo[24];
+    int ci[24], co[24], md[24];
+    for (int k = 0; k < n; ++k) {
+        SOL_REQUIRE(w_hwio[k] && packed[k], "sol_conv5x5_pack_jobs: NULL pointer in job %d", k);
+        SOL_REQUIRE(cin[k] >= 1 && cin[k] <= 32 && cout[k] >= 1 && cout[k] <= 32, "sol_conv5x5_pack_jobs: channels out of range in job %d", k);
+        SOL_REQUIRE(mode[k] == SOL_CONV_FWD || mode[k] == SOL_CONV_BWD_DATA, "sol_conv5x5_pack_jobs: bad mode %d in job %d", mode[k], k);
+        bi[k] = nullptr; bo[k] = nullptr; ci[k] = cin[k]; co[k] = cout[k]; md[k] = mode[k];
+    }
+    return sol_pack_jobs((hipStream_t)stream, n, w_hwio, packed, bo, bi, ci, co, md, 0);
+}
+
 int sol_init_conv_kernels() {
     static std::atomic<unsigned long long> optin{0};
     return sol_lds_optin(optin, {SOL_K(k_conv5x5_r3<1>), SOL_K(k_conv5x5_r3<2>), SOL_K(k_conv5x5_c32<1>), SOL_K(k_conv5x5_c32<2>)}, "conv kernels");
@@ -1286,6 +1303,16 @@ int sol_bww_reduce_layers(void* stream, int n, float* const* partial, float* con
     SOL_LAUNCH(k_bww_reduce_jobs, dim3((max_total + 255) / 256, 1, n), dim3(256), 0, hs, J, 1);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
+}
+
+// the reduction of sol_conv5x5_bwd_weight's partial sums for n <= 12 layers of one image size in two launches (same summation order as n calls
+// of sol_conv5x5_bwd_weight_reduce); dw_hwio[k] / db[k] may point straight into a flat gradient buffer
+extern "C" int sol_conv5x5_bwd_weight_reduce_jobs(void* stream, int32_t n, float* const* partial, float* const* dw_hwio, float* const* db,
+                                                  int32_t B, int32_t H, int32_t /*W*/, const int32_t* cin, const int32_t* cout, int32_t accumulate) {
+    SOL_REQUIRE(n >= 1 && n <= 12 && partial && dw_hwio && db && cin && cout && B >= 1 && H >= 1, "sol_conv5x5_bwd_weight_reduce_jobs: 1 <= n <= 12 layers, no NULL array");
+    int rows[12], rb[12], ci[12], co[12];
+    for (int k = 0; k < n; ++k) { rows[k] = B * H; rb[k] = RB; ci[k] = cin[k]; co[k] = cout[k]; }
+    return sol_bww_reduce_layers(stream, n, partial, dw_hwio, db, rows, rb, ci, co, accumulate, 0);
 }
 
 int sol_bww_step_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int B, int H, int rb, int cin, int cout, int accumulate) {

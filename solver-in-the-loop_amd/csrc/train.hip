@@ -20,7 +20,7 @@ int sol_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* sol_last_error(void) { return g_sol_err; }
-extern "C" int sol_version(void) { return 212; }
+extern "C" int sol_version(void) { return 213; }
 // sizes of the ABI structs: the ctypes mirror in _lib.py checks them at load time
 extern "C" int sol_abi_sizes(int32_t* karman_cfg, int32_t* burgers_cfg, int32_t* train_cfg) {
     if (karman_cfg) *karman_cfg = (int32_t)sizeof(sol_karman_cfg);

@@ -241,20 +241,27 @@ class SolRollout:
 
 class GraphTrainer:
     """The SolTrainer call surface for networks the C++ trainer has no fused schedule for (`model_mercury`,
-    karman_train.py:92-99 / `eval('model_'+...)` at :394).  The unrolled step of karman_train.py:397-457 is COMPOSED from
-    the differentiable HIP ops (KarmanFlow.step, to_feature, the network, to_staggered) by torch autograd and captured once
-    into a hipGraph over static buffers; a step copies the batch in and replays.  Same outputs as SolTrainer: the loss,
-    `grads` (flat, Keras get_weights() order), `loss_steps`, `final` = [density, vy, vx] after the last step; TF-Adam with
-    optional per-tensor clip; data parallel through the same DPStep (one SUM all-reduce of `grads`)."""
+    karman_train.py:92-99 / `eval('model_'+...)` at :394).  The unrolled step of karman_train.py:397-457 runs as a HAND-WRITTEN
+    schedule over the C ABI (`schedule="manual"`, default since round 6: _unrolled_schedule -- forward unroll keeping what the
+    reverse sweep needs, reverse sweep with the weight gradients accumulated over the steps, no autograd graph) or, as the
+    cross-check, COMPOSED from the differentiable HIP ops (KarmanFlow.step, to_feature, the network, to_staggered) by torch autograd
+    (`schedule="autograd"`, rounds 2-5); either way captured once into a hipGraph over static buffers: a step copies the batch in
+    and replays.  Same outputs as SolTrainer: the loss, `grads` (flat, Keras get_weights() order), `loss_steps`, `final` =
+    [density, vy, vx] after the last step; TF-Adam with optional per-tensor clip; data parallel through the same DPStep (one SUM
+    all-reduce of `grads`)."""
 
     def __init__(self, net, B, Y, X, msteps, std_v, std_re, res=None, clip_grad=False, beta1=0.9, beta2=0.999, eps=1e-8,
                  group=None, use_graph=True, comm=None, in_std_v=None, out_std_v=None, pressure_solver=None,
                  dx=None, dt=1.0, masks=None, cg_rtol=1e-6, cg_atol=1e-9, cg_max_iter=2000, grad_pad="replicate",
-                 inflow_order="after", conv_precision="split"):
+                 inflow_order="after", conv_precision="split", schedule="manual"):
         """dx: cell size (default 100 / X, the reference's `--len 100`); the domain is box[0:Y*dx, 0:X*dx] as the scripts
         build it (karman_train.py:363: box[0:len*2, 0:len]).  masks: optional SceneMasks of the caller -- its boundary
         arrays are used; its scene must be the one KarmanFlow derives from the domain (checked).  The solver options are
-        those of SolTrainer and are forwarded to KarmanFlow."""
+        those of SolTrainer and are forwarded to KarmanFlow.  schedule: "manual" | "autograd" (see the class docstring)."""
+        if schedule not in ("manual", "autograd"):
+            raise ValueError("schedule must be 'manual' or 'autograd'")
+        self.schedule = schedule
+        self._sched = None
         from . import fluid, karman
         _lib.require_gpu()
         self.lib = _lib.load()
@@ -283,6 +290,9 @@ class GraphTrainer:
         self._std_loss_host = (float(std_v[0]), float(std_v[1]))
         self.scale_in = t(list(in_std_v if in_std_v is not None else std_v) + [std_re])
         self.scale_out = t(out_std_v if out_std_v is not None else std_v)
+        # (host copies: a .tolist() of a device tensor is a synchronising copy -- illegal inside a capture)
+        self._scale_in_host = tuple(float(a) for a in (list(in_std_v if in_std_v is not None else std_v) + [std_re]))
+        self._scale_out_host = tuple(float(a) for a in (out_std_v if out_std_v is not None else std_v))
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         self._in = [f32(B, Y, X), f32(B, Y + 1, X), f32(B, Y, X + 1), f32(B), f32(msteps, B, Y + 1, X), f32(msteps, B, Y, X + 1)]
         n = net.n_params
@@ -301,6 +311,65 @@ class GraphTrainer:
         self._dp = DPStep(self._fwd_bwd_flat, self._apply_flat, group=group, comm=comm, flat=self._flat)
 
     def _unrolled(self):
+        if self.schedule == "manual":
+            with torch.no_grad():                   # nothing here is differentiated by torch: the reverse sweep is written out
+                return self._unrolled_schedule()
+        return self._unrolled_autograd()
+
+    def _unrolled_schedule(self):
+        """karman_train.py:397-457 differentiated by hand (the 2-D counterpart of karman3d.Karman3DTrainer._unrolled_schedule; train.hip does
+        the same in C++ for model_mars_moon).  Forward, per unrolled step i: sol_karman_step_fwd (saves the post-diffusion velocity, writes
+        the SCALED features itself) -> the network's forward launches (schedule2d.NetSchedule2D) -> velocity += out_std * to_staggered(out)
+        -> loss_i and d loss_i / d v_i in one pass (sol_l2_loss_fwd_bwd, gradient pre-scaled by 1 / msteps).  Reverse, i = n-1 .. 0:
+        G = d loss_i / d v_i + (adjoint of step i+1 w.r.t. its input) -> d out = out_std * G at the corrected faces -> the network's reverse
+        sweep (weight gradients accumulated over the steps in the layers' partial buffers) -> sol_karman_step_bwd, which adds the feature
+        gradient / in_std itself (dfeat).  One reduce per layer at the end."""
+        from .schedule2d import NetSchedule2D
+        d, vy, vx, re, gt_vy, gt_vx = self._in
+        B, Y, X, ms = self.B, self.Y, self.X, self.msteps
+        dev = self.device
+        if self._sched is None:
+            self._sched = NetSchedule2D(self.net, B, Y, X)
+            self._mk = self.sim._masks(self.dom, self.bcv, self.bcm, dev)
+            self._kcfg = ops.karman_cfg(B, Y, X, self.dom.dx[1], dt=self.dt, res=self.res, masks=self._mk, **self.sim._solver)
+            self._fs = [1.0 / float(v) for v in self._scale_in_host]
+        sch, mk, cfg, lib = self._sched, self._mk, self._kcfg, self.lib
+        fs3 = (C.c_float * 3)(*self._fs)
+        so, sl = self._scale_out_host, self._std_loss_host
+        sch.begin_step()
+        keep, losses = [], []
+        for i in range(ms):
+            d2, vy2, vx2, svy, svx = torch.empty_like(d), torch.empty_like(vy), torch.empty_like(vx), torch.empty_like(vy), torch.empty_like(vx)
+            feat = torch.empty(B, Y, X, 4, dtype=torch.float32, device=dev)
+            check(lib.sol_karman_step_fwd(C.byref(cfg), stream(), ptr(d), ptr(vy), ptr(vx), ptr(re), ptr(mk.active), ptr(mk.inflow), ptr(mk.velBCy),
+                                          ptr(mk.velBCyMask), mk.bc_stride, ptr(d2), ptr(vy2), ptr(vx2), ptr(svy), ptr(svx), ptr(feat), fs3, None))
+            out, state = sch.forward(feat)
+            vy2[:, :Y].add_(out[..., 0], alpha=so[0])             # to_staggered + add (karman_train.py:88-90, 424-426): the last row / column gets no correction
+            vx2[:, :, :X].add_(out[..., 1], alpha=so[1])
+            li, gi = ops.l2_loss_fwd_bwd((vy2, vx2), (gt_vy[i], gt_vx[i]), sl, gscale=1.0 / ms)
+            losses.append(li.reshape(()))
+            keep.append((svy, svx, state, gi))
+            d, vy, vx = d2, vy2, vx2
+        gin = None
+        for i in range(ms - 1, -1, -1):
+            svy, svx, state, G = keep[i]
+            if gin is not None:
+                G[0].add_(gin[0])
+                G[1].add_(gin[1])
+            dO = torch.stack([G[0][:, :Y] * so[0], G[1][:, :, :X] * so[1]], dim=-1)
+            dfeat = sch.backward(state, dO)[..., :2].contiguous()
+            oy, ox = torch.empty_like(svy), torch.empty_like(svx)
+            check(lib.sol_karman_step_bwd(C.byref(cfg), stream(), ptr(svy), ptr(svx), ptr(re), ptr(mk.active), ptr(mk.velBCyMask), mk.bc_stride,
+                                          ptr(G[0]), ptr(G[1]), ptr(dfeat), fs3, ptr(oy), ptr(ox), None))
+            gin = (oy, ox)
+            keep[i] = None
+        losses = _lib.stack0(losses)
+        _lib.dcopy_(self.loss_steps, losses)
+        _lib.dcopy_(self.grads, sch.end_step())
+        for dst, src in zip(self._fin, (d, vy, vx)):
+            _lib.dcopy_(dst, src)
+
+    def _unrolled_autograd(self):
         from . import fluid, karman
         d0, vy0, vx0, re, gt_vy, gt_vx = self._in
         B, Y, X = self.B, self.Y, self.X

@@ -757,6 +757,49 @@ def test_captured_trainers_stay_correct_over_many_replays_with_changing_weights(
         assert rel(outs[0][1], outs[1][1]) < 1e-5, (it, rel(outs[0][1], outs[1][1]))
 
 
+@pytest.mark.parametrize("name,Y,X,pretf", [("mercury", 32, 16, False), ("mercury", 128, 64, True), ("mars_moon", 128, 64, False), ("mars_moon", 64, 32, True)])
+def test_graph_trainer_manual_schedule_equals_autograd_composition(name, Y, X, pretf):
+    """GraphTrainer's hand-written schedule over the C ABI (round 6: trainer.GraphTrainer._unrolled_schedule + schedule2d.NetSchedule2D --
+    karman_train.py:92-99 / 101-138 and :397-457 differentiated by hand) against the torch-autograd composition of the differentiable HIP ops
+    it replaces as the default (schedule="autograd"): per-step losses, the flat gradient, the final state; eager and through the captured
+    graph (kernel nodes only -- the capture guard runs on both); with separate input / output scales (--pretf).  128x64: the 32-channel
+    layers run the fp16 three-product kernels with the absmax slots handed from layer to layer (the autograd form: bf16 six-product)."""
+    from sol_amd import _lib
+    B, ms = 2, 3
+    g = o.geometry(Y, X)
+    mk = ops.SceneMasks(g.active, g.inflow, g.bc_mask, g.bc_mask)
+    d, vy, vx = (f32(t) for t in o.synthetic_state(B, Y, X, 5))
+    re = f32(torch.tensor([o.RE_TRAIN[i % 6] for i in range(B)]))
+    gts = [o.synthetic_state(B, Y, X, 900 + i, project_it=False) for i in range(ms)]
+    gy, gx = f32(torch.stack([s[1] for s in gts])), f32(torch.stack([s[2] for s in gts]))
+    mk_net = sol_amd.model_mercury if name == "mercury" else sol_amd.model_mars_moon
+    kw = dict(in_std_v=(0.3, 0.35), out_std_v=(0.15, 0.1)) if pretf else {}
+    res = {}
+    for sched in ("manual", "autograd"):
+        for graph in (False, True):
+            net = mk_net(cin=3, cout=2, seed=4, device=DEV)
+            with torch.no_grad():
+                net.params.add_(0.01 * torch.randn(net.params.shape, generator=torch.Generator().manual_seed(9)).to(DEV))      # non-zero biases
+            tr = sol_amd.GraphTrainer(net, B, Y, X, ms, (0.2, 0.25), o.STD_RE, dx=g.dx, masks=mk, use_graph=graph, schedule=sched, **kw)
+            for _ in range(2):                  # second call: the replay (or the second eager sweep: partial buffers re-zeroed)
+                loss = tr.fwd_bwd(d, vy, vx, re, gy, gx, want_final=True)
+            torch.cuda.synchronize()
+            res[(sched, graph)] = (float(loss), tr.loss_steps.clone(), tr.grads.clone(), [t.clone() for t in tr.final])
+            if graph:
+                census = _lib.graph_census(tr._graph.raw_cuda_graph())
+                assert set(census) <= {"kernel", "empty"}, census
+                res[(sched, "nodes")] = census["kernel"]
+    ref = res[("autograd", False)]
+    for key in (("manual", False), ("manual", True), ("autograd", True)):
+        got = res[key]
+        assert abs(got[0] - ref[0]) < 2e-6 * abs(ref[0]), (key, got[0], ref[0])
+        assert rel(got[1], ref[1]) < 2e-6, (key, rel(got[1], ref[1]))
+        assert rel(got[2], ref[2]) < 3e-5, (key, rel(got[2], ref[2]))
+        assert all(rel(a, b) < 2e-6 for a, b in zip(got[3], ref[3])), key
+    assert torch.equal(res[("manual", False)][2], res[("manual", True)][2])          # the replayed graph IS the eager schedule: bit for bit
+    assert res[("manual", "nodes")] < 0.75 * res[("autograd", "nodes")], (res[("manual", "nodes")], res[("autograd", "nodes")])
+
+
 def test_shard_gradients_sum_to_the_large_batch_gradient():
     """What the RCCL all-reduce(SUM) relies on: grad(batch) == grad(shard 0) + grad(shard 1)."""
     B, Y, X, ms = 4, 16, 8, 2
@@ -1589,6 +1632,52 @@ def test_burgers_fused_trainer_graph_equals_eager_and_oracle(noforce, ms):
 # ---------------------------------------------------------------------------------------------
 # Burgers roll-out (burgers_apply.py:129-151)
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("noforce,ms,model", [(False, 1, "mars_moon"), (False, 4, "mars_moon"), (True, 2, "mars_moon"), (False, 2, "mercury")])
+def test_burgers_trainer_manual_schedule_equals_autograd_composition(noforce, ms, model):
+    """BurgersTrainer's hand-written schedule over the C ABI (round 6: burgers.BurgersTrainer._schedule_step -- burgers_train.py:379-437
+    differentiated by hand; NON `-m 1` and SOL-04 `-m 4` of burgers/Makefile:69-77) against the torch-autograd composition
+    (schedule="autograd"): loss and flat gradient, eager and replayed, after new batch data and after a TF-Adam step; far fewer kernel
+    nodes in the captured graph."""
+    from sol_amd import _lib
+    B, Y, X, dt = 5, 32, 32, 0.1
+    gen = torch.Generator().manual_seed(13)
+    dom = sol_amd.Domain([Y, X], box=sol_amd.box([32, 32]), boundaries=sol_amd.PERIODIC)
+    mk_net = sol_amd.model_mercury if model == "mercury" else sol_amd.model_mars_moon
+    cin = 2 if noforce else 4
+
+    def batch():
+        velo = (0.3 * torch.randn(ms + 1, B, Y + 1, X + 1, 2, generator=gen, dtype=torch.float32)).to(DEV)
+        forc = (0.1 * torch.randn(ms, B, Y + 1, X + 1, 2, generator=gen, dtype=torch.float32)).to(DEV)
+        return velo, forc
+
+    trs = {}
+    for sched in ("manual", "autograd"):
+        for graph in (False, True):
+            net = mk_net(cin=cin, cout=2, seed=2, device=DEV)
+            with torch.no_grad():
+                net.params.add_(0.01 * torch.randn(net.params.shape, generator=torch.Generator().manual_seed(9)).to(DEV))
+            trs[(sched, graph)] = sol_amd.BurgersTrainer(net, dom, B, ms, dt, (0.21, 0.19), (0.09, 0.11), noforce=noforce, use_graph=graph, schedule=sched)
+    for it in range(3):
+        velo, forc = batch()
+        out = {}
+        for key, tr in trs.items():
+            loss = tr.train_step(velo, forc, 1e-4) if it == 2 else tr.fwd_bwd(velo, forc)       # last batch: one TF-Adam step in every trainer
+            torch.cuda.synchronize()
+            out[key] = (float(loss), tr.net.params.grad.detach().clone(), tr.net.params.detach().clone())
+        ref = out[("autograd", False)]
+        for key, got in out.items():
+            assert abs(got[0] - ref[0]) < 2e-6 * abs(ref[0]), (it, key, got[0], ref[0])
+            # the forward passes of the two forms are bit-identical (same launches on the same operands), so every LeakyReLU mask is too;
+            # what differs is the summation order of the weight gradients (accumulated over the steps vs summed by autograd)
+            assert rel(got[1], ref[1]) < 1e-5, (it, key, rel(got[1], ref[1]))
+            # the first Adam update is lr * sign(g) per weight: gradient elements at rounding level move by 2 lr between the two summation orders
+            assert rel(got[2], ref[2]) < 1e-4, (it, key)
+        assert torch.equal(out[("manual", False)][1], out[("manual", True)][1]) and torch.equal(out[("manual", False)][2], out[("manual", True)][2])
+    nodes = {s_: _lib.graph_census(trs[(s_, True)]._graph.raw_cuda_graph()) for s_ in ("manual", "autograd")}
+    assert all(set(c) <= {"kernel", "empty"} for c in nodes.values()), nodes
+    assert nodes["manual"]["kernel"] < 0.75 * nodes["autograd"]["kernel"], nodes
+
+
 @pytest.mark.parametrize("noforce,use_graph", [(False, True), (False, False), (True, True)])
 def test_burgers_rollout_against_oracle(noforce, use_graph):
     """BurgersRollout: 10 corrected steps (solver step with the PREVIOUS force frame, network input with the CURRENT one, as
