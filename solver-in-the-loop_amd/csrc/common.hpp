@@ -25,7 +25,7 @@ int sol_conv5x5_correct(void* stream, const float* x, const float* packed, const
 size_t sol_bww_batched_ws_floats(int nseg, int B, int H, int cin, int cout);
 int sol_bww_batched(void* stream, const float* x, const float* dz, float* partial, int nseg, int nseg_layout, int overwrite,
                     long x_seg, long dz_seg, int B, int H, int W, int cin, int cout,
-                    const unsigned* xmax = nullptr, const unsigned* zmax = nullptr, long xmax_seg = 0, long zmax_seg = 0);
+                    const unsigned* xmax = nullptr, const unsigned* zmax = nullptr, long xmax_seg = 0, long zmax_seg = 0, int cin_real = 0);
 int sol_bww_batched_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int nseg, int B, int H,
                            int cin, int cout, int accumulate, int taps_transposed = 0);
 
@@ -83,6 +83,7 @@ struct BwArgs {
     int overwrite;                // 1: partial = acc (single launch), 0: partial += acc (accumulate over launches)
     const unsigned *xmax, *zmax;  // absmax slots of segment 0 of x / dz (NULL: bf16 six-product kernel) ...
     long xmax_seg, zmax_seg;      // ... and their strides (uint32 words) between consecutive segments
+    int cin_real;                 // thin first layer (cin == 4): 1..3 = the channels beyond it are zero padding (their gradient rows are not computed); 0: all four are data
 };
 int sol_bww_sb_launch(hipStream_t s, const BwArgs& a, int nblk_run);
 // ---- persistent chain of 32 -> 32 layers (cnn_chain.hip) ----

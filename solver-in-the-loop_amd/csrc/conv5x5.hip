@@ -780,14 +780,18 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww32(BwArgs a) {
 }
 
 // Weight gradient of the two thin layers (first: 3(+1 pad) -> 32 channels, last: 32 -> 2) on
-// v_mfma_f32_32x32x2_f32 with the five dx taps folded into the otherwise empty matrix dimension:
-//   MODE 0 (cin 4, cout 32):  A[i = 4*dx+ci][k = px] = x[px+dx][ci],   B[k = px][j = co]      = dz[px][co]
-//   MODE 1 (cin 32, cout 2):  A[i = ci][k = q]       = x[q][ci],       B[k = q][j = 2*dx+co]  = dz[q-dx][co]
-// so one accumulator per tap row dy holds all five dx taps and a workgroup (4 waves, K split over the
-// pixels) keeps the 5 accumulators of ALL tap rows: x and dz are read once instead of 5 times, and the
-// MFMA count per row drops 10x/16x compared with the generic kernel (which spent as long on these
-// layers as on a full 32x32 one).  Rows are double buffered in LDS with register prefetch.
-template <int MODE>
+// v_mfma_f32_16x16x4_f32 with the five dx taps folded into the otherwise empty matrix dimension:
+//   MODE 0 (cin 4, cout 32):  A[i = (dx, ci)][k = px] = x[px+dx][ci],   B[k = px][j = co]      = dz[px][co]
+//   MODE 1 (cin 32, cout 2):  A[i = ci][k = q]        = x[q][ci],       B[k = q][j = 2*dx+co]  = dz[q-dx][co]
+// so one accumulator set per tap row dy holds all five dx taps and a workgroup (4 waves, K split over the
+// pixels) keeps the accumulators of ALL tap rows: x and dz are read once instead of 5 times.  Rows are double
+// buffered in LDS with register prefetch.
+// Round 6: 16 x 16 tiles instead of one 32 x 32 x 2 tile per tap row.  The folded dimension has 5 x 3 = 15 entries when the
+// fourth input channel is zero padding (MODE 0, MT = 1: ONE 16-row tile, 15 / 16 used instead of 20 / 32) and 10 entries in
+// MODE 1 (ONE 16-column tile, 10 / 16 used instead of 10 / 32): half the matrix-pipe cycles per pixel for the same products
+// (the kernels are bound by the fp32 matrix pipe: 40 x 64 clocks per row and wave before, 40 x 32 / 50 x 32 now).  MT = 2 (four
+// real input channels: 20 folded entries, two 16-row tiles) costs what the 32 x 32 form did.
+template <int MODE, int MT>
 __global__ void __launch_bounds__(256) k_conv5x5_bww_thin(BwArgs a) {
     constexpr int W = 64;
     constexpr int XC = MODE == 0 ? 4 : 32, ZC = MODE == 0 ? 32 : 2;            // channels per pixel of x / dz
@@ -798,16 +802,21 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww_thin(BwArgs a) {
     constexpr int IP = MODE == 0 ? 16 : 32, OP = MODE == 0 ? 32 : 16;
     constexpr int XF4 = XROWS * XSZ / 4, ZF4 = ZROWS * ZSZ / 4;                // float4 per stage
     constexpr int NXR = (XF4 + 255) / 256, NZR = (ZF4 + 255) / 256;
+    constexpr int NTM = MODE == 0 ? MT : 2, NTN = MODE == 0 ? 2 : 1;           // 16 x 16 tiles of a tap row's accumulator
+    constexpr int CI0 = MT == 1 ? 3 : 4;                                       // MODE 0: input channels folded with dx (15 or 20 rows)
+    typedef float bt_f4 __attribute__((ext_vector_type(4)));
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = lane & 31, kpx = lane >> 5;
+    const int n16 = lane & 15, kq = lane >> 4;
     const int H = a.H, blk = blockIdx.x;
-    f32x16 acc[5];
+    bt_f4 acc[5][NTM][NTN];
 #pragma unroll
     for (int d = 0; d < 5; ++d)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
-    float bsum = 0.f;
+        for (int tm = 0; tm < NTM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < NTN; ++tn) acc[d][tm][tn] = (bt_f4){0.f, 0.f, 0.f, 0.f};
+    float bsum[2] = {0.f, 0.f};
     const int R = a.nseg * a.B * H, RPS = a.B * H;
     const int gr_end = min((blk + 1) * a.rb, R);
     float4 xr[NXR], zr[NZR];
@@ -857,33 +866,50 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww_thin(BwArgs a) {
         const float* xs = smem + cur * STG;
         const float* zs = xs + XROWS * XSZ;
         if (MODE == 0) {
-            // wave handles pixels [16*wave, 16*wave+16): 8 k-steps of 2 pixels
-            const int dxi = c >> 2, ci = c & 3;
+            // A operand lane (m = n16, k = kq): folded row i = 16 tm + n16 = (dx, ci); B operand lane (k = kq, n = n16): co = 16 tn + n16.
+            // A wave handles pixels [16 wave, 16 wave + 16): four k-steps of four pixels.
+            int aoff[NTM];
+            bool aok[NTM];
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const int px = 16 * wave + 2 * ks + kpx;
-                const float bv = zs[px * 32 + c];
-                bsum += bv;
+            for (int tm = 0; tm < NTM; ++tm) {
+                const int i = 16 * tm + n16;
+                aok[tm] = i < 5 * CI0;
+                aoff[tm] = aok[tm] ? (i / CI0) * 4 + i % CI0 : 0;              // (px + dx) * 4 + ci relative to pixel px
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int px = 16 * wave + 4 * ks + kq;
+                float bv[2];
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) { bv[tn] = zs[px * 32 + 16 * tn + n16]; bsum[tn] += bv[tn]; }
 #pragma unroll
                 for (int d = 0; d < 5; ++d) {        // tap row dy = d uses x row slot d (= image row y+d-2, zero if outside)
-                    const float av = c < 20 ? xs[d * XSZ + (px + dxi) * 4 + ci] : 0.f;
-                    acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[d], 0, 0, 0);
+#pragma unroll
+                    for (int tm = 0; tm < NTM; ++tm) {
+                        const float av = aok[tm] ? xs[d * XSZ + px * 4 + aoff[tm]] : 0.f;
+#pragma unroll
+                        for (int tn = 0; tn < NTN; ++tn) acc[d][tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[tn], acc[d][tm][tn], 0, 0, 0);
+                    }
                 }
             }
         } else {
-            // K runs over the 68 halo pixels q of the x row: wave handles q in [17*wave, 17*wave+17) -> 9 k-steps (last half masked)
-            const int dxi = c >> 1, co = c & 1;
+            // K runs over the 68 halo pixels q of the x row in 17 groups of four; wave w takes the groups g = w, w + 4, ... (5, 4, 4, 4 of them)
+            const int dxi = n16 >> 1, co = n16 & 1;
 #pragma unroll
-            for (int ks = 0; ks < 9; ++ks) {
-                const int qq = 17 * wave + 2 * ks + kpx;
-                const bool ok = 2 * ks + kpx < 17;
-                const float av = ok ? xs[qq * 32 + c] : 0.f;
-                // B[q][j=(dx,co)] = dz[q-2-dx+... ]: x halo pixel q is image pixel q-2; output pixel = q-2-(dx-2) = q-dx -> stage pixel q-dx+4
+            for (int ks = 0; ks < 5; ++ks) {
+                const int g = wave + 4 * ks;
+                const bool ok = g < 17;
+                const int qq = ok ? 4 * g + kq : 0;
+                float av[2];
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) av[tm] = ok ? xs[qq * 32 + 16 * tm + n16] : 0.f;
+                // B[q][j = (dx, co)]: x halo pixel q is image pixel q-2; output pixel = q-2-(dx-2) = q-dx -> stage pixel q-dx+4
 #pragma unroll
                 for (int d = 0; d < 5; ++d) {        // tap row dy = d pairs x row y with dz row y+2-d (stage slot d)
-                    const float bv = (ok && c < 10) ? zs[d * ZSZ + (qq - dxi + 4) * 2 + co] : 0.f;
-                    if (d == 2 && c < 2) bsum += bv;  // dx = 0 columns of the dy = 2 slot: dz[q-... ] summed once per pixel
-                    acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[d], 0, 0, 0);
+                    const float bv = (ok && n16 < 10) ? zs[d * ZSZ + (qq - dxi + 4) * 2 + co] : 0.f;
+                    if (d == 2 && n16 < 2) bsum[0] += bv;    // dx = 0 columns of the dy = 2 slot: every dz pixel of the row once
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm) acc[d][tm][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tm], bv, acc[d][tm][0], 0, 0, 0);
                 }
             }
         }
@@ -891,15 +917,16 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww_thin(BwArgs a) {
         __syncthreads();
         cur ^= 1;
     }
-    // fold the 4 K-split accumulators through LDS, one tap row at a time
+    // fold the 4 K-split accumulators through LDS, one tap row at a time: red[wave][row = folded / input-channel index][32 columns]
     float* red = smem;                                  // [4][32][32]
     float* pw = a.partial + (size_t)blk * (25 * IP * OP);
     for (int d = 0; d < 5; ++d) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * kpx;
-            red[wave * 1024 + row * 32 + c] = acc[d][r];
-        }
+        for (int tm = 0; tm < NTM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < NTN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave * 1024 + (16 * tm + 4 * kq + r) * 32 + 16 * tn + n16] = acc[d][tm][tn][r];
         __syncthreads();
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -907,7 +934,7 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww_thin(BwArgs a) {
             const float v = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
             int tap, ci, co;
             bool keep;
-            if (MODE == 0) { tap = d * 5 + (row >> 2); ci = row & 3; co = col; keep = row < 20; }
+            if (MODE == 0) { tap = d * 5 + row / CI0; ci = row % CI0; co = col; keep = row < 5 * CI0; }
             else { tap = d * 5 + (col >> 1); ci = row; co = col & 1; keep = col < 10; }
             if (keep) {
                 float* dst = &pw[(tap * IP + ci) * OP + co];
@@ -917,8 +944,12 @@ __global__ void __launch_bounds__(256) k_conv5x5_bww_thin(BwArgs a) {
         __syncthreads();
     }
     {
-        bsum += __shfl_xor(bsum, 32, 64);
-        if (kpx == 0) red[wave * 32 + c] = bsum;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bsum[t] += __shfl_xor(bsum[t], 16, 64);
+            bsum[t] += __shfl_xor(bsum[t], 32, 64);
+            if (kq == 0) red[wave * 32 + 16 * t + n16] = bsum[t];
+        }
         __syncthreads();
         const int nb = MODE == 0 ? 32 : 2;
         if (tid < nb) {
@@ -1177,7 +1208,7 @@ size_t sol_bww_batched_ws_floats(int nseg, int B, int H, int cin, int cout) {
 
 static int bww_launch(void* stream, const float* x, const float* dz, float* partial, int nseg, long x_seg, long dz_seg,
                       int rb, int overwrite, int B, int H, int W, int cin, int cout, int nblk_layout = 0,
-                      const unsigned* xmax = nullptr, const unsigned* zmax = nullptr, long xmax_seg = 0, long zmax_seg = 0) {
+                      const unsigned* xmax = nullptr, const unsigned* zmax = nullptr, long xmax_seg = 0, long zmax_seg = 0, int cin_real = 0) {
     SOL_REQUIRE(x && dz && partial, "sol_conv5x5_bwd_weight: NULL pointer");
     SOL_REQUIRE(B >= 1 && H >= 1 && W >= 4 && W % 4 == 0 && W <= 64, "sol_conv5x5_bwd_weight: need 4 <= W <= 64, W %% 4 == 0 (got %d)", W);
     SOL_REQUIRE((cin == 4 || cin == 32) && (cout == 2 || cout == 32),
@@ -1185,7 +1216,7 @@ static int bww_launch(void* stream, const float* x, const float* dz, float* part
     BwArgs a{};
     a.x = x; a.dz = dz; a.partial = partial; a.B = B; a.H = H; a.W = W; a.cin = cin; a.cout = cout;
     a.nseg = nseg; a.rb = rb; a.x_seg = x_seg; a.dz_seg = dz_seg; a.overwrite = overwrite;
-    a.xmax = xmax; a.zmax = zmax; a.xmax_seg = xmax_seg; a.zmax_seg = zmax_seg;
+    a.xmax = xmax; a.zmax = zmax; a.xmax_seg = xmax_seg; a.zmax_seg = zmax_seg; a.cin_real = cin_real;
     int IP, OP;
     bww_dims(nseg * B * H, rb, cin, cout, &a.nblk, &IP, &OP);
     const int nblk_run = a.nblk;                    // workgroups needed for this launch's rows
@@ -1198,10 +1229,12 @@ static int bww_launch(void* stream, const float* x, const float* dz, float* part
         // all five tap rows in one workgroup: grid = nblk; LDS = 2 stages (>= the 16 KB fold buffer)
         if (cin == 4) {
             const size_t l0 = 2 * (size_t)(5 * 68 * 4 + 68 * 32) * sizeof(float);
-            SOL_LAUNCH(k_conv5x5_bww_thin<0>, dim3(nblk_run), dim3(256), l0, s, a);
+            // a.cin_real <= 3: the fourth channel of x is zero padding (the karman features): its gradient rows are not computed
+            if (a.cin_real >= 1 && a.cin_real <= 3) SOL_LAUNCH((k_conv5x5_bww_thin<0, 1>), dim3(nblk_run), dim3(256), l0, s, a);
+            else SOL_LAUNCH((k_conv5x5_bww_thin<0, 2>), dim3(nblk_run), dim3(256), l0, s, a);
         } else {
             const size_t l1 = 2 * (size_t)(68 * 32 + 5 * 72 * 2) * sizeof(float);
-            SOL_LAUNCH(k_conv5x5_bww_thin<1>, dim3(nblk_run), dim3(256), l1, s, a);
+            SOL_LAUNCH((k_conv5x5_bww_thin<1, 2>), dim3(nblk_run), dim3(256), l1, s, a);
         }
         SOL_LAUNCH_CHECK();
         return SOL_OK;
@@ -1229,11 +1262,11 @@ extern "C" int sol_conv5x5_bwd_weight(void* stream, const float* x, const float*
 // overwrite = 1 for the first chunk, 0 afterwards).
 int sol_bww_batched(void* stream, const float* x, const float* dz, float* partial, int nseg, int nseg_layout, int overwrite,
                     long x_seg, long dz_seg, int B, int H, int W, int cin, int cout,
-                    const unsigned* xmax, const unsigned* zmax, long xmax_seg, long zmax_seg) {
+                    const unsigned* xmax, const unsigned* zmax, long xmax_seg, long zmax_seg, int cin_real) {
     const int rb = pick_rb(nseg_layout * B * H, cin, cout);
     int nblk, IP, OP;
     bww_dims(nseg_layout * B * H, rb, cin, cout, &nblk, &IP, &OP);
-    return bww_launch(stream, x, dz, partial, nseg, x_seg, dz_seg, rb, overwrite, B, H, W, cin, cout, nblk, xmax, zmax, xmax_seg, zmax_seg);
+    return bww_launch(stream, x, dz, partial, nseg, x_seg, dz_seg, rb, overwrite, B, H, W, cin, cout, nblk, xmax, zmax, xmax_seg, zmax_seg, cin_real);
 }
 
 static int bww_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int rows, int rb, int cin, int cout, int accumulate, int tt = 0) {

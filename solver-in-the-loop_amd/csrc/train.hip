@@ -727,7 +727,8 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
             const float* feat_i = w.feat + (size_t)i * w.cells * 4;
             const float* acts_i = w.acts + (size_t)i * 11 * cl32;
             const float* dz_i = w.dzb + (size_t)i * 11 * cl32;
-            if (int e = sol_bww_batched(bs, feat_i, dz_i, w.part[0], n, CH, first, (long)(w.cells * 4), seg32, B, cY, cX, 4, 32)) return e;
+            // (cin_real = 3: the features are (v_y, v_x, Re) + one zero channel, whose gradient rows the thin kernel then skips)
+            if (int e = sol_bww_batched(bs, feat_i, dz_i, w.part[0], n, CH, first, (long)(w.cells * 4), seg32, B, cY, cX, 4, 32, nullptr, nullptr, 0, 0, 3)) return e;
             const long amseg = 11 * SOL_AMAX_SLOTS;      // absmax slots: [step][11][SOL_AMAX_SLOTS]
             for (int l = 1; l <= 10 && !fuse; ++l)
                 if (int e = sol_bww_batched(bs, acts_i + (size_t)(l - 1) * cl32, dz_i + (size_t)l * cl32, w.part[l], n, CH, first, seg32, seg32, B, cY, cX, 32, 32,
