@@ -278,6 +278,9 @@ def _sysfs_gpu(dev_index):
     return out
 
 
+_DISPATCH_GRAPH = None
+
+
 def device_state(sol_amd, dev, iters=4000000):
     """Clock / power sample of the device: (a) ~90 ms of a dependent-MFMA chain on every SIMD (sol_clock_probe): ns per dependent
     v_mfma_f32_16x16x16_f16 follows the engine clock the box holds UNDER MATRIX LOAD and nothing else, and the ratio of the two device
@@ -302,6 +305,46 @@ def device_state(sol_amd, dev, iters=4000000):
         out["cycles_per_dependent_mfma"] = out["ns_per_dependent_mfma"] * out["shader_clock_mhz_measured"] * 1e-3
     except Exception as e:
         out["probe_error"] = str(e)
+    # (d) the cost of a launch boundary: a chain of dependent one-word copy kernels in a replayed graph -- us per node is what EVERY one of
+    #     the ~920 launches of a step pays between the end of one kernel and the start of the next (command processor, not shader clock);
+    # (e) device-to-device copy bandwidth of a 256 MB buffer (HBM + fabric clocks)
+    try:
+        global _DISPATCH_GRAPH
+        lib = sol_amd._lib.load()
+        if _DISPATCH_GRAPH is None:
+            word = torch.zeros(64, dtype=torch.int32, device=dev)
+
+            def chain():
+                for i in range(400):
+                    sol_amd._lib.check(lib.sol_copy_words(sol_amd._lib.stream(), C.c_void_p(word.data_ptr() + 4 * (i & 1)), C.c_void_p(word.data_ptr() + 8 + 4 * (i & 1)), 1))
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                chain()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            _DISPATCH_GRAPH = (sol_amd._lib.capture_graph(chain, "bench.py dispatch probe"), word)
+        g = _DISPATCH_GRAPH[0]
+        g.replay()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5):
+            g.replay()
+        b.record()
+        torch.cuda.synchronize()
+        out["us_per_dependent_launch_in_graph"] = a.elapsed_time(b) * 1e3 / (5 * 400)
+        big = torch.empty(2, 64 * 1024 * 1024, dtype=torch.float32, device=dev)
+        for rep in range(2):
+            a.record()
+            for _ in range(4):
+                sol_amd._lib.check(lib.sol_copy_words(sol_amd._lib.stream(), C.c_void_p(big[1].data_ptr()), C.c_void_p(big[0].data_ptr()), big[0].numel()))
+            b.record()
+            torch.cuda.synchronize()
+        out["copy_GBps_256MB"] = 4 * 2 * big[0].numel() * 4 / (a.elapsed_time(b) * 1e-3) / 1e9
+        del big
+    except Exception as e:
+        out["dispatch_probe_error"] = str(e)
     out.update(_sysfs_gpu(dev.index if dev.index is not None else 0))
     try:
         out["advertised_max_clock_mhz"] = torch.cuda.get_device_properties(dev).clock_rate / 1e3

@@ -65,6 +65,9 @@ int sol_abi_sizes(int32_t* karman_cfg, int32_t* burgers_cfg, int32_t* train_cfg)
  *   conv_thin_valu (1)  the thin 32 -> (<= 4) layers of 64-pixel images without residual / activation (the trainer's output layer with the
  *                       correction + loss epilogue, the first layer's data gradient) in exact fp32 on the vector ALU; 2: its eight-wave
  *                       form; 0: the split-precision MFMA kernels
+ *   seed_fuse (1)       trainer, 64-pixel rows: the loss-gradient seed of an unrolled step (d loss / d v_i + the adjoint of step i+1, scaled
+ *                       to the network's output gradient) is computed by the 2 -> 32 backward-data launch in its staging phase; 0: a k_seed
+ *                       launch per unrolled step in front of it
  *   bww_chunk (0), bww_side (1), streams (1), cpt (0), conv_split3 (0), dbg_skip (0), step_prof (0): experiments, debugging */
 int sol_set_option(const char* name, int32_t value);
 int sol_get_option(const char* name, int32_t* value);

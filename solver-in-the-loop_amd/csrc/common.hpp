@@ -19,6 +19,9 @@ int sol_density_chain(const sol_karman_cfg* c, void* stream, int ms, const float
 // internal (train.hip): last CNN layer (32 -> 2, no activation) fused with `velocity += std * to_staggered(output)` and the
 // l2 loss of the step (karman_train.py:413-447); needs the split-precision kernels (sol_conv_correct_fusable)
 bool sol_conv_correct_fusable(int W, int rows);      // W, rows = B * H of the CNN's images (the transposed ones in transposed CNN mode)
+int sol_conv5x5_seed(void* stream, const float* packed_bwd, const float* act_ref, float* y, int B, int H, int W, float slope, unsigned* y_absmax,
+                     const float* vy, const float* vx, const float* gt_vy, const float* gt_vx, const float* gin_vy, const float* gin_vx,
+                     float* g_vy, float* g_vx, float* dO2, float s0, float s1, float l0, float l1, float inv_m);
 int sol_conv5x5_correct(void* stream, const float* x, const float* packed, const float* bias, int B, int H, int W,
                         const unsigned* x_absmax, float* vy, float* vx, const float* gt_vy, const float* gt_vx,
                         float s0, float s1, float l0, float l1, unsigned long long* loss_acc, int transposed);
@@ -52,6 +55,13 @@ struct ConvArgs {
     float ls0, ls1;                 // loss scale (std_v)
     unsigned long long* closs;      // exact accumulator ([SOL_LOSS_ACC_WORDS], loss_add_exact) of 0.5 * sum(((gt - v) / std)^2) over ALL faces, or NULL
     int ctr;                        // 1: the CNN runs on the transposed grid -- image row = the solver's x index, pixel = its y index (velocity [B,W+1,H] / [B,W,H+1])
+    // trainer only (sol_conv5x5_seed): the 2 -> 32 backward-data layer of the reverse sweep computes its OWN input -- the loss-gradient seed of
+    // the unrolled step (k_seed until round 6: one launch per unrolled step for 1.2 MB of elementwise work).  x is not read: the halo tile's
+    // two channels are dO_c = cs_c * G_c with G_c = (v_c - gt_c) * sinv_m / ls_c^2 (+ gin_c), evaluated per halo pixel at the cell's low faces;
+    // the workgroup of image row y also writes G (its row, plus v_y row Y from the last row's workgroup and the v_x column X face) and dO2
+    const float *svy, *svx, *sginy, *sginx;   // v_i [B,H+1,W] / [B,H,W+1]; adjoint output of step i+1 (NULL at the last unrolled step); gt = gty / gtx
+    float *sgy, *sgx, *sdO2;                  // G out (same shapes as v), dO2 out [B,H,W,2] (operand of the last layer's weight gradient)
+    float sinv_m;                             // 1 / msteps
     int CI;                         // input channels per pixel of x as the caller declared them (0: not stated).  Kernels that read a fixed number of
                                     // channels per pixel whatever the caller meant (k_conv5x5_thin32: eight float4 = 32) check it before they are chosen
 };
@@ -193,6 +203,8 @@ struct SolOptions {
                           //    half-channel workgroups per tile (k_conv5x5_dx<1, 1, true>).  Default 11.
     int conv_thin_valu;   // 1 (default): the thin 32 -> (<= 4) layers of 64-pixel images (the trainer's output layer with the correction epilogue, the first
                           //    layer's data gradient) in exact fp32 on the vector ALU (conv5x5_thin.hip: no absmax wait, no operand split); 0: k_conv5x5_sb<1, KIND>
+    int seed_fuse;        // 1 (default): on 64-pixel rows the trainer's loss-gradient seed is computed inside the 2 -> 32 backward-data launch (sol_conv5x5_seed)
+                          //    instead of a k_seed launch per unrolled step
     int k3d_tile;         // 1: karman-3d advection from LDS tiles holding the full z column + halo; 0 (default, measured faster at B <= 2): wave-per-column gathers from global memory
 };
 SolOptions& sol_opt();

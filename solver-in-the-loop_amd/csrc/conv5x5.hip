@@ -72,6 +72,40 @@ __global__ void __launch_bounds__(256) k_conv5x5(ConvArgs a) {
         constexpr int C4 = CIN / 4;
         const int npix = (RPW + 4) * HW;
         const float4* gx = reinterpret_cast<const float4*>(a.x);
+        if (CIN == 4 && a.svy) {
+            // seed mode (see ConvArgs): RPW == 1, TW == W == 64.  Same arithmetic, operation for operation, as k_seed
+            const float l00 = a.ls0 * a.ls0, l11 = a.ls1 * a.ls1;
+            const size_t by = (size_t)b * (H + 1) * W, bx = (size_t)b * H * (W + 1);
+            for (int pix = tid; pix < npix; pix += 256) {
+                const int hr = pix / HW, hc = pix - hr * HW;
+                const int yy = y0 + hr - 2, xx = hc - 2;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                    const size_t ky = by + (size_t)yy * W + xx, kx = bx + (size_t)yy * (W + 1) + xx;
+                    float gy = (a.svy[ky] - a.gty[ky]) * a.sinv_m / l00, gxx = (a.svx[kx] - a.gtx[kx]) * a.sinv_m / l11;
+                    if (a.sginy) { gy += a.sginy[ky]; gxx += a.sginx[kx]; }
+                    v.x = a.cs0 * gy; v.y = a.cs1 * gxx;
+                    if (hr == 2) {                       // this workgroup's own row: publish G and dO2
+                        a.sgy[ky] = gy; a.sgx[kx] = gxx;
+                        *reinterpret_cast<float2*>(a.sdO2 + ((size_t)(b * H + yy) * W + xx) * 2) = make_float2(v.x, v.y);
+                    }
+                }
+                *reinterpret_cast<float4*>(&smem[pix * CP]) = v;
+            }
+            // the faces without a cell of their own: v_x column X of this row, v_y row Y (by the workgroup of the last image row)
+            if (tid == 0) {
+                const size_t kx = bx + (size_t)y0 * (W + 1) + W;
+                float g = (a.svx[kx] - a.gtx[kx]) * a.sinv_m / l11;
+                if (a.sginx) g += a.sginx[kx];
+                a.sgx[kx] = g;
+            }
+            if (y0 == H - 1 && tid >= 64 && tid < 64 + W) {
+                const size_t ky = by + (size_t)H * W + (tid - 64);
+                float g = (a.svy[ky] - a.gty[ky]) * a.sinv_m / l00;
+                if (a.sginy) g += a.sginy[ky];
+                a.sgy[ky] = g;
+            }
+        } else
         for (int e = tid; e < npix * C4; e += 256) {
             const int pix = e / C4, c4 = e - pix * C4;
             const int hr = pix / HW, hc = pix - hr * HW;
@@ -1145,6 +1179,28 @@ extern "C" int sol_conv5x5(void* stream, const float* x, const float* packed, co
 
 const void* sol_conv_packed_wsh(const float* packed, int cout) {
     return packed + (size_t)25 * 32 * pad_out(cout) + sol_conv_sb_packed_floats(pad_out(cout));
+}
+
+// The 2 -> 32 backward-data layer of the trainer's reverse sweep with the loss-gradient seed computed in its staging phase (ConvArgs seed
+// fields): y = conv(dO, packed_bwd) * lrelu'(act_ref), dO = out_std * G, G = (v - gt) / (std^2 msteps) (+ gin); writes G and dO2.  W == 64.
+int sol_conv5x5_seed(void* stream, const float* packed_bwd, const float* act_ref, float* y, int B, int H, int W, float slope, unsigned* y_absmax,
+                     const float* vy, const float* vx, const float* gt_vy, const float* gt_vx, const float* gin_vy, const float* gin_vx,
+                     float* g_vy, float* g_vx, float* dO2, float s0, float s1, float l0, float l1, float inv_m) {
+    if (int e = check_shape(B, H, W, 4, 32)) return e;
+    SOL_REQUIRE(W == 64 && packed_bwd && act_ref && y && vy && vx && gt_vy && gt_vx && g_vy && g_vx && dO2 && !gin_vy == !gin_vx, "sol_conv5x5_seed: bad arguments");
+    if (int e = sol_init_conv_kernels()) return e;
+    ConvArgs a{};
+    a.x = nullptr; a.wp = packed_bwd; a.act = act_ref; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.CO = 32; a.CI = 4; a.epi = SOL_EPI_DLRELU; a.slope = slope;
+    a.TW = 64; a.RPW = 1; a.tiles_x = 1;
+    if (sol_opt().conv_precision != 2) a.ymax = y_absmax;
+    a.svy = vy; a.svx = vx; a.gty = gt_vy; a.gtx = gt_vx; a.sginy = gin_vy; a.sginx = gin_vx; a.sgy = g_vy; a.sgx = g_vx; a.sdO2 = dO2;
+    a.cs0 = s0; a.cs1 = s1; a.ls0 = l0; a.ls1 = l1; a.sinv_m = inv_m;
+    size_t lds = (size_t)5 * 68 * 4 * sizeof(float) + (size_t)25 * 32 * 4 * sizeof(float);
+    if (lds < 4 * 16 * 32 * sizeof(float)) lds = 4 * 16 * 32 * sizeof(float);
+    SOL_LAUNCH((k_conv5x5<4, 2>), dim3(B * H), dim3(256), lds, (hipStream_t)stream, a);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
 }
 
 bool sol_conv_correct_fusable(int W, int rows) {

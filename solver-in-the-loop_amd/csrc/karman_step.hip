@@ -1780,9 +1780,15 @@ struct BwPack {
 };
 __global__ void __launch_bounds__(512) k_karman_bwd_bww(StepArgs a, BwPack bw) {
     extern __shared__ __align__(16) float smem[];
+    // timing experiments (option dbg_skip, results invalid; tools/adjoint_split_experiment.py): 4096 = the gradient workgroups end at once (the
+    // adjoint ALONE inside the pipeline, cold operands), 8192 = the adjoint workgroups end at once (the gradient half alone), 2048 = the
+    // gradient workgroups start ~3.4 us late (does the adjoint's load phase recover when it does not queue behind their 24 MB prologue burst?)
     if ((int)blockIdx.x < a.B) {
+        if (a.dbg & 8192) return;
         karman_bwd_body<16, 2>(a, smem);
     } else {
+        if (a.dbg & 4096) return;
+        if (a.dbg & 2048) __builtin_amdgcn_s_sleep(127);
         // XCD-aware job order (workgroup u runs on XCD u % 8): the 32-row blocks of image rows 96x .. 96x+95 -- what XCD x's
         // convolution workgroups wrote (xcd_tile) -- are handed to the gradient workgroups of XCD x, layer after layer
         int idx = (int)blockIdx.x - a.B, job = idx / bw.wg_per, sub = idx % bw.wg_per;

@@ -35,7 +35,7 @@ SolOptions& sol_opt() {
         SolOptions d{};
         d.conv_precision = 0; d.conv_split3 = 0; d.conv_r3 = 1; d.conv_thin = 1; d.conv_bww32 = 1;
         d.correct_fuse = 1; d.bww_fuse = 1; d.bww_chunk = 0; d.bww_side = 1; d.streams = 1;
-        d.density_mode = 0; d.cpt = 0; d.dbg_skip = 0; d.step_prof = 0; d.cnn_persistent = 0; d.graph_stream = 0; d.k3d_tile = 0; d.k3d_fused_tf = 1; d.k3d_conv_fused = 1; d.k3d_conv_rows = 8; d.conv_dx = 11; d.k3d_mfma_tf = 1; d.conv_thin_valu = 1;
+        d.density_mode = 0; d.cpt = 0; d.dbg_skip = 0; d.step_prof = 0; d.cnn_persistent = 0; d.graph_stream = 0; d.k3d_tile = 0; d.k3d_fused_tf = 1; d.k3d_conv_fused = 1; d.k3d_conv_rows = 8; d.conv_dx = 11; d.k3d_mfma_tf = 1; d.conv_thin_valu = 1; d.seed_fuse = 1;
         return d;
     }();
     return o;
@@ -52,6 +52,7 @@ const OptName OPT_NAMES[] = {
     {"step_prof", &SolOptions::step_prof, 0, 1}, {"cnn_persistent", &SolOptions::cnn_persistent, 0, 1},
     {"graph_stream", &SolOptions::graph_stream, 0, 1}, {"k3d_tile", &SolOptions::k3d_tile, 0, 1}, {"k3d_fused_tf", &SolOptions::k3d_fused_tf, 0, 1}, {"k3d_conv_fused", &SolOptions::k3d_conv_fused, 0, 1}, {"k3d_conv_rows", &SolOptions::k3d_conv_rows, 3, 8},
     {"conv_dx", &SolOptions::conv_dx, 0, 15}, {"conv_thin_valu", &SolOptions::conv_thin_valu, 0, 2}, {"k3d_mfma_tf", &SolOptions::k3d_mfma_tf, 0, 1},
+    {"seed_fuse", &SolOptions::seed_fuse, 0, 1},
 };
 }  // namespace
 
@@ -684,10 +685,6 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         const float* vycur = w.vy + (size_t)i * w.st_vy;
         const float* vxcur = w.vx + (size_t)i * w.st_vx;
         float* dO2 = w.dO2 + (size_t)i * w.cells * 2;
-        SOL_LAUNCH(k_seed, dim3(egrid), dim3(256), 0, hs, gvy, gvx, vycur, vxcur,
-                           gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx,
-                           out_s0(c), out_s1(c), c->std_v0, c->std_v1, 1.f / (float)ms, w.dO4, dO2, i == ms - 1 ? 1 : 0, B, Y, X, tr ? 1 : 0);
-        SOL_LAUNCH_CHECK();
         const float* act[11];
         float* D[11];
         for (int k = 0; k < 11; ++k) {
@@ -696,7 +693,23 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         }
         uint32_t* amd = w.amax_dz + (size_t)i * 11 * SOL_AMAX_SLOTS;
         auto am = [&](int k) { return amd + (size_t)k * SOL_AMAX_SLOTS; };
-        if (int e = sol_conv5x5_scaled(stream, w.dO4, wn.wb[11], nullptr, nullptr, act[10], D[10], B, cY, cX, 4, 32, SOL_EPI_DLRELU, sl, nullptr, am(10))) return e;
+        // Round 6: on 64-pixel rows the loss-gradient seed is computed by the 2 -> 32 backward-data launch itself (sol_conv5x5_seed): it reads the
+        // adjoint output of step i+1 from gvy[cur] and writes G = d loss / d v_i into gvy[cur ^ 1] (whose previous content, G of step i+1,
+        // the adjoint launch of step i+1 has consumed) -- one launch less per unrolled step.  Otherwise: k_seed, in place on gvy[cur].
+        const bool seed_fused = !tr && cX == 64 && sol_opt().seed_fuse;
+        if (seed_fused) {
+            if (int e = sol_conv5x5_seed(stream, wn.wb[11], act[10], D[10], B, cY, cX, sl, am(10), vycur, vxcur, gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx,
+                                         i == ms - 1 ? nullptr : w.gvy[cur], i == ms - 1 ? nullptr : w.gvx[cur], w.gvy[cur ^ 1], w.gvx[cur ^ 1], dO2,
+                                         out_s0(c), out_s1(c), c->std_v0, c->std_v1, 1.f / (float)ms)) return e;
+            gvy = w.gvy[cur ^ 1];
+            gvx = w.gvx[cur ^ 1];
+        } else {
+            SOL_LAUNCH(k_seed, dim3(egrid), dim3(256), 0, hs, gvy, gvx, vycur, vxcur,
+                               gt_vy + (size_t)i * gVy, gt_vx + (size_t)i * gVx,
+                               out_s0(c), out_s1(c), c->std_v0, c->std_v1, 1.f / (float)ms, w.dO4, dO2, i == ms - 1 ? 1 : 0, B, Y, X, tr ? 1 : 0);
+            SOL_LAUNCH_CHECK();
+            if (int e = sol_conv5x5_scaled(stream, w.dO4, wn.wb[11], nullptr, nullptr, act[10], D[10], B, cY, cX, 4, 32, SOL_EPI_DLRELU, sl, nullptr, am(10))) return e;
+        }
         if (sol_cnn_chain_usable(B, cY, cX)) {
             // the ten backward-data convolutions as ONE persistent launch
             ChainLayer L[10];
@@ -739,7 +752,9 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         BwArgs jobs[10];
         if (fuse) {       // this step's dz tensors are complete: one job per 32 -> 32 layer
             for (int l = 1; l <= 10; ++l)
-                if (int e = sol_bww_step_job(&jobs[l - 1], act[l - 1], D[l], w.part[l], i == ms - 1 ? 1 : 0, B, cY, cX, FRB,
+                // (dbg_skip & 1024, timing experiment, results invalid: every step OVERWRITES its partial slice -- the launch without the
+                //  read of the old partials = the upper bound of what accumulators kept resident across the steps could save)
+                if (int e = sol_bww_step_job(&jobs[l - 1], act[l - 1], D[l], w.part[l], (i == ms - 1 || (sol_opt().dbg_skip & 1024)) ? 1 : 0, B, cY, cX, FRB,
                                              w.amax_act + ((size_t)i * 11 + (l - 1)) * SOL_AMAX_SLOTS, am(l))) return e;
         }
         SolDensRide ride{};
@@ -753,10 +768,10 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
             const float* dF = w.dF;
             FeatOrder feat_order(tr);       // the adjoint reads the feature gradient in the CNN's (transposed) cell order
             if (int e = sol_karman_step_bwd_fused(kc, stream, w.svy + (size_t)i * w.st_vy, w.svx + (size_t)i * w.st_vx, re, io.active,
-                                                  bcm, io.bc_stride, gvy, gvx, dF, fscale, w.gvy[cur ^ 1], w.gvx[cur ^ 1],
+                                                  bcm, io.bc_stride, gvy, gvx, dF, fscale, seed_fused ? w.gvy[cur] : w.gvy[cur ^ 1], seed_fused ? w.gvx[cur] : w.gvx[cur ^ 1],
                                                   io.iters_bwd ? io.iters_bwd + (size_t)i * Btot + b0 : nullptr,
                                                   jobs, fuse ? 10 : 0, wg_per, dens_ride_bwd ? &ride : nullptr)) return e;
-            cur ^= 1;
+            if (!seed_fused) cur ^= 1;        // (seed fused: G lives in gvy[cur ^ 1], the adjoint's output goes back to gvy[cur] -- no toggle)
         } else if (fuse) {
             if (int e = sol_bww_jobs_launch(stream, jobs, 10, wg_per, kc, dens_ride_bwd ? &ride : nullptr)) return e;     // step 0 has no adjoint to ride with
         }
