@@ -200,19 +200,39 @@ def timed_steps(wl, lr, steps, warmup, barrier, trainer=None, per_step=False):
     for _ in range(warmup):
         trace.append(float(wl.step(lr, trainer)))
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step else None
+    stamps = None
+    if per_step:
+        import ctypes as C
+        import sol_amd
+        stamps = torch.zeros(steps + 1, 32, dtype=torch.int32, device=wl.d0.device)      # per XCD (s_memtime, s_memrealtime) in front of every step and behind the last
+        lib, strm = sol_amd._lib.load(), sol_amd._lib.stream
+        stamp = lambda i: sol_amd._lib.check(lib.sol_clock_stamp(strm(), C.c_void_p(stamps.data_ptr() + 128 * i)))
+        stamp(0)                                                                           # (code object load outside the timed region)
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         if evs:
             evs[i].record()
+            stamp(i)
         loss = wl.step(lr, trainer)
     if evs:
         evs[steps].record()
+        stamp(steps)
     barrier()
     sec = time.perf_counter() - t0
     if per_step:
+        w = stamps.cpu().numpy().view("uint64").reshape(steps + 1, 8, 2).astype("float64")
+        ok = [x for x in range(8) if all(w[i, x, 1] > 0 for i in range(steps + 1))]                      # XCDs that took every stamp
+        mhz = lambda a, b, x: (w[b, x, 0] - w[a, x, 0]) / max(w[b, x, 1] - w[a, x, 1], 1.0) * 100.0
+        if ok:
+            per_xcd = [mhz(0, steps, x) for x in ok]
+            clk = [sum(mhz(i, i + 1, x) for x in ok) / len(ok) for i in range(steps)]                      # MHz per step, mean over the XCDs
+            CLOCK_DURING.update(mhz_mean=sum(per_xcd) / len(per_xcd), mhz_min_step=min(clk), mhz_max_step=max(clk), mhz_per_xcd=[round(v, 1) for v in per_xcd], xcds=ok)
         return sec, float(loss), trace, [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
     return sec, float(loss), trace
+
+
+CLOCK_DURING = {}      # average shader clock of the timed region (sol_clock_stamp brackets), filled by timed_steps(per_step=True)
 
 
 def _quantile(v, q):
@@ -342,6 +362,14 @@ def device_state(sol_amd, dev, iters=4000000):
             b.record()
             torch.cuda.synchronize()
         out["copy_GBps_256MB"] = 4 * 2 * big[0].numel() * 4 / (a.elapsed_time(b) * 1e-3) / 1e9
+        # (f) dependent-load latency: one lane walking a 64 MB (memory-side cache) and a 512 MB (HBM) working set of the same zero-filled buffer
+        big.zero_()
+        res = torch.zeros(8, dtype=torch.int32, device=dev)
+        for key, nlines in (("load_latency_ns_64MB", 1 << 19), ("load_latency_ns_512MB", 1 << 22)):
+            sol_amd._lib.check(lib.sol_latency_probe(sol_amd._lib.stream(), C.c_void_p(big.data_ptr()), nlines, 20000, C.c_void_p(res.data_ptr())))
+            torch.cuda.synchronize()
+            w = res.cpu().numpy().view("uint64")
+            out[key] = float(w[0]) * 10.0 / float(w[1])
         del big
     except Exception as e:
         out["dispatch_probe_error"] = str(e)
@@ -799,6 +827,11 @@ def main():
             ],
             "loss": loss, "loss_warmup": trace,
             "step_time_distribution_ms": step_distribution(per_step_ms),
+            # the shader clock the device HELD during the timed steps (s_memtime / s_memrealtime stamps in front of every step): boxes of this pool
+            # run the same build at 11.8 .. 12.8 ms per step with identical idle / probe clocks; this is the number that moves with them
+            "shader_clock_during_timed_steps": dict(CLOCK_DURING, note="100 MHz x d(s_memtime) / d(s_memrealtime) between stamp kernels on the launch stream; "
+                                                    "ms_per_step x mhz_mean / 2400 = the step time normalised to a 2.4 GHz clock",
+                                                    ms_per_step_at_2400_mhz=(ms_per_step * CLOCK_DURING["mhz_mean"] / 2400.0) if CLOCK_DURING.get("mhz_mean") else None),
             "device_state_before": state_before, "device_state_after": state_after,
             "roofline": roof_conv if roof_conv and (not roof_solver or cst["total_us"] >= sst["total_us"]) else roof_solver,
             "roofline_solver_step": roof_solver,

@@ -335,6 +335,14 @@ int sol_copy_words(void* stream, void* dst, const void* src, int64_t nwords);
  *                     {duration in 10 ns ticks (s_memrealtime), duration in s_memtime ticks, iters, 0}.  ns per dependent MFMA follows
  *                     the engine clock the device holds under matrix load: it tells a slow box from a slower kernel.                  */
 int sol_clock_probe(void* stream, uint64_t* out4, int32_t iters);
+/*   sol_clock_stamp   out16 (device, zero it first) [xcd] = {s_memtime, s_memrealtime} of XCD `xcd` (0..7) at this point of the stream (every XCD
+ *                     has its own counter).  Two stamps around a region give the AVERAGE shader clock the device held while the region ran:
+ *                     100 MHz x d(memtime) / d(memrealtime) per XCD (gfx950: s_memtime counts engine clocks).  bench.py brackets its timed steps.  */
+int sol_clock_stamp(void* stream, uint64_t* out16);
+/*   sol_latency_probe measurement aid (bench.py): one lane walks `steps` dependent loads through a ZERO-FILLED device buffer of `nlines` 128-byte
+ *                     lines (a power of two) in a pseudo-random order; out4 (device) = {duration in 10 ns ticks, steps, last index, -}.  ns per
+ *                     load = the memory round trip a kernel's first loads pay (the L2 is invalid at every kernel boundary).                   */
+int sol_latency_probe(void* stream, const uint32_t* buf, int64_t nlines, int32_t steps, uint64_t* out4);
 int sol_graph_census(void* graph, int32_t* counts, int32_t ncounts);
 int sol_graph_check(void* graph, const char* what);
 const char* sol_graph_node_type_name(int32_t type);

@@ -88,6 +88,8 @@ _SIGS = {
     "sol_train_graph_destroy": (C.c_int, [_P]),
     "sol_copy_words": (C.c_int, [_P, _P, _P, C.c_int64]),
     "sol_clock_probe": (C.c_int, [_P, _P, C.c_int32]),
+    "sol_clock_stamp": (C.c_int, [_P, _P]),
+    "sol_latency_probe": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "sol_graph_census": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32]),
     "sol_graph_check": (C.c_int, [_P, C.c_char_p]),
     "sol_graph_node_type_name": (C.c_char_p, [C.c_int32]),
@@ -130,7 +132,7 @@ def lib_path():
     return _build.LIB
 
 
-ABI_VERSION = 213     # sol_version() of the library these bindings were written against
+ABI_VERSION = 214     # sol_version() of the library these bindings were written against
 
 # Debugging overrides: environment variable -> (option, value).  Read ONCE here, in Python, when the library is loaded;
 # the library itself never reads the environment (options are set through sol_set_option, include/sol_hip.h).

@@ -20,7 +20,7 @@ int sol_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* sol_last_error(void) { return g_sol_err; }
-extern "C" int sol_version(void) { return 213; }
+extern "C" int sol_version(void) { return 214; }
 // sizes of the ABI structs: the ctypes mirror in _lib.py checks them at load time
 extern "C" int sol_abi_sizes(int32_t* karman_cfg, int32_t* burgers_cfg, int32_t* train_cfg) {
     if (karman_cfg) *karman_cfg = (int32_t)sizeof(sol_karman_cfg);
@@ -298,6 +298,45 @@ __global__ void __launch_bounds__(256) k_clock_probe(unsigned long long* out, in
     if (acc[0] == 1.2345e-30f) out[3] = 1;      // never true: keeps the chain alive
 }
 }  // namespace
+// Memory-latency probe: ONE lane walks `steps` dependent 4-byte loads through a zero-filled buffer of `nlines` 128-byte lines (power of two) in a
+// pseudo-random (LCG) order -- every load's address depends on the previous load's value.  ns per load = the round trip a kernel's FIRST
+// loads pay (L2 is invalid at every kernel boundary): working sets of 64 MB / 1 GB answer "MALL hit" / "HBM".
+__global__ void __launch_bounds__(64) k_latency_probe(const unsigned* __restrict__ buf, unsigned nlines_mask, int steps, unsigned long long* out) {
+    if (threadIdx.x != 0) return;
+    unsigned idx = 12345u & nlines_mask;
+    const unsigned long long t0 = wall_clock64();
+    for (int i = 0; i < steps; ++i) {
+        const unsigned v = __builtin_nontemporal_load(buf + (size_t)idx * 32);
+        idx = (idx * 1664525u + 1013904223u + v) & nlines_mask;
+    }
+    const unsigned long long t1 = wall_clock64();
+    out[0] = t1 - t0; out[1] = (unsigned long long)steps; out[2] = idx;
+}
+extern "C" int sol_latency_probe(void* stream, const uint32_t* buf, int64_t nlines, int32_t steps, uint64_t* out4) {
+    SOL_REQUIRE(buf && out4 && nlines >= 2 && (nlines & (nlines - 1)) == 0 && nlines <= (1ll << 31) && steps >= 1, "sol_latency_probe: buf (zero filled, nlines x 128 B, nlines a power of two), steps >= 1");
+    SOL_LAUNCH(k_latency_probe, dim3(1), dim3(64), 0, (hipStream_t)stream, buf, (unsigned)(nlines - 1), steps, reinterpret_cast<unsigned long long*>(out4));
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+// (s_memtime, s_memrealtime) at this point of the stream: two stamps bracket a region whose AVERAGE shader clock is then
+// 100 MHz x d(memtime) / d(memrealtime) -- the clock the device actually held while the region's kernels ran (bench.py: the timed steps)
+// (every XCD has its own s_memtime counter with its own offset: the stamp is taken once per XCD -- 32 workgroups are dealt round robin to the
+//  eight of them -- and filed under the XCD's id, so that differences are formed between stamps of ONE counter)
+__global__ void k_clock_stamp(unsigned long long* out16) {
+    if (threadIdx.x == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7u;
+        out16[2 * xcc] = clock64();
+        out16[2 * xcc + 1] = wall_clock64();
+    }
+}
+extern "C" int sol_clock_stamp(void* stream, uint64_t* out16) {
+    SOL_REQUIRE(out16 != nullptr, "sol_clock_stamp: out16 (device, sixteen 64-bit words: {s_memtime, s_memrealtime} per XCD)");
+    SOL_LAUNCH(k_clock_stamp, dim3(32), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(out16));
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
 extern "C" int sol_clock_probe(void* stream, uint64_t* out4, int32_t iters) {
     SOL_REQUIRE(out4 && iters >= 1 && iters <= (1 << 24), "sol_clock_probe: out4 (device, four 64-bit words), 1 <= iters <= 2^24");
     SOL_LAUNCH(k_clock_probe, dim3(256), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(out4), iters, 0.3f);

@@ -1,27 +1,37 @@
 #!/bin/bash
-# Round-5 measurement artefacts (same recipe as rounds 3 and 4), run ON THE GPU BOX (gpurun -- 'bash tools/collect_profiles.sh'):
-#   1. bench.py line (unprofiled)                                   -> gpurun_out/r5prof/bench.json
+# Round-6 measurement artefacts (same recipe as rounds 3 to 5), run ON THE GPU BOX (gpurun -- 'bash tools/collect_profiles.sh'):
+#   1. bench.py line (unprofiled)                                   -> gpurun_out/r6prof/bench.json
 #   2. rocprofv3 --kernel-trace --stats of the SAME bench command   -> kernel_stats.txt (tools/rocpd_stats.py)
 #   3. PMC passes, one counter set each (FETCH_SIZE / WRITE_SIZE cannot share a pass; --pmc never combined with other
-#      trace domains): HBM traffic per launch -> r05_pmc_traffic.json (with the library's source hash), and the SQ
+#      trace domains): HBM traffic per launch -> r06_pmc_traffic.json (with the library's source hash), and the SQ
 #      counters of the conv / solver kernels -> pmc_sq.txt
-# Copy what is to be judged from gpurun_out/r5prof/ into profiles/ afterwards.
+# Copy what is to be judged from gpurun_out/r6prof/ into profiles/ afterwards.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$R/gpurun_out/r5prof
+OUT=$R/gpurun_out/r6prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
 ARGS="--steps 20 --warmup 5"
 [ "${1:-}" = "--2d-only" ] && ARGS="--steps 10 --warmup 3 --no-cpu-baseline"
+if [ "${1:-}" = "--pmc-only" ]; then      # the counter passes of the 2-D step alone (after a source change: the traffic file is tied to the build)
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o pmc -- python $R/bench.py --steps 3 --warmup 1 --prewarm 0 --no-extras --no-cpu-baseline --no-device-state > /dev/null 2>>$OUT/rocprof.err
+    python $R/tools/pmc_summary.py $OUT/pmc_$C "" --json $OUT/r06_pmc_traffic.json > $OUT/pmc_$C.txt
+  done
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F16 \
+    --output-format csv -d $OUT/pmc_sq -o pmc -- python $R/bench.py --steps 3 --warmup 1 --prewarm 0 --no-extras --no-cpu-baseline --no-device-state > /dev/null 2>>$OUT/rocprof.err
+  python $R/tools/pmc_summary.py $OUT/pmc_sq "k_" > $OUT/pmc_sq.txt
+  rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq; ls -la $OUT; exit 0
+fi
 python $R/bench.py $ARGS 2>$OUT/bench.err | tail -1 > $OUT/bench.json
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $R/bench.py $ARGS > $OUT/bench_under_rocprof.json 2>$OUT/rocprof.err
 DB=$(find $OUT/trace -name "*.db" | head -1)
 if [ -n "$DB" ]; then python $R/tools/rocpd_stats.py "$DB" > $OUT/kernel_stats.txt; else ls -R $OUT/trace > $OUT/kernel_stats.txt; fi
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline > /dev/null 2>>$OUT/rocprof.err
-  python $R/tools/pmc_summary.py $OUT/pmc_$C "" --json $OUT/r05_pmc_traffic.json > $OUT/pmc_$C.txt
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o pmc -- python $R/bench.py --steps 3 --warmup 1 --prewarm 0 --no-extras --no-cpu-baseline --no-device-state > /dev/null 2>>$OUT/rocprof.err
+  python $R/tools/pmc_summary.py $OUT/pmc_$C "" --json $OUT/r06_pmc_traffic.json > $OUT/pmc_$C.txt
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F16 \
-  --output-format csv -d $OUT/pmc_sq -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline > /dev/null 2>>$OUT/rocprof.err
+  --output-format csv -d $OUT/pmc_sq -o pmc -- python $R/bench.py --steps 3 --warmup 1 --prewarm 0 --no-extras --no-cpu-baseline --no-device-state > /dev/null 2>>$OUT/rocprof.err
 python $R/tools/pmc_summary.py $OUT/pmc_sq "k_" > $OUT/pmc_sq.txt
 if [ "${1:-}" = "--2d-only" ]; then rm -rf $OUT/trace $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq; ls -la $OUT; exit 0; fi     # (the karman-3d passes take ten minutes of box time)
 # karman-3d: kernel trace + HBM counters of the forward roll-out and one training step
