@@ -132,7 +132,7 @@ def lib_path():
     return _build.LIB
 
 
-ABI_VERSION = 214     # sol_version() of the library these bindings were written against
+ABI_VERSION = 215     # sol_version() of the library these bindings were written against
 
 # Debugging overrides: environment variable -> (option, value).  Read ONCE here, in Python, when the library is loaded;
 # the library itself never reads the environment (options are set through sol_set_option, include/sol_hip.h).

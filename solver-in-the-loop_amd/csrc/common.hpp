@@ -140,7 +140,10 @@ int sol_karman_step_fwd_dens(const sol_karman_cfg* cfg, void* stream,
                              const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
                              float* vy_out, float* vx_out, float* saved_vy, float* saved_vx,
                              float* feat_out, const float* feat_scale, int32_t* iters,
-                             const float* dens_d_in, const float* dens_svy, const float* dens_svx, float* dens_d_out);
+                             const float* dens_d_in, const float* dens_svy, const float* dens_svx, float* dens_d_out, uint32_t* xchg = nullptr);
+// band-split forward launch (k_karman_fwd_bands: four workgroups per simulation): usable for this configuration? / words of its hand-off region
+int sol_karman_fwd_bands_usable(const sol_karman_cfg* cfg);
+size_t sol_karman_fwd_bands_words(int B);
 int sol_density_step(const sol_karman_cfg* c, void* stream, const float* d_in, const float* svy, const float* svx, const float* inflow, float* d_out);
 int sol_bww_jobs_launch(void* stream, const BwArgs* bw, int nbw, int wg_per, const sol_karman_cfg* cfg = nullptr, const SolDensRide* dens = nullptr);
 // weight-gradient job description for one layer of ONE unrolled step with `rb` rows per workgroup (train.hip -> fused launch)
@@ -205,6 +208,8 @@ struct SolOptions {
                           //    layer's data gradient) in exact fp32 on the vector ALU (conv5x5_thin.hip: no absmax wait, no operand split); 0: k_conv5x5_sb<1, KIND>
     int seed_fuse;        // 1 (default): on 64-pixel rows the trainer's loss-gradient seed is computed inside the 2 -> 32 backward-data launch (sol_conv5x5_seed)
                           //    instead of a k_seed launch per unrolled step
+    int fwd_bands;        // 1 (default): the 128 x 64 forward solver step of the training / roll-out path as FOUR workgroups per simulation (k_karman_fwd_bands:
+                          //    stencil phases on row bands with recomputed halos, the direct solve on band 0's CU, two hand-offs through global memory); 0: one workgroup
     int k3d_tile;         // 1: karman-3d advection from LDS tiles holding the full z column + halo; 0 (default, measured faster at B <= 2): wave-per-column gathers from global memory
 };
 SolOptions& sol_opt();

@@ -673,6 +673,8 @@ __device__ __forceinline__ void fd_load_qys(const float* __restrict__ Qy, int w,
 
 // rhs in rf[] (strip layout: rows 16*wave + k, column lane); returns the solution as a [128][64] LDS array (inside buf,
 // complete for every thread).  buf = 2*FD_BUF floats of LDS.
+// RHS_STAGED: the caller has written the right-hand side into buf as [128][FD_LD] itself (k_karman_fwd_bands); rf is then unused
+template <bool RHS_STAGED = false>
 __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const float (&qys)[FD_QYS], float* buf, const float (&rf)[16], long long* prof) {
 #define FD_STAMP(i) do { if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[i] = wall_clock64(); } while (0)
     const FdView F = fd_view(blob);
@@ -699,8 +701,10 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
     }
 
     // ---- forward transform: T2 = (Qy b Qx) / lam ---------------------------------------
+    if constexpr (!RHS_STAGED) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) B0[(16 * w + k) * FD_LD + lane] = rf[k];
+        for (int k = 0; k < 16; ++k) B0[(16 * w + k) * FD_LD + lane] = rf[k];
+    }
 #if SOL_FD_MFMA
     float bx[32];
     fd_load_bx(F.Qx, w, bx);             // x-transform operand + the eigenvalue reciprocals: in flight behind the y transform
@@ -1450,6 +1454,294 @@ __global__ void __launch_bounds__(512) k_karman_fwd_dens(StepArgs a, DensStep q)
 __global__ void __launch_bounds__(512) k_density_step(DensStep q) { density_step_body(q, blockIdx.x); }
 
 // ------------------------------------------------------------------------------------
+// forward, 128 x 64, direct solver: FOUR workgroups per simulation (round 6)
+// ------------------------------------------------------------------------------------
+// The stencil phases of the one-workgroup kernel (load, diffusion + BC, advection, divergence, projection, outputs: 28 of its 44 us at
+// B = 6) are bound by the vector ALU of ONE compute unit -- 2 waves per SIMD run ~100 instructions per face -- while 250 CUs idle.  Here a
+// simulation is cut into BD_N bands of BD_R cell rows; every band's workgroup recomputes the diffusion on BD_HA halo rows each side
+// (departure points of the semi-Lagrangian step are then band local for |u| dt / dx < BD_HA; a face whose departure point lies outside the
+// halo is POISONED with NaN -- the loss of the step reads NaN -- instead of being clamped silently), advects its faces and forms its rows
+// of the divergence.  Two hand-offs through global memory: the divergence rows of bands 1.. go to band 0's workgroup, which runs the
+// direct solve on its CU as before (the transforms couple every cell with every other: DESIGN_HISTORY section 8 prices their split) and
+// sends every band the pressure rows its projection needs.  "The data is the flag" (cdna_hip_programming.md, guideline 16): a word is
+// stored as bits ^ BD_KEY with write-through (sc1) stores and the exchange region holds zeros otherwise, so the consumer polls its own
+// 16-byte pieces with sc1 loads until no word is zero (bits == BD_KEY is a NaN payload no arithmetic produces), decodes, and restores the
+// zeros for the next launch -- no flag, no fence, no drain.  A band that never arrives (spin limit) leaves NaNs, not stale numbers.
+// Workgroup u = 32 g + 8 w + (b & 7) for simulation b = 8 g + (b & 7), band w: the four workgroups of a simulation run on ONE XCD
+// (workgroups are dealt round robin to the eight XCDs) and meet in its L2; correctness does not depend on it (sc1 = agent scope).
+// Arithmetic, operation order and therefore every output bit equal the one-workgroup kernel's (tests/test_gpu_parity.py).
+constexpr int BD_N = 4, BD_R = FD_Y / BD_N, BD_HA = 8, BD_PROWS = BD_R + 1;
+constexpr unsigned BD_KEY = 0x7fc0deadu;
+constexpr int BD_DIV_WORDS = FD_Y * FD_X, BD_P_WORDS = (BD_N - 1) * BD_PROWS * FD_X, BD_WORDS = BD_DIV_WORDS + BD_P_WORDS;
+constexpr unsigned BD_SPIN_LIMIT = 1u << 15;
+__device__ __forceinline__ uint4 bd_load(const __amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));      // aux 16 = sc1: agent scope, misses the vector L1
+}
+__device__ __forceinline__ void bd_store(const __amdgpu_buffer_rsrc_t r, int byte_off, const uint4& v) {
+    typedef unsigned bd_u4 __attribute__((ext_vector_type(4)));
+    const bd_u4 q = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(q, r, byte_off, 0, 16);
+}
+__device__ __forceinline__ bool bd_valid(const uint4& v) { return v.x != 0u && v.y != 0u && v.z != 0u && v.w != 0u; }
+__device__ __forceinline__ float4 bd_decode(const uint4& v) {
+    return make_float4(__uint_as_float(v.x ^ BD_KEY), __uint_as_float(v.y ^ BD_KEY), __uint_as_float(v.z ^ BD_KEY), __uint_as_float(v.w ^ BD_KEY));
+}
+__device__ __forceinline__ uint4 bd_encode(const float4& v) {
+    return make_uint4(__float_as_uint(v.x) ^ BD_KEY, __float_as_uint(v.y) ^ BD_KEY, __float_as_uint(v.z) ^ BD_KEY, __float_as_uint(v.w) ^ BD_KEY);
+}
+// poll NQ 16-byte pieces (byte offsets off[], piece n wanted iff on[n]) until every word of every wanted piece of the WAVE is there
+template <int NQ>
+__device__ __forceinline__ void bd_recv(const __amdgpu_buffer_rsrc_t r, const int (&off)[NQ], const bool (&on)[NQ], uint4 (&v)[NQ]) {
+    unsigned spins = 0;
+    for (;;) {
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) v[n] = bd_load(r, off[n]);
+        bool ok = true;
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) ok = ok && (!on[n] || bd_valid(v[n]));
+        if (__all(ok) || ++spins > BD_SPIN_LIMIT) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+__device__ __forceinline__ void karman_fwd_band_body(const StepArgs& a, float* smem, const int b, const int w, unsigned* xw) {
+    constexpr int Y = FD_Y, X = FD_X, XP = X + 1, N = Y * X, nVy = (Y + 1) * X, nVx = Y * XP, nthr = 512, lx = 6;
+    const int tid = threadIdx.x;
+    const float invXP = 1.f / (float)XP;
+    const Lds L = carve(smem, Y, X, 16);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(xw, 0, BD_WORDS * 4, 0x00020000);
+    // row ranges of this band (cells c0 .. c1-1)
+    const int c0 = w * BD_R, c1 = c0 + BD_R;
+    const int fy1 = w == BD_N - 1 ? Y + 1 : c1;                                  // owned v_y face rows [c0, fy1)
+    const int ay1 = min(c1 + 1, Y + 1);                                          // advected v_y rows [c0, ay1): the divergence of row c1-1 needs face row c1
+    const int dy0 = max(c0 - BD_HA, 0), dy1 = min(c1 + BD_HA + 1, Y + 1);        // diffused v_y rows
+    const int dx0 = max(c0 - BD_HA, 0), dx1 = min(c1 + BD_HA, Y);                // diffused v_x rows
+    const int ly0 = max(dy0 - 1, 0), ly1 = min(dy1 + 1, Y + 1);                  // loaded rows
+    const int lx0 = max(dx0 - 1, 0), lx1 = min(dx1 + 1, Y);
+    const int m0 = max(c0 - 1, 0), m1 = min(c1 + 1, Y);                          // mask rows
+
+    SOL_STAMP(0);
+    float fdp = 0.f;
+    if (w == 0) fdp = fd_prefetch(a.fd, a.fd_n);
+    // ---- phase 1: load (16-byte pieces, all requests in flight before the first LDS store) ----
+    constexpr int NV = 2;                       // <= 51 rows x 16 quads (v_y), <= 50 rows x 65 floats (v_x): at most 816 quads each
+    float4 bcv_r[NV], bcm_r[NV];
+    const int qy0 = ly0 * (X / 4), qy1 = ly1 * (X / 4);
+    const int qx0 = (lx0 * XP) >> 2, qx1 = min((lx1 * XP + 3) >> 2, nVx >> 2);
+    const int qd0 = dy0 * (X / 4), qd1 = dy1 * (X / 4);
+    const int qm0 = m0 * (X / 4), qm1 = m1 * (X / 4);
+    {
+        const float4* gvy = reinterpret_cast<const float4*>(a.vy_in + (size_t)b * nVy);
+        const float4* gvx = reinterpret_cast<const float4*>(a.vx_in + (size_t)b * nVx);
+        const float4* bcv = reinterpret_cast<const float4*>(a.bcv + (size_t)b * a.bc_stride);
+        const float4* bcm = reinterpret_cast<const float4*>(a.bcm + (size_t)b * a.bc_stride);
+        const float4* gact = reinterpret_cast<const float4*>(a.active);
+        float4 ty[NV], tx[NV], ta[NV];
+#pragma unroll
+        for (int n = 0; n < NV; ++n) { ty[n] = gvy[min(qy0 + tid + n * nthr, qy1 - 1)]; tx[n] = gvx[min(qx0 + tid + n * nthr, qx1 - 1)]; }
+#pragma unroll
+        for (int n = 0; n < NV; ++n) ta[n] = gact[min(qm0 + tid + n * nthr, qm1 - 1)];
+#pragma unroll
+        for (int n = 0; n < NV; ++n) { const int q = min(qd0 + tid + n * nthr, qd1 - 1); bcv_r[n] = bcv[q]; bcm_r[n] = bcm[q]; }
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int qy = qy0 + tid + n * nthr, qx = qx0 + tid + n * nthr, qm = qm0 + tid + n * nthr;
+            if (qy < qy1) reinterpret_cast<float4*>(L.Avy)[qy] = ty[n];
+            if (qx < qx1) reinterpret_cast<float4*>(L.Avx)[qx] = tx[n];
+            if (qm < qm1) reinterpret_cast<uchar4*>(L.act)[qm] = make_uchar4(ta[n].x != 0.f, ta[n].y != 0.f, ta[n].z != 0.f, ta[n].w != 0.f);
+        }
+    }
+    __syncthreads();
+    SOL_STAMP(1);
+
+    // ---- phase 2: explicit diffusion + velocity BC on the band and its halo ----
+    {
+        const float alpha = a.adt / a.re[b];
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int q = qd0 + tid + n * nthr;
+            if (q >= qd1) continue;
+            const int k = q << 2, j = k >> lx, i = k & (X - 1);
+            const float4 c = reinterpret_cast<const float4*>(L.Avy)[q];
+            const float4 up = *reinterpret_cast<const float4*>(&L.Avy[min(j + 1, Y) * X + i]);
+            const float4 dn = *reinterpret_cast<const float4*>(&L.Avy[max(j - 1, 0) * X + i]);
+            const float rt = L.Avy[j * X + min(i + 4, X - 1)], lf = L.Avy[j * X + max(i - 1, 0)];
+            float4 v;
+            v.x = c.x + alpha * (up.x + dn.x + c.y + lf - 4.f * c.x);
+            v.y = c.y + alpha * (up.y + dn.y + c.z + c.x - 4.f * c.y);
+            v.z = c.z + alpha * (up.z + dn.z + c.w + c.y - 4.f * c.z);
+            v.w = c.w + alpha * (up.w + dn.w + rt + c.z - 4.f * c.w);
+            v.x = v.x * (1.f - bcm_r[n].x) + bcv_r[n].x; v.y = v.y * (1.f - bcm_r[n].y) + bcv_r[n].y;
+            v.z = v.z * (1.f - bcm_r[n].z) + bcv_r[n].z; v.w = v.w * (1.f - bcm_r[n].w) + bcv_r[n].w;
+            reinterpret_cast<float4*>(L.Bvy)[q] = v;
+            if (a.saved_vy && j >= c0 && j < fy1) reinterpret_cast<float4*>(a.saved_vy + (size_t)b * nVy)[q] = v;
+        }
+        #pragma unroll 4
+        for (int k = dx0 * XP + tid; k < dx1 * XP; k += nthr) {
+            const int j = (int)(((float)k + 0.5f) * invXP), i = k - j * XP;
+            const float c = L.Avx[k];
+            const float lap = L.Avx[min(j + 1, Y - 1) * XP + i] + L.Avx[max(j - 1, 0) * XP + i] +
+                              L.Avx[j * XP + min(i + 1, X)] + L.Avx[j * XP + max(i - 1, 0)] - 4.f * c;
+            const float v = c + alpha * lap;
+            L.Bvx[k] = v;
+            if (a.saved_vx && j >= c0 && j < c1) a.saved_vx[(size_t)b * nVx + k] = v;
+        }
+    }
+    __syncthreads();
+    SOL_STAMP(2);
+
+    // ---- phase 3: semi-Lagrangian advection (B -> A) of the band's faces, hard-BC face mask fused ----
+    const float poison = __uint_as_float(0x7fc00000u);
+    #pragma unroll 4
+    for (int k = c0 * X + tid; k < ay1 * X; k += nthr) {
+        const int j = k >> lx, i = k & (X - 1);
+        const float uy = L.Bvy[k];
+        const int ja = max(j - 1, 0), jb = min(j, Y - 1);
+        const float ux = 0.25f * (L.Bvx[ja * XP + i] + L.Bvx[ja * XP + i + 1] + L.Bvx[jb * XP + i] + L.Bvx[jb * XP + i + 1]);
+        const Bil s = bil_clamp(Y + 1, X, j, -uy * a.dtdx, i, -ux * a.dtdx);
+        const float v = bil_eval(L.Bvy, X, s) * mask_y(L.act, Y, X, j, i);
+        L.Avy[k] = (s.j0 >= dy0 && s.j1 < dy1) ? v : poison;
+    }
+    #pragma unroll 4
+    for (int k = c0 * XP + tid; k < c1 * XP; k += nthr) {
+        const int j = (int)(((float)k + 0.5f) * invXP), i = k - j * XP;
+        const float ux = L.Bvx[k];
+        const int ia = max(i - 1, 0), ib = min(i, X - 1);
+        const float uy = 0.25f * (L.Bvy[j * X + ia] + L.Bvy[j * X + ib] + L.Bvy[(j + 1) * X + ia] + L.Bvy[(j + 1) * X + ib]);
+        const Bil s = bil_clamp(Y, XP, j, -uy * a.dtdx, i, -ux * a.dtdx);
+        const float v = bil_eval(L.Bvx, XP, s) * mask_x(L.act, Y, X, j, i);
+        L.Avx[k] = (s.j0 >= dx0 && s.j1 < dx1) ? v : poison;
+    }
+    __syncthreads();
+    SOL_STAMP(4);
+
+    // ---- phase 4: divergence of the band (one 4-cell piece per thread); band 0 gathers the other bands' rows and solves ----
+    float4 rq;
+    {
+        const int j = c0 + (tid >> 4), i = (tid & 15) << 2;
+        const float4 y1 = *reinterpret_cast<const float4*>(&L.Avy[(j + 1) * X + i]), y0 = *reinterpret_cast<const float4*>(&L.Avy[j * X + i]);
+        const float* xr = &L.Avx[j * XP + i];
+        const float x0 = xr[0], x1 = xr[1], x2 = xr[2], x3 = xr[3], x4 = xr[4];
+        rq = make_float4(-((y1.x - y0.x) + (x1 - x0)), -((y1.y - y0.y) + (x2 - x1)), -((y1.z - y0.z) + (x3 - x2)), -((y1.w - y0.w) + (x4 - x3)));
+    }
+    float* P = L.Bvy + FD_BUF;          // [128][64]: fd_solve's result (band 0) / the received pressure rows (other bands)
+    if (w == 0) {
+        float qys[FD_QYS];
+        fd_load_qys(a.fd + 16, __builtin_amdgcn_readfirstlane(tid >> 6), qys);
+        float* B0 = L.Bvy;              // region B is free after the advection: the solver's right-hand side, [128][FD_LD]
+        {
+            float* d = &B0[(tid >> 4) * FD_LD + ((tid & 15) << 2)];
+            d[0] = rq.x; d[1] = rq.y; d[2] = rq.z; d[3] = rq.w;
+        }
+        constexpr int NG = (BD_N - 1) * BD_R * (X / 4) / nthr;      // 3 pieces per thread: rows 32 .. 127
+        int off[NG]; bool on[NG]; uint4 v[NG];
+#pragma unroll
+        for (int n = 0; n < NG; ++n) { off[n] = (BD_R * X + 4 * (tid + n * nthr)) * 4; on[n] = true; }
+        bd_recv<NG>(rx, off, on, v);
+#pragma unroll
+        for (int n = 0; n < NG; ++n) {
+            const int e = tid + n * nthr, j = BD_R + (e >> 4), i = (e & 15) << 2;
+            const float4 f = bd_decode(v[n]);
+            float* d = &B0[j * FD_LD + i];
+            d[0] = f.x; d[1] = f.y; d[2] = f.z; d[3] = f.w;
+            bd_store(rx, off[n], make_uint4(0u, 0u, 0u, 0u));
+        }
+        SOL_STAMP(5);
+        const float rdummy[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        fd_solve<true>(a.fd, qys, L.Bvy, rdummy, a.prof);
+        if (a.iters && tid == 0) a.iters[b] = 0;
+        SOL_STAMP(6);
+        // the pressure rows c0-1 .. c1-1 of every other band, one copy per band
+        constexpr int NS = ((BD_N - 1) * BD_PROWS * (X / 4) + nthr - 1) / nthr;
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            const int e = tid + n * nthr;
+            if (e < (BD_N - 1) * BD_PROWS * (X / 4)) {
+                const int h = e / (BD_PROWS * (X / 4)), r = e - h * (BD_PROWS * (X / 4));
+                const int j = BD_R * (h + 1) - 1 + (r >> 4), i = (r & 15) << 2;
+                bd_store(rx, (BD_DIV_WORDS + (h * BD_PROWS + (r >> 4)) * X + i) * 4, bd_encode(*reinterpret_cast<const float4*>(&P[j * X + i])));
+            }
+        }
+    } else {
+        bd_store(rx, ((c0 + (tid >> 4)) * X + ((tid & 15) << 2)) * 4, bd_encode(rq));
+        constexpr int NG = (BD_PROWS * (X / 4) + nthr - 1) / nthr;       // 2 (528 pieces)
+        int off[NG]; bool on[NG]; uint4 v[NG];
+#pragma unroll
+        for (int n = 0; n < NG; ++n) {
+            const int e = tid + n * nthr;
+            on[n] = e < BD_PROWS * (X / 4);
+            off[n] = (BD_DIV_WORDS + (w - 1) * BD_PROWS * X + 4 * min(e, BD_PROWS * (X / 4) - 1)) * 4;
+        }
+        bd_recv<NG>(rx, off, on, v);
+#pragma unroll
+        for (int n = 0; n < NG; ++n) {
+            const int e = tid + n * nthr;
+            if (on[n]) {
+                *reinterpret_cast<float4*>(&P[(c0 - 1 + (e >> 4)) * X + ((e & 15) << 2)]) = bd_decode(v[n]);
+                bd_store(rx, off[n], make_uint4(0u, 0u, 0u, 0u));
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 6: v -= mask * grad p on the band's faces; outputs ----
+    {
+        float* gvy = a.vy_out + (size_t)b * nVy;
+        float* gvx = a.vx_out + (size_t)b * nVx;
+        #pragma unroll 2
+        for (int q = c0 * (X / 4) + tid; q < fy1 * (X / 4); q += nthr) {
+            const int k = q << 2, j = k >> lx, i = k & (X - 1);
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j >= 1 && j <= Y - 1) {
+                const float4 p1 = *reinterpret_cast<const float4*>(&P[j * X + i]), p0 = *reinterpret_cast<const float4*>(&P[(j - 1) * X + i]);
+                g = make_float4(p1.x - p0.x, p1.y - p0.y, p1.z - p0.z, p1.w - p0.w);
+            } else if (a.grad_pad == 1) {
+                const float4 p = *reinterpret_cast<const float4*>(&P[(j == 0 ? 0 : Y - 1) * X + i]);
+                g = j == 0 ? p : make_float4(-p.x, -p.y, -p.z, -p.w);
+            }
+            const uchar4 m0 = *reinterpret_cast<const uchar4*>(&L.act[max(j - 1, 0) * X + i]), m1 = *reinterpret_cast<const uchar4*>(&L.act[min(j, Y - 1) * X + i]);
+            float4 v = reinterpret_cast<const float4*>(L.Avy)[q];
+            v.x -= (float)min(m0.x, m1.x) * g.x; v.y -= (float)min(m0.y, m1.y) * g.y;
+            v.z -= (float)min(m0.z, m1.z) * g.z; v.w -= (float)min(m0.w, m1.w) * g.w;
+            reinterpret_cast<float4*>(L.Avy)[q] = v;
+            reinterpret_cast<float4*>(gvy)[q] = v;
+        }
+        #pragma unroll 4
+        for (int k = c0 * XP + tid; k < c1 * XP; k += nthr) {
+            const int j = (int)(((float)k + 0.5f) * invXP), i = k - j * XP;
+            float g = 0.f;
+            if (i >= 1 && i <= X - 1) g = P[j * X + i] - P[j * X + i - 1];
+            else if (a.grad_pad == 1) g = (i == 0) ? P[j * X] : -P[j * X + X - 1];
+            const float v = L.Avx[k] - mask_x(L.act, Y, X, j, i) * g;
+            L.Avx[k] = v;
+            gvx[k] = v;
+        }
+    }
+    SOL_STAMP(7);
+    if (a.feat) {   // fused to_feature + 1/std scaling of the band's cells
+        __syncthreads();
+        float4* gf = reinterpret_cast<float4*>(a.feat) + (size_t)b * N;
+        const float rech = a.re[b] * a.fs2;
+        #pragma unroll 4
+        for (int k = c0 * X + tid; k < c1 * X; k += nthr) {
+            const int j = k >> lx, i = k & (X - 1);
+            gf[k] = make_float4(L.Avy[k] * a.fs0, L.Avx[j * XP + i] * a.fs1, rech, 0.f);
+        }
+    }
+    SOL_STAMP(8);
+    if (fdp == 1.2345678e-30f && a.iters) a.iters[b] = -2;      // never true: keeps the prefetch loads alive
+}
+
+__global__ void __launch_bounds__(512) k_karman_fwd_bands(StepArgs a, DensStep q, unsigned* xch) {
+    extern __shared__ __align__(16) float smem[];
+    const int u = (int)blockIdx.x, nsol = 8 * BD_N * ((a.B + 7) >> 3);
+    if (u < nsol) {
+        const int b = (u / (8 * BD_N)) * 8 + (u & 7), w = (u >> 3) & (BD_N - 1);
+        if (b < a.B) karman_fwd_band_body(a, smem, b, w, xch + (size_t)b * BD_WORDS);
+    } else density_step_body(q, u - nsol);
+}
+
+// ------------------------------------------------------------------------------------
 // backward (adjoint w.r.t. the input velocity)
 // ------------------------------------------------------------------------------------
 // NT != 0: the body runs on the first NT threads of a larger workgroup whose other waves have ended (k_karman_bwd_bww_small)
@@ -1986,7 +2278,7 @@ int sol_init_karman_kernels() {
     static std::atomic<unsigned long long> optin{0};
     return sol_lds_optin(optin, {SOL_K(k_karman_fwd<8, 0>), SOL_K(k_karman_bwd<8, 0>), SOL_K(k_karman_fwd<8, 2>), SOL_K(k_karman_bwd<8, 2>),
                                  SOL_K(k_karman_fwd<16, 0>), SOL_K(k_karman_bwd<16, 0>), SOL_K(k_karman_fwd<16, 1>), SOL_K(k_karman_bwd<16, 1>),
-                                 SOL_K(k_karman_fwd<16, 2>), SOL_K(k_karman_bwd<16, 2>), SOL_K(k_karman_bwd_bww), SOL_K(k_karman_fwd_dens), SOL_K(k_karman_bwd_bww_small)},
+                                 SOL_K(k_karman_fwd<16, 2>), SOL_K(k_karman_bwd<16, 2>), SOL_K(k_karman_bwd_bww), SOL_K(k_karman_fwd_dens), SOL_K(k_karman_bwd_bww_small), SOL_K(k_karman_fwd_bands)},
                          "karman kernels");
 }
 
@@ -2067,7 +2359,7 @@ static int step_fwd_impl(const sol_karman_cfg* cfg, void* stream,
                                    float* d_out, float* vy_out, float* vx_out,
                                    float* saved_vy, float* saved_vx,
                                    float* feat_out, const float* feat_scale, int32_t* iters,
-                                   const float* dens_d_in, const float* dens_svy, const float* dens_svx, float* dens_d_out) {
+                                   const float* dens_d_in, const float* dens_svy, const float* dens_svx, float* dens_d_out, uint32_t* xchg = nullptr) {
     if (int e = check_cfg(cfg)) return e;
     SOL_REQUIRE(vy_in && vx_in && re && active && velBCy && velBCyMask && vy_out && vx_out,
                 "sol_karman_step_fwd: NULL pointer argument");
@@ -2082,6 +2374,19 @@ static int step_fwd_impl(const sol_karman_cfg* cfg, void* stream,
     if (feat_scale) { a.fs0 = feat_scale[0]; a.fs1 = feat_scale[1]; a.fs2 = feat_scale[2]; }
     a.iters = iters;
     const int cpt = pick_cpt(cfg);
+    if (xchg && sol_karman_fwd_bands_usable(cfg) && !d_out && !a.feat_tr) {
+        // four workgroups per simulation (k_karman_fwd_bands); the density workgroups of the previous step, if any, ride behind them
+        SOL_REQUIRE(!dens_d_out || (dens_d_in && dens_svy && dens_svx && inflow), "fused solver + density launch: unsupported configuration");
+        if (int e = sol_init_karman_kernels()) return e;
+        DensStep q{};
+        if (dens_d_out) q = DensStep{cfg->B, cfg->Y, cfg->X, cfg->inflow_before, cfg->dt / cfg->dx, cfg->dt, dens_d_in, dens_svy, dens_svx, inflow, dens_d_out};
+        if (sol_opt().step_prof) a.prof = prof_buffer();
+        const int nsol = 8 * BD_N * ((cfg->B + 7) / 8);
+        SOL_LAUNCH(k_karman_fwd_bands, dim3(nsol + (dens_d_out ? cfg->B : 0)), dim3(512), lds_bytes(cfg->Y, cfg->X, 16), (hipStream_t)stream, a, q, xchg);
+        SOL_LAUNCH_CHECK();
+        if (a.prof) return prof_print((hipStream_t)stream, a, false);
+        return SOL_OK;
+    }
     if (dens_d_out) {   // density workgroups of the PREVIOUS step ride in this launch (direct-solver kernels only)
         SOL_REQUIRE(cpt == 16 && a.fd && dens_d_in && dens_svy && dens_svx && inflow, "fused solver + density launch: unsupported configuration");
         if (int e = sol_init_karman_kernels()) return e;
@@ -2115,10 +2420,16 @@ int sol_karman_step_fwd_dens(const sol_karman_cfg* cfg, void* stream,
                              const float* velBCy, const float* velBCyMask, int64_t bc_batch_stride,
                              float* vy_out, float* vx_out, float* saved_vy, float* saved_vx,
                              float* feat_out, const float* feat_scale, int32_t* iters,
-                             const float* dens_d_in, const float* dens_svy, const float* dens_svx, float* dens_d_out) {
+                             const float* dens_d_in, const float* dens_svy, const float* dens_svx, float* dens_d_out, uint32_t* xchg) {
     return step_fwd_impl(cfg, stream, nullptr, vy_in, vx_in, re, active, inflow, velBCy, velBCyMask, bc_batch_stride, nullptr, vy_out, vx_out,
-                         saved_vy, saved_vx, feat_out, feat_scale, iters, dens_d_in, dens_svy, dens_svx, dens_d_out);
+                         saved_vy, saved_vx, feat_out, feat_scale, iters, dens_d_in, dens_svy, dens_svx, dens_d_out, xchg);
 }
+// the band-split forward launch (k_karman_fwd_bands): 128 x 64, direct solver, every workgroup of the launch resident at once.
+// xchg: sol_karman_fwd_bands_words(B) zeroed 32-bit words that the launches keep zeroed between uses.
+int sol_karman_fwd_bands_usable(const sol_karman_cfg* cfg) {
+    return cfg && sol_opt().fwd_bands && cfg->direct && cfg->Y == FD_Y && cfg->X == FD_X && pick_cpt(cfg) == 16 && 8 * BD_N * ((cfg->B + 7) / 8) + cfg->B <= 256;
+}
+size_t sol_karman_fwd_bands_words(int B) { return (size_t)B * BD_WORDS; }
 // internal: one density step alone (the last step of the unroll)
 int sol_density_step(const sol_karman_cfg* c, void* stream, const float* d_in, const float* svy, const float* svx, const float* inflow, float* d_out) {
     SOL_REQUIRE(c && d_in && svy && svx && inflow && d_out, "sol_density_step: NULL pointer argument");

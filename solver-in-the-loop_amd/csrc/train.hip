@@ -20,7 +20,7 @@ int sol_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* sol_last_error(void) { return g_sol_err; }
-extern "C" int sol_version(void) { return 214; }
+extern "C" int sol_version(void) { return 215; }
 // sizes of the ABI structs: the ctypes mirror in _lib.py checks them at load time
 extern "C" int sol_abi_sizes(int32_t* karman_cfg, int32_t* burgers_cfg, int32_t* train_cfg) {
     if (karman_cfg) *karman_cfg = (int32_t)sizeof(sol_karman_cfg);
@@ -35,7 +35,7 @@ SolOptions& sol_opt() {
         SolOptions d{};
         d.conv_precision = 0; d.conv_split3 = 0; d.conv_r3 = 1; d.conv_thin = 1; d.conv_bww32 = 1;
         d.correct_fuse = 1; d.bww_fuse = 1; d.bww_chunk = 0; d.bww_side = 1; d.streams = 1;
-        d.density_mode = 0; d.cpt = 0; d.dbg_skip = 0; d.step_prof = 0; d.cnn_persistent = 0; d.graph_stream = 0; d.k3d_tile = 0; d.k3d_fused_tf = 1; d.k3d_conv_fused = 1; d.k3d_conv_rows = 8; d.conv_dx = 11; d.k3d_mfma_tf = 1; d.conv_thin_valu = 1; d.seed_fuse = 1;
+        d.density_mode = 0; d.cpt = 0; d.dbg_skip = 0; d.step_prof = 0; d.cnn_persistent = 0; d.graph_stream = 0; d.k3d_tile = 0; d.k3d_fused_tf = 1; d.k3d_conv_fused = 1; d.k3d_conv_rows = 8; d.conv_dx = 11; d.k3d_mfma_tf = 1; d.conv_thin_valu = 1; d.seed_fuse = 1; d.fwd_bands = 1;
         return d;
     }();
     return o;
@@ -52,7 +52,7 @@ const OptName OPT_NAMES[] = {
     {"step_prof", &SolOptions::step_prof, 0, 1}, {"cnn_persistent", &SolOptions::cnn_persistent, 0, 1},
     {"graph_stream", &SolOptions::graph_stream, 0, 1}, {"k3d_tile", &SolOptions::k3d_tile, 0, 1}, {"k3d_fused_tf", &SolOptions::k3d_fused_tf, 0, 1}, {"k3d_conv_fused", &SolOptions::k3d_conv_fused, 0, 1}, {"k3d_conv_rows", &SolOptions::k3d_conv_rows, 3, 8},
     {"conv_dx", &SolOptions::conv_dx, 0, 15}, {"conv_thin_valu", &SolOptions::conv_thin_valu, 0, 2}, {"k3d_mfma_tf", &SolOptions::k3d_mfma_tf, 0, 1},
-    {"seed_fuse", &SolOptions::seed_fuse, 0, 1},
+    {"seed_fuse", &SolOptions::seed_fuse, 0, 1}, {"fwd_bands", &SolOptions::fwd_bands, 0, 1},
 };
 }  // namespace
 
@@ -412,6 +412,8 @@ struct Ws {
     float *part[NL];
     size_t part_floats[NL];
     float *adam_scale;
+    uint32_t* xchg;                // hand-off region of the band-split forward solver launches (k_karman_fwd_bands): zero between uses
+    size_t xchg_words;
     unsigned long long* loss_acc;  // [msteps][SOL_LOSS_ACC_WORDS] exact accumulators of the per-step losses (loss_add_exact)
     size_t total_floats;
 };
@@ -456,6 +458,8 @@ size_t carve_ws(const sol_train_cfg* c, float* base, Ws& w, bool training) {
         w.part[l] = take(w.part_floats[l]);
     }
     w.adam_scale = take(64);
+    w.xchg_words = sol_karman_fwd_bands_words(B);       // (carved whatever the option says: a workspace stays valid when fwd_bands is switched)
+    w.xchg = reinterpret_cast<uint32_t*>(take(w.xchg_words));
     w.loss_acc = reinterpret_cast<unsigned long long*>(take((size_t)ms * SOL_LOSS_ACC_WORDS * 2));   // 64-bit words
     w.total_floats = off;
     return off * sizeof(float);
@@ -664,11 +668,15 @@ int run_chain(const sol_train_cfg* c, const Ws& w, const Ws& shared, int Btot, i
         float* svy_i = w.svy + (size_t)i * w.st_vy;
         float* svx_i = w.svx + (size_t)i * w.st_vx;
         int32_t* it_i = io.iters_fwd ? io.iters_fwd + (size_t)i * Btot + b0 : nullptr;
+        const bool bands = !dens_inline && !tr && sol_karman_fwd_bands_usable(kc);
         if (dens_fused && i >= 1) {
             const float* dprev = i == 1 ? d0 : w.d + (size_t)(i - 2) * w.st_d;
             if (int e = sol_karman_step_fwd_dens(kc, stream, vyin, vxin, re, io.active, io.inflow, bcv, bcm, io.bc_stride, vycur, vxcur, svy_i, svx_i,
                                                  feat, fscale, it_i, dprev, w.svy + (size_t)(i - 1) * w.st_vy, w.svx + (size_t)(i - 1) * w.st_vx,
-                                                 w.d + (size_t)(i - 1) * w.st_d)) return e;
+                                                 w.d + (size_t)(i - 1) * w.st_d, bands ? w.xchg : nullptr)) return e;
+        } else if (bands) {     // no density workgroups in this launch (first step, or the density runs as one chain behind the unroll)
+            if (int e = sol_karman_step_fwd_dens(kc, stream, vyin, vxin, re, io.active, io.inflow, bcv, bcm, io.bc_stride, vycur, vxcur, svy_i, svx_i,
+                                                 feat, fscale, it_i, nullptr, nullptr, nullptr, nullptr, w.xchg)) return e;
         } else if (int e = sol_karman_step_fwd(kc, stream, din, vyin, vxin, re, io.active, io.inflow, bcv, bcm, io.bc_stride,
                                                dens_inline ? dcur : nullptr, vycur, vxcur, svy_i, svx_i, feat, fscale, it_i)) return e;
         feat_order.restore();
@@ -844,6 +852,7 @@ int train_fwd_bwd_impl(const sol_train_cfg* cfg, hipStream_t hs, const TrainIO& 
         z.zero(w[k].dO4, w[k].cells * 4 * sizeof(float));
         if (k == 0) z.zero(w[0].loss_acc, (size_t)ms * SOL_LOSS_ACC_WORDS * sizeof(unsigned long long));   // every chain adds into chain 0's accumulators
         z.zero(w[k].amax_act, 2 * w[k].amax_words * sizeof(uint32_t));                 // activation + gradient absmax slots
+        if (sol_karman_fwd_bands_usable(&sub.karman)) z.zero(w[k].xchg, w[k].xchg_words * sizeof(uint32_t));   // (the launches restore the zeros themselves; this covers an aborted step)
         const bool chain = sol_cnn_chain_usable(sub.karman.B, cnn_transposed(Y, X) ? X : Y, cnn_transposed(Y, X) ? Y : X);
         // hand-off regions of the persistent CNN launches: zero ONCE (tag 0 = "never written"); afterwards the tags do the work
         if (chain) z.zero_once(w[k].chain_flags, (size_t)ms * 2 * w[k].chain_words * sizeof(uint32_t), w[k].chain_ctl + 1, w[k].chain_magic);
@@ -1158,6 +1167,12 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
     // training workspace are free here) -- rides in the solver launch of step i as B extra workgroups (k_karman_fwd_dens), the last
     // one is its own small launch behind the loop.  Same buffers, same values.
     const bool dens_ride = sol_karman_bwd_fusable(kc) && sol_opt().density_mode == 0;
+    const bool bands = dens_ride && !cnn_transposed(Y, X) && sol_karman_fwd_bands_usable(kc);      // four workgroups per simulation (k_karman_fwd_bands)
+    if (bands && nsteps > 0) {
+        MemList z;
+        z.zero(w.xchg, w.xchg_words * sizeof(uint32_t));
+        if (int e = z.launch(hs)) return e;
+    }
     for (int i = 0; i < nsteps; ++i) {
         float* sd = (i & 1) ? w.d : d;   float* svy = (i & 1) ? w.vy : vy;   float* svx = (i & 1) ? w.vx : vx;
         float* td = (i & 1) ? d : w.d;   float* tvy = (i & 1) ? vy : w.vy;   float* tvx = (i & 1) ? vx : w.vx;
@@ -1169,14 +1184,17 @@ extern "C" int sol_rollout(const sol_train_cfg* cfg, void* stream, const float* 
                 if (int e = sol_karman_step_fwd(kc, stream, sd, svy, svx, re, active, inflow, velBCy, velBCyMask, bc_batch_stride,
                                                 td, tvy, tvx, nullptr, nullptr, w.feat, fscale, it_i)) return e;
             } else if (i == 0) {
-                if (int e = sol_karman_step_fwd(kc, stream, sd, svy, svx, re, active, inflow, velBCy, velBCyMask, bc_batch_stride,
-                                                nullptr, tvy, tvx, w.gvy[0], w.gvx[0], w.feat, fscale, it_i)) return e;
+                if (bands) {
+                    if (int e = sol_karman_step_fwd_dens(kc, stream, svy, svx, re, active, inflow, velBCy, velBCyMask, bc_batch_stride, tvy, tvx,
+                                                         w.gvy[0], w.gvx[0], w.feat, fscale, it_i, nullptr, nullptr, nullptr, nullptr, w.xchg)) return e;
+                } else if (int e = sol_karman_step_fwd(kc, stream, sd, svy, svx, re, active, inflow, velBCy, velBCyMask, bc_batch_stride,
+                                                       nullptr, tvy, tvx, w.gvy[0], w.gvx[0], w.feat, fscale, it_i)) return e;
             } else {
                 float* psd = ((i - 1) & 1) ? w.d : d;           // density in / out of step i-1 (the buffers it would have used itself)
                 float* ptd = ((i - 1) & 1) ? d : w.d;
                 if (int e = sol_karman_step_fwd_dens(kc, stream, svy, svx, re, active, inflow, velBCy, velBCyMask, bc_batch_stride, tvy, tvx,
                                                      w.gvy[i & 1], w.gvx[i & 1], w.feat, fscale, it_i,
-                                                     psd, w.gvy[(i - 1) & 1], w.gvx[(i - 1) & 1], ptd)) return e;
+                                                     psd, w.gvy[(i - 1) & 1], w.gvx[(i - 1) & 1], ptd, bands ? w.xchg : nullptr)) return e;
             }
         }
         if (i % ROLLOUT_AMAX_SETS == 0) {

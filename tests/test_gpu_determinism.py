@@ -413,3 +413,60 @@ def test_captured_graphs_hold_kernel_nodes_only_and_the_guard_refuses_a_planted_
     tr2.fwd_bwd(*batch)
     torch.cuda.synchronize()
     assert len(tr2._graphs) == 1
+
+
+# ---------------------------------------------------------------------------------------------
+# band-split forward solver launch (k_karman_fwd_bands, round 6) == the one-workgroup kernel, bit for bit
+# ---------------------------------------------------------------------------------------------
+class _option:
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = sol_amd._lib.get_option(self.name)
+        sol_amd._lib.set_option(self.name, self.value)
+
+    def __exit__(self, *exc):
+        sol_amd._lib.set_option(self.name, self.old)
+        return False
+
+
+@pytest.mark.parametrize("B,ms,use_graph", [(6, 4, False), (6, 4, True), (1, 3, False), (9, 2, False)])
+def test_band_split_forward_launch_equals_the_one_workgroup_kernel_bit_for_bit(B, ms, use_graph):
+    """Four workgroups per simulation (stencil phases on row bands with recomputed halos, two hand-offs through global memory) must
+    reproduce every bit of the one-workgroup kernel: same arithmetic, same order.  Checked through the trainer (per-step losses,
+    gradient, final velocity and density: the forward states feed all of them), eager and replayed, B not a multiple of 8 included."""
+    out = {}
+    for bands in (0, 1):
+        with _option("fwd_bands", bands):
+            tr, batch = _trainer2d(B, 128, 64, ms, use_graph)
+            for _ in range(2):
+                tr.grads.zero_()
+                tr.fwd_bwd(*batch, want_final=True)
+                torch.cuda.synchronize()
+                _scramble()
+            out[bands] = (tr.grads.clone(), tr.loss_steps.clone()) + tuple(t.clone() for t in tr.final)
+            if bands and not use_graph:
+                with sol_amd._lib.profile() as p:
+                    tr.fwd_bwd(*batch, want_final=True)
+                assert any("k_karman_fwd_bands" in k for k in p.kernels), sorted(p.kernels)
+                assert not any("k_karman_fwd_dens" in k for k in p.kernels), sorted(p.kernels)
+    assert torch.isfinite(out[0][1]).all() and float(out[0][0].abs().max()) > 0
+    for t0, t1 in zip(out[0], out[1]):
+        assert same_bits(t0, t1), "band-split forward launch differs from the one-workgroup kernel"
+
+
+def test_band_split_forward_launch_poisons_a_departure_point_outside_its_halo():
+    """A face whose semi-Lagrangian departure point lies more than the halo (8 rows) away is not clamped silently: it reads NaN, and so
+    does the loss of the step.  (The one-workgroup kernel handles any displacement; |u| dt / dx >= 8 is far outside the scene's range.)"""
+    tr, (d, vy, vx, re, gy, gx) = _trainer2d(2, 128, 64, 2, False)
+    vy = vy.clone()
+    vy[1, 60:70, 20:30] = 40.0           # 40 cells per step
+    with _option("fwd_bands", 1):
+        tr.fwd_bwd(d, vy, vx, re, gy, gx, want_final=True)
+        torch.cuda.synchronize()
+        assert not torch.isfinite(tr.loss_steps).all()
+    with _option("fwd_bands", 0):
+        tr.fwd_bwd(d, vy, vx, re, gy, gx, want_final=True)
+        torch.cuda.synchronize()
+        assert torch.isfinite(tr.loss_steps).all()
