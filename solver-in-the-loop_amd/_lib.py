@@ -143,7 +143,7 @@ _ENV_OPTIONS = {
     "SOL_DENSITY_INLINE": ("density_mode", 1), "SOL_DENSITY_NO_FUSE": ("density_mode", 2), "SOL_STEP_PROF": ("step_prof", 1),
     "SOL_CNN_NO_PERSISTENT": ("cnn_persistent", 0), "SOL_CONV_NO_DX": ("conv_dx", 0), "SOL_CONV_NO_THIN_VALU": ("conv_thin_valu", 0),
 }
-_ENV_INT_OPTIONS = {"SOL_CONV_THIN_VALU": "conv_thin_valu", "SOL_BWW_CHUNK": "bww_chunk", "SOL_STREAMS": "streams", "SOL_CPT": "cpt", "SOL_DBG_SKIP": "dbg_skip"}
+_ENV_INT_OPTIONS = {"SOL_FWD_BANDS": "fwd_bands", "SOL_CONV_THIN_VALU": "conv_thin_valu", "SOL_BWW_CHUNK": "bww_chunk", "SOL_STREAMS": "streams", "SOL_CPT": "cpt", "SOL_DBG_SKIP": "dbg_skip"}
 
 
 def load():

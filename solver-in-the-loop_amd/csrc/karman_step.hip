@@ -108,11 +108,24 @@ __device__ __forceinline__ Bil bil_clamp(int H, int W, int jb, float oy, int ib,
     s.i1 = clampi(i0 + 1, 0, W - 1);
     return s;
 }
+// (One expression for every caller.  OPEN OBSERVATION, round 6: spelling the three fused multiply-adds out with __builtin_fmaf -- algebraically the
+//  same blend -- made k_karman_fwd<8, 2> (64 x 32, small-grid direct solve) miss its golden step by 2.3e-4 / 2.7e-3 while k_karman_fwd<8, 0>
+//  (CG) of the same build stayed at 5e-8; deterministic, unexplained (tools/debug_6432.py), so the expression stays as it has been since round 1.)
+__device__ __forceinline__ float bil_mix(const Bil& s, float f00, float f01, float f10, float f11) {
+    return (1.f - s.wy) * ((1.f - s.wx) * f00 + s.wx * f01) + s.wy * ((1.f - s.wx) * f10 + s.wx * f11);
+}
 __device__ __forceinline__ float bil_eval(const float* f, int W, const Bil& s) {
     const float f00 = f[s.j0 * W + s.i0], f01 = f[s.j0 * W + s.i1];
     const float f10 = f[s.j1 * W + s.i0], f11 = f[s.j1 * W + s.i1];
-    return (1.f - s.wy) * ((1.f - s.wx) * f00 + s.wx * f01) + s.wy * ((1.f - s.wx) * f10 + s.wx * f11);
+    return bil_mix(s, f00, f01, f10, f11);
 }
+
+// explicit diffusion of one face (phase 2 of the forward kernels), fused multiply-adds spelled out (see bil_mix): v_y with the velocity BC blend
+__device__ __forceinline__ float dif_y(float c, float up, float dn, float rt, float lf, float alpha, float bcm, float bcv) {
+    const float lap = up + dn + rt + lf - 4.f * c;          // summation order ((up + down) + right) + left - 4 c  (4 c is exact)
+    return __builtin_fmaf(__builtin_fmaf(alpha, lap, c), 1.f - bcm, bcv);
+}
+__device__ __forceinline__ float dif_x(float c, float lap, float alpha) { return __builtin_fmaf(alpha, lap, c); }
 
 // ------------------------------------------------------------------------------------
 // Strip ownership for the CG: thread -> (strip, column i), rows j0..j0+7
@@ -673,10 +686,35 @@ __device__ __forceinline__ void fd_load_qys(const float* __restrict__ Qy, int w,
 
 // rhs in rf[] (strip layout: rows 16*wave + k, column lane); returns the solution as a [128][64] LDS array (inside buf,
 // complete for every thread).  buf = 2*FD_BUF floats of LDS.
+// The first request group of fd_solve (x-transform operand, window operands, eigenvalue reciprocals: 68 registers), loadable at KERNEL START
+// (k_karman_fwd_bands, band 0): inside the solve these requests cost ~3 us in front of the first transform (fwd-transform 8.1 us against 4.4 us
+// for the inverse pair, which finds its operands in registers).
+struct FdOps { float bx[32], qxw[16], qyk[4], il[16]; };
+__device__ __forceinline__ void fd_load_ops(const float* __restrict__ blob, FdOps& o) {
+    const FdView F = fd_view(blob);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = tid & 127, cb = __builtin_amdgcn_readfirstlane(tid >> 7);
+    fd_load_bx(F.Qx, w, o.bx);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) o.qxw[t] = F.QxW[(4 * t + (lane >> 4)) * FD_WIN + (lane & 15)];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o.qyk[t] = F.Qy[(size_t)(F.wy0 + (lane & 15)) * FD_Y + 16 * w + 4 * t + (lane >> 4)];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = 8 * cb + 2 * q + e;
+            o.il[2 * q + e] = F.ilT[c * FD_Y + m];
+            o.il[8 + 2 * q + e] = F.ilT[(FD_X - 1 - c) * FD_Y + m];
+        }
+}
 // RHS_STAGED: the caller has written the right-hand side into buf as [128][FD_LD] itself (k_karman_fwd_bands); rf is then unused
-template <bool RHS_STAGED = false>
-__device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const float (&qys)[FD_QYS], float* buf, const float (&rf)[16], long long* prof) {
-#define FD_STAMP(i) do { if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[i] = wall_clock64(); } while (0)
+// pre != nullptr: the first request group was loaded by the caller (fd_load_ops)
+template <bool RHS_STAGED = false, bool PRELOADED = false>
+__device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const float (&qys)[FD_QYS], float* buf, const float (&rf)[16], long long* prof,
+                                           const FdOps& pre) {
+#define FD_STAMP(i) do { if (prof && (blockIdx.x == 0 || (RHS_STAGED && blockIdx.x == 32)) && threadIdx.x == 0) prof[i] = wall_clock64(); } while (0)   /* (32: the solver workgroup of simulation 0 in k_karman_fwd_bands) */
     const FdView F = fd_view(blob);
     float* B0 = buf;
     float* B1 = buf + FD_BUF;
@@ -707,17 +745,26 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
     }
 #if SOL_FD_MFMA
     float bx[32];
-    fd_load_bx(F.Qx, w, bx);             // x-transform operand + the eigenvalue reciprocals: in flight behind the y transform
     float* XP8 = B0 + 4096;              // [8 waves][256] partial window values (MFMA form)
     // window products on v_mfma_f32_16x16x4_f32 (wave = 16 rows m; B operand lane: column lane & 15, k = lane >> 4).  Two request groups, so
     // that no more than 20 extra registers are live across the transforms: what the first two window phases need here, the rest behind them.
     float qxw[16], qyk[4];               // QxW[c][i'] (u = T2 QxW);  window rows of Qy as A operand [16 jw x 4 m] of x0w = Qy[win, :] u (this wave's K slice)
+    if constexpr (PRELOADED) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t) qxw[t] = F.QxW[(4 * t + (lane >> 4)) * FD_WIN + (lane & 15)];
+        for (int t = 0; t < 32; ++t) bx[t] = pre.bx[t];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) qyk[t] = F.Qy[(size_t)(F.wy0 + (lane & 15)) * FD_Y + 16 * w + 4 * t + (lane >> 4)];
+        for (int t = 0; t < 16; ++t) { qxw[t] = pre.qxw[t]; il[t] = pre.il[t]; }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) il[e] = F.ilT[col[e] * FD_Y + m];
+        for (int t = 0; t < 4; ++t) qyk[t] = pre.qyk[t];
+    } else {
+        fd_load_bx(F.Qx, w, bx);         // x-transform operand + the eigenvalue reciprocals: in flight behind the y transform
+#pragma unroll
+        for (int t = 0; t < 16; ++t) qxw[t] = F.QxW[(4 * t + (lane >> 4)) * FD_WIN + (lane & 15)];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) qyk[t] = F.Qy[(size_t)(F.wy0 + (lane & 15)) * FD_Y + 16 * w + 4 * t + (lane >> 4)];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) il[e] = F.ilT[col[e] * FD_Y + m];
+    }
     __syncthreads();
     fd_mfma_y<FD_LD>(qys, B0, B1, w);    // B1 = Qy b
     __syncthreads();
@@ -840,7 +887,7 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
         const float* kp = F.KpT + (size_t)(h * half) * F.SP + sidx_;
         const float* xs = XS + h * half;
         float s = 0.f;
-#pragma unroll 8
+#pragma unroll 8         /* (unroll 32 measured: 2.4 -> 8.4 us) */
         for (int q = 0; q < half; ++q) s += kp[(size_t)q * F.SP] * xs[q];
         CP[h * 256 + sidx_] = s;
     }
@@ -971,6 +1018,11 @@ __device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const
     __syncthreads();                     // solution complete in LDS
     return B1;
 #endif
+}
+
+__device__ __forceinline__ float* fd_solve(const float* __restrict__ blob, const float (&qys)[FD_QYS], float* buf, const float (&rf)[16], long long* prof) {
+    const FdOps none{};
+    return fd_solve<false, false>(blob, qys, buf, rf, prof, none);
 }
 
 // ---- the same direct solve for small grids (Y*X <= 2048, e.g. the reference's 64x32 training recipe,
@@ -1224,13 +1276,11 @@ __device__ __forceinline__ void karman_fwd_body(const StepArgs& a, float* smem) 
             const float4 up = *reinterpret_cast<const float4*>(&L.Avy[min(j + 1, Y) * X + i]);
             const float4 dn = *reinterpret_cast<const float4*>(&L.Avy[max(j - 1, 0) * X + i]);
             const float rt = L.Avy[j * X + min(i + 4, X - 1)], lf = L.Avy[j * X + max(i - 1, 0)];
-            float4 v;                               // summation order as in the scalar form: ((up + down) + right) + left - 4 c
-            v.x = c.x + alpha * (up.x + dn.x + c.y + lf - 4.f * c.x);
-            v.y = c.y + alpha * (up.y + dn.y + c.z + c.x - 4.f * c.y);
-            v.z = c.z + alpha * (up.z + dn.z + c.w + c.y - 4.f * c.z);
-            v.w = c.w + alpha * (up.w + dn.w + rt + c.z - 4.f * c.w);
-            v.x = v.x * (1.f - bcm_r[n].x) + bcv_r[n].x; v.y = v.y * (1.f - bcm_r[n].y) + bcv_r[n].y;
-            v.z = v.z * (1.f - bcm_r[n].z) + bcv_r[n].z; v.w = v.w * (1.f - bcm_r[n].w) + bcv_r[n].w;
+            float4 v;
+            v.x = dif_y(c.x, up.x, dn.x, c.y, lf, alpha, bcm_r[n].x, bcv_r[n].x);
+            v.y = dif_y(c.y, up.y, dn.y, c.z, c.x, alpha, bcm_r[n].y, bcv_r[n].y);
+            v.z = dif_y(c.z, up.z, dn.z, c.w, c.y, alpha, bcm_r[n].z, bcv_r[n].z);
+            v.w = dif_y(c.w, up.w, dn.w, rt, c.z, alpha, bcm_r[n].w, bcv_r[n].w);
             reinterpret_cast<float4*>(L.Bvy)[q] = v;
             if (a.saved_vy) reinterpret_cast<float4*>(a.saved_vy + (size_t)b * nVy)[q] = v;
         }
@@ -1240,7 +1290,7 @@ __device__ __forceinline__ void karman_fwd_body(const StepArgs& a, float* smem) 
             const float c = L.Avx[k];
             const float lap = L.Avx[min(j + 1, Y - 1) * XP + i] + L.Avx[max(j - 1, 0) * XP + i] +
                               L.Avx[j * XP + min(i + 1, X)] + L.Avx[j * XP + max(i - 1, 0)] - 4.f * c;
-            const float v = c + alpha * lap;
+            const float v = dif_x(c, lap, alpha);
             L.Bvx[k] = v;
             if (a.saved_vx) a.saved_vx[(size_t)b * nVx + k] = v;
         }
@@ -1460,8 +1510,8 @@ __global__ void __launch_bounds__(512) k_density_step(DensStep q) { density_step
 // B = 6) are bound by the vector ALU of ONE compute unit -- 2 waves per SIMD run ~100 instructions per face -- while 250 CUs idle.  Here a
 // simulation is cut into BD_N bands of BD_R cell rows; every band's workgroup recomputes the diffusion on BD_HA halo rows each side
 // (departure points of the semi-Lagrangian step are then band local for |u| dt / dx < BD_HA; a face whose departure point lies outside the
-// halo is POISONED with NaN -- the loss of the step reads NaN -- instead of being clamped silently), advects its faces and forms its rows
-// of the divergence.  Two hand-offs through global memory: the divergence rows of bands 1.. go to band 0's workgroup, which runs the
+// halo recomputes the diffused corner values it needs from the step's input in global memory: same result, slow, and only the garbage
+// states of an untrained network ever take it), advects its faces and forms its rows of the divergence.  Two hand-offs through global memory: the divergence rows of bands 1.. go to band 0's workgroup, which runs the
 // direct solve on its CU as before (the transforms couple every cell with every other: DESIGN_HISTORY section 8 prices their split) and
 // sends every band the pressure rows its projection needs.  "The data is the flag" (cdna_hip_programming.md, guideline 16): a word is
 // stored as bits ^ BD_KEY with write-through (sc1) stores and the exchange region holds zeros otherwise, so the consumer polls its own
@@ -1472,7 +1522,7 @@ __global__ void __launch_bounds__(512) k_density_step(DensStep q) { density_step
 // Arithmetic, operation order and therefore every output bit equal the one-workgroup kernel's (tests/test_gpu_parity.py).
 constexpr int BD_N = 4, BD_R = FD_Y / BD_N, BD_HA = 8, BD_PROWS = BD_R + 1;
 constexpr unsigned BD_KEY = 0x7fc0deadu;
-constexpr int BD_DIV_WORDS = FD_Y * FD_X, BD_P_WORDS = (BD_N - 1) * BD_PROWS * FD_X, BD_WORDS = BD_DIV_WORDS + BD_P_WORDS;
+constexpr int BD_DIV_WORDS = FD_Y * FD_X, BD_P_WORDS = BD_N * BD_PROWS * FD_X, BD_WORDS = BD_DIV_WORDS + BD_P_WORDS;
 constexpr unsigned BD_SPIN_LIMIT = 1u << 15;
 __device__ __forceinline__ uint4 bd_load(const __amdgpu_buffer_rsrc_t r, int byte_off) {
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));      // aux 16 = sc1: agent scope, misses the vector L1
@@ -1504,6 +1554,8 @@ __device__ __forceinline__ void bd_recv(const __amdgpu_buffer_rsrc_t r, const in
     }
 }
 
+#define BD_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")   /* LDS only: global requests stay in flight */
+#define BD_STAMP(i) do { if (a.prof && blockIdx.x == 8 && threadIdx.x == 0) a.prof[20 + (i)] = wall_clock64(); } while (0)   /* band 1 of simulation 0 */
 __device__ __forceinline__ void karman_fwd_band_body(const StepArgs& a, float* smem, const int b, const int w, unsigned* xw) {
     constexpr int Y = FD_Y, X = FD_X, XP = X + 1, N = Y * X, nVy = (Y + 1) * X, nVx = Y * XP, nthr = 512, lx = 6;
     const int tid = threadIdx.x;
@@ -1521,8 +1573,8 @@ __device__ __forceinline__ void karman_fwd_band_body(const StepArgs& a, float* s
     const int m0 = max(c0 - 1, 0), m1 = min(c1 + 1, Y);                          // mask rows
 
     SOL_STAMP(0);
-    float fdp = 0.f;
-    if (w == 0) fdp = fd_prefetch(a.fd, a.fd_n);
+    BD_STAMP(0);
+
     // ---- phase 1: load (16-byte pieces, all requests in flight before the first LDS store) ----
     constexpr int NV = 2;                       // <= 51 rows x 16 quads (v_y), <= 50 rows x 65 floats (v_x): at most 816 quads each
     float4 bcv_r[NV], bcm_r[NV];
@@ -1551,7 +1603,9 @@ __device__ __forceinline__ void karman_fwd_band_body(const StepArgs& a, float* s
             if (qm < qm1) reinterpret_cast<uchar4*>(L.act)[qm] = make_uchar4(ta[n].x != 0.f, ta[n].y != 0.f, ta[n].z != 0.f, ta[n].w != 0.f);
         }
     }
-    __syncthreads();
+    // the solver's coefficients (100 registers): requested behind the state, consumed 5 us later.  The barriers up to the solve wait for LDS
+    // only (__syncthreads would wait for these requests as well)
+    BD_BARRIER();
     SOL_STAMP(1);
 
     // ---- phase 2: explicit diffusion + velocity BC on the band and its halo ----
@@ -1567,12 +1621,10 @@ __device__ __forceinline__ void karman_fwd_band_body(const StepArgs& a, float* s
             const float4 dn = *reinterpret_cast<const float4*>(&L.Avy[max(j - 1, 0) * X + i]);
             const float rt = L.Avy[j * X + min(i + 4, X - 1)], lf = L.Avy[j * X + max(i - 1, 0)];
             float4 v;
-            v.x = c.x + alpha * (up.x + dn.x + c.y + lf - 4.f * c.x);
-            v.y = c.y + alpha * (up.y + dn.y + c.z + c.x - 4.f * c.y);
-            v.z = c.z + alpha * (up.z + dn.z + c.w + c.y - 4.f * c.z);
-            v.w = c.w + alpha * (up.w + dn.w + rt + c.z - 4.f * c.w);
-            v.x = v.x * (1.f - bcm_r[n].x) + bcv_r[n].x; v.y = v.y * (1.f - bcm_r[n].y) + bcv_r[n].y;
-            v.z = v.z * (1.f - bcm_r[n].z) + bcv_r[n].z; v.w = v.w * (1.f - bcm_r[n].w) + bcv_r[n].w;
+            v.x = dif_y(c.x, up.x, dn.x, c.y, lf, alpha, bcm_r[n].x, bcv_r[n].x);
+            v.y = dif_y(c.y, up.y, dn.y, c.z, c.x, alpha, bcm_r[n].y, bcv_r[n].y);
+            v.z = dif_y(c.z, up.z, dn.z, c.w, c.y, alpha, bcm_r[n].z, bcv_r[n].z);
+            v.w = dif_y(c.w, up.w, dn.w, rt, c.z, alpha, bcm_r[n].w, bcv_r[n].w);
             reinterpret_cast<float4*>(L.Bvy)[q] = v;
             if (a.saved_vy && j >= c0 && j < fy1) reinterpret_cast<float4*>(a.saved_vy + (size_t)b * nVy)[q] = v;
         }
@@ -1582,16 +1634,36 @@ __device__ __forceinline__ void karman_fwd_band_body(const StepArgs& a, float* s
             const float c = L.Avx[k];
             const float lap = L.Avx[min(j + 1, Y - 1) * XP + i] + L.Avx[max(j - 1, 0) * XP + i] +
                               L.Avx[j * XP + min(i + 1, X)] + L.Avx[j * XP + max(i - 1, 0)] - 4.f * c;
-            const float v = c + alpha * lap;
+            const float v = dif_x(c, lap, alpha);
             L.Bvx[k] = v;
             if (a.saved_vx && j >= c0 && j < c1) a.saved_vx[(size_t)b * nVx + k] = v;
         }
     }
-    __syncthreads();
+    BD_BARRIER();
     SOL_STAMP(2);
 
     // ---- phase 3: semi-Lagrangian advection (B -> A) of the band's faces, hard-BC face mask fused ----
-    const float poison = __uint_as_float(0x7fc00000u);
+    // Departure points outside the halo (|u| dt / dx >= BD_HA: an untrained network's first corrections can do that) take a slow path with the
+    // SAME result: the diffused value of a far corner is recomputed from the step's input in global memory (phase 2's expressions).
+    const float alpha_s = a.adt / a.re[b];
+    const float* gvy_in = a.vy_in + (size_t)b * nVy;
+    const float* gvx_in = a.vx_in + (size_t)b * nVx;
+    const float* gbcv = a.bcv + (size_t)b * a.bc_stride;
+    const float* gbcm = a.bcm + (size_t)b * a.bc_stride;
+    auto far_y = [&](int j, int i) -> float {
+        if (j >= dy0 && j < dy1) return L.Bvy[j * X + i];
+        const float c = gvy_in[j * X + i], up = gvy_in[min(j + 1, Y) * X + i], dn = gvy_in[max(j - 1, 0) * X + i];
+        const float rt = gvy_in[j * X + min(i + 1, X - 1)], lf = gvy_in[j * X + max(i - 1, 0)];
+        return dif_y(c, up, dn, rt, lf, alpha_s, gbcm[j * X + i], gbcv[j * X + i]);
+    };
+    auto far_x = [&](int j, int i) -> float {
+        if (j >= dx0 && j < dx1) return L.Bvx[j * XP + i];
+        const float c = gvx_in[j * XP + i];
+        const float lap = gvx_in[min(j + 1, Y - 1) * XP + i] + gvx_in[max(j - 1, 0) * XP + i] +
+                          gvx_in[j * XP + min(i + 1, X)] + gvx_in[j * XP + max(i - 1, 0)] - 4.f * c;
+        return dif_x(c, lap, alpha_s);
+    };
+    bool far = false;
     #pragma unroll 4
     for (int k = c0 * X + tid; k < ay1 * X; k += nthr) {
         const int j = k >> lx, i = k & (X - 1);
@@ -1599,8 +1671,8 @@ __device__ __forceinline__ void karman_fwd_band_body(const StepArgs& a, float* s
         const int ja = max(j - 1, 0), jb = min(j, Y - 1);
         const float ux = 0.25f * (L.Bvx[ja * XP + i] + L.Bvx[ja * XP + i + 1] + L.Bvx[jb * XP + i] + L.Bvx[jb * XP + i + 1]);
         const Bil s = bil_clamp(Y + 1, X, j, -uy * a.dtdx, i, -ux * a.dtdx);
-        const float v = bil_eval(L.Bvy, X, s) * mask_y(L.act, Y, X, j, i);
-        L.Avy[k] = (s.j0 >= dy0 && s.j1 < dy1) ? v : poison;
+        L.Avy[k] = bil_eval(L.Bvy, X, s) * mask_y(L.act, Y, X, j, i);
+        far = far || !(s.j0 >= dy0 && s.j1 < dy1);
     }
     #pragma unroll 4
     for (int k = c0 * XP + tid; k < c1 * XP; k += nthr) {
@@ -1609,10 +1681,32 @@ __device__ __forceinline__ void karman_fwd_band_body(const StepArgs& a, float* s
         const int ia = max(i - 1, 0), ib = min(i, X - 1);
         const float uy = 0.25f * (L.Bvy[j * X + ia] + L.Bvy[j * X + ib] + L.Bvy[(j + 1) * X + ia] + L.Bvy[(j + 1) * X + ib]);
         const Bil s = bil_clamp(Y, XP, j, -uy * a.dtdx, i, -ux * a.dtdx);
-        const float v = bil_eval(L.Bvx, XP, s) * mask_x(L.act, Y, X, j, i);
-        L.Avx[k] = (s.j0 >= dx0 && s.j1 < dx1) ? v : poison;
+        L.Avx[k] = bil_eval(L.Bvx, XP, s) * mask_x(L.act, Y, X, j, i);
+        far = far || !(s.j0 >= dx0 && s.j1 < dx1);
     }
-    __syncthreads();
+    if (__builtin_amdgcn_ballot_w64(far) != 0ull) {     // (wave uniform) redo this wave's faces whose departure point left the halo
+        for (int k = c0 * X + tid; k < ay1 * X; k += nthr) {
+            const int j = k >> lx, i = k & (X - 1);
+            const float uy = L.Bvy[k];
+            const int ja = max(j - 1, 0), jb = min(j, Y - 1);
+            const float ux = 0.25f * (L.Bvx[ja * XP + i] + L.Bvx[ja * XP + i + 1] + L.Bvx[jb * XP + i] + L.Bvx[jb * XP + i + 1]);
+            const Bil s = bil_clamp(Y + 1, X, j, -uy * a.dtdx, i, -ux * a.dtdx);
+            if (!(s.j0 >= dy0 && s.j1 < dy1))
+                L.Avy[k] = bil_mix(s, far_y(s.j0, s.i0), far_y(s.j0, s.i1), far_y(s.j1, s.i0), far_y(s.j1, s.i1)) * mask_y(L.act, Y, X, j, i);
+        }
+        for (int k = c0 * XP + tid; k < c1 * XP; k += nthr) {
+            const int j = (int)(((float)k + 0.5f) * invXP), i = k - j * XP;
+            const float ux = L.Bvx[k];
+            const int ia = max(i - 1, 0), ib = min(i, X - 1);
+            const float uy = 0.25f * (L.Bvy[j * X + ia] + L.Bvy[j * X + ib] + L.Bvy[(j + 1) * X + ia] + L.Bvy[(j + 1) * X + ib]);
+            const Bil s = bil_clamp(Y, XP, j, -uy * a.dtdx, i, -ux * a.dtdx);
+            if (!(s.j0 >= dx0 && s.j1 < dx1))
+                L.Avx[k] = bil_mix(s, far_x(s.j0, s.i0), far_x(s.j0, s.i1), far_x(s.j1, s.i0), far_x(s.j1, s.i1)) * mask_x(L.act, Y, X, j, i);
+        }
+    }
+    SOL_STAMP(3);
+    BD_STAMP(3);
+    BD_BARRIER();
     SOL_STAMP(4);
 
     // ---- phase 4: divergence of the band (one 4-cell piece per thread); band 0 gathers the other bands' rows and solves ----
@@ -1624,63 +1718,31 @@ __device__ __forceinline__ void karman_fwd_band_body(const StepArgs& a, float* s
         const float x0 = xr[0], x1 = xr[1], x2 = xr[2], x3 = xr[3], x4 = xr[4];
         rq = make_float4(-((y1.x - y0.x) + (x1 - x0)), -((y1.y - y0.y) + (x2 - x1)), -((y1.z - y0.z) + (x3 - x2)), -((y1.w - y0.w) + (x4 - x3)));
     }
-    float* P = L.Bvy + FD_BUF;          // [128][64]: fd_solve's result (band 0) / the received pressure rows (other bands)
-    if (w == 0) {
-        float qys[FD_QYS];
-        fd_load_qys(a.fd + 16, __builtin_amdgcn_readfirstlane(tid >> 6), qys);
-        float* B0 = L.Bvy;              // region B is free after the advection: the solver's right-hand side, [128][FD_LD]
-        {
-            float* d = &B0[(tid >> 4) * FD_LD + ((tid & 15) << 2)];
-            d[0] = rq.x; d[1] = rq.y; d[2] = rq.z; d[3] = rq.w;
-        }
-        constexpr int NG = (BD_N - 1) * BD_R * (X / 4) / nthr;      // 3 pieces per thread: rows 32 .. 127
-        int off[NG]; bool on[NG]; uint4 v[NG];
-#pragma unroll
-        for (int n = 0; n < NG; ++n) { off[n] = (BD_R * X + 4 * (tid + n * nthr)) * 4; on[n] = true; }
-        bd_recv<NG>(rx, off, on, v);
-#pragma unroll
-        for (int n = 0; n < NG; ++n) {
-            const int e = tid + n * nthr, j = BD_R + (e >> 4), i = (e & 15) << 2;
-            const float4 f = bd_decode(v[n]);
-            float* d = &B0[j * FD_LD + i];
-            d[0] = f.x; d[1] = f.y; d[2] = f.z; d[3] = f.w;
-            bd_store(rx, off[n], make_uint4(0u, 0u, 0u, 0u));
-        }
-        SOL_STAMP(5);
-        const float rdummy[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        fd_solve<true>(a.fd, qys, L.Bvy, rdummy, a.prof);
-        if (a.iters && tid == 0) a.iters[b] = 0;
-        SOL_STAMP(6);
-        // the pressure rows c0-1 .. c1-1 of every other band, one copy per band
-        constexpr int NS = ((BD_N - 1) * BD_PROWS * (X / 4) + nthr - 1) / nthr;
-#pragma unroll
-        for (int n = 0; n < NS; ++n) {
-            const int e = tid + n * nthr;
-            if (e < (BD_N - 1) * BD_PROWS * (X / 4)) {
-                const int h = e / (BD_PROWS * (X / 4)), r = e - h * (BD_PROWS * (X / 4));
-                const int j = BD_R * (h + 1) - 1 + (r >> 4), i = (r & 15) << 2;
-                bd_store(rx, (BD_DIV_WORDS + (h * BD_PROWS + (r >> 4)) * X + i) * 4, bd_encode(*reinterpret_cast<const float4*>(&P[j * X + i])));
-            }
-        }
-    } else {
+    float* P = L.Bvy + FD_BUF;          // [128][64]: the received pressure rows c0-1 .. c1-1
+    {
         bd_store(rx, ((c0 + (tid >> 4)) * X + ((tid & 15) << 2)) * 4, bd_encode(rq));
-        constexpr int NG = (BD_PROWS * (X / 4) + nthr - 1) / nthr;       // 2 (528 pieces)
+        SOL_STAMP(5);
+        BD_STAMP(4);
+        constexpr int NG = (BD_PROWS * (X / 4) + nthr - 1) / nthr;       // 2 (528 pieces; band 0 has no row -1: 512)
+        const int skip = w == 0 ? X / 4 : 0;
         int off[NG]; bool on[NG]; uint4 v[NG];
 #pragma unroll
         for (int n = 0; n < NG; ++n) {
-            const int e = tid + n * nthr;
+            const int e = skip + tid + n * nthr;
             on[n] = e < BD_PROWS * (X / 4);
-            off[n] = (BD_DIV_WORDS + (w - 1) * BD_PROWS * X + 4 * min(e, BD_PROWS * (X / 4) - 1)) * 4;
+            off[n] = (BD_DIV_WORDS + w * BD_PROWS * X + 4 * min(e, BD_PROWS * (X / 4) - 1)) * 4;
         }
         bd_recv<NG>(rx, off, on, v);
 #pragma unroll
         for (int n = 0; n < NG; ++n) {
-            const int e = tid + n * nthr;
+            const int e = skip + tid + n * nthr;
             if (on[n]) {
                 *reinterpret_cast<float4*>(&P[(c0 - 1 + (e >> 4)) * X + ((e & 15) << 2)]) = bd_decode(v[n]);
                 bd_store(rx, off[n], make_uint4(0u, 0u, 0u, 0u));
             }
         }
+        SOL_STAMP(6);
+        BD_STAMP(6);
         __syncthreads();
     }
 
@@ -1729,15 +1791,66 @@ __device__ __forceinline__ void karman_fwd_band_body(const StepArgs& a, float* s
         }
     }
     SOL_STAMP(8);
+    BD_STAMP(8);
+}
+
+// the simulation's SOLVER workgroup: no stencil work -- its coefficients (100 registers) are in flight while the bands advect --, gathers
+// the divergence rows of all bands, runs the direct solve, hands every band its pressure rows
+#define BS_STAMP(i) do { if (a.prof && blockIdx.x == 8 * BD_N && threadIdx.x == 0) a.prof[i] = wall_clock64(); } while (0)   /* solver workgroup of simulation 0 */
+__device__ __forceinline__ void karman_fwd_solver_wg(const StepArgs& a, float* smem, const int b, unsigned* xw) {
+    constexpr int Y = FD_Y, X = FD_X, nthr = 512;
+    const int tid = threadIdx.x;
+    const Lds L = carve(smem, Y, X, 16);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(xw, 0, BD_WORDS * 4, 0x00020000);
+    BS_STAMP(29);
+    const float fdp = fd_prefetch(a.fd, a.fd_n);
+    FdOps fops;
+    float qys[FD_QYS];
+    fd_load_qys(a.fd + 16, __builtin_amdgcn_readfirstlane(tid >> 6), qys);
+    fd_load_ops(a.fd, fops);
+    float* B0 = L.Bvy;                  // the solver's right-hand side, [128][FD_LD]
+    float* P = L.Bvy + FD_BUF;          // its result, [128][64]
+    constexpr int NG = Y * (X / 4) / nthr;      // 4 pieces per thread
+    int off[NG]; bool on[NG]; uint4 v[NG];
+#pragma unroll
+    for (int n = 0; n < NG; ++n) { off[n] = 4 * (tid + n * nthr) * 4; on[n] = true; }
+    bd_recv<NG>(rx, off, on, v);
+#pragma unroll
+    for (int n = 0; n < NG; ++n) {
+        const int e = tid + n * nthr, j = e >> 4, i = (e & 15) << 2;
+        const float4 f = bd_decode(v[n]);
+        float* d = &B0[j * FD_LD + i];
+        d[0] = f.x; d[1] = f.y; d[2] = f.z; d[3] = f.w;
+        bd_store(rx, off[n], make_uint4(0u, 0u, 0u, 0u));
+    }
+    BS_STAMP(30);
+    const float rdummy[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    fd_solve<true, true>(a.fd, qys, L.Bvy, rdummy, a.prof, fops);
+    if (a.iters && tid == 0) a.iters[b] = 0;
+    BS_STAMP(31);
+    // the pressure rows c0-1 .. c1-1 of every band, one copy per band (band 0 has no row -1)
+    constexpr int NS = (BD_N * BD_PROWS * (X / 4) + nthr - 1) / nthr;
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+        const int e = tid + n * nthr;
+        if (e < BD_N * BD_PROWS * (X / 4)) {
+            const int h = e / (BD_PROWS * (X / 4)), r = e - h * (BD_PROWS * (X / 4));
+            const int j = BD_R * h - 1 + (r >> 4), i = (r & 15) << 2;
+            if (j >= 0) bd_store(rx, (BD_DIV_WORDS + (h * BD_PROWS + (r >> 4)) * X + i) * 4, bd_encode(*reinterpret_cast<const float4*>(&P[j * X + i])));
+        }
+    }
+    BS_STAMP(27);
     if (fdp == 1.2345678e-30f && a.iters) a.iters[b] = -2;      // never true: keeps the prefetch loads alive
 }
 
 __global__ void __launch_bounds__(512) k_karman_fwd_bands(StepArgs a, DensStep q, unsigned* xch) {
     extern __shared__ __align__(16) float smem[];
-    const int u = (int)blockIdx.x, nsol = 8 * BD_N * ((a.B + 7) >> 3);
+    const int u = (int)blockIdx.x, nsol = 8 * (BD_N + 1) * ((a.B + 7) >> 3);
     if (u < nsol) {
-        const int b = (u / (8 * BD_N)) * 8 + (u & 7), w = (u >> 3) & (BD_N - 1);
-        if (b < a.B) karman_fwd_band_body(a, smem, b, w, xch + (size_t)b * BD_WORDS);
+        const int b = (u / (8 * (BD_N + 1))) * 8 + (u & 7), w = (u >> 3) % (BD_N + 1);
+        if (b >= a.B) return;
+        if (w < BD_N) karman_fwd_band_body(a, smem, b, w, xch + (size_t)b * BD_WORDS);
+        else karman_fwd_solver_wg(a, smem, b, xch + (size_t)b * BD_WORDS);
     } else density_step_body(q, u - nsol);
 }
 
@@ -2290,7 +2403,7 @@ static long long* prof_buffer() {
     if (!pbuf && hipMalloc(&pbuf, 32 * sizeof(long long)) != hipSuccess) pbuf = nullptr;
     return pbuf;
 }
-static int prof_print(hipStream_t stream, const StepArgs& a, bool fused) {
+static int prof_print(hipStream_t stream, const StepArgs& a, bool fused, bool bands = false) {
     long long h[32];
     SOL_HIP_CHECK(hipStreamSynchronize(stream));
     SOL_HIP_CHECK(hipMemcpy(h, a.prof, sizeof(h), hipMemcpyDeviceToHost));
@@ -2298,10 +2411,16 @@ static int prof_print(hipStream_t stream, const StepArgs& a, bool fused) {
     for (int i = 1; i <= 8; ++i) fprintf(stderr, " %.2f", (double)(h[i] - h[i - 1]) * 0.01);
     fprintf(stderr, "  total %.2f\n", (double)(h[8] - h[0]) * 0.01);
     if (a.fd) {
-        const int s0 = a.g_vy_in ? 2 : 5;      // stamp taken just before the solve
+        const int s0 = bands ? 30 : (a.g_vy_in ? 2 : 5);      // stamp taken just before the solve
         fprintf(stderr, "[SOL_STEP_PROF direct] fwd-transform %.2f  u %.2f  x0w %.2f  K' %.2f  scatter+t2w %.2f  spectral add %.2f  x-inverse %.2f\n",
                 (double)(h[9] - h[s0]) * 0.01, (double)(h[10] - h[9]) * 0.01, (double)(h[11] - h[10]) * 0.01, (double)(h[12] - h[11]) * 0.01,
                 (double)(h[13] - h[12]) * 0.01, (double)(h[14] - h[13]) * 0.01, (double)(h[15] - h[14]) * 0.01);
+    }
+    if (bands) {   // band-split forward launch: band 1's stamps (h[20..]: 0 start, 3 advected, 4 divergence sent, 6 pressure received, 8 end) and the solver workgroup's, relative to band 0's first
+        fprintf(stderr, "[SOL_STEP_PROF bands] band 1: start %.2f  advected %.2f  divergence sent %.2f  pressure received %.2f  end %.2f\n",
+                (double)(h[20] - h[0]) * 0.01, (double)(h[23] - h[0]) * 0.01, (double)(h[24] - h[0]) * 0.01, (double)(h[26] - h[0]) * 0.01, (double)(h[28] - h[0]) * 0.01);
+        fprintf(stderr, "[SOL_STEP_PROF bands] solver workgroup: start %.2f  divergence gathered %.2f  solved %.2f  pressure sent %.2f\n",
+                (double)(h[29] - h[0]) * 0.01, (double)(h[30] - h[0]) * 0.01, (double)(h[31] - h[0]) * 0.01, (double)(h[27] - h[0]) * 0.01);
     }
     if (fused)      // relative to the adjoint workgroup's first stamp: first / last weight-gradient workgroup
         fprintf(stderr, "[SOL_STEP_PROF fused] adjoint 0.00 .. %.2f | first gradient workgroup %.2f .. %.2f | last %.2f .. %.2f\n",
@@ -2381,10 +2500,10 @@ static int step_fwd_impl(const sol_karman_cfg* cfg, void* stream,
         DensStep q{};
         if (dens_d_out) q = DensStep{cfg->B, cfg->Y, cfg->X, cfg->inflow_before, cfg->dt / cfg->dx, cfg->dt, dens_d_in, dens_svy, dens_svx, inflow, dens_d_out};
         if (sol_opt().step_prof) a.prof = prof_buffer();
-        const int nsol = 8 * BD_N * ((cfg->B + 7) / 8);
+        const int nsol = 8 * (BD_N + 1) * ((cfg->B + 7) / 8);
         SOL_LAUNCH(k_karman_fwd_bands, dim3(nsol + (dens_d_out ? cfg->B : 0)), dim3(512), lds_bytes(cfg->Y, cfg->X, 16), (hipStream_t)stream, a, q, xchg);
         SOL_LAUNCH_CHECK();
-        if (a.prof) return prof_print((hipStream_t)stream, a, false);
+        if (a.prof) return prof_print((hipStream_t)stream, a, false, true);
         return SOL_OK;
     }
     if (dens_d_out) {   // density workgroups of the PREVIOUS step ride in this launch (direct-solver kernels only)
@@ -2427,7 +2546,7 @@ int sol_karman_step_fwd_dens(const sol_karman_cfg* cfg, void* stream,
 // the band-split forward launch (k_karman_fwd_bands): 128 x 64, direct solver, every workgroup of the launch resident at once.
 // xchg: sol_karman_fwd_bands_words(B) zeroed 32-bit words that the launches keep zeroed between uses.
 int sol_karman_fwd_bands_usable(const sol_karman_cfg* cfg) {
-    return cfg && sol_opt().fwd_bands && cfg->direct && cfg->Y == FD_Y && cfg->X == FD_X && pick_cpt(cfg) == 16 && 8 * BD_N * ((cfg->B + 7) / 8) + cfg->B <= 256;
+    return cfg && sol_opt().fwd_bands && cfg->direct && cfg->Y == FD_Y && cfg->X == FD_X && pick_cpt(cfg) == 16 && 8 * (BD_N + 1) * ((cfg->B + 7) / 8) + cfg->B <= 256;
 }
 size_t sol_karman_fwd_bands_words(int B) { return (size_t)B * BD_WORDS; }
 // internal: one density step alone (the last step of the unroll)

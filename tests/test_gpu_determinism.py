@@ -456,17 +456,23 @@ def test_band_split_forward_launch_equals_the_one_workgroup_kernel_bit_for_bit(B
         assert same_bits(t0, t1), "band-split forward launch differs from the one-workgroup kernel"
 
 
-def test_band_split_forward_launch_poisons_a_departure_point_outside_its_halo():
-    """A face whose semi-Lagrangian departure point lies more than the halo (8 rows) away is not clamped silently: it reads NaN, and so
-    does the loss of the step.  (The one-workgroup kernel handles any displacement; |u| dt / dx >= 8 is far outside the scene's range.)"""
-    tr, (d, vy, vx, re, gy, gx) = _trainer2d(2, 128, 64, 2, False)
-    vy = vy.clone()
-    vy[1, 60:70, 20:30] = 40.0           # 40 cells per step
-    with _option("fwd_bands", 1):
-        tr.fwd_bwd(d, vy, vx, re, gy, gx, want_final=True)
-        torch.cuda.synchronize()
-        assert not torch.isfinite(tr.loss_steps).all()
-    with _option("fwd_bands", 0):
-        tr.fwd_bwd(d, vy, vx, re, gy, gx, want_final=True)
-        torch.cuda.synchronize()
-        assert torch.isfinite(tr.loss_steps).all()
+def test_band_split_forward_launch_with_departure_points_outside_the_halo():
+    """Departure points more than the halo (8 rows) away -- |u| dt / dx >= 8: what an untrained network's first corrections can produce --
+    take the band kernel's slow path (far corners recomputed from the step's input in global memory).  Same arithmetic as the one-workgroup
+    kernel; the recomputed corners can differ from the LDS-resident ones in the last bit (one face in its last bit moves the roundings of the
+    whole pressure solve), so this case is held to 1e-6 relative L2, not to bit identity."""
+    out = {}
+    for bands in (0, 1):
+        with _option("fwd_bands", bands):
+            tr, (d, vy, vx, re, gy, gx) = _trainer2d(2, 128, 64, 3, False)
+            vy, vx = vy.clone(), vx.clone()
+            vy[1, 60:70, 20:30] = 40.0           # 25 cells per step
+            vy[0, 100:110, 5:50] = -17.0
+            vx[0, 30:40, 10:20] = 30.0
+            vx[1, 5:9, :] = -55.0
+            tr.fwd_bwd(d, vy, vx, re, gy, gx, want_final=True)
+            torch.cuda.synchronize()
+            out[bands] = (tr.grads.clone(), tr.loss_steps.clone()) + tuple(t.clone() for t in tr.final)
+    assert torch.isfinite(out[1][1]).all()
+    for t0, t1 in zip(out[0], out[1]):
+        assert rel(t1, t0) < 1e-6, "band-split forward launch differs from the one-workgroup kernel for far departure points"
