@@ -759,13 +759,16 @@ def main():
                                   "mfma_pipe_busy = %d x frac is the occupancy of that pipe, frac_of_fp32_matrix_peak compares with v_mfma_f32_*_f32." % (nprod, nprod))
                                  if nprod > 1 else "fp32 MFMA (v_mfma_f32_16x16x4_f32); achieved = algorithmic fp32 FLOPs / average in-pipeline duration"}
         # (2) the fused advect+pressure step the north star names, as launched in the training graph at this batch size
-        sname, sst = pick("k_karman_fwd_dens", "k_karman_fwd")
+        sname, sst = pick("k_karman_fwd_bands", "k_karman_fwd_dens", "k_karman_fwd")
+        bands = sname == "k_karman_fwd_bands"
+        solver_wgs = (40 * ((B + 7) // 8) + B) if bands else ((2 if sname and sname.endswith("dens") else 1) * B)      # workgroups of the launch (bands: 8 x 5 slots per 8 simulations, B of each 8 used, + B density workgroups)
+        solver_cus = (5 * B + B) if bands else solver_wgs
         roof_solver = None
         if sst:
             bytes_step = fwd_b / ms            # algorithmic bytes of one forward launch (SURVEY 8d formula, measured k; 0 with the direct solver)
             t_s = sst["avg_us"] * 1e-6
             roof_solver = {"kernel": sname, "bound": "hbm", "achieved": bytes_step / t_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                           "frac": bytes_step / t_s / (PEAK_HBM_GBS * 1e9), "traffic": traffic_bytes(traffic, sname, (2 if sname.endswith("dens") else 1) * B * 512),
+                           "frac": bytes_step / t_s / (PEAK_HBM_GBS * 1e9), "traffic": traffic_bytes(traffic, sname, solver_wgs * 512),
                            "launch_us": sst["avg_us"], "launches_per_train_step": sst["calls"], "share_of_step_kernel_time": sst["total_us"] / tot_prof,
                            "cg_iters": kf_tr, "algorithmic_bytes_per_launch": bytes_step,
                            "accounting": "SURVEY 8d formula 4*(10*Nf + 9*N + 11*N*k) per sample-step with the MEASURED k of this solver (k = 0 for the direct solve)",
@@ -775,8 +778,13 @@ def main():
                                        "would move for the same result.  This launch does not move it, so no fraction of peak is quoted for it"},
                            "pressure_solver": "direct (sine-transform diagonalisation + capacitance correction, no iteration)" if direct
                                               else "two-level preconditioned CG",
-                           "note": "LDS-resident, one workgroup (CU) per simulation: B = %d simulations occupy %d of 256 CUs, so the fraction of "
-                                   "the CHIP's HBM roofline at this batch size is bounded by B/256 = %.3f" % (B, B, B / 256.0)}
+                           "workgroups_per_simulation": 5 if bands else 1,
+                           "note": ("LDS-resident, FIVE workgroups per simulation since round 6 (four row bands for the stencil phases with recomputed halos + one "
+                                    "solver workgroup; hand-offs of divergence and pressure through global memory) + one density workgroup: B = %d simulations "
+                                    "occupy %d of 256 CUs; the launch is a latency chain (bands 5.7 us -> solve 15.4 us -> projection 2 us), not a streaming kernel"
+                                    % (B, solver_cus)) if bands else
+                                   ("LDS-resident, one workgroup (CU) per simulation: B = %d simulations occupy %d of 256 CUs, so the fraction of "
+                                    "the CHIP's HBM roofline at this batch size is bounded by B/256 = %.3f" % (B, B, B / 256.0))}
         bname, bst = pick("k_karman_bwd_bww", "k_karman_bwd")
         kern_tab = {k: {"calls": v["calls"], "avg_us": round(v["avg_us"], 2), "share": round(v["total_us"] / tot_prof, 4)}
                     for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_us"])}

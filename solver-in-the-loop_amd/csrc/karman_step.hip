@@ -108,9 +108,13 @@ __device__ __forceinline__ Bil bil_clamp(int H, int W, int jb, float oy, int ib,
     s.i1 = clampi(i0 + 1, 0, W - 1);
     return s;
 }
-// (One expression for every caller.  OPEN OBSERVATION, round 6: spelling the three fused multiply-adds out with __builtin_fmaf -- algebraically the
-//  same blend -- made k_karman_fwd<8, 2> (64 x 32, small-grid direct solve) miss its golden step by 2.3e-4 / 2.7e-3 while k_karman_fwd<8, 0>
-//  (CG) of the same build stayed at 5e-8; deterministic, unexplained (tools/debug_6432.py), so the expression stays as it has been since round 1.)
+// (One expression for every caller.  OBSERVATION, round 6 (tools/debug_6432.py): with the three fused multiply-adds spelled out through
+//  __builtin_fmaf -- algebraically the same blend -- k_karman_fwd<8, 2> (64 x 32, small-grid direct solve) missed its golden step by 2.3e-4 / 2.7e-3,
+//  deterministically, with an error pattern centred on the obstacle window, while k_karman_fwd<8, 0> (CG) of the same build stayed at 5e-8.  The
+//  same source built WITHOUT `-mllvm --amdgpu-sched-strategy=iterative-ilp` (_build.py) is correct (4.5e-8): LLVM's experimental scheduler
+//  strategy mis-schedules that kernel for that spelling.  The strategy is worth 0.49 ms of a 11.7 ms C3 step (the weight-gradient body in the
+//  fused adjoint launch), so it stays; what guards the shipped binary is that every kernel of this file is compared with the oracle / golden
+//  vectors by the GPU suite ON THE BUILD THAT SHIPS.  Do not respell numerics here without running `pytest -m gpu`.)
 __device__ __forceinline__ float bil_mix(const Bil& s, float f00, float f01, float f10, float f11) {
     return (1.f - s.wy) * ((1.f - s.wx) * f00 + s.wx * f01) + s.wy * ((1.f - s.wx) * f10 + s.wx * f11);
 }

@@ -344,6 +344,8 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
             const int c4 = e & 3, row = (e >> 2) & 15, tp = (e >> 6) % 25, wt = e / (25 * 64);      // wt = (mt, nt) tile
             return reinterpret_cast<float4*>(&pw[(tp * 32 + 16 * (wt & 1) + row) * 32 + 16 * (wt >> 1) + c4 * 4]);
         };
+        // (round 6, measured: pulling the old slice into the L2 with one dword per line and thread under the MFMAs of the last six rows made the
+        //  step SLOWER, 11.76 vs 11.67 ms over three alternations: the requests compete with the row loads the MFMAs are waiting for)
         float4 old[NP];
         if (!a.overwrite) {
 #pragma unroll
