@@ -208,6 +208,8 @@ struct SolOptions {
                           //    layer's data gradient) in exact fp32 on the vector ALU (conv5x5_thin.hip: no absmax wait, no operand split); 0: k_conv5x5_sb<1, KIND>
     int seed_fuse;        // 1 (default): on 64-pixel rows the trainer's loss-gradient seed is computed inside the 2 -> 32 backward-data launch (sol_conv5x5_seed)
                           //    instead of a k_seed launch per unrolled step
+    int conv_thin_t3;     // 1 (default): the thin-INPUT layers of 64-pixel images (first layer, last backward-data layer incl. seed mode) as three image rows per
+                          //    twelve-wave workgroup (k_conv5x5_t3); 0: k_conv5x5<4, NT>, one row per workgroup
     int fwd_bands;        // 1 (default): the 128 x 64 forward solver step of the training / roll-out path as FOUR workgroups per simulation (k_karman_fwd_bands:
                           //    stencil phases on row bands with recomputed halos, the direct solve on band 0's CU, two hand-offs through global memory); 0: one workgroup
     int k3d_tile;         // 1: karman-3d advection from LDS tiles holding the full z column + halo; 0 (default, measured faster at B <= 2): wave-per-column gathers from global memory

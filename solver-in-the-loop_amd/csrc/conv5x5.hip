@@ -226,6 +226,156 @@ __global__ void __launch_bounds__(256) k_conv5x5(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// thin-INPUT layer (4 -> 16 NT channels, 64-pixel rows), THREE image rows per workgroup (round 6)
+// ------------------------------------------------------------------------------------
+// The trainer's first layer (3 -> 32) and its last backward-data layer (2 -> 32, seed mode): 0.24 GFLOP per launch, pure launch latency.  As
+// k_conv5x5<4, NT> they ran one image row per 256-thread workgroup: 768 workgroups (three per CU), each staging FIVE halo rows and the
+// whole 12.8 KB weight block for one row of output -- and, in seed mode, evaluating the loss gradient of every pixel five times.  Here a
+// workgroup of twelve waves owns three consecutive rows of the (batch x height) row stack (the dx kernel's tiling: 256 workgroups, one per
+// CU): seven halo rows, one weight block, wave = (row, 16-pixel segment).  Rows of the stack that belong to another image than the output row
+// (the stack is cut anywhere, also between two images) contribute zeros: the test is wave uniform, one v_cndmask per MFMA operand.
+// Arithmetic and summation order per output pixel are k_conv5x5<4, NT>'s (same MFMA sequence over the taps): bit-identical results.
+template <int NT>
+__global__ void __launch_bounds__(768) k_conv5x5_t3(ConvArgs a) {
+    constexpr int CP = 4, OP = NT * 16, W = 64, HW = W + 4, NR = 3, NH = NR + 4, NTHR = 768;
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int H = a.H, R = a.B * H;
+    const int r0 = xcd_tile(blockIdx.x, gridDim.x) * NR;          // first row of the stack owned by this workgroup
+    // the epilogue's operands (residual, activation reference of LeakyReLU') are requested FIRST: they are HBM-cold and nothing but the
+    // launch's own latency chain (stage -> 50 MFMAs -> transpose -> store) is there to cover their round trip
+    constexpr int F4 = 16 * OP / 4 / 64;              // float4 per lane of the wave's [16 px][OP] output tile
+    float4 eres[F4], eact[F4];
+    {
+        const int gro_ = r0 + (wave >> 2), seg_ = wave & 3;
+#pragma unroll
+        for (int n = 0; n < F4; ++n) {
+            const int e = lane + n * 64, px = e / (OP / 4), c4 = e % (OP / 4);
+            const size_t o4 = ((size_t)gro_ * W + seg_ * 16 + px) * (OP / 4) + c4;
+            eres[n] = a.res ? reinterpret_cast<const float4*>(a.res)[o4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            eact[n] = a.epi == SOL_EPI_DLRELU ? reinterpret_cast<const float4*>(a.act)[o4] : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+    }
+
+    // ---- stage the seven halo rows (zero outside the stack / outside the row) and the weight block ----
+    if (a.svy) {
+        // seed mode (ConvArgs): the halo pixel IS the loss gradient, same arithmetic, operation for operation, as k_seed / k_conv5x5<4, 2>
+        const float l00 = a.ls0 * a.ls0, l11 = a.ls1 * a.ls1;
+        for (int pix = tid; pix < NH * HW; pix += NTHR) {
+            const int hr = pix / HW, hc = pix - hr * HW;
+            const int gr = r0 + hr - 2, xx = hc - 2;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gr >= 0 && gr < R && xx >= 0 && xx < W) {
+                const int b = gr / H, yy = gr - b * H;
+                const size_t ky = (size_t)b * (H + 1) * W + (size_t)yy * W + xx, kx = (size_t)b * H * (W + 1) + (size_t)yy * (W + 1) + xx;
+                float gy = (a.svy[ky] - a.gty[ky]) * a.sinv_m / l00, gxx = (a.svx[kx] - a.gtx[kx]) * a.sinv_m / l11;
+                if (a.sginy) { gy += a.sginy[ky]; gxx += a.sginx[kx]; }
+                v.x = a.cs0 * gy; v.y = a.cs1 * gxx;
+                if (hr >= 2 && hr < 2 + NR) {            // the workgroup's own rows: publish G and dO2
+                    a.sgy[ky] = gy; a.sgx[kx] = gxx;
+                    *reinterpret_cast<float2*>(a.sdO2 + ((size_t)gr * W + xx) * 2) = make_float2(v.x, v.y);
+                }
+            }
+            *reinterpret_cast<float4*>(&smem[pix * CP]) = v;
+        }
+        // the faces without a cell of their own: v_x column X of every own row, v_y row Y behind the last row of an image
+        if (tid < NR) {
+            const int gr = r0 + tid, b = gr / H, yy = gr - b * H;
+            const size_t kx = (size_t)b * H * (W + 1) + (size_t)yy * (W + 1) + W;
+            float gq = (a.svx[kx] - a.gtx[kx]) * a.sinv_m / l11;
+            if (a.sginx) gq += a.sginx[kx];
+            a.sgx[kx] = gq;
+        }
+        if (tid >= 64 && tid < 64 + NR * W) {
+            const int o = (tid - 64) / W, xx = (tid - 64) - o * W, gr = r0 + o, b = gr / H, yy = gr - b * H;
+            if (yy == H - 1) {
+                const size_t ky = (size_t)b * (H + 1) * W + (size_t)H * W + xx;
+                float gq = (a.svy[ky] - a.gty[ky]) * a.sinv_m / l00;
+                if (a.sginy) gq += a.sginy[ky];
+                a.sgy[ky] = gq;
+            }
+        }
+    } else {
+        const float4* gx = reinterpret_cast<const float4*>(a.x);
+        for (int pix = tid; pix < NH * HW; pix += NTHR) {
+            const int hr = pix / HW, hc = pix - hr * HW;
+            const int gr = r0 + hr - 2, xx = hc - 2;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gr >= 0 && gr < R && xx >= 0 && xx < W) v = gx[(size_t)gr * W + xx];
+            *reinterpret_cast<float4*>(&smem[pix * CP]) = v;
+        }
+    }
+    {
+        const float4* gw = reinterpret_cast<const float4*>(a.wp);
+        float* wl = smem + NH * HW * CP;
+        for (int e = tid; e < 25 * OP; e += NTHR) *reinterpret_cast<float4*>(&wl[e * 4]) = gw[e];
+    }
+    __syncthreads();
+
+    // ---- implicit GEMM: wave = (output row, 16-pixel segment), one MFMA per tap and channel tile, lane group g = input channel ----
+    const int orow = wave >> 2, seg = wave & 3;
+    const int gro = r0 + orow, yo = gro % H;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        const float* abase = &smem[(orow * HW + seg * 16 + li) * CP + g];
+        const float* wl = smem + NH * HW * CP + li * 4 + g;
+#pragma unroll
+        for (int tap = 0; tap < 25; ++tap) {
+            const int dy = tap / 5, dx = tap - dy * 5;
+            const bool ok = yo + dy - 2 >= 0 && yo + dy - 2 < H;       // the tap's row lies in the output row's image (wave uniform)
+            const float av = ok ? abase[(dy * HW + dx) * CP] : 0.f;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wl[(tap * OP + n * 16) * 4], acc[n], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: bias, residual, LeakyReLU / LeakyReLU'; the wave's [16 px][OP] tile leaves as 16-byte pieces of full pixels ----
+    float vmax = 0.f;
+    __syncthreads();                                 // every wave is done with the halo tile
+    float* tb = smem + wave * (16 * OP);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const float bias = a.bias ? a.bias[n * 16 + li] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tb[(4 * g + r) * OP + n * 16 + li] = acc[n][r] + bias;
+    }
+#pragma unroll
+    for (int n = 0; n < F4; ++n) {
+        const int e = lane + n * 64;
+        const int px = e / (OP / 4), c4 = e % (OP / 4);
+        float4 v = *reinterpret_cast<const float4*>(&tb[px * OP + c4 * 4]);
+        const size_t o4 = ((size_t)gro * W + seg * 16 + px) * (OP / 4) + c4;
+        if (a.res) { const float4 q = eres[n]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+        if (a.epi == SOL_EPI_LRELU) {
+            v.x = v.x > 0.f ? v.x : a.slope * v.x; v.y = v.y > 0.f ? v.y : a.slope * v.y;
+            v.z = v.z > 0.f ? v.z : a.slope * v.z; v.w = v.w > 0.f ? v.w : a.slope * v.w;
+        } else if (a.epi == SOL_EPI_DLRELU) {
+            const float4 q = eact[n];
+            v.x *= q.x > 0.f ? 1.f : a.slope; v.y *= q.y > 0.f ? 1.f : a.slope;
+            v.z *= q.z > 0.f ? 1.f : a.slope; v.w *= q.w > 0.f ? 1.f : a.slope;
+        }
+        vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        st_wt(reinterpret_cast<float4*>(a.y) + o4, v);
+    }
+    if (a.ymax) {                                    // workgroup uniform
+        __syncthreads();
+        amax_publish(vmax, a.ymax, smem);
+    }
+}
+// usable where the launch is the thin-input layer of 64-pixel rows and the row stack divides into triples
+static bool conv_t3_usable(int B, int H, int W, int cin, int cout_padded) {
+    return sol_opt().conv_thin_t3 && cin == 4 && W == 64 && (cout_padded == 32 || cout_padded == 16) && ((B * H) % 3) == 0;
+}
+static size_t conv_t3_lds(int OP) {
+    size_t lds = ((size_t)7 * 68 * 4 + (size_t)25 * OP * 4) * sizeof(float);
+    const size_t epi = (size_t)12 * 16 * OP * sizeof(float);
+    return lds < epi ? epi : lds;
+}
+
+// ------------------------------------------------------------------------------------
 // 32-input-channel kernel (the 22 FLOP-dominant launches per sim-step): software pipelined.
 //   * halo tile UNPADDED with an XOR swizzle of the 16-byte channel chunks
 //     (chunk ^= ((pix >> 1) & 3) << 1) -> conflict-free ds_read_b128 for the A operand, and
@@ -1164,6 +1314,10 @@ static int conv_impl(void* stream, const float* x, const float* packed, const fl
             SOL_LAUNCH((k_conv5x5_c32<1>), dim3(grid), dim3(256), lds32, s, a);
         }
     }
+    else if (conv_t3_usable(B, H, W, cin, pad_out(cout)) && cout == pad_out(cout)) {
+        if (NT == 2) SOL_LAUNCH((k_conv5x5_t3<2>), dim3(B * H / 3), dim3(768), conv_t3_lds(32), s, a);
+        else SOL_LAUNCH((k_conv5x5_t3<1>), dim3(B * H / 3), dim3(768), conv_t3_lds(16), s, a);
+    }
     else if (cin == 4 && NT == 2) SOL_LAUNCH((k_conv5x5<4, 2>), dim3(grid), dim3(256), lds, s, a);
     else SOL_LAUNCH((k_conv5x5<4, 1>), dim3(grid), dim3(256), lds, s, a);
     SOL_LAUNCH_CHECK();
@@ -1198,7 +1352,8 @@ int sol_conv5x5_seed(void* stream, const float* packed_bwd, const float* act_ref
     a.cs0 = s0; a.cs1 = s1; a.ls0 = l0; a.ls1 = l1; a.sinv_m = inv_m;
     size_t lds = (size_t)5 * 68 * 4 * sizeof(float) + (size_t)25 * 32 * 4 * sizeof(float);
     if (lds < 4 * 16 * 32 * sizeof(float)) lds = 4 * 16 * 32 * sizeof(float);
-    SOL_LAUNCH((k_conv5x5<4, 2>), dim3(B * H), dim3(256), lds, (hipStream_t)stream, a);
+    if (conv_t3_usable(B, H, W, 4, 32)) SOL_LAUNCH((k_conv5x5_t3<2>), dim3(B * H / 3), dim3(768), conv_t3_lds(32), (hipStream_t)stream, a);
+    else SOL_LAUNCH((k_conv5x5<4, 2>), dim3(B * H), dim3(256), lds, (hipStream_t)stream, a);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }

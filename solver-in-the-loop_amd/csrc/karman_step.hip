@@ -112,11 +112,18 @@ __device__ __forceinline__ Bil bil_clamp(int H, int W, int jb, float oy, int ib,
 //  __builtin_fmaf -- algebraically the same blend -- k_karman_fwd<8, 2> (64 x 32, small-grid direct solve) missed its golden step by 2.3e-4 / 2.7e-3,
 //  deterministically, with an error pattern centred on the obstacle window, while k_karman_fwd<8, 0> (CG) of the same build stayed at 5e-8.  The
 //  same source built WITHOUT `-mllvm --amdgpu-sched-strategy=iterative-ilp` (_build.py) is correct (4.5e-8): LLVM's experimental scheduler
-//  strategy mis-schedules that kernel for that spelling.  The strategy is worth 0.49 ms of a 11.7 ms C3 step (the weight-gradient body in the
+//  strategy mis-schedules that kernel for that spelling (`max-ilp` is correct too, and as slow as the default: 12.11 vs 11.60 ms per step).  The strategy is worth 0.49 ms of a 11.7 ms C3 step (the weight-gradient body in the
 //  fused adjoint launch), so it stays; what guards the shipped binary is that every kernel of this file is compared with the oracle / golden
 //  vectors by the GPU suite ON THE BUILD THAT SHIPS.  Do not respell numerics here without running `pytest -m gpu`.)
 __device__ __forceinline__ float bil_mix(const Bil& s, float f00, float f01, float f10, float f11) {
+#ifdef BIL_EXPLICIT       // the respelling of the observation above (variant builds only)
+    const float ux = 1.f - s.wx, uy = 1.f - s.wy;
+    const float a0 = __builtin_fmaf(s.wx, f01, ux * f00);
+    const float a1 = __builtin_fmaf(s.wx, f11, ux * f10);
+    return __builtin_fmaf(s.wy, a1, uy * a0);
+#else
     return (1.f - s.wy) * ((1.f - s.wx) * f00 + s.wx * f01) + s.wy * ((1.f - s.wx) * f10 + s.wx * f11);
+#endif
 }
 __device__ __forceinline__ float bil_eval(const float* f, int W, const Bil& s) {
     const float f00 = f[s.j0 * W + s.i0], f01 = f[s.j0 * W + s.i1];

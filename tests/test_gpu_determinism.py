@@ -476,3 +476,25 @@ def test_band_split_forward_launch_with_departure_points_outside_the_halo():
     assert torch.isfinite(out[1][1]).all()
     for t0, t1 in zip(out[0], out[1]):
         assert rel(t1, t0) < 1e-6, "band-split forward launch differs from the one-workgroup kernel for far departure points"
+
+
+@pytest.mark.parametrize("B,Y,X,ms,use_graph", [(6, 128, 64, 3, False), (3, 128, 64, 2, True), (3, 64, 32, 2, False)])
+def test_three_row_thin_input_kernel_equals_the_one_row_kernel_bit_for_bit(B, Y, X, ms, use_graph):
+    """k_conv5x5_t3 (first layer 3 -> 32 and last backward-data layer 2 -> 32 with the loss-gradient seed: three rows of the batch x height stack
+    per twelve-wave workgroup, stack cut across image boundaries) against k_conv5x5<4, 2> (one row per workgroup): same MFMA sequence per
+    pixel, so every bit of the trainer's outputs must agree.  64 x 32 runs the transposed CNN (rows of 64 pixels, 32 rows per image)."""
+    out = {}
+    for t3 in (0, 1):
+        with _option("conv_thin_t3", t3):
+            tr, batch = _trainer2d(B, Y, X, ms, use_graph)
+            tr.grads.zero_()
+            tr.fwd_bwd(*batch, want_final=True)
+            torch.cuda.synchronize()
+            out[t3] = (tr.grads.clone(), tr.loss_steps.clone()) + tuple(t.clone() for t in tr.final)
+            if not use_graph:
+                with sol_amd._lib.profile() as p:
+                    tr.fwd_bwd(*batch, want_final=True)
+                assert any("k_conv5x5_t3" in k for k in p.kernels) == bool(t3), sorted(p.kernels)
+    assert torch.isfinite(out[0][1]).all() and float(out[0][0].abs().max()) > 0
+    for t0, t1 in zip(out[0], out[1]):
+        assert same_bits(t0, t1), "three-row thin-input kernel differs from the one-row kernel"
