@@ -91,6 +91,9 @@ __device__ __forceinline__ void split2u(float x, float y, float scale, unsigned&
 #ifndef BWW_B_UPFRONT
 #define BWW_B_UPFRONT 1
 #endif
+#ifndef BWW_PHASE_SHIFT
+#define BWW_PHASE_SHIFT 1
+#endif
 #ifndef BWW_DBG        // timing experiments (tools/ab_lib.py variants + tools/bww3d_time.py; results invalid): 1 no MFMAs, 2 no staging (the
 #define BWW_DBG 0      // requests die with it), 4 no row barrier, 8 no requests.  Measured per 32 -> 32 Conv3D layer at 128 x 64 x 64 (five
 #endif                 // passes + reduce, 464 us): 187 / 345 / 404 / 354 us; staging interleaved into the MFMA stream (branch-free, one basic block): 460 us
@@ -228,6 +231,22 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
         const int y = gr % H;
         request(gr + 3 < r1 ? gr + 3 : r0, gr + 5, i0, i1);
         __builtin_amdgcn_sched_barrier(0);
+        // Phase shift between the two waves of a SIMD (waves w and w + 4): the dz role stages its row at the HEAD of the iteration, the x role
+        // at its tail -- one wave's split / ds_write phase then lies under the other wave's MFMA block instead of both staging (matrix pipe
+        // idle) and both multiplying at the same time.  Legal: the slot written (dz row gr+3) is read by nobody during this iteration.
+        // Same-box A/B, three alternations (tools/ab_lib.py): 0 (both late) 11.554, 1 (dz early) 11.430, 2 (x early) 11.612, 3 (both early) 11.521 ms per step.
+        if (BWW_PHASE_SHIFT == 1 && !xrole) {
+            if (!(BWW_DBG & 2) && z_in_range(gr + 3)) stage(gr + 1, gr + 3, o0, o1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (BWW_PHASE_SHIFT == 2 && xrole) {            // (variant: the x role stages early, the dz role late)
+            if (!(BWW_DBG & 2) && gr + 1 < r1) stage(gr + 1, gr + 3, o0, o1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (BWW_PHASE_SHIFT == 3) {                     // (variant: both roles stage early)
+            if (!(BWW_DBG & 2) && (xrole ? gr + 1 < r1 : z_in_range(gr + 3))) stage(gr + 1, gr + 3, o0, o1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 
         // x operand of this lane: pixels 8*c0 .. 8*c0+11 (halo coordinates) of channel 16*mt + li, three planes
         uint4 A[NPL][5];
@@ -300,7 +319,7 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
             }
 }
         __builtin_amdgcn_sched_barrier(0);
-        if (!(BWW_DBG & 2) && (xrole ? gr + 1 < r1 : z_in_range(gr + 3))) stage(gr + 1, gr + 3, o0, o1);
+        if (!(BWW_DBG & 2) && (xrole ? ((BWW_PHASE_SHIFT & 2) == 0 && gr + 1 < r1) : ((BWW_PHASE_SHIFT & 1) == 0 && z_in_range(gr + 3)))) stage(gr + 1, gr + 3, o0, o1);
         if (!(BWW_DBG & 4)) BW_BARRIER();
     };
     // (six rows per trip: at the loop's back edge the compiler's wait-count pass gives up on the requests in flight and waits
