@@ -68,6 +68,12 @@ int sol_abi_sizes(int32_t* karman_cfg, int32_t* burgers_cfg, int32_t* train_cfg)
  *   seed_fuse (1)       trainer, 64-pixel rows: the loss-gradient seed of an unrolled step (d loss / d v_i + the adjoint of step i+1, scaled
  *                       to the network's output gradient) is computed by the 2 -> 32 backward-data launch in its staging phase; 0: a k_seed
  *                       launch per unrolled step in front of it
+ *   fwd_bands (1)       trainer / roll-out, 128 x 64, direct solver, B <= 40: the forward solver step of a simulation as FIVE workgroups in one
+ *                       launch (four row bands run the stencil phases with recomputed 8-row halos, a fifth runs the direct solve; hand-offs
+ *                       of divergence and pressure through a workspace region); 0: one workgroup per simulation.  Same results bit for bit
+ *                       (departure points beyond the halo: recomputed from the step's input, 1e-6)
+ *   conv_thin_t3 (1)    thin-input layers (3 -> 32 first layer, 2 -> 32 last backward-data layer incl. the seed form) of 64-pixel rows as three rows
+ *                       of the batch x height stack per twelve-wave workgroup; 0: one row per 256-thread workgroup.  Same results bit for bit
  *   bww_chunk (0), bww_side (1), streams (1), cpt (0), conv_split3 (0), dbg_skip (0), step_prof (0): experiments, debugging */
 int sol_set_option(const char* name, int32_t value);
 int sol_get_option(const char* name, int32_t* value);
