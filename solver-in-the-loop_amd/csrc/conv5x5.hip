@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_t3(ConvArgs a) {
     constexpr int F4 = 16 * OP / 4 / 64;              // float4 per lane of the wave's [16 px][OP] output tile
     float4 eres[F4], eact[F4];
     {
-        const int gro_ = r0 + (wave >> 2), seg_ = wave & 3;
+        const int gro_ = min(r0 + (wave >> 2), R - 1), seg_ = wave & 3;          // (a stack that is no multiple of three: the last workgroup's surplus rows load row R-1 and store nothing)
 #pragma unroll
         for (int n = 0; n < F4; ++n) {
             const int e = lane + n * 64, px = e / (OP / 4), c4 = e % (OP / 4);
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_t3(ConvArgs a) {
             *reinterpret_cast<float4*>(&smem[pix * CP]) = v;
         }
         // the faces without a cell of their own: v_x column X of every own row, v_y row Y behind the last row of an image
-        if (tid < NR) {
+        if (tid < NR && r0 + tid < R) {
             const int gr = r0 + tid, b = gr / H, yy = gr - b * H;
             const size_t kx = (size_t)b * H * (W + 1) + (size_t)yy * (W + 1) + W;
             float gq = (a.svx[kx] - a.gtx[kx]) * a.sinv_m / l11;
@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(768) k_conv5x5_t3(ConvArgs a) {
         }
         if (tid >= 64 && tid < 64 + NR * W) {
             const int o = (tid - 64) / W, xx = (tid - 64) - o * W, gr = r0 + o, b = gr / H, yy = gr - b * H;
-            if (yy == H - 1) {
+            if (yy == H - 1 && gr < R) {
                 const size_t ky = (size_t)b * (H + 1) * W + (size_t)H * W + xx;
                 float gq = (a.svy[ky] - a.gty[ky]) * a.sinv_m / l00;
                 if (a.sginy) gq += a.sginy[ky];
@@ -357,17 +357,21 @@ __global__ void __launch_bounds__(768) k_conv5x5_t3(ConvArgs a) {
             v.x *= q.x > 0.f ? 1.f : a.slope; v.y *= q.y > 0.f ? 1.f : a.slope;
             v.z *= q.z > 0.f ? 1.f : a.slope; v.w *= q.w > 0.f ? 1.f : a.slope;
         }
-        vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-        st_wt(reinterpret_cast<float4*>(a.y) + o4, v);
+        if (gro < R) {
+            vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            st_wt(reinterpret_cast<float4*>(a.y) + o4, v);
+        }
     }
     if (a.ymax) {                                    // workgroup uniform
         __syncthreads();
         amax_publish(vmax, a.ymax, smem);
     }
 }
-// usable where the launch is the thin-input layer of 64-pixel rows and the row stack divides into triples
+// usable where the launch is a SMALL thin-input layer of 64-pixel rows (any number of rows: the last workgroup's surplus rows store nothing)
 static bool conv_t3_usable(int B, int H, int W, int cin, int cout_padded) {
-    return sol_opt().conv_thin_t3 && cin == 4 && W == 64 && (cout_padded == 32 || cout_padded == 16) && ((B * H) % 3) == 0;
+    // small launches only (<= 4 workgroups per CU in the one-row form): at 8192 rows (a Conv3D tap pass at 128 x 64 x 64) the one-row kernel is
+    // the faster one, 45.3 vs 50.8 us per launch (tools/k3d_time.py)
+    return sol_opt().conv_thin_t3 && cin == 4 && W == 64 && (cout_padded == 32 || cout_padded == 16) && B * H <= 1024;
 }
 static size_t conv_t3_lds(int OP) {
     size_t lds = ((size_t)7 * 68 * 4 + (size_t)25 * OP * 4) * sizeof(float);
@@ -1315,8 +1319,8 @@ static int conv_impl(void* stream, const float* x, const float* packed, const fl
         }
     }
     else if (conv_t3_usable(B, H, W, cin, pad_out(cout)) && cout == pad_out(cout)) {
-        if (NT == 2) SOL_LAUNCH((k_conv5x5_t3<2>), dim3(B * H / 3), dim3(768), conv_t3_lds(32), s, a);
-        else SOL_LAUNCH((k_conv5x5_t3<1>), dim3(B * H / 3), dim3(768), conv_t3_lds(16), s, a);
+        if (NT == 2) SOL_LAUNCH((k_conv5x5_t3<2>), dim3((B * H + 2) / 3), dim3(768), conv_t3_lds(32), s, a);
+        else SOL_LAUNCH((k_conv5x5_t3<1>), dim3((B * H + 2) / 3), dim3(768), conv_t3_lds(16), s, a);
     }
     else if (cin == 4 && NT == 2) SOL_LAUNCH((k_conv5x5<4, 2>), dim3(grid), dim3(256), lds, s, a);
     else SOL_LAUNCH((k_conv5x5<4, 1>), dim3(grid), dim3(256), lds, s, a);
@@ -1352,7 +1356,7 @@ int sol_conv5x5_seed(void* stream, const float* packed_bwd, const float* act_ref
     a.cs0 = s0; a.cs1 = s1; a.ls0 = l0; a.ls1 = l1; a.sinv_m = inv_m;
     size_t lds = (size_t)5 * 68 * 4 * sizeof(float) + (size_t)25 * 32 * 4 * sizeof(float);
     if (lds < 4 * 16 * 32 * sizeof(float)) lds = 4 * 16 * 32 * sizeof(float);
-    if (conv_t3_usable(B, H, W, 4, 32)) SOL_LAUNCH((k_conv5x5_t3<2>), dim3(B * H / 3), dim3(768), conv_t3_lds(32), (hipStream_t)stream, a);
+    if (conv_t3_usable(B, H, W, 4, 32)) SOL_LAUNCH((k_conv5x5_t3<2>), dim3((B * H + 2) / 3), dim3(768), conv_t3_lds(32), (hipStream_t)stream, a);
     else SOL_LAUNCH((k_conv5x5<4, 2>), dim3(B * H), dim3(256), lds, (hipStream_t)stream, a);
     SOL_LAUNCH_CHECK();
     return SOL_OK;

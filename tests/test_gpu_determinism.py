@@ -498,3 +498,21 @@ def test_three_row_thin_input_kernel_equals_the_one_row_kernel_bit_for_bit(B, Y,
     assert torch.isfinite(out[0][1]).all() and float(out[0][0].abs().max()) > 0
     for t0, t1 in zip(out[0], out[1]):
         assert same_bits(t0, t1), "three-row thin-input kernel differs from the one-row kernel"
+
+
+@pytest.mark.parametrize("B,H", [(1, 10), (2, 7), (3, 128), (1, 1)])
+@pytest.mark.parametrize("cout,lrelu,with_res", [(32, True, False), (32, False, True), (16, False, False)])
+def test_three_row_thin_input_kernel_on_row_stacks_that_are_no_multiple_of_three(B, H, cout, lrelu, with_res):
+    """The per-op convolution (3 -> cout channels, 64-pixel rows) on k_conv5x5_t3 against the one-row kernel, bit for bit, for row stacks
+    that end inside a triple, images shorter than the 5-row stencil, a residual input and the LeakyReLU epilogue."""
+    gen = torch.Generator().manual_seed(B * 100 + H)
+    x = f32(torch.randn(B, H, 64, 3, generator=gen))
+    w = f32(torch.randn(5, 5, 3, cout, generator=gen) * 0.2)
+    b = f32(torch.randn(cout, generator=gen))
+    res = f32(torch.randn(B, H, 64, cout, generator=gen)) if with_res else None
+    out = {}
+    for t3 in (0, 1):
+        with _option("conv_thin_t3", t3):
+            out[t3] = ops.conv5x5(x, w, b, residual=res, lrelu=lrelu).clone()
+    assert torch.isfinite(out[0]).all() and float(out[0].abs().max()) > 0
+    assert same_bits(out[0], out[1])
