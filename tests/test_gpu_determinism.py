@@ -516,3 +516,27 @@ def test_three_row_thin_input_kernel_on_row_stacks_that_are_no_multiple_of_three
             out[t3] = ops.conv5x5(x, w, b, residual=res, lrelu=lrelu).clone()
     assert torch.isfinite(out[0]).all() and float(out[0].abs().max()) > 0
     assert same_bits(out[0], out[1])
+
+
+def test_band_split_forward_launch_under_cu_pressure_from_another_stream():
+    """The band workgroups of a simulation wait for each other inside one launch; that is safe while every workgroup of the launch becomes
+    resident eventually.  Chip-filling work of ANOTHER stream (long GEMMs that keep all CUs busy while the trainer's launches arrive) must
+    only delay the step, never hang it or change a bit of its results."""
+    tr, batch = _trainer2d(6, 128, 64, 3, False)
+    tr.grads.zero_()
+    tr.fwd_bwd(*batch, want_final=True)
+    torch.cuda.synchronize()
+    ref = (tr.grads.clone(), tr.loss_steps.clone()) + tuple(t.clone() for t in tr.final)
+    side = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device=DEV)
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                a = (a @ a).clamp_(-1.0, 1.0)             # ~ 1 ms each, every CU
+        tr.grads.zero_()
+        tr.fwd_bwd(*batch, want_final=True)
+        torch.cuda.synchronize()
+        got = (tr.grads, tr.loss_steps) + tuple(tr.final)
+        assert torch.isfinite(tr.loss_steps).all()
+        for t0, t1 in zip(ref, got):
+            assert same_bits(t0, t1), "results changed under CU pressure (a band hand-off timed out?)"
