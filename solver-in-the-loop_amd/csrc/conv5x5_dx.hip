@@ -45,6 +45,12 @@ constexpr int dx_wph(int COT) { return 5 * 2 * dx_wpl(COT); }  // bytes per dx p
 constexpr int dx_wbufs(int R) { return R == 1 ? 5 : 2; }       // one row per workgroup: all five weight sets stay resident (see RW in the kernel)
 constexpr int dx_lds(int R, int COT) { return (R + 4) * DX_SLOT + dx_wbufs(R) * dx_wph(COT) + 16 + 64; }    // + absmax words, loss_publish_last's 4 + 12
 
+// DX_ACL2: the two cross products of a tap (h1 h2', h2' h1) accumulate into SEPARATE registers that are added in the epilogue.  With one
+// accumulator a row's two cross-term MFMAs of step s and the first of step s + 1 are 6 and then 3 issue slots apart (1-row steps: 2), and a
+// dependent v_mfma_f32_16x16x32_f16 issues ~4 slots after its producer (tools/mfma_dep_distance.py): bubbles only the other wave can fill.
+#ifndef DX_ACL2
+#define DX_ACL2 0
+#endif
 #define DX_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // -DSOL_CONV_PROF (tools/conv_dx_probe.py builds such a library next to the product one): phase stamps (100 MHz s_memrealtime,
@@ -238,9 +244,9 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
         else biasv = make_float4(4 * g < a.CO ? bp[0] : 0.f, 4 * g + 1 < a.CO ? bp[1] : 0.f, 4 * g + 2 < a.CO ? bp[2] : 0.f, 4 * g + 3 < a.CO ? bp[3] : 0.f);
     }
 
-    f32x4 acc[R], acl[R];                                       // acl: the 2^-11 weighted cross terms
+    f32x4 acc[R], acl[R], acm[R];                               // acl (+ acm, DX_ACL2): the 2^-11 weighted cross terms
 #pragma unroll
-    for (int j = 0; j < R; ++j) { acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acl[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int j = 0; j < R; ++j) { acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acl[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acm[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     // epilogue operands (residual, activation reference): requested at the start of the last phase, consumed after the last MFMA
     float4 resv[R], actv[R];
@@ -434,8 +440,10 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
                 for (int j = jlo; j <= jhi; ++j)
                     acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bw[set][s - j][0]), x1, acc[j], 0, 0, 0);
 #pragma unroll
-                for (int j = jlo; j <= jhi; ++j)
-                    acl[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bw[set][s - j][1]), x1, acl[j], 0, 0, 0);
+                for (int j = jlo; j <= jhi; ++j) {
+                    if (DX_ACL2) acm[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bw[set][s - j][1]), x1, acm[j], 0, 0, 0);
+                    else acl[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bw[set][s - j][1]), x1, acl[j], 0, 0, 0);
+                }
             } else {
                 // border / image-straddling workgroups: the pairs whose input row lies in another image are skipped
 #pragma unroll
@@ -444,7 +452,8 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
                         const f16x8 b1 = __builtin_bit_cast(f16x8, bw[set][s - j][0]), b2 = __builtin_bit_cast(f16x8, bw[set][s - j][1]);
                         acl[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1, x2, acl[j], 0, 0, 0);
                         acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1, x1, acc[j], 0, 0, 0);
-                        acl[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2, x1, acl[j], 0, 0, 0);
+                        if (DX_ACL2) acm[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2, x1, acm[j], 0, 0, 0);
+                        else acl[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2, x1, acl[j], 0, 0, 0);
                     }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -474,6 +483,10 @@ __global__ void __launch_bounds__(512) k_conv5x5_dx(const float* __restrict__ ar
     // The wave that is through with its MFMAs issues its epilogue AHEAD of the other wave's MFMA stream on the same SIMD (the ~60 VALU
     // instructions per row otherwise wait behind it, 10-20 clocks apiece).  Same-box A/B, four alternations: 12.49 -> 12.45 ms per step.
     __builtin_amdgcn_s_setprio(3);
+    if (DX_ACL2) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) acl[j] += acm[j];
+    }
     if (COT == 2 || SPLIT) {
         if (mma) {
 #pragma unroll

@@ -495,6 +495,10 @@ __global__ void __launch_bounds__(512) k_conv5x5_bww_sb(BwArgs a) {
     bww_sb_body<KIND>(a, blockIdx.x, smem_sb);
 }
 
+#ifdef BWW_PROF
+extern "C" int sol_bww_prof_set(unsigned* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(sbk::g_bww_prof), &buf, sizeof(buf)) == hipSuccess ? 0 : -1; }
+#endif
+
 // ------------------------------------------------------------------------------------
 // all layers, all operand forms, one launch (training / roll-out path)
 // ------------------------------------------------------------------------------------

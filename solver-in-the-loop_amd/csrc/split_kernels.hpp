@@ -94,9 +94,29 @@ __device__ __forceinline__ void split2u(float x, float y, float scale, unsigned&
 #ifndef BWW_PHASE_SHIFT
 #define BWW_PHASE_SHIFT 1
 #endif
+#ifndef BWW_PIPE        // KIND 2: rows are staged ONE ROW FURTHER AHEAD (x row gr + 2 / dz row gr + 4 during row gr) and a wave reads the operand
+#define BWW_PIPE 0      // fragments of row gr + 1 at the TAIL of row gr, in front of the row barrier: the first MFMA of a row waits for no LDS round trip
+#endif
+#ifndef BWW_REQ_LATE    // BWW_PIPE: the dz role (which stages at the head of the row, on the row's critical path) issues its requests BEHIND its staging
+#define BWW_REQ_LATE 1
+#endif
+#ifndef BWW_PIN_ORDER
+#define BWW_PIN_ORDER 1
+#endif
+#ifndef BWW_Z_ROTATE     // KIND 2: the dz fragments live in registers ACROSS rows (row gr's tap row dy is row gr+1's tap row dy+1): one new
+#define BWW_Z_ROTATE 1   // fragment pair is read per row instead of five (0: all five re-read from the ring every row, rounds 4-6)
+#endif
 #ifndef BWW_DBG        // timing experiments (tools/ab_lib.py variants + tools/bww3d_time.py; results invalid): 1 no MFMAs, 2 no staging (the
 #define BWW_DBG 0      // requests die with it), 4 no row barrier, 8 no requests.  Measured per 32 -> 32 Conv3D layer at 128 x 64 x 64 (five
 #endif                 // passes + reduce, 464 us): 187 / 345 / 404 / 354 us; staging interleaved into the MFMA stream (branch-free, one basic block): 460 us
+// -DBWW_PROF (tools/bww_row_probe.py): per-WAVE s_memtime stamps (low 32 bits), six per image row, kept in the unused LDS behind the KIND-2
+// ring (81,920 .. 122,880) and dumped before the fold: [workgroup][wave][row][8] into the buffer set with sol_bww_prof_set().
+#ifdef BWW_PROF
+static __device__ unsigned* g_bww_prof = nullptr;
+#define BWW_STAMP(row, k) do { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (lane == 0 && (row) - r0 < 40) bww_st[((row) - r0) * 8 + (k)] = t_; } while (0)
+#else
+#define BWW_STAMP(row, k) do { } while (0)
+#endif
 constexpr int BW_XPL = 32 * 256;                          // bytes: x plane of one row stage
 constexpr int BW_ZPL = 32 * 128;                          // bytes: dz plane of one row stage
 constexpr int BW_LDS = 2 * 3 * BW_XPL + 6 * 3 * BW_ZPL;   // 122,880 B (three planes; also >= the 102,400 B fold buffer)
@@ -123,6 +143,9 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
     // both roles have exactly 256 items per row: x items are the image pixel pairs (2i, 2i+1) -> halo positions (2i+2, 2i+3);
     // the halo positions 0, 1, 66, 67 of every x stage are zero for good (written once below).  No request is predicated.
     const bool xrole = wave < 4;
+#ifdef BWW_PROF
+    unsigned* const bww_st = reinterpret_cast<unsigned*>(smem_sb + 81920) + wave * 320;      // 8 waves x 40 rows x 8 stamps x 4 B = 10 KB
+#endif
     const int it = tid & 255;
     const int pxg = it >> 3, c4 = it & 7;          // 2-pixel group, channel quad
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -187,21 +210,30 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
 
     // ---- prologue: dz rows r0-2 .. r0+2 and x row r0 go to LDS; the items of x rows r0+1, r0+2 / dz rows r0+3, r0+4 are
     //      requested into the register sets B and C (three rows of look-ahead: the operands come from HBM -- forward activations
-    //      and gradients written hundreds of launches ago -- and a row of MFMA work covers about half of that round trip) ----
+    //      and gradients written hundreds of launches ago -- and a row of MFMA work covers about half of that round trip).
+    //      PIPE (KIND 2): everything one row further -- x rows r0, r0+1 and dz rows r0-2 .. r0+3 staged, sets B / C = x rows r0+2, r0+3 /
+    //      dz rows r0+4, r0+5 ----
+    constexpr bool PIPE = KIND == 2 && BWW_B_UPFRONT && BWW_Z_ROTATE && BWW_PIPE;
+    constexpr int XD = PIPE ? 2 : 1, ZD = PIPE ? 4 : 3;          // row gr stages x row gr + XD and dz row gr + ZD
     float4 sA0, sA1, sB0, sB1, sC0, sC1;
     sA0 = sA1 = sB0 = sB1 = sC0 = sC1 = make_float4(0.f, 0.f, 0.f, 0.f);
     {
-        float4 pv[5][2];
-        if (xrole) request(r0, 0, pv[0][0], pv[0][1]);
-        else {
+        constexpr int NZ0 = ZD + 2;                              // dz rows staged here: r0-2 .. r0+ZD-1
+        float4 pv[NZ0][2];
+        if (xrole) {
 #pragma unroll
-            for (int k = 0; k < 5; ++k) request(0, r0 - 2 + k, pv[k][0], pv[k][1]);
+            for (int k = 0; k < XD; ++k) request(r0 + k < r1 ? r0 + k : r0, 0, pv[k][0], pv[k][1]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NZ0; ++k) request(0, r0 - 2 + k, pv[k][0], pv[k][1]);
         }
-        request(r0 + 1 < r1 ? r0 + 1 : r0, r0 + 3, sB0, sB1);
-        request(r0 + 2 < r1 ? r0 + 2 : r0, r0 + 4, sC0, sC1);
+        request(r0 + XD < r1 ? r0 + XD : r0, r0 + ZD, sB0, sB1);
+        request(r0 + XD + 1 < r1 ? r0 + XD + 1 : r0, r0 + ZD + 1, sC0, sC1);
         __builtin_amdgcn_sched_barrier(0);
         if (xrole) {
-            stage(r0, 0, pv[0][0], pv[0][1]);
+#pragma unroll
+            for (int k = 0; k < XD; ++k)
+                if (r0 + k < r1) stage(r0 + k, 0, pv[k][0], pv[k][1]);
             // the zero halo positions (0, 1) and (66, 67) of both stages, all planes: 2 x NPL x 32 channels x 2 pieces
             for (int e = tid; e < 2 * NPL * 32 * 2; e += 256) {
                 const int side = e & 1, ch = (e >> 1) & 31, pl = (e >> 6) % NPL, st = e / (64 * NPL);
@@ -210,7 +242,7 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 5; ++k)
+            for (int k = 0; k < NZ0; ++k)
                 if (z_in_range(r0 - 2 + k)) stage(0, r0 - 2 + k, pv[k][0], pv[k][1]);
         }
     }
@@ -225,37 +257,73 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
     const int c0 = 4 * kb + g;
     const int swx_l = bw_swx(16 * mt + li), swz_l = bw_swz(16 * nt + li);      // this lane's channel rows of the x / dz operands
 
-    // one image row: request the items of x row gr+3 / dz row gr+5 into (i0, i1), run the 25 taps of row gr, write the items
-    // held in (o0, o1) -- x row gr+1 / dz row gr+3, requested two iterations ago -- to LDS
+    // KIND 2, BWW_Z_ROTATE: Bz[dy] = this lane's fragments of dz row gr + 2 - dy.  Row gr + 1 meets the same dz rows one tap row further
+    // down, so the set is SHIFTED at the head of a row and only Bz[0] (dz row gr + 2, staged during the previous row) is read: 6
+    // ds_reads (13 -> 5 KB) per wave and row instead of 14 -- the operand reads of a row were 106 KB per CU, ~900 clocks of the LDS
+    // pipe in front of every row's first MFMA.  Same products in the same order: bit-identical sums.
+    uint4 Bz[5][NPL];
+    auto read_z = [&](int gz, uint4 (&dst)[NPL]) __attribute__((always_inline)) {
+        const unsigned char* zs = ZS + ((gz + 6) % 6) * BW_ZST + (16 * nt + li) * 128 + ((c0 ^ swz_l) << 4);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) dst[pl] = *reinterpret_cast<const uint4*>(zs + pl * BW_ZPL);
+    };
+    // PIPE: the raw x fragments (16 + 8 bytes per plane) of the NEXT row and the dz fragments of dz row gr + 3, read at the tail of row gr
+    uint4 Aq[NPL], Bn[NPL];
+    uint2 Ae[NPL];
+    auto read_x = [&](int gx) __attribute__((always_inline)) {
+        const unsigned char* xs = XS + (gx & 1) * BW_XST + (16 * mt + li) * 256;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            Aq[pl] = *reinterpret_cast<const uint4*>(xs + pl * BW_XPL + ((c0 ^ swx_l) << 4));
+            Ae[pl] = *reinterpret_cast<const uint2*>(xs + pl * BW_XPL + (((c0 + 1) ^ swx_l) << 4));
+        }
+    };
+    if constexpr (KIND == 2 && BWW_B_UPFRONT && BWW_Z_ROTATE) {
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) read_z(r0 + 1 - dy, Bz[dy]);      // rows r0+1 .. r0-2: do_row(r0) shifts them to dy = 1 .. 4
+        if constexpr (PIPE) { read_x(r0); read_z(r0 + 2, Bn); }
+    }
+
+    // one image row: request the items of x row gr+XD+2 / dz row gr+ZD+2 into (i0, i1), run the 25 taps of row gr, write the items
+    // held in (o0, o1) -- x row gr+XD / dz row gr+ZD, requested two iterations ago -- to LDS
     auto do_row = [&](const int gr, float4& i0, float4& i1, const float4& o0, const float4& o1) __attribute__((always_inline)) {
         const int y = gr % H;
-        request(gr + 3 < r1 ? gr + 3 : r0, gr + 5, i0, i1);
+        BWW_STAMP(gr, 0);
+#ifdef BWW_PROF
+        { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memrealtime(); if (lane == 0 && gr - r0 < 40) bww_st[(gr - r0) * 8 + 6] = t_; }      // 100 MHz: the clock the CU holds
+#endif
+        const bool req_late = PIPE && BWW_REQ_LATE && !xrole;            // (wave uniform)
+        if (!req_late) request(gr + XD + 2 < r1 ? gr + XD + 2 : r0, gr + ZD + 2, i0, i1);
         __builtin_amdgcn_sched_barrier(0);
         // Phase shift between the two waves of a SIMD (waves w and w + 4): the dz role stages its row at the HEAD of the iteration, the x role
         // at its tail -- one wave's split / ds_write phase then lies under the other wave's MFMA block instead of both staging (matrix pipe
-        // idle) and both multiplying at the same time.  Legal: the slot written (dz row gr+3) is read by nobody during this iteration.
+        // idle) and both multiplying at the same time.  Legal: the slot written (dz row gr+ZD) is read by nobody during this iteration.
         // Same-box A/B, three alternations (tools/ab_lib.py): 0 (both late) 11.554, 1 (dz early) 11.430, 2 (x early) 11.612, 3 (both early) 11.521 ms per step.
         if (BWW_PHASE_SHIFT == 1 && !xrole) {
-            if (!(BWW_DBG & 2) && z_in_range(gr + 3)) stage(gr + 1, gr + 3, o0, o1);
+            if (!(BWW_DBG & 2) && z_in_range(gr + ZD)) stage(gr + XD, gr + ZD, o0, o1);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (BWW_PHASE_SHIFT == 2 && xrole) {            // (variant: the x role stages early, the dz role late)
-            if (!(BWW_DBG & 2) && gr + 1 < r1) stage(gr + 1, gr + 3, o0, o1);
+            if (!(BWW_DBG & 2) && gr + XD < r1) stage(gr + XD, gr + ZD, o0, o1);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (BWW_PHASE_SHIFT == 3) {                     // (variant: both roles stage early)
-            if (!(BWW_DBG & 2) && (xrole ? gr + 1 < r1 : z_in_range(gr + 3))) stage(gr + 1, gr + 3, o0, o1);
+            if (!(BWW_DBG & 2) && (xrole ? gr + XD < r1 : z_in_range(gr + ZD))) stage(gr + XD, gr + ZD, o0, o1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (req_late) {
+            request(gr + XD + 2 < r1 ? gr + XD + 2 : r0, gr + ZD + 2, i0, i1);
             __builtin_amdgcn_sched_barrier(0);
         }
 
         // x operand of this lane: pixels 8*c0 .. 8*c0+11 (halo coordinates) of channel 16*mt + li, three planes
         uint4 A[NPL][5];
         {
-            const unsigned char* xs = XS + (gr & 1) * BW_XST + (16 * mt + li) * 256;
+            if constexpr (!PIPE) read_x(gr);            // (PIPE: read at the tail of the previous row)
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) {
-                const uint4 q = *reinterpret_cast<const uint4*>(xs + pl * BW_XPL + ((c0 ^ swx_l) << 4));
-                const uint2 e = *reinterpret_cast<const uint2*>(xs + pl * BW_XPL + (((c0 + 1) ^ swx_l) << 4));
+                const uint4 q = Aq[pl];
+                const uint2 e = Ae[pl];
                 A[pl][0] = q;
                 A[pl][2] = make_uint4(q.y, q.z, q.w, e.x);
                 A[pl][4] = make_uint4(q.z, q.w, e.x, e.y);
@@ -266,17 +334,26 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
             }
         }
         if constexpr (KIND == 2 && BWW_B_UPFRONT) {
-            // the dz fragments of ALL five tap rows are read with the x fragments at the head of the row (40 VGPRs): one exposed LDS
+            // the dz fragments of ALL five tap rows are in registers at the head of the row (40 VGPRs): one exposed LDS
             // round trip per row instead of one per tap row in front of every group of 15 MFMAs (rows outside the image: the read
             // hits a valid ring slot and is dropped)
-            uint4 Bv[5][NPL];
+            uint4 (&Bv)[5][NPL] = Bz;
+            BWW_STAMP(gr, 1);                           // (early staging issued; the stamp itself waits for lgkmcnt(0): LDS writes done)
+            if constexpr (BWW_Z_ROTATE) {
 #pragma unroll
-            for (int dy = 0; dy < 5; ++dy) {
-                const int gz = gr + 2 - dy;
-                const unsigned char* zs = ZS + ((gz + 6) % 6) * BW_ZST + (16 * nt + li) * 128 + ((c0 ^ swz_l) << 4);
+                for (int dy = 4; dy > 0; --dy)
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) Bv[dy][pl] = *reinterpret_cast<const uint4*>(zs + pl * BW_ZPL);
+                    for (int pl = 0; pl < NPL; ++pl) Bv[dy][pl] = Bv[dy - 1][pl];
+                if constexpr (PIPE) {
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) Bv[0][pl] = Bn[pl];
+                } else read_z(gr + 2, Bv[0]);
+            } else {
+#pragma unroll
+                for (int dy = 0; dy < 5; ++dy) read_z(gr + 2 - dy, Bv[dy]);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            BWW_STAMP(gr, 2);                           // operand fragments in registers
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int dy = 0; dy < 5; ++dy) {
@@ -286,9 +363,15 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
 #pragma unroll
                 for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
-                    for (int dx = 0; dx < 5; ++dx)
+                    for (int dx = 0; dx < 5; ++dx) {
                         acc[dy * 5 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[QA[pr]][dx]), __builtin_bit_cast(f16x8, Bv[dy][QB[pr]]),
                                                                                   acc[dy * 5 + dx], 0, 0, 0);
+                        // SOURCE ORDER pinned: the scheduler emitted the three groups of five as a snake (dx 0..4, 4..0, 0..4), i.e. two
+                        // pairs of back-to-back DEPENDENT MFMAs per tap row; a dependent 16x16x32 MFMA issues ~4 slots after its
+                        // producer (round-robin over five accumulators hides that, the snake does not: 21.6 instead of 16 clocks per
+                        // MFMA while a wave has the matrix pipe to itself, tools/bww_row_probe.py)
+                        if (BWW_PIN_ORDER) __builtin_amdgcn_sched_barrier(0);
+                    }
             }
         } else {
 #pragma unroll
@@ -319,20 +402,43 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
             }
 }
         __builtin_amdgcn_sched_barrier(0);
-        if (!(BWW_DBG & 2) && (xrole ? ((BWW_PHASE_SHIFT & 2) == 0 && gr + 1 < r1) : ((BWW_PHASE_SHIFT & 1) == 0 && z_in_range(gr + 3)))) stage(gr + 1, gr + 3, o0, o1);
+        BWW_STAMP(gr, 3);                               // last MFMA issued
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(BWW_DBG & 2) && (xrole ? ((BWW_PHASE_SHIFT & 2) == 0 && gr + XD < r1) : ((BWW_PHASE_SHIFT & 1) == 0 && z_in_range(gr + ZD)))) stage(gr + XD, gr + ZD, o0, o1);
+        if constexpr (PIPE) {
+            // operands of row gr + 1: x row gr + 1 and dz row gr + 3 were staged during row gr - 1 (visible since its barrier); the slots written
+            // during THIS row (x row gr + 2, dz row gr + 4) are other slots.  The x role waits for the barrier here anyway; for the dz role the
+            // round trip replaces the one that stood in front of its MFMA block.
+            __builtin_amdgcn_sched_barrier(0);
+            read_x(gr + 1);
+            read_z(gr + 3, Bn);
+        }
+        BWW_STAMP(gr, 4);                               // late staging written (lgkmcnt(0))
         if (!(BWW_DBG & 4)) BW_BARRIER();
+        BWW_STAMP(gr, 5);
     };
     // (six rows per trip: at the loop's back edge the compiler's wait-count pass gives up on the requests in flight and waits
     // for all of them -- once per six rows instead of once per three)
 #pragma unroll 1
     for (int gr = r0; gr < r1; gr += 6) {
+        // (early exits, not `if (gr + k < r1) do_row(...)`: behind a conditional row every register-resident dz fragment would be a
+        // phi of its shifted and unshifted place -- 32 copies and their temporaries per row, 227 spilled registers)
         do_row(gr, sA0, sA1, sB0, sB1);
-        if (gr + 1 < r1) do_row(gr + 1, sB0, sB1, sC0, sC1);
-        if (gr + 2 < r1) do_row(gr + 2, sC0, sC1, sA0, sA1);
-        if (gr + 3 < r1) do_row(gr + 3, sA0, sA1, sB0, sB1);
-        if (gr + 4 < r1) do_row(gr + 4, sB0, sB1, sC0, sC1);
-        if (gr + 5 < r1) do_row(gr + 5, sC0, sC1, sA0, sA1);
+        if (gr + 1 >= r1) break;
+        do_row(gr + 1, sB0, sB1, sC0, sC1);
+        if (gr + 2 >= r1) break;
+        do_row(gr + 2, sC0, sC1, sA0, sA1);
+        if (gr + 3 >= r1) break;
+        do_row(gr + 3, sA0, sA1, sB0, sB1);
+        if (gr + 4 >= r1) break;
+        do_row(gr + 4, sB0, sB1, sC0, sC1);
+        if (gr + 5 >= r1) break;
+        do_row(gr + 5, sC0, sC1, sA0, sA1);
     }
+#ifdef BWW_PROF
+    if (g_bww_prof)
+        for (int i = lane; i < 320; i += 64) g_bww_prof[((size_t)blk * 8 + wave) * 320 + i] = bww_st[i];
+#endif
     __syncthreads();                                     // (also retires the requests of rows beyond r1)
 
     // ---- fold the two pixel halves through LDS and add into this block's partial slice --------
@@ -363,6 +469,8 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
             const int c4 = e & 3, row = (e >> 2) & 15, tp = (e >> 6) % 25, wt = e / (25 * 64);      // wt = (mt, nt) tile
             return reinterpret_cast<float4*>(&pw[(tp * 32 + 16 * (wt & 1) + row) * 32 + 16 * (wt >> 1) + c4 * 4]);
         };
+        // (round 6, measured: the read-modify-write as no-return global_atomic_add_f32 -- the L2 does it, one add per address and launch, still bit
+        //  reproducible -- 12.97 vs 11.12 ms per step: 100 KB of dword atomics per workgroup take ~58 us longer than load - add - store)
         // (round 6, measured: pulling the old slice into the L2 with one dword per line and thread under the MFMAs of the last six rows made the
         //  step SLOWER, 11.76 vs 11.67 ms over three alternations: the requests compete with the row loads the MFMAs are waiting for)
         float4 old[NP];
