@@ -474,6 +474,20 @@ int sol_conv3d(void* stream, const float* x, const float* packed, const float* b
                int32_t B, int32_t D, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t epilogue, float slope,
                const uint32_t* x_absmax, uint32_t* y_absmax);
 
+/* Thin-INPUT Conv3D layers (<= 4 -> 32 channels: the first layer of model_mars_moon in 3-D, karman_train.py:103 generalised, and the
+ * output layer's data gradient) with the depth taps packed into the channel axis: x'[..][4 s + c] = x[d + s - 2][..][c] is gathered
+ * into ws and the layer runs as ONE 2-D 32 -> 32 convolution over the (H, W) planes (25 taps of K = 32 on the 16-bit matrix pipe
+ * instead of 125 taps of K = 4 on the fp32 one; per-product arithmetic of sol_conv5x5 with 32 input channels, option conv_precision).
+ * x [B,D,H,W,4] (zero padded from cin channels), y [B,D,H,W,32]; packed: sol_conv3d_thin_packed_floats() floats from
+ * sol_conv3d_thin_pack (w_dhwio = the FORWARD kernel: [5,5,5,cin,32] for SOL_CONV_FWD, [5,5,5,32,cin] for SOL_CONV_BWD_DATA; cin = the
+ * channels the convolution that is RUN reads, 1..4); ws: sol_conv3d_thin_ws_floats() floats of scratch (the gathered tensor + the
+ * absmax slots of x, which this call computes itself); bias / act_ref / epilogue / y_absmax as in sol_conv3d. */
+size_t sol_conv3d_thin_packed_floats(void);
+size_t sol_conv3d_thin_ws_floats(int32_t B, int32_t D, int32_t H, int32_t W);
+int sol_conv3d_thin_pack(void* stream, const float* w_dhwio, int32_t cin, int32_t mode, float* packed);
+int sol_conv3d_thin(void* stream, const float* x, const float* packed, const float* bias, const float* act_ref, float* y, float* ws,
+                    int32_t B, int32_t D, int32_t H, int32_t W, int32_t epilogue, float slope, uint32_t* y_absmax);
+
 /* Conv3D weight gradient: dw_dhwio [5,5,5,cin_real,cout] = sum_px x[px + tap] * dz[px], db [cout] = sum_px dz[px]; five passes
  * of the 2-D weight-gradient kernels over the shifted plane ranges.  x [B,D,H,W,cin] (cin in {4, 32}, zero padded from
  * cin_real), dz [B,D,H,W,cout] (cout in {2, 32}); x_absmax / dz_absmax (or NULL): absmax slots of the two tensors -> fp16

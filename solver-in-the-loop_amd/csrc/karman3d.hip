@@ -1150,6 +1150,70 @@ extern "C" int sol_conv3d(void* stream, const float* x, const float* packed, con
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Thin-INPUT Conv3D (<= 4 -> 32 channels: the network's first layer 4 -> 32 and the output layer's data gradient 3 -> 32) with the
+// DEPTH taps packed into the channel axis.  The five-pass form above runs these layers on the fp32 matrix pipe (k_conv5x5<4, 2>: K = 4
+// channels per tap, 5 x 43 us at 128 x 64 x 64 = 78 TF, the rate that pipe sustains) and moves the 67 MB result through HBM five times.
+// Here x[d][h][w][0:4] is first gathered into x'[d][h][w][4 s + c] = x[d + s - 2][h][w][c] (s = 0..4; 5..7 and planes outside the volume
+// are zero: the SAME padding of the depth axis) -- "im2col along depth", 32 channels -- and the layer becomes ONE 2-D 5 x 5 convolution
+// 32 -> 32 over the (H, W) planes with w'[dy][dx][4 s + c][co] = w[s][dy][dx][c][co]: the dx-major split-fp16 kernel of the 32 -> 32
+// layers (conv5x5_dx.hip), 25 taps of K = 32 (20 of them in use) instead of 125 taps of K = 4, bias / activation / absmax publish in
+// its epilogue, the result written once.  Same per-product arithmetic as every other 32 -> 32 layer of the network (option conv_precision).
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) k3_kpack_depth(const float4* __restrict__ x, float4* __restrict__ out, int D, int HW, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int s = (int)(e & 7);
+        const size_t q = e >> 3, plane = q / HW;
+        const int p = (int)(q - plane * HW), ds = (int)(plane % D) + s - 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < 5 && ds >= 0 && ds < D) v = x[(plane + s - 2) * HW + p];
+        out[e] = v;
+    }
+}
+// w' [5][5][32][32] (HWIO of the 2-D convolution that is RUN) from the FORWARD kernel w:
+//   mode SOL_CONV_FWD:      w [5][5][5][cin][32]:  w'[dy][dx][4 s + c][co] = w[s][dy][dx][c][co]
+//   mode SOL_CONV_BWD_DATA: w [5][5][5][32][cr], the run convolution reads the cr channels of dy and writes 32: the flipped kernel with
+//                           its channel axes swapped, w'[dy][dx][4 s + c][co] = w[4 - s][4 - dy][4 - dx][co][c]
+__global__ void __launch_bounds__(256) k3_kpack_weights(const float* __restrict__ w, float* __restrict__ w2, int cin, int mode) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= 25 * 32 * 32) return;
+    const int co = e & 31, k = (e >> 5) & 31, tap = e >> 10, dy = tap / 5, dx = tap % 5, s = k >> 2, c = k & 3;
+    float v = 0.f;
+    if (s < 5 && c < cin)
+        v = mode == SOL_CONV_FWD ? w[((((size_t)s * 5 + dy) * 5 + dx) * cin + c) * 32 + co]
+                                 : w[((((size_t)(4 - s) * 5 + (4 - dy)) * 5 + (4 - dx)) * 32 + co) * cin + c];
+    w2[e] = v;
+}
+}  // namespace
+
+extern "C" size_t sol_conv3d_thin_packed_floats(void) { return align_up(sol_conv5x5_packed_floats(32, 32, SOL_CONV_FWD), 64) + 25 * 32 * 32; }
+extern "C" size_t sol_conv3d_thin_ws_floats(int32_t B, int32_t D, int32_t H, int32_t W) { return (size_t)B * D * H * W * 32 + 256; }
+
+extern "C" int sol_conv3d_thin_pack(void* stream, const float* w_dhwio, int32_t cin, int32_t mode, float* packed) {
+    SOL_REQUIRE(w_dhwio && packed, "sol_conv3d_thin_pack: NULL pointer");
+    SOL_REQUIRE(mode == SOL_CONV_FWD || mode == SOL_CONV_BWD_DATA, "sol_conv3d_thin_pack: bad mode %d", mode);
+    SOL_REQUIRE(cin >= 1 && cin <= 4, "sol_conv3d_thin_pack: 1..4 input channels of the convolution that is run (got %d)", cin);
+    float* w2 = packed + align_up(sol_conv5x5_packed_floats(32, 32, SOL_CONV_FWD), 64);
+    SOL_LAUNCH(k3_kpack_weights, dim3(100), dim3(256), 0, (hipStream_t)stream, w_dhwio, w2, cin, mode);
+    SOL_LAUNCH_CHECK();
+    return sol_conv5x5_pack(stream, w2, 32, 32, SOL_CONV_FWD, packed);
+}
+
+extern "C" int sol_conv3d_thin(void* stream, const float* x, const float* packed, const float* bias, const float* act_ref, float* y, float* ws,
+                               int32_t B, int32_t D, int32_t H, int32_t W, int32_t epilogue, float slope, uint32_t* y_absmax) {
+    SOL_REQUIRE(x && packed && y && ws && x != y, "sol_conv3d_thin: NULL pointer / in-place call");
+    SOL_REQUIRE(B >= 1 && D >= 1 && H >= 1 && W >= 4 && W % 4 == 0, "sol_conv3d_thin: bad shape (B %d, D %d, H %d, W %d)", B, D, H, W);
+    SOL_REQUIRE(epilogue == SOL_EPI_NONE || epilogue == SOL_EPI_LRELU || epilogue == SOL_EPI_DLRELU, "sol_conv3d_thin: epilogue must be SOL_EPI_NONE, SOL_EPI_LRELU or SOL_EPI_DLRELU");
+    SOL_REQUIRE((epilogue == SOL_EPI_DLRELU) == (act_ref != nullptr) && act_ref != y, "sol_conv3d_thin: SOL_EPI_DLRELU needs an activation reference (and only it does), distinct from y");
+    const size_t npx = (size_t)B * D * H * W;
+    uint32_t* slots = reinterpret_cast<uint32_t*>(ws + npx * 32);
+    if (int e = sol_absmax(stream, x, (int64_t)(npx * 4), slots)) return e;
+    SOL_LAUNCH(k3_kpack_depth, dim3(grid_for(npx * 8)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(ws), D, H * W, npx * 8);
+    SOL_LAUNCH_CHECK();
+    return sol_conv5x5_scaled(stream, ws, packed, bias, nullptr, act_ref, y, B * D, H, W, 32, 32, epilogue, slope, slots, y_absmax);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // Conv3D weight gradient: dW[kd][dy][dx][ci][co] = sum over planes d of the 2-D weight gradient of (x[d + kd - 2], dz[d]) --
 // five passes of the batched 2-D weight-gradient kernels (conv5x5_sb.hip: one workgroup per CU owning many rows, fp16
 // three-product operands when the absmax of both tensors is given) over the shifted plane ranges, each into `partial` and

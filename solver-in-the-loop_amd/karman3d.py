@@ -222,8 +222,20 @@ class MarsMoon3D:
                 w = t[2 * l].detach()
                 wf = w if cin_k == cin else torch.nn.functional.pad(w, (0, 0, 0, cin_k - cin))   # the forward kernels read cin_k input channels (as pack())
                 self._tpacks.append((_pack3d(wf, cin_k, cout, 0), _pack3d(w, cout, cin, 1)))
+            # the two thin-INPUT layers (first layer 4 -> 32; the output layer's data gradient cout -> 32) as ONE 2-D launch with the depth
+            # taps packed into the channel axis (sol_conv3d_thin): packed for the convolution that is RUN
+            self._kpacks = None
+            if self.thin_kpack and self.cin <= 4 and self.cout <= 4:
+                self._kpacks = (_pack3d_thin(t[0].detach(), self.cin, 0), _pack3d_thin(t[22].detach(), self.cout, 1))
             self._tpacks_key = key
         return self._tpacks
+
+    thin_kpack = True          # False: the thin-input layers as five passes of the 2-D fp32-MFMA kernel (sol_conv3d), rounds 3-6
+
+    def thin_packs(self):
+        """(first layer forward, output layer backward-data) packed for sol_conv3d_thin, or None (thin_kpack off / more than four channels)"""
+        self.train_packs()
+        return self._kpacks
 
     def _params_key(self):
         """Identity of the weight buffer's CONTENT as far as torch can see it: an optimizer that updates `params` in place through
@@ -236,6 +248,7 @@ class MarsMoon3D:
         buffer (the library's own Adam: Karman3DTrainer.apply_gradients calls this), external kernels.  `set_weights` calls it itself;
         in-place torch ops on `params` bump `_version` and need nothing."""
         self._packed = None
+        self._packed_thin = None
         self._tpacks = None
 
     fused_backward = True      # one autograd node with a hand-written reverse sweep (False: one node per layer, torch glue)
@@ -278,6 +291,16 @@ class MarsMoon3D:
             self.params.copy_(torch.as_tensor(flat, device=self.params.device))
         self.invalidate()
 
+    def pack_thin(self):
+        """the first layer packed for sol_conv3d_thin (inference path; cached like pack()), or None"""
+        if not (self.thin_kpack and self.cin <= 4):
+            return None
+        key = self._params_key()
+        if getattr(self, "_packed_thin", None) is None or getattr(self, "_packed_thin_key", None) != key:
+            self._packed_thin_key = key
+            self._packed_thin = _pack3d_thin(self.tensors()[0].detach(), self.cin, 0)
+        return self._packed_thin
+
     def pack(self):
         """(packed weights, padded biases) per layer in the layout the conv kernels consume; cached until set_weights."""
         key = self._params_key()
@@ -309,6 +332,29 @@ def conv3d(x, packed, bias, residual, cout, lrelu, slope, x_absmax=None, y_absma
     check(lib.sol_conv3d(stream(), ptr(x), ptr(packed), ptr(bias), ptr(residual), ptr(act_ref), ptr(y), B, D, H, W, cin, cout,
                          epi, float(slope), ptr(x_absmax), ptr(y_absmax)))
     return y
+
+
+def conv3d_thin(x4, packed, bias, lrelu, slope, y_absmax=None, act_ref=None, out=None, ws=None):
+    """sol_conv3d_thin: x4 [B,Y,X,Z,4] (zero padded input channels) -> [B,Y,X,Z,32]; the depth taps are gathered into the channel axis
+    (scratch: 32 channels of the volume) and the layer runs as ONE 2-D 32 -> 32 convolution over the (X, Z) planes."""
+    lib = _lib.load()
+    B, D, H, W, c = x4.shape
+    assert c == 4, "conv3d_thin reads four (zero padded) input channels"
+    y = out if out is not None else torch.empty(B, D, H, W, 32, dtype=torch.float32, device=x4.device)
+    if ws is None:
+        ws = torch.empty(lib.sol_conv3d_thin_ws_floats(B, D, H, W), dtype=torch.float32, device=x4.device)
+    assert ws.numel() >= lib.sol_conv3d_thin_ws_floats(B, D, H, W)
+    epi = EPI_DLRELU if act_ref is not None else (EPI_LRELU if lrelu else EPI_NONE)
+    check(lib.sol_conv3d_thin(stream(), ptr(x4), ptr(packed), ptr(bias), ptr(act_ref), ptr(y), ptr(ws), B, D, H, W, epi, float(slope), ptr(y_absmax)))
+    return y
+
+
+def _pack3d_thin(w, cin_run, mode):
+    """w: the FORWARD kernel ([5,5,5,cin_run,32] for mode 0, [5,5,5,32,cin_run] for mode 1 = backward-data)"""
+    lib = _lib.load()
+    buf = torch.empty(lib.sol_conv3d_thin_packed_floats(), dtype=torch.float32, device=w.device)
+    check(lib.sol_conv3d_thin_pack(stream(), ptr(w.contiguous()), cin_run, mode, ptr(buf)))
+    return buf
 
 
 def _pack3d(w, cin_run, cout_run, mode):
@@ -396,7 +442,10 @@ class _Conv3DFn(torch.autograd.Function):
         ctx.packed_bwd = packs[1] if packs is not None else None
         res = None if residual is None else _lib.f32(residual)
         # the operand's absmax selects the fp16 three-product kernels (and, for 32 -> 32 layers, the one-launch 5x5x5 kernel)
-        y = conv3d(xk, packed, _lib.f32(b), res, cout, lrelu, slope, _absmax(xk) if cin_k == 32 else None)
+        if MarsMoon3D.thin_kpack and cin <= 4 and cout == 32 and res is None:      # the depth-packed one-launch form, as the fused network runs it
+            y = conv3d_thin(xk, _pack3d_thin(_lib.f32(w), cin, 0), _lib.f32(b), lrelu, slope)
+        else:
+            y = conv3d(xk, packed, _lib.f32(b), res, cout, lrelu, slope, _absmax(xk) if cin_k == 32 else None)
         ctx.save_for_backward(xk, w, y)
         ctx.meta = (cin, cout, cin_k, lrelu, slope, residual is not None)
         return y
@@ -413,7 +462,10 @@ class _Conv3DFn(torch.autograd.Function):
         co_k = 4 if cout <= 4 else 32
         packed = ctx.packed_bwd if ctx.packed_bwd is not None else _pack3d(_lib.f32(w), cout, cin, 1)
         dzk = _pad_ch(dz, co_k)
-        dx = conv3d(dzk, packed, None, None, cin, False, slope, _absmax(dzk) if co_k == 32 else None)
+        if MarsMoon3D.thin_kpack and cout <= 4 and cin == 32:
+            dx = conv3d_thin(dzk, _pack3d_thin(_lib.f32(w), cout, 1), None, False, slope)
+        else:
+            dx = conv3d(dzk, packed, None, None, cin, False, slope, _absmax(dzk) if co_k == 32 else None)
         return dx, dW, db, (dz if has_res else None), None, None, None
 
 
@@ -433,7 +485,8 @@ class _MarsMoon3DFn(torch.autograd.Function):
         sl, cout = net.slope, net.cout
         xk = _pad_ch(_lib.f32(x.detach()), 4)
         amax = torch.zeros(11, 256, dtype=torch.int32, device=xk.device)       # absmax slots of the eleven 32-channel activations
-        acts = [conv3d(xk, pk[0][0], p[1], None, 32, True, sl, None, amax[0])]
+        kp = net.thin_packs()
+        acts = [conv3d_thin(xk, kp[0], p[1], True, sl, amax[0]) if kp else conv3d(xk, pk[0][0], p[1], None, 32, True, sl, None, amax[0])]
         for k in range(5):
             a = conv3d(acts[-1], pk[1 + 2 * k][0], p[3 + 4 * k], None, 32, True, sl, amax[2 * k], amax[2 * k + 1])
             acts.append(a)
@@ -462,7 +515,11 @@ class _MarsMoon3DFn(torch.autograd.Function):
         g = _lib.f32(g_out).contiguous()
         grads[22], grads[23] = conv3d_bwd_weight(acts[10], g, 32, cout, xmax=amax[10], acc=A(11))
         # d loss / d (pre-activation of the last residual block's output) = conv3d(g, flip(w11)^T) * lrelu'(h5)
-        dz = conv3d(_pad_ch(g, 4), pk[11][1], None, None, 32, False, sl, None, zm[10], act_ref=acts[10])
+        kp = net.thin_packs()
+        if kp:
+            dz = conv3d_thin(_pad_ch(g, 4), kp[1], None, False, sl, zm[10], act_ref=acts[10])
+        else:
+            dz = conv3d(_pad_ch(g, 4), pk[11][1], None, None, 32, False, sl, None, zm[10], act_ref=acts[10])
         for k in range(4, -1, -1):
             a, hprev = acts[1 + 2 * k], acts[2 * k]
             # block k: h_k = lrelu(conv_b(a) + h_{k-1}), a = lrelu(conv_a(h_{k-1}))
@@ -707,7 +764,13 @@ class Karman3DRollout:
         self.amax.zero_()
         am = lambda k: self.amax[k]
         h, a, n = self.h
-        conv3d(self.feat, pk[0][0], pk[0][1], None, 32, True, sl, None, am(0), out=h)
+        kp = self.net.pack_thin()
+        if kp is not None:
+            if getattr(self, "_thin_ws", None) is None:
+                self._thin_ws = torch.empty(self.lib.sol_conv3d_thin_ws_floats(*self.feat.shape[:4]), dtype=torch.float32, device=self.feat.device)
+            conv3d_thin(self.feat, kp, pk[0][1], True, sl, am(0), out=h, ws=self._thin_ws)
+        else:
+            conv3d(self.feat, pk[0][0], pk[0][1], None, 32, True, sl, None, am(0), out=h)
         for k in range(5):
             conv3d(h, pk[1 + 2 * k][0], pk[1 + 2 * k][1], None, 32, True, sl, am(2 * k), am(2 * k + 1), out=a)
             conv3d(a, pk[2 + 2 * k][0], pk[2 + 2 * k][1], h, 32, True, sl, am(2 * k + 1), am(2 * k + 2), out=n)

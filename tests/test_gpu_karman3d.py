@@ -387,6 +387,40 @@ def test_conv3d_full_size_one_launch_against_five_pass_and_shift_property(cout, 
     assert torch.equal(ys[:, 4:-4], torch.roll(y, 1, dims=1)[:, 4:-4])
 
 
+@pytest.mark.parametrize("shape,cin,mode", [((1, 6, 8, 64), 4, "fwd"), ((2, 5, 16, 16), 3, "fwd"), ((1, 4, 64, 64), 3, "bwd"), ((1, 128, 64, 64), 4, "fwd"),
+                                            ((1, 128, 64, 64), 3, "bwd")])
+def test_conv3d_thin_input_depth_packed_launch_against_float64_and_the_five_pass_form(shape, cin, mode):
+    """sol_conv3d_thin (the <= 4 -> 32 layers as ONE 2-D 32 -> 32 launch over depth-packed channels): the first layer (forward packing,
+    bias + LeakyReLU) and the output layer's data gradient (backward-data packing of the FORWARD kernel [5,5,5,32,cin], times
+    LeakyReLU'(act_ref)) against torch float64 F.conv3d on the same device and against the five-pass composition of the 2-D fp32-MFMA
+    kernel (sol_conv3d); small shapes, W = 16 (not the dx kernel's width) and the BASELINE configs[4] volume 128 x 64 x 64."""
+    import torch.nn.functional as F
+    B, D, H, W = shape
+    gen = torch.Generator().manual_seed(31 + D + cin)
+    x = torch.randn(B, D, H, W, cin, generator=gen, dtype=torch.float32).to(DEV)
+    x4 = k3._pad_ch(x, 4)
+    if mode == "fwd":
+        w = (torch.randn(5, 5, 5, cin, 32, generator=gen, dtype=torch.float32) / np.sqrt(125 * cin)).to(DEV)
+        b = torch.randn(32, generator=gen, dtype=torch.float32).to(DEV)
+        y = k3.conv3d_thin(x4, k3._pack3d_thin(w, cin, 0), b, True, 0.3)
+        z = F.conv3d(x.double().permute(0, 4, 1, 2, 3), w.double().permute(4, 3, 0, 1, 2), b.double(), padding=2).permute(0, 2, 3, 4, 1)
+        ref = torch.where(z > 0, z, 0.3 * z)
+        wf = torch.nn.functional.pad(w, (0, 0, 0, 4 - cin))
+        y5 = k3.conv3d(x4, k3._pack3d(wf, 4, 32, 0), b, None, 32, True, 0.3)
+    else:
+        w = (torch.randn(5, 5, 5, 32, cin, generator=gen, dtype=torch.float32) / np.sqrt(125 * 32)).to(DEV)      # the forward kernel of a 32 -> cin layer
+        act = torch.randn(B, D, H, W, 32, generator=gen, dtype=torch.float32).to(DEV)
+        y = k3.conv3d_thin(x4, k3._pack3d_thin(w, cin, 1), None, False, 0.3, act_ref=act)
+        # dx = conv3d(dy, flip(w)^T) = the transposed convolution of the forward layer
+        z = F.conv_transpose3d(x.double().permute(0, 4, 1, 2, 3), w.double().permute(4, 3, 0, 1, 2), padding=2).permute(0, 2, 3, 4, 1)
+        ref = z * torch.where(act > 0, 1.0, 0.3).double()
+        y5 = k3.conv3d(x4, k3._pack3d(w, cin, 32, 1), None, None, 32, False, 0.3, act_ref=act)
+    torch.cuda.synchronize()
+    e, e5 = rel(y, ref), rel(y5, ref)
+    print("depth-packed launch vs float64 %.2e (five-pass fp32-MFMA form %.2e)" % (e, e5))
+    assert torch.isfinite(y).all() and e < 2e-6 and rel(y, y5) < 3e-6, (e, e5, rel(y, y5))
+
+
 @pytest.mark.parametrize("D", [16, 128])
 def test_network_w64_against_torch_float64_autograd(D):
     """model_mars_moon3d on 16 x 64 x 64 and on the BASELINE configs[4] grid 128 x 64 x 64 (the one-launch Conv3D kernels): forward, input gradient
