@@ -488,6 +488,15 @@ int sol_conv3d_thin_pack(void* stream, const float* w_dhwio, int32_t cin, int32_
 int sol_conv3d_thin(void* stream, const float* x, const float* packed, const float* bias, const float* act_ref, float* y, float* ws,
                     int32_t B, int32_t D, int32_t H, int32_t W, int32_t epilogue, float slope, uint32_t* y_absmax);
 
+/* Weight gradient of a thin-input layer in the same packing: ONE pass of the 2-D 32 -> 32 fp16 three-product weight-gradient kernel over
+ * the gathered tensor instead of five passes of the thin fp32 kernel.  x [B,D,H,W,4], dz [B,D,H,W,32], W == 64; dz_absmax: the slots the
+ * producer of dz published, or NULL (computed here); ws: sol_conv3d_thin_ws_floats(); partial: sol_conv3d_thin_bwd_weight_ws_floats();
+ * dw_dhwio [5,5,5,cin_real,32], db [32] are written when do_reduce is set; accumulate_partial / do_reduce as in sol_conv3d_bwd_weight_acc. */
+size_t sol_conv3d_thin_bwd_weight_ws_floats(int32_t B, int32_t D, int32_t H, int32_t W);
+int sol_conv3d_thin_bwd_weight_acc(void* stream, const float* x, const float* dz, const uint32_t* dz_absmax, float* ws, float* partial,
+                                   float* dw_dhwio, float* db, int32_t B, int32_t D, int32_t H, int32_t W, int32_t cin_real,
+                                   int32_t accumulate_partial, int32_t do_reduce);
+
 /* Conv3D weight gradient: dw_dhwio [5,5,5,cin_real,cout] = sum_px x[px + tap] * dz[px], db [cout] = sum_px dz[px]; five passes
  * of the 2-D weight-gradient kernels over the shifted plane ranges.  x [B,D,H,W,cin] (cin in {4, 32}, zero padded from
  * cin_real), dz [B,D,H,W,cout] (cout in {2, 32}); x_absmax / dz_absmax (or NULL): absmax slots of the two tensors -> fp16

@@ -1187,7 +1187,7 @@ __global__ void __launch_bounds__(256) k3_kpack_weights(const float* __restrict_
 }  // namespace
 
 extern "C" size_t sol_conv3d_thin_packed_floats(void) { return align_up(sol_conv5x5_packed_floats(32, 32, SOL_CONV_FWD), 64) + 25 * 32 * 32; }
-extern "C" size_t sol_conv3d_thin_ws_floats(int32_t B, int32_t D, int32_t H, int32_t W) { return (size_t)B * D * H * W * 32 + 256; }
+extern "C" size_t sol_conv3d_thin_ws_floats(int32_t B, int32_t D, int32_t H, int32_t W) { return (size_t)B * D * H * W * 32 + 512; }      // gathered tensor + absmax slots of x (and of dz: weight gradient)
 
 extern "C" int sol_conv3d_thin_pack(void* stream, const float* w_dhwio, int32_t cin, int32_t mode, float* packed) {
     SOL_REQUIRE(w_dhwio && packed, "sol_conv3d_thin_pack: NULL pointer");
@@ -1211,6 +1211,48 @@ extern "C" int sol_conv3d_thin(void* stream, const float* x, const float* packed
     SOL_LAUNCH(k3_kpack_depth, dim3(grid_for(npx * 8)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(ws), D, H * W, npx * 8);
     SOL_LAUNCH_CHECK();
     return sol_conv5x5_scaled(stream, ws, packed, bias, nullptr, act_ref, y, B * D, H, W, 32, 32, epilogue, slope, slots, y_absmax);
+}
+
+// Weight gradient of a thin-INPUT layer in the same packing: dW'[dy][dx][4 s + c][co] = sum_px x'[px + (dy, dx)][4 s + c] dz[px][co] is the 2-D
+// 32 -> 32 weight gradient of the gathered tensor -- ONE pass of the fp16 three-product body (bww_sb_body) instead of five passes of the
+// thin fp32-MFMA kernel (k_conv5x5_bww_thin<0, 2>: 5 x 79 us at 128 x 64 x 64) -- and dW[s][dy][dx][c][co] = dW'[dy][dx][4 s + c][co].
+namespace {
+__global__ void __launch_bounds__(256) k3_kunpack_dw(const float* __restrict__ dw2, float* __restrict__ dw, int cin) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= 125 * cin * 32) return;
+    const int co = e & 31, c = (e >> 5) % cin, t = e / (32 * cin), s = t / 25, tap = t % 25;
+    dw[e] = dw2[(tap * 32 + 4 * s + c) * 32 + co];
+}
+}  // namespace
+
+extern "C" size_t sol_conv3d_thin_bwd_weight_ws_floats(int32_t B, int32_t D, int32_t H, int32_t /*W*/) {
+    return align_up(sol_bww_batched_ws_floats(1, B * D, H, 32, 32), 64) + 25 * 32 * 32;
+}
+
+extern "C" int sol_conv3d_thin_bwd_weight_acc(void* stream, const float* x, const float* dz, const uint32_t* dz_absmax, float* ws, float* partial,
+                                              float* dw_dhwio, float* db, int32_t B, int32_t D, int32_t H, int32_t W, int32_t cin_real,
+                                              int32_t accumulate_partial, int32_t do_reduce) {
+    SOL_REQUIRE(x && dz && ws && partial && dw_dhwio && db, "sol_conv3d_thin_bwd_weight: NULL pointer");
+    SOL_REQUIRE(B >= 1 && D >= 1 && H >= 1 && W == 64 && cin_real >= 1 && cin_real <= 4, "sol_conv3d_thin_bwd_weight: needs W == 64 and 1..4 input channels (B %d, D %d, H %d, W %d, cin %d)", B, D, H, W, cin_real);
+    const size_t npx = (size_t)B * D * H * W;
+    uint32_t* slots_x = reinterpret_cast<uint32_t*>(ws + npx * 32);
+    uint32_t* slots_z = slots_x + 256;
+    if (int e = sol_absmax(stream, x, (int64_t)(npx * 4), slots_x)) return e;
+    if (!dz_absmax) {
+        if (int e = sol_absmax(stream, dz, (int64_t)(npx * 32), slots_z)) return e;
+        dz_absmax = slots_z;
+    }
+    SOL_LAUNCH(k3_kpack_depth, dim3(grid_for(npx * 8)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(ws), D, H * W, npx * 8);
+    SOL_LAUNCH_CHECK();
+    if (int e = sol_bww_batched(stream, ws, dz, partial, 1, 1, accumulate_partial ? 0 : 1, 0, 0, B * D, H, W, 32, 32, slots_x, dz_absmax, 0, 0)) return e;
+    if (!do_reduce) return SOL_OK;
+    float* dw2 = partial + align_up(sol_bww_batched_ws_floats(1, B * D, H, 32, 32), 64);
+    float* parts[1] = {partial}; float* dws[1] = {dw2}; float* dbs[1] = {db};
+    const int rows[1] = {B * D * H}, rbs[1] = {0}, ci[1] = {32}, co[1] = {32};
+    if (int e = sol_bww_reduce_layers(stream, 1, parts, dws, dbs, rows, rbs, ci, co, 0, 0)) return e;
+    SOL_LAUNCH(k3_kunpack_dw, dim3((125 * cin_real * 32 + 255) / 256), dim3(256), 0, (hipStream_t)stream, dw2, dw_dhwio, cin_real);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

@@ -375,6 +375,38 @@ def _pad_ch(x, c):
     return x.contiguous() if x.shape[-1] == c else torch.nn.functional.pad(x, (0, c - x.shape[-1])).contiguous()
 
 
+def conv3d_thin_bwd_weight(x4, dz, cin, zmax=None, acc=None):
+    """dW [5,5,5,cin,32], db [32] of a thin-input layer y = conv3d(x, W) + b from x4 [B,D,H,W,4] (zero padded) and dz [B,D,H,W,32], W == 64:
+    sol_conv3d_thin_bwd_weight_acc -- the depth taps packed into the channel axis, ONE pass of the 2-D 32 -> 32 weight-gradient kernel.
+    acc = (state dict, first, last) as in conv3d_bwd_weight."""
+    lib = _lib.load()
+    B, D, H, W, c = x4.shape
+    assert c == 4 and dz.shape[-1] == 32 and W == 64
+    dev = x4.device
+    shape_key = ("thin", B, D, H, W, cin, str(dev))
+    if acc is not None and "part" in acc[0]:
+        if acc[0].get("shape") != shape_key:
+            raise _lib.SolError("conv3d_thin_bwd_weight: the accumulation state was allocated for %s, this call has %s" % (acc[0].get("shape"), shape_key))
+        if not acc[1] and not acc[0].get("open"):
+            raise _lib.SolError("conv3d_thin_bwd_weight: first=False on a state whose sequence is not open (the previous sweep ended with last=True)")
+        part, dW, db, ws = (acc[0][k] for k in ("part", "dW", "db", "ws"))
+    else:
+        if acc is not None and not acc[1]:
+            raise _lib.SolError("conv3d_thin_bwd_weight: the first call on a fresh accumulation state must have first=True (nothing to add onto yet)")
+        part = torch.empty(lib.sol_conv3d_thin_bwd_weight_ws_floats(B, D, H, W), dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.sol_conv3d_thin_ws_floats(B, D, H, W), dtype=torch.float32, device=dev)
+        dW = torch.empty(5, 5, 5, cin, 32, dtype=torch.float32, device=dev)
+        db = torch.empty(32, dtype=torch.float32, device=dev)
+        if acc is not None:
+            acc[0].update(part=part, dW=dW, db=db, ws=ws, shape=shape_key)
+    first, last = (True, True) if acc is None else (acc[1], acc[2])
+    if acc is not None:
+        acc[0]["open"] = not last
+    check(lib.sol_conv3d_thin_bwd_weight_acc(stream(), ptr(x4), ptr(dz), ptr(zmax), ptr(ws), ptr(part), ptr(dW), ptr(db), B, D, H, W, cin,
+                                             0 if first else 1, 1 if last else 0))
+    return (dW, db) if last else (None, None)
+
+
 def conv3d_bwd_weight(xk, dz, cin, cout, xmax=None, zmax=None, acc=None):
     """dW [5,5,5,cin,cout], db [cout] of y = conv3d(x, W) + b from xk [B,D,H,W,cin_k] (channels padded to 4 / 32) and dz
     [B,D,H,W,cout]: sol_conv3d_bwd_weight (five passes of the batched 2-D weight-gradient kernels over the shifted plane
@@ -457,7 +489,10 @@ class _Conv3DFn(torch.autograd.Function):
         dz = gy.contiguous()
         if lrelu:
             dz = dz * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, slope))
-        dW, db = conv3d_bwd_weight(xk, dz, cin, cout)
+        if MarsMoon3D.thin_kpack and cin <= 4 and cout == 32 and xk.shape[3] == 64:
+            dW, db = conv3d_thin_bwd_weight(xk, dz, cin)
+        else:
+            dW, db = conv3d_bwd_weight(xk, dz, cin, cout)
         # data gradient: the flipped kernel, run channels (cout -> cin)
         co_k = 4 if cout <= 4 else 32
         packed = ctx.packed_bwd if ctx.packed_bwd is not None else _pack3d(_lib.f32(w), cout, cin, 1)
@@ -527,7 +562,10 @@ class _MarsMoon3DFn(torch.autograd.Function):
             dz1 = conv3d(dz, pk[2 + 2 * k][1], None, None, 32, False, sl, zm[2 * k + 2], zm[2 * k + 1], act_ref=a)
             grads[2 + 4 * k], grads[3 + 4 * k] = conv3d_bwd_weight(hprev, dz1, 32, 32, xmax=amax[2 * k], zmax=zm[2 * k + 1], acc=A(1 + 2 * k))
             dz = conv3d(dz1, pk[1 + 2 * k][1], None, dz, 32, False, sl, zm[2 * k + 1], zm[2 * k], act_ref=hprev)
-        grads[0], grads[1] = conv3d_bwd_weight(xk, dz, cin, 32, acc=A(0))
+        if kp and xk.shape[3] == 64 and cin <= 4:
+            grads[0], grads[1] = conv3d_thin_bwd_weight(xk, dz, cin, zmax=zm[0], acc=A(0))
+        else:
+            grads[0], grads[1] = conv3d_bwd_weight(xk, dz, cin, 32, acc=A(0))
         dx = conv3d(dz, pk[0][1], None, None, xk.shape[-1], False, sl, zm[0], None)
         return dx, (None if grads[0] is None else torch.cat([t.reshape(-1) for t in grads]))
 

@@ -421,6 +421,34 @@ def test_conv3d_thin_input_depth_packed_launch_against_float64_and_the_five_pass
     assert torch.isfinite(y).all() and e < 2e-6 and rel(y, y5) < 3e-6, (e, e5, rel(y, y5))
 
 
+@pytest.mark.parametrize("shape,cin", [((1, 6, 8, 64), 4), ((2, 5, 16, 64), 3), ((1, 128, 64, 64), 4)])
+def test_conv3d_thin_input_depth_packed_weight_gradient_against_float64(shape, cin):
+    """sol_conv3d_thin_bwd_weight_acc (the thin-input layer's weight gradient as ONE pass of the 2-D 32 -> 32 fp16 three-product kernel over the
+    depth-packed tensor) against torch float64 autograd of F.conv3d and against the five-pass thin kernel; single call, and two calls
+    accumulated in the caller's state (the unrolled trainer's form)."""
+    import torch.nn.functional as F
+    B, D, H, W = shape
+    gen = torch.Generator().manual_seed(41 + D + cin)
+    xs = [torch.randn(B, D, H, W, cin, generator=gen, dtype=torch.float32).to(DEV) for _ in range(2)]
+    dzs = [(torch.randn(B, D, H, W, 32, generator=gen, dtype=torch.float32) * 1e-3).to(DEV) for _ in range(2)]
+    refs = []
+    for x, dz in zip(xs, dzs):
+        w = torch.zeros(32, cin, 5, 5, 5, dtype=torch.float64, device=DEV, requires_grad=True)
+        (F.conv3d(x.double().permute(0, 4, 1, 2, 3), w, padding=2) * dz.double().permute(0, 4, 1, 2, 3)).sum().backward()
+        refs.append((w.grad.permute(2, 3, 4, 1, 0), dz.double().sum(dim=(0, 1, 2, 3))))
+    dW, db = k3.conv3d_thin_bwd_weight(k3._pad_ch(xs[0], 4), dzs[0], cin)
+    dW5, db5 = k3.conv3d_bwd_weight(k3._pad_ch(xs[0], 4), dzs[0], cin, 32)
+    torch.cuda.synchronize()
+    e, e5 = rel(dW, refs[0][0]), rel(dW5, refs[0][0])
+    print("depth-packed weight gradient vs float64 %.2e (five-pass thin kernel %.2e), db %.2e" % (e, e5, rel(db, refs[0][1])))
+    assert dW.shape == (5, 5, 5, cin, 32) and e < 3e-6 and rel(db, refs[0][1]) < 3e-6, (e, e5)
+    st = {}
+    assert k3.conv3d_thin_bwd_weight(k3._pad_ch(xs[0], 4), dzs[0], cin, acc=(st, True, False)) == (None, None)
+    dW2, db2 = k3.conv3d_thin_bwd_weight(k3._pad_ch(xs[1], 4), dzs[1], cin, acc=(st, False, True))
+    torch.cuda.synchronize()
+    assert rel(dW2, refs[0][0] + refs[1][0]) < 3e-6 and rel(db2, refs[0][1] + refs[1][1]) < 3e-6
+
+
 @pytest.mark.parametrize("D", [16, 128])
 def test_network_w64_against_torch_float64_autograd(D):
     """model_mars_moon3d on 16 x 64 x 64 and on the BASELINE configs[4] grid 128 x 64 x 64 (the one-launch Conv3D kernels): forward, input gradient
