@@ -497,6 +497,13 @@ int sol_conv3d_thin_bwd_weight_acc(void* stream, const float* x, const float* dz
                                    float* dw_dhwio, float* db, int32_t B, int32_t D, int32_t H, int32_t W, int32_t cin_real,
                                    int32_t accumulate_partial, int32_t do_reduce);
 
+/* ... and of a thin-OUTPUT layer (32 -> cout_real <= 4: the network's last layer): dz4 [B,D,H,W,4] (zero padded) is gathered with the opposite
+ * depth offsets and dW [5,5,5,32,cout_real], db [cout_real] come from ONE pass of the 32 -> 32 kernel (the five-pass form pads dz to 32
+ * channels and runs five full 32 -> 32 passes).  x [B,D,H,W,32] with x_absmax (or NULL: computed here); ws / partial as above. */
+int sol_conv3d_thin_out_bwd_weight_acc(void* stream, const float* x, const uint32_t* x_absmax, const float* dz4, float* ws, float* partial,
+                                       float* dw_dhwio, float* db, int32_t B, int32_t D, int32_t H, int32_t W, int32_t cout_real,
+                                       int32_t accumulate_partial, int32_t do_reduce);
+
 /* Conv3D weight gradient: dw_dhwio [5,5,5,cin_real,cout] = sum_px x[px + tap] * dz[px], db [cout] = sum_px dz[px]; five passes
  * of the 2-D weight-gradient kernels over the shifted plane ranges.  x [B,D,H,W,cin] (cin in {4, 32}, zero padded from
  * cin_real), dz [B,D,H,W,cout] (cout in {2, 32}); x_absmax / dz_absmax (or NULL): absmax slots of the two tensors -> fp16

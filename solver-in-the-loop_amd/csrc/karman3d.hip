@@ -1160,13 +1160,15 @@ extern "C" int sol_conv3d(void* stream, const float* x, const float* packed, con
 // its epilogue, the result written once.  Same per-product arithmetic as every other 32 -> 32 layer of the network (option conv_precision).
 // ------------------------------------------------------------------------------------------------------------------------
 namespace {
-__global__ void __launch_bounds__(256) k3_kpack_depth(const float4* __restrict__ x, float4* __restrict__ out, int D, int HW, size_t total) {
+// dir = +1: out[d][..][4 s + c] = x[d + s - 2][..][c] (an INPUT gathered for the taps that read it); dir = -1: out[d][..][4 s + c] = x[d - s + 2][..][c]
+// (an OUTPUT gradient gathered for the weight gradient of a thin-OUTPUT layer: slot s pairs plane d of the wide input with dz of plane d - s + 2)
+__global__ void __launch_bounds__(256) k3_kpack_depth(const float4* __restrict__ x, float4* __restrict__ out, int D, int HW, size_t total, int dir) {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const int s = (int)(e & 7);
         const size_t q = e >> 3, plane = q / HW;
-        const int p = (int)(q - plane * HW), ds = (int)(plane % D) + s - 2;
+        const int p = (int)(q - plane * HW), off = dir * (s - 2), ds = (int)(plane % D) + off;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s < 5 && ds >= 0 && ds < D) v = x[(plane + s - 2) * HW + p];
+        if (s < 5 && ds >= 0 && ds < D) v = x[(size_t)((long)plane + off) * HW + p];
         out[e] = v;
     }
 }
@@ -1208,7 +1210,7 @@ extern "C" int sol_conv3d_thin(void* stream, const float* x, const float* packed
     const size_t npx = (size_t)B * D * H * W;
     uint32_t* slots = reinterpret_cast<uint32_t*>(ws + npx * 32);
     if (int e = sol_absmax(stream, x, (int64_t)(npx * 4), slots)) return e;
-    SOL_LAUNCH(k3_kpack_depth, dim3(grid_for(npx * 8)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(ws), D, H * W, npx * 8);
+    SOL_LAUNCH(k3_kpack_depth, dim3(grid_for(npx * 8)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(ws), D, H * W, npx * 8, 1);
     SOL_LAUNCH_CHECK();
     return sol_conv5x5_scaled(stream, ws, packed, bias, nullptr, act_ref, y, B * D, H, W, 32, 32, epilogue, slope, slots, y_absmax);
 }
@@ -1223,10 +1225,48 @@ __global__ void __launch_bounds__(256) k3_kunpack_dw(const float* __restrict__ d
     const int co = e & 31, c = (e >> 5) % cin, t = e / (32 * cin), s = t / 25, tap = t % 25;
     dw[e] = dw2[(tap * 32 + 4 * s + c) * 32 + co];
 }
+// thin-OUTPUT layer (32 -> cout <= 4): dW[s][dy][dx][ci][c] = dW'[dy][dx][ci][4 s + c], db[c] = db'[8 + c] (the centre slot holds every plane of dz)
+__global__ void __launch_bounds__(256) k3_kunpack_dw_out(const float* __restrict__ dw2, const float* __restrict__ db2, float* __restrict__ dw, float* __restrict__ db, int cout) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < cout) db[e] = db2[8 + e];
+    if (e >= 125 * 32 * cout) return;
+    const int c = e % cout, ci = (e / cout) & 31, t = e / (32 * cout), s = t / 25, tap = t % 25;
+    dw[e] = dw2[(tap * 32 + ci) * 32 + 4 * s + c];
+}
 }  // namespace
 
 extern "C" size_t sol_conv3d_thin_bwd_weight_ws_floats(int32_t B, int32_t D, int32_t H, int32_t /*W*/) {
-    return align_up(sol_bww_batched_ws_floats(1, B * D, H, 32, 32), 64) + 25 * 32 * 32;
+    return align_up(sol_bww_batched_ws_floats(1, B * D, H, 32, 32), 64) + 25 * 32 * 32 + 32;
+}
+
+// The thin-OUTPUT layer (32 -> cout <= 4: the network's last layer) the same way: its output gradient dz [B,D,H,W,4] (zero padded) is gathered
+// with the OPPOSITE depth offsets, dz'[d][..][4 s + c] = dz[d - s + 2][..][c], and dW'[dy][dx][ci][4 s + c] = sum x[px + (dy, dx)][ci] dz'[px][4 s + c]
+// is one pass of the 32 -> 32 kernel (the five-pass form pads dz to 32 channels and runs FIVE full 32 -> 32 passes for three useful columns).
+extern "C" int sol_conv3d_thin_out_bwd_weight_acc(void* stream, const float* x, const uint32_t* x_absmax, const float* dz4, float* ws, float* partial,
+                                                  float* dw_dhwio, float* db, int32_t B, int32_t D, int32_t H, int32_t W, int32_t cout_real,
+                                                  int32_t accumulate_partial, int32_t do_reduce) {
+    SOL_REQUIRE(x && dz4 && ws && partial && dw_dhwio && db, "sol_conv3d_thin_out_bwd_weight: NULL pointer");
+    SOL_REQUIRE(B >= 1 && D >= 1 && H >= 1 && W == 64 && cout_real >= 1 && cout_real <= 4, "sol_conv3d_thin_out_bwd_weight: needs W == 64 and 1..4 output channels (B %d, D %d, H %d, W %d, cout %d)", B, D, H, W, cout_real);
+    const size_t npx = (size_t)B * D * H * W;
+    uint32_t* slots_z = reinterpret_cast<uint32_t*>(ws + npx * 32);
+    uint32_t* slots_x = slots_z + 256;
+    if (int e = sol_absmax(stream, dz4, (int64_t)(npx * 4), slots_z)) return e;
+    if (!x_absmax) {
+        if (int e = sol_absmax(stream, x, (int64_t)(npx * 32), slots_x)) return e;
+        x_absmax = slots_x;
+    }
+    SOL_LAUNCH(k3_kpack_depth, dim3(grid_for(npx * 8)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(dz4), reinterpret_cast<float4*>(ws), D, H * W, npx * 8, -1);
+    SOL_LAUNCH_CHECK();
+    if (int e = sol_bww_batched(stream, x, ws, partial, 1, 1, accumulate_partial ? 0 : 1, 0, 0, B * D, H, W, 32, 32, x_absmax, slots_z, 0, 0)) return e;
+    if (!do_reduce) return SOL_OK;
+    float* dw2 = partial + align_up(sol_bww_batched_ws_floats(1, B * D, H, 32, 32), 64);
+    float* db2 = dw2 + 25 * 32 * 32;
+    float* parts[1] = {partial}; float* dws[1] = {dw2}; float* dbs[1] = {db2};
+    const int rows[1] = {B * D * H}, rbs[1] = {0}, ci[1] = {32}, co[1] = {32};
+    if (int e = sol_bww_reduce_layers(stream, 1, parts, dws, dbs, rows, rbs, ci, co, 0, 0)) return e;
+    SOL_LAUNCH(k3_kunpack_dw_out, dim3((125 * 32 * cout_real + 255) / 256), dim3(256), 0, (hipStream_t)stream, dw2, db2, dw_dhwio, db, cout_real);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
 }
 
 extern "C" int sol_conv3d_thin_bwd_weight_acc(void* stream, const float* x, const float* dz, const uint32_t* dz_absmax, float* ws, float* partial,
@@ -1242,7 +1282,7 @@ extern "C" int sol_conv3d_thin_bwd_weight_acc(void* stream, const float* x, cons
         if (int e = sol_absmax(stream, dz, (int64_t)(npx * 32), slots_z)) return e;
         dz_absmax = slots_z;
     }
-    SOL_LAUNCH(k3_kpack_depth, dim3(grid_for(npx * 8)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(ws), D, H * W, npx * 8);
+    SOL_LAUNCH(k3_kpack_depth, dim3(grid_for(npx * 8)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(ws), D, H * W, npx * 8, 1);
     SOL_LAUNCH_CHECK();
     if (int e = sol_bww_batched(stream, ws, dz, partial, 1, 1, accumulate_partial ? 0 : 1, 0, 0, B * D, H, W, 32, 32, slots_x, dz_absmax, 0, 0)) return e;
     if (!do_reduce) return SOL_OK;

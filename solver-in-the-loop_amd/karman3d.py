@@ -375,15 +375,17 @@ def _pad_ch(x, c):
     return x.contiguous() if x.shape[-1] == c else torch.nn.functional.pad(x, (0, c - x.shape[-1])).contiguous()
 
 
-def conv3d_thin_bwd_weight(x4, dz, cin, zmax=None, acc=None):
+def conv3d_thin_bwd_weight(x4, dz, cin, zmax=None, acc=None, thin_out=False):
     """dW [5,5,5,cin,32], db [32] of a thin-input layer y = conv3d(x, W) + b from x4 [B,D,H,W,4] (zero padded) and dz [B,D,H,W,32], W == 64:
     sol_conv3d_thin_bwd_weight_acc -- the depth taps packed into the channel axis, ONE pass of the 2-D 32 -> 32 weight-gradient kernel.
+    thin_out=True: the thin-OUTPUT layer (32 -> cin <= 4 channels; `x4` is then the zero-padded output gradient [B,D,H,W,4], `dz` the layer's
+    32-channel input and `zmax` its absmax slots): dW [5,5,5,32,cin], db [cin] (sol_conv3d_thin_out_bwd_weight_acc).
     acc = (state dict, first, last) as in conv3d_bwd_weight."""
     lib = _lib.load()
     B, D, H, W, c = x4.shape
     assert c == 4 and dz.shape[-1] == 32 and W == 64
     dev = x4.device
-    shape_key = ("thin", B, D, H, W, cin, str(dev))
+    shape_key = ("thin_out" if thin_out else "thin", B, D, H, W, cin, str(dev))
     if acc is not None and "part" in acc[0]:
         if acc[0].get("shape") != shape_key:
             raise _lib.SolError("conv3d_thin_bwd_weight: the accumulation state was allocated for %s, this call has %s" % (acc[0].get("shape"), shape_key))
@@ -395,15 +397,19 @@ def conv3d_thin_bwd_weight(x4, dz, cin, zmax=None, acc=None):
             raise _lib.SolError("conv3d_thin_bwd_weight: the first call on a fresh accumulation state must have first=True (nothing to add onto yet)")
         part = torch.empty(lib.sol_conv3d_thin_bwd_weight_ws_floats(B, D, H, W), dtype=torch.float32, device=dev)
         ws = torch.empty(lib.sol_conv3d_thin_ws_floats(B, D, H, W), dtype=torch.float32, device=dev)
-        dW = torch.empty(5, 5, 5, cin, 32, dtype=torch.float32, device=dev)
-        db = torch.empty(32, dtype=torch.float32, device=dev)
+        dW = torch.empty((5, 5, 5, 32, cin) if thin_out else (5, 5, 5, cin, 32), dtype=torch.float32, device=dev)
+        db = torch.empty(cin if thin_out else 32, dtype=torch.float32, device=dev)
         if acc is not None:
             acc[0].update(part=part, dW=dW, db=db, ws=ws, shape=shape_key)
     first, last = (True, True) if acc is None else (acc[1], acc[2])
     if acc is not None:
         acc[0]["open"] = not last
-    check(lib.sol_conv3d_thin_bwd_weight_acc(stream(), ptr(x4), ptr(dz), ptr(zmax), ptr(ws), ptr(part), ptr(dW), ptr(db), B, D, H, W, cin,
-                                             0 if first else 1, 1 if last else 0))
+    if thin_out:
+        check(lib.sol_conv3d_thin_out_bwd_weight_acc(stream(), ptr(dz), ptr(zmax), ptr(x4), ptr(ws), ptr(part), ptr(dW), ptr(db), B, D, H, W, cin,
+                                                     0 if first else 1, 1 if last else 0))
+    else:
+        check(lib.sol_conv3d_thin_bwd_weight_acc(stream(), ptr(x4), ptr(dz), ptr(zmax), ptr(ws), ptr(part), ptr(dW), ptr(db), B, D, H, W, cin,
+                                                 0 if first else 1, 1 if last else 0))
     return (dW, db) if last else (None, None)
 
 
@@ -491,6 +497,8 @@ class _Conv3DFn(torch.autograd.Function):
             dz = dz * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, slope))
         if MarsMoon3D.thin_kpack and cin <= 4 and cout == 32 and xk.shape[3] == 64:
             dW, db = conv3d_thin_bwd_weight(xk, dz, cin)
+        elif MarsMoon3D.thin_kpack and cin == 32 and cout <= 4 and xk.shape[3] == 64:
+            dW, db = conv3d_thin_bwd_weight(_pad_ch(dz, 4), xk, cout, thin_out=True)
         else:
             dW, db = conv3d_bwd_weight(xk, dz, cin, cout)
         # data gradient: the flipped kernel, run channels (cout -> cin)
@@ -548,11 +556,15 @@ class _MarsMoon3DFn(torch.autograd.Function):
         grads = [None] * 24
         zm = torch.zeros(11, 256, dtype=torch.int32, device=xk.device)         # absmax slots of the eleven pre-activation gradients
         g = _lib.f32(g_out).contiguous()
-        grads[22], grads[23] = conv3d_bwd_weight(acts[10], g, 32, cout, xmax=amax[10], acc=A(11))
-        # d loss / d (pre-activation of the last residual block's output) = conv3d(g, flip(w11)^T) * lrelu'(h5)
         kp = net.thin_packs()
+        g4 = _pad_ch(g, 4) if kp else None
+        if kp and g.shape[3] == 64:
+            grads[22], grads[23] = conv3d_thin_bwd_weight(g4, acts[10], cout, zmax=amax[10], acc=A(11), thin_out=True)
+        else:
+            grads[22], grads[23] = conv3d_bwd_weight(acts[10], g, 32, cout, xmax=amax[10], acc=A(11))
+        # d loss / d (pre-activation of the last residual block's output) = conv3d(g, flip(w11)^T) * lrelu'(h5)
         if kp:
-            dz = conv3d_thin(_pad_ch(g, 4), kp[1], None, False, sl, zm[10], act_ref=acts[10])
+            dz = conv3d_thin(g4, kp[1], None, False, sl, zm[10], act_ref=acts[10])
         else:
             dz = conv3d(_pad_ch(g, 4), pk[11][1], None, None, 32, False, sl, None, zm[10], act_ref=acts[10])
         for k in range(4, -1, -1):

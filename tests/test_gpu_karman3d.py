@@ -449,6 +449,26 @@ def test_conv3d_thin_input_depth_packed_weight_gradient_against_float64(shape, c
     assert rel(dW2, refs[0][0] + refs[1][0]) < 3e-6 and rel(db2, refs[0][1] + refs[1][1]) < 3e-6
 
 
+@pytest.mark.parametrize("shape,cout", [((1, 6, 8, 64), 3), ((2, 5, 16, 64), 4), ((1, 128, 64, 64), 3)])
+def test_conv3d_thin_output_depth_packed_weight_gradient_against_float64(shape, cout):
+    """sol_conv3d_thin_out_bwd_weight_acc: the weight gradient of the 32 -> cout (<= 4) output layer with the output gradient gathered over the
+    depth offsets (one 32 -> 32 pass instead of five on a dz padded to 32 channels) against torch float64 autograd and the five-pass form."""
+    import torch.nn.functional as F
+    B, D, H, W = shape
+    gen = torch.Generator().manual_seed(51 + D + cout)
+    x = torch.randn(B, D, H, W, 32, generator=gen, dtype=torch.float32).to(DEV)
+    dz = (torch.randn(B, D, H, W, cout, generator=gen, dtype=torch.float32) * 1e-3).to(DEV)
+    w = torch.zeros(cout, 32, 5, 5, 5, dtype=torch.float64, device=DEV, requires_grad=True)
+    (F.conv3d(x.double().permute(0, 4, 1, 2, 3), w, padding=2) * dz.double().permute(0, 4, 1, 2, 3)).sum().backward()
+    ref_w, ref_b = w.grad.permute(2, 3, 4, 1, 0), dz.double().sum(dim=(0, 1, 2, 3))
+    dW, db = k3.conv3d_thin_bwd_weight(k3._pad_ch(dz, 4), x, cout, thin_out=True)
+    dW5, db5 = k3.conv3d_bwd_weight(x, dz, 32, cout)
+    torch.cuda.synchronize()
+    e, e5 = rel(dW, ref_w), rel(dW5, ref_w)
+    print("depth-packed output-layer weight gradient vs float64 %.2e (five-pass form %.2e), db %.2e" % (e, e5, rel(db, ref_b)))
+    assert dW.shape == (5, 5, 5, 32, cout) and db.shape == (cout,) and e < 3e-6 and rel(db, ref_b) < 3e-6, (e, e5)
+
+
 @pytest.mark.parametrize("D", [16, 128])
 def test_network_w64_against_torch_float64_autograd(D):
     """model_mars_moon3d on 16 x 64 x 64 and on the BASELINE configs[4] grid 128 x 64 x 64 (the one-launch Conv3D kernels): forward, input gradient
