@@ -96,6 +96,15 @@ struct BwArgs {
     int cin_real;                 // thin first layer (cin == 4): 1..3 = the channels beyond it are zero padding (their gradient rows are not computed); 0: all four are data
 };
 int sol_bww_sb_launch(hipStream_t s, const BwArgs& a, int nblk_run);
+struct BwJobs {
+    BwArgs a[5];
+    int nrun[5];            // workgroups job k needs (<= wg_per; the surplus ones end at once)
+    int n, wg_per;
+};
+int sol_bww_sb_jobs_launch(hipStream_t s, const BwJobs& p);
+// n <= 5 independent 32 -> 32 weight-gradient passes (x[k], dz[k] -> partial[k], nplanes[k] x H rows of 64 pixels) in one launch (conv5x5.hip)
+int sol_bww_batched_jobs(void* stream, int n, const float* const* x, const float* const* dz, float* const* partial, const int* nplanes, int overwrite,
+                         int H, int W, const unsigned* xmax, const unsigned* zmax);
 // ---- persistent chain of 32 -> 32 layers (cnn_chain.hip) ----
 constexpr int SOL_CHAIN_MAXL = 12;
 struct ChainLayer {
@@ -210,6 +219,7 @@ struct SolOptions {
                           //    instead of a k_seed launch per unrolled step
     int conv_thin_t3;     // 1 (default): the thin-INPUT layers of 64-pixel images (first layer, last backward-data layer incl. seed mode) as three image rows per
                           //    twelve-wave workgroup (k_conv5x5_t3); 0: k_conv5x5<4, NT>, one row per workgroup
+    int k3d_bww_jobs;     // 1 (default): the five depth slices of a 32 -> 32 Conv3D weight gradient as ONE launch (k_conv5x5_bww_sb_jobs); 0: five launches
     int fwd_bands;        // 1 (default): the 128 x 64 forward solver step of the training / roll-out path as FOUR workgroups per simulation (k_karman_fwd_bands:
                           //    stencil phases on row bands with recomputed halos, the direct solve on band 0's CU, two hand-offs through global memory); 0: one workgroup
     int k3d_tile;         // 1: karman-3d advection from LDS tiles holding the full z column + halo; 0 (default, measured faster at B <= 2): wave-per-column gathers from global memory

@@ -1484,6 +1484,27 @@ int sol_bww_batched(void* stream, const float* x, const float* dz, float* partia
     return bww_launch(stream, x, dz, partial, nseg, x_seg, dz_seg, rb, overwrite, B, H, W, cin, cout, nblk, xmax, zmax, xmax_seg, zmax_seg, cin_real);
 }
 
+// n <= 5 passes of the 32 -> 32 split kernels in ONE launch: same blocks, partial layouts and arithmetic as n calls of
+// sol_bww_batched(stream, x[k], dz[k], partial[k], 1, 1, overwrite, 0, 0, nplanes[k], H, 64, 32, 32, xmax, zmax, 0, 0)
+int sol_bww_batched_jobs(void* stream, int n, const float* const* x, const float* const* dz, float* const* partial, const int* nplanes, int overwrite,
+                         int H, int W, const unsigned* xmax, const unsigned* zmax) {
+    SOL_REQUIRE(n >= 1 && n <= 5 && W == 64 && H >= 1 && sol_opt().conv_precision != 2, "sol_bww_batched_jobs: 1..5 jobs of the split kernels, W == 64");
+    BwJobs p{};
+    p.n = n;
+    for (int k = 0; k < n; ++k) {
+        SOL_REQUIRE(x[k] && dz[k] && partial[k] && nplanes[k] >= 1, "sol_bww_batched_jobs: bad job %d", k);
+        BwArgs& a = p.a[k];
+        a.x = x[k]; a.dz = dz[k]; a.partial = partial[k]; a.B = nplanes[k]; a.H = H; a.W = W; a.cin = 32; a.cout = 32;
+        a.nseg = 1; a.rb = pick_rb(nplanes[k] * H); a.x_seg = 0; a.dz_seg = 0; a.overwrite = overwrite;
+        a.xmax = xmax; a.zmax = zmax; a.xmax_seg = 0; a.zmax_seg = 0; a.cin_real = 0;
+        int IP, OP;
+        bww_dims(nplanes[k] * H, a.rb, 32, 32, &a.nblk, &IP, &OP);
+        p.nrun[k] = a.nblk;
+        p.wg_per = p.wg_per > a.nblk ? p.wg_per : a.nblk;
+    }
+    return sol_bww_sb_jobs_launch((hipStream_t)stream, p);
+}
+
 static int bww_reduce(void* stream, const float* partial, float* dw_hwio, float* db, int rows, int rb, int cin, int cout, int accumulate, int tt = 0) {
     SOL_REQUIRE(partial && dw_hwio && db, "sol_conv5x5_bwd_weight_reduce: NULL pointer");
     SOL_REQUIRE(cin >= 1 && cin <= 32 && cout >= 1 && cout <= 32, "sol_conv5x5_bwd_weight_reduce: channels out of range");

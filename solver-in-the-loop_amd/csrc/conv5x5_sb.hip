@@ -494,6 +494,15 @@ __global__ void __launch_bounds__(512) k_conv5x5_bww_sb(BwArgs a) {
     extern __shared__ __align__(16) unsigned char smem_sb[];
     bww_sb_body<KIND>(a, blockIdx.x, smem_sb);
 }
+// n <= 5 weight-gradient jobs in ONE launch (karman-3d: the five depth slices of a Conv3D layer, which were five launches of one round of
+// workgroups each -- every one with its own dispatch gap, cold start and tail): workgroup u runs block u % wg_per of job u / wg_per
+template <int KIND>
+__global__ void __launch_bounds__(512) k_conv5x5_bww_sb_jobs(BwJobs p) {
+    extern __shared__ __align__(16) unsigned char smem_sb[];
+    const int job = (int)blockIdx.x / p.wg_per, sub = (int)blockIdx.x % p.wg_per;
+    if (sub >= p.nrun[job]) return;
+    bww_sb_body<KIND>(p.a[job], sub, smem_sb);
+}
 
 #ifdef BWW_PROF
 extern "C" int sol_bww_prof_set(unsigned* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(sbk::g_bww_prof), &buf, sizeof(buf)) == hipSuccess ? 0 : -1; }
@@ -565,7 +574,7 @@ constexpr size_t sb_lds(int OP) { return (size_t)4 * 3 * 68 * 64 + 2 * (size_t)5
 int init_sb_kernels() {
     // static LDS (the conv kernels' epilogue-prefetch regions) counts against the same 160 KB
     static std::atomic<unsigned long long> optin{0};
-    return sol_lds_optin(optin, {SOL_K(k_conv5x5_bww_sb<0>), SOL_K(k_conv5x5_bww_sb<2>), SOL_K(k_conv5x5_sb<1, 0>), SOL_K(k_conv5x5_sb<2, 0>),
+    return sol_lds_optin(optin, {SOL_K(k_conv5x5_bww_sb<0>), SOL_K(k_conv5x5_bww_sb<2>), SOL_K(k_conv5x5_bww_sb_jobs<0>), SOL_K(k_conv5x5_bww_sb_jobs<2>), SOL_K(k_conv5x5_sb<1, 0>), SOL_K(k_conv5x5_sb<2, 0>),
                                  SOL_K(k_conv5x5_sb<1, 1>), SOL_K(k_conv5x5_sb<2, 1>), SOL_K(k_conv5x5_sb<1, 2>), SOL_K(k_conv5x5_sb<2, 2>)},
                          "split conv kernels", true);
 }
@@ -642,6 +651,17 @@ int sol_bww_sb_launch(hipStream_t s, const BwArgs& a, int nblk_run) {
     // fp16 three-product kernel: absmax of both operands known and no workgroup straddles two segments
     if (use_sh && a.xmax && a.zmax && (a.B * a.H) % a.rb == 0) SOL_LAUNCH(k_conv5x5_bww_sb<2>, dim3(nblk_run), dim3(512), BW_LDS, s, a);
     else SOL_LAUNCH(k_conv5x5_bww_sb<0>, dim3(nblk_run), dim3(512), BW_LDS, s, a);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
+int sol_bww_sb_jobs_launch(hipStream_t s, const BwJobs& p) {
+    if (int e = init_sb_kernels()) return e;
+    SOL_REQUIRE(p.n >= 1 && p.n <= 5 && p.wg_per >= 1, "sol_bww_sb_jobs_launch: 1..5 jobs");
+    bool sh = sol_opt().conv_precision == 0;
+    for (int k = 0; k < p.n; ++k) sh = sh && p.a[k].xmax && p.a[k].zmax && (p.a[k].B * p.a[k].H) % p.a[k].rb == 0;
+    if (sh) SOL_LAUNCH(k_conv5x5_bww_sb_jobs<2>, dim3(p.n * p.wg_per), dim3(512), BW_LDS, s, p);
+    else SOL_LAUNCH(k_conv5x5_bww_sb_jobs<0>, dim3(p.n * p.wg_per), dim3(512), BW_LDS, s, p);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }

@@ -1331,10 +1331,24 @@ extern "C" int sol_conv3d_bwd_weight_acc(void* stream, const float* x, const flo
     // one's blocks (same plane range, same block layout) --, then ONE two-stage reduce launch pair for all five slices
     // (it was a pair per slice and simulation: 10 B launches of a few microseconds of work each per layer).
     float* parts[5]; float* dws[5]; float* dbs[5]; int rows[5], rbs[5], cins[5], couts[5];
+    // 32 -> 32 on the split kernels: the five slices of a simulation are ONE launch (five rounds of workgroups back to back instead of five
+    // launches of one round each; option k3d_bww_jobs)
+    const bool jobs = cin == 32 && cout == 32 && W == 64 && sol_opt().conv_precision != 2 && sol_opt().k3d_bww_jobs;
     for (int kd = 0; kd < 5; ++kd) {
         const int lo = kd < 2 ? 2 - kd : 0, hi = kd > 2 ? D + 2 - kd : D;       // output planes that see input plane d + kd - 2
         parts[kd] = partial + kd * per; dws[kd] = dw_dhwio + kd * slice; dbs[kd] = kd == 2 ? db : db_scratch + (size_t)kd * cout;
         rows[kd] = (hi - lo) * H; rbs[kd] = 0; cins[kd] = cin_real; couts[kd] = cout_real;
+    }
+    for (int b = 0; jobs && b < B; ++b) {
+        const float* xs[5]; const float* zs[5]; int np[5];
+        for (int kd = 0; kd < 5; ++kd) {
+            const int lo = kd < 2 ? 2 - kd : 0, hi = kd > 2 ? D + 2 - kd : D;
+            xs[kd] = x + ((size_t)b * D + lo + kd - 2) * pin; zs[kd] = dz + ((size_t)b * D + lo) * pout; np[kd] = hi - lo;
+        }
+        if (int e = sol_bww_batched_jobs(stream, 5, xs, zs, parts, np, b == 0 && !accumulate_partial, H, W, x_absmax, dz_absmax)) return e;
+    }
+    for (int kd = 0; !jobs && kd < 5; ++kd) {
+        const int lo = kd < 2 ? 2 - kd : 0, hi = kd > 2 ? D + 2 - kd : D;
         for (int b = 0; b < B; ++b) {
             const float* xb = x + ((size_t)b * D + lo + kd - 2) * pin;
             const float* zb = dz + ((size_t)b * D + lo) * pout;

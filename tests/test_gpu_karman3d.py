@@ -351,6 +351,30 @@ def test_conv3d_weight_gradient_accumulation_state_is_checked():
     assert rel(dW, ref[0][0].double() + ref[1][0].double()) < 2e-6 and rel(db, ref[0][1].double() + ref[1][1].double()) < 2e-6
 
 
+@pytest.mark.parametrize("shape", [(1, 6, 8, 64), (2, 5, 16, 64), (1, 128, 64, 64)])
+def test_conv3d_weight_gradient_one_launch_for_the_five_depth_slices_is_bit_identical(shape):
+    """Option k3d_bww_jobs: the five depth slices of a 32 -> 32 Conv3D weight gradient as ONE launch (k_conv5x5_bww_sb_jobs: same blocks, same
+    partial layout, same arithmetic) against five launches -- dW and db bit for bit, single call and accumulated over two calls."""
+    B, D, H, W = shape
+    gen = torch.Generator().manual_seed(77 + D)
+    x = torch.randn(B, D, H, W, 32, generator=gen, dtype=torch.float32).to(DEV)
+    dz = [(torch.randn(B, D, H, W, 32, generator=gen, dtype=torch.float32) * 1e-2).to(DEV) for _ in range(2)]
+    out = {}
+    for jobs in (1, 0):
+        sol_amd._lib.set_option("k3d_bww_jobs", jobs)
+        try:
+            one = k3.conv3d_bwd_weight(x, dz[0], 32, 32)
+            st = {}
+            k3.conv3d_bwd_weight(x, dz[0], 32, 32, acc=(st, True, False))
+            two = k3.conv3d_bwd_weight(x, dz[1], 32, 32, acc=(st, False, True))
+            torch.cuda.synchronize()
+            out[jobs] = [t.clone() for t in one + two]
+        finally:
+            sol_amd._lib.set_option("k3d_bww_jobs", 1)
+    for a, b in zip(out[1], out[0]):
+        assert torch.equal(a, b), float((a - b).abs().max())
+
+
 @pytest.mark.parametrize("cout,res,mode", [(32, True, "lrelu"), (32, True, "dlrelu"), (3, False, "none"), (4, False, "none")])
 def test_conv3d_full_size_one_launch_against_five_pass_and_shift_property(cout, res, mode):
     """BASELINE configs[4] size (128 x 64 x 64, all 1 024 workgroups and every XCD tile mapping of the one-launch kernel): (i) the
