@@ -74,8 +74,9 @@ int sol_abi_sizes(int32_t* karman_cfg, int32_t* burgers_cfg, int32_t* train_cfg)
  *                       (departure points beyond the halo: recomputed from the step's input, 1e-6)
  *   conv_thin_t3 (1)    thin-input layers (3 -> 32 first layer, 2 -> 32 last backward-data layer incl. the seed form) of 64-pixel rows as three rows
  *                       of the batch x height stack per twelve-wave workgroup; 0: one row per 256-thread workgroup.  Same results bit for bit
- *   k3d_bww_jobs (1)    karman-3d: the five depth slices of a 32 -> 32 Conv3D weight gradient (sol_conv3d_bwd_weight*) as ONE launch of five rounds of
- *                       workgroups; 0: five launches.  Same results bit for bit
+ *   k3d_bww_jobs (2)    karman-3d: the five depth slices of a 32 -> 32 Conv3D weight gradient (sol_conv3d_bwd_weight*) as ONE launch of ONE round of
+ *                       workgroups (51 per slice; other block partition: sums equal to round-off); 1: one launch of five rounds of 32-row
+ *                       workgroups (bit-identical to 0); 0: five launches
  *   bww_chunk (0), bww_side (1), streams (1), cpt (0), conv_split3 (0), dbg_skip (0), step_prof (0): experiments, debugging */
 int sol_set_option(const char* name, int32_t value);
 int sol_get_option(const char* name, int32_t* value);

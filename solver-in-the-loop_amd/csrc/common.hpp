@@ -104,7 +104,8 @@ struct BwJobs {
 int sol_bww_sb_jobs_launch(hipStream_t s, const BwJobs& p);
 // n <= 5 independent 32 -> 32 weight-gradient passes (x[k], dz[k] -> partial[k], nplanes[k] x H rows of 64 pixels) in one launch (conv5x5.hip)
 int sol_bww_batched_jobs(void* stream, int n, const float* const* x, const float* const* dz, float* const* partial, const int* nplanes, int overwrite,
-                         int H, int W, const unsigned* xmax, const unsigned* zmax);
+                         int H, int W, const unsigned* xmax, const unsigned* zmax, int rb);
+int sol_bww_pick_rb(int rows);
 // ---- persistent chain of 32 -> 32 layers (cnn_chain.hip) ----
 constexpr int SOL_CHAIN_MAXL = 12;
 struct ChainLayer {
@@ -219,7 +220,9 @@ struct SolOptions {
                           //    instead of a k_seed launch per unrolled step
     int conv_thin_t3;     // 1 (default): the thin-INPUT layers of 64-pixel images (first layer, last backward-data layer incl. seed mode) as three image rows per
                           //    twelve-wave workgroup (k_conv5x5_t3); 0: k_conv5x5<4, NT>, one row per workgroup
-    int k3d_bww_jobs;     // 1 (default): the five depth slices of a 32 -> 32 Conv3D weight gradient as ONE launch (k_conv5x5_bww_sb_jobs); 0: five launches
+    int k3d_bww_jobs;     // the five depth slices of a 32 -> 32 Conv3D weight gradient: 2 (default) ONE launch of ONE round of workgroups (51 per slice, each
+                          //    with a fifth of the rows of its slice: a fifth of the prologues and of the partial read-modify-writes); 1: one launch,
+                          //    five rounds of 32-row workgroups (k_conv5x5_bww_sb_jobs); 0: five launches
     int fwd_bands;        // 1 (default): the 128 x 64 forward solver step of the training / roll-out path as FOUR workgroups per simulation (k_karman_fwd_bands:
                           //    stencil phases on row bands with recomputed halos, the direct solve on band 0's CU, two hand-offs through global memory); 0: one workgroup
     int k3d_tile;         // 1: karman-3d advection from LDS tiles holding the full z column + halo; 0 (default, measured faster at B <= 2): wave-per-column gathers from global memory

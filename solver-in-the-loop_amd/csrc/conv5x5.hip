@@ -1414,6 +1414,8 @@ extern "C" size_t sol_conv5x5_bwd_weight_ws_floats(int32_t B, int32_t H, int32_t
     return (size_t)nblk * (25 * IP * OP + OP);
 }
 
+int sol_bww_pick_rb(int rows) { return pick_rb(rows); }
+
 size_t sol_bww_batched_ws_floats(int nseg, int B, int H, int cin, int cout) {
     int nblk, IP, OP;
     const int rows = nseg * B * H;
@@ -1486,8 +1488,10 @@ int sol_bww_batched(void* stream, const float* x, const float* dz, float* partia
 
 // n <= 5 passes of the 32 -> 32 split kernels in ONE launch: same blocks, partial layouts and arithmetic as n calls of
 // sol_bww_batched(stream, x[k], dz[k], partial[k], 1, 1, overwrite, 0, 0, nplanes[k], H, 64, 32, 32, xmax, zmax, 0, 0)
+// rb > 0: image rows per workgroup (every job; >= pick_rb of the job's rows, so that the partial layout fits the buffer sized for pick_rb);
+// the reduce must then be called with the same rb
 int sol_bww_batched_jobs(void* stream, int n, const float* const* x, const float* const* dz, float* const* partial, const int* nplanes, int overwrite,
-                         int H, int W, const unsigned* xmax, const unsigned* zmax) {
+                         int H, int W, const unsigned* xmax, const unsigned* zmax, int rb) {
     SOL_REQUIRE(n >= 1 && n <= 5 && W == 64 && H >= 1 && sol_opt().conv_precision != 2, "sol_bww_batched_jobs: 1..5 jobs of the split kernels, W == 64");
     BwJobs p{};
     p.n = n;
@@ -1495,7 +1499,8 @@ int sol_bww_batched_jobs(void* stream, int n, const float* const* x, const float
         SOL_REQUIRE(x[k] && dz[k] && partial[k] && nplanes[k] >= 1, "sol_bww_batched_jobs: bad job %d", k);
         BwArgs& a = p.a[k];
         a.x = x[k]; a.dz = dz[k]; a.partial = partial[k]; a.B = nplanes[k]; a.H = H; a.W = W; a.cin = 32; a.cout = 32;
-        a.nseg = 1; a.rb = pick_rb(nplanes[k] * H); a.x_seg = 0; a.dz_seg = 0; a.overwrite = overwrite;
+        a.nseg = 1; a.rb = rb > 0 ? rb : pick_rb(nplanes[k] * H); a.x_seg = 0;
+        SOL_REQUIRE(a.rb >= pick_rb(nplanes[k] * H), "sol_bww_batched_jobs: %d rows per workgroup is below the layout's %d", a.rb, pick_rb(nplanes[k] * H)); a.dz_seg = 0; a.overwrite = overwrite;
         a.xmax = xmax; a.zmax = zmax; a.xmax_seg = 0; a.zmax_seg = 0; a.cin_real = 0;
         int IP, OP;
         bww_dims(nplanes[k] * H, a.rb, 32, 32, &a.nblk, &IP, &OP);

@@ -659,7 +659,8 @@ int sol_bww_sb_jobs_launch(hipStream_t s, const BwJobs& p) {
     if (int e = init_sb_kernels()) return e;
     SOL_REQUIRE(p.n >= 1 && p.n <= 5 && p.wg_per >= 1, "sol_bww_sb_jobs_launch: 1..5 jobs");
     bool sh = sol_opt().conv_precision == 0;
-    for (int k = 0; k < p.n; ++k) sh = sh && p.a[k].xmax && p.a[k].zmax && (p.a[k].B * p.a[k].H) % p.a[k].rb == 0;
+    // (a workgroup must not straddle two SEGMENTS -- their scales differ; with one segment a ragged last block is fine)
+    for (int k = 0; k < p.n; ++k) sh = sh && p.a[k].xmax && p.a[k].zmax && (p.a[k].nseg == 1 || (p.a[k].B * p.a[k].H) % p.a[k].rb == 0);
     if (sh) SOL_LAUNCH(k_conv5x5_bww_sb_jobs<2>, dim3(p.n * p.wg_per), dim3(512), BW_LDS, s, p);
     else SOL_LAUNCH(k_conv5x5_bww_sb_jobs<0>, dim3(p.n * p.wg_per), dim3(512), BW_LDS, s, p);
     SOL_LAUNCH_CHECK();

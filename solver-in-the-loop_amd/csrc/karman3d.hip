@@ -1339,13 +1339,20 @@ extern "C" int sol_conv3d_bwd_weight_acc(void* stream, const float* x, const flo
         parts[kd] = partial + kd * per; dws[kd] = dw_dhwio + kd * slice; dbs[kd] = kd == 2 ? db : db_scratch + (size_t)kd * cout;
         rows[kd] = (hi - lo) * H; rbs[kd] = 0; cins[kd] = cin_real; couts[kd] = cout_real;
     }
+    // k3d_bww_jobs == 2: ONE round -- 51 workgroups per slice (255 of 256 CUs), each with a fifth of the rows a 32-row block form gives a CU
+    // over five rounds: one prologue (three rows of look-ahead from HBM) and one read-modify-write of the 100 KB partial instead of five
+    int rb_jobs = 0;
+    if (jobs && sol_opt().k3d_bww_jobs == 2) {
+        const int rbw = (D * H + 50) / 51;
+        if (rbw > sol_bww_pick_rb((D - 2) * H) && rbw > sol_bww_pick_rb(D * H)) { rb_jobs = rbw; for (int kd = 0; kd < 5; ++kd) rbs[kd] = rbw; }
+    }
     for (int b = 0; jobs && b < B; ++b) {
         const float* xs[5]; const float* zs[5]; int np[5];
         for (int kd = 0; kd < 5; ++kd) {
             const int lo = kd < 2 ? 2 - kd : 0, hi = kd > 2 ? D + 2 - kd : D;
             xs[kd] = x + ((size_t)b * D + lo + kd - 2) * pin; zs[kd] = dz + ((size_t)b * D + lo) * pout; np[kd] = hi - lo;
         }
-        if (int e = sol_bww_batched_jobs(stream, 5, xs, zs, parts, np, b == 0 && !accumulate_partial, H, W, x_absmax, dz_absmax)) return e;
+        if (int e = sol_bww_batched_jobs(stream, 5, xs, zs, parts, np, b == 0 && !accumulate_partial, H, W, x_absmax, dz_absmax, rb_jobs)) return e;
     }
     for (int kd = 0; !jobs && kd < 5; ++kd) {
         const int lo = kd < 2 ? 2 - kd : 0, hi = kd > 2 ? D + 2 - kd : D;

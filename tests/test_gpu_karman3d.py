@@ -353,14 +353,16 @@ def test_conv3d_weight_gradient_accumulation_state_is_checked():
 
 @pytest.mark.parametrize("shape", [(1, 6, 8, 64), (2, 5, 16, 64), (1, 128, 64, 64)])
 def test_conv3d_weight_gradient_one_launch_for_the_five_depth_slices_is_bit_identical(shape):
-    """Option k3d_bww_jobs: the five depth slices of a 32 -> 32 Conv3D weight gradient as ONE launch (k_conv5x5_bww_sb_jobs: same blocks, same
-    partial layout, same arithmetic) against five launches -- dW and db bit for bit, single call and accumulated over two calls."""
+    """Option k3d_bww_jobs: the five depth slices of a 32 -> 32 Conv3D weight gradient as ONE launch.  1 (k_conv5x5_bww_sb_jobs with the
+    five-launch form's blocks, partial layout and arithmetic) against 0 (five launches): dW and db bit for bit, single call and accumulated
+    over two calls.  2 (the default: ONE round of workgroups, 51 per slice -- another block partition, so another summation order): equal to
+    the five-launch form to round-off and not further from float64 than it."""
     B, D, H, W = shape
     gen = torch.Generator().manual_seed(77 + D)
     x = torch.randn(B, D, H, W, 32, generator=gen, dtype=torch.float32).to(DEV)
     dz = [(torch.randn(B, D, H, W, 32, generator=gen, dtype=torch.float32) * 1e-2).to(DEV) for _ in range(2)]
     out = {}
-    for jobs in (1, 0):
+    for jobs in (2, 1, 0):
         sol_amd._lib.set_option("k3d_bww_jobs", jobs)
         try:
             one = k3.conv3d_bwd_weight(x, dz[0], 32, 32)
@@ -370,9 +372,19 @@ def test_conv3d_weight_gradient_one_launch_for_the_five_depth_slices_is_bit_iden
             torch.cuda.synchronize()
             out[jobs] = [t.clone() for t in one + two]
         finally:
-            sol_amd._lib.set_option("k3d_bww_jobs", 1)
+            sol_amd._lib.set_option("k3d_bww_jobs", 2)
     for a, b in zip(out[1], out[0]):
         assert torch.equal(a, b), float((a - b).abs().max())
+    for a, b in zip(out[2], out[0]):
+        assert rel(a, b) < 2e-6, rel(a, b)
+    if D <= 6:      # float64 reference of the single call (small case only: the direct sum over taps on the host)
+        import torch.nn.functional as F
+        w = torch.zeros(32, 32, 5, 5, 5, dtype=torch.float64, device=DEV, requires_grad=True)
+        (F.conv3d(x.double().permute(0, 4, 1, 2, 3), w, padding=2) * dz[0].double().permute(0, 4, 1, 2, 3)).sum().backward()
+        ref = w.grad.permute(2, 3, 4, 1, 0)
+        e2, e0 = rel(out[2][0], ref), rel(out[0][0], ref)
+        print("one-round form vs float64 %.2e, five-launch form %.2e" % (e2, e0))
+        assert e2 < 3e-6 and e2 < 1.5 * e0 + 1e-7
 
 
 @pytest.mark.parametrize("cout,res,mode", [(32, True, "lrelu"), (32, True, "dlrelu"), (3, False, "none"), (4, False, "none")])
