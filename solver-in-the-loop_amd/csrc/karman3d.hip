@@ -1105,12 +1105,15 @@ extern "C" int sol_conv3d_pack(void* stream, const float* w_dhwio, int32_t cin, 
     SOL_REQUIRE(w_dhwio && packed, "sol_conv3d_pack: NULL pointer");
     SOL_REQUIRE(mode == SOL_CONV_FWD || mode == SOL_CONV_BWD_DATA, "sol_conv3d_pack: bad mode %d", mode);
     const size_t per = align_up(sol_conv5x5_packed_floats(cin, cout, SOL_CONV_FWD), 64);
+    // backward-data: the flipped kernel -- slice kd of the run convolution is the forward slice 4 - kd, its 2-D taps flipped
+    // and its channel axes swapped by the 2-D packer's SOL_CONV_BWD_DATA mode.  The five slices are ONE launch (k_pack_jobs: the same
+    // sections as sol_conv5x5_pack writes, which took three launches per slice -- 330 launches of a karman-3d training step)
+    const float* ws[5]; float* outs[5]; int32_t ci[5], co[5], md[5];
     for (int kd = 0; kd < 5; ++kd) {
-        // backward-data: the flipped kernel -- slice kd of the run convolution is the forward slice 4 - kd, its 2-D taps flipped
-        // and its channel axes swapped by the 2-D packer's SOL_CONV_BWD_DATA mode
         const int src = mode == SOL_CONV_FWD ? kd : 4 - kd;
-        if (int e = sol_conv5x5_pack(stream, w_dhwio + (size_t)src * 25 * cin * cout, cin, cout, mode, packed + kd * per)) return e;
+        ws[kd] = w_dhwio + (size_t)src * 25 * cin * cout; outs[kd] = packed + kd * per; ci[kd] = cin; co[kd] = cout; md[kd] = mode;
     }
+    if (int e = sol_conv5x5_pack_jobs(stream, 5, ws, ci, co, md, outs)) return e;
     if (conv3d_fusable_shape(cin, cout)) return sol_conv3d_sh_pack((hipStream_t)stream, w_dhwio, mode, cout, packed + 5 * per);
     return SOL_OK;
 }
