@@ -74,6 +74,9 @@ int sol_abi_sizes(int32_t* karman_cfg, int32_t* burgers_cfg, int32_t* train_cfg)
  *                       (departure points beyond the halo: recomputed from the step's input, 1e-6)
  *   conv_thin_t3 (1)    thin-input layers (3 -> 32 first layer, 2 -> 32 last backward-data layer incl. the seed form) of 64-pixel rows as three rows
  *                       of the batch x height stack per twelve-wave workgroup; 0: one row per 256-thread workgroup.  Same results bit for bit
+ *   k3d_conv_persist (0) karman-3d: 1 = the one-launch Conv3D kernel as 256 workgroups of consecutive eight-row tiles (the next tile's rows and weight
+ *                       sets requested during the last tap rows of the tile) when the tile count is a multiple of 256; same results bit for bit,
+ *                       measured slower (register spills), kept as a tested experiment
  *   k3d_bww_jobs (2)    karman-3d: the five depth slices of a 32 -> 32 Conv3D weight gradient (sol_conv3d_bwd_weight*) as ONE launch of ONE round of
  *                       workgroups (51 per slice; other block partition: sums equal to round-off); 1: one launch of five rounds of 32-row
  *                       workgroups (bit-identical to 0); 0: five launches

@@ -566,8 +566,13 @@ constexpr size_t c6_lds() { return (size_t)8 * 68 * 160 + 3 * (size_t)5 * 2 * 32
 template <int DBG> __device__ __forceinline__ void c8_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DBG) : "memory"); }
 // NT = output-channel tiles of 16: 2 for the 32 -> 32 layers, 1 for the thin 32 -> (<= 16) layers (32 -> 3 forward, 32 -> 4 data
 // gradient of the first layer): half the MFMAs and weight bytes on the same staging skeleton, outputs stored channel by channel.
-template <int NT, int DBG>
-__global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D) {
+// PERS (round 6, option k3d_conv_persist): a workgroup runs `tpw` CONSECUTIVE tiles (256 workgroups x 4 tiles at 128 x 64 x 64 instead of four
+// rounds of 256): the tile boundary is treated like a depth-slice boundary -- the next tile's first nine rows and weight sets 0, 1 are requested
+// during the last two tap rows of the tile -- with the epilogue in between, so that only the first tile of a workgroup pays the cold round trip
+// in front of its first MFMA.  Same products in the same order per output: bit-identical to the one-tile form.  MEASURED SLOWER (default off):
+// SOL-16 174.8 vs 163.8 ms -- the runtime tile loop around the unrolled tap rows spills 68 VGPRs (8 in the one-tile form).
+template <int NT, int DBG, bool PERS = false>
+__global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D, int tpw) {
     constexpr int OP = NT * 16, HWP = 68;
     constexpr int PLANE = HWP * 64, SLOT = 2 * PLANE, WPL = OP * 64, WSET = 5 * 2 * WPL;
     constexpr int NSLOT = 11, ROWS = 8, NWB = 3;
@@ -580,22 +585,27 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
     const int H = a.H;
     constexpr int W = 64;
     const int bx = xcd_tile(blockIdx.x, gridDim.x);
-    const int G0 = bx * ROWS;
-    const int gy = G0 + r;
-    const bool tvalid = gy < nrows;
-    const int plane = (tvalid ? gy : 0) / H, dpl = plane % D;
-    const int row_lo = plane * H, row_hi = row_lo + H;
+    const int ntile = PERS ? tpw : 1;
+    int G0 = bx * ntile * ROWS;                       // (per tile: G0 .. row_hi change at a tile boundary)
+    int gy = G0 + r;
+    bool tvalid = gy < nrows;
+    int plane = (tvalid ? gy : 0) / H, dpl = plane % D;
+    int row_lo = plane * H, row_hi = row_lo + H;
     unsigned char* Wt = smem_c8;                      // weight buffers first: LDS-DMA destinations (M0) below 64 KB
     unsigned char* ring = smem_c8 + NWB * WSET;
     const float4* gx = reinterpret_cast<const float4*>(a.x);
     const unsigned char* gw = reinterpret_cast<const unsigned char*>(a.wsh) + 16;
     float sa = 1.f, out_scale = 1.f;
 
-    // halo pixels hc = 0, 1, 66, 67 (x = -2, -1, 64, 65) of every slot and plane are zero for the whole launch
-    if (tid < NSLOT * 2 * 4 * 4) {
-        const int c = tid & 3, px = (tid >> 2) & 3, pl = (tid >> 4) & 1, sl = tid >> 5;
-        *reinterpret_cast<uint4*>(ring + sl * SLOT + pl * PLANE + (px < 2 ? px : 64 + px) * 64 + c * 16) = make_uint4(0u, 0u, 0u, 0u);
-    }
+    // halo pixels hc = 0, 1, 66, 67 (x = -2, -1, 64, 65) of every slot and plane are zero for the whole launch (PERS: written again behind
+    // every epilogue, whose transposition buffers lie over the ring)
+    auto zero_halo = [&]() {
+        if (tid < NSLOT * 2 * 4 * 4) {
+            const int c = tid & 3, px = (tid >> 2) & 3, pl = (tid >> 4) & 1, sl = tid >> 5;
+            *reinterpret_cast<uint4*>(ring + sl * SLOT + pl * PLANE + (px < 2 ? px : 64 + px) * 64 + c * 16) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    zero_halo();
     // a row = 64 pixels x 8 float4 = one item per thread: pixel x = tid >> 3 (LDS column hc = x + 2), channels 4 (tid & 7) ..
     const int st_off = ((tid >> 3) + 2) * 64 + (((((tid & 7) >> 1) ^ swzb((tid >> 3) + 2)) << 4) | ((tid & 1) << 3));
     auto row_in = [&](int gr) { return gr >= 0 && gr < nrows; };
@@ -683,19 +693,22 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
     // Before tap 4 the A fragments of tap (dy + 1, 0) are read: every row of the next tap row was published a barrier ago
     // (rows are staged TWO tap rows ahead), so after the barrier only the four B reads stand before the first MFMA.
     auto tap_row = [&](const int kd, const int dy, const bool last, const int wb, const int wb2) __attribute__((always_inline)) {
-        const int sh = (kd - 2) * H, shn = (kd - 1) * H;
-        const bool more_w = !last || dy < 3;          // set t + 2 exists (t + 2 <= 124)
+        const int sh = (kd - 2) * H;
+        // rr = 2 of the NEXT slice: of this tile's slice kd + 1, or (PERS, kd == 4, not the last tile) of the next tile's slice 0
+        const int nb = kd == 4 ? G0 + ROWS - 2 * H : G0 + (kd - 1) * H;
+        const bool more_w = !last || dy < 3;          // set t + 2 exists (t + 2 <= 24; PERS: sets 0, 1 of the next tile)
+        const int t2 = kd * 5 + dy + 2 >= 25 ? kd * 5 + dy + 2 - 25 : kd * 5 + dy + 2;      // (25 tap-row sets of five taps)
         auto block = [&]() __attribute__((always_inline)) {
             if (dy == 0) { store_row(9, G0 + 7 + sh, hvA); hvB = load_row(G0 + 8 + sh); }
             if (dy == 1) { store_row(10, G0 + 8 + sh, hvB); hvA = load_row(G0 + 9 + sh); }
             if (dy == 2) { store_row(0, G0 + 9 + sh, hvA); }                      // rr = 11 in slot 0 (row 0: dead since tap row 0)
             if (dy == 3 && !last) {
 #pragma unroll
-                for (int n = 0; n <= ROWS; ++n) hvP[n] = load_row(G0 - 2 + n + shn);
+                for (int n = 0; n <= ROWS; ++n) hvP[n] = load_row(nb - 2 + n);
             }
-            if (dy == 4 && !last) hvA = load_row(G0 + 7 + shn);
+            if (dy == 4 && !last) hvA = load_row(nb + 7);
             __builtin_amdgcn_sched_barrier(0);
-            if (more_w) dma_w(kd * 5 + dy + 2, wb2);
+            if (more_w) dma_w(t2, wb2);
             __builtin_amdgcn_sched_barrier(0);
         };
         const int src = gy + sh + dy - 2;
@@ -765,8 +778,11 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
     };
 
     int wb0 = 0;                                      // buffer of weight set 5 kd
+    float vmax = 0.f;
+    for (int ti = 0; ti < ntile; ++ti) {
+    const bool last_tile = ti == ntile - 1;
     for (int kd = 0; kd < 5; ++kd) {
-        const bool last = kd == 4;
+        const bool last = kd == 4 && last_tile;
         const int w1 = wb0 == 2 ? 0 : wb0 + 1, w2 = w1 == 2 ? 0 : w1 + 1;     // (wb0 + 1) % 3, (wb0 + 2) % 3
         tap_row(kd, 0, last, wb0, w2);
         tap_row(kd, 1, last, w1, wb0);
@@ -774,7 +790,7 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
         tap_row(kd, 3, last, wb0, w2);
         tap_row(kd, 4, last, w1, wb0);
         wb0 = w2;                                     // (wb0 + 5) % 3
-        if (!last) {
+        if (kd < 4) {
             // slice boundary: every wave is past the barrier of tap row 4, slots 0..8 are free; the rows were requested two tap rows ago
             const int shn = (kd - 1) * H;
 #pragma unroll
@@ -793,7 +809,6 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
             for (int q = 0; q < 4; ++q)
                 tb[(16 * m + 4 * g + q) * OP + n * 16 + li] = (acc[m][n][q] + acl[m][n][q] * (1.f / 2048.f)) * out_scale + bias;
         }
-    float vmax = 0.f;
     if (tvalid && a.CO == OP) {                       // full channel tiles: 16-byte stores
 #pragma unroll
         for (int n = 0; n < OP / 4; ++n) {            // 64 * OP / 4 float4 per wave
@@ -825,6 +840,25 @@ __global__ void __launch_bounds__(512) k_conv3d_sb8(ConvArgs a, int nrows, int D
             a.y[o] = v;
         }
     }
+    if (PERS && !last_tile) {
+        // tile boundary: the transposition buffers are read (barrier), the halo columns they covered are zeroed again, the next tile's rows
+        // rr = 0..8 of slice 0 (requested during tap row 3 of the last slice) go to slots 0..8
+        C3_BARRIER();
+        zero_halo();
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) { acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; acl[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        G0 += ROWS;
+        gy = G0 + r;
+        tvalid = gy < nrows;
+        plane = (tvalid ? gy : 0) / H; dpl = plane % D;
+        row_lo = plane * H; row_hi = row_lo + H;
+#pragma unroll
+        for (int n = 0; n <= ROWS; ++n) store_row(n, G0 - 2 + n - 2 * H, hvP[n]);
+        C3_BARRIER();
+    }
+    }   // tiles
     if (a.ymax) amax_publish_last(vmax, a.ymax, reinterpret_cast<unsigned*>(smem_c8 + AMAX_LDS));
 }
 
@@ -902,22 +936,24 @@ int sol_conv3d_sb_launch(hipStream_t s, const float* x, const float* wsh, const 
     a.wsh = wsh; a.xmax = x_absmax; a.ymax = y_absmax; a.tiles_x = 1;
     const int nrows = B * D * H;
     if (cout <= 16) {                                 // thin layers: the eight-row kernel with one output-channel tile
-        if (int e = sol_lds_optin(optin8, {SOL_K(k_conv3d_sb8<1, 0>), SOL_K(k_conv3d_sb8<2, 0>), SOL_K(k_conv3d_sb8<2, 1>), SOL_K(k_conv3d_sb8<2, 8>),
+        if (int e = sol_lds_optin(optin8, {SOL_K(k_conv3d_sb8<1, 0>), SOL_K(k_conv3d_sb8<2, 0>), SOL_K((k_conv3d_sb8<1, 0, true>)), SOL_K((k_conv3d_sb8<2, 0, true>)), SOL_K(k_conv3d_sb8<2, 1>), SOL_K(k_conv3d_sb8<2, 8>),
                                            SOL_K(k_conv3d_sb8<2, 32>), SOL_K(k_conv3d_sb8<2, 64>), SOL_K(k_conv3d_sb8<2, 104>)}, "k_conv3d_sb8")) return e;
         const int nt8 = (nrows + 7) / 8, grid8 = (nt8 + 7) / 8 * 8;
-        SOL_LAUNCH((k_conv3d_sb8<1, 0>), dim3(grid8), dim3(512), c8_lds(1), s, a, nrows, D);
+        if (sol_opt().k3d_conv_persist && nt8 % 256 == 0 && nt8 >= 512) SOL_LAUNCH((k_conv3d_sb8<1, 0, true>), dim3(256), dim3(512), c8_lds(1), s, a, nrows, D, nt8 / 256);
+        else SOL_LAUNCH((k_conv3d_sb8<1, 0>), dim3(grid8), dim3(512), c8_lds(1), s, a, nrows, D, 1);
         SOL_LAUNCH_CHECK();
         return SOL_OK;
     }
     if (sol_opt().k3d_conv_rows == 8) {               // eight rows per workgroup, 64 x 32 tile per wave, two waves per SIMD
-        if (int e = sol_lds_optin(optin8, {SOL_K(k_conv3d_sb8<1, 0>), SOL_K(k_conv3d_sb8<2, 0>), SOL_K(k_conv3d_sb8<2, 1>), SOL_K(k_conv3d_sb8<2, 8>),
+        if (int e = sol_lds_optin(optin8, {SOL_K(k_conv3d_sb8<1, 0>), SOL_K(k_conv3d_sb8<2, 0>), SOL_K((k_conv3d_sb8<1, 0, true>)), SOL_K((k_conv3d_sb8<2, 0, true>)), SOL_K(k_conv3d_sb8<2, 1>), SOL_K(k_conv3d_sb8<2, 8>),
                                            SOL_K(k_conv3d_sb8<2, 32>), SOL_K(k_conv3d_sb8<2, 64>), SOL_K(k_conv3d_sb8<2, 104>)}, "k_conv3d_sb8")) return e;
         const int nt8 = (nrows + 7) / 8, grid8 = (nt8 + 7) / 8 * 8;
 #define C8_DBG(N) case N: { \
-            SOL_LAUNCH((k_conv3d_sb8<2, N>), dim3(grid8), dim3(512), c8_lds(2), s, a, nrows, D); break; }
+            SOL_LAUNCH((k_conv3d_sb8<2, N>), dim3(grid8), dim3(512), c8_lds(2), s, a, nrows, D, 1); break; }
         switch (sol_opt().dbg_skip) { C8_DBG(1) C8_DBG(8) C8_DBG(32) C8_DBG(64) C8_DBG(104) default: break; }
         if (sol_opt().dbg_skip) { SOL_LAUNCH_CHECK(); return SOL_OK; }
-        SOL_LAUNCH((k_conv3d_sb8<2, 0>), dim3(grid8), dim3(512), c8_lds(2), s, a, nrows, D);
+        if (sol_opt().k3d_conv_persist && nt8 % 256 == 0 && nt8 >= 512) SOL_LAUNCH((k_conv3d_sb8<2, 0, true>), dim3(256), dim3(512), c8_lds(2), s, a, nrows, D, nt8 / 256);
+        else SOL_LAUNCH((k_conv3d_sb8<2, 0>), dim3(grid8), dim3(512), c8_lds(2), s, a, nrows, D, 1);
         SOL_LAUNCH_CHECK();
         return SOL_OK;
     }

@@ -417,6 +417,14 @@ def test_conv3d_full_size_one_launch_against_five_pass_and_shift_property(cout, 
         sol_amd._lib.set_option("k3d_conv_fused", 1)
     torch.cuda.synchronize()
     assert torch.isfinite(y).all() and rel(y, y5) < 1e-6, rel(y, y5)
+    # option k3d_conv_persist (256 workgroups of four consecutive tiles; default off, measured slower): bit-identical to one tile per workgroup
+    sol_amd._lib.set_option("k3d_conv_persist", 1)
+    try:
+        yp = run(x, r, act)
+        torch.cuda.synchronize()
+    finally:
+        sol_amd._lib.set_option("k3d_conv_persist", 0)
+    assert torch.equal(yp, y)
     roll = lambda t: None if t is None else torch.roll(t, 1, dims=1).contiguous()
     ys = run(roll(x), roll(r), roll(act))
     torch.cuda.synchronize()
