@@ -442,6 +442,37 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
     __syncthreads();                                     // (also retires the requests of rows beyond r1)
 
     // ---- fold the two pixel halves through LDS and add into this block's partial slice --------
+    // All 512 threads move 16-byte pieces (4 consecutive co of one ci) into the block's partial slice.  Accumulating launches first
+    // request ALL of the thread's thirteen old pieces (the slice was written an unrolled step ago: HBM-cold), then add and store --
+    // as a load-add-store loop the compiler kept one or two requests in flight.  BWW_OLD_EARLY: the requests go out BEFORE the fold
+    // (they depend on nothing it does), and the fold's two barriers are LDS-only, so the cold round trip lies under the fold's
+    // LDS traffic instead of behind it.
+    float* pw = a.partial + (size_t)blk * (25 * 1024);
+    constexpr int NP = (4 * 25 * 64 + 511) / 512;       // 13 (the last one for threads < 256)
+    auto dst_of = [&](int e) {
+        const int c4 = e & 3, row = (e >> 2) & 15, tp = (e >> 6) % 25, wt = e / (25 * 64);      // wt = (mt, nt) tile
+        return reinterpret_cast<float4*>(&pw[(tp * 32 + 16 * (wt & 1) + row) * 32 + 16 * (wt >> 1) + c4 * 4]);
+    };
+    float4 old[NP];
+    auto request_old = [&]() __attribute__((always_inline)) {
+        if (!a.overwrite) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) old[k] = *dst_of(min(tid + k * 512, 4 * 25 * 64 - 1));
+        } else {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) old[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#ifndef BWW_OLD_EARLY
+#define BWW_OLD_EARLY 0
+#endif
+#if BWW_OLD_EARLY
+#define BW_FOLD_BARRIER() BW_BARRIER()
+    request_old();
+#else
+#define BW_FOLD_BARRIER() __syncthreads()
+#endif
     float* red = reinterpret_cast<float*>(smem_sb);      // [4 waves][25 taps][256]
     if (kb == 1) {
 #pragma unroll
@@ -449,7 +480,7 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[((wave & 3) * 25 + tp) * 256 + (4 * g + r) * 16 + li] = acc[tp][r];
     }
-    __syncthreads();
+    BW_FOLD_BARRIER();
     if (kb == 0) {      // second pixel half added in LDS, scaled: red = this block's complete [tile][tap][16 ci][16 co] sums
 #pragma unroll
         for (int tp = 0; tp < 25; ++tp)
@@ -459,28 +490,15 @@ __device__ __forceinline__ void bww_sb_body(const BwArgs& a, const int blk, unsi
                 *q = (acc[tp][r] + *q) * out_scale;
             }
     }
-    __syncthreads();
-    {   // all 512 threads move 16-byte pieces (4 consecutive co of one ci) into the block's partial slice.  Accumulating launches first
-        // request ALL of the thread's thirteen old pieces (the slice was written an unrolled step ago: HBM-cold), then add and store --
-        // as a load-add-store loop the compiler kept one or two requests in flight (the accumulator registers are free by now)
-        float* pw = a.partial + (size_t)blk * (25 * 1024);
-        constexpr int NP = (4 * 25 * 64 + 511) / 512;       // 13 (the last one for threads < 256)
-        auto dst_of = [&](int e) {
-            const int c4 = e & 3, row = (e >> 2) & 15, tp = (e >> 6) % 25, wt = e / (25 * 64);      // wt = (mt, nt) tile
-            return reinterpret_cast<float4*>(&pw[(tp * 32 + 16 * (wt & 1) + row) * 32 + 16 * (wt >> 1) + c4 * 4]);
-        };
+    BW_FOLD_BARRIER();
+    {
         // (round 6, measured: the read-modify-write as no-return global_atomic_add_f32 -- the L2 does it, one add per address and launch, still bit
         //  reproducible -- 12.97 vs 11.12 ms per step: 100 KB of dword atomics per workgroup take ~58 us longer than load - add - store)
         // (round 6, measured: pulling the old slice into the L2 with one dword per line and thread under the MFMAs of the last six rows made the
         //  step SLOWER, 11.76 vs 11.67 ms over three alternations: the requests compete with the row loads the MFMAs are waiting for)
-        float4 old[NP];
-        if (!a.overwrite) {
-#pragma unroll
-            for (int k = 0; k < NP; ++k) old[k] = *dst_of(min(tid + k * 512, 4 * 25 * 64 - 1));
-        } else {
-#pragma unroll
-            for (int k = 0; k < NP; ++k) old[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+#if !BWW_OLD_EARLY
+        request_old();
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
