@@ -175,3 +175,28 @@ def test_round5_entry_points_reject_bad_arguments_and_options_have_their_default
     for name in ("conv_precision", "conv_dx", "conv_thin_valu", "cnn_persistent", "k3d_conv_rows"):
         assert name in hdr, name
     assert "SOL_ERR_GRAPH (-4)" in hdr
+
+
+def test_round6_karman3d_entry_points_reject_bad_arguments_and_options_have_their_defaults(lib):
+    """The depth-packed thin-layer entry points (sol_conv3d_thin_bwd_weight_acc, sol_conv3d_thin_out_bwd_weight_acc) validate their arguments
+    before any launch (no GPU needed); the karman-3d options added in round 6 have their documented defaults and ranges and are in the header."""
+    one = C.c_void_p(4)
+    rc = lib.sol_conv3d_thin_out_bwd_weight_acc(None, None, None, one, one, one, one, one, 1, 8, 8, 64, 3, 0, 1)
+    assert rc == -1 and b"NULL pointer" in lib.sol_last_error()
+    rc = lib.sol_conv3d_thin_out_bwd_weight_acc(None, one, None, one, one, one, one, one, 1, 8, 8, 32, 3, 0, 1)
+    assert rc == -1 and b"W == 64" in lib.sol_last_error()                  # the depth-packed form runs the 64-pixel-row kernels only
+    rc = lib.sol_conv3d_thin_out_bwd_weight_acc(None, one, None, one, one, one, one, one, 1, 8, 8, 64, 5, 0, 1)
+    assert rc == -1 and b"output channels" in lib.sol_last_error()          # more than four output channels is not a thin layer
+    rc = lib.sol_conv3d_thin_bwd_weight_acc(None, None, one, None, one, one, one, one, 1, 8, 8, 64, 3, 0, 1)
+    assert rc == -1
+    assert lib.sol_conv3d_thin_bwd_weight_ws_floats(1, 8, 8, 64) > 25 * 32 * 32
+    assert _lib.get_option("k3d_bww_jobs") == 2 and _lib.get_option("k3d_conv_persist") == 0
+    with pytest.raises(sol_amd.SolError):
+        _lib.set_option("k3d_bww_jobs", 3)
+    for name, vals in (("k3d_bww_jobs", (0, 1, 2)), ("k3d_conv_persist", (1, 0))):
+        for v in vals:
+            _lib.set_option(name, v)
+            assert _lib.get_option(name) == v
+    hdr = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "sol_hip.h")).read()
+    for name in ("k3d_bww_jobs", "k3d_conv_persist", "sol_conv3d_thin_out_bwd_weight_acc"):
+        assert name in hdr, name
