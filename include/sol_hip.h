@@ -74,6 +74,8 @@ int sol_abi_sizes(int32_t* karman_cfg, int32_t* burgers_cfg, int32_t* train_cfg)
  *                       (departure points beyond the halo: recomputed from the step's input, 1e-6)
  *   conv_thin_t3 (1)    thin-input layers (3 -> 32 first layer, 2 -> 32 last backward-data layer incl. the seed form) of 64-pixel rows as three rows
  *                       of the batch x height stack per twelve-wave workgroup; 0: one row per 256-thread workgroup.  Same results bit for bit
+ *   k3d_adj_tile (1)    karman-3d: the advection adjoint's fixed-point scatter goes through an int64 LDS window per workgroup (4 x 4 columns + halo 2),
+ *                       flushed with one global atomic per non-zero cell; 0: every contribution is a global atomic.  Same results bit for bit
  *   k3d_conv_persist (0) karman-3d: 1 = the one-launch Conv3D kernel as 256 workgroups of consecutive eight-row tiles (the next tile's rows and weight
  *                       sets requested during the last tap rows of the tile) when the tile count is a multiple of 256; same results bit for bit,
  *                       measured slower (register spills), kept as a tested experiment

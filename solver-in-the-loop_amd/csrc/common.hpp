@@ -220,6 +220,7 @@ struct SolOptions {
                           //    instead of a k_seed launch per unrolled step
     int conv_thin_t3;     // 1 (default): the thin-INPUT layers of 64-pixel images (first layer, last backward-data layer incl. seed mode) as three image rows per
                           //    twelve-wave workgroup (k_conv5x5_t3); 0: k_conv5x5<4, NT>, one row per workgroup
+    int k3d_adj_tile;     // 1 (default): the karman-3d advection adjoint scatters into an int64 LDS window per workgroup (k3b_advect_adj_tile); 0: global atomics only
     int k3d_conv_persist; // 1: the one-launch Conv3D kernel runs consecutive tiles per workgroup (256 workgroups) when the tile count is a multiple of 256.
                           //    Default 0: measured SLOWER (SOL-16 174.8 vs 163.8 ms same box, profiles/r06_k3d_conv_persist_ab.txt) -- the tile loop around the
                           //    unrolled tap rows costs 68 spilled VGPRs (8 without) in a kernel that sits at the 256-register limit of two waves per SIMD

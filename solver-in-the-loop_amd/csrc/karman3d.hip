@@ -815,14 +815,38 @@ __global__ void __launch_bounds__(256) k3b_gva(K3BArgs a) {
 }
 
 // adjoint of one advected face value of component C at (j, i, k): gs = g_a there
-template <int C>
-__device__ __forceinline__ void advect_adj_point(const K3BArgs& a, const GR& r, long long* gy, long long* gx, long long* gz, float qs, int j, int i, int k, float gs) {
-    // order-independent accumulation: round to the fixed-point grid FIRST (each contribution on its own), then integer add
-    auto atomicAdd = [qs](long long* p, float v) { ::atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__float2ll_rn(v * qs)); };
+// Where a contribution goes.  GAdd: straight into the int64 accumulators in global memory.  TAdd (k3b_advect_adj_tile): into the workgroup's int64
+// LDS window when the target face lies inside it, else into global memory -- integer adds commute, so both give the same bits.
+// Order-independent accumulation: round to the fixed-point grid FIRST (each contribution on its own), then integer add.
+struct GAdd {
+    long long *gy, *gx, *gz;
+    float qs;
+    int X, Z;
+    __device__ __forceinline__ void operator()(int comp, int jj, int ii, int kk, float v) const {
+        long long* p = comp == 0 ? gy + ((size_t)jj * X + ii) * Z + kk : (comp == 1 ? gx + ((size_t)jj * (X + 1) + ii) * Z + kk : gz + ((size_t)jj * X + ii) * (Z + 1) + kk);
+        ::atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__float2ll_rn(v * qs));
+    }
+};
+constexpr int K3B_TJ = 4, K3B_TH = 2, K3B_TW = K3B_TJ + 2 * K3B_TH;      // tile of 4 x 4 columns, window of 8 x 8 columns (halo 2: CFL < 2)
+struct TAdd {
+    GAdd g;
+    unsigned long long* L;         // [3][K3B_TW][K3B_TW][ZP]
+    int jw0, iw0, ZP;
+    __device__ __forceinline__ void operator()(int comp, int jj, int ii, int kk, float v) const {
+        const int lj = jj - jw0, li = ii - iw0;
+        if ((unsigned)lj < (unsigned)K3B_TW && (unsigned)li < (unsigned)K3B_TW)
+            ::atomicAdd(&L[((comp * K3B_TW + lj) * K3B_TW + li) * ZP + kk], (unsigned long long)__float2ll_rn(v * g.qs));
+        else g(comp, jj, ii, kk, v);
+    }
+};
+
+template <int C, class Add>
+__device__ __forceinline__ void advect_adj_point(const K3BArgs& a, const GR& r, const Add& add, int j, int i, int k, float gs) {
+    // no fused multiply-adds here: which products the compiler contracts depends on the kernel this is inlined into, and the two scatter
+    // kernels (global atomics / LDS window) are held to the SAME BITS by the test suite (the integer accumulation is exact, so the only
+    // freedom is in the fp32 contributions themselves)
+#pragma clang fp contract(off)
     const int Y = a.Y, X = a.X, Z = a.Z;
-    auto iy = [&](int jj, int ii, int kk) { return ((size_t)jj * X + ii) * Z + kk; };
-    auto ix = [&](int jj, int ii, int kk) { return ((size_t)jj * (X + 1) + ii) * Z + kk; };
-    auto iz = [&](int jj, int ii, int kk) { return ((size_t)jj * X + ii) * (Z + 1) + kk; };
     // velocity at the sample point, exactly as the forward pass forms it
     float uy, ux, uz;
     int ja, jb, ia, ib, ka, kb;
@@ -849,8 +873,6 @@ __device__ __forceinline__ void advect_adj_point(const K3BArgs& a, const GR& r, 
     const int j0 = clampi(j + (int)fy, 0, n0 - 1), j1 = clampi(j + (int)fy + 1, 0, n0 - 1);
     const int i0 = clampi(i + (int)fx, 0, n1 - 1), i1 = clampi(i + (int)fx + 1, 0, n1 - 1);
     const int k0 = clampi(k + (int)fz, 0, n2 - 1), k1 = clampi(k + (int)fz + 1, 0, n2 - 1);
-    long long* gT = C == 0 ? gy : (C == 1 ? gx : gz);
-    auto idx = [&](int jj, int ii, int kk) { return C == 0 ? iy(jj, ii, kk) : (C == 1 ? ix(jj, ii, kk) : iz(jj, ii, kk)); };
     auto val = [&](int jj, int ii, int kk) { return C == 0 ? r.y(jj, ii, kk) : (C == 1 ? r.x(jj, ii, kk) : r.z(jj, ii, kk)); };
     float dy = 0.f, dx = 0.f, dz = 0.f;          // d(sample) / d(offset) along each axis
 #pragma unroll
@@ -862,7 +884,7 @@ __device__ __forceinline__ void advect_adj_point(const K3BArgs& a, const GR& r, 
                 const int jj = cj ? j1 : j0, ii = ci ? i1 : i0, kk = ck ? k1 : k0;
                 const float by = cj ? wy : 1.f - wy, bx = ci ? wx : 1.f - wx, bz = ck ? wz : 1.f - wz;
                 const float v = val(jj, ii, kk);
-                atomicAdd(&gT[idx(jj, ii, kk)], by * bx * bz * gs);          // field term
+                add(C, jj, ii, kk, by * bx * bz * gs);          // field term
                 dy += (cj ? 1.f : -1.f) * bx * bz * v;
                 dx += by * (ci ? 1.f : -1.f) * bz * v;
                 dz += by * bx * (ck ? 1.f : -1.f) * v;
@@ -870,20 +892,20 @@ __device__ __forceinline__ void advect_adj_point(const K3BArgs& a, const GR& r, 
     // back-trace term: offset_a = -dtdx * u_a(x0)
     const float guy = -a.dtdx * gs * dy, gux = -a.dtdx * gs * dx, guz = -a.dtdx * gs * dz;
     if (C == 0) {
-        atomicAdd(&gy[iy(j, i, k)], guy);
+        add(0, j, i, k, guy);
         const float qx = 0.25f * gux, qz = 0.25f * guz;
-        atomicAdd(&gx[ix(ja, i, k)], qx); atomicAdd(&gx[ix(ja, i + 1, k)], qx); atomicAdd(&gx[ix(jb, i, k)], qx); atomicAdd(&gx[ix(jb, i + 1, k)], qx);
-        atomicAdd(&gz[iz(ja, i, k)], qz); atomicAdd(&gz[iz(ja, i, k + 1)], qz); atomicAdd(&gz[iz(jb, i, k)], qz); atomicAdd(&gz[iz(jb, i, k + 1)], qz);
+        add(1, ja, i, k, qx); add(1, ja, i + 1, k, qx); add(1, jb, i, k, qx); add(1, jb, i + 1, k, qx);
+        add(2, ja, i, k, qz); add(2, ja, i, k + 1, qz); add(2, jb, i, k, qz); add(2, jb, i, k + 1, qz);
     } else if (C == 1) {
-        atomicAdd(&gx[ix(j, i, k)], gux);
+        add(1, j, i, k, gux);
         const float qy = 0.25f * guy, qz = 0.25f * guz;
-        atomicAdd(&gy[iy(j, ia, k)], qy); atomicAdd(&gy[iy(j, ib, k)], qy); atomicAdd(&gy[iy(j + 1, ia, k)], qy); atomicAdd(&gy[iy(j + 1, ib, k)], qy);
-        atomicAdd(&gz[iz(j, ia, k)], qz); atomicAdd(&gz[iz(j, ia, k + 1)], qz); atomicAdd(&gz[iz(j, ib, k)], qz); atomicAdd(&gz[iz(j, ib, k + 1)], qz);
+        add(0, j, ia, k, qy); add(0, j, ib, k, qy); add(0, j + 1, ia, k, qy); add(0, j + 1, ib, k, qy);
+        add(2, j, ia, k, qz); add(2, j, ia, k + 1, qz); add(2, j, ib, k, qz); add(2, j, ib, k + 1, qz);
     } else {
-        atomicAdd(&gz[iz(j, i, k)], guz);
+        add(2, j, i, k, guz);
         const float qy = 0.25f * guy, qx = 0.25f * gux;
-        atomicAdd(&gy[iy(j, i, ka)], qy); atomicAdd(&gy[iy(j, i, kb)], qy); atomicAdd(&gy[iy(j + 1, i, ka)], qy); atomicAdd(&gy[iy(j + 1, i, kb)], qy);
-        atomicAdd(&gx[ix(j, i, ka)], qx); atomicAdd(&gx[ix(j, i, kb)], qx); atomicAdd(&gx[ix(j, i + 1, ka)], qx); atomicAdd(&gx[ix(j, i + 1, kb)], qx);
+        add(0, j, i, ka, qy); add(0, j, i, kb, qy); add(0, j + 1, i, ka, qy); add(0, j + 1, i, kb, qy);
+        add(1, j, i, ka, qx); add(1, j, i, kb, qx); add(1, j, i + 1, ka, qx); add(1, j, i + 1, kb, qx);
     }
 }
 
@@ -898,6 +920,7 @@ __global__ void __launch_bounds__(256) k3b_advect_adj(K3BArgs a) {
     long long* gz = a.gcz + (size_t)b * nVz;
     float qs, qi;
     k3b_scale(a.gmax + b * K3B_SLOTS, qs, qi);
+    const GAdd add{gy, gx, gz, qs, X, Z};
     const int cY = (Y + 1) * X, cX = Y * (X + 1), cC = Y * X;
     const int lane = threadIdx.x & 63;
     const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
@@ -905,14 +928,63 @@ __global__ void __launch_bounds__(256) k3b_advect_adj(K3BArgs a) {
     for (int c = wave0; c < cY + cX + cC; c += nwaves) {
         if (c < cY) {
             const int j = c / X, i = c % X;
-            for (int k = lane; k < Z; k += 64) { const float g = a.gay[(size_t)b * nVy + ((size_t)j * X + i) * Z + k]; if (g != 0.f) advect_adj_point<0>(a, r, gy, gx, gz, qs, j, i, k, g); }
+            for (int k = lane; k < Z; k += 64) { const float g = a.gay[(size_t)b * nVy + ((size_t)j * X + i) * Z + k]; if (g != 0.f) advect_adj_point<0>(a, r, add, j, i, k, g); }
         } else if (c < cY + cX) {
             const int q = c - cY, j = q / (X + 1), i = q % (X + 1);
-            for (int k = lane; k < Z; k += 64) { const float g = a.gax[(size_t)b * nVx + ((size_t)j * (X + 1) + i) * Z + k]; if (g != 0.f) advect_adj_point<1>(a, r, gy, gx, gz, qs, j, i, k, g); }
+            for (int k = lane; k < Z; k += 64) { const float g = a.gax[(size_t)b * nVx + ((size_t)j * (X + 1) + i) * Z + k]; if (g != 0.f) advect_adj_point<1>(a, r, add, j, i, k, g); }
         } else {
             const int q = c - cY - cX, j = q / X, i = q % X;
-            for (int k = lane; k <= Z; k += 64) { const float g = a.gaz[(size_t)b * nVz + ((size_t)j * X + i) * (Z + 1) + k]; if (g != 0.f) advect_adj_point<2>(a, r, gy, gx, gz, qs, j, i, k, g); }
+            for (int k = lane; k <= Z; k += 64) { const float g = a.gaz[(size_t)b * nVz + ((size_t)j * X + i) * (Z + 1) + k]; if (g != 0.f) advect_adj_point<2>(a, r, add, j, i, k, g); }
         }
+    }
+}
+
+// The same scatter with an LDS window per workgroup (round 6, option k3d_adj_tile): the 17 contributions of a face value -- eight corners of
+// its trilinear gather, nine back-trace terms -- land within two cells of it (CFL < 2), so a workgroup that owns the faces of 4 x 4 columns
+// (all k) accumulates into an 8 x 8-column int64 window in LDS (3 x 8 x 8 x (Z + 1) x 8 B = 99,840 B at Z = 64) and flushes the non-zero
+// cells with ONE global atomic each: 52 K contributions per tile become <= 12.5 K global atomics (the int64 device-scope atomics were the
+// whole cost of the kernel: 26.7 M of them in 250 us at 128 x 64 x 64).  Targets beyond the window go to global memory directly.  Integer
+// adds commute: the result equals k3b_advect_adj's BIT FOR BIT.
+__global__ void __launch_bounds__(256) k3b_advect_adj_tile(K3BArgs a, int nti) {
+    extern __shared__ __align__(16) unsigned long long smem_adj[];
+    const int Y = a.Y, X = a.X, Z = a.Z, ZP = Z + 1;
+    const int nVy = (Y + 1) * X * Z, nVx = Y * (X + 1) * Z, nVz = Y * X * (Z + 1);
+    const int b = blockIdx.y;
+    const int tj = (int)blockIdx.x / nti, ti = (int)blockIdx.x % nti, j0 = tj * K3B_TJ, i0 = ti * K3B_TJ;
+    GR r;
+    r.sy = a.svy + (size_t)b * nVy; r.sx = a.svx + (size_t)b * nVx; r.sz = a.svz + (size_t)b * nVz; r.Y = Y; r.X = X; r.Z = Z;
+    float qs, qi;
+    k3b_scale(a.gmax + b * K3B_SLOTS, qs, qi);
+    const GAdd gadd{a.gcy + (size_t)b * nVy, a.gcx + (size_t)b * nVx, a.gcz + (size_t)b * nVz, qs, X, Z};
+    const TAdd add{gadd, smem_adj, j0 - K3B_TH, i0 - K3B_TH, ZP};
+    const int ncell = 3 * K3B_TW * K3B_TW * ZP;
+    for (int e = threadIdx.x; e < ncell; e += 256) smem_adj[e] = 0ull;
+    __syncthreads();
+    // column tasks: y faces j0 .. j1y-1 (the last tile row also owns face row Y), x faces i0 .. i1x-1 (the last tile column: face column X), cells
+    const int j1 = min(j0 + K3B_TJ, Y), i1 = min(i0 + K3B_TJ, X);
+    const int j1y = j0 + K3B_TJ >= Y ? Y + 1 : j1, i1x = i0 + K3B_TJ >= X ? X + 1 : i1;
+    const int nJ = j1 - j0, nI = i1 - i0, nY = (j1y - j0) * nI, nX = nJ * (i1x - i0), nC = nJ * nI;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (int t = wave; t < nY + nX + nC; t += 4) {
+        if (t < nY) {
+            const int j = j0 + t / nI, i = i0 + t % nI;
+            for (int k = lane; k < Z; k += 64) { const float g = a.gay[(size_t)b * nVy + ((size_t)j * X + i) * Z + k]; if (g != 0.f) advect_adj_point<0>(a, r, add, j, i, k, g); }
+        } else if (t < nY + nX) {
+            const int q = t - nY, w = i1x - i0, j = j0 + q / w, i = i0 + q % w;
+            for (int k = lane; k < Z; k += 64) { const float g = a.gax[(size_t)b * nVx + ((size_t)j * (X + 1) + i) * Z + k]; if (g != 0.f) advect_adj_point<1>(a, r, add, j, i, k, g); }
+        } else {
+            const int q = t - nY - nX, j = j0 + q / nI, i = i0 + q % nI;
+            for (int k = lane; k <= Z; k += 64) { const float g = a.gaz[(size_t)b * nVz + ((size_t)j * X + i) * (Z + 1) + k]; if (g != 0.f) advect_adj_point<2>(a, r, add, j, i, k, g); }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < ncell; e += 256) {
+        const unsigned long long v = smem_adj[e];
+        if (v == 0ull) continue;                                   // (cells outside the arrays never receive a contribution)
+        const int kk = e % ZP, li = (e / ZP) % K3B_TW, lj = (e / (ZP * K3B_TW)) % K3B_TW, comp = e / (ZP * K3B_TW * K3B_TW);
+        const int jj = j0 - K3B_TH + lj, ii = i0 - K3B_TH + li;
+        long long* p = comp == 0 ? gadd.gy + ((size_t)jj * X + ii) * Z + kk : (comp == 1 ? gadd.gx + ((size_t)jj * (X + 1) + ii) * Z + kk : gadd.gz + ((size_t)jj * X + ii) * (Z + 1) + kk);
+        ::atomicAdd(reinterpret_cast<unsigned long long*>(p), v);
     }
 }
 
@@ -1075,6 +1147,12 @@ extern "C" int sol_karman3d_step_bwd(const sol_karman3d_cfg* c, void* stream,
     if (int e = pressure_solve3d(s, c, direct_header_host, R, T1, T2, &res)) return e;
     a.gdiv = res;
     SOL_LAUNCH(k3b_gva, dim3(grid_for(faces), B), dim3(256), 0, s, a);
+    if (sol_opt().k3d_adj_tile && Z <= 64) {
+        static std::atomic<unsigned long long> optin_adj{0};
+        if (int e = sol_lds_optin(optin_adj, {SOL_K(k3b_advect_adj_tile)}, "k3b_advect_adj_tile")) return e;
+        const int ntj = (Y + K3B_TJ - 1) / K3B_TJ, nti = (X + K3B_TJ - 1) / K3B_TJ;
+        SOL_LAUNCH(k3b_advect_adj_tile, dim3(ntj * nti, B), dim3(256), (size_t)3 * K3B_TW * K3B_TW * (Z + 1) * 8, s, a, nti);
+    } else
     SOL_LAUNCH(k3b_advect_adj, dim3(grid_for((size_t)((Y + 1) * X + Y * (X + 1) + Y * X) * 64), B), dim3(256), 0, s, a);
     SOL_LAUNCH(k3b_diffuse_adj, dim3(grid_for(faces), B), dim3(256), 0, s, a);
     SOL_LAUNCH_CHECK();

@@ -35,7 +35,7 @@ SolOptions& sol_opt() {
         SolOptions d{};
         d.conv_precision = 0; d.conv_split3 = 0; d.conv_r3 = 1; d.conv_thin = 1; d.conv_bww32 = 1;
         d.correct_fuse = 1; d.bww_fuse = 1; d.bww_chunk = 0; d.bww_side = 1; d.streams = 1;
-        d.density_mode = 0; d.cpt = 0; d.dbg_skip = 0; d.step_prof = 0; d.cnn_persistent = 0; d.graph_stream = 0; d.k3d_tile = 0; d.k3d_fused_tf = 1; d.k3d_conv_fused = 1; d.k3d_conv_rows = 8; d.conv_dx = 11; d.k3d_mfma_tf = 1; d.conv_thin_valu = 1; d.seed_fuse = 1; d.fwd_bands = 1; d.conv_thin_t3 = 1; d.k3d_bww_jobs = 2; d.k3d_conv_persist = 0;
+        d.density_mode = 0; d.cpt = 0; d.dbg_skip = 0; d.step_prof = 0; d.cnn_persistent = 0; d.graph_stream = 0; d.k3d_tile = 0; d.k3d_fused_tf = 1; d.k3d_conv_fused = 1; d.k3d_conv_rows = 8; d.conv_dx = 11; d.k3d_mfma_tf = 1; d.conv_thin_valu = 1; d.seed_fuse = 1; d.fwd_bands = 1; d.conv_thin_t3 = 1; d.k3d_bww_jobs = 2; d.k3d_conv_persist = 0; d.k3d_adj_tile = 1;
         return d;
     }();
     return o;
@@ -52,7 +52,7 @@ const OptName OPT_NAMES[] = {
     {"step_prof", &SolOptions::step_prof, 0, 1}, {"cnn_persistent", &SolOptions::cnn_persistent, 0, 1},
     {"graph_stream", &SolOptions::graph_stream, 0, 1}, {"k3d_tile", &SolOptions::k3d_tile, 0, 1}, {"k3d_fused_tf", &SolOptions::k3d_fused_tf, 0, 1}, {"k3d_conv_fused", &SolOptions::k3d_conv_fused, 0, 1}, {"k3d_conv_rows", &SolOptions::k3d_conv_rows, 3, 8},
     {"conv_dx", &SolOptions::conv_dx, 0, 15}, {"conv_thin_valu", &SolOptions::conv_thin_valu, 0, 2}, {"k3d_mfma_tf", &SolOptions::k3d_mfma_tf, 0, 1},
-    {"seed_fuse", &SolOptions::seed_fuse, 0, 1}, {"fwd_bands", &SolOptions::fwd_bands, 0, 1}, {"conv_thin_t3", &SolOptions::conv_thin_t3, 0, 1}, {"k3d_bww_jobs", &SolOptions::k3d_bww_jobs, 0, 2}, {"k3d_conv_persist", &SolOptions::k3d_conv_persist, 0, 1},
+    {"seed_fuse", &SolOptions::seed_fuse, 0, 1}, {"fwd_bands", &SolOptions::fwd_bands, 0, 1}, {"conv_thin_t3", &SolOptions::conv_thin_t3, 0, 1}, {"k3d_bww_jobs", &SolOptions::k3d_bww_jobs, 0, 2}, {"k3d_conv_persist", &SolOptions::k3d_conv_persist, 0, 1}, {"k3d_adj_tile", &SolOptions::k3d_adj_tile, 0, 1},
 };
 }  // namespace
 

@@ -278,6 +278,38 @@ def test_karman3d_step_adjoint_identity_by_finite_differences():
     assert min(abs(x - rhs) for x in res.values()) < 2e-3 * abs(rhs) + 2e-4 * scale, (rhs, res, scale)
 
 
+@pytest.mark.parametrize("shape,vscale", [((2, 16, 8, 8), 1.0), ((1, 20, 10, 10), 1.0), ((1, 32, 16, 16), 3.5), ((1, 128, 64, 64), 1.0)])
+def test_karman3d_advection_adjoint_lds_window_equals_global_atomics_bit_for_bit(shape, vscale):
+    """Option k3d_adj_tile: the advection adjoint's fixed-point scatter through an int64 LDS window per workgroup (k3b_advect_adj_tile: 4 x 4
+    columns + halo 2, one global atomic per non-zero cell) against the all-global-atomics kernel -- integer adds commute, so the step's input
+    gradient must be equal BIT FOR BIT: tiles that end inside the grid (20 x 10), the extra face row / column of the last tiles, targets
+    beyond the window (velocities scaled to CFL > 2: those go to global memory directly), two simulations, the BASELINE configs[4] grid."""
+    from sol_amd import synthetic
+    B, Y, X, Z = shape
+    sc = k3.Scene3D(Y, X, Z, device=DEV)
+    sim = k3.Karman3DFlow(sc, B)
+    gen = torch.Generator().manual_seed(41 + Y)
+    rn = lambda *s_: torch.randn(*s_, generator=gen, dtype=torch.float32)
+    st = (torch.rand(B, Y, X, Z, generator=gen).to(DEV), (vscale * (1.0 + 0.3 * rn(B, Y + 1, X, Z))).to(DEV), (vscale * 0.5 * rn(B, Y, X + 1, Z)).to(DEV),
+          (vscale * 0.5 * rn(B, Y, X, Z + 1)).to(DEV))
+    re = synthetic.reynolds(B).float().to(DEV)
+    w = [rn(*t.shape).to(DEV) for t in st[1:]]
+    grads = {}
+    for tile in (1, 0):
+        sol_amd._lib.set_option("k3d_adj_tile", tile)
+        try:
+            a = [t.clone().requires_grad_(True) for t in st[1:]]
+            out = sim.step(st[0], a[0], a[1], a[2], re)
+            sum((o_ * w_).sum() for o_, w_ in zip(out[1:], w)).backward()
+            torch.cuda.synchronize()
+            grads[tile] = [t.grad.clone() for t in a]
+        finally:
+            sol_amd._lib.set_option("k3d_adj_tile", 1)
+    for x, y in zip(grads[1], grads[0]):
+        assert torch.isfinite(x).all() and float(x.abs().max()) > 0
+        assert torch.equal(x, y), float((x - y).abs().max())
+
+
 @pytest.mark.timeout(1500)
 def test_karman3d_full_size_step_adjoint_against_oracle():
     """BASELINE configs[4] grid: the ADJOINT of one step at 128 x 64 x 64 (diffusion^T, the scatter form of the advection's
