@@ -781,20 +781,35 @@ __global__ void __launch_bounds__(256) k3b_gva(K3BArgs a) {
     auto cell = [&](int j, int i, int k) { return ((unsigned)j < (unsigned)Y && (unsigned)i < (unsigned)X && (unsigned)k < (unsigned)Z) ? P[((size_t)j * X + i) * Z + k] : 0.f; };
     float vmax = 0.f;
     bool bad = false;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nVy + nVx + nVz; e += gridDim.x * blockDim.x) {
-        float v;
-        if (e < nVy) {
-            const int k = e % Z, i = (e / Z) % X, j = e / (Z * X);
-            a.gay[(size_t)b * nVy + e] = v = face_mask<0>(a.active, Y, X, Z, j, i, k) * (a.goy[(size_t)b * nVy + e] + cell(j - 1, i, k) - cell(j, i, k));
-        } else if (e < nVy + nVx) {
-            const int q = e - nVy, k = q % Z, i = (q / Z) % (X + 1), j = q / (Z * (X + 1));
-            a.gax[(size_t)b * nVx + q] = v = face_mask<1>(a.active, Y, X, Z, j, i, k) * (a.gox[(size_t)b * nVx + q] + cell(j, i - 1, k) - cell(j, i, k));
+    // one wave per z column (round 6; it was one thread per face with three runtime divisions each and 6 200 workgroups queueing on the 64
+    // absmax slots: 72 us for 6 MB): (component, j, i) are wave uniform, lanes run along the contiguous k
+    const int cY = (Y + 1) * X, cX = Y * (X + 1), cC = Y * X;
+    const int lane = threadIdx.x & 63;
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    for (int c = wave0; c < cY + cX + cC; c += nwaves) {
+        if (c < cY) {
+            const int j = c / X, i = c % X;
+            for (int k = lane; k < Z; k += 64) {
+                const size_t e = (size_t)b * nVy + ((size_t)j * X + i) * Z + k;
+                const float v = face_mask<0>(a.active, Y, X, Z, j, i, k) * (a.goy[e] + cell(j - 1, i, k) - cell(j, i, k));
+                a.gay[e] = v; vmax = fmaxf(vmax, fabsf(v)); bad |= !(fabsf(v) <= 3.402823466e38f);      // inf or nan (fmaxf drops a NaN)
+            }
+        } else if (c < cY + cX) {
+            const int q = c - cY, j = q / (X + 1), i = q % (X + 1);
+            for (int k = lane; k < Z; k += 64) {
+                const size_t e = (size_t)b * nVx + ((size_t)j * (X + 1) + i) * Z + k;
+                const float v = face_mask<1>(a.active, Y, X, Z, j, i, k) * (a.gox[e] + cell(j, i - 1, k) - cell(j, i, k));
+                a.gax[e] = v; vmax = fmaxf(vmax, fabsf(v)); bad |= !(fabsf(v) <= 3.402823466e38f);
+            }
         } else {
-            const int q = e - nVy - nVx, k = q % (Z + 1), i = (q / (Z + 1)) % X, j = q / ((Z + 1) * X);
-            a.gaz[(size_t)b * nVz + q] = v = face_mask<2>(a.active, Y, X, Z, j, i, k) * (a.goz[(size_t)b * nVz + q] + cell(j, i, k - 1) - cell(j, i, k));
+            const int q = c - cY - cX, j = q / X, i = q % X;
+            for (int k = lane; k <= Z; k += 64) {
+                const size_t e = (size_t)b * nVz + ((size_t)j * X + i) * (Z + 1) + k;
+                const float v = face_mask<2>(a.active, Y, X, Z, j, i, k) * (a.goz[e] + cell(j, i, k - 1) - cell(j, i, k));
+                a.gaz[e] = v; vmax = fmaxf(vmax, fabsf(v)); bad |= !(fabsf(v) <= 3.402823466e38f);
+            }
         }
-        vmax = fmaxf(vmax, fabsf(v));
-        bad |= !(fabsf(v) <= 3.402823466e38f);                   // inf or nan (fmaxf drops a NaN)
     }
     // max|g_a| of this simulation -> the scale of the fixed-point scatter (one atomic per workgroup).  A non-finite g_a publishes
     // the bits of a NaN -- the largest value the integer maximum can see -- and k3b_scale turns that into "scatter nothing, convert
@@ -1146,7 +1161,11 @@ extern "C" int sol_karman3d_step_bwd(const sol_karman3d_cfg* c, void* stream,
     float* res = nullptr;
     if (int e = pressure_solve3d(s, c, direct_header_host, R, T1, T2, &res)) return e;
     a.gdiv = res;
-    SOL_LAUNCH(k3b_gva, dim3(grid_for(faces), B), dim3(256), 0, s, a);
+    {   // wave per column, a few columns per wave: 1 024 workgroups at most publish into the 64 absmax slots
+        const size_t cols = (size_t)(Y + 1) * X + (size_t)Y * (X + 1) + (size_t)Y * X;
+        const unsigned g_gva = (unsigned)std::min<size_t>(1024, (cols + 3) / 4);
+        SOL_LAUNCH(k3b_gva, dim3(g_gva, B), dim3(256), 0, s, a);
+    }
     if (sol_opt().k3d_adj_tile && Z <= 64) {
         static std::atomic<unsigned long long> optin_adj{0};
         if (int e = sol_lds_optin(optin_adj, {SOL_K(k3b_advect_adj_tile)}, "k3b_advect_adj_tile")) return e;
