@@ -496,6 +496,15 @@ int sol_conv3d_thin_pack(void* stream, const float* w_dhwio, int32_t cin, int32_
 int sol_conv3d_thin(void* stream, const float* x, const float* packed, const float* bias, const float* act_ref, float* y, float* ws,
                     int32_t B, int32_t D, int32_t H, int32_t W, int32_t epilogue, float slope, uint32_t* y_absmax);
 
+/* Thin-OUTPUT Conv3D layers (32 -> cout <= 4 channels: the network's output layer, karman_train.py:137 generalised, and the first layer's data
+ * gradient) with the depth taps packed into the OUTPUT channel axis: ONE 2-D 32 -> 32 convolution y'[q][..][4 s + c] over the (H, W) planes into
+ * ws, then y[d][..][c] = bias[c] + sum_s y'[d + s - 2][..][4 s + c].  x [B,D,H,W,32] with its absmax slots (or NULL: computed here), y [B,D,H,W,cout];
+ * packed: sol_conv3d_thin_packed_floats() floats from sol_conv3d_thin_out_pack (w_dhwio = the FORWARD kernel: [5,5,5,32,cout] for SOL_CONV_FWD,
+ * [5,5,5,cout,32] for SOL_CONV_BWD_DATA; cout = the channels the convolution that is RUN writes); ws: sol_conv3d_thin_ws_floats(); no activation. */
+int sol_conv3d_thin_out_pack(void* stream, const float* w_dhwio, int32_t cout, int32_t mode, float* packed);
+int sol_conv3d_thin_out(void* stream, const float* x, const float* packed, const float* bias, float* y, float* ws,
+                        int32_t B, int32_t D, int32_t H, int32_t W, int32_t cout, const uint32_t* x_absmax);
+
 /* Weight gradient of a thin-input layer in the same packing: ONE pass of the 2-D 32 -> 32 fp16 three-product weight-gradient kernel over
  * the gathered tensor instead of five passes of the thin fp32 kernel.  x [B,D,H,W,4], dz [B,D,H,W,32], W == 64; dz_absmax: the slots the
  * producer of dz published, or NULL (computed here); ws: sol_conv3d_thin_ws_floats(); partial: sol_conv3d_thin_bwd_weight_ws_floats();

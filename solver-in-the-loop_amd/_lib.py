@@ -115,6 +115,8 @@ _SIGS = {
     "sol_conv3d_thin_ws_floats": (C.c_size_t, [C.c_int32] * 4),
     "sol_conv3d_thin_pack": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "sol_conv3d_thin": (C.c_int, [_P] * 7 + [C.c_int32] * 5 + [C.c_float, _P]),
+    "sol_conv3d_thin_out_pack": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    "sol_conv3d_thin_out": (C.c_int, [_P] * 6 + [C.c_int32] * 5 + [_P]),
     "sol_conv3d_thin_bwd_weight_ws_floats": (C.c_size_t, [C.c_int32] * 4),
     "sol_conv3d_thin_bwd_weight_acc": (C.c_int, [_P] * 8 + [C.c_int32] * 7),
     "sol_conv3d_thin_out_bwd_weight_acc": (C.c_int, [_P] * 8 + [C.c_int32] * 7),

@@ -1315,6 +1315,79 @@ extern "C" int sol_conv3d_thin(void* stream, const float* x, const float* packed
     return sol_conv5x5_scaled(stream, ws, packed, bias, nullptr, act_ref, y, B * D, H, W, 32, 32, epilogue, slope, slots, y_absmax);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Thin-OUTPUT layers (32 -> cr <= 4 channels: the network's output layer, and the first layer's data gradient) with the depth taps packed into
+// the OUTPUT channel axis: y'[q][..][4 s + c] = sum_(dy, dx, ci) x[q][.. + (dy, dx)][ci] w_run[s][dy][dx][ci][c] is ONE 2-D 32 -> 32 convolution
+// over the (H, W) planes (20 of its 32 output channels in use), and y[d][..][c] = bias[c] + sum_s y'[d + s - 2][..][4 s + c] a gather over five
+// planes.  Replaces k_conv3d_sb8<1, 0> for these layers (180 us at 128 x 64 x 64: the eight-row kernel's staging skeleton for half a
+// channel tile of which 3 / 4 of 16 columns are real).
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+//   mode SOL_CONV_FWD:      w [5][5][5][32][cr]:  w'[dy][dx][ci][4 s + c] = w[s][dy][dx][ci][c]
+//   mode SOL_CONV_BWD_DATA: w [5][5][5][cr][32] (the FORWARD kernel of a cr -> 32 layer); the run convolution reads the 32 channels of dz and
+//                           writes cr: the flipped kernel with its channel axes swapped, w'[dy][dx][ci][4 s + c] = w[4 - s][4 - dy][4 - dx][c][ci]
+__global__ void __launch_bounds__(256) k3_kpack_weights_out(const float* __restrict__ w, float* __restrict__ w2, int cr, int mode) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= 25 * 32 * 32) return;
+    const int k = e & 31, ci = (e >> 5) & 31, tap = e >> 10, dy = tap / 5, dx = tap % 5, s = k >> 2, c = k & 3;
+    float v = 0.f;
+    if (s < 5 && c < cr)
+        v = mode == SOL_CONV_FWD ? w[((((size_t)s * 5 + dy) * 5 + dx) * 32 + ci) * cr + c]
+                                 : w[((((size_t)(4 - s) * 5 + (4 - dy)) * 5 + (4 - dx)) * cr + c) * 32 + ci];
+    w2[e] = v;
+}
+// y [planes][HW][cout] from y' [planes][HW][32]: one thread per output pixel (float4 per depth offset; the five planes of a pixel are 512 KB
+// apart at 64 x 64 -- L2 / MALL resident, the tensor was just written)
+__global__ void __launch_bounds__(256) k3_gather_depth(const float4* __restrict__ y2, const float* __restrict__ bias, float* __restrict__ y, int D, int HW, int cout, size_t npx) {
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < npx; q += (size_t)gridDim.x * 256) {
+        const size_t plane = q / HW;
+        const int d = (int)(plane % D);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const int ds = d + s - 2;
+            if (ds < 0 || ds >= D) continue;
+            const float4 v = y2[((size_t)((long)q + (long)(s - 2) * HW)) * 8 + s];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        const float r[4] = {acc.x, acc.y, acc.z, acc.w};
+        if (cout == 4) {
+            float4 o = acc;
+            if (bias) { o.x += bias[0]; o.y += bias[1]; o.z += bias[2]; o.w += bias[3]; }
+            reinterpret_cast<float4*>(y)[q] = o;
+        } else {
+            for (int c = 0; c < cout; ++c) y[q * cout + c] = r[c] + (bias ? bias[c] : 0.f);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int sol_conv3d_thin_out_pack(void* stream, const float* w_dhwio, int32_t cr, int32_t mode, float* packed) {
+    SOL_REQUIRE(w_dhwio && packed, "sol_conv3d_thin_out_pack: NULL pointer");
+    SOL_REQUIRE(mode == SOL_CONV_FWD || mode == SOL_CONV_BWD_DATA, "sol_conv3d_thin_out_pack: bad mode %d", mode);
+    SOL_REQUIRE(cr >= 1 && cr <= 4, "sol_conv3d_thin_out_pack: 1..4 output channels of the convolution that is run (got %d)", cr);
+    float* w2 = packed + align_up(sol_conv5x5_packed_floats(32, 32, SOL_CONV_FWD), 64);
+    SOL_LAUNCH(k3_kpack_weights_out, dim3(100), dim3(256), 0, (hipStream_t)stream, w_dhwio, w2, cr, mode);
+    SOL_LAUNCH_CHECK();
+    return sol_conv5x5_pack(stream, w2, 32, 32, SOL_CONV_FWD, packed);
+}
+
+extern "C" int sol_conv3d_thin_out(void* stream, const float* x, const float* packed, const float* bias, float* y, float* ws,
+                                   int32_t B, int32_t D, int32_t H, int32_t W, int32_t cout, const uint32_t* x_absmax) {
+    SOL_REQUIRE(x && packed && y && ws && x != y, "sol_conv3d_thin_out: NULL pointer / in-place call");
+    SOL_REQUIRE(B >= 1 && D >= 1 && H >= 1 && W >= 4 && W % 4 == 0 && cout >= 1 && cout <= 4, "sol_conv3d_thin_out: bad shape (B %d, D %d, H %d, W %d, cout %d)", B, D, H, W, cout);
+    const size_t npx = (size_t)B * D * H * W;
+    if (!x_absmax) {
+        uint32_t* slots = reinterpret_cast<uint32_t*>(ws + npx * 32);
+        if (int e = sol_absmax(stream, x, (int64_t)(npx * 32), slots)) return e;
+        x_absmax = slots;
+    }
+    if (int e = sol_conv5x5_scaled(stream, x, packed, nullptr, nullptr, nullptr, ws, B * D, H, W, 32, 32, SOL_EPI_NONE, 0.f, x_absmax, nullptr)) return e;
+    SOL_LAUNCH(k3_gather_depth, dim3(grid_for(npx)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(ws), bias, y, D, H * W, cout, npx);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
 // Weight gradient of a thin-INPUT layer in the same packing: dW'[dy][dx][4 s + c][co] = sum_px x'[px + (dy, dx)][4 s + c] dz[px][co] is the 2-D
 // 32 -> 32 weight gradient of the gathered tensor -- ONE pass of the fp16 three-product body (bww_sb_body) instead of five passes of the
 // thin fp32-MFMA kernel (k_conv5x5_bww_thin<0, 2>: 5 x 79 us at 128 x 64 x 64) -- and dW[s][dy][dx][c][co] = dW'[dy][dx][4 s + c][co].

@@ -225,12 +225,22 @@ class MarsMoon3D:
             # the two thin-INPUT layers (first layer 4 -> 32; the output layer's data gradient cout -> 32) as ONE 2-D launch with the depth
             # taps packed into the channel axis (sol_conv3d_thin): packed for the convolution that is RUN
             self._kpacks = None
+            self._kpacks_out = None
             if self.thin_kpack and self.cin <= 4 and self.cout <= 4:
                 self._kpacks = (_pack3d_thin(t[0].detach(), self.cin, 0), _pack3d_thin(t[22].detach(), self.cout, 1))
+                # ... and into the OUTPUT channel axis (sol_conv3d_thin_out): the output layer's forward, the first layer's data gradient
+                self._kpacks_out = (_pack3d_thin_out(t[22].detach(), self.cout, 0), _pack3d_thin_out(t[0].detach(), self.cin, 1))
             self._tpacks_key = key
         return self._tpacks
 
     thin_kpack = True          # False: the thin-input layers as five passes of the 2-D fp32-MFMA kernel (sol_conv3d), rounds 3-6
+
+    thin_out_kpack = True      # False: the 32 -> (<= 4) layers on the eight-row Conv3D kernel with one channel tile (k_conv3d_sb8<1, 0>), rounds 4-6
+
+    def thin_out_packs(self):
+        """(output layer forward, first layer backward-data) packed for sol_conv3d_thin_out, or None"""
+        self.train_packs()
+        return self._kpacks_out if self.thin_out_kpack else None
 
     def thin_packs(self):
         """(first layer forward, output layer backward-data) packed for sol_conv3d_thin, or None (thin_kpack off / more than four channels)"""
@@ -249,6 +259,7 @@ class MarsMoon3D:
         in-place torch ops on `params` bump `_version` and need nothing."""
         self._packed = None
         self._packed_thin = None
+        self._packed_thin_out = None
         self._tpacks = None
 
     fused_backward = True      # one autograd node with a hand-written reverse sweep (False: one node per layer, torch glue)
@@ -301,6 +312,16 @@ class MarsMoon3D:
             self._packed_thin = _pack3d_thin(self.tensors()[0].detach(), self.cin, 0)
         return self._packed_thin
 
+    def pack_thin_out(self):
+        """the output layer packed for sol_conv3d_thin_out (inference path; cached like pack()), or None"""
+        if not (self.thin_kpack and self.thin_out_kpack and self.cout <= 4):
+            return None
+        key = self._params_key()
+        if getattr(self, "_packed_thin_out", None) is None or getattr(self, "_packed_thin_out_key", None) != key:
+            self._packed_thin_out_key = key
+            self._packed_thin_out = _pack3d_thin_out(self.tensors()[22].detach(), self.cout, 0)
+        return self._packed_thin_out
+
     def pack(self):
         """(packed weights, padded biases) per layer in the layout the conv kernels consume; cached until set_weights."""
         key = self._params_key()
@@ -347,6 +368,27 @@ def conv3d_thin(x4, packed, bias, lrelu, slope, y_absmax=None, act_ref=None, out
     epi = EPI_DLRELU if act_ref is not None else (EPI_LRELU if lrelu else EPI_NONE)
     check(lib.sol_conv3d_thin(stream(), ptr(x4), ptr(packed), ptr(bias), ptr(act_ref), ptr(y), ptr(ws), B, D, H, W, epi, float(slope), ptr(y_absmax)))
     return y
+
+
+def conv3d_thin_out(x, packed, bias, cout, x_absmax=None, out=None, ws=None):
+    """y [B,D,H,W,cout (<= 4)] = conv3d(x [B,D,H,W,32], w) + bias with the depth taps packed into the OUTPUT channel axis: one 2-D 32 -> 32
+    launch + a gather over five planes (sol_conv3d_thin_out; `packed` from _pack3d_thin_out).  No activation."""
+    lib = _lib.load()
+    B, D, H, W, c = x.shape
+    assert c == 32 and 1 <= cout <= 4
+    y = out if out is not None else torch.empty(B, D, H, W, cout, dtype=torch.float32, device=x.device)
+    if ws is None:
+        ws = torch.empty(lib.sol_conv3d_thin_ws_floats(B, D, H, W), dtype=torch.float32, device=x.device)
+    check(lib.sol_conv3d_thin_out(stream(), ptr(x), ptr(packed), ptr(bias), ptr(y), ptr(ws), B, D, H, W, cout, ptr(x_absmax)))
+    return y
+
+
+def _pack3d_thin_out(w, cr, mode):
+    """sol_conv3d_thin_out_pack: w = the FORWARD kernel ([5,5,5,32,cr] for mode 0, [5,5,5,cr,32] for mode 1 = backward-data), cr <= 4"""
+    lib = _lib.load()
+    buf = torch.empty(lib.sol_conv3d_thin_packed_floats(), dtype=torch.float32, device=w.device)
+    check(lib.sol_conv3d_thin_out_pack(stream(), ptr(w.contiguous()), cr, mode, ptr(buf)))
+    return buf
 
 
 def _pack3d_thin(w, cin_run, mode):
@@ -482,6 +524,8 @@ class _Conv3DFn(torch.autograd.Function):
         # the operand's absmax selects the fp16 three-product kernels (and, for 32 -> 32 layers, the one-launch 5x5x5 kernel)
         if MarsMoon3D.thin_kpack and cin <= 4 and cout == 32 and res is None:      # the depth-packed one-launch form, as the fused network runs it
             y = conv3d_thin(xk, _pack3d_thin(_lib.f32(w), cin, 0), _lib.f32(b), lrelu, slope)
+        elif MarsMoon3D.thin_kpack and MarsMoon3D.thin_out_kpack and cin == 32 and cout <= 4 and res is None and not lrelu:      # ... and the thin-output form
+            y = conv3d_thin_out(xk, _pack3d_thin_out(_lib.f32(w), cout, 0), _lib.f32(b), cout, _absmax(xk))
         else:
             y = conv3d(xk, packed, _lib.f32(b), res, cout, lrelu, slope, _absmax(xk) if cin_k == 32 else None)
         ctx.save_for_backward(xk, w, y)
@@ -507,6 +551,8 @@ class _Conv3DFn(torch.autograd.Function):
         dzk = _pad_ch(dz, co_k)
         if MarsMoon3D.thin_kpack and cout <= 4 and cin == 32:
             dx = conv3d_thin(dzk, _pack3d_thin(_lib.f32(w), cout, 1), None, False, slope)
+        elif MarsMoon3D.thin_kpack and MarsMoon3D.thin_out_kpack and cin <= 4 and cout == 32:
+            dx = conv3d_thin_out(dzk, _pack3d_thin_out(_lib.f32(w), cin, 1), None, 4, _absmax(dzk))[..., :cin]
         else:
             dx = conv3d(dzk, packed, None, None, cin, False, slope, _absmax(dzk) if co_k == 32 else None)
         return dx, dW, db, (dz if has_res else None), None, None, None
@@ -534,7 +580,11 @@ class _MarsMoon3DFn(torch.autograd.Function):
             a = conv3d(acts[-1], pk[1 + 2 * k][0], p[3 + 4 * k], None, 32, True, sl, amax[2 * k], amax[2 * k + 1])
             acts.append(a)
             acts.append(conv3d(a, pk[2 + 2 * k][0], p[5 + 4 * k], acts[-2], 32, True, sl, amax[2 * k + 1], amax[2 * k + 2]))
-        out = conv3d(acts[-1], pk[11][0], p[23], None, cout, False, sl, amax[10], None)
+        ko = net.thin_out_packs()
+        if ko:
+            out = conv3d_thin_out(acts[-1], ko[0], p[23], cout, amax[10])
+        else:
+            out = conv3d(acts[-1], pk[11][0], p[23], None, cout, False, sl, amax[10], None)
         return out, xk, amax, acts
 
     @staticmethod
@@ -578,7 +628,11 @@ class _MarsMoon3DFn(torch.autograd.Function):
             grads[0], grads[1] = conv3d_thin_bwd_weight(xk, dz, cin, zmax=zm[0], acc=A(0))
         else:
             grads[0], grads[1] = conv3d_bwd_weight(xk, dz, cin, 32, acc=A(0))
-        dx = conv3d(dz, pk[0][1], None, None, xk.shape[-1], False, sl, zm[0], None)
+        ko = net.thin_out_packs()
+        if ko and xk.shape[-1] == 4:
+            dx = conv3d_thin_out(dz, ko[1], None, 4, zm[0])           # (channels >= cin of the packed kernel are zero)
+        else:
+            dx = conv3d(dz, pk[0][1], None, None, xk.shape[-1], False, sl, zm[0], None)
         return dx, (None if grads[0] is None else torch.cat([t.reshape(-1) for t in grads]))
 
     @staticmethod
@@ -825,7 +879,13 @@ class Karman3DRollout:
             conv3d(h, pk[1 + 2 * k][0], pk[1 + 2 * k][1], None, 32, True, sl, am(2 * k), am(2 * k + 1), out=a)
             conv3d(a, pk[2 + 2 * k][0], pk[2 + 2 * k][1], h, 32, True, sl, am(2 * k + 1), am(2 * k + 2), out=n)
             h, n = n, h
-        conv3d(h, pk[11][0], pk[11][1], None, self.net.cout, False, sl, am(10), None, out=self.out)
+        ko = self.net.pack_thin_out()
+        if ko is not None:
+            if getattr(self, "_thin_ws", None) is None:
+                self._thin_ws = torch.empty(self.lib.sol_conv3d_thin_ws_floats(*self.feat.shape[:4]), dtype=torch.float32, device=self.feat.device)
+            conv3d_thin_out(h, ko, pk[11][1], self.net.cout, am(10), out=self.out, ws=self._thin_ws)
+        else:
+            conv3d(h, pk[11][0], pk[11][1], None, self.net.cout, False, sl, am(10), None, out=self.out)
         return self.out
 
     def step(self, d, vy, vx, vz, re):

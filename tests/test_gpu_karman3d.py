@@ -497,6 +497,36 @@ def test_conv3d_thin_input_depth_packed_launch_against_float64_and_the_five_pass
     assert torch.isfinite(y).all() and e < 2e-6 and rel(y, y5) < 3e-6, (e, e5, rel(y, y5))
 
 
+@pytest.mark.parametrize("shape,cr,mode", [((1, 6, 8, 64), 3, "fwd"), ((2, 5, 16, 16), 4, "bwd"), ((1, 3, 8, 64), 4, "fwd"), ((1, 128, 64, 64), 3, "fwd"),
+                                           ((1, 128, 64, 64), 4, "bwd")])
+def test_conv3d_thin_output_depth_packed_launch_against_float64_and_the_eight_row_kernel(shape, cr, mode):
+    """sol_conv3d_thin_out (the 32 -> (<= 4) layers as ONE 2-D 32 -> 32 launch whose output channels are the depth taps, then a gather over five
+    planes): the output layer (forward packing, bias) and the first layer's data gradient (backward-data packing of the FORWARD kernel
+    [5,5,5,cr,32]) against torch float64 F.conv3d on the same device and against sol_conv3d (k_conv3d_sb8<1, 0> where W == 64); small shapes,
+    fewer planes than taps (D = 3), W = 16 and the BASELINE configs[4] volume."""
+    import torch.nn.functional as F
+    B, D, H, W = shape
+    gen = torch.Generator().manual_seed(61 + D + cr)
+    x = torch.randn(B, D, H, W, 32, generator=gen, dtype=torch.float32).to(DEV)
+    if mode == "fwd":
+        w = (torch.randn(5, 5, 5, 32, cr, generator=gen, dtype=torch.float32) / np.sqrt(125 * 32)).to(DEV)
+        b = torch.randn(cr, generator=gen, dtype=torch.float32).to(DEV)
+        ref = F.conv3d(x.double().permute(0, 4, 1, 2, 3), w.double().permute(4, 3, 0, 1, 2), b.double(), padding=2).permute(0, 2, 3, 4, 1)
+        y = k3.conv3d_thin_out(x, k3._pack3d_thin_out(w, cr, 0), b, cr, sol_amd.ops.absmax_slots(x))
+        y8 = k3.conv3d(x, k3._pack3d(w, 32, cr, 0), b, None, cr, False, 0.3, sol_amd.ops.absmax_slots(x), None)
+    else:
+        w = (torch.randn(5, 5, 5, cr, 32, generator=gen, dtype=torch.float32) / np.sqrt(125 * 32)).to(DEV)      # forward kernel of a cr -> 32 layer
+        xin = torch.zeros(B, cr, D, H, W, dtype=torch.float64, device=DEV, requires_grad=True)
+        (F.conv3d(xin, w.double().permute(4, 3, 0, 1, 2), padding=2) * x.double().permute(0, 4, 1, 2, 3)).sum().backward()
+        ref = xin.grad.permute(0, 2, 3, 4, 1)
+        y = k3.conv3d_thin_out(x, k3._pack3d_thin_out(w, cr, 1), None, cr)                   # (absmax computed by the call)
+        y8 = k3.conv3d(x, k3._pack3d(w, 32, cr, 1), None, None, cr, False, 0.3, sol_amd.ops.absmax_slots(x), None)
+    torch.cuda.synchronize()
+    e, e8 = rel(y, ref), rel(y8, ref)
+    print("depth-packed thin-output launch vs float64 %.2e (sol_conv3d %.2e)" % (e, e8))
+    assert y.shape == (B, D, H, W, cr) and e < 3e-6 and e < 2.0 * e8 + 2e-7, (e, e8)
+
+
 @pytest.mark.parametrize("shape,cin", [((1, 6, 8, 64), 4), ((2, 5, 16, 64), 3), ((1, 128, 64, 64), 4)])
 def test_conv3d_thin_input_depth_packed_weight_gradient_against_float64(shape, cin):
     """sol_conv3d_thin_bwd_weight_acc (the thin-input layer's weight gradient as ONE pass of the 2-D 32 -> 32 fp16 three-product kernel over the
