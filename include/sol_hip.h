@@ -463,6 +463,15 @@ int sol_karman3d_step_bwd(const sol_karman3d_cfg* cfg, void* stream,
  * out [B,Y,X,Z,cout], cout >= 3; the last face of each component's own axis receives no correction. */
 int sol_karman3d_correct(void* stream, const float* out, int32_t cout, float s0, float s1, float s2,
                          float* vy, float* vx, float* vz, int32_t B, int32_t Y, int32_t X, int32_t Z);
+/* The reverse-sweep counterparts (one launch each between the CNN's reverse sweep and sol_karman3d_step_bwd):
+ * sol_karman3d_correct_bwd: g_v* += gin_v* on every face (the adjoint of the NEXT unrolled step w.r.t. its input; all three NULL: nothing to add) and
+ *   d_out4 [B,Y,X,Z,4] = (s0 g_vy, s1 g_vx, s2 g_vz, 0) at the low faces of every cell -- the adjoint of sol_karman3d_correct, zero padded to the four
+ *   channels the thin-layer launches read;
+ * sol_karman3d_feature_bwd: g_v*[low faces] += f_c dx4[..., c] -- the adjoint of the scaled feature output of sol_karman3d_step_fwd (f_c = 1 / std_in). */
+int sol_karman3d_correct_bwd(void* stream, float* g_vy, float* g_vx, float* g_vz, const float* gin_vy, const float* gin_vx, const float* gin_vz,
+                             float s0, float s1, float s2, float* d_out4, int32_t B, int32_t Y, int32_t X, int32_t Z);
+int sol_karman3d_feature_bwd(void* stream, const float* dx4, float f0, float f1, float f2, float* g_vy, float* g_vx, float* g_vz,
+                             int32_t B, int32_t Y, int32_t X, int32_t Z);
 
 /* 5 x 5 x 5 SAME convolution, NDHWC fp32 (keras.layers.Conv3D(filters, 5, padding='same') + bias / LeakyReLU / add).
  * w_dhwio [5,5,5,cin,cout] (Keras layout, D = y).  Layers with cin = 32 and cout = 32 or <= 16 on W == 64 with x_absmax given run as

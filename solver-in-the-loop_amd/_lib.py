@@ -108,6 +108,8 @@ _SIGS = {
     "sol_karman3d_step_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Karman3DCfg)]),
     "sol_karman3d_step_bwd": (C.c_int, [C.POINTER(Karman3DCfg), _P] + [_P] * 6 + [C.c_int64] + [_P] * 6 + [_P, _P, C.c_size_t]),
     "sol_karman3d_correct": (C.c_int, [_P, _P, C.c_int32] + [C.c_float] * 3 + [_P] * 3 + [C.c_int32] * 4),
+    "sol_karman3d_correct_bwd": (C.c_int, [_P] * 7 + [C.c_float] * 3 + [_P] + [C.c_int32] * 4),
+    "sol_karman3d_feature_bwd": (C.c_int, [_P, _P] + [C.c_float] * 3 + [_P] * 3 + [C.c_int32] * 4),
     "sol_conv3d_packed_floats": (C.c_size_t, [C.c_int32] * 2),
     "sol_conv3d_pack": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "sol_conv3d": (C.c_int, [_P] * 7 + [C.c_int32] * 7 + [C.c_float] + [_P] * 2),

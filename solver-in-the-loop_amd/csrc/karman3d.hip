@@ -607,6 +607,44 @@ __global__ void __launch_bounds__(256) k3_correct(const float* __restrict__ out,
     }
 }
 
+// The two pieces of glue of an unrolled step's REVERSE sweep (they were seven + three torch elementwise launches per step):
+//   k3_correct_bwd  G_c += gin_c on every face (gin: the adjoint of step i + 1 w.r.t. its input; NULL for the last step), and the adjoint of
+//                   k3_correct, dO [B][Y][X][Z][4] = (s0 Gy, s1 Gx, s2 Gz, 0) at the low faces of every cell
+//   k3_feature_bwd  the adjoint of the solver's scaled feature output: G_c[low faces] += f_c dx[..][c], dx [B][Y][X][Z][4]
+__global__ void __launch_bounds__(256) k3_correct_bwd(float* __restrict__ gy, float* __restrict__ gx, float* __restrict__ gz, const float* __restrict__ iy,
+                                                       const float* __restrict__ ix, const float* __restrict__ iz, float s0, float s1, float s2,
+                                                       float4* __restrict__ dO, int B, int Y, int X, int Z) {
+    const size_t N = (size_t)Y * X * Z, nb = (size_t)X * Z + (size_t)Y * Z + (size_t)Y * X, per = N + (iy ? nb : 0), total = (size_t)B * per;
+    const size_t nVy = (size_t)(Y + 1) * X * Z, nVx = (size_t)Y * (X + 1) * Z, nVz = (size_t)Y * X * (Z + 1);
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = e / per, c = e - b * per;
+        if (c < N) {
+            const int k = (int)(c % Z), i = (int)((c / Z) % X), j = (int)(c / ((size_t)Z * X));
+            const size_t ey = b * nVy + ((size_t)j * X + i) * Z + k, ex = b * nVx + ((size_t)j * (X + 1) + i) * Z + k, ez = b * nVz + ((size_t)j * X + i) * (Z + 1) + k;
+            float a0 = gy[ey], a1 = gx[ex], a2 = gz[ez];
+            if (iy) { a0 += iy[ey]; a1 += ix[ex]; a2 += iz[ez]; gy[ey] = a0; gx[ex] = a1; gz[ez] = a2; }
+            dO[b * N + c] = make_float4(a0 * s0, a1 * s1, a2 * s2, 0.f);
+        } else {                                          // the high boundary faces of the three components (no cell has them as a low face)
+            size_t q = c - N;
+            if (q < (size_t)X * Z) { const size_t f = b * nVy + (size_t)Y * X * Z + q; gy[f] += iy[f]; }
+            else if ((q -= (size_t)X * Z) < (size_t)Y * Z) { const size_t f = b * nVx + ((q / Z) * (X + 1) + X) * Z + q % Z; gx[f] += ix[f]; }
+            else { q -= (size_t)Y * Z; const size_t f = b * nVz + q * (Z + 1) + Z; gz[f] += iz[f]; }
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k3_feature_bwd(const float4* __restrict__ dx, float f0, float f1, float f2, float* __restrict__ gy, float* __restrict__ gx,
+                                                       float* __restrict__ gz, int B, int Y, int X, int Z) {
+    const size_t N = (size_t)Y * X * Z, total = (size_t)B * N;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = e / N, c = e - b * N;
+        const int k = (int)(c % Z), i = (int)((c / Z) % X), j = (int)(c / ((size_t)Z * X));
+        const float4 d = dx[e];
+        gy[b * (size_t)(Y + 1) * X * Z + ((size_t)j * X + i) * Z + k] += f0 * d.x;
+        gx[b * (size_t)Y * (X + 1) * Z + ((size_t)j * (X + 1) + i) * Z + k] += f1 * d.y;
+        gz[b * (size_t)Y * X * (Z + 1) + ((size_t)j * X + i) * (Z + 1) + k] += f2 * d.z;
+    }
+}
+
 // y = src (or 0): small fill / copy without memset / memcpy graph nodes (ROCm 7.2 graph memset defect)
 __global__ void __launch_bounds__(256) k3_fill(float* __restrict__ y, const float* __restrict__ src, size_t n) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) y[e] = src ? src[e] : 0.f;
@@ -1182,6 +1220,26 @@ extern "C" int sol_karman3d_correct(void* stream, const float* out, int32_t cout
                                     float* vy, float* vx, float* vz, int32_t B, int32_t Y, int32_t X, int32_t Z) {
     SOL_REQUIRE(out && vy && vx && vz && cout >= 3 && B >= 1 && Y >= 1 && X >= 1 && Z >= 1, "sol_karman3d_correct: bad arguments");
     SOL_LAUNCH(k3_correct, dim3(grid_for((size_t)B * Y * X * Z)), dim3(256), 0, (hipStream_t)stream, out, cout, s0, s1, s2, vy, vx, vz, B, Y, X, Z);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
+extern "C" int sol_karman3d_correct_bwd(void* stream, float* g_vy, float* g_vx, float* g_vz, const float* gin_vy, const float* gin_vx, const float* gin_vz,
+                                        float s0, float s1, float s2, float* d_out4, int32_t B, int32_t Y, int32_t X, int32_t Z) {
+    SOL_REQUIRE(g_vy && g_vx && g_vz && d_out4 && B >= 1 && Y >= 1 && X >= 1 && Z >= 1, "sol_karman3d_correct_bwd: bad arguments");
+    SOL_REQUIRE((gin_vy != nullptr) == (gin_vx != nullptr) && (gin_vy != nullptr) == (gin_vz != nullptr), "sol_karman3d_correct_bwd: the three gin pointers are all NULL or all set");
+    SOL_REQUIRE(reinterpret_cast<uintptr_t>(d_out4) % 16 == 0, "sol_karman3d_correct_bwd: d_out4 must be 16-byte aligned");
+    SOL_LAUNCH(k3_correct_bwd, dim3(grid_for((size_t)B * ((size_t)Y * X * Z + (gin_vy ? (size_t)X * Z + (size_t)Y * Z + (size_t)Y * X : 0)))), dim3(256), 0, (hipStream_t)stream,
+               g_vy, g_vx, g_vz, gin_vy, gin_vx, gin_vz, s0, s1, s2, reinterpret_cast<float4*>(d_out4), B, Y, X, Z);
+    SOL_LAUNCH_CHECK();
+    return SOL_OK;
+}
+
+extern "C" int sol_karman3d_feature_bwd(void* stream, const float* dx4, float f0, float f1, float f2, float* g_vy, float* g_vx, float* g_vz,
+                                        int32_t B, int32_t Y, int32_t X, int32_t Z) {
+    SOL_REQUIRE(dx4 && g_vy && g_vx && g_vz && B >= 1 && Y >= 1 && X >= 1 && Z >= 1, "sol_karman3d_feature_bwd: bad arguments");
+    SOL_REQUIRE(reinterpret_cast<uintptr_t>(dx4) % 16 == 0, "sol_karman3d_feature_bwd: dx4 must be 16-byte aligned");
+    SOL_LAUNCH(k3_feature_bwd, dim3(grid_for((size_t)B * Y * X * Z)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(dx4), f0, f1, f2, g_vy, g_vx, g_vz, B, Y, X, Z);
     SOL_LAUNCH_CHECK();
     return SOL_OK;
 }

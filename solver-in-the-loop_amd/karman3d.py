@@ -605,18 +605,22 @@ class _MarsMoon3DFn(torch.autograd.Function):
         sl, cin, cout = net.slope, net.cin, net.cout
         grads = [None] * 24
         zm = torch.zeros(11, 256, dtype=torch.int32, device=xk.device)         # absmax slots of the eleven pre-activation gradients
-        g = _lib.f32(g_out).contiguous()
+        g = _lib.f32(g_out).contiguous()                      # [.., cout], or already zero padded to 4 channels (the trainer's fused glue)
         kp = net.thin_packs()
-        g4 = _pad_ch(g, 4) if kp else None
+        if g.shape[-1] == 4 and cout != 4:
+            g4, gc = g, None
+        else:
+            g4, gc = (_pad_ch(g, 4) if kp else None), g
         if kp and g.shape[3] == 64:
             grads[22], grads[23] = conv3d_thin_bwd_weight(g4, acts[10], cout, zmax=amax[10], acc=A(11), thin_out=True)
         else:
-            grads[22], grads[23] = conv3d_bwd_weight(acts[10], g, 32, cout, xmax=amax[10], acc=A(11))
+            gc = gc if gc is not None else g4[..., :cout].contiguous()
+            grads[22], grads[23] = conv3d_bwd_weight(acts[10], gc, 32, cout, xmax=amax[10], acc=A(11))
         # d loss / d (pre-activation of the last residual block's output) = conv3d(g, flip(w11)^T) * lrelu'(h5)
         if kp:
             dz = conv3d_thin(g4, kp[1], None, False, sl, zm[10], act_ref=acts[10])
         else:
-            dz = conv3d(_pad_ch(g, 4), pk[11][1], None, None, 32, False, sl, None, zm[10], act_ref=acts[10])
+            dz = conv3d(g4 if g4 is not None else _pad_ch(gc, 4), pk[11][1], None, None, 32, False, sl, None, zm[10], act_ref=acts[10])
         for k in range(4, -1, -1):
             a, hprev = acts[1 + 2 * k], acts[2 * k]
             # block k: h_k = lrelu(conv_b(a) + h_{k-1}), a = lrelu(conv_a(h_{k-1}))
@@ -660,7 +664,7 @@ class Karman3DTrainer:
     (sol_adam_tf_step).  gts: [msteps] of (vy, vx, vz) ground-truth frames."""
 
     def __init__(self, net, scene, B, msteps, std_v, std_re, dt=1.0, res=None, beta1=0.9, beta2=0.999, eps=1e-8, conv_precision="split",
-                 use_graph=False, group=None, comm=None, schedule="manual", **solver):
+                 use_graph=False, group=None, comm=None, schedule="manual", glue="fused", **solver):
         """schedule: "manual" (default) = the hand-written forward unroll + reverse sweep over the C ABI (_unrolled_schedule), "autograd" = the
         torch-autograd composition of the differentiable HIP ops (rounds 3-4; kept as the cross-check).
         use_graph: capture the whole forward unroll + reverse sweep ONCE into a hipGraph over static input buffers (the
@@ -671,6 +675,8 @@ class Karman3DTrainer:
         _lib.require_gpu()
         self.lib = _lib.load()
         self.net, self.scene, self.B, self.ms = net, scene, B, msteps
+        assert glue in ("fused", "torch")
+        self.glue = glue          # reverse-sweep glue of the manual schedule: sol_karman3d_correct_bwd / _feature_bwd, or the torch elementwise composition
         self.sim = Karman3DFlow(scene, B, dt=dt, res=res, **solver)
         dev = scene.active.device
         self.std_v = torch.tensor([float(v) for v in std_v], dtype=torch.float32, device=dev)
@@ -744,17 +750,27 @@ class Karman3DTrainer:
         inv_in = fs[:3]
         for i in range(ms - 1, -1, -1):
             saved, xk, amax, acts, G = keep[i]
-            if gin is not None:
-                for c in range(3):
-                    G[c].add_(gin[c])
-            # adjoint of  v += std * to_staggered(out):  d out[..., c] = std_c * G_c restricted to the faces that received a correction
-            dO = torch.stack([G[0][:, :Y] * sv[0], G[1][:, :, :X] * sv[1], G[2][..., :Z] * sv[2]], dim=-1)
+            # G += gin and the adjoint of  v += std * to_staggered(out):  d out[..., c] = std_c * G_c restricted to the faces that received a correction
+            # (one launch, zero padded to the four channels the thin-layer launches read; glue="torch": the elementwise composition of rounds 5-6)
+            fused_glue = self.glue == "fused" and net.cout == 3
+            if fused_glue:
+                dO = torch.empty(B, Y, X, Z, 4, dtype=torch.float32, device=G[0].device)
+                gi = gin if gin is not None else (None, None, None)
+                check(self.lib.sol_karman3d_correct_bwd(stream(), ptr(G[0]), ptr(G[1]), ptr(G[2]), ptr(gi[0]), ptr(gi[1]), ptr(gi[2]), sv[0], sv[1], sv[2], ptr(dO), B, Y, X, Z))
+            else:
+                if gin is not None:
+                    for c in range(3):
+                        G[c].add_(gin[c])
+                dO = torch.stack([G[0][:, :Y] * sv[0], G[1][:, :, :X] * sv[1], G[2][..., :Z] * sv[2]], dim=-1)
             dx, gflat = _MarsMoon3DFn.run_backward(net, xk, amax, acts, dO, acc=(wstate, i == ms - 1, i == 0))
             flat = gflat if gflat is not None else flat
             # adjoint of the feature map (the three components at the low faces of every cell, divided by std_in; the Re channel has no gradient)
-            G[0][:, :Y].add_(dx[..., 0], alpha=inv_in[0])
-            G[1][:, :, :X].add_(dx[..., 1], alpha=inv_in[1])
-            G[2][..., :Z].add_(dx[..., 2], alpha=inv_in[2])
+            if fused_glue and dx.shape[-1] == 4:
+                check(self.lib.sol_karman3d_feature_bwd(stream(), ptr(dx), inv_in[0], inv_in[1], inv_in[2], ptr(G[0]), ptr(G[1]), ptr(G[2]), B, Y, X, Z))
+            else:
+                G[0][:, :Y].add_(dx[..., 0], alpha=inv_in[0])
+                G[1][:, :, :X].add_(dx[..., 1], alpha=inv_in[1])
+                G[2][..., :Z].add_(dx[..., 2], alpha=inv_in[2])
             gin = sim._bwd(saved, re, G[0], G[1], G[2])
             keep[i] = None                          # (eager runs: the step's activations can go)
         losses = _lib.stack0(losses)

@@ -945,3 +945,34 @@ def test_karman3d_manual_schedule_equals_autograd_composition(shape, use_graph):
     assert float(lm[2].abs().max()) > 0
     with pytest.raises(ValueError):
         k3.Karman3DTrainer(k3.MarsMoon3D(device=DEV), sc, B, ms, (0.2, 0.25, 0.3), o.STD_RE, schedule="tf1")
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 16, 16), (1, 128, 64, 64)])
+def test_karman3d_fused_reverse_sweep_glue_equals_the_torch_composition(shape):
+    """glue="fused" (sol_karman3d_correct_bwd: G += gin and the 4-channel output gradient in one launch; sol_karman3d_feature_bwd: the feature map's
+    adjoint in one launch) against glue="torch" (the seven + three elementwise torch kernels per unrolled step they replace): same per-step losses
+    bit for bit (the forward is untouched), the parameter gradient to round-off (one add differs: a + f b is a fused multiply-add in the kernel).
+    16 x 16 planes run the five-pass weight gradients (the 4-channel gradient is sliced back to cout there), 64 x 64 the depth-packed launches."""
+    B, Y, X, Z = shape
+    ms = 3
+    sc = k3.Scene3D(Y, X, Z, device=DEV)
+    gen = torch.Generator().manual_seed(19)
+    r = lambda *s: torch.randn(*s, generator=gen)
+    st = (torch.rand(B, Y, X, Z, generator=gen), 1.0 + 0.2 * r(B, Y + 1, X, Z), 0.2 * r(B, Y, X + 1, Z), 0.2 * r(B, Y, X, Z + 1))
+    re = torch.tensor(o.RE_TRAIN[:B])
+    gts = [(1.0 + 0.2 * r(B, Y + 1, X, Z), 0.2 * r(B, Y, X + 1, Z), 0.2 * r(B, Y, X, Z + 1)) for _ in range(ms)]
+    res = {}
+    for glue in ("fused", "torch"):
+        net = k3.MarsMoon3D(device=DEV)
+        w = net.get_weights()
+        w[22] = w[22] * 0.05
+        net.set_weights(w)
+        tr = k3.Karman3DTrainer(net, sc, B, ms, (0.2, 0.25, 0.3), o.STD_RE, glue=glue)
+        tr._grads.zero_()
+        loss = tr.fwd_bwd(*st, re, gts)
+        torch.cuda.synchronize()
+        res[glue] = (float(loss), tr.loss_steps.clone(), tr.grads.clone())
+        del tr, net
+    f, t = res["fused"], res["torch"]
+    assert np.isfinite(f[0]) and torch.equal(f[1], t[1])
+    assert float(f[2].abs().max()) > 0 and rel(f[2], t[2]) < 2e-6, rel(f[2], t[2])
